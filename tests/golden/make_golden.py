@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the real reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box); the .npz files it writes next to this script are committed and are what the tests
+read.  No reference source is copied: the reference is imported, called and its outputs
+are saved.  Usage:  python tests/golden/make_golden.py [names...]
+
+Fixture families:
+  relfeat_*    Pedestrians.get_relative_features (+ get_nearby_obj_in_sight indices)
+  collision_*  Pedestrians.collision_detection / calculate_collision_label
+  mlapm_*      MLAPM.step (raw / GC as shipped; UCY with the one-line coll.unsqueeze(-1)
+               fix applied at import time) + autograd gradients
+  calcacc      utils.calc_acceleration
+  model_*      PINNSF family forward outputs + state_dicts (seed 666)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, os.path.join(REF, 'src'))
+sys.path.insert(0, REPO)
+sys.modules.setdefault('setproctitle', types.SimpleNamespace(setproctitle=lambda *_: None))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import data.data as DATA  # noqa: E402  (reference)
+from piml_amd.scenes import synthetic_gc_scene  # noqa: E402
+
+torch.set_num_threads(8)
+GC_CLIP = os.path.join(REF, 'data/GC_Dataset/GC_Dataset_ped1-12685_time1000-1060_interp9_xrange5-25_yrange15-35.npy')
+UCY_CLIP = os.path.join(REF, 'data/UCY_dataset/UCY_Dataset_time0-54_timeunit0.08.npy')
+TOY = os.path.join(REF, 'data/GC_Dataset/GC_Dataset_toy1.npy')
+
+
+def T(x):
+    return torch.tensor(np.asarray(x))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f'wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def load_raw(path):
+    raw = DATA.RawData()
+    raw.load_trajectory_data(path)
+    return raw
+
+
+def run_relfeat(p, v, a, dest, obs, kp=6, ang_p=90, dp=4, ko=10, ang_o=90, do=4):
+    """Call the reference; also capture the neighbour indices/distances it used."""
+    ped = DATA.Pedestrians()
+    p, v, a, dest, obs = [T(x).clone() for x in (p, v, a, dest, obs)]
+    v_in, a_in = v.clone(), a.clone()
+    pf, of, df = ped.get_relative_features(p, v, a, dest, obs, kp, ang_p, dp, ko, ang_o, do)
+    hd = ped.get_heading_direction(v)
+    pd_, pi_ = ped.get_nearby_obj_in_sight(p, p, hd, kp, ang_p)
+    dim = obs.dim()
+    obs_t = obs.unsqueeze(-3).repeat(*([1] * (dim - 2) + [p.shape[-3]] + [1, 1]))
+    if p.dim() > obs_t.dim():
+        obs_t = obs_t.expand(*p.shape[:-2], *obs_t.shape[-2:])
+    od_, oi_ = ped.get_nearby_obj_in_sight(p, obs_t, hd, ko, ang_o)
+    return dict(position=p, velocity=v_in, acceleration=a_in, destination=dest, obstacles=obs,
+                params=np.array([kp, ang_p, dp, ko, ang_o, do], np.float64),
+                ped_features=pf, obs_features=of, dest_features=df, heading=hd,
+                velocity_after=v, acceleration_after=a,
+                ped_idx=pi_.to(torch.int32), ped_dist=pd_, obs_idx=oi_.to(torch.int32), obs_dist=od_)
+
+
+def gen_relfeat():
+    # (i) real clips: single frames (t=1, the per-step call) and a short multi-frame window
+    for tag, path in (('gc', GC_CLIP), ('ucy', UCY_CLIP)):
+        raw = load_raw(path)
+        frames = [25, 100, 400, min(749, raw.num_steps - 1)]
+        for f in frames:
+            sl = slice(f, f + 1)
+            save(f'relfeat_{tag}_f{f}', **run_relfeat(raw.position[sl], raw.velocity[sl], raw.acceleration[sl],
+                                                     raw.destination[sl], raw.obstacles))
+        sl = slice(96, 104)
+        save(f'relfeat_{tag}_window', **run_relfeat(raw.position[sl], raw.velocity[sl], raw.acceleration[sl],
+                                                   raw.destination[sl], raw.obstacles))
+    raw = load_raw(TOY)
+    save('relfeat_toy1', **run_relfeat(raw.position, raw.velocity, raw.acceleration, raw.destination, raw.obstacles))
+
+    # (iii) seeded synthetic scenes
+    for N, M, seed, ang in ((64, 0, 0, 90), (64, 100, 1, 100), (256, 100, 2, 90), (256, 2000, 0, 90),
+                            (1024, 100, 1, 90), (1024, 2000, 2, 90)):
+        sc = synthetic_gc_scene(N, M, seed=seed)
+        rng = np.random.default_rng(1000 + seed)
+        v = sc['velocity'].copy()
+        v[rng.random(N) < 0.05] = 0.0            # standing agents: heading 0 -> blind
+        a = (rng.standard_normal((N, 2)) * 0.3).astype(np.float32)
+        a[rng.random(N) < 0.02] = np.nan          # exercised by the NaN->0 in-place rule
+        save(f'relfeat_syn_N{N}_M{M}_a{ang}',
+             **run_relfeat(sc['position'][None], v[None], a[None], sc['destination'][None], sc['obstacles'],
+                           ang_p=ang, ang_o=ang))
+    # channelled (C,1,N,2) input as HOT LOOP C uses it (simulators.py:772-776)
+    sc = synthetic_gc_scene(96, 100, seed=5, channels=4)
+    save('relfeat_syn_channels',
+         **run_relfeat(sc['position'][:, None], sc['velocity'][:, None], sc['acceleration'][:, None],
+                       sc['destination'][:, None], sc['obstacles']))
+    # non-default k / thresholds, k > #objects
+    sc = synthetic_gc_scene(40, 0, seed=7)
+    save('relfeat_syn_smallk', **run_relfeat(sc['position'][None], sc['velocity'][None], sc['acceleration'][None],
+                                             sc['destination'][None], sc['obstacles'], kp=3, dp=2, ko=10, do=3))
+    sc = synthetic_gc_scene(5, 100, seed=8, nan_frac=0.0)
+    save('relfeat_syn_kgtN', **run_relfeat(sc['position'][None], sc['velocity'][None], sc['acceleration'][None],
+                                           sc['destination'][None], sc['obstacles'], kp=6, ko=10))
+
+
+def gen_collision():
+    raw = load_raw(GC_CLIP)
+    ped = DATA.Pedestrians
+    p3 = raw.position[380:440].clone()               # (t,N,2) with NaNs, > 25 frames for the friends rule
+    out = {}
+    for thr in (0.5, 0.25, 1.5):
+        out[f'coll3_thr{thr}'] = ped.collision_detection(p3.clone(), thr).to(torch.uint8)
+    out['coll3_real_thr0.5'] = ped.collision_detection(p3.clone() + 0.05, 0.5, real_position=p3.clone()).to(torch.uint8)
+    out['coll3_real_thr1.5'] = ped.collision_detection(p3.clone() + 0.05, 1.5, real_position=p3.clone()).to(torch.uint8)
+    p4 = torch.stack([raw.position[s:s + 6] for s in (100, 250, 400, 560)])   # (C,T,N,2)
+    for thr in (0.5, 1.5):
+        out[f'coll4_thr{thr}'] = ped.collision_detection(p4.clone(), thr).to(torch.uint8)
+    pc = raw.position[[100, 250, 400, 560]].clone()  # (C,N,2) as in HOT LOOP C (simulators.py:708)
+    for thr in (0.5, 0.25, 1.5):
+        out[f'collc_thr{thr}'] = ped.collision_detection(pc.clone(), thr).to(torch.uint8)
+    save('collision_gc', p3=p3, p4=p4, pc=pc, **out)
+
+    sc = synthetic_gc_scene(512, 100, seed=3, channels=3)
+    ps = T(sc['position'])
+    save('collision_syn', pc=ps, **{f'collc_thr{thr}': ped.collision_detection(ps.clone(), thr).to(torch.uint8)
+                                    for thr in (0.5, 0.25)})
+
+    # collision label on real gathered features
+    g = np.load(os.path.join(HERE, 'relfeat_gc_f400.npz'))
+    pf = T(g['ped_features'])
+    rng = np.random.default_rng(11)
+    rnd = T((rng.standard_normal((64, 6, 6)) * np.array([0.6, 0.6, 1.2, 1.2, 1, 1])).astype(np.float32))
+    rnd[0, 0] = 0.0
+    save('collision_label', feat_real=pf, label_real=ped.calculate_collision_label(pf.clone()),
+         feat_rnd=rnd, label_rnd=ped.calculate_collision_label(rnd.clone()))
+
+
+def _mlapm_class(fixed_ucy):
+    """The reference class; for UCY the documented one-line fix is applied to the module
+    text at import time (nothing is written to disk)."""
+    path = os.path.join(REF, 'src/models/mlapm.py')
+    src = open(path).read()
+    if fixed_ucy:
+        old = "self.args['B'] * r * coll + self.args['C'] * coll"
+        assert old in src
+        src = src.replace(old, "self.args['B'] * r * coll.unsqueeze(-1) + self.args['C'] * coll.unsqueeze(-1)")
+    mod = types.ModuleType('ref_mlapm')
+    exec(compile(src, path, 'exec'), mod.__dict__)
+    return mod.MLAPM
+
+
+def gen_mlapm():
+    params = {
+        'raw': dict(version='raw', tau=0.5, A=7.55, B=-3.00),
+        'GC': dict(version='GC', tau=0.5, A=7.55, B=-3.00, C=0.2, D=-0.3, theta=56),   # main_mlapm.py:16
+        'UCY': dict(version='UCY', tau=5 / 6, A=10.67, B=-3.33, C=0.5, theta=20),
+    }
+    out = {}
+    for ver, pr in params.items():
+        M = _mlapm_class(ver == 'UCY')(**pr)
+        for N in (7, 64, 1024):
+            if N == 7:   # the main_mlapm.py:8-14 antipodal circle
+                th = torch.linspace(0, 2 * torch.pi * (1 - 1. / N), N)
+                p = torch.stack([10 * th.cos(), 10 * th.sin()], dim=-1)
+                g = torch.Generator().manual_seed(0)
+                v = torch.rand(N, 2, generator=g)
+                v0 = torch.full([N, 1], 1.5)
+                d = -p
+            else:
+                sc = synthetic_gc_scene(N, 0, seed=N, nan_frac=0.0)
+                p, v, d, v0 = (T(sc[k]) for k in ('position', 'velocity', 'destination', 'desired_speed'))
+                if N == 64:
+                    p = p * 0.35 + 5.0      # dense: collisions / tmin branches fire
+                rng = np.random.default_rng(N)
+                v = v + T((rng.standard_normal((N, 2)) * 0.4).astype(np.float32))
+            pg, vg, v0g, dg = [x.clone().requires_grad_(True) for x in (p, v, v0, d)]
+            act = M.step(pg, vg, v0g, dg, dt=0.08, radius=0.3)
+            gen = torch.Generator().manual_seed(N)
+            w = torch.randn(act.shape, generator=gen)
+            gp, gv, gv0, gd = torch.autograd.grad((act * w).sum(), (pg, vg, v0g, dg))
+            key = f'{ver}_N{N}'
+            out.update({f'{key}_p': p, f'{key}_v': v, f'{key}_v0': v0, f'{key}_dest': d,
+                        f'{key}_action': act, f'{key}_w': w, f'{key}_gp': gp, f'{key}_gv': gv,
+                        f'{key}_gv0': gv0, f'{key}_gdest': gd})
+        out[f'{ver}_params'] = np.array([pr.get(k, 0.0) for k in ('tau', 'A', 'B', 'C', 'D', 'theta')], np.float64)
+    # the 200-step demo trajectory of main_mlapm.py:18-36 (fixed velocity seed)
+    M = _mlapm_class(False)(**params['GC'])
+    N = 7
+    th = torch.linspace(0, 2 * torch.pi * (1 - 1. / N), N)
+    p = torch.stack([10 * th.cos(), 10 * th.sin()], dim=-1)
+    v = torch.rand(N, 2, generator=torch.Generator().manual_seed(0))
+    v0 = torch.full([N, 1], 1.5)
+    d = -p.clone()
+    traj = [p.clone()]
+    for _ in range(200):
+        v = M.step(p, v, v0, d, dt=0.08, radius=0.3)
+        p = p + v * 0.08
+        traj.append(p.clone())
+    out['demo_traj'] = torch.stack(traj)
+    save('mlapm', **out)
+
+
+def gen_calcacc():
+    import utils.utils as UTILS
+    g = np.load(os.path.join(HERE, 'relfeat_gc_f400.npz'))
+    pf = T(g['ped_features'])                                  # (1,N,k,6)
+    rng = np.random.default_rng(5)
+    rnd = T((rng.standard_normal((3, 50, 6, 6))).astype(np.float32))
+    out = {'feat_real': pf, 'feat_rnd': rnd}
+    for ver, ds in (('v0', 'gc1560'), ('v0', 'ucy'), ('v1', 'ucy'), ('v2', 'gc2344')):
+        out[f'real_{ver}_{ds}'] = UTILS.calc_acceleration(pf[0].clone(), ver, ds)
+        out[f'rnd_{ver}_{ds}'] = UTILS.calc_acceleration(rnd.clone(), ver, ds)
+    save('calcacc', **out)
+
+
+def model_args(**kw):
+    a = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3,
+        processor_hidden_layers=16, decoder_hidden_layers=2, dropout=0.5, activation='relu',
+        dataset_name='ucy', res_hidden_layers=3, correction_hidden_layers=1, time_unit=0.08,
+        collision_threshold=0.5)
+    a.__dict__.update(kw)
+    return a
+
+
+def gen_model():
+    import models.model as MODEL
+    g = np.load(os.path.join(HERE, 'relfeat_gc_f400.npz'))
+    pf, of, df = T(g['ped_features'])[0], T(g['obs_features'])[0], T(g['dest_features'])[0]   # (N,k,6)
+    N = pf.shape[0]
+    rng = np.random.default_rng(9)
+    selff = torch.cat((df, T(g['velocity'])[0], T(np.nan_to_num(g['acceleration']))[0],
+                       T((1.0 + rng.random((N, 1))).astype(np.float32))), dim=-1)            # (N,7)
+    gc = np.load(os.path.join(HERE, 'relfeat_syn_channels.npz'))
+    pfc, ofc, dfc = T(gc['ped_features'])[:, 0], T(gc['obs_features'])[:, 0], T(gc['dest_features'])[:, 0]
+    selfc = torch.cat((dfc, T(gc['velocity'])[:, 0], T(gc['acceleration'])[:, 0],
+                       T((1.0 + rng.random(dfc.shape[:-1] + (1,))).astype(np.float32))), dim=-1)
+    out = dict(ped=pf, obs=of, selff=selff, pedc=pfc, obsc=ofc, selfc=selfc)
+    for name, cls, kw in (('pinnsf_m', MODEL.PINNSF_multitask, {}),
+                          ('pinnsf_m_gc', MODEL.PINNSF_multitask, dict(dataset_name='gc1560')),
+                          ('pinnsf_bm', MODEL.PINNSF_bottleneck_multitask, {}),
+                          ('pinnsf', MODEL.PINNSF, {}),
+                          ('pinnsf_bottleneck', MODEL.PINNSF_bottleneck, {}),
+                          ('pinnsf_res', MODEL.PINNSF_residual, {}),
+                          ('pinnsf_m_p1', MODEL.PINNSF_multitask, dict(processor_hidden_layers=1))):
+        torch.manual_seed(666)
+        m = cls(model_args(**kw)).eval()
+        for k, v in m.state_dict().items():
+            out[f'{name}/sd/{k}'] = v
+        with torch.no_grad():
+            for tag, args in (('n', (pf, of, selff)), ('c', (pfc, ofc, selfc))):
+                res = m(*[x.clone() for x in args])
+                for q, r in enumerate(res):
+                    out[f'{name}/out_{tag}{q}'] = r
+    save('model', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model)
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(GENS)
+    for n in names:
+        GENS[n]()
