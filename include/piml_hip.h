@@ -1,0 +1,111 @@
+/*
+ * piml_hip.h -- C ABI of libpiml_hip.so, the MI355X (gfx950) implementation of PIML's
+ * per-timestep pairwise hot path.
+ *
+ * The reference (tsinghua-fib-lab/PIML) is pure Python/PyTorch and has no FFI layer; the
+ * entry points below are what a binding for this path binds (ctypes stub: INTEGRATION.md).
+ * Each entry cites the reference interface it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch allocates); float32,
+ *    C-contiguous; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - nothing is allocated, freed or synchronised inside: every call only enqueues work on
+ *    `stream`, so calls are re-entrant and capturable into a hipGraph;
+ *  - return value is a hipError_t as int (0 = hipSuccess, 1 = hipErrorInvalidValue for a
+ *    rejected argument); no exceptions cross the boundary;
+ *  - absent agents are NaN positions (the reference's sentinel, src/data/data.py:141-143),
+ *    never compacted;
+ *  - leading dimensions (channels, time) are flattened by the caller into C "slices".
+ */
+#ifndef PIML_HIP_H
+#define PIML_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIML_HIP_ABI_VERSION 1
+#define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
+
+/* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
+int piml_abi_version(void);
+
+/* hipGetErrorString for the codes returned below. */
+const char* piml_error_string(int err);
+
+/*
+ * Heading direction.  Replaces Pedestrians.get_heading_direction
+ * (src/data/data.py:350-395): zero-velocity frames are filled from the temporally nearest
+ * non-zero frame (backward sweep then forward sweep), then h/|h| (|h| == 0 -> h/0.1).
+ * velocity, heading: (C, T, N, 2).
+ */
+int piml_heading_fwd(const float* velocity, int C, int T, int N, float* heading, void* stream);
+
+/*
+ * Relative features, forward.  Replaces Pedestrians.get_relative_features
+ * (src/data/data.py:466-512) = get_nearby_obj_in_sight (:416-447) + get_relative_quantity
+ * (:397-414) + get_filtered_features (:449-464), for C slices of N agents and M shared
+ * obstacle points, without materialising any N x N tensor.
+ *
+ *   position, velocity, acceleration, destination : (C, N, 2)
+ *   heading : (C, N, 2) unit heading from piml_heading_fwd, or NULL = derive it from
+ *             `velocity` (the T == 1 per-step case, where heading = v/|v|)
+ *   obstacles : (M, 2), may be NULL when M == 0
+ *   focal_begin, focal_count : the block of focal agents this call computes (multi-GPU
+ *             agent-block sharding; single GPU: 0, N).  Sources are always all N agents.
+ *   topk_ped/topk_obs : k (<= PIML_MAX_TOPK); effective k is min(k, N) / min(k, M)
+ *   cos_thr_* : float32(cos(3.14 * sight_angle / 180))  (the reference's 3.14, quirk Q1)
+ *   dist_thr_* : neighbours farther than this (strict >) are zero-padded
+ * Outputs (row i = focal_begin + i):
+ *   ped_feat (C, focal_count, kp_eff, 6) = (p_j - p_i, v_j - v_i, a_j - a_i), zero-padded
+ *   obs_feat (C, focal_count, ko_eff, 6) = (o_j - p_i, -v_i, -a_i), zero-padded
+ *   dest_feat (C, focal_count, 2) = destination - position, NaN -> 0
+ *   ped_idx / obs_idx (int32, same leading shape, k_eff) : source index per slot, -1 = empty
+ * NaN velocity / acceleration entries are read as 0 (the reference zeroes them in place
+ * first, data.py:483-484; the host wrapper performs that in-place write).
+ * Ordering rule: slots ascend by (distance, index); exact distance ties resolve to the
+ * lower index (torch.sort leaves ties unspecified).
+ */
+int piml_relfeat_fwd(const float* position, const float* heading, const float* velocity,
+                     const float* acceleration, const float* destination,
+                     const float* obstacles, int C, int N, int M, int focal_begin,
+                     int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                     float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                     float* ped_feat, float* obs_feat, float* dest_feat, int32_t* ped_idx,
+                     int32_t* obs_idx, void* stream);
+
+/*
+ * Relative features, backward: what autograd computes through gather / repeat / masked
+ * zeroing in src/data/data.py:397-414, 449-464, 491-510.
+ *   g_ped_feat (C, focal_count, kp_eff, 6), g_obs_feat (C, focal_count, ko_eff, 6),
+ *   g_dest_feat (C, focal_count, 2) : upstream gradients
+ *   ped_idx, obs_idx : as written by piml_relfeat_fwd
+ *   position, destination : forward inputs (only their NaN pattern is used)
+ * Outputs:
+ *   g_state (C, N, 6) : d/d(position, velocity, acceleration) concatenated per agent, for
+ *             ALL N sources (a rank's partial sum under agent-block sharding); the kernel
+ *             ACCUMULATES into it with float atomics, the caller zeroes it first;
+ *   g_destination (C, focal_count, 2) : overwritten.
+ */
+int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,
+                     const int32_t* ped_idx, const int32_t* obs_idx, const float* position,
+                     const float* destination, int C, int N, int focal_begin, int focal_count,
+                     int kp_eff, int ko_eff, float* g_state, float* g_destination, void* stream);
+
+/*
+ * Diagnostic (tests only): evaluates, per element, the exact float32 arithmetic of the
+ * neighbour-selection predicates -- dist = |r| as torch.norm computes it and
+ * cos = torch.cosine_similarity(r, h) (src/data/data.py:434, 439-440) -- so that it can be
+ * pinned bit-for-bit against the CPU restatement.  All arrays have n elements.
+ */
+int piml_probe_arith(const float* rx, const float* ry, const float* hx, const float* hy,
+                     float* dist, float* cosv, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIML_HIP_H */

@@ -1,0 +1,222 @@
+"""PINNSF network family (reference src/models/model.py:16-119, 720-792, 950-1305).
+
+The residual MLPs stay plain PyTorch-ROCm modules (rocBLAS GEMMs); the pairwise geometry
+that feeds them is the HIP path (piml_amd.ops).  Class names, constructor `args` fields,
+forward input/output lists and state_dict keys match the reference so its checkpoints load
+unchanged (tests/test_models.py loads reference-initialised state_dicts and reproduces the
+reference's outputs).
+
+Reference behaviours kept on purpose:
+  Q2  the desired-force normalisation reduces over dim=1 (model.py:1290): the per-agent norm
+      for (N,7) inputs, a norm over AGENTS for channelled (C,N,7) inputs;
+      `fix_dest_norm=True` on the module switches to the per-agent norm.
+  Q3  ResDNN feeds every block the ORIGINAL input and keeps only the last block's output
+      (model.py:115-119); blocks 1.. have no layers, so with >= 2 "layers" the processor is
+      Dropout(2x) and resnet.0's weights are dead (but present in the state_dict).
+  Q4  zero-padded neighbour rows still pass through the encoder (bias-driven constants).
+Deviation: in train mode the reference calls Dropout once per (discarded) block; here only the
+surviving block is evaluated, so the RNG stream differs (eval mode is exact).
+"""
+import torch
+import torch.nn as nn
+
+
+def activation_layer(act_name, negative_slope=0.1):
+    if isinstance(act_name, str):
+        table = {'sigmoid': nn.Sigmoid, 'relu': nn.ReLU}
+        if act_name.lower() in table:
+            return table[act_name.lower()]()
+        if act_name.lower() == 'leaky_relu':
+            return nn.LeakyReLU(negative_slope)
+        raise NotImplementedError(act_name)
+    if isinstance(act_name, type) and issubclass(act_name, nn.Module):
+        return act_name()
+    raise NotImplementedError(act_name)
+
+
+class MLP(nn.Module):
+    """Linear layers at even indices of `self.mlp`, activations at odd ones (model.py:40-65)."""
+
+    def __init__(self, input_size, layer_sizes, activation=None, dropout=0, output_act=None):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError('MLP dropout > 0 is unreachable in the reference (model.py:60-61 raises)')
+        self.dropout = dropout
+        sizes = [input_size] + list(layer_sizes)
+        mods = []
+        for i in range(len(sizes) - 1):
+            last = i == len(sizes) - 2
+            act = (output_act if output_act is not None else nn.Identity()) if last else \
+                (activation if activation is not None else nn.ReLU())
+            mods += [nn.Linear(sizes[i], sizes[i + 1]), act]
+        self.mlp = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_dim, hidden_units, activation, dropout=0, use_bn=False):
+        super().__init__()
+        if use_bn:
+            raise NotImplementedError('bn in resblock has not been implemented!')
+        self.lin = MLP(in_dim, hidden_units, activation, dropout, activation)
+
+    def forward(self, x):
+        return self.lin(x) + x
+
+
+class ResDNN(nn.Module):
+    """model.py:82-119, including quirk Q3 (see module docstring)."""
+
+    def __init__(self, input_dim, hidden_units, activation=None, dropout=0, use_bn=False):
+        super().__init__()
+        hidden_units = [list(h) for h in hidden_units]
+        if input_dim != hidden_units[0][0]:
+            raise ValueError('In ResBlock, the feature size must be equal to the hidden size! '
+                             'input_dim:{}, hidden_size: {}'.format(input_dim, hidden_units[0]))
+        activation = activation if activation is not None else nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+        hidden_units[0] = [input_dim] + hidden_units[0]
+        self.hidden_units = hidden_units
+        # the reference passes `use_bn` in ResBlock's dropout slot (model.py:113)
+        self.resnet = nn.ModuleList([ResBlock(h[0], h[1:], activation, use_bn) for h in hidden_units])
+
+    def forward(self, x):
+        return self.dropout(self.resnet[len(self.hidden_units) - 1](x))
+
+
+class attn_pooling(nn.Module):
+    """model.py:950-970: softmax(exp(w(x))) pooling over the neighbour axis."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.get_weights = MLP(dim, [dim, 1])
+
+    def forward(self, x):
+        attn = torch.softmax(torch.exp(self.get_weights(x)), dim=-2)
+        return torch.matmul(x.transpose(-1, -2), attn).squeeze()
+
+
+class _PINNSFBase(nn.Module):
+    """Shared body of the PINNSF variants; subclasses set the class attributes below."""
+    bottleneck = False          # decoder + predictor applied per neighbour, then summed over k
+    collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
+    residual = False            # pinnsf_res corrector branch
+    obs_encoder_in = 6          # PINNSF_residual uses args.obs_feature_dim instead
+    taus = (2, 2)               # (non-ucy tau, ucy tau)
+
+    def __init__(self, args):
+        super().__init__()
+        ucy = getattr(args, 'dataset_name', None) in {'ucy'}
+        self.tau = self.taus[1] if ucy else self.taus[0]
+        self.fix_dest_norm = False
+        self.ped_feature_dim = args.ped_feature_dim
+        self.obs_feature_dim = args.obs_feature_dim
+        self.self_feature_dim = args.self_feature_dim
+        enc = [args.encoder_hidden_size] * args.encoder_hidden_layers
+        pro = [[args.processor_hidden_size] for _ in range(args.processor_hidden_layers)]
+        dec = [args.decoder_hidden_size] * args.decoder_hidden_layers
+        act = activation_layer(args.activation)
+
+        self.ped_encoder = MLP(self.ped_feature_dim, enc)
+        obs_in = self.obs_encoder_in if self.obs_encoder_in else self.obs_feature_dim
+        if self.obs_encoder_in or self.obs_feature_dim > 0:
+            self.obs_encoder = MLP(obs_in, enc)
+        self.ped_processor = ResDNN(enc[-1], pro, act, args.dropout)
+        self.obs_processor = ResDNN(enc[-1], [list(h) for h in pro], act, args.dropout)
+        self.ped_decoder = MLP(pro[-1][-1], dec)
+        self.obs_decoder = MLP(pro[-1][-1], dec)
+        self.ped_predictor = MLP(dec[-1], [2])
+        self.obs_predictor = MLP(dec[-1], [2])
+        if self.collision_head == 'msgs':
+            self.ped_collision_predictor = MLP(pro[-1][-1], [dec[-1], 1])
+        elif self.collision_head == 'decoded':
+            self.ped_collision_predictor = MLP(dec[-1], [dec[-1], 1])
+        if self.residual:
+            res = [[args.processor_hidden_size] for _ in range(args.res_hidden_layers)]
+            self.corrector = nn.ModuleList([
+                ResDNN(enc[-1], res, act, args.dropout), attn_pooling(res[-1][-1]),
+                MLP(res[-1][-1], [int(res[-1][-1] / 2), 2])])
+
+    def desired_force(self, self_features):
+        """(v0 * e - v) / tau with e = dest_features / |dest_features| (model.py:1289-1294)."""
+        desired_speed = self_features[..., -1].unsqueeze(-1)
+        dim = -1 if self.fix_dest_norm else 1                       # quirk Q2
+        temp = torch.norm(self_features[..., :2], p=2, dim=dim, keepdim=True)
+        temp = torch.where(temp == 0, temp + 0.1, temp)
+        dest_direction = self_features[..., :2] / temp
+        return (desired_speed * dest_direction - self_features[..., 2:4]) / self.tau
+
+    def _branch(self, feats, encoder, processor, decoder, predictor):
+        emb = processor(encoder(feats))
+        if self.bottleneck:
+            decoded = decoder(emb)
+            msgs = predictor(decoded)
+            return msgs.sum(dim=-2), msgs, decoded, emb
+        acc = predictor(decoder(emb.sum(dim=-2)))
+        return acc, emb, None, emb
+
+    def forward(self, ped_features, obs_features, self_features):
+        assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'
+        encoded = self.ped_encoder(ped_features) if self.residual else None
+        if self.residual:
+            emb = self.ped_processor(encoded)
+            ped_msgs = emb
+            acc = self.ped_predictor(self.ped_decoder(emb.sum(dim=-2)))
+            decoded = None
+        else:
+            acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
+                                                       self.ped_decoder, self.ped_predictor)
+        out_obs = None
+        if self.obs_feature_dim > 0:
+            acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
+                                                self.obs_decoder, self.obs_predictor)
+            acc = acc + acc_o
+        predictions = acc + self.desired_force(self_features)
+        if self.residual:
+            r = self.corrector[0](encoded)
+            predictions = predictions + self.corrector[2](self.corrector[1](r))
+        out = [predictions, ped_msgs]
+        if out_obs is not None:
+            out.append(out_obs)
+        if self.collision_head is not None:
+            src = ped_msgs if self.collision_head == 'msgs' else decoded
+            out.append(torch.sigmoid(self.ped_collision_predictor(src)).squeeze())
+        return out
+
+
+class PINNSF(_PINNSFBase):
+    """model.py:720-792 (`--model pinnsf`, and the pre-training net of `pinnsf_res`)."""
+
+
+class PINNSF_residual(_PINNSFBase):
+    """model.py:973-1059 (`--model pinnsf_res`, fine-tune stage)."""
+    residual = True
+    obs_encoder_in = 0
+
+
+class PINNSF_bottleneck(_PINNSFBase):
+    """model.py:1062-1135 (`--model pinnsf_bottleneck`)."""
+    bottleneck = True
+
+
+class PINNSF_bottleneck_multitask(_PINNSFBase):
+    """model.py:1138-1221 (`--model pinnsf_bm`)."""
+    bottleneck = True
+    collision_head = 'decoded'
+    taus = (2, 5 / 6)
+
+
+class PINNSF_multitask(_PINNSFBase):
+    """model.py:1224-1305 (`--model pinnsf_m`, the default)."""
+    collision_head = 'msgs'
+    taus = (0.5, 5 / 6)
+
+
+MODEL_TABLE = {   # simulators.py:40-106 (set_model / set_ft_model), PINNSF-family rows
+    'pinnsf': (PINNSF, PINNSF), 'pinnsf_res': (PINNSF, PINNSF_residual),
+    'pinnsf_bottleneck': (PINNSF_bottleneck, PINNSF_bottleneck),
+    'pinnsf_bm': (PINNSF_bottleneck_multitask, PINNSF_bottleneck_multitask),
+    'pinnsf_m': (PINNSF_multitask, PINNSF_multitask),
+}
