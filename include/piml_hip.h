@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 1
+#define PIML_HIP_ABI_VERSION 2
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -51,7 +51,11 @@ int piml_heading_fwd(const float* velocity, int C, int T, int N, float* heading,
  * (:397-414) + get_filtered_features (:449-464), for C slices of N agents and M shared
  * obstacle points, without materialising any N x N tensor.
  *
- *   position, velocity, acceleration, destination : (C, N, 2)
+ *   position, velocity, acceleration : (C, N, .) per-agent records whose consecutive agents
+ *             are `state_ld` floats apart: state_ld = 2 for three separate (C, N, 2) arrays,
+ *             6 for one interleaved (C, N, 6) = (p, v, a) buffer (pass base, base+2, base+4),
+ *             which is what the per-step all-gather of agent-block sharding produces
+ *   destination : (C, focal_count, 2), destinations of the focal rows only
  *   heading : (C, N, 2) unit heading from piml_heading_fwd, or NULL = derive it from
  *             `velocity` (the T == 1 per-step case, where heading = v/|v|)
  *   obstacles : (M, 2), may be NULL when M == 0
@@ -71,7 +75,7 @@ int piml_heading_fwd(const float* velocity, int C, int T, int N, float* heading,
  * lower index (torch.sort leaves ties unspecified).
  */
 int piml_relfeat_fwd(const float* position, const float* heading, const float* velocity,
-                     const float* acceleration, const float* destination,
+                     const float* acceleration, int state_ld, const float* destination,
                      const float* obstacles, int C, int N, int M, int focal_begin,
                      int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                      float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
@@ -84,7 +88,8 @@ int piml_relfeat_fwd(const float* position, const float* heading, const float* v
  *   g_ped_feat (C, focal_count, kp_eff, 6), g_obs_feat (C, focal_count, ko_eff, 6),
  *   g_dest_feat (C, focal_count, 2) : upstream gradients
  *   ped_idx, obs_idx : as written by piml_relfeat_fwd
- *   position, destination : forward inputs (only their NaN pattern is used)
+ *   position (stride state_ld), destination (focal rows) : forward inputs (only their NaN
+ *             pattern is used)
  * Outputs:
  *   g_state (C, N, 6) : d/d(position, velocity, acceleration) concatenated per agent, for
  *             ALL N sources (a rank's partial sum under agent-block sharding); the kernel
@@ -93,7 +98,7 @@ int piml_relfeat_fwd(const float* position, const float* heading, const float* v
  */
 int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,
                      const int32_t* ped_idx, const int32_t* obs_idx, const float* position,
-                     const float* destination, int C, int N, int focal_begin, int focal_count,
+                     int state_ld, const float* destination, int C, int N, int focal_begin, int focal_count,
                      int kp_eff, int ko_eff, float* g_state, float* g_destination, void* stream);
 
 /*

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -20,10 +20,10 @@ _i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 SIGNATURES = {
     'piml_abi_version': [],
     'piml_heading_fwd': [_p, _i, _i, _i, _p, _p],
-    'piml_relfeat_fwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
+    'piml_relfeat_fwd': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                          _p, _p, _p, _p, _p, _p],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
-    'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 
 

@@ -9,45 +9,76 @@
 //   phase 2 (survivors only, 64 at a time): the exact float32 arithmetic PyTorch's CPU
 //            kernels use for the distance and the view-cone cosine, so the neighbour sets
 //            are bit-identical to the reference's;
-//   phase 3 insertion into a sorted top-k list held one entry per lane (key =
-//            distance bits << 32 | source index), which also tightens the phase-1 cut-off
-//            to the current k-th distance.
+//   phase 3 each chunk is drained smallest-distance-first (DPP row reductions) into a sorted
+//            top-k list held one entry per lane, at most k insertions per chunk; the k-th
+//            distance tightens the phase-1 cut-off.
 //
 // No N x N intermediate exists; v / a are touched only for the k selected neighbours.
 #include "common.hpp"
 #include "../../include/piml_hip.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace piml {
 
 constexpr int kTile = 4096;        // source points per LDS tile (32 KiB)
-constexpr int kRing = 128;         // per-wave candidate ring (entries), power of two
+constexpr int kRing = 1024;        // per-wave candidate ring (entries), power of two; a 512-group
+                                   // can append up to 512 candidates on top of < 64 pending ones
 
 struct RelfeatArgs {
-    const float2* p; const float2* hd; const float2* v; const float2* a; const float2* dest;
-    const float2* obs;
+    const float* p; const float* v; const float* a;   // per-agent records, `ld` floats apart
+    const float2* hd; const float2* dest; const float2* obs;
+    int ld;
     int C, N, M, f0, fcnt, kp, ko;
     float cos_p, cos_o, cut2_p, cut2_o, dthr_p, dthr_o;
     float* ped_feat; float* obs_feat; float2* dest_feat; int* ped_idx; int* obs_idx;
+    int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates}
 };
 
-// Insert `nk` (known to be < the current k-th key) into the ascending list held one key per
-// lane.  Lanes >= k carry don't-care values.
-__device__ __forceinline__ u64 list_insert(u64 list, u64 nk, int lane) {
-    const u64 up = shift_up1(list);
-    const int pos = __ffsll((long long)__ballot(list > nk)) - 1;   // first lane whose key is larger
-    return lane > pos ? up : (lane == pos ? nk : list);
+// ---- sorted top-k list, one entry per lane: (distance bits, source index) ----
+// Entries ascend by (distance, index); exact distance ties resolve to the lower index.
+constexpr unsigned kEmptyDist = 0xffffffffu;   // > bits of every finite non-negative float
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
+}
+// minimum over the 64 lanes, returned wave-uniform (4 DPP row steps + 4 readlanes)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
+    x = min(x, dpp_mov<0xB1>(x));     // quad_perm [1,0,3,2]
+    x = min(x, dpp_mov<0x4E>(x));     // quad_perm [2,3,0,1]
+    x = min(x, dpp_mov<0x141>(x));    // row_half_mirror
+    x = min(x, dpp_mov<0x140>(x));    // row_mirror: every lane of a row holds the row minimum
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0);
+    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32);
+    const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+    return min(min(a, b), min(c, d));
+}
+// Insert the wave-uniform entry (nd, ni), which precedes the current k-th entry.  The lower
+// neighbour's entry arrives by a DPP wave_shr:1 move (lane 0 reads (0, 0), which never
+// follows the new entry, so lane 0 can only be the receiving slot).
+__device__ __forceinline__ void list_insert(unsigned& ld, unsigned& li, unsigned nd, unsigned ni) {
+    const unsigned up_d = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ld, 0x138, 0xf, 0xf, false);
+    const unsigned up_i = (unsigned)__builtin_amdgcn_update_dpp(0, (int)li, 0x138, 0xf, 0xf, false);
+    const bool moves = ld > nd || (ld == nd && li > ni);
+    const bool below_moves = up_d > nd || (up_d == nd && up_i > ni);
+    ld = moves ? (below_moves ? up_d : nd) : ld;
+    li = moves ? (below_moves ? up_i : ni) : li;
 }
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatArgs A) {
-    __shared__ float2 tile[kTile];
+    // source tile, structure-of-arrays so that a lane fetches 4 consecutive points per
+    // ds_read_b128 (x) + ds_read_b128 (y)
+    __shared__ __attribute__((aligned(16))) float tile_x[kTile];
+    __shared__ __attribute__((aligned(16))) float tile_y[kTile];
     __shared__ unsigned short ring_all[WAVES][kRing];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    volatile unsigned short* ring = ring_all[wave];
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    unsigned short* ring = ring_all[wave];                  // stays in the LDS address space
 
     const int bpc = (A.fcnt + WAVES - 1) / WAVES;          // blocks per slice
     const int c = blockIdx.x / bpc;
@@ -57,9 +88,11 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     const size_t ci = (size_t)c * A.N + i;
 
     // focal state: identical in every lane -> scalar registers
-    const float2 pi2 = A.p[ci];
+    const int ld = A.ld;
+    const float2 pi2 = *reinterpret_cast<const float2*>(A.p + ci * ld);
     const float pix = uniform(pi2.x), piy = uniform(pi2.y);
-    const float2 vi2 = A.v[ci], ai2 = A.a[ci];
+    const float2 vi2 = *reinterpret_cast<const float2*>(A.v + ci * ld);
+    const float2 ai2 = *reinterpret_cast<const float2*>(A.a + ci * ld);
     const float vix = uniform(nan_to_zero(vi2.x)), viy = uniform(nan_to_zero(vi2.y));
     const float aix = uniform(nan_to_zero(ai2.x)), aiy = uniform(nan_to_zero(ai2.y));
     const bool alive = has && pix == pix && piy == piy;     // NaN focal: every distance is inf
@@ -76,75 +109,135 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     }
     const float n2c = fmaxf(norm2(hx, hy), 1e-8f);
     const float h0 = __fdiv_rn(hx, n2c), h1 = __fdiv_rn(hy, n2c);
+    const float qnan = __uint_as_float(0x7fc00000u);
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f pix2 = {pix, pix}, piy2 = {piy, piy};
 
-    u64 lists[2];
-#pragma unroll
+#ifdef PIML_RELFEAT_STATS
+    int st_evals = 0, st_rounds = 0, st_ins = 0, st_cand = 0;
+#define PIML_STAT(x) x
+#else
+#define PIML_STAT(x)
+#endif
+    u64 lists[2] = {kEmptyKey, kEmptyKey};
+    // Runtime loop and a single evaluation site: the exact-evaluation / drain code exists once
+    // in the binary, so it stays resident in the instruction cache (inlining it at every
+    // append site made each execution an instruction-fetch miss chain).
+#pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        const float2* __restrict__ src = pass == 0 ? A.p + (size_t)c * A.N : A.obs;
+        const float* __restrict__ src = pass == 0 ? A.p + (size_t)c * A.N * ld : (const float*)A.obs;
+        const int sld = pass == 0 ? ld : 2;
         const int cnt = pass == 0 ? A.N : A.M;
         const int k = pass == 0 ? A.kp : A.ko;
         const float cos_thr = pass == 0 ? A.cos_p : A.cos_o;
         const float dthr = pass == 0 ? A.dthr_p : A.dthr_o;
-        float cut2 = pass == 0 ? A.cut2_p : A.cut2_o;
+        float cut2 = pass == 0 ? A.cut2_p : A.cut2_o;      // wave-uniform
 
-        u64 list = kEmptyKey, kth = kEmptyKey;
+        unsigned list_d = kEmptyDist, list_i = 0;          // lane s: s-th nearest in-view source so far
+        unsigned kth_d = kEmptyDist, kth_i = 0;            // wave-uniform copy of lane k-1's entry
         unsigned head = 0, tail = 0;                       // wave-uniform ring cursors
 
+#pragma unroll 1
         for (int base = 0; base < cnt; base += kTile) {
             const int tn = min(kTile, cnt - base);
+            const int tn_pad = (tn + 511) & ~511;          // phase 1 reads whole 512-groups
             __syncthreads();                                // previous tile fully consumed
-            for (int t = threadIdx.x; t < tn; t += WAVES * 64) tile[t] = src[base + t];
+            for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
+                float2 q = make_float2(qnan, qnan);         // NaN never passes the cut-off
+                if (t < tn) q = *reinterpret_cast<const float2*>(src + (size_t)(base + t) * sld);
+                tile_x[t] = q.x; tile_y[t] = q.y;
+            }
             __syncthreads();
             if (!alive || k <= 0) continue;
 
-            // exact evaluation of `n` buffered candidates (lane l takes ring[head + l])
-            auto eval_chunk = [&](unsigned n) {
-                const bool act = (unsigned)lane < n;
-                const int jl = act ? (int)ring[(head + lane) & (kRing - 1)] : 0;
-                head += n;
-                const float2 q = tile[jl];
-                const float rx = q.x - pix, ry = q.y - piy;
-                const float d = norm2(rx, ry);                         // data.py:434
-                const float cs = cos_sim_prenorm(rx, ry, d, h0, h1);   // :439-440
-                const bool ok = act && cs >= cos_thr && d <= dthr;     // :441-443, :461
-                const u64 key = ok ? (((u64)__float_as_uint(d) << 32) | (unsigned)(base + jl)) : kEmptyKey;
-                u64 better = __ballot(key < kth);
-                while (better) {
-                    const int s = __ffsll((long long)better) - 1;
-                    better &= better - 1;
-                    const u64 nk = readlane64(key, s);
-                    if (nk < kth) {
-                        list = list_insert(list, nk, lane);
-                        kth = readlane64(list, k - 1);
+            // one extra trip (j0 == tn_pad) appends nothing and flushes the ring, because the
+            // ring holds tile-local indices
+#pragma unroll 1
+            for (int j0 = 0; j0 <= tn_pad; j0 += 512) {
+                const bool flush = j0 == tn_pad;
+                if (!flush) {
+                    // phase 1: lane owns points j0 + 4*lane + {0..3} and j0 + 256 + 4*lane + {0..3}
+                    // packed fp32 (v_pk_add/mul/fma): two points per instruction
+                    float d2[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 x = *reinterpret_cast<const float4*>(&tile_x[j0 + h * 256 + 4 * lane]);
+                        const float4 y = *reinterpret_cast<const float4*>(&tile_y[j0 + h * 256 + 4 * lane]);
+                        const v2f rx0 = v2f{x.x, x.y} - pix2, ry0 = v2f{y.x, y.y} - piy2;
+                        const v2f rx1 = v2f{x.z, x.w} - pix2, ry1 = v2f{y.z, y.w} - piy2;
+                        const v2f q0 = __builtin_elementwise_fma(ry0, ry0, rx0 * rx0);
+                        const v2f q1 = __builtin_elementwise_fma(ry1, ry1, rx1 * rx1);
+                        d2[h * 4 + 0] = q0.x; d2[h * 4 + 1] = q0.y; d2[h * 4 + 2] = q1.x; d2[h * 4 + 3] = q1.y;
+                    }
+                    // one compare for all 8 (fminf ignores the NaNs of padding / absent agents)
+                    const float dmin = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])),
+                                             fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+                    if (__builtin_amdgcn_ballot_w64(dmin <= cut2) == 0) continue;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const u64 m = __builtin_amdgcn_ballot_w64(d2[u] <= cut2);
+                        if (m == 0) continue;                  // the common case once the cut-off is tight
+                        if (d2[u] <= cut2)
+                            ring[(tail + mbcnt(m)) & (kRing - 1)] =
+                                (unsigned short)(j0 + (u >> 2) * 256 + 4 * lane + (u & 3));
+                        tail += (unsigned)__builtin_popcountll(m);
                     }
                 }
-                if (kth != kEmptyKey) {
-                    // any source that can still enter the list has dist <= d_k, hence
-                    // d2 <= d_k^2 (1 + 2^-20) whatever the rounding of sqrt and the product
-                    const float dk = __uint_as_float((unsigned)(kth >> 32));
-                    cut2 = fminf(cut2, dk * dk * 1.00000095367431640625f);
-                }
-            };
-
-            for (int j0 = 0; j0 < tn; j0 += 64) {
-                const int jl = j0 + lane;
-                const float2 q = tile[min(jl, tn - 1)];
-                const float rx = q.x - pix, ry = q.y - piy;
-                const float d2 = sq2(rx, ry);
-                const bool cand = jl < tn && d2 <= cut2;              // NaN / inf never pass
-                const u64 m = __ballot(cand);
-                if (m) {
-                    if (cand) ring[(tail + mbcnt(m)) & (kRing - 1)] = (unsigned short)jl;
-                    tail += (unsigned)__popcll(m);
-                    if (tail - head >= 64u) eval_chunk(64u);
+                // phase 2 + 3: exact evaluation of buffered candidates, 64 per trip
+#pragma unroll 1
+                while (tail - head >= (flush ? 1u : 64u)) {
+                    const unsigned n = min(64u, tail - head);
+                    PIML_STAT(++st_evals; st_cand += (int)n;)
+                    const bool act = (unsigned)lane < n;
+                    const int jl = act ? (int)ring[(head + lane) & (kRing - 1)] : 0;
+                    head = uniform((int)(head + n));
+                    const float rx = tile_x[jl] - pix, ry = tile_y[jl] - piy;
+                    const float d = norm2(rx, ry);                         // data.py:434
+                    const float cs = cos_sim_prenorm(rx, ry, d, h0, h1);   // :439-440
+                    const bool ok = act && cs >= cos_thr && d <= dthr;     // :441-443, :461
+                    unsigned cd = ok ? __float_as_uint(d) : kEmptyDist;
+                    // drain the chunk in (distance, index) order: at most k entries can enter
+#pragma unroll 1
+                    for (;;) {
+                        PIML_STAT(++st_rounds;)
+                        const unsigned md = wave_min_u32(cd);
+                        if (md > kth_d || md == kEmptyDist) break;
+                        u64 tied = __builtin_amdgcn_ballot_w64(cd == md);
+                        int s = __builtin_ctzll(tied);
+                        int nj = __builtin_amdgcn_readlane(jl, s);
+                        for (tied &= tied - 1; tied; tied &= tied - 1) {   // exact ties: lowest index first
+                            const int s2 = __builtin_ctzll(tied);
+                            const int j2 = __builtin_amdgcn_readlane(jl, s2);
+                            if (j2 < nj) { nj = j2; s = s2; }
+                        }
+                        const unsigned ni = (unsigned)(base + nj);
+                        if (md == kth_d && ni > kth_i) break;      // every remaining candidate follows the k-th
+                        PIML_STAT(++st_ins;)
+                        list_insert(list_d, list_i, md, ni);
+                        kth_d = (unsigned)__builtin_amdgcn_readlane((int)list_d, k - 1);
+                        kth_i = (unsigned)__builtin_amdgcn_readlane((int)list_i, k - 1);
+                        if (lane == s) cd = kEmptyDist;
+                    }
+                    if (kth_d != kEmptyDist) {
+                        // any source that can still enter the list has dist <= d_k, hence
+                        // d2 <= d_k^2 (1 + 2^-20) whatever the rounding of sqrt and the product
+                        const float dk = __uint_as_float(kth_d);
+                        cut2 = fminf(cut2, dk * dk * 1.00000095367431640625f);
+                    }
                 }
             }
-            if (tail != head) eval_chunk(tail - head);       // ring holds tile-local indices
         }
-        lists[pass] = list;
+        const u64 mine = list_d == kEmptyDist ? kEmptyKey : (u64)list_i;
+        if (pass == 0) lists[0] = mine; else lists[1] = mine;
     }
 
     if (!has) return;
+#ifdef PIML_RELFEAT_STATS
+    if (A.stats && lane == 0) {
+        int* o = A.stats + ((size_t)c * A.fcnt + fl) * 4;
+        o[0] = st_evals; o[1] = st_rounds; o[2] = st_ins; o[3] = st_cand;
+    }
+#endif
 
     // ---- epilogue: gather the k selected sources, write features / indices ----
     const int kpe = min(A.kp, A.N), koe = min(A.ko, A.M);
@@ -154,8 +247,10 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
         if (j >= 0) {
-            const size_t cj = (size_t)c * A.N + j;
-            const float2 pj = A.p[cj], vj = A.v[cj], aj = A.a[cj];
+            const size_t cj = ((size_t)c * A.N + j) * ld;
+            const float2 pj = *reinterpret_cast<const float2*>(A.p + cj);
+            const float2 vj = *reinterpret_cast<const float2*>(A.v + cj);
+            const float2 aj = *reinterpret_cast<const float2*>(A.a + cj);
             f0 = pj.x - pix; f1 = pj.y - piy;                           // data.py:491-492
             f2 = nan_to_zero(vj.x) - vix; f3 = nan_to_zero(vj.y) - viy;
             f4 = nan_to_zero(aj.x) - aix; f5 = nan_to_zero(aj.y) - aiy;
@@ -178,46 +273,50 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         A.obs_idx[row * koe + lane] = j;
     }
     if (lane == 0) {
-        const float2 d = A.dest[ci];
+        const float2 d = A.dest[row];
         A.dest_feat[row] = make_float2(nan_to_zero(d.x - pix), nan_to_zero(d.y - piy));   // :496-497
     }
 }
 
-// One thread per focal row.  The scatter into the selected sources uses float atomics
-// (<= (kp+1)*6 per row, a few hundred KB in total); the caller zeroes g_state first.
-__global__ void relfeat_bwd_kernel(const float* __restrict__ g_ped, const float* __restrict__ g_obs,
-                                   const float2* __restrict__ g_destf, const int* __restrict__ ped_idx,
-                                   const int* __restrict__ obs_idx, const float2* __restrict__ p,
-                                   const float2* __restrict__ dest, int C, int N, int f0, int fcnt,
-                                   int kpe, int koe, float* g_state, float2* g_dest) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= C * fcnt) return;
-    const int c = t / fcnt, fl = t - c * fcnt;
-    const size_t row = (size_t)t;
+// One wavefront per focal row; lane = slot * 8 + component (components 6, 7 idle), so a
+// row's gradient block is read nearly coalesced and the sum over slots is three xor-shuffles.
+// The scatter into the selected sources uses float atomics (a few hundred KB in total); the
+// row's own term is added atomically too because other rows scatter into it concurrently.
+__global__ __launch_bounds__(256) void relfeat_bwd_kernel(
+        const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
+        const int* __restrict__ ped_idx, const int* __restrict__ obs_idx, const float* __restrict__ p, int ld,
+        const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
+        float2* g_dest) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)C * fcnt) return;
+    const int c = (int)(row / fcnt), fl = (int)(row - (long)c * fcnt);
     const size_t ci = (size_t)c * N + f0 + fl;
-    float own[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < kpe; ++s) {
-        const int j = ped_idx[row * kpe + s];
-        if (j < 0) continue;
-        const float* g = g_ped + (row * kpe + s) * 6;
-        float* dst = g_state + ((size_t)c * N + j) * 6;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { const float gv = g[q]; atomicAdd(dst + q, gv); own[q] -= gv; }
+    const int q = lane & 7, s0 = lane >> 3;
+    float own = 0.f;
+    if (q < 6) {
+        for (int s = s0; s < kpe; s += 8) {
+            const int j = ped_idx[row * kpe + s];
+            if (j < 0) continue;
+            const float g = g_ped[(row * kpe + s) * 6 + q];
+            atomicAdd(g_state + ((size_t)c * N + j) * 6 + q, g);
+            own -= g;
+        }
+        for (int s = s0; s < koe; s += 8)
+            if (obs_idx[row * koe + s] >= 0) own -= g_obs[(row * koe + s) * 6 + q];
     }
-    for (int s = 0; s < koe; ++s) {
-        if (obs_idx[row * koe + s] < 0) continue;
-        const float* g = g_obs + (row * koe + s) * 6;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) own[q] -= g[q];
+    own += __shfl_xor(own, 8, 64);
+    own += __shfl_xor(own, 16, 64);
+    own += __shfl_xor(own, 32, 64);
+    if (s0 == 0 && q < 6) {
+        if (q < 2) {
+            const float dq = reinterpret_cast<const float*>(dest)[row * 2 + q] - p[ci * ld + q];
+            const float gd = dq != dq ? 0.f : reinterpret_cast<const float*>(g_destf)[row * 2 + q];
+            reinterpret_cast<float*>(g_dest)[row * 2 + q] = gd;
+            own -= gd;
+        }
+        atomicAdd(g_state + ci * 6 + q, own);
     }
-    const float2 pp = p[ci], dd = dest[ci], gd = g_destf[row];
-    const float dx = dd.x - pp.x, dy = dd.y - pp.y;
-    const float gx = dx != dx ? 0.f : gd.x, gy = dy != dy ? 0.f : gd.y;
-    g_dest[row] = make_float2(gx, gy);
-    own[0] -= gx; own[1] -= gy;
-    float* dst = g_state + ci * 6;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) atomicAdd(dst + q, own[q]);
 }
 
 // One thread per (slice, agent): two sweeps over time (data.py:363-389), then normalise.
@@ -257,21 +356,22 @@ static float dist2_cutoff(float thr) {
 using namespace piml;
 
 PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const float* velocity,
-                              const float* acceleration, const float* destination,
+                              const float* acceleration, int state_ld, const float* destination,
                               const float* obstacles, int C, int N, int M, int focal_begin,
                               int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                               float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
                               float* ped_feat, float* obs_feat, float* dest_feat,
                               int32_t* ped_idx, int32_t* obs_idx, void* stream) {
     if (C < 0 || N < 0 || M < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
-        topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK)
+        topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK ||
+        state_ld < 2 || (state_ld & 1))
         return hipErrorInvalidValue;
     if (C == 0 || focal_count == 0) return hipSuccess;
     if (!position || !velocity || !acceleration || !destination || !dest_feat || (M > 0 && !obstacles))
         return hipErrorInvalidValue;
     RelfeatArgs A;
-    A.p = (const float2*)position; A.hd = (const float2*)heading; A.v = (const float2*)velocity;
-    A.a = (const float2*)acceleration; A.dest = (const float2*)destination; A.obs = (const float2*)obstacles;
+    A.p = position; A.v = velocity; A.a = acceleration; A.ld = state_ld;
+    A.hd = (const float2*)heading; A.dest = (const float2*)destination; A.obs = (const float2*)obstacles;
     A.C = C; A.N = N; A.M = M; A.f0 = focal_begin; A.fcnt = focal_count;
     A.kp = topk_ped < N ? topk_ped : N; A.ko = topk_obs < M ? topk_obs : M;
     A.cos_p = cos_thr_ped; A.cos_o = cos_thr_obs;
@@ -279,32 +379,40 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     A.dthr_p = dist_thr_ped; A.dthr_o = dist_thr_obs;
     A.ped_feat = ped_feat; A.obs_feat = obs_feat; A.dest_feat = (float2*)dest_feat;
     A.ped_idx = ped_idx; A.obs_idx = obs_idx;
+    A.stats = nullptr;
+#ifdef PIML_RELFEAT_STATS
+    if (const char* e = getenv("PIML_RELFEAT_STATS_PTR")) A.stats = (int*)strtoull(e, nullptr, 0);
+#endif
     const long rows = (long)C * focal_count;
-    // 16 waves (one workgroup per CU at 4 waves/SIMD) once the launch fills the 256 CUs,
-    // 4-wave workgroups for small scenes so the rows spread over more CUs.
-    if (rows >= 16 * 256) {
-        const int bpc = (focal_count + 15) / 16;
-        hipLaunchKernelGGL(relfeat_fwd_kernel<16>, dim3(C * bpc), dim3(1024), 0, as_stream(stream), A);
-    } else {
-        const int bpc = (focal_count + 3) / 4;
-        hipLaunchKernelGGL(relfeat_fwd_kernel<4>, dim3(C * bpc), dim3(256), 0, as_stream(stream), A);
+    // Workgroup size: every workgroup stages the whole source array once, so bigger groups cut
+    // L2->LDS traffic, while smaller groups shorten the barrier tails (the per-wave work is
+    // data dependent) and spread small launches over more CUs.
+    int waves = rows >= 16384 ? 8 : (rows >= 4096 ? 16 : 4);   // measured on MI355X (tools/time_phase1.py)
+    if (const char* e = getenv("PIML_RELFEAT_WAVES")) waves = atoi(e);
+    const int bpc = (focal_count + waves - 1) / waves;
+    const dim3 grid((unsigned)(C * bpc)), block((unsigned)(waves * 64));
+    switch (waves) {
+        case 16: hipLaunchKernelGGL(relfeat_fwd_kernel<16>, grid, block, 0, as_stream(stream), A); break;
+        case 8: hipLaunchKernelGGL(relfeat_fwd_kernel<8>, grid, block, 0, as_stream(stream), A); break;
+        case 4: hipLaunchKernelGGL(relfeat_fwd_kernel<4>, grid, block, 0, as_stream(stream), A); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 PIML_API int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,
                               const int32_t* ped_idx, const int32_t* obs_idx, const float* position,
-                              const float* destination, int C, int N, int focal_begin, int focal_count,
+                              int state_ld, const float* destination, int C, int N, int focal_begin, int focal_count,
                               int kp_eff, int ko_eff, float* g_state, float* g_destination, void* stream) {
     if (C < 0 || N < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
-        kp_eff < 0 || ko_eff < 0)
+        kp_eff < 0 || ko_eff < 0 || state_ld < 2 || (state_ld & 1))
         return hipErrorInvalidValue;
     if (C == 0 || focal_count == 0) return hipSuccess;
     if (!g_dest_feat || !position || !destination || !g_state || !g_destination) return hipErrorInvalidValue;
     const long rows = (long)C * focal_count;
-    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream),
                        g_ped_feat, g_obs_feat, (const float2*)g_dest_feat, ped_idx, obs_idx,
-                       (const float2*)position, (const float2*)destination, C, N, focal_begin, focal_count,
+                       position, state_ld, (const float2*)destination, C, N, focal_begin, focal_count,
                        kp_eff, ko_eff, g_state, (float2*)g_destination);
     return hipGetLastError();
 }

@@ -49,7 +49,45 @@ def heading_direction(velocity):
     return out
 
 
+def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f0, fcnt, kp, ko,
+                        cos_p, cos_o, dthr_p, dthr_o, device):
+    M = o.shape[0]
+    kpe, koe = min(kp, N), min(ko, M)
+    opt = dict(device=device, dtype=torch.float32)
+    ped_feat = torch.empty(*lead, fcnt, kpe, 6, **opt)
+    obs_feat = torch.empty(*lead, fcnt, koe, 6, **opt)
+    dest_feat = torch.empty(*lead, fcnt, 2, **opt)
+    ped_idx = torch.empty(*lead, fcnt, kpe, device=device, dtype=torch.int32)
+    obs_idx = torch.empty(*lead, fcnt, koe, device=device, dtype=torch.int32)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().piml_relfeat_fwd(
+            p_ptr, _ptr(hd), v_ptr, a_ptr, ld, _ptr(dest_rows), _ptr(o), C, N, M, f0, fcnt,
+            kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat),
+            _ptr(ped_idx), _ptr(obs_idx), _stream()), 'piml_relfeat_fwd')
+    return ped_feat, obs_feat, dest_feat, ped_idx, obs_idx
+
+
+def _launch_relfeat_bwd(ctx_geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, p_ptr, ld, dest_rows, device):
+    C, N, f0, fcnt, kpe, koe, lead = ctx_geom
+
+    def dense(g, shape):
+        return torch.zeros(shape, device=device, dtype=torch.float32) if g is None else _gpu_f32('grad', g)
+    g_ped = dense(g_ped, (*lead, fcnt, kpe, 6))
+    g_obs = dense(g_obs, (*lead, fcnt, koe, 6))
+    g_dest = dense(g_dest, (*lead, fcnt, 2))
+    g_state = torch.zeros(*lead, N, 6, device=device, dtype=torch.float32)
+    g_dest_rows = torch.empty(*lead, fcnt, 2, device=device, dtype=torch.float32)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().piml_relfeat_bwd(
+            _ptr(g_ped), _ptr(g_obs), _ptr(g_dest), _ptr(ped_idx), _ptr(obs_idx), p_ptr, ld,
+            _ptr(dest_rows), C, N, f0, fcnt, kpe, koe, _ptr(g_state), _ptr(g_dest_rows), _stream()),
+            'piml_relfeat_bwd')
+    return g_state, g_dest_rows
+
+
 class _RelativeFeatures(torch.autograd.Function):
+    """Separate (..., N, 2) position / velocity / acceleration / destination tensors."""
+
     @staticmethod
     def forward(ctx, position, velocity, acceleration, destination, obstacles, heading,
                 focal_begin, focal_count, kp, ko, cos_p, cos_o, dthr_p, dthr_o):
@@ -61,53 +99,79 @@ class _RelativeFeatures(torch.autograd.Function):
         if not (p.shape == v.shape == a.shape == d.shape) or p.shape[-1] != 2 or p.dim() < 2:
             raise ValueError(f'position/velocity/acceleration/destination must share a (..., N, 2) shape, got '
                              f'{tuple(p.shape)} {tuple(v.shape)} {tuple(a.shape)} {tuple(d.shape)}')
-        N, M = p.shape[-2], o.shape[0]
-        lead = p.shape[:-2]
+        N = p.shape[-2]
+        lead = tuple(p.shape[:-2])
         C = p.numel() // max(N * 2, 1)
         if focal_count is None:
             focal_begin, focal_count = 0, N
-        kpe, koe = min(kp, N), min(ko, M)
         hd = None if heading is None else _gpu_f32('heading', heading)
-        ped_feat = torch.empty(*lead, focal_count, kpe, 6, device=p.device, dtype=torch.float32)
-        obs_feat = torch.empty(*lead, focal_count, koe, 6, device=p.device, dtype=torch.float32)
-        dest_feat = torch.empty(*lead, focal_count, 2, device=p.device, dtype=torch.float32)
-        ped_idx = torch.empty(*lead, focal_count, kpe, device=p.device, dtype=torch.int32)
-        obs_idx = torch.empty(*lead, focal_count, koe, device=p.device, dtype=torch.int32)
-        with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().piml_relfeat_fwd(
-                _ptr(p), _ptr(hd), _ptr(v), _ptr(a), _ptr(d), _ptr(o), C, N, M, focal_begin, focal_count,
-                kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat),
-                _ptr(ped_idx), _ptr(obs_idx), _stream()), 'piml_relfeat_fwd')
-        ctx.save_for_backward(ped_idx, obs_idx, p, d)
-        ctx.geom = (C, N, focal_begin, focal_count, kpe, koe, tuple(p.shape))
-        ctx.mark_non_differentiable(ped_idx, obs_idx)
-        return ped_feat, obs_feat, dest_feat, ped_idx, obs_idx
+        d_rows = d if focal_count == N else d[..., focal_begin:focal_begin + focal_count, :].contiguous()
+        out = _launch_relfeat_fwd(_ptr(p), _ptr(v), _ptr(a), 2, hd, d_rows, o, lead, C, N, focal_begin,
+                                  focal_count, kp, ko, cos_p, cos_o, dthr_p, dthr_o, p.device)
+        ctx.save_for_backward(out[3], out[4], p, d_rows)
+        ctx.geom = (C, N, focal_begin, focal_count, out[3].shape[-1], out[4].shape[-1], lead)
+        ctx.mark_non_differentiable(out[3], out[4])
+        return out
 
     @staticmethod
     def backward(ctx, g_ped, g_obs, g_dest, _gi, _go):
-        ped_idx, obs_idx, p, d = ctx.saved_tensors
-        C, N, f0, fcnt, kpe, koe, shape = ctx.geom
-        lead = shape[:-2]
-
-        def dense(g, like_shape):
-            return torch.zeros(like_shape, device=p.device, dtype=torch.float32) if g is None \
-                else _gpu_f32('grad', g)
-        g_ped = dense(g_ped, (*lead, fcnt, kpe, 6))
-        g_obs = dense(g_obs, (*lead, fcnt, koe, 6))
-        g_dest = dense(g_dest, (*lead, fcnt, 2))
-        g_state = torch.zeros(*lead, N, 6, device=p.device, dtype=torch.float32)
-        g_d_rows = torch.empty(*lead, fcnt, 2, device=p.device, dtype=torch.float32)
-        with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().piml_relfeat_bwd(
-                _ptr(g_ped), _ptr(g_obs), _ptr(g_dest), _ptr(ped_idx), _ptr(obs_idx), _ptr(p), _ptr(d),
-                C, N, f0, fcnt, kpe, koe, _ptr(g_state), _ptr(g_d_rows), _stream()), 'piml_relfeat_bwd')
+        ped_idx, obs_idx, p, d_rows = ctx.saved_tensors
+        C, N, f0, fcnt, kpe, koe, lead = ctx.geom
+        g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx,
+                                                _ptr(p), 2, d_rows, p.device)
         if fcnt == N:
             g_destination = g_d_rows
         else:
-            g_destination = torch.zeros(shape, device=p.device, dtype=torch.float32)
+            g_destination = torch.zeros(*lead, N, 2, device=p.device, dtype=torch.float32)
             g_destination[..., f0:f0 + fcnt, :] = g_d_rows
-        return (g_state[..., 0:2], g_state[..., 2:4], g_state[..., 4:6], g_destination,
-                None, None, None, None, None, None, None, None, None, None)
+        return (g_state[..., 0:2], g_state[..., 2:4], g_state[..., 4:6], g_destination) + (None,) * 10
+
+
+class _RelativeFeaturesPacked(torch.autograd.Function):
+    """Interleaved (..., N, 6) = (p, v, a) state records (the all-gathered buffer of
+    agent-block sharding) + destinations of the focal rows only."""
+
+    @staticmethod
+    def forward(ctx, state, destination_rows, obstacles, focal_begin, focal_count, kp, ko,
+                cos_p, cos_o, dthr_p, dthr_o):
+        s = _gpu_f32('state', state)
+        d_rows = _gpu_f32('destination_rows', destination_rows)
+        o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
+        if s.shape[-1] != 6 or s.dim() < 2:
+            raise ValueError(f'state must be (..., N, 6), got {tuple(s.shape)}')
+        N = s.shape[-2]
+        lead = tuple(s.shape[:-2])
+        if tuple(d_rows.shape) != (*lead, focal_count, 2):
+            raise ValueError(f'destination_rows must be {(*lead, focal_count, 2)}, got {tuple(d_rows.shape)}')
+        C = s.numel() // max(N * 6, 1)
+        base = s.data_ptr()
+        out = _launch_relfeat_fwd(base, base + 8, base + 16, 6, None, d_rows, o, lead, C, N, focal_begin,
+                                  focal_count, kp, ko, cos_p, cos_o, dthr_p, dthr_o, s.device)
+        ctx.save_for_backward(out[3], out[4], s, d_rows)
+        ctx.geom = (C, N, focal_begin, focal_count, out[3].shape[-1], out[4].shape[-1], lead)
+        ctx.mark_non_differentiable(out[3], out[4])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_ped, g_obs, g_dest, _gi, _go):
+        ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
+        g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx,
+                                                s.data_ptr(), 6, d_rows, s.device)
+        return (g_state, g_d_rows) + (None,) * 9
+
+
+def relative_features_packed(state, destination_rows, obstacles, focal_begin, focal_count,
+                             topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                             topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, return_index=False):
+    """relative_features for an interleaved (..., N, 6) state buffer; the gradient w.r.t.
+    `state` covers all N sources (a rank's partial sum under agent-block sharding)."""
+    if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
+        raise ValueError(f'topk must be <= {MAX_TOPK}')
+    out = _RelativeFeaturesPacked.apply(state, destination_rows, obstacles, int(focal_begin), int(focal_count),
+                                        int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped),
+                                        cos_threshold(sight_angle_obs), float(dist_threshold_ped),
+                                        float(dist_threshold_obs))
+    return out if return_index else out[:3]
 
 
 def relative_features(position, velocity, acceleration, destination, obstacles,

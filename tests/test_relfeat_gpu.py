@@ -131,3 +131,27 @@ def test_selection_arithmetic_is_bit_exact():
         c = ((r[:, 0] / n1) * (h[:, 0] / n2)).astype(f32) + ((r[:, 1] / n1) * (h[:, 1] / n2)).astype(f32)
     assert np.array_equal(bits(dist.cpu().numpy()), bits(d))
     assert np.array_equal(bits(cosv.cpu().numpy()), bits(c.astype(f32)))
+
+
+def test_relfeat_packed_state_equals_separate(oracle):
+    """Interleaved (N,6) records + focal-row destinations (the sharded layout) give the same
+    features and gradients as three separate arrays."""
+    from piml_amd import ops
+    sc = synthetic_gc_scene(700, 300, seed=13)
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal((700, 2)) * 0.3).astype(np.float32)
+    p, v, a_, d = [dev(x).requires_grad_(True) for x in (sc['position'], sc['velocity'], a, sc['destination'])]
+    obs = dev(sc['obstacles'])
+    f0, fc = 200, 300
+    ref = ops.relative_features(p, v, a_, d, obs, focal_begin=f0, focal_count=fc, return_index=True)
+    state = torch.cat((p, v, a_), dim=-1).detach().requires_grad_(True)
+    drow = d[f0:f0 + fc].detach().requires_grad_(True)
+    out = ops.relative_features_packed(state, drow, obs, f0, fc, return_index=True)
+    for x, y in zip(out, ref):
+        assert torch.equal(x, y)
+    w = [torch.randn_like(t) for t in out[:3]]
+    sum((x * y).sum() for x, y in zip(out[:3], w)).backward()
+    sum((x * y).sum() for x, y in zip(ref[:3], w)).backward()
+    want = torch.cat((p.grad, v.grad, a_.grad), dim=-1)
+    assert (state.grad - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
+    assert (drow.grad - d.grad[f0:f0 + fc]).abs().max() <= 1e-6
