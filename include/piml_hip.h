@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 2
+#define PIML_HIP_ABI_VERSION 3
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -100,6 +100,71 @@ int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const flo
                      const int32_t* ped_idx, const int32_t* obs_idx, const float* position,
                      int state_ld, const float* destination, int C, int N, int focal_begin, int focal_count,
                      int kp_eff, int ko_eff, float* g_state, float* g_destination, void* stream);
+
+/*
+ * Closed-form social-force step.  Replaces MLAPM.step (src/models/mlapm.py:10-58).
+ *   position, velocity, destination (N, 2); desired_speed (N); variant 0 = 'raw', 1 = 'GC',
+ *   2 = 'UCY' (with the one-line coll.unsqueeze(-1) fix the shipped code needs for N > 2);
+ *   tau, A, B, C, D, theta_deg = self.args[...]; radius, dt = step() arguments.
+ * Outputs: action (N, 2) = velocity + force * dt; force (N, 2) optional (NULL to skip).
+ * Like the reference, a NaN position poisons every row: filter absent agents first
+ * (src/main_mlapm.py:19-25 does).
+ */
+int piml_mlapm_step_fwd(const float* position, const float* velocity, const float* desired_speed,
+                        const float* destination, int N, int variant, float tau, float A, float B,
+                        float C, float D, float theta_deg, float radius, float dt, float* action,
+                        float* force, void* stream);
+
+/*
+ * Analytic gradient of piml_mlapm_step_fwd (what autograd gives through mlapm.py:10-58):
+ * g_action (N, 2) -> g_position, g_velocity, g_destination (N, 2), g_desired_speed (N), all
+ * overwritten.  view / rotation sign / collision flags are piecewise constant (no gradient).
+ * No atomics: every pair is evaluated in both roles by the owning wavefront.
+ */
+int piml_mlapm_step_bwd(const float* g_action, const float* position, const float* velocity,
+                        const float* desired_speed, const float* destination, int N, int variant,
+                        float tau, float A, float B, float C, float D, float theta_deg, float radius,
+                        float dt, float* g_position, float* g_velocity, float* g_desired_speed,
+                        float* g_destination, void* stream);
+
+/*
+ * Collision matrix, pair part of Pedestrians.collision_detection (src/data/data.py:549-564):
+ * coll (S, N, N) = [|p_j - p_i| < threshold] (- I when minus_identity), NaN -> 0; S slices.
+ * With minus_identity = 0 it is the `real_position` matrix of data.py:576-581.
+ */
+int piml_collision_matrix(const float* position, int S, int N, float threshold, int minus_identity,
+                          float* coll, void* stream);
+
+/*
+ * "Friends" filter of collision_detection, in place on coll (C, T, N, N):
+ *   base != NULL : 3-D rule (data.py:573-591), C must be 1: pairs whose `base` (S_base, N, N)
+ *                  sum over slices exceeds 25 are zeroed in all T slices (base may be coll);
+ *   base == NULL : 4-D rule (data.py:592-598): per channel, pairs colliding in any of the first
+ *                  4 frames are zeroed in every frame.
+ */
+int piml_collision_friends(float* coll, const float* base, int C, int T, int S_base, int N, void* stream);
+
+/*
+ * Fused collision_detection(position (S,N,2), thr_h).sum(-1) for n_thresholds thresholds
+ * (device array) with the 3-D friends rule, without materialising (S,N,N):
+ * counts (n_thresholds, S, N), overwritten.  Callers: src/models/simulators.py:708-724,
+ * src/functions/metrics.py:16-26.
+ */
+int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
+                          float* counts, void* stream);
+
+/*
+ * Pedestrians.calculate_collision_label (src/data/data.py:514-535): rows of >= 4 floats
+ * (dp, dv, ...), `row_stride` floats apart -> label[rows] in {0, 1}.
+ */
+int piml_collision_label(const float* ped_features, size_t rows, int row_stride, float* label, void* stream);
+
+/*
+ * utils.calc_acceleration (src/utils/utils.py:31-100): version 0/1/2 = 'v0'/'v1'/'v2' with the
+ * caller-supplied constants (A, B, C, D, theta [rad]); rows of >= 2 floats -> acc (rows, 2).
+ */
+int piml_calc_acceleration(const float* relative_data, size_t rows, int row_stride, int version, float A,
+                           float B, float C, float D, float theta, float eps, float* acc, void* stream);
 
 /*
  * Diagnostic (tests only): evaluates, per element, the exact float32 arithmetic of the

@@ -10,11 +10,11 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
-_i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_i, _f, _p, _z = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -22,6 +22,13 @@ SIGNATURES = {
     'piml_heading_fwd': [_p, _i, _i, _i, _p, _p],
     'piml_relfeat_fwd': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                          _p, _p, _p, _p, _p, _p],
+    'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p],
+    'piml_mlapm_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p],
+    'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
+    'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],
+    'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
+    'piml_collision_label': [_p, _z, _i, _p, _p],
+    'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }

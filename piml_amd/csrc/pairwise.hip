@@ -1,0 +1,426 @@
+// Closed-form social force (MLAPM.step) forward + analytic backward, collision matrices and
+// the small per-neighbour physics labels, for gfx950.
+//
+// MLAPM (reference src/models/mlapm.py:10-58) materialises (N,N,2) x 3-5 and an (N,N,2,2)
+// rotation tensor; here one 64-lane wavefront owns one focal agent, every agent's
+// (p, v[, e, G]) record is staged once per workgroup into an LDS tile, lanes stream the
+// sources and the per-agent force is a wave reduction.  No MFMA: there is no contraction.
+#include "common.hpp"
+#include "../../include/piml_hip.h"
+
+#include <cmath>
+
+namespace piml {
+
+constexpr int kMlTile = 2048;   // agents per LDS tile (fwd 32 KiB, bwd 64 KiB)
+
+struct MlapmParams {
+    int variant;                 // 0 raw, 1 GC, 2 UCY (mlapm.py:28-53)
+    float tau, A, B, Cc, D, cth, sth, r2;   // cos/sin of theta, 2*radius
+};
+
+// One ordered pair: focal (vix, viy, ex, ey) at the origin, source at (rx, ry) with
+// relative velocity (wx, wy).  Returns view * A * g * direction (mlapm.py:25-53).
+__device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, float ry, float wx, float wy,
+                                             float vix, float viy, float ex, float ey) {
+    const float r = norm2(rx, ry);                                  // :26
+    const float view = (vix * rx + viy * ry > 0.f) ? 1.f : 0.f;     // :27
+    const float rn = fmaxf(r, 1e-12f);                              // F.normalize eps
+    const float nx = rx / rn, ny = ry / rn;
+    float g, dx, dy;
+    if (P.variant == 0) {
+        g = expf(P.B * r);                                          // :29
+        dx = nx; dy = ny;
+    } else {
+        const float cr = rx * ey - ry * ex;                         // :34 / :48
+        // theta = -sign(cr) * theta, 0 -> +theta; sign(NaN) = NaN propagates like the reference
+        const float st = cr > 0.f ? -P.sth : (cr <= 0.f ? P.sth : cr);
+        dx = P.cth * nx - st * ny; dy = st * nx + P.cth * ny;       // :36-39
+        if (P.variant == 1) {
+            const float wn = norm2(wx, wy);
+            const float cs = (rx / fmaxf(r, 1e-8f)) * (wx / fmaxf(wn, 1e-8f)) +
+                             (ry / fmaxf(r, 1e-8f)) * (wy / fmaxf(wn, 1e-8f));    // :32
+            g = expf(P.B * r + P.Cc * cs + P.D * r * cs);           // :40
+        } else {
+            bool coll = r < P.r2;                                   // :43
+            coll |= norm2(rx + wx, ry + wy) < P.r2;                 // :44
+            const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy, rr = rx * rx + ry * ry;
+            const float tmin = -rw / ww;                            // :45
+            const float dmin = sqrtf(rr - rw * rw / ww);            // :46
+            coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin < P.r2);  // :47
+            const float cf = coll ? 1.f : 0.f;
+            g = expf(P.B * r * cf + P.Cc * cf);                     // :53 (with coll.unsqueeze(-1), Q8)
+        }
+    }
+    const float s = view * P.A * g;
+    return make_float2(s * dx, s * dy);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
+        const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
+        const float2* __restrict__ dest, int N, MlapmParams P, float dt, float2* __restrict__ action,
+        float2* __restrict__ force) {
+    __shared__ float4 tile[kMlTile];                        // (px, py, vx, vy)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * WAVES + wave;
+    const bool has = i < N;
+    const float2 pi = p[has ? i : 0], vi = v[has ? i : 0], di = dest[has ? i : 0];
+    float ex = di.x - pi.x, ey = di.y - pi.y;
+    const float en = fmaxf(norm2(ex, ey), 1e-12f);          // :21
+    ex /= en; ey /= en;
+    float sx = 0.f, sy = 0.f;
+    for (int base = 0; base < N; base += kMlTile) {
+        const int tn = min(kMlTile, N - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn; t += WAVES * 64) {
+            const float2 a = p[base + t], b = v[base + t];
+            tile[t] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();
+        if (!has) continue;
+        for (int j = lane; j < tn; j += 64) {
+            const float4 s = tile[j];
+            const float2 t = mlapm_pair(P, s.x - pi.x, s.y - pi.y, s.z - vi.x, s.w - vi.y, vi.x, vi.y, ex, ey);
+            sx += t.x; sy += t.y;
+        }
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy);
+    if (has && lane == 0) {
+        const float v0i = v0[i];
+        const float fx = (v0i * ex - vi.x) / P.tau - sx;    // :22, :29/:40/:53
+        const float fy = (v0i * ey - vi.y) / P.tau - sy;
+        if (force) force[i] = make_float2(fx, fy);
+        action[i] = make_float2(vi.x + fx * dt, vi.y + fy * dt);   // :57
+    }
+}
+
+// d(-G . T)/d(vr), d(-G . T)/d(vv) of one ordered pair, T the pair term of mlapm_pair and
+// (Gx, Gy) the upstream gradient on the focal agent's force.  view, the rotation sign and the
+// UCY collision flag are piecewise constant and carry no gradient (as in autograd).
+__device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, float ry, float wx, float wy,
+                                                float vix, float viy, float ex, float ey, float Gx, float Gy,
+                                                float& ax, float& ay, float& bx, float& by) {
+    ax = ay = bx = by = 0.f;
+    const float r = norm2(rx, ry);
+    if (!(r > 0.f) || !(vix * rx + viy * ry > 0.f)) return;
+    const float rn = fmaxf(r, 1e-12f);
+    const float nx = rx / rn, ny = ry / rn;
+    float st = 0.f, ct = 1.f;
+    if (P.variant != 0) {
+        const float cr = rx * ey - ry * ex;
+        st = cr > 0.f ? -P.sth : P.sth; ct = P.cth;
+    }
+    const float ux = ct * Gx + st * Gy, uy = -st * Gx + ct * Gy;   // R^T G
+    const float un = ux * nx + uy * ny;
+    float phi, fx, fy, hx = 0.f, hy = 0.f;                         // d(phi)/d(vr), d(phi)/d(vv)
+    if (P.variant == 0) {
+        phi = P.B * r; fx = P.B * nx; fy = P.B * ny;
+    } else if (P.variant == 1) {
+        const float q = norm2(wx, wy);
+        const float rc = fmaxf(r, 1e-8f), qc = fmaxf(q, 1e-8f);
+        const float n8x = rx / rc, n8y = ry / rc, mx = wx / qc, my = wy / qc;
+        const float cs = n8x * mx + n8y * my;
+        phi = P.B * r + P.Cc * cs + P.D * r * cs;
+        const float k1 = P.Cc + P.D * r;
+        const float csx = r > 1e-8f ? (mx - cs * n8x) / rc : mx / rc;   // d(cs)/d(vr)
+        const float csy = r > 1e-8f ? (my - cs * n8y) / rc : my / rc;
+        fx = P.B * nx + k1 * csx + P.D * cs * nx;
+        fy = P.B * ny + k1 * csy + P.D * cs * ny;
+        const float cwx = q > 1e-8f ? (n8x - cs * mx) / q : n8x / qc;   // d(cs)/d(vv)
+        const float cwy = q > 1e-8f ? (n8y - cs * my) / q : n8y / qc;
+        hx = k1 * cwx; hy = k1 * cwy;
+    } else {
+        bool coll = r < P.r2;
+        coll |= norm2(rx + wx, ry + wy) < P.r2;
+        const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy, rr = rx * rx + ry * ry;
+        const float tmin = -rw / ww;
+        const float dmin = sqrtf(rr - rw * rw / ww);
+        coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin < P.r2);
+        const float cf = coll ? 1.f : 0.f;
+        phi = (P.B * r + P.Cc) * cf; fx = P.B * cf * nx; fy = P.B * cf * ny;
+    }
+    const float AE = -P.A * expf(phi);
+    ax = AE * (un * fx + (ux - un * nx) / rn);
+    ay = AE * (un * fy + (uy - un * ny) / rn);
+    bx = AE * un * hx;
+    by = AE * un * hy;
+}
+
+// Backward: one wavefront per agent x accumulates BOTH its focal-side sums (-a_xo, -b_xo) and
+// its source-side sums (+a_ox, +b_ox) by evaluating every pair in both roles, so no atomics
+// and a fixed summation order (bitwise reproducible).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_kernel(
+        const float2* __restrict__ g_action, const float2* __restrict__ p, const float2* __restrict__ v,
+        const float* __restrict__ v0, const float2* __restrict__ dest, int N, MlapmParams P, float dt,
+        float2* __restrict__ g_p, float2* __restrict__ g_v, float* __restrict__ g_v0,
+        float2* __restrict__ g_dest) {
+    __shared__ float4 tile_pv[kMlTile];                     // (px, py, vx, vy)
+    __shared__ float4 tile_eg[kMlTile];                     // (ex, ey, Gx, Gy), G = dt * g_action
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * WAVES + wave;
+    const bool has = x < N;
+    const float2 px = p[has ? x : 0], vx = v[has ? x : 0], dx = dest[has ? x : 0], ga = g_action[has ? x : 0];
+    float ex = dx.x - px.x, ey = dx.y - px.y;
+    const float dn = norm2(ex, ey), en = fmaxf(dn, 1e-12f);
+    ex /= en; ey /= en;
+    const float Gx = ga.x * dt, Gy = ga.y * dt;
+    float spx = 0.f, spy = 0.f, svx = 0.f, svy = 0.f;
+    for (int base = 0; base < N; base += kMlTile) {
+        const int tn = min(kMlTile, N - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn; t += WAVES * 64) {
+            const float2 a = p[base + t], b = v[base + t], d = dest[base + t], g = g_action[base + t];
+            float qx = d.x - a.x, qy = d.y - a.y;
+            const float qn = fmaxf(norm2(qx, qy), 1e-12f);
+            tile_pv[t] = make_float4(a.x, a.y, b.x, b.y);
+            tile_eg[t] = make_float4(qx / qn, qy / qn, g.x * dt, g.y * dt);
+        }
+        __syncthreads();
+        if (!has) continue;
+        for (int j = lane; j < tn; j += 64) {
+            const float4 s = tile_pv[j], t = tile_eg[j];
+            float ax, ay, bx, by;
+            // x focal, o source
+            mlapm_pair_grad(P, s.x - px.x, s.y - px.y, s.z - vx.x, s.w - vx.y, vx.x, vx.y, ex, ey, Gx, Gy,
+                            ax, ay, bx, by);
+            spx -= ax; spy -= ay; svx -= bx; svy -= by;
+            // o focal, x source
+            mlapm_pair_grad(P, px.x - s.x, px.y - s.y, vx.x - s.z, vx.y - s.w, s.z, s.w, t.x, t.y, t.z, t.w,
+                            ax, ay, bx, by);
+            spx += ax; spy += ay; svx += bx; svy += by;
+        }
+    }
+    spx = wave_sum(spx); spy = wave_sum(spy); svx = wave_sum(svx); svy = wave_sum(svy);
+    if (has && lane == 0) {
+        // desired force (v0 e - v)/tau, e = d/|d| (mlapm.py:21-22), and action = v + F dt (:57)
+        const float v0x = v0[x];
+        const float ge = Gx * ex + Gy * ey;
+        g_v0[x] = ge / P.tau;
+        float tdx = 0.f, tdy = 0.f;
+        if (dn > 1e-12f) {
+            tdx = v0x / P.tau * (Gx - ge * ex) / dn;
+            tdy = v0x / P.tau * (Gy - ge * ey) / dn;
+        } else {
+            tdx = v0x / P.tau * Gx / 1e-12f; tdy = v0x / P.tau * Gy / 1e-12f;
+        }
+        g_dest[x] = make_float2(tdx, tdy);
+        g_p[x] = make_float2(spx - tdx, spy - tdy);
+        g_v[x] = make_float2(svx + ga.x - Gx / P.tau, svy + ga.y - Gy / P.tau);
+    }
+}
+
+// ---- collision matrices (data.py:537-601) ----
+// coll[s,i,j] = [|p_j - p_i| < thr] (- 1 on the diagonal when `minus_identity`), NaN -> 0.
+__global__ void collision_pairs_kernel(const float2* __restrict__ p, int S, int N, float thr,
+                                       int minus_identity, float* __restrict__ coll) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, s = blockIdx.z;
+    if (j >= N) return;
+    const float2 pi = p[(size_t)s * N + i], pj = p[(size_t)s * N + j];
+    const float d = norm2(pj.x - pi.x, pj.y - pi.y);
+    float c = d != d ? d : (d < thr ? 1.f : 0.f);          // NaN stays NaN until the final NaN -> 0
+    if (minus_identity && i == j) c -= 1.f;
+    coll[((size_t)s * N + i) * N + j] = c != c ? 0.f : c;
+}
+
+// 3-D friends rule (data.py:573-591): pairs whose `base` sum over the leading dim exceeds 25
+// are zeroed in every slice of `coll`.
+__global__ void collision_friends3_kernel(float* __restrict__ coll, const float* __restrict__ base,
+                                          int S_coll, int S_base, size_t NN) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= NN) return;
+    float sum = 0.f;
+    for (int s = 0; s < S_base; ++s) sum += base[(size_t)s * NN + q];
+    if (!(sum <= 25.f))
+        for (int s = 0; s < S_coll; ++s) coll[(size_t)s * NN + q] = 0.f;
+}
+
+// 4-D friends rule (data.py:592-598): pairs colliding in any of the first 4 frames of a channel
+// are dropped for every frame of that channel.
+__global__ void collision_friends4_kernel(float* __restrict__ coll, int C, int T, size_t NN) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (q >= NN) return;
+    float sum = 0.f;
+    for (int t = 0; t < min(T, 4); ++t) sum += coll[((size_t)c * T + t) * NN + q];
+    if (sum > 0.f)
+        for (int t = 0; t < T; ++t) coll[((size_t)c * T + t) * NN + q] = 0.f;
+}
+
+// Fused per-agent collision counts for a 3-D stack (S, N, 2): counts[h, s, i] =
+// sum_j coll_h[s,i,j] * friends_h[i,j] for `nthr` thresholds, i.e.
+// collision_detection(position, thr_h).sum(-1) without the (S,N,N) matrices (callers:
+// simulators.py:708-724, metrics.py:16-26).  One wavefront per agent i, lane = j; the friends
+// total over all slices is taken first, then the per-slice counts (pairs are recomputed, not
+// stored).
+__device__ __forceinline__ bool collide(const float2* __restrict__ p, int N, int s, int i, int j, float th) {
+    if (j >= N || i == j) return false;                    // diagonal: 1 - 1 = 0 (or NaN -> 0)
+    const float2 pi = p[(size_t)s * N + i], pj = p[(size_t)s * N + j];
+    return norm2(pj.x - pi.x, pj.y - pi.y) < th;           // NaN compares false -> 0
+}
+
+__global__ __launch_bounds__(256) void collision_counts_kernel(const float2* __restrict__ p, int S, int N,
+                                                               const float* __restrict__ thr, int nthr,
+                                                               float* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    for (int h = 0; h < nthr; ++h) {
+        const float th = thr[h];
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int j = j0 + lane;
+            int total = 0;
+            for (int s = 0; s < S; ++s) total += collide(p, N, s, i, j, th) ? 1 : 0;
+            if (__builtin_amdgcn_ballot_w64(total > 0) == 0) continue;
+            const bool keep = total <= 25;                  // friends rule, data.py:587-591
+            for (int s = 0; s < S; ++s) {
+                const u64 m = __builtin_amdgcn_ballot_w64(keep && collide(p, N, s, i, j, th));
+                if (m && lane == 0) counts[((size_t)h * S + s) * N + i] += (float)__builtin_popcountll(m);
+            }
+        }
+    }
+}
+
+// calculate_collision_label (data.py:514-535): any tau in {0,.1,...,.9} with 0 != |dp + dv tau| < 0.5
+__global__ void collision_label_kernel(const float* __restrict__ feat, size_t R, int ld, float* __restrict__ label) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* f = feat + r * ld;
+    const float px = f[0], py = f[1], vx = f[2], vy = f[3];
+    float hit = 0.f;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const float tau = __fmul_rn((float)t, 0.1f);        // torch.arange(10) * 0.1 in float32
+        const float d = norm2(__fadd_rn(px, __fmul_rn(vx, tau)), __fadd_rn(py, __fmul_rn(vy, tau)));
+        if (d < 0.5f && d != 0.f) hit = 1.f;
+    }
+    label[r] = hit;
+}
+
+// calc_acceleration (utils.py:31-100); version 0/1/2 = 'v0'/'v1'/'v2' incl. quirk Q10
+__global__ void calc_acceleration_kernel(const float* __restrict__ rel, size_t R, int ld, int version, float A,
+                                         float B, float Cc, float D, float ct, float st, float eps,
+                                         float2* __restrict__ acc) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= R) return;
+    const float dx = rel[q * ld], dy = rel[q * ld + 1];
+    const float r = norm2(dx, dy) + eps;                    // utils.py:54-55
+    const float ux = dx / r, uy = dy / r;
+    float g, bx = ux, by = uy;
+    if (version == 0) {
+        g = A * expf(B * r);
+    } else {
+        const float vn = norm2(dx, dy) + eps;               // dv is read from the position slice (Q10)
+        const float cs = (dx * dx + dy * dy) / r / vn;
+        g = A * expf(B * r + Cc * cs + D * r * cs);
+        if (version == 2) { bx = ct * ux - st * uy; by = st * ux + ct * uy; }
+    }
+    acc[q] = make_float2(-g * bx, -g * by);
+}
+
+static MlapmParams make_params(int variant, float tau, float A, float B, float Cc, float D, float theta_deg,
+                               float radius) {
+    MlapmParams P;
+    P.variant = variant; P.tau = tau; P.A = A; P.B = B; P.Cc = Cc; P.D = D;
+    // the reference forms theta = sign * theta / 180 * pi in float32 (mlapm.py:34)
+    const float th = theta_deg / 180.f * 3.14159265358979323846f;
+    P.cth = cosf(th); P.sth = sinf(th);
+    P.r2 = radius * 2.f;
+    return P;
+}
+
+}  // namespace piml
+
+using namespace piml;
+
+PIML_API int piml_mlapm_step_fwd(const float* position, const float* velocity, const float* desired_speed,
+                                 const float* destination, int N, int variant, float tau, float A, float B,
+                                 float C, float D, float theta_deg, float radius, float dt, float* action,
+                                 float* force, void* stream) {
+    if (N < 0 || variant < 0 || variant > 2) return hipErrorInvalidValue;
+    if (N == 0) return hipSuccess;
+    if (!position || !velocity || !desired_speed || !destination || !action) return hipErrorInvalidValue;
+    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
+    hipLaunchKernelGGL(mlapm_fwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
+                       (const float2*)position, (const float2*)velocity, desired_speed, (const float2*)destination,
+                       N, P, dt, (float2*)action, (float2*)force);
+    return hipGetLastError();
+}
+
+PIML_API int piml_mlapm_step_bwd(const float* g_action, const float* position, const float* velocity,
+                                 const float* desired_speed, const float* destination, int N, int variant,
+                                 float tau, float A, float B, float C, float D, float theta_deg, float radius,
+                                 float dt, float* g_position, float* g_velocity, float* g_desired_speed,
+                                 float* g_destination, void* stream) {
+    if (N < 0 || variant < 0 || variant > 2) return hipErrorInvalidValue;
+    if (N == 0) return hipSuccess;
+    if (!g_action || !position || !velocity || !desired_speed || !destination || !g_position || !g_velocity ||
+        !g_desired_speed || !g_destination)
+        return hipErrorInvalidValue;
+    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
+    hipLaunchKernelGGL(mlapm_bwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
+                       (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
+                       (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
+                       g_desired_speed, (float2*)g_destination);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_matrix(const float* position, int S, int N, float threshold, int minus_identity,
+                                   float* coll, void* stream) {
+    if (S < 0 || N < 0 || N > 65535 || S > 65535) return hipErrorInvalidValue;
+    if ((long)S * N == 0) return hipSuccess;
+    if (!position || !coll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(collision_pairs_kernel, dim3((N + 255) / 256, N, S), dim3(256), 0, as_stream(stream),
+                       (const float2*)position, S, N, threshold, minus_identity, coll);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_friends(float* coll, const float* base, int C, int T, int S_base, int N, void* stream) {
+    if (C < 0 || T < 0 || N < 0 || S_base < 0 || C > 65535) return hipErrorInvalidValue;
+    const size_t NN = (size_t)N * N;
+    if ((size_t)C * T * NN == 0) return hipSuccess;
+    if (!coll) return hipErrorInvalidValue;
+    const unsigned gx = (unsigned)((NN + 255) / 256);
+    if (C == 0 || T == 0) return hipSuccess;
+    if (base) {   // 3-D rule: C == 1, T slices of coll; base has S_base slices
+        hipLaunchKernelGGL(collision_friends3_kernel, dim3(gx), dim3(256), 0, as_stream(stream), coll, base, T,
+                           S_base, NN);
+    } else {      // 4-D rule per channel
+        hipLaunchKernelGGL(collision_friends4_kernel, dim3(gx, C), dim3(256), 0, as_stream(stream), coll, C, T, NN);
+    }
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
+                                   float* counts, void* stream) {
+    if (S < 0 || N < 0 || n_thresholds < 0) return hipErrorInvalidValue;
+    if ((long)S * N * n_thresholds == 0) return hipSuccess;
+    if (!position || !thresholds || !counts) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)n_thresholds * S * N, as_stream(stream));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(collision_counts_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
+                       (const float2*)position, S, N, thresholds, n_thresholds, counts);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_label(const float* ped_features, size_t rows, int row_stride, float* label, void* stream) {
+    if (row_stride < 4) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!ped_features || !label) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(collision_label_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       ped_features, rows, row_stride, label);
+    return hipGetLastError();
+}
+
+PIML_API int piml_calc_acceleration(const float* relative_data, size_t rows, int row_stride, int version, float A,
+                                    float B, float C, float D, float theta, float eps, float* acc, void* stream) {
+    if (row_stride < 2 || version < 0 || version > 2) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!relative_data || !acc) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(calc_acceleration_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), relative_data, rows, row_stride, version, A, B, C, D,
+                       (float)cos((double)theta), (float)sin((double)theta), eps, (float2*)acc);
+    return hipGetLastError();
+}

@@ -193,3 +193,148 @@ def relative_features(position, velocity, acceleration, destination, obstacles,
                                   cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
                                   float(dist_threshold_ped), float(dist_threshold_obs))
     return out if return_index else out[:3]
+
+
+# ------------------------------------------------------------------------------------------
+# closed-form social force (MLAPM.step)
+# ------------------------------------------------------------------------------------------
+MLAPM_VARIANTS = {'raw': 0, 'GC': 1, 'UCY': 2}
+
+
+class _MlapmStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, velocity, desired_speed, destination, variant, tau, A, B, C, D, theta,
+                radius, dt):
+        p = _gpu_f32('position', position)
+        v = _gpu_f32('velocity', velocity)
+        d = _gpu_f32('destination', destination)
+        v0 = _gpu_f32('desired_speed', desired_speed)
+        if p.dim() != 2 or p.shape[-1] != 2 or p.shape != v.shape or p.shape != d.shape:
+            raise ValueError('position / velocity / destination must be (N, 2)')
+        N = p.shape[0]
+        if v0.numel() != N:
+            raise ValueError(f'desired_speed must hold N={N} values, got {tuple(v0.shape)}')
+        action = torch.empty_like(p)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().piml_mlapm_step_fwd(_ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau, A, B,
+                                                      C, D, theta, radius, dt, _ptr(action), None, _stream()),
+                       'piml_mlapm_step_fwd')
+        ctx.save_for_backward(p, v, v0, d)
+        ctx.params = (variant, tau, A, B, C, D, theta, radius, dt)
+        ctx.v0_shape = tuple(desired_speed.shape)
+        return action
+
+    @staticmethod
+    def backward(ctx, g_action):
+        p, v, v0, d = ctx.saved_tensors
+        g = _gpu_f32('g_action', g_action)
+        N = p.shape[0]
+        gp, gv, gd = torch.empty_like(p), torch.empty_like(p), torch.empty_like(p)
+        gv0 = torch.empty(N, device=p.device, dtype=torch.float32)
+        variant, tau, A, B, C, D, theta, radius, dt = ctx.params
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().piml_mlapm_step_bwd(_ptr(g), _ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau,
+                                                      A, B, C, D, theta, radius, dt, _ptr(gp), _ptr(gv), _ptr(gv0),
+                                                      _ptr(gd), _stream()), 'piml_mlapm_step_bwd')
+        return (gp, gv, gv0.reshape(ctx.v0_shape), gd) + (None,) * 9
+
+
+def mlapm_step(position, velocity, desired_speed, destination, dt, radius=0.3, version='GC', tau=0.5,
+               A=0.0, B=0.0, C=0.0, D=0.0, theta=0.0):
+    """MLAPM.step (src/models/mlapm.py:10-58) on the GPU; differentiable (analytic backward)."""
+    if version not in MLAPM_VARIANTS:
+        raise NotImplementedError(version)
+    return _MlapmStep.apply(position, velocity, desired_speed, destination, MLAPM_VARIANTS[version],
+                            float(tau), float(A), float(B), float(C), float(D), float(theta), float(radius),
+                            float(dt))
+
+
+# ------------------------------------------------------------------------------------------
+# collisions (Pedestrians.collision_detection / calculate_collision_label)
+# ------------------------------------------------------------------------------------------
+def collision_matrix(position, threshold, minus_identity=True):
+    """(..., N, 2) -> (..., N, N): [|p_j - p_i| < threshold] (- I), NaN -> 0 (data.py:549-564)."""
+    p = _gpu_f32('position', position)
+    N = p.shape[-2]
+    S = p.numel() // max(N * 2, 1)
+    coll = torch.empty(*p.shape[:-2], N, N, device=p.device, dtype=torch.float32)
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.lib().piml_collision_matrix(_ptr(p), S, N, float(threshold), int(bool(minus_identity)),
+                                                    _ptr(coll), _stream()), 'piml_collision_matrix')
+    return coll
+
+
+def collision_detection(position, threshold, real_position=None):
+    """Pedestrians.collision_detection (data.py:537-601) incl. both "friends" rules."""
+    if position.dim() not in (3, 4):
+        raise ValueError('position must be (t,n,2) / (c,n,2) or (c,t,n,2)')
+    coll = collision_matrix(position.detach(), threshold, True)
+    N = coll.shape[-1]
+    L = _lib.lib()
+    with torch.cuda.device(coll.device):
+        if real_position is not None:
+            assert real_position.dim() == 3, 'Value Error: real_position only supports 3 dimensional inputs (t,n,2)'
+            if position.dim() != 3:
+                raise ValueError('real_position requires a 3-dimensional position')
+            base = collision_matrix(real_position.detach(), threshold, False)
+            _lib.check(L.piml_collision_friends(_ptr(coll), _ptr(base), 1, coll.shape[0], base.shape[0], N,
+                                                _stream()), 'piml_collision_friends')
+        elif position.dim() == 3:
+            _lib.check(L.piml_collision_friends(_ptr(coll), _ptr(coll), 1, coll.shape[0], coll.shape[0], N,
+                                                _stream()), 'piml_collision_friends')
+        else:
+            _lib.check(L.piml_collision_friends(_ptr(coll), None, coll.shape[0], coll.shape[1], 0, N,
+                                                _stream()), 'piml_collision_friends')
+    return coll
+
+
+def collision_counts(position, thresholds):
+    """collision_detection(position (S,N,2), thr).sum(-1) for several thresholds in one sweep,
+    without the (S,N,N) matrices.  Returns (len(thresholds), S, N)."""
+    p = _gpu_f32('position', position.detach())
+    if p.dim() != 3:
+        raise ValueError('position must be (S, N, 2)')
+    S, N = p.shape[0], p.shape[1]
+    thr = torch.tensor([float(t) for t in thresholds], device=p.device, dtype=torch.float32)
+    counts = torch.empty(len(thresholds), S, N, device=p.device, dtype=torch.float32)
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.lib().piml_collision_counts(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(counts),
+                                                    _stream()), 'piml_collision_counts')
+    return counts
+
+
+def collision_label(ped_features):
+    """Pedestrians.calculate_collision_label (data.py:514-535): (..., k, >=4) -> (..., k)."""
+    f = _gpu_f32('ped_features', ped_features.detach())
+    rows = f.numel() // max(f.shape[-1], 1)
+    out = torch.empty(f.shape[:-1], device=f.device, dtype=torch.float32)
+    with torch.cuda.device(f.device):
+        _lib.check(_lib.lib().piml_collision_label(_ptr(f), rows, f.shape[-1], _ptr(out), _stream()),
+                   'piml_collision_label')
+    return out
+
+
+_CALC_ACC = {  # utils.py:44-81: (A, B, C, D, theta)
+    ('v0', 'gc1560'): (8.75, -2.5, 0., 0., 0.), ('v0', 'gc2344'): (8.75, -2.5, 0., 0., 0.),
+    ('v0', 'ucy'): (10.67, -3.33, 0., 0., 0.),
+    ('v1', 'gc1560'): (8.75, -2.5, 0., 0., 0.), ('v1', 'gc2344'): (8.75, -2.5, 0., 0., 0.),
+    ('v1', 'ucy'): (10.67, -3.33, 0., 0., 0.),
+    ('v2', 'gc2344'): (9.00, -2.75, 0.06, -0.3, 10 * 3.1415 / 180),
+}
+
+
+def calc_acceleration(relative_data, equation_version='v0', dataset='gc1560', eps=1e-6):
+    """utils.calc_acceleration (src/utils/utils.py:31-100), forward only (it is a label)."""
+    if (equation_version, dataset) not in _CALC_ACC:
+        raise NotImplementedError((equation_version, dataset))
+    A, B, C, D, th = _CALC_ACC[(equation_version, dataset)]
+    r = _gpu_f32('relative_data', relative_data.detach())
+    if equation_version == 'v2' and r.dim() not in (3, 4):
+        raise ValueError
+    rows = r.numel() // max(r.shape[-1], 1)
+    out = torch.empty(*r.shape[:-1], 2, device=r.device, dtype=torch.float32)
+    with torch.cuda.device(r.device):
+        _lib.check(_lib.lib().piml_calc_acceleration(_ptr(r), rows, r.shape[-1], int(equation_version[1]), A, B, C,
+                                                     D, th, float(eps), _ptr(out), _stream()),
+                   'piml_calc_acceleration')
+    return out

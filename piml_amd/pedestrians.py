@@ -35,3 +35,16 @@ class Pedestrians(object):
             position, velocity, acceleration, destination, obstacles,
             topk_ped, sight_angle_ped, dist_threshold_ped, topk_obs, sight_angle_obs,
             dist_threshold_obs, heading=heading)
+
+    @staticmethod
+    def calculate_collision_label(ped_features):
+        """(..., k, 6) -> (..., k): collides within 1 s at the current relative velocity
+        (data.py:514-535)."""
+        return ops.collision_label(ped_features)
+
+    @staticmethod
+    def collision_detection(position, threshold, real_position=None):
+        """(t,n,2) / (c,n,2) / (c,t,n,2) -> same-rank (..., n, n) 0/1 matrix with the reference's
+        "friends" filters (data.py:537-601, quirk Q7).  Callers that only need per-agent counts
+        should use `ops.collision_counts`, which never builds the matrix."""
+        return ops.collision_detection(position, threshold, real_position)

@@ -1,0 +1,134 @@
+"""GPU parity tests (through the C ABI) of MLAPM.step fwd/bwd, collision detection / counts /
+labels and calc_acceleration against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from piml_amd.scenes import synthetic_gc_scene
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REL = 1e-5      # north-star tolerance on float32 forces
+
+
+def dev(x):
+    return torch.tensor(np.asarray(x), device=DEV)
+
+
+def rel_err(got, ref, floor):
+    return (np.linalg.norm(got - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), floor)).max()
+
+
+def mlapm_model(g, ver):
+    from piml_amd.models.mlapm import MLAPM
+    tau, A, B, C, D, theta = g[f'{ver}_params']
+    return MLAPM(version=ver, tau=tau, A=A, B=B, C=C, D=D, theta=theta)
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC', 'UCY'])
+@pytest.mark.parametrize('N', [7, 64, 1024])
+def test_mlapm_step_matches_reference(ver, N):
+    g = golden('mlapm')
+    k = f'{ver}_N{N}'
+    act = mlapm_model(g, ver).step(dev(g[k + '_p']), dev(g[k + '_v']), dev(g[k + '_v0']), dev(g[k + '_dest']),
+                                   dt=0.08, radius=0.3)
+    assert rel_err(act.cpu().numpy(), g[k + '_action'], 1e-3) < REL
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC', 'UCY'])
+@pytest.mark.parametrize('N', [7, 64, 1024])
+def test_mlapm_backward_matches_reference_autograd(ver, N):
+    g = golden('mlapm')
+    k = f'{ver}_N{N}'
+    p, v, v0, d = [dev(g[k + s]).requires_grad_(True) for s in ('_p', '_v', '_v0', '_dest')]
+    act = mlapm_model(g, ver).step(p, v, v0, d, dt=0.08, radius=0.3)
+    (act * dev(g[k + '_w'])).sum().backward()
+    for got, name in ((p.grad, 'gp'), (v.grad, 'gv'), (v0.grad, 'gv0'), (d.grad, 'gdest')):
+        ref = g[f'{k}_{name}']
+        got = got.cpu().numpy().reshape(ref.shape)
+        # gradients of a sum of ~N terms: tolerance relative to the largest entry
+        assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (name, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC', 'UCY'])
+def test_mlapm_step_matches_oracle_4096(oracle, ver):
+    """BASELINE configs[2]-sized scene against the oracle (double-accumulated pair sums)."""
+    sc = synthetic_gc_scene(4096, 0, seed=3, nan_frac=0.0)
+    pr = dict(raw=dict(tau=0.5, A=7.55, B=-3.0), GC=dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56),
+              UCY=dict(tau=5 / 6, A=10.67, B=-3.33, C=0.5, theta=20))[ver]
+    from piml_amd.models.mlapm import MLAPM
+    act = MLAPM(version=ver, **pr).step(dev(sc['position']), dev(sc['velocity']), dev(sc['desired_speed']),
+                                        dev(sc['destination']), dt=0.08, radius=0.3)
+    ref = oracle.mlapm_step(sc['position'], sc['velocity'], sc['desired_speed'], sc['destination'], 0.08, 0.3,
+                            version=ver, **pr)
+    assert rel_err(act.cpu().numpy(), ref, 1e-3) < REL
+
+
+def test_mlapm_demo_trajectory():
+    """main_mlapm.py:18-36, first 10 of the 200 Euler steps (the system is chaotic later)."""
+    g = golden('mlapm')
+    m = mlapm_model(g, 'GC')
+    p, v = dev(g['GC_N7_p']), dev(g['GC_N7_v'])
+    v0, d = dev(g['GC_N7_v0']), dev(g['GC_N7_dest'])
+    for t in range(10):
+        v = m.step(p, v, v0, d, dt=0.08, radius=0.3)
+        p = p + v * 0.08
+        assert np.abs(p.cpu().numpy() - g['demo_traj'][t + 1]).max() < 1e-4
+
+
+def test_mlapm_nan_poisons_like_reference():
+    from piml_amd.models.mlapm import MLAPM
+    sc = synthetic_gc_scene(64, 0, seed=1, nan_frac=0.0)
+    p = sc['position'].copy()
+    p[5] = np.nan
+    act = MLAPM(version='raw', tau=0.5, A=7.55, B=-3.0).step(dev(p), dev(sc['velocity']), dev(sc['desired_speed']),
+                                                             dev(sc['destination']), dt=0.08)
+    assert torch.isnan(act).all()
+
+
+def test_collision_detection_matches_reference():
+    from piml_amd.pedestrians import Pedestrians as P
+    g = golden('collision_gc')
+    for thr in (0.5, 0.25, 1.5):
+        assert np.array_equal(P.collision_detection(dev(g['p3']), thr).cpu().numpy(), g[f'coll3_thr{thr}'])
+        assert np.array_equal(P.collision_detection(dev(g['pc']), thr).cpu().numpy(), g[f'collc_thr{thr}'])
+    for thr in (0.5, 1.5):
+        assert np.array_equal(P.collision_detection(dev(g['p4']), thr).cpu().numpy(), g[f'coll4_thr{thr}'])
+        got = P.collision_detection(dev(g['p3']) + 0.05, thr, real_position=dev(g['p3']))
+        assert np.array_equal(got.cpu().numpy(), g[f'coll3_real_thr{thr}'])
+    s = golden('collision_syn')
+    for thr in (0.5, 0.25):
+        assert np.array_equal(P.collision_detection(dev(s['pc']), thr).cpu().numpy(), s[f'collc_thr{thr}'])
+
+
+def test_collision_counts_match_matrix_sums():
+    from piml_amd import ops
+    g = golden('collision_gc')
+    for key in ('p3', 'pc'):
+        thr = (0.5, 0.25, 1.5)
+        counts = ops.collision_counts(dev(g[key]), thr).cpu().numpy()
+        tag = 'coll3' if key == 'p3' else 'collc'
+        for h, t in enumerate(thr):
+            assert np.array_equal(counts[h], g[f'{tag}_thr{t}'].sum(-1).astype(np.float32))
+    s = golden('collision_syn')
+    counts = ops.collision_counts(dev(s['pc']), (0.5, 0.25)).cpu().numpy()
+    for h, t in enumerate((0.5, 0.25)):
+        assert np.array_equal(counts[h], s[f'collc_thr{t}'].sum(-1).astype(np.float32))
+
+
+def test_collision_label_matches_reference():
+    from piml_amd.pedestrians import Pedestrians as P
+    g = golden('collision_label')
+    assert np.array_equal(P.calculate_collision_label(dev(g['feat_real'])).cpu().numpy(), g['label_real'])
+    assert np.array_equal(P.calculate_collision_label(dev(g['feat_rnd'])).cpu().numpy(), g['label_rnd'])
+
+
+@pytest.mark.parametrize('ver,ds', [('v0', 'gc1560'), ('v0', 'ucy'), ('v1', 'ucy'), ('v2', 'gc2344')])
+def test_calc_acceleration_matches_reference(ver, ds):
+    from piml_amd.utils.utils import calc_acceleration
+    g = golden('calcacc')
+    for tag, feat in (('real', g['feat_real'][0]), ('rnd', g['feat_rnd'])):
+        out = calc_acceleration(dev(feat), ver, ds).cpu().numpy()
+        ref = g[f'{tag}_{ver}_{ds}']
+        assert np.allclose(out, ref, rtol=1e-5, atol=1e-6), np.abs(out - ref).max()
