@@ -78,6 +78,14 @@ def cpu_baseline(scene, n_agents, n_obs, budget_s):
                       f'(C restatement, OpenMP {cores} threads) + PINNSF_multitask fwd+bwd in torch-CPU'}
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(msg):
+    if os.environ.get('PIML_BENCH_VERBOSE'):
+        print(f'[bench +{time.perf_counter() - _T0:7.2f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -88,6 +96,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the cpu_baseline leg')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured HIP graph')
+    ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -102,7 +111,22 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
-    from piml_amd import ops
+    # PyTorch-ROCm TunableOp: pick the rocBLAS / hipBLASLt solution per GEMM shape of the PINNSF
+    # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
+    # done here).  A file whose validators do not match this software stack is ignored by torch.
+    tuned = os.path.join(ROOT, 'piml_amd', 'tuning', 'tunableop_gfx950_cfg3.csv')
+    gemm_tuning = 'default'
+    if args.tunableop and os.path.exists(tuned):
+        try:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(False)
+            torch.cuda.tunable.record_untuned_enable(False)
+            gemm_tuning = 'tunableop-file' if torch.cuda.tunable.read_file(tuned) else 'default'
+        except Exception as ex:   # noqa: BLE001
+            print(f'[bench] TunableOp results not loaded ({ex})', file=sys.stderr)
+
+    _phase('tunableop setup done')
+    from piml_amd import ops, _lib
     from piml_amd.models.model import PINNSF_multitask
     from piml_amd.scenes import synthetic_gc_scene, pair_count, algorithmic_bytes
     from piml_amd.sharded import ShardedScene, allreduce_gradients
@@ -125,21 +149,13 @@ def main():
     params = [p for p in model.parameters()]
     ones = torch.ones(n_own, 2, device=dev)
 
-    ev_pairs = []
-
-    def step(timed):
-        """One forward + backward pass of the hot path over the scene."""
-        state_own.grad = None
-        for p in params:
-            p.grad = None
+    def features():
+        """all-gather of the owners' records (N > 1) + relfeat forward (HIP)."""
         state_full = sh.gather_state(state_own) if sh is not None else state_own
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        pf, of, df = ops.relative_features_packed(state_full, dest_own, obstacles, b0, n_own)
-        if timed:
-            e1.record()
-            ev_pairs.append((e0, e1))
+        return ops.relative_features_packed(state_full, dest_own, obstacles, b0, n_own, return_index=True)
+
+    def rest(pf, of, df, *_idx):
+        """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
         self_features = torch.cat((df, state_own[:, 2:4], state_own[:, 4:6], v0_own), dim=-1)
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
@@ -147,28 +163,143 @@ def main():
             allreduce_gradients(params, sh.group)
         return acc
 
+    def step_body(timer=None):
+        """One forward + backward pass of the hot path over the scene."""
+        if timer is not None:
+            timer.start()
+        feats = features()
+        if timer is not None:
+            timer.stop()
+        return rest(*feats)
+
+    def reset_grads():
+        state_own.grad = None
+        for p in params:
+            p.grad = None
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    _phase('scene + model on device')
+    # ---- whole-step HIP graph (removes ~60 per-kernel launch gaps); eager fallback ----
+    graph, g_timer, static_feats = None, None, None
+    mode = 'eager'
+    if args.graph:
+        ok = 1
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    reset_grads()
+                    step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            reset_grads()
+            # Two graphs per step, split right after the relfeat forward, so that the HIP events
+            # timing that kernel are recorded on the stream BETWEEN the two replays (ROCm cannot
+            # record events inside a captured graph).  One autograd pass spans both captures.
+            g_timer = _lib.StreamTimer()
+            graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+            with torch.cuda.graph(graph[0]):
+                feats = features()
+            with torch.cuda.graph(graph[1], pool=graph[0].pool()):
+                rest(*feats)
+            static_feats = feats     # the captured step's feature / index buffers stay alive
+            graph[0].replay(); graph[1].replay()
+            torch.cuda.synchronize()
+        except Exception as ex:   # noqa: BLE001 - any capture problem means: run eagerly
+            print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
+                  file=sys.stderr)
+            ok, graph = 0, None
+        if world > 1:   # all ranks must run the same mode
+            t = torch.tensor([ok], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                graph = None
+        mode = 'hipgraph' if graph is not None else 'eager'
+
+    _phase(f'capture done, mode={mode}')
+    kernel_ms_samples, overhead_ms_samples = [], []
+    cal_timer = _lib.StreamTimer()
+    ev_pairs = []
+    sample_every = max(1, args.steps // 10)
+
+    def run_step(i, timed):
+        if graph is not None:
+            sample = timed and i % sample_every == 0
+            if world == 1:
+                # the forward graph holds exactly one kernel: launch it directly into the captured
+                # buffers.  On sampled steps it is launched twice and the HIP events bracket the
+                # SECOND launch, so the interval holds one kernel behind another kernel rather than
+                # the idle gap that follows the previous graph replay.
+                ops.relative_features_packed_into(static_feats, state_own, dest_own, obstacles, b0, n_own)
+                if sample:
+                    g_timer.start()
+                    ops.relative_features_packed_into(static_feats, state_own, dest_own, obstacles, b0, n_own)
+                    g_timer.stop()
+            else:
+                if sample:
+                    g_timer.start()
+                graph[0].replay()                     # all-gather + relfeat forward
+                if sample:
+                    g_timer.stop()
+            graph[1].replay()
+            if sample:     # read this step's event pair (syncs on `stop` only)
+                # calibration: an empty start/stop pair right behind the step measures what the two
+                # event records themselves add to an interval on this stream
+                cal_timer.start(); cal_timer.stop()
+                kernel_ms_samples.append(g_timer.elapsed_ms())
+                overhead_ms_samples.append(cal_timer.elapsed_ms())
+        else:
+            reset_grads()
+            if timed:
+                tm = _lib.StreamTimer()
+                step_body(tm)
+                ev_pairs.append(tm)
+                if i % sample_every == 0:
+                    cal_timer.start(); cal_timer.stop()
+                    torch.cuda.current_stream().synchronize()
+                    overhead_ms_samples.append(cal_timer.elapsed_ms())
+            else:
+                step_body()
+
+    for i in range(args.warmup):
+        run_step(i, False)
     barrier()
+    _phase('warmup done')
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        run_step(i, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    _phase('timed region done')
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(len(ev_pairs), 1)
+    if graph is None:
+        kernel_ms_samples = [tm.elapsed_ms() for tm in ev_pairs]
+    def median(xs):
+        xs = sorted(xs)
+        return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
+    # median over the sampled launches: robust against the occasional preempted / cold sample
+    raw_ms = median(kernel_ms_samples)
+    overhead_ms = median(overhead_ms_samples)
+    kernel_ms = max(raw_ms - overhead_ms, 1e-6)
     pairs_step = N * (N + M_eff)                       # all ranks together
     alg_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own   # this rank's launch (SURVEY 8d)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_relfeat_traffic.json')
+    if world == 1 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get('config', {}).get('agents_total') == N and tj['config'].get('obstacle_points') == M_eff:
+            traffic = tj['relfeat_fwd_kernel']['hbm_bytes_per_launch']
 
     if rank == 0:
         out = {
@@ -178,7 +309,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'steps_per_s': args.steps / elapsed,
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning,
             'config': {'workload': 'cfg3: synthetic GC scene, forward+backward PINSF step '
                                    '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
@@ -187,7 +318,10 @@ def main():
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + reduce-scatter(grad) per step'},
             'roofline': {'bound': 'hbm', 'kernel': 'relfeat_fwd_kernel', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel_us': kernel_ms * 1e3, 'algorithmic_bytes': alg_bytes,
+                         'traffic': traffic, 'kernel_us': kernel_ms * 1e3, 'event_interval_us': raw_ms * 1e3,
+                         'event_pair_overhead_us': overhead_ms * 1e3, 'kernel_samples': len(kernel_ms_samples),
+                         'algorithmic_bytes': alg_bytes,
+                         'traffic_source': 'profiles/r01_relfeat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' if traffic else None,
                          'note': 'operand-stream byte model (24 B/ped pair + 8 B/obstacle pair + 488 B/focal); '
                                  'the sources are LDS/L2 resident, so frac > 1 is possible and HBM traffic '
                                  'is far below the model (see DESIGN.md)'},

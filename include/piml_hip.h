@@ -167,6 +167,17 @@ int piml_calc_acceleration(const float* relative_data, size_t rows, int row_stri
                            float B, float C, float D, float theta, float eps, float* acc, void* stream);
 
 /*
+ * HIP-event timer for measuring a kernel live on the stream it is launched on, also while
+ * that stream is being captured into a hipGraph (the record then becomes an external
+ * event-record node).  create -> record(start) -> [kernel launches] -> record(stop) ->
+ * elapsed_ms (synchronises on `stop`).  Not a reference interface: measurement plumbing.
+ */
+int piml_timer_create(void** event);
+int piml_timer_record(void* event, void* stream);
+int piml_timer_elapsed_ms(void* start, void* stop, float* ms);
+int piml_timer_destroy(void* event);
+
+/*
  * Diagnostic (tests only): evaluates, per element, the exact float32 arithmetic of the
  * neighbour-selection predicates -- dist = |r| as torch.norm computes it and
  * cos = torch.cosine_similarity(r, h) (src/data/data.py:434, 439-440) -- so that it can be

@@ -29,6 +29,10 @@ SIGNATURES = {
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
     'piml_collision_label': [_p, _z, _i, _p, _p],
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
+    'piml_timer_create': [ctypes.POINTER(_p)],
+    'piml_timer_record': [_p, _p],
+    'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],
+    'piml_timer_destroy': [_p],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
@@ -61,3 +65,31 @@ def lib():
 def check(err, what):
     if err != 0:
         raise PimlHipError(f'{what} failed: hipError {err} ({lib().piml_error_string(err).decode()})')
+
+
+class StreamTimer:
+    """A pair of HIP events recorded on torch's current stream through the C ABI; works
+    inside HIP-graph capture (torch.cuda.Event(external=True) is refused on ROCm)."""
+
+    def __init__(self):
+        self._e = [_p(), _p()]
+        for e in self._e:
+            check(lib().piml_timer_create(ctypes.byref(e)), 'piml_timer_create')
+
+    def start(self):
+        check(lib().piml_timer_record(self._e[0], torch.cuda.current_stream().cuda_stream), 'piml_timer_record')
+
+    def stop(self):
+        check(lib().piml_timer_record(self._e[1], torch.cuda.current_stream().cuda_stream), 'piml_timer_record')
+
+    def elapsed_ms(self):
+        ms = _f()
+        check(lib().piml_timer_elapsed_ms(self._e[0], self._e[1], ctypes.byref(ms)), 'piml_timer_elapsed_ms')
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            for e in self._e:
+                lib().piml_timer_destroy(e)
+        except Exception:   # interpreter shutdown
+            pass

@@ -424,3 +424,33 @@ PIML_API int piml_calc_acceleration(const float* relative_data, size_t rows, int
                        (float)cos((double)theta), (float)sin((double)theta), eps, (float2*)acc);
     return hipGetLastError();
 }
+
+// ---- HIP-event timer usable inside stream capture (bench.py's live kernel timing) ----
+PIML_API int piml_timer_create(void** event) {
+    if (!event) return hipErrorInvalidValue;
+    hipEvent_t e;
+    hipError_t err = hipEventCreate(&e);
+    *event = (void*)e;
+    return err;
+}
+
+PIML_API int piml_timer_record(void* event, void* stream) {
+    if (!event) return hipErrorInvalidValue;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    hipError_t err = hipStreamIsCapturing(as_stream(stream), &st);
+    if (err != hipSuccess) return err;
+    // while capturing, the record must become an external event-record node of the graph
+    return hipEventRecordWithFlags((hipEvent_t)event, as_stream(stream),
+                                   st == hipStreamCaptureStatusActive ? hipEventRecordExternal : hipEventRecordDefault);
+}
+
+PIML_API int piml_timer_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!start || !stop || !ms) return hipErrorInvalidValue;
+    hipError_t err = hipEventSynchronize((hipEvent_t)stop);
+    if (err != hipSuccess) return err;
+    return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+
+PIML_API int piml_timer_destroy(void* event) {
+    return event ? hipEventDestroy((hipEvent_t)event) : hipSuccess;
+}

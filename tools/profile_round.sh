@@ -1,0 +1,13 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel stats of the default bench command, plus
+# separate PMC passes (never combined with --stats/sys traces) for the HBM traffic of the
+# relfeat kernels.  Outputs under gpurun_out/profile_round/.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profile_round; mkdir -p $O
+ARGS="--steps 50 --warmup 10 --cpu-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- python3 $R/bench.py $ARGS > $O/l2.log 2>&1
+python3 $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err
+tail -c 300 $O/stats.log
