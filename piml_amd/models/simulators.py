@@ -1,0 +1,448 @@
+"""`BaseSimulator`: the reference's rollout / training driver (src/models/simulators.py:25-832)
+with the same method names and arguments, whose per-step body runs on the HIP operators.
+
+What is restated here is the CALLER side of the hot path:
+lagged explicit Euler, waypoint switching, leave-scene NaN, ground-truth injection of newly
+entering agents, feature recomputation, rollout / collision losses and the Adam loop.  Data
+objects are duck-typed: anything exposing the attributes of the reference's `TimeIndexedPedData` /
+`ChanneledTimeIndexedPedData` (ped_features, obs_features, self_features, position, velocity,
+acceleration, destination, dest_idx, dest_num, waypoints, obstacles, mask_p, mask_p_pred, labels,
+num_frames, time_unit, ...) works.
+
+Differences from the reference, all behaviour-preserving for a single call:
+  * no per-step host synchronisation: boolean-mask assignments (`x[mask] = y`, which run
+    `nonzero()` on the host) are `torch.where`, `if torch.sum(mask) > 0` blocks are gated
+    arithmetically, the NaN assertion on the predicted acceleration is checked once after the loop;
+  * the four `collision_detection(...).sum(-1)` calls per training step (simulators.py:708-724)
+    are two fused `ops.collision_counts` launches (no (C,N,N) matrices);
+  * the caller's data tensors are never mutated (the reference advances `data.dest_idx`,
+    `data.self_features` and `data.labels` in place through views).
+"""
+import os
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..pedestrians import Pedestrians
+from . import model as MODEL
+
+
+class RolloutResult(types.SimpleNamespace):
+    """What the reference returns as a `RawData` from get_multiple_rollouts (simulators.py:655-657)."""
+
+
+def _gather_waypoints(waypoints, dest_idx):
+    """waypoints (*c, D, N, 2), dest_idx (*c, N) -> (*c, N, 2)   (simulators.py:614-616)."""
+    idx = dest_idx.unsqueeze(-2).unsqueeze(-1).expand(*dest_idx.shape[:-1], 1, dest_idx.shape[-1], 2)
+    return torch.gather(waypoints, -3, idx).squeeze(-3)
+
+
+class BaseSimulator(Pedestrians):
+    """Same constructor contract as the reference: `args` is the argparse namespace of src/main.py."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.set_model(args)
+        self.set_optimizer(args)
+        self.set_scheduler(args)
+        self.finetune_flag = False
+        self.test_flag = False
+        self.time_iter = 0.0
+        self.epoch = 0
+        self.batch_idx = 0
+        self.collision_count = 0
+        self.hard_collision_count = 0
+        n_params = int(np.sum([p.numel() for p in self.model.parameters() if p.requires_grad]))
+        print('#Trainable Parameters:', n_params)
+
+    # ---- model / optimiser selection (simulators.py:40-136) ----
+    def _build(self, args, finetune):
+        if args.model not in MODEL.MODEL_TABLE:
+            raise NotImplementedError(f'{args.model}: only the PINNSF family is on the accelerated path')
+        net = MODEL.MODEL_TABLE[args.model][1 if finetune else 0](args)
+        return net.to(args.device)
+
+    def set_model(self, args):
+        self.model = self._build(args, False)
+
+    def set_ft_model(self, args):
+        self.model = self._build(args, True)
+
+    def set_optimizer(self, args):
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=args.learning_rate,
+                                          weight_decay=args.weight_decay)
+
+    def set_ft_optimizer(self, args):
+        if args.model == 'pinnsf_res':
+            corr = list(self.model.corrector.parameters())
+            ids = {id(p) for p in corr}
+            rest = [p for p in self.model.parameters() if id(p) not in ids]
+            self.optimizer = torch.optim.Adam(
+                [{'params': corr, 'lr': args.learning_rate * args.ft_lr_decay2},
+                 {'params': rest, 'lr': args.learning_rate * args.finetune_lr_decay}],
+                lr=args.learning_rate, weight_decay=args.weight_decay)
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(),
+                                              lr=args.learning_rate * args.finetune_lr_decay,
+                                              weight_decay=args.weight_decay * args.finetune_wd_aug)
+
+    def set_scheduler(self, args):
+        self.scheduler = None
+
+    set_ft_scheduler = set_scheduler
+
+    # ---- losses (simulators.py:141-249) ----
+    @staticmethod
+    def get_dist(pred, label):
+        return torch.norm(pred - label, p=2, dim=-1)
+
+    @staticmethod
+    def reduction(values, mode):
+        if mode == 'sum':
+            return torch.sum(values)
+        if mode == 'mean':
+            return torch.mean(values)
+        if mode == 'none':
+            return values
+        raise NotImplementedError
+
+    def loss_func(self, pred, labels, reduction='none'):
+        return F.mse_loss(pred, labels, reduction=reduction)
+
+    def l1_reg_loss(self, embeddings, weight=1e-3, reduction='none'):
+        return self.reduction(weight * torch.abs(embeddings), reduction)
+
+    def multiple_rollout_mse_loss(self, pred, labels, time_decay, reduction='none', reverse=False):
+        """(c,t,n,2) squared error weighted by time_decay^(T-1-t) (or ^t when `reverse`)."""
+        T = pred.shape[1]
+        steps = torch.arange(T, device=pred.device, dtype=pred.dtype)
+        expo = steps if reverse else (T - 1 - steps)
+        decay = (torch.as_tensor(float(time_decay), device=pred.device, dtype=pred.dtype) ** expo).reshape(1, T, 1, 1)
+        return self.reduction((pred - labels) ** 2 * decay, reduction)
+
+    def multiple_rollout_collision_avoidance_loss(self, pred, labels, time_decay, reduction='none'):
+        """MSE of the components perpendicular to each agent's label displacement."""
+        ni = labels[:, -1:, :, :] - labels[:, 0:1, :, :]
+        ni = ni / (torch.norm(ni, p=2, dim=-1, keepdim=True) + 1e-6)
+        pred_ = pred - torch.sum(pred * ni, dim=-1, keepdim=True) * ni
+        labels_ = labels - torch.sum(labels * ni, dim=-1, keepdim=True) * ni
+        return self.reduction(self.multiple_rollout_mse_loss(pred_, labels_, time_decay, reduction='none'), reduction)
+
+    def multiple_rollout_collision_loss(self, pred, labels, time_decay, coll_focus_weight, collisions,
+                                        reduction='none', abnormal_mask=None):
+        """Collision-focus loss: the avoidance loss of agents that collided anywhere in the window."""
+        w = (torch.sum(collisions, dim=1) > 0).to(pred.dtype)                 # c, n
+        w = w.unsqueeze(1).unsqueeze(-1)                                      # c, 1, n, 1
+        loss = w * self.multiple_rollout_collision_avoidance_loss(pred, labels, time_decay, reduction='none')
+        if abnormal_mask is not None:
+            loss = loss * abnormal_mask.reshape(1, 1, -1, 1)
+        return self.reduction(loss, reduction)
+
+    # ---- checkpoints (simulators.py:254-289); paths are explicit here ----
+    def _ckpt_path(self, args, finetune_flag):
+        path = os.path.join(getattr(args, 'save_dir', '../saved_model'), f'{args.exp_name}_{args.model_name_suffix}')
+        return path + ('_finetuned' if finetune_flag else '')
+
+    def load_model(self, args, set_model=True, finetune_flag=True, load_path=''):
+        if set_model:
+            (self.set_ft_model if finetune_flag else self.set_model)(args)
+        sd = torch.load(load_path or self._ckpt_path(args, finetune_flag), map_location=args.device)
+        if next(iter(sd)).startswith('module.'):           # saved from nn.DataParallel
+            sd = {k[7:]: v for k, v in sd.items()}
+        self.model.load_state_dict(sd)
+
+    def save_model(self, args, finetune_flag=True, cpu_version=False):
+        path = self._ckpt_path(args, finetune_flag) + ('_cpu' if cpu_version else '')
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        sd = self.model.state_dict()
+        torch.save({k: v.cpu() for k, v in sd.items()} if cpu_version else sd, path)
+
+    # ---- shared per-step pieces ----
+    def _features(self, p_cur, v_cur, a_cur, dest_cur, obstacles):
+        """get_relative_features on one frame of state (simulators.py:642-649 / 772-776)."""
+        a = self.args
+        pf, of, df = self.get_relative_features(
+            p_cur.unsqueeze(-3), v_cur.unsqueeze(-3), a_cur.unsqueeze(-3), dest_cur.unsqueeze(-3), obstacles,
+            a.topk_ped, a.sight_angle_ped, a.dist_threshold_ped, a.topk_obs, a.sight_angle_obs,
+            a.dist_threshold_obs)
+        return pf.squeeze(-4), of.squeeze(-4), df.squeeze(-3)
+
+    @staticmethod
+    def _inject(new_mask, cur, truth):
+        """cur[new] = truth[new] without a host-side nonzero()."""
+        m = new_mask.unsqueeze(-1) if cur.dim() > new_mask.dim() else new_mask
+        return torch.where(m, truth, cur)
+
+    # ---- HOT LOOP B: inference rollout (simulators.py:556-657) ----
+    def get_multiple_rollouts(self, data, t_start=0, load_model=True):
+        args = self.args
+        if load_model:
+            self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
+        dt = data.time_unit
+        waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
+        T = data.num_frames
+
+        pf, of = data.ped_features[..., t_start, :, :, :], data.obs_features[..., t_start, :, :, :]
+        self_f = data.self_features[..., t_start, :, :].clone()
+        desired_speed = self_f[..., -1:].clone()
+        hist_v = self_f[..., 2:-3].clone()                                   # *c, n, 2*num_history_velocity
+        a_cur = data.acceleration[..., t_start, :, :].clone()
+        v_cur = data.velocity[..., t_start, :, :].clone()
+        p_cur = data.position[..., t_start, :, :].clone()
+        dest_cur = data.destination[..., t_start, :, :].clone()
+        dest_idx = data.dest_idx[..., t_start, :].clone()
+
+        p_res = torch.zeros_like(data.position)
+        v_res = torch.zeros_like(data.velocity)
+        a_res = torch.zeros_like(data.acceleration)
+        p_res[..., :t_start + 1, :, :] = data.position[..., :t_start + 1, :, :]
+        v_res[..., :t_start + 1, :, :] = data.velocity[..., :t_start + 1, :, :]
+        a_res[..., :t_start + 1, :, :] = data.acceleration[..., :t_start + 1, :, :]
+        mask_new = torch.zeros_like(data.mask_p_pred, dtype=torch.float32)
+        mask_new[..., :t_start + 1, :] = data.mask_p[..., :t_start + 1, :].long()
+        new_flag = (data.mask_p - data.mask_p_pred).long() == 1            # c, t, n
+        nan = torch.tensor(float('nan'), device=p_cur.device)
+
+        state = [pf, of, self_f]
+        for t in range(t_start, T):
+            p_res[..., t, :, :] = p_cur
+            v_res[..., t, :, :] = v_cur
+            a_res[..., t, :, :] = a_cur
+            mask_new[..., t, :] = torch.where(p_cur[..., 0].isnan(), mask_new[..., t, :],
+                                              torch.ones_like(mask_new[..., t, :]))
+
+            a_next = self.model(*state)[0]                                    # :602
+            v_next = v_cur + a_cur * dt                                       # lagged Euler, quirk Q6
+            p_next = p_cur + v_cur * dt
+
+            near = torch.norm(p_cur - dest_cur, p=2, dim=-1) < 0.5           # :608-609
+            dest_idx = dest_idx + near.long()
+            gone = dest_idx > dest_num - 1                                    # arrived at the last waypoint
+            p_next = torch.where(gone.unsqueeze(-1), nan, p_next)             # leaves the scene (:611)
+            dest_idx = dest_idx - gone.long()
+            dest_cur = _gather_waypoints(waypoints, dest_idx)
+
+            p_cur, v_cur, a_cur = p_next, v_next, a_next
+            hist_v = torch.cat((hist_v[..., 2:], v_cur), dim=-1)              # :624-626
+
+            if t < T - 1:                                                     # newly entering agents (:629-639)
+                new = new_flag[..., t + 1, :]
+                p_cur = self._inject(new, p_cur, data.position[..., t + 1, :, :])
+                v_cur = self._inject(new, v_cur, data.velocity[..., t + 1, :, :])
+                a_cur = self._inject(new, a_cur, data.acceleration[..., t + 1, :, :])
+                dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
+                dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
+                hist_v = self._inject(new, hist_v, data.self_features[..., t + 1, :, 2:-3])
+
+            pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)
+            state = [pf, of, torch.cat((df, hist_v, a_cur, desired_speed), dim=-1)]     # :651
+
+        return RolloutResult(position=p_res, velocity=v_res, acceleration=a_res, destination=data.destination,
+                             waypoints=data.destination, obstacles=obstacles, mask_p=mask_new,
+                             meta_data=getattr(data, 'meta_data', None), time_unit=dt)
+
+    # ---- HOT LOOP C: differentiable rollout for fine-tuning (simulators.py:659-832) ----
+    def test_multiple_rollouts_for_training(self, data, t_start=0):
+        args = self.args
+        dt = data.time_unit
+        waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
+        T = data.num_frames
+        mask_pred = data.mask_p_pred.clone().long()                           # c, t, n
+        labels = data.labels.clone()
+        thr = args.collision_threshold
+
+        state = [data.ped_features[..., t_start, :, :, :], data.obs_features[..., t_start, :, :, :],
+                 data.self_features[..., t_start, :, :]]
+        desired_speed = state[2][..., -1:].clone()
+        a_cur = data.acceleration[..., t_start, :, :].clone()
+        v_cur = data.velocity[..., t_start, :, :].clone()
+        p_cur = data.position[..., t_start, :, :].clone()
+        dest_cur = data.destination[..., t_start, :, :].clone()
+        dest_idx = data.dest_idx[..., t_start, :].clone()
+        new_flag = (data.mask_p - data.mask_p_pred).long() == 1
+
+        dev = p_cur.device
+        zeros_ctn = lambda: torch.zeros(mask_pred.shape, device=dev)         # noqa: E731
+        collisions, hard_collisions = zeros_ctn(), zeros_ctn()
+        label_collisions, label_hard = zeros_ctn(), zeros_ctn()
+        p_steps, a_steps = [], []
+        pred_collisions = torch.zeros(data.ped_features[..., 0].shape, device=dev)
+        true_collision = torch.zeros(data.ped_features[..., 0].shape, device=dev)
+        loss = torch.zeros((), device=dev)
+        reg_loss = torch.zeros((), device=dev)
+        nan_seen = torch.zeros((), device=dev, dtype=torch.bool)
+        bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
+
+        for t in range(t_start, T):
+            predictions = self.model(*state)                                  # :701
+            p_msg = predictions[1]
+            gate = (mask_pred[:, t, :].sum() > 0)                             # `if torch.sum(mask) > 0` (:707)
+            gf = gate.to(p_cur.dtype)
+
+            cnt = ops.collision_counts(p_cur, (thr, thr / 2))                 # :708-715, fused, quirk Q7
+            lab = ops.collision_counts(labels[:, t, :, :2].contiguous(), (thr, thr / 2))   # :717-724
+            collisions[:, t, :] = cnt[0] * gf
+            hard_collisions[:, t, :] = cnt[1] * gf
+            label_collisions[:, t, :] = lab[0] * gf
+            label_hard[:, t, :] = lab[1] * gf
+            p_steps.append(torch.where(gate, p_cur, torch.zeros_like(p_cur)))   # :728-729 (NaN-safe gate)
+            a_steps.append(torch.where(gate, a_cur, torch.zeros_like(a_cur)))
+            if bm_head:                                                       # :731-733
+                pred_collisions[:, t] = predictions[-1] * gf
+                true_collision[:, t] = self.calculate_collision_label(state[0]) * gf
+            if args.reg_weight > 0:                                           # :735-737 (cumulative, as shipped)
+                reg_loss = reg_loss + self.l1_reg_loss(p_msg, args.reg_weight, 'sum') * gf
+                loss = loss + reg_loss * gf
+
+            a_next = predictions[0]
+            nan_seen = nan_seen | a_next.isnan().any()
+            v_next = v_cur + a_cur * dt                                       # :741-743
+            p_next = p_cur + v_cur * dt
+
+            near = torch.norm(p_cur - dest_cur, p=2, dim=-1) < 0.5           # :748-754, nobody is removed
+            dest_idx = dest_idx + near.long()
+            dest_idx = dest_idx - (dest_idx > dest_num - 1).long()
+            dest_cur = _gather_waypoints(waypoints, dest_idx)
+            p_cur, v_cur, a_cur = p_next, v_next, a_next
+
+            if t < T - 1:                                                     # :762-769
+                new = new_flag[..., t + 1, :]
+                p_cur = self._inject(new, p_cur, data.position[..., t + 1, :, :])
+                v_cur = self._inject(new, v_cur, data.velocity[..., t + 1, :, :])
+                a_cur = self._inject(new, a_cur, data.acceleration[..., t + 1, :, :])
+                dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
+                dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
+
+            pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)       # :772-776, differentiable
+            state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]      # :778-779
+
+        assert not bool(nan_seen), f'find nan in epoch : {self.epoch} {self.batch_idx}'  # :745
+
+        if args.new_collision_loss_flag:                                      # :782-788
+            collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
+            hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
+        self.collision_count += torch.sum(collisions).item()
+        self.hard_collision_count += torch.sum(hard_collisions).item()
+
+        pad = [torch.zeros_like(p_steps[0])] * t_start
+        p_res = torch.stack(pad + p_steps, dim=1)                             # c, t, n, 2
+        a_res = torch.stack(pad + a_steps, dim=1)
+        keep = (mask_pred != 0).unsqueeze(-1)
+        p_res = torch.where(keep, p_res, torch.zeros_like(p_res))             # :793 delete 'nan'
+        labels = torch.where(keep, labels, torch.zeros_like(labels))          # :794
+        lab_p = labels[:, :, :, :2]
+        mse_loss = self.multiple_rollout_mse_loss(p_res, lab_p, args.time_decay, reduction='sum')
+        loss = loss + mse_loss
+
+        zero = torch.zeros((), device=dev)
+        collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc = zero, zero, zero, zero
+        if args.collision_loss_weight > 0 and args.collision_loss_version in ('v0', 'v2'):   # :800-819
+            am = data.abnormal_mask if args.collision_loss_version == 'v2' else None
+            collision_loss = self.multiple_rollout_collision_loss(
+                p_res, lab_p, args.time_decay, args.collision_focus_weight, collisions, reduction='sum',
+                abnormal_mask=am) * args.collision_loss_weight
+            hard_collision_loss = self.multiple_rollout_collision_loss(
+                p_res, lab_p, args.time_decay, args.collision_focus_weight, hard_collisions, reduction='sum',
+                abnormal_mask=am) * args.collision_loss_weight * args.hard_collision_penalty
+            loss = loss + collision_loss + hard_collision_loss
+        if args.teacher_weight > 0:                                           # :821-824
+            a_mse = self.multiple_rollout_mse_loss(a_res, labels[..., 4:6], args.time_decay, reduction='sum',
+                                                   reverse=True)
+            loss = loss + a_mse * args.teacher_weight
+        if args.collision_pred_weight > 0:                                    # :826-830
+            collision_pred_loss = F.binary_cross_entropy(pred_collisions, true_collision,
+                                                         reduction='sum') * args.collision_pred_weight
+            collision_pred_acc = torch.sum(torch.round(pred_collisions) == true_collision) / true_collision.numel()
+            loss = loss + collision_pred_loss
+        return loss, mse_loss, collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc, reg_loss
+
+    # ---- pointwise evaluation and the Adam loop (simulators.py:291-440) ----
+    def test_pointwise(self, data):
+        self.model.eval()
+        with torch.no_grad():
+            ped_features, obs_features, self_features, labels = data[:]
+            pred = self.model(ped_features, obs_features, self_features)[0]
+            loss = torch.mean(self.loss_func(pred, labels[:, 4:6])).item()
+        return loss, loss
+
+    def train_batch(self, batch_data):
+        """One optimiser step on either batch type (the body of simulators.py:314-360).
+        Returns the dict of scalar logs of this batch."""
+        args = self.args
+        self.optimizer.zero_grad()
+        log = {}
+        if hasattr(batch_data, 'mask_p_pred') and hasattr(batch_data, 'waypoints'):       # channelled windows
+            out = self.test_multiple_rollouts_for_training(batch_data)
+            loss = out[0]
+            names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')
+            log.update({k: float(v) for k, v in zip(names, out)})
+            log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
+        else:                                                                              # pointwise rows
+            ped_features, obs_features, self_features, labels = batch_data
+            predictions = self.model(ped_features, obs_features, self_features)
+            pred, p_msg = predictions[0], predictions[1]
+            if args.pinnsf_interaction == 'sim':
+                mse_loss = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+            elif args.pinnsf_interaction == 'loss':                                        # PINN-loss pretraining
+                version = 'v2' if args.iter_flag else 'v0'
+                target = ops.calc_acceleration(ped_features, version, args.dataset_name)
+                mse_loss = F.mse_loss(p_msg, target, reduction='sum') + \
+                    args.true_label_weight * F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+            else:
+                raise NotImplementedError(args.pinnsf_interaction)
+            loss = mse_loss
+            if args.reg_weight > 0:
+                reg = self.l1_reg_loss(p_msg, args.reg_weight, 'sum')
+                loss = loss + reg
+                log['reg'] = float(reg)
+            if args.collision_pred_weight > 0 and args.model == 'pinnsf_bm':
+                cp = F.binary_cross_entropy(predictions[-1], labels[:, 6:], reduction='sum')
+                loss = loss + cp
+                log['collision_pred'] = float(cp)
+            log.update(loss=float(loss), mse=float(mse_loss), n=int(labels.shape[0]))
+        loss.backward()
+        self.optimizer.step()
+        return log
+
+    def train(self, train_loaders, val_data=None, test_data=None, validate_fn=None):
+        """Epoch loop with best-validation checkpointing and the reference's patience rule
+        (incl. its swapped patience / ft_patience, simulators.py:393)."""
+        args = self.args
+        start = time.time()
+        best, patience = 1e5, 0
+        history = []
+        for epoch in range(args.epochs):
+            self.epoch, self.collision_count, self.hard_collision_count = epoch, 0, 0
+            self.model.train()
+            sums, n = {}, 0
+            for batch_idx, batch in enumerate(train_loaders):
+                self.batch_idx = batch_idx
+                log = self.train_batch(batch)
+                n += log.pop('n')
+                for k, v in log.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                self.time_iter = time.time() - start
+            epoch_log = {k: v / max(n, 1) for k, v in sums.items()}
+            history.append(epoch_log)
+            print('Epoch {}:'.format(epoch))
+            print('Time {:.4f} -- Training loss:{}, mse:{}'.format(self.time_iter, epoch_log.get('loss'),
+                                                                  epoch_log.get('mse')))
+            if validate_fn is None and val_data is None:
+                continue
+            val_loss = validate_fn(self) if validate_fn is not None else self.test_pointwise(val_data)[0]
+            print('Time {:.4f} -- Validation loss:{}'.format(self.time_iter, val_loss))
+            if val_loss < best:
+                best, patience = val_loss, 0
+                if getattr(args, 'save_dir', None):
+                    self.save_model(args, self.finetune_flag)
+            else:
+                patience += 1
+                if patience > (args.patience if self.finetune_flag else args.ft_patience):
+                    break
+        return history

@@ -269,7 +269,94 @@ def gen_model():
     save('model', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model)
+def sim_args(**kw):
+    """The argparse namespace of src/main.py:26-112 (defaults), as far as the simulator reads it."""
+    a = model_args(dataset_name='gc1560')
+    a.__dict__.update(
+        model='pinnsf_m', device='cpu', gpus='3', learning_rate=0.002, weight_decay=5e-4, batch_size=3,
+        topk_ped=6, topk_obs=10, sight_angle_ped=90, sight_angle_obs=90, dist_threshold_ped=4,
+        dist_threshold_obs=4, num_history_velocity=1, skip_frames=25, valid_steps=5, time_decay=1,
+        reg_weight=0., collision_threshold=0.5, collision_loss_weight=10, val_coll_weight=30,
+        hard_collision_penalty=10, teacher_weight=0, collision_pred_weight=10, collision_focus_weight=10,
+        new_collision_loss_flag=0, collision_loss_version='v0', finetune_lr_decay=1, finetune_wd_aug=1,
+        ft_lr_decay2=0., exp_name='golden', model_name_suffix='x', epochs=1, patience=1, ft_patience=5)
+    a.__dict__.update(kw)
+    return a
+
+
+DATA_FIELDS = ('ped_features', 'obs_features', 'self_features', 'labels', 'position', 'velocity', 'acceleration',
+               'destination', 'dest_idx', 'dest_num', 'waypoints', 'obstacles', 'mask_p', 'mask_p_pred',
+               'abnormal_mask')
+
+
+def dump_data(prefix, d, out):
+    for k in DATA_FIELDS:
+        out[f'{prefix}/{k}'] = getattr(d, k).clone()
+    out[f'{prefix}/time_unit'] = np.float64(d.time_unit)
+    out[f'{prefix}/num_frames'] = np.int64(d.num_frames)
+
+
+def gen_rollout():
+    import models.simulators as SIM
+    out = {}
+    raw = load_raw(GC_CLIP)
+    # ---- HOT LOOP B: inference rollout (simulators.py:556-657) on frames 300..459 of the clip ----
+    sl = list(range(300, 460))
+    args = sim_args()
+    full = DATA.TimeIndexedPedData()
+    full.make_dataset(args, raw)
+    full.set_dataset_info(full, raw, list(range(len(full))))
+    data = DATA.TimeIndexedPedData()
+    for k in ('ped_features', 'obs_features', 'self_features', 'labels'):
+        setattr(data, k, getattr(full, k)[sl].clone())
+    data.topk_obs = full.topk_obs
+    data.num_frames = len(sl)
+    data.set_dataset_info(full, raw, sl)
+    data.num_frames = data.dataset_len = len(sl)
+    for k in ('position', 'velocity', 'acceleration', 'destination', 'dest_idx', 'mask_p', 'mask_p_pred'):
+        setattr(data, k, getattr(data, k).clone())
+    data.mask_p_pred = data.mask_p.clone()          # every present agent is simulated
+    data.mask_p_pred[:1] = data.mask_p[:1]
+    torch.manual_seed(666)
+    sim = SIM.BaseSimulator(args)
+    sim.model.eval()
+    for k, v in sim.model.state_dict().items():
+        out[f'sd_m/{k}'] = v.clone()
+    dump_data('roll', data, out)
+    with torch.no_grad():
+        res = sim.get_multiple_rollouts(data, t_start=0, load_model=False)
+    out['roll/out_position'] = res.position
+    out['roll/out_velocity'] = res.velocity
+    out['roll/out_acceleration'] = res.acceleration
+    out['roll/out_mask_p'] = res.mask_p
+
+    # ---- HOT LOOP C: differentiable training rollout (simulators.py:659-832), C = 4 windows ----
+    for model_name in ('pinnsf_m', 'pinnsf_bm'):
+        args = sim_args(model=model_name)
+        cdata = full.to_channeled_time_index_data(args.valid_steps, 'slice')
+        batch = DATA.ChanneledTimeIndexedPedData.slice(cdata, [396, 401, 406, 411])
+        for k in DATA_FIELDS:
+            if torch.is_tensor(getattr(batch, k)):
+                setattr(batch, k, getattr(batch, k).clone())
+        torch.manual_seed(666)
+        sim = SIM.BaseSimulator(args)
+        sim.model.eval()
+        sim.collision_count = sim.hard_collision_count = 0
+        sim.epoch = sim.batch_idx = 0
+        tag = f'train_{model_name}'
+        for k, v in sim.model.state_dict().items():
+            out[f'{tag}/sd/{k}'] = v.clone()
+        dump_data(tag, batch, out)
+        res = sim.test_multiple_rollouts_for_training(batch)
+        res[0].backward()
+        out[f'{tag}/scalars'] = np.array([float(x) for x in res], np.float64)
+        out[f'{tag}/counts'] = np.array([sim.collision_count, sim.hard_collision_count], np.float64)
+        for k, p in sim.model.named_parameters():
+            out[f'{tag}/grad/{k}'] = torch.zeros_like(p) if p.grad is None else p.grad.clone()
+    save('rollout', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
