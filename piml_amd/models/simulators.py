@@ -180,72 +180,117 @@ class BaseSimulator(Pedestrians):
         return torch.where(m, truth, cur)
 
     # ---- HOT LOOP B: inference rollout (simulators.py:556-657) ----
-    def get_multiple_rollouts(self, data, t_start=0, load_model=True):
+    def _rollout_state(self, data, t_start):
+        """Persistent (static-address) buffers of one rollout; the frame counter lives on the
+        device so that one captured step can be replayed for every frame."""
+        st = types.SimpleNamespace()
+        dev = data.position.device
+        st.td = data.position.dim() - 3                     # time axis of (*c, t, n, 2) tensors
+        st.T = data.num_frames
+        st.pf = data.ped_features[..., t_start, :, :, :].clone()
+        st.of = data.obs_features[..., t_start, :, :, :].clone()
+        st.selff = data.self_features[..., t_start, :, :].clone()
+        st.desired_speed = st.selff[..., -1:].clone()
+        st.hist = st.selff[..., 2:-3].clone()               # *c, n, 2*num_history_velocity
+        st.a = data.acceleration[..., t_start, :, :].clone()
+        st.v = data.velocity[..., t_start, :, :].clone()
+        st.p = data.position[..., t_start, :, :].clone()
+        st.dest = data.destination[..., t_start, :, :].clone()
+        st.dest_idx = data.dest_idx[..., t_start, :].clone()
+        st.p_res = torch.zeros_like(data.position)
+        st.v_res = torch.zeros_like(data.velocity)
+        st.a_res = torch.zeros_like(data.acceleration)
+        st.p_res[..., :t_start + 1, :, :] = data.position[..., :t_start + 1, :, :]
+        st.v_res[..., :t_start + 1, :, :] = data.velocity[..., :t_start + 1, :, :]
+        st.a_res[..., :t_start + 1, :, :] = data.acceleration[..., :t_start + 1, :, :]
+        st.mask_new = torch.zeros_like(data.mask_p_pred, dtype=torch.float32)
+        st.mask_new[..., :t_start + 1, :] = data.mask_p[..., :t_start + 1, :].long()
+        new_flag = (data.mask_p - data.mask_p_pred).long() == 1                       # *c, t, n
+        pad = torch.zeros_like(new_flag.narrow(st.td, 0, 1))
+        st.new_flag = torch.cat((new_flag, pad), dim=st.td)                          # frame T: nobody enters
+        st.t = torch.full((1,), t_start, device=dev, dtype=torch.long)
+        st.nan = torch.tensor(float('nan'), device=dev)
+        return st
+
+    def _rollout_step(self, data, st):
+        """One simulated frame (the body of simulators.py:595-652) on the persistent buffers.
+        Every index into the time axis comes from the device-side counter `st.t`."""
+        dt = data.time_unit
+        td, t = st.td, st.t
+        st.p_res.index_copy_(td, t, st.p.unsqueeze(td))
+        st.v_res.index_copy_(td, t, st.v.unsqueeze(td))
+        st.a_res.index_copy_(td, t, st.a.unsqueeze(td))
+        row = st.mask_new.index_select(td, t).squeeze(td)
+        st.mask_new.index_copy_(td, t, torch.where(st.p[..., 0].isnan(), row, torch.ones_like(row)).unsqueeze(td))
+
+        a_next = self.model(st.pf, st.of, st.selff)[0]                        # :602
+        v_next = st.v + st.a * dt                                             # lagged Euler, quirk Q6
+        p_next = st.p + st.v * dt
+
+        near = torch.norm(st.p - st.dest, p=2, dim=-1) < 0.5                  # :608-609
+        dest_idx = st.dest_idx + near.long()
+        gone = dest_idx > data.dest_num - 1                                   # arrived at the last waypoint
+        p_next = torch.where(gone.unsqueeze(-1), st.nan, p_next)              # leaves the scene (:611)
+        dest_idx = dest_idx - gone.long()
+        dest = _gather_waypoints(data.waypoints, dest_idx)
+        hist = torch.cat((st.hist[..., 2:], v_next), dim=-1)                  # :624-626
+
+        # newly entering agents are injected from the ground truth of frame t+1 (:629-639)
+        tn = t + 1
+        tc = torch.clamp(tn, max=st.T - 1)
+        new = st.new_flag.index_select(td, tn).squeeze(td)
+
+        def frame(x):
+            return x.index_select(td, tc).squeeze(td)
+        p_next = self._inject(new, p_next, frame(data.position))
+        v_next = self._inject(new, v_next, frame(data.velocity))
+        a_next = self._inject(new, a_next, frame(data.acceleration))
+        dest = self._inject(new, dest, frame(data.destination))
+        dest_idx = self._inject(new, dest_idx, frame(data.dest_idx))
+        hist = self._inject(new, hist, frame(data.self_features)[..., 2:-3])
+
+        pf, of, df = self._features(p_next, v_next, a_next, dest, data.obstacles)
+        st.p.copy_(p_next); st.v.copy_(v_next); st.a.copy_(a_next)
+        st.dest.copy_(dest); st.dest_idx.copy_(dest_idx); st.hist.copy_(hist)
+        st.pf.copy_(pf); st.of.copy_(of)
+        st.selff.copy_(torch.cat((df, hist, a_next, st.desired_speed), dim=-1))     # :651
+        st.t.add_(1)
+
+    def get_multiple_rollouts(self, data, t_start=0, load_model=True, use_graph=None):
+        """Roll the scene forward from frame `t_start` (simulators.py:556-657).  On the GPU, under
+        no_grad, the per-frame body is captured once into a HIP graph and replayed for the
+        remaining frames (`use_graph=None` = automatic): the ~60 small launches of a frame become
+        one graph launch."""
         args = self.args
         if load_model:
             self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
-        dt = data.time_unit
-        waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
-        T = data.num_frames
-
-        pf, of = data.ped_features[..., t_start, :, :, :], data.obs_features[..., t_start, :, :, :]
-        self_f = data.self_features[..., t_start, :, :].clone()
-        desired_speed = self_f[..., -1:].clone()
-        hist_v = self_f[..., 2:-3].clone()                                   # *c, n, 2*num_history_velocity
-        a_cur = data.acceleration[..., t_start, :, :].clone()
-        v_cur = data.velocity[..., t_start, :, :].clone()
-        p_cur = data.position[..., t_start, :, :].clone()
-        dest_cur = data.destination[..., t_start, :, :].clone()
-        dest_idx = data.dest_idx[..., t_start, :].clone()
-
-        p_res = torch.zeros_like(data.position)
-        v_res = torch.zeros_like(data.velocity)
-        a_res = torch.zeros_like(data.acceleration)
-        p_res[..., :t_start + 1, :, :] = data.position[..., :t_start + 1, :, :]
-        v_res[..., :t_start + 1, :, :] = data.velocity[..., :t_start + 1, :, :]
-        a_res[..., :t_start + 1, :, :] = data.acceleration[..., :t_start + 1, :, :]
-        mask_new = torch.zeros_like(data.mask_p_pred, dtype=torch.float32)
-        mask_new[..., :t_start + 1, :] = data.mask_p[..., :t_start + 1, :].long()
-        new_flag = (data.mask_p - data.mask_p_pred).long() == 1            # c, t, n
-        nan = torch.tensor(float('nan'), device=p_cur.device)
-
-        state = [pf, of, self_f]
-        for t in range(t_start, T):
-            p_res[..., t, :, :] = p_cur
-            v_res[..., t, :, :] = v_cur
-            a_res[..., t, :, :] = a_cur
-            mask_new[..., t, :] = torch.where(p_cur[..., 0].isnan(), mask_new[..., t, :],
-                                              torch.ones_like(mask_new[..., t, :]))
-
-            a_next = self.model(*state)[0]                                    # :602
-            v_next = v_cur + a_cur * dt                                       # lagged Euler, quirk Q6
-            p_next = p_cur + v_cur * dt
-
-            near = torch.norm(p_cur - dest_cur, p=2, dim=-1) < 0.5           # :608-609
-            dest_idx = dest_idx + near.long()
-            gone = dest_idx > dest_num - 1                                    # arrived at the last waypoint
-            p_next = torch.where(gone.unsqueeze(-1), nan, p_next)             # leaves the scene (:611)
-            dest_idx = dest_idx - gone.long()
-            dest_cur = _gather_waypoints(waypoints, dest_idx)
-
-            p_cur, v_cur, a_cur = p_next, v_next, a_next
-            hist_v = torch.cat((hist_v[..., 2:], v_cur), dim=-1)              # :624-626
-
-            if t < T - 1:                                                     # newly entering agents (:629-639)
-                new = new_flag[..., t + 1, :]
-                p_cur = self._inject(new, p_cur, data.position[..., t + 1, :, :])
-                v_cur = self._inject(new, v_cur, data.velocity[..., t + 1, :, :])
-                a_cur = self._inject(new, a_cur, data.acceleration[..., t + 1, :, :])
-                dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
-                dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
-                hist_v = self._inject(new, hist_v, data.self_features[..., t + 1, :, 2:-3])
-
-            pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)
-            state = [pf, of, torch.cat((df, hist_v, a_cur, desired_speed), dim=-1)]     # :651
-
-        return RolloutResult(position=p_res, velocity=v_res, acceleration=a_res, destination=data.destination,
-                             waypoints=data.destination, obstacles=obstacles, mask_p=mask_new,
-                             meta_data=getattr(data, 'meta_data', None), time_unit=dt)
+        st = self._rollout_state(data, t_start)
+        steps = st.T - t_start
+        if use_graph is None:
+            use_graph = data.position.is_cuda and not torch.is_grad_enabled() and steps > 8
+        done = 0
+        if use_graph and steps > 3:
+            try:
+                for _ in range(2):                        # real frames, also warm every lazy init up
+                    self._rollout_step(data, st)
+                done = 2
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._rollout_step(data, st)
+                for _ in range(steps - done):
+                    graph.replay()
+                done = steps
+            except RuntimeError as ex:                    # capture unsupported: finish eagerly
+                print(f'[piml_amd] rollout graph capture failed ({ex}); continuing eagerly')
+                torch.cuda.synchronize()
+                done = int(st.t.item()) - t_start
+        for _ in range(steps - done):
+            self._rollout_step(data, st)
+        return RolloutResult(position=st.p_res, velocity=st.v_res, acceleration=st.a_res,
+                             destination=data.destination, waypoints=data.destination, obstacles=data.obstacles,
+                             mask_p=st.mask_new, meta_data=getattr(data, 'meta_data', None),
+                             time_unit=data.time_unit)
 
     # ---- HOT LOOP C: differentiable rollout for fine-tuning (simulators.py:659-832) ----
     def test_multiple_rollouts_for_training(self, data, t_start=0):

@@ -57,7 +57,11 @@ def test_inference_rollout_matches_reference():
     sim = make_sim(g, sim_args(), 'sd_m/')
     data = load_data(g, 'roll')
     with torch.no_grad():
-        res = sim.get_multiple_rollouts(data, t_start=0, load_model=False)
+        res = sim.get_multiple_rollouts(data, t_start=0, load_model=False)            # HIP-graph replay
+        eager = sim.get_multiple_rollouts(data, t_start=0, load_model=False, use_graph=False)
+    # the captured step replays exactly the kernels of the eager step
+    assert torch.equal(torch.nan_to_num(res.position), torch.nan_to_num(eager.position))
+    assert torch.equal(res.mask_p, eager.mask_p)
     p, ref = res.position.cpu().numpy(), g['roll/out_position']
     m, mref = res.mask_p.cpu().numpy(), g['roll/out_mask_p']
     # short horizon: tight; the first steps must agree to float32 round-off
@@ -106,3 +110,21 @@ def test_train_batch_runs_and_learns():
     for _ in range(15):
         last = sim.train_batch(data)['loss']
     assert last < first
+
+
+def test_rollout_speed_report():
+    """Not a parity test: prints simulated steps/s of the inference rollout on the real GC clip
+    (reference on 8 CPU cores: 95 steps/s)."""
+    import time
+    g = golden('rollout')
+    sim = make_sim(g, sim_args(), 'sd_m/')
+    data = load_data(g, 'roll')
+    with torch.no_grad():
+        for graph in (False, True):
+            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f'rollout N=122 M=100, {data.num_frames} frames, graph={graph}: {data.num_frames / dt:.0f} steps/s')
