@@ -17,19 +17,30 @@ constexpr int kMlTile = 2048;   // agents per LDS tile (fwd 32 KiB, bwd 64 KiB)
 struct MlapmParams {
     int variant;                 // 0 raw, 1 GC, 2 UCY (mlapm.py:28-53)
     float tau, A, B, Cc, D, cth, sth, r2;   // cos/sin of theta, 2*radius
+    float B2, C2, D2;            // B, C, D pre-multiplied by log2(e): exp(x) = exp2(x * log2 e)
 };
+
+// MLAPM is a smooth force law checked to 1e-5 relative (not a discrete selection like relfeat), so
+// its pair arithmetic uses the hardware reciprocal-sqrt / reciprocal / exp2 units (<= 1 ulp
+// each) instead of the multi-instruction IEEE division / sqrt / expf expansions.
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // One ordered pair: focal (vix, viy, ex, ey) at the origin, source at (rx, ry) with
 // relative velocity (wx, wy).  Returns view * A * g * direction (mlapm.py:25-53).
 __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, float ry, float wx, float wy,
                                              float vix, float viy, float ex, float ey) {
-    const float r = norm2(rx, ry);                                  // :26
+    const float d2 = rx * rx + ry * ry;
+    const bool pos = d2 > 0.f;                                      // NaN -> false, handled below
+    const float rinv = fast_rsq(d2);
+    const float r = pos ? d2 * rinv : d2;                           // :26 (0 stays 0, NaN stays NaN)
     const float view = (vix * rx + viy * ry > 0.f) ? 1.f : 0.f;     // :27
-    const float rn = fmaxf(r, 1e-12f);                              // F.normalize eps
-    const float nx = rx / rn, ny = ry / rn;
+    const float ninv = pos ? rinv : 0.f;                            // F.normalize: 0 / eps = 0
+    const float nx = rx * ninv, ny = ry * ninv;
     float g, dx, dy;
     if (P.variant == 0) {
-        g = expf(P.B * r);                                          // :29
+        g = fast_exp2(P.B2 * r);                                    // :29
         dx = nx; dy = ny;
     } else {
         const float cr = rx * ey - ry * ex;                         // :34 / :48
@@ -37,19 +48,22 @@ __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, flo
         const float st = cr > 0.f ? -P.sth : (cr <= 0.f ? P.sth : cr);
         dx = P.cth * nx - st * ny; dy = st * nx + P.cth * ny;       // :36-39
         if (P.variant == 1) {
-            const float wn = norm2(wx, wy);
-            const float cs = (rx / fmaxf(r, 1e-8f)) * (wx / fmaxf(wn, 1e-8f)) +
-                             (ry / fmaxf(r, 1e-8f)) * (wy / fmaxf(wn, 1e-8f));    // :32
-            g = expf(P.B * r + P.Cc * cs + P.D * r * cs);           // :40
+            const float w2 = wx * wx + wy * wy;
+            // cosine_similarity clamps both norms at 1e-8 (:32)
+            const float cs = (rx * wx + ry * wy) * fminf(rinv, 1e8f) * fminf(fast_rsq(w2), 1e8f);
+            g = fast_exp2(P.B2 * r + P.C2 * cs + P.D2 * r * cs);    // :40
         } else {
             bool coll = r < P.r2;                                   // :43
-            coll |= norm2(rx + wx, ry + wy) < P.r2;                 // :44
-            const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy, rr = rx * rx + ry * ry;
-            const float tmin = -rw / ww;                            // :45
-            const float dmin = sqrtf(rr - rw * rw / ww);            // :46
-            coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin < P.r2);  // :47
-            const float cf = coll ? 1.f : 0.f;
-            g = expf(P.B * r * cf + P.Cc * cf);                     // :53 (with coll.unsqueeze(-1), Q8)
+            const float sx = rx + wx, sy = ry + wy;
+            coll |= sx * sx + sy * sy < P.r2 * P.r2;                // :44
+            const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy;
+            const float wwi = fast_rcp(ww);
+            const float tmin = -rw * wwi;                           // :45
+            const float dmin2 = d2 - rw * rw * wwi;                 // :46 (compared squared)
+            // sqrt of a (rounding-)negative argument is NaN in the reference: that branch is then false
+            coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin2 >= 0.f) && (dmin2 < P.r2 * P.r2);   // :47
+            g = coll ? fast_exp2(P.B2 * r + P.C2) : 1.f;            // :53 (with coll.unsqueeze(-1), Q8)
+            if (r != r) g = r;                                      // NaN poisons like the reference
         }
     }
     const float s = view * P.A * g;
@@ -102,10 +116,10 @@ __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, 
                                                 float vix, float viy, float ex, float ey, float Gx, float Gy,
                                                 float& ax, float& ay, float& bx, float& by) {
     ax = ay = bx = by = 0.f;
-    const float r = norm2(rx, ry);
-    if (!(r > 0.f) || !(vix * rx + viy * ry > 0.f)) return;
-    const float rn = fmaxf(r, 1e-12f);
-    const float nx = rx / rn, ny = ry / rn;
+    const float d2 = rx * rx + ry * ry;
+    if (!(d2 > 0.f) || !(vix * rx + viy * ry > 0.f)) return;
+    const float rinv = fast_rsq(d2), r = d2 * rinv;
+    const float nx = rx * rinv, ny = ry * rinv;
     float st = 0.f, ct = 1.f;
     if (P.variant != 0) {
         const float cr = rx * ey - ry * ex;
@@ -113,36 +127,38 @@ __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, 
     }
     const float ux = ct * Gx + st * Gy, uy = -st * Gx + ct * Gy;   // R^T G
     const float un = ux * nx + uy * ny;
-    float phi, fx, fy, hx = 0.f, hy = 0.f;                         // d(phi)/d(vr), d(phi)/d(vv)
+    float phi2, fx, fy, hx = 0.f, hy = 0.f;                        // phi*log2e, d(phi)/d(vr), d(phi)/d(vv)
     if (P.variant == 0) {
-        phi = P.B * r; fx = P.B * nx; fy = P.B * ny;
+        phi2 = P.B2 * r; fx = P.B * nx; fy = P.B * ny;
     } else if (P.variant == 1) {
-        const float q = norm2(wx, wy);
-        const float rc = fmaxf(r, 1e-8f), qc = fmaxf(q, 1e-8f);
-        const float n8x = rx / rc, n8y = ry / rc, mx = wx / qc, my = wy / qc;
+        const float w2 = wx * wx + wy * wy;
+        const float ri8 = fminf(rinv, 1e8f), qi8 = fminf(fast_rsq(w2), 1e8f);
+        const float n8x = rx * ri8, n8y = ry * ri8, mx = wx * qi8, my = wy * qi8;
         const float cs = n8x * mx + n8y * my;
-        phi = P.B * r + P.Cc * cs + P.D * r * cs;
+        phi2 = P.B2 * r + P.C2 * cs + P.D2 * r * cs;
         const float k1 = P.Cc + P.D * r;
-        const float csx = r > 1e-8f ? (mx - cs * n8x) / rc : mx / rc;   // d(cs)/d(vr)
-        const float csy = r > 1e-8f ? (my - cs * n8y) / rc : my / rc;
+        const bool r_ok = r > 1e-8f, q_ok = w2 > 1e-16f;
+        const float csx = (r_ok ? mx - cs * n8x : mx) * ri8;       // d(cs)/d(vr)
+        const float csy = (r_ok ? my - cs * n8y : my) * ri8;
         fx = P.B * nx + k1 * csx + P.D * cs * nx;
         fy = P.B * ny + k1 * csy + P.D * cs * ny;
-        const float cwx = q > 1e-8f ? (n8x - cs * mx) / q : n8x / qc;   // d(cs)/d(vv)
-        const float cwy = q > 1e-8f ? (n8y - cs * my) / q : n8y / qc;
-        hx = k1 * cwx; hy = k1 * cwy;
+        hx = k1 * (q_ok ? n8x - cs * mx : n8x) * qi8;              // d(cs)/d(vv)
+        hy = k1 * (q_ok ? n8y - cs * my : n8y) * qi8;
     } else {
         bool coll = r < P.r2;
-        coll |= norm2(rx + wx, ry + wy) < P.r2;
-        const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy, rr = rx * rx + ry * ry;
-        const float tmin = -rw / ww;
-        const float dmin = sqrtf(rr - rw * rw / ww);
-        coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin < P.r2);
+        const float sx = rx + wx, sy = ry + wy;
+        coll |= sx * sx + sy * sy < P.r2 * P.r2;
+        const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy;
+        const float wwi = fast_rcp(ww);
+        const float tmin = -rw * wwi;
+        const float dmin2 = d2 - rw * rw * wwi;
+        coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin2 >= 0.f) && (dmin2 < P.r2 * P.r2);
         const float cf = coll ? 1.f : 0.f;
-        phi = (P.B * r + P.Cc) * cf; fx = P.B * cf * nx; fy = P.B * cf * ny;
+        phi2 = (P.B2 * r + P.C2) * cf; fx = P.B * cf * nx; fy = P.B * cf * ny;
     }
-    const float AE = -P.A * expf(phi);
-    ax = AE * (un * fx + (ux - un * nx) / rn);
-    ay = AE * (un * fy + (uy - un * ny) / rn);
+    const float AE = -P.A * fast_exp2(phi2);
+    ax = AE * (un * fx + (ux - un * nx) * rinv);
+    ay = AE * (un * fy + (uy - un * ny) * rinv);
     bx = AE * un * hx;
     by = AE * un * hy;
 }
@@ -328,6 +344,8 @@ static MlapmParams make_params(int variant, float tau, float A, float B, float C
     const float th = theta_deg / 180.f * 3.14159265358979323846f;
     P.cth = cosf(th); P.sth = sinf(th);
     P.r2 = radius * 2.f;
+    const float log2e = 1.4426950408889634f;
+    P.B2 = B * log2e; P.C2 = Cc * log2e; P.D2 = D * log2e;
     return P;
 }
 
@@ -343,9 +361,15 @@ PIML_API int piml_mlapm_step_fwd(const float* position, const float* velocity, c
     if (N == 0) return hipSuccess;
     if (!position || !velocity || !desired_speed || !destination || !action) return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
-    hipLaunchKernelGGL(mlapm_fwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
-                       (const float2*)position, (const float2*)velocity, desired_speed, (const float2*)destination,
-                       N, P, dt, (float2*)action, (float2*)force);
+    // big scenes: 16-wave workgroups (the whole (p,v) array is staged once per workgroup)
+    if (N >= 4096)
+        hipLaunchKernelGGL(mlapm_fwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),
+                           (const float2*)position, (const float2*)velocity, desired_speed,
+                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force);
+    else
+        hipLaunchKernelGGL(mlapm_fwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
+                           (const float2*)position, (const float2*)velocity, desired_speed,
+                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force);
     return hipGetLastError();
 }
 
@@ -360,10 +384,16 @@ PIML_API int piml_mlapm_step_bwd(const float* g_action, const float* position, c
         !g_desired_speed || !g_destination)
         return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
-    hipLaunchKernelGGL(mlapm_bwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
-                       (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
-                       (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
-                       g_desired_speed, (float2*)g_destination);
+    if (N >= 4096)
+        hipLaunchKernelGGL(mlapm_bwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),
+                           (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
+                           (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
+                           g_desired_speed, (float2*)g_destination);
+    else
+        hipLaunchKernelGGL(mlapm_bwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
+                           (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
+                           (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
+                           g_desired_speed, (float2*)g_destination);
     return hipGetLastError();
 }
 
