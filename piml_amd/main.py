@@ -1,0 +1,121 @@
+# -*- coding: utf-8 -*-
+"""Experiment driver with the reference's command line (src/main.py:26-173): pre-train PINNSF
+pointwise, optionally fine-tune it through differentiable rollouts (-f), then roll a clip out and
+count collisions -- every pairwise operator on the MI355X (HIP), the MLP in PyTorch-ROCm.
+
+    python -m piml_amd.main [--flags as in the reference]
+
+Flag names and defaults are the reference's, except `--device` (default `cuda`: there is no CPU
+path) and the data YAMLs (shipped under piml_amd/configs/, paths relative to the YAML).  Fixes of
+reference driver bugs: fine-tuning uses `--ft_batch_size` (main.py:153 reads an
+undefined `args.f_batch_size`) on channelled windows, and does not need a checkpoint on disk.
+"""
+import argparse
+import os
+import random
+import string
+import time
+
+import numpy as np
+import torch
+
+from .data import dataset as DATASET
+from .functions import metrics as METRIC
+from .models import simulators as SIMULATOR
+from .utils import data_loader as LOADER
+
+_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs', 'data_configs')
+
+
+def get_args(argv=None):
+    p = argparse.ArgumentParser(description='AI pedestrian simulation')
+    A = p.add_argument
+    A('--exp_name', type=str, default='pedsim_debug'); A('--user_name', type=str, default='guozhen')
+    A('--seed', type=int, default=666); A('-f', '--finetune_flag', action='store_true')
+    A('--data_config', type=str, default=os.path.join(_CFG, 'toy.yaml'))
+    A('--ft_data_config', type=str, default=os.path.join(_CFG, 'toy_f.yaml'))
+    A('--vis_data_config', type=str, default=os.path.join(_CFG, 'data_vis.yaml'))
+    A('--model', type=str, default='pinnsf_m'); A('--device', type=str, default='cuda')
+    A('--gpus', type=str, default='3'); A('--learning_rate', type=float, default=0.002)
+    A('--batch_size', type=int, default=3); A('--ft_batch_size', type=int, default=4)
+    A('--shuffle', action='store_true'); A('--num_workers', type=int, default=0)
+    A('--weight_decay', type=float, default=5e-4); A('--epochs', type=int, default=2)
+    A('--dropout', type=float, default=0.5); A('--n_embedding', type=int, default=10)
+    A('--hidden_size', type=int, default=32); A('--activation', type=str, default='relu')
+    A('--patience', type=int, default=1); A('--ft_patience', type=int, default=5)
+    A('--topk_ped', type=int, default=6); A('--topk_obs', type=int, default=10)
+    A('--sight_angle_ped', type=int, default=90); A('--sight_angle_obs', type=int, default=90)
+    A('--dist_threshold_ped', type=int, default=4); A('--dist_threshold_obs', type=int, default=4)
+    A('--train_ratio', type=float, default=0.6); A('--val_ratio', type=float, default=0.2)
+    A('--test_ratio', type=float, default=0.2)
+    A('--encoder_hidden_size', type=int, default=128); A('--processor_hidden_size', type=int, default=128)
+    A('--decoder_hidden_size', type=int, default=64); A('--encoder_hidden_layers', type=int, default=3)
+    A('--processor_hidden_layers', type=int, default=16); A('--decoder_hidden_layers', type=int, default=2)
+    A('--add_noise_flag', action='store_true'); A('--add_noise_std', type=float, default=0.05)
+    A('--correction_hidden_layers', type=int, default=1); A('--finetune_lr_decay', type=float, default=1)
+    A('--finetune_wd_aug', type=int, default=1); A('--num_history_velocity', type=int, default=1)
+    A('--skip_frames', type=int, default=25); A('--valid_steps', type=int, default=5)
+    A('--time_decay', type=float, default=1); A('--training_mode', type=str, default='normal')
+    A('--res_hidden_layers', type=int, default=3); A('--ft_lr_decay2', type=float, default=0.)
+    A('--save_configs', action='store_true'); A('--reg_weight', type=float, default=0.)
+    A('--collision_threshold', type=float, default=0.5); A('--collision_loss_weight', type=float, default=10)
+    A('--val_coll_weight', type=float, default=30); A('--hard_collision_penalty', type=float, default=10)
+    A('--teacher_weight', type=float, default=0); A('--collision_pred_weight', type=float, default=10)
+    A('--collision_focus_weight', type=float, default=10); A('--new_collision_loss_flag', type=int, default=0)
+    A('--tags', type=str, default=''); A('--iter_flag', type=int, default=0)
+    A('--iter_model_name_suffix', type=str, default=''); A('--pinnsf_interaction', type=str, default='sim')
+    A('--dataset_name', type=str, default='ucy'); A('--true_label_weight', type=float, default=0)
+    A('--collision_loss_version', type=str, default='v0')
+    A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
+    args = p.parse_args(argv)
+    args.model_name_suffix = ''.join(random.sample(list(string.ascii_lowercase) + list(string.digits), 8))
+    return args
+
+
+def set_exp_configs(args):
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(args.seed)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    set_exp_configs(args)
+    start_time = time.time()
+
+    synthetic = DATASET.PointwisePedDataset()
+    synthetic.load_data(args.data_config)
+    print('number of training dataset: ', len(synthetic.raw_data['train']))
+    synthetic.build_dataset(args)
+    loaders = LOADER.data_loader(synthetic.train_data, args.batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
+    simulator = SIMULATOR.BaseSimulator(args)
+    history = simulator.train(loaders, synthetic.valid_data)
+    if hasattr(synthetic, 'test_data'):
+        simulator.test_multiple_rollouts(synthetic.test_data, load_model=False)
+
+    if args.finetune_flag:
+        real = DATASET.TimeIndexedPedDataset2()
+        real.load_data(args.ft_data_config)
+        real.build_dataset(args)
+        ft_loaders = LOADER.data_loader(real.train_data, args.ft_batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
+        history += simulator.finetune(ft_loaders, real.valid_data, real.test_data)
+    print('Total train time: {}'.format(time.time() - start_time))
+
+    vis = DATASET.TimeIndexedPedDatasetforVis()
+    vis.load_data(args.vis_data_config)
+    vis.build_dataset(args)
+    results = []
+    with torch.no_grad():
+        simulator.model.eval()
+        for d in vis.dataset['vis']:
+            out = simulator.get_multiple_rollouts(d, load_model=False)
+            soft = METRIC.collision_count(out.position, 0.5, reduction='sum')
+            hard = METRIC.collision_count(out.position, 0.5 / 2, reduction='sum')
+            print('#collisions soft/hard: {} / {}'.format(soft, hard))
+            results.append((soft, hard))
+    return history, results
+
+
+if __name__ == '__main__':
+    main()

@@ -426,7 +426,7 @@ class BaseSimulator(Pedestrians):
             out = self.test_multiple_rollouts_for_training(batch_data)
             loss = out[0]
             names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')
-            log.update({k: float(v) for k, v in zip(names, out)})
+            log.update({k: float(v.detach()) for k, v in zip(names, out)})
             log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
         else:                                                                              # pointwise rows
             ped_features, obs_features, self_features, labels = batch_data
@@ -445,12 +445,12 @@ class BaseSimulator(Pedestrians):
             if args.reg_weight > 0:
                 reg = self.l1_reg_loss(p_msg, args.reg_weight, 'sum')
                 loss = loss + reg
-                log['reg'] = float(reg)
+                log['reg'] = float(reg.detach())
             if args.collision_pred_weight > 0 and args.model == 'pinnsf_bm':
                 cp = F.binary_cross_entropy(predictions[-1], labels[:, 6:], reduction='sum')
                 loss = loss + cp
-                log['collision_pred'] = float(cp)
-            log.update(loss=float(loss), mse=float(mse_loss), n=int(labels.shape[0]))
+                log['collision_pred'] = float(cp.detach())
+            log.update(loss=float(loss.detach()), mse=float(mse_loss.detach()), n=int(labels.shape[0]))
         loss.backward()
         self.optimizer.step()
         return log
@@ -490,4 +490,76 @@ class BaseSimulator(Pedestrians):
                 patience += 1
                 if patience > (args.patience if self.finetune_flag else args.ft_patience):
                     break
+        return history
+
+    # ---- rollout evaluation and fine-tuning (simulators.py:395-554) ----
+    @staticmethod
+    def post_process(data, pred_data, pred_mask_p, mask_p):
+        """Agents that have arrived (gone in the rollout, still present in the data) are pinned to
+        their final destination (simulators.py:442-463)."""
+        dest_idx = (data.dest_num - 1).expand(data.waypoints.shape[:-3] + data.dest_num.shape[-1:])
+        dest = _gather_waypoints(data.waypoints, dest_idx).unsqueeze(-3).expand_as(pred_data)
+        return torch.where(((mask_p == 1) & (pred_mask_p == 0)).unsqueeze(-1), dest, pred_data)
+
+    def test_multiple_rollouts(self, data, load_model=True, test_flag=True, reduction='sum'):
+        """Roll every clip of `data` (a list of TimeIndexedPedData) from `skip_frames` and score it:
+        (loss, mse, mae, ot, mmd) like simulators.py:465-554.  MAE is the mean displacement (the
+        reference has no FDE); the Sinkhorn-OT / MMD figures of the reference (metrics.py:45-273)
+        are outside the accelerated path and reported as None."""
+        from ..functions import metrics as METRIC
+        args = self.args
+        self.model.eval()
+        clips = data if isinstance(data, list) else [data]
+        loss_sum = mse_sum = mae_sum = 0.0
+        coll = hard = 0.0
+        n = 0
+        for d in clips:
+            with torch.no_grad():
+                pred = self.get_multiple_rollouts(d, t_start=args.skip_frames, load_model=load_model)
+                p_pred = pred.position
+                mask = d.mask_p_pred.long()
+                c = METRIC.collision_count(p_pred[args.skip_frames:], args.collision_threshold, reduction='sum')
+                h = METRIC.collision_count(p_pred[args.skip_frames:], args.collision_threshold / 2, reduction='sum')
+                coll, hard = coll + c, hard + h
+                p_pred = self.post_process(d, p_pred, pred.mask_p, mask)
+                labels = d.labels[..., :2]
+                m = (mask == 1).unsqueeze(-1)
+                mse = torch.where(m, (p_pred - labels) ** 2, torch.zeros_like(p_pred)).sum().item()
+                loss = mse + (0 if test_flag else args.val_coll_weight * (c + h))
+                if test_flag:
+                    mae_sum += METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='sum')
+                n += int((mask == 1).sum().item())
+                loss_sum, mse_sum = loss_sum + loss, mse_sum + mse
+        n = max(n, 1)
+        loss, mse, mae = loss_sum / n, mse_sum / n, mae_sum / n
+        if test_flag:
+            print('---------------------------------------')
+            print('Test loss:{}, test_mse:{}, test_mae:{}, test ot:{}, test mmd:{}'.format(loss, mse, mae, None, None))
+        print('test/val collision count hard/soft: {} & {}'.format(hard, coll))
+        return loss, mse, mae, None, None
+
+    def validate(self, val_data):
+        if isinstance(val_data, list):
+            val_loss, val_mse = self.test_multiple_rollouts(val_data, load_model=False, test_flag=False)[:2]
+        else:
+            val_loss, val_mse = self.test_pointwise(val_data)
+        print('Time {:.4f} -- Validation loss:{}, val_mse:{}'.format(self.time_iter, val_loss, val_mse))
+        return val_loss, val_mse
+
+    def finetune(self, train_loaders, val_data, test_data, pretrained_state=None):
+        """Rollout fine-tuning (simulators.py:409-428): switch to the fine-tune network / optimiser,
+        load the intersection of the pre-trained weights, train on channelled windows."""
+        args = self.args
+        pretrained = pretrained_state if pretrained_state is not None else self.model.state_dict()
+        self.set_ft_model(args)
+        self.set_ft_optimizer(args)
+        self.set_ft_scheduler(args)
+        own = self.model.state_dict()
+        own.update({k: v for k, v in pretrained.items() if k in own})
+        self.model.load_state_dict(own)
+        self.finetune_flag = True
+        history = self.train(train_loaders, validate_fn=(lambda s: s.validate(val_data)[0]) if val_data else None)
+        if test_data:
+            self.test_multiple_rollouts(test_data, load_model=False)
+        self.finetune_flag = False
         return history

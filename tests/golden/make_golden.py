@@ -356,7 +356,41 @@ def gen_rollout():
     save('rollout', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout)
+def gen_dataset():
+    """The feature-building pipeline (data.py:746-833, 958-1043, 1046-1123) on the toy clip (whole)
+    and on the real GC clip (every 25th frame kept, to bound the fixture size)."""
+    out = {}
+    args = sim_args()
+    for tag, path, keep in (('toy1', TOY, 1), ('gc', GC_CLIP, 25)):
+        raw = load_raw(path)
+        d = DATA.TimeIndexedPedData()
+        d.make_dataset(args, raw)
+        d.set_dataset_info(d, raw, list(range(len(d))))
+        for k in ('ped_features', 'obs_features', 'self_features', 'labels', 'mask_p_pred', 'mask_a_pred', 'mask_v_pred'):
+            out[f'{tag}/{k}'] = getattr(d, k)[::keep].clone()
+        out[f'{tag}/abnormal_mask'] = d.abnormal_mask.clone()
+        out[f'{tag}/desired_speed'] = d.self_features[0, :, -1].clone()
+        for k in ('position', 'velocity', 'acceleration', 'destination', 'dest_idx', 'mask_p', 'mask_v', 'mask_a'):
+            out[f'{tag}/raw_{k}'] = getattr(raw, k)[::keep].clone()
+        out[f'{tag}/raw_waypoints'] = raw.waypoints.clone()
+        out[f'{tag}/raw_dest_num'] = raw.dest_num.clone()
+        out[f'{tag}/raw_obstacles'] = raw.obstacles.clone()
+        ch = d.to_channeled_time_index_data(args.valid_steps, 'slice')
+        out[f'{tag}/ch_slice_shape'] = np.array(ch.position.shape)
+        out[f'{tag}/ch_slice_pos_win7'] = ch.position[7].clone()
+        out[f'{tag}/ch_slice_pf_sum'] = ch.ped_features.sum(dim=(1, 2, 3, 4)).clone()
+        sp = d.to_channeled_time_index_data(args.valid_steps, 'split')
+        out[f'{tag}/ch_split_shape'] = np.array(sp.position.shape)
+        out[f'{tag}/ch_split_pos_win3'] = sp.position[3].clone()
+        pw = d.to_pointwise_data()        # NB: shifts d.labels in place in the reference -> call last
+        out[f'{tag}/pw_len'] = np.int64(len(pw))
+        out[f'{tag}/pw_labels_head'] = pw.labels[:64].clone()
+        out[f'{tag}/pw_self_head'] = pw.self_features[:64].clone()
+        out[f'{tag}/pw_ped_sum'] = pw.ped_features.sum(dim=(1, 2)).clone()
+    save('dataset', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
