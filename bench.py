@@ -87,6 +87,12 @@ def _phase(msg):
 
 
 def main():
+    # stdout must carry exactly ONE JSON line: anything libraries print to fd 1 (e.g. RCCL's version
+    # banner) is sent to stderr, and the result is written to the saved stdout at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -96,6 +102,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the cpu_baseline leg')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured HIP graph')
+    ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
     args = ap.parse_args()
 
@@ -107,9 +114,11 @@ def main():
                          f'--nproc-per-node {args.gpus}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(args.force_dist)
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     # PyTorch-ROCm TunableOp: pick the rocBLAS / hipBLASLt solution per GEMM shape of the PINNSF
     # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
@@ -136,7 +145,7 @@ def main():
     scene = synthetic_gc_scene(N, M, seed=args.seed)
     obstacles = torch.tensor(scene['obstacles'], device=dev)
     M_eff = obstacles.shape[0]
-    sh = ShardedScene(N, obstacles) if world > 1 else None
+    sh = ShardedScene(N, obstacles) if use_dist else None
     b0 = rank * n_own
     rows = slice(b0, b0 + n_own)
     state_own = torch.tensor(np.concatenate([scene[k][rows] for k in ('position', 'velocity', 'acceleration')],
@@ -178,7 +187,7 @@ def main():
             p.grad = None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +223,7 @@ def main():
             print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
                   file=sys.stderr)
             ok, graph = 0, None
-        if world > 1:   # all ranks must run the same mode
+        if use_dist:   # all ranks must run the same mode
             t = torch.tensor([ok], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if int(t.item()) == 0:
@@ -230,7 +239,7 @@ def main():
     def run_step(i, timed):
         if graph is not None:
             sample = timed and i % sample_every == 0
-            if world == 1:
+            if not use_dist:
                 # the forward graph holds exactly one kernel: launch it directly into the captured
                 # buffers.  On sampled steps it is launched twice and the HIP events bracket the
                 # SECOND launch, so the interval holds one kernel behind another kernel rather than
@@ -276,7 +285,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _phase('timed region done')
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -314,7 +323,7 @@ def main():
                                    '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
                        'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
-                       'sharding': 'single GPU' if world == 1 else
+                       'sharding': 'single GPU' if not use_dist else
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + reduce-scatter(grad) per step'},
             'roofline': {'bound': 'hbm', 'kernel': 'relfeat_fwd_kernel', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -330,8 +339,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
         elif world > 1:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
