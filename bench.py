@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the cpu_baseline leg')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured HIP graph')
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
+    ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
     args = ap.parse_args()
 
@@ -155,6 +156,8 @@ def main():
 
     torch.manual_seed(666)
     model = PINNSF_multitask(model_args()).to(dev).eval()   # eval: dropout off, deterministic
+    if args.two_streams:
+        model.obs_stream = torch.cuda.Stream()
     params = [p for p in model.parameters()]
     ones = torch.ones(n_own, 2, device=dev)
 
@@ -318,7 +321,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'steps_per_s': args.steps / elapsed,
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning,
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if args.two_streams else 1,
             'config': {'workload': 'cfg3: synthetic GC scene, forward+backward PINSF step '
                                    '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,

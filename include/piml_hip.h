@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 3
+#define PIML_HIP_ABI_VERSION 4
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -67,7 +67,8 @@ int piml_heading_fwd(const float* velocity, int C, int T, int N, float* heading,
  * Outputs (row i = focal_begin + i):
  *   ped_feat (C, focal_count, kp_eff, 6) = (p_j - p_i, v_j - v_i, a_j - a_i), zero-padded
  *   obs_feat (C, focal_count, ko_eff, 6) = (o_j - p_i, -v_i, -a_i), zero-padded
- *   dest_feat (C, focal_count, 2) = destination - position, NaN -> 0
+ *   dest_feat (C, focal_count, 2) = destination - position, NaN -> 0; rows `dest_feat_ld` floats
+ *             apart (2 = dense; 7 writes columns 0..1 of a (C, focal_count, 7) self_features buffer)
  *   ped_idx / obs_idx (int32, same leading shape, k_eff) : source index per slot, -1 = empty
  * NaN velocity / acceleration entries are read as 0 (the reference zeroes them in place
  * first, data.py:483-484; the host wrapper performs that in-place write).
@@ -79,8 +80,8 @@ int piml_relfeat_fwd(const float* position, const float* heading, const float* v
                      const float* obstacles, int C, int N, int M, int focal_begin,
                      int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                      float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
-                     float* ped_feat, float* obs_feat, float* dest_feat, int32_t* ped_idx,
-                     int32_t* obs_idx, void* stream);
+                     float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
+                     int32_t* ped_idx, int32_t* obs_idx, void* stream);
 
 /*
  * Relative features, backward: what autograd computes through gather / repeat / masked
@@ -165,6 +166,31 @@ int piml_collision_label(const float* ped_features, size_t rows, int row_stride,
  */
 int piml_calc_acceleration(const float* relative_data, size_t rows, int row_stride, int version, float A,
                            float B, float C, float D, float theta, float eps, float* acc, void* stream);
+
+/*
+ * Fused per-frame epilogue of the inference rollout: the body of
+ * BaseSimulator.get_multiple_rollouts between the model call and the feature recomputation
+ * (src/models/simulators.py:596-639, 651) in one launch.  For every (slice, agent):
+ *   record (p, v, a) and the presence mask of frame t; v' = v + a dt, p' = p + v dt (lagged
+ *   Euler); waypoint switch when |p - dest| < 0.5; past the last waypoint the agent leaves the
+ *   scene (p' = NaN, only if remove_arrived); agents entering at frame t+1 are re-initialised
+ *   from the ground-truth series; history-velocity shift; columns 2.. of the next self_features
+ *   row = (history, a', desired speed)  [columns 0..1 are written by piml_relfeat_fwd].
+ * State (C,N,.) is updated IN PLACE; a_next (C,N,2) is the model's prediction.  Series are
+ * (C,T,N,.); new_flag (C,T+1,N) uint8 (frame T all zero); F = hist_width + 5; waypoints
+ * (D,N,2) shared (waypoints_per_slice = 0) or (C,D,N,2).  The frame index t is read from DEVICE
+ * memory (frame_counter), so one captured launch serves every frame of a replayed hipGraph.
+ */
+int piml_rollout_step(float* position, float* velocity, float* acceleration, float* destination,
+                      int64_t* dest_idx, float* hist_velocity, int hist_width, const float* a_next,
+                      const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                      const float* position_series, const float* velocity_series,
+                      const float* acceleration_series, const float* destination_series,
+                      const int64_t* dest_idx_series, const float* self_features_series, int F,
+                      const uint8_t* new_flag, float* position_out, float* velocity_out,
+                      float* acceleration_out, float* mask_out, float* self_features_next,
+                      const float* desired_speed, const int64_t* frame_counter, int C, int T, int N,
+                      float dt, int remove_arrived, void* stream);
 
 /*
  * HIP-event timer for measuring a kernel live on the stream it is launched on, also while

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -21,7 +21,7 @@ SIGNATURES = {
     'piml_abi_version': [],
     'piml_heading_fwd': [_p, _i, _i, _i, _p, _p],
     'piml_relfeat_fwd': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
-                         _p, _p, _p, _p, _p, _p],
+                         _p, _p, _p, _i, _p, _p, _p],
     'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     'piml_mlapm_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p],
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
@@ -29,6 +29,8 @@ SIGNATURES = {
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
     'piml_collision_label': [_p, _z, _i, _p, _p],
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
+    'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,
+                          _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],

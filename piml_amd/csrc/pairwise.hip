@@ -484,3 +484,92 @@ PIML_API int piml_timer_elapsed_ms(void* start, void* stop, float* ms) {
 PIML_API int piml_timer_destroy(void* event) {
     return event ? hipEventDestroy((hipEvent_t)event) : hipSuccess;
 }
+
+// ---- fused per-frame integrator epilogue of the inference rollout (simulators.py:596-639) ----
+namespace piml {
+
+struct RolloutArgs {
+    float2 *p, *v, *a, *dest; long long* dest_idx; float* hist; int hist_w;
+    const float2* a_next; const float2* waypoints; int D, wp_per_slice; const long long* dest_num;
+    const float2 *pos_s, *vel_s, *acc_s, *dest_s; const long long* dest_idx_s; const float* selff_s; int F;
+    const unsigned char* new_flag;
+    float2 *p_res, *v_res, *a_res; float* mask_new;
+    float* selff_out; const float* desired_speed;
+    const long long* t_dev; int C, T, N; float dt; int remove_arrived;
+};
+
+// One thread per (slice, agent): record frame t, lagged explicit Euler (quirk Q6), waypoint switch
+// at 0.5 m, leave-scene NaN, injection of agents entering at frame t+1 from the ground truth,
+// history shift, and the (hist, a, v0) columns of the next self_features row.
+__global__ void rollout_step_kernel(const RolloutArgs A) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)A.C * A.N) return;
+    const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
+    const long long t = *A.t_dev;
+    const long long tn = t + 1, tc = tn < A.T ? tn : A.T - 1;
+    const size_t ft = ((size_t)c * A.T + t) * A.N + i;           // (c, t, i) in the time series
+    const size_t fn = ((size_t)c * A.T + tc) * A.N + i;          // (c, t+1, i), clamped
+    const float2 p = A.p[g], v = A.v[g], a = A.a[g], d = A.dest[g];
+    A.p_res[ft] = p; A.v_res[ft] = v; A.a_res[ft] = a;           // :596-600
+    if (!(p.x != p.x)) A.mask_new[ft] = 1.f;
+
+    float2 vn = make_float2(__fadd_rn(v.x, __fmul_rn(a.x, A.dt)), __fadd_rn(v.y, __fmul_rn(a.y, A.dt)));   // :603
+    float2 pn = make_float2(__fadd_rn(p.x, __fmul_rn(v.x, A.dt)), __fadd_rn(p.y, __fmul_rn(v.y, A.dt)));   // :604
+    float2 an = A.a_next[g];
+    long long idx = A.dest_idx[g];
+    if (norm2(p.x - d.x, p.y - d.y) < 0.5f) idx += 1;            // :608-609
+    const bool gone = idx > A.dest_num[i] - 1;
+    if (gone) {
+        if (A.remove_arrived) { const float qn = __uint_as_float(0x7fc00000u); pn = make_float2(qn, qn); }   // :611
+        idx -= 1;                                                // :613
+    }
+    float2 dn = A.waypoints[((size_t)(A.wp_per_slice ? c : 0) * A.D + idx) * A.N + i];   // :614-616
+
+    const int hw = A.hist_w;
+    float* h = A.hist + (size_t)g * hw;
+    float* so = A.selff_out + (size_t)g * A.F;
+    const bool enter = A.new_flag[((size_t)c * (A.T + 1) + tn) * A.N + i] != 0;        // :629-639
+    if (enter) {
+        pn = A.pos_s[fn]; vn = A.vel_s[fn]; an = A.acc_s[fn]; dn = A.dest_s[fn]; idx = A.dest_idx_s[fn];
+        const float* hs = A.selff_s + fn * A.F + 2;
+        for (int q = 0; q < hw; ++q) { h[q] = hs[q]; so[2 + q] = hs[q]; }
+    } else {
+        for (int q = 0; q + 2 < hw; ++q) h[q] = h[q + 2];        // :624-626
+        h[hw - 2] = vn.x; h[hw - 1] = vn.y;
+        for (int q = 0; q < hw; ++q) so[2 + q] = h[q];
+    }
+    so[2 + hw] = an.x; so[3 + hw] = an.y; so[4 + hw] = A.desired_speed[g];             // :651
+    A.p[g] = pn; A.v[g] = vn; A.a[g] = an; A.dest[g] = dn; A.dest_idx[g] = idx;
+}
+
+}  // namespace piml
+
+PIML_API int piml_rollout_step(float* position, float* velocity, float* acceleration, float* destination,
+                               int64_t* dest_idx, float* hist_velocity, int hist_width, const float* a_next,
+                               const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                               const float* position_series, const float* velocity_series,
+                               const float* acceleration_series, const float* destination_series,
+                               const int64_t* dest_idx_series, const float* self_features_series, int F,
+                               const uint8_t* new_flag, float* position_out, float* velocity_out,
+                               float* acceleration_out, float* mask_out, float* self_features_next,
+                               const float* desired_speed, const int64_t* frame_counter, int C, int T, int N,
+                               float dt, int remove_arrived, void* stream) {
+    if (C < 0 || T <= 0 || N < 0 || hist_width < 2 || F != hist_width + 5 || D <= 0) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    piml::RolloutArgs A;
+    A.p = (float2*)position; A.v = (float2*)velocity; A.a = (float2*)acceleration; A.dest = (float2*)destination;
+    A.dest_idx = (long long*)dest_idx; A.hist = hist_velocity; A.hist_w = hist_width;
+    A.a_next = (const float2*)a_next; A.waypoints = (const float2*)waypoints; A.D = D;
+    A.wp_per_slice = waypoints_per_slice; A.dest_num = (const long long*)dest_num;
+    A.pos_s = (const float2*)position_series; A.vel_s = (const float2*)velocity_series;
+    A.acc_s = (const float2*)acceleration_series; A.dest_s = (const float2*)destination_series;
+    A.dest_idx_s = (const long long*)dest_idx_series; A.selff_s = self_features_series; A.F = F;
+    A.new_flag = new_flag; A.p_res = (float2*)position_out; A.v_res = (float2*)velocity_out;
+    A.a_res = (float2*)acceleration_out; A.mask_new = mask_out; A.selff_out = self_features_next;
+    A.desired_speed = desired_speed; A.t_dev = (const long long*)frame_counter;
+    A.C = C; A.T = T; A.N = N; A.dt = dt; A.remove_arrived = remove_arrived;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::rollout_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       piml::as_stream(stream), A);
+    return hipGetLastError();
+}

@@ -32,7 +32,7 @@ struct RelfeatArgs {
     int ld;
     int C, N, M, f0, fcnt, kp, ko;
     float cos_p, cos_o, cut2_p, cut2_o, dthr_p, dthr_o;
-    float* ped_feat; float* obs_feat; float2* dest_feat; int* ped_idx; int* obs_idx;
+    float* ped_feat; float* obs_feat; float* dest_feat; int dest_ld; int* ped_idx; int* obs_idx;
     int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates}
 };
 
@@ -274,7 +274,8 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     }
     if (lane == 0) {
         const float2 d = A.dest[row];
-        A.dest_feat[row] = make_float2(nan_to_zero(d.x - pix), nan_to_zero(d.y - piy));   // :496-497
+        float* df = A.dest_feat + row * A.dest_ld;          // row stride: 2, or the width of a self_features row
+        df[0] = nan_to_zero(d.x - pix); df[1] = nan_to_zero(d.y - piy);                    // :496-497
     }
 }
 
@@ -360,11 +361,11 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
                               const float* obstacles, int C, int N, int M, int focal_begin,
                               int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                               float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
-                              float* ped_feat, float* obs_feat, float* dest_feat,
+                              float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
                               int32_t* ped_idx, int32_t* obs_idx, void* stream) {
     if (C < 0 || N < 0 || M < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
         topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK ||
-        state_ld < 2 || (state_ld & 1))
+        state_ld < 2 || (state_ld & 1) || dest_feat_ld < 2)
         return hipErrorInvalidValue;
     if (C == 0 || focal_count == 0) return hipSuccess;
     if (!position || !velocity || !acceleration || !destination || !dest_feat || (M > 0 && !obstacles))
@@ -377,7 +378,7 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     A.cos_p = cos_thr_ped; A.cos_o = cos_thr_obs;
     A.cut2_p = dist2_cutoff(dist_thr_ped); A.cut2_o = dist2_cutoff(dist_thr_obs);
     A.dthr_p = dist_thr_ped; A.dthr_o = dist_thr_obs;
-    A.ped_feat = ped_feat; A.obs_feat = obs_feat; A.dest_feat = (float2*)dest_feat;
+    A.ped_feat = ped_feat; A.obs_feat = obs_feat; A.dest_feat = dest_feat; A.dest_ld = dest_feat_ld;
     A.ped_idx = ped_idx; A.obs_idx = obs_idx;
     A.stats = nullptr;
 #ifdef PIML_RELFEAT_STATS

@@ -111,6 +111,10 @@ class _PINNSFBase(nn.Module):
         ucy = getattr(args, 'dataset_name', None) in {'ucy'}
         self.tau = self.taus[1] if ucy else self.taus[0]
         self.fix_dest_norm = False
+        # optional: a side stream on which the obstacle branch runs concurrently with the pedestrian
+        # branch (the two are independent until their accelerations are added; inside a captured
+        # HIP graph this becomes two parallel chains of GEMMs that fill the 256 CUs better)
+        self.obs_stream = None
         self.ped_feature_dim = args.ped_feature_dim
         self.obs_feature_dim = args.obs_feature_dim
         self.self_feature_dim = args.self_feature_dim
@@ -159,6 +163,13 @@ class _PINNSFBase(nn.Module):
 
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'
+        side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda) else None
+        acc_o = None
+        if self.obs_feature_dim > 0 and side is not None:      # fork: obstacle branch on the side stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                acc_o, out_obs_side, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
+                                                         self.obs_decoder, self.obs_predictor)
         encoded = self.ped_encoder(ped_features) if self.residual else None
         if self.residual:
             emb = self.ped_processor(encoded)
@@ -170,8 +181,12 @@ class _PINNSFBase(nn.Module):
                                                        self.ped_decoder, self.ped_predictor)
         out_obs = None
         if self.obs_feature_dim > 0:
-            acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
-                                                self.obs_decoder, self.obs_predictor)
+            if side is not None:                                 # join
+                torch.cuda.current_stream().wait_stream(side)
+                out_obs = out_obs_side
+            else:
+                acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
+                                                    self.obs_decoder, self.obs_predictor)
             acc = acc + acc_o
         predictions = acc + self.desired_force(self_features)
         if self.residual:

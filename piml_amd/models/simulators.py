@@ -210,7 +210,31 @@ class BaseSimulator(Pedestrians):
         st.new_flag = torch.cat((new_flag, pad), dim=st.td)                          # frame T: nobody enters
         st.t = torch.full((1,), t_start, device=dev, dtype=torch.long)
         st.nan = torch.tensor(float('nan'), device=dev)
+        # contiguous views / copies the fused epilogue kernel indexes with the device-side frame counter
+        st.new_flag_u8 = st.new_flag.to(torch.uint8).contiguous()
+        st.series = {k: getattr(data, k).contiguous() for k in
+                     ('position', 'velocity', 'acceleration', 'destination', 'self_features')}
+        st.series['dest_idx'] = data.dest_idx.long().contiguous()
+        st.waypoints = data.waypoints.contiguous()
+        st.dest_num = data.dest_num.long().contiguous().to(dev)
+        st.dest_idx = st.dest_idx.long().contiguous()
+        st.ped_idx = torch.empty(st.pf.shape[:-1], device=dev, dtype=torch.int32)
+        st.obs_idx = torch.empty(st.of.shape[:-1], device=dev, dtype=torch.int32)
+        for k in ('pf', 'of', 'selff', 'hist', 'p', 'v', 'a', 'dest', 'desired_speed'):
+            setattr(st, k, getattr(st, k).contiguous())
         return st
+
+    def _rollout_step_fused(self, data, st):
+        """The same frame as `_rollout_step` in three launches besides the MLP: the fused integrator
+        epilogue (piml_rollout_step), the relative-feature kernel writing straight into the state
+        buffers, and the frame-counter increment."""
+        a = self.args
+        a_next = self.model(st.pf, st.of, st.selff)[0]
+        ops.rollout_step(st, data, a_next.contiguous(), remove_arrived=True)
+        ops.relative_features_into((st.pf, st.of, st.selff, st.ped_idx, st.obs_idx), st.p, st.v, st.a, st.dest,
+                                   data.obstacles, a.topk_ped, a.sight_angle_ped, a.dist_threshold_ped,
+                                   a.topk_obs, a.sight_angle_obs, a.dist_threshold_obs)
+        st.t.add_(1)
 
     def _rollout_step(self, data, st):
         """One simulated frame (the body of simulators.py:595-652) on the persistent buffers.
@@ -256,7 +280,7 @@ class BaseSimulator(Pedestrians):
         st.selff.copy_(torch.cat((df, hist, a_next, st.desired_speed), dim=-1))     # :651
         st.t.add_(1)
 
-    def get_multiple_rollouts(self, data, t_start=0, load_model=True, use_graph=None):
+    def get_multiple_rollouts(self, data, t_start=0, load_model=True, use_graph=None, fused=None):
         """Roll the scene forward from frame `t_start` (simulators.py:556-657).  On the GPU, under
         no_grad, the per-frame body is captured once into a HIP graph and replayed for the
         remaining frames (`use_graph=None` = automatic): the ~60 small launches of a frame become
@@ -266,18 +290,21 @@ class BaseSimulator(Pedestrians):
             self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
         st = self._rollout_state(data, t_start)
         steps = st.T - t_start
+        if fused is None:
+            fused = data.position.is_cuda and not torch.is_grad_enabled()
+        step_fn = self._rollout_step_fused if fused else self._rollout_step
         if use_graph is None:
             use_graph = data.position.is_cuda and not torch.is_grad_enabled() and steps > 8
         done = 0
         if use_graph and steps > 3:
             try:
                 for _ in range(2):                        # real frames, also warm every lazy init up
-                    self._rollout_step(data, st)
+                    step_fn(data, st)
                 done = 2
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self._rollout_step(data, st)
+                    step_fn(data, st)
                 for _ in range(steps - done):
                     graph.replay()
                 done = steps
@@ -286,7 +313,7 @@ class BaseSimulator(Pedestrians):
                 torch.cuda.synchronize()
                 done = int(st.t.item()) - t_start
         for _ in range(steps - done):
-            self._rollout_step(data, st)
+            step_fn(data, st)
         return RolloutResult(position=st.p_res, velocity=st.v_res, acceleration=st.a_res,
                              destination=data.destination, waypoints=data.destination, obstacles=data.obstacles,
                              mask_p=st.mask_new, meta_data=getattr(data, 'meta_data', None),

@@ -50,7 +50,7 @@ def heading_direction(velocity):
 
 
 def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f0, fcnt, kp, ko,
-                        cos_p, cos_o, dthr_p, dthr_o, device, outs=None):
+                        cos_p, cos_o, dthr_p, dthr_o, device, outs=None, dest_ld=2):
     M = o.shape[0]
     kpe, koe = min(kp, N), min(ko, M)
     if outs is None:
@@ -62,14 +62,14 @@ def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f
         obs_idx = torch.empty(*lead, fcnt, koe, device=device, dtype=torch.int32)
     else:
         ped_feat, obs_feat, dest_feat, ped_idx, obs_idx = outs
-        want = ((*lead, fcnt, kpe, 6), (*lead, fcnt, koe, 6), (*lead, fcnt, 2), (*lead, fcnt, kpe), (*lead, fcnt, koe))
+        want = ((*lead, fcnt, kpe, 6), (*lead, fcnt, koe, 6), (*lead, fcnt, dest_ld), (*lead, fcnt, kpe), (*lead, fcnt, koe))
         for t, shp, dt in zip(outs, want, (torch.float32,) * 3 + (torch.int32,) * 2):
             if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or t.device != device:
                 raise ValueError(f'output buffer mismatch: expected {shp} {dt}, got {tuple(t.shape)} {t.dtype}')
     with torch.cuda.device(device):
         _lib.check(_lib.lib().piml_relfeat_fwd(
             p_ptr, _ptr(hd), v_ptr, a_ptr, ld, _ptr(dest_rows), _ptr(o), C, N, M, f0, fcnt,
-            kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat),
+            kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat), dest_ld,
             _ptr(ped_idx), _ptr(obs_idx), _stream()), 'piml_relfeat_fwd')
     return ped_feat, obs_feat, dest_feat, ped_idx, obs_idx
 
@@ -365,3 +365,39 @@ def calc_acceleration(relative_data, equation_version='v0', dataset='gc1560', ep
                                                      D, th, float(eps), _ptr(out), _stream()),
                    'piml_calc_acceleration')
     return out
+
+
+def relative_features_into(outs, position, velocity, acceleration, destination, obstacles,
+                           topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                           topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4):
+    """Forward only, no autograd, no allocation: per-step features of (..., N, 2) state into the
+    preallocated `outs` = (ped_features, obs_features, self_features, ped_idx, obs_idx), where
+    dest_features land in columns 0..1 of the (..., N, F) self_features buffer (row stride F).
+    Used by the captured inference-rollout step."""
+    p, v, a, d = [_gpu_f32(n, x) for n, x in (('position', position), ('velocity', velocity),
+                                              ('acceleration', acceleration), ('destination', destination))]
+    o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
+    N = p.shape[-2]
+    lead = tuple(p.shape[:-2])
+    C = p.numel() // max(N * 2, 1)
+    _launch_relfeat_fwd(_ptr(p), _ptr(v), _ptr(a), 2, None, d, o, lead, C, N, 0, N, int(topk_ped), int(topk_obs),
+                        cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs), float(dist_threshold_ped),
+                        float(dist_threshold_obs), p.device, outs=tuple(outs), dest_ld=outs[2].shape[-1])
+    return outs
+
+
+def rollout_step(st, data, a_next, remove_arrived=True):
+    """One launch of the fused integrator epilogue (piml_rollout_step) on the rollout state `st`
+    built by BaseSimulator._rollout_state (buffers updated in place)."""
+    C = st.p.numel() // max(st.p.shape[-2] * 2, 1)
+    N, T = st.p.shape[-2], st.T
+    wp = data.waypoints
+    with torch.cuda.device(st.p.device):
+        _lib.check(_lib.lib().piml_rollout_step(
+            _ptr(st.p), _ptr(st.v), _ptr(st.a), _ptr(st.dest), _ptr(st.dest_idx), _ptr(st.hist), st.hist.shape[-1],
+            _ptr(a_next), _ptr(st.waypoints), wp.shape[-3], int(wp.dim() > 3), _ptr(st.dest_num),
+            _ptr(st.series['position']), _ptr(st.series['velocity']), _ptr(st.series['acceleration']),
+            _ptr(st.series['destination']), _ptr(st.series['dest_idx']), _ptr(st.series['self_features']),
+            st.selff.shape[-1], _ptr(st.new_flag_u8), _ptr(st.p_res), _ptr(st.v_res), _ptr(st.a_res),
+            _ptr(st.mask_new), _ptr(st.selff), _ptr(st.desired_speed), _ptr(st.t), C, T, N,
+            float(data.time_unit), int(remove_arrived), _stream()), 'piml_rollout_step')

@@ -34,14 +34,14 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     # negative sizes / oversize k are rejected before any HIP call
     assert L.piml_relfeat_fwd(None, None, None, None, 2, None, None, 1, -1, 0, 0, 0, 6, 10, 0., 0., 4., 4.,
-                              None, None, None, None, None, None) == 1
+                              None, None, None, 2, None, None, None) == 1
     assert L.piml_relfeat_fwd(None, None, None, None, 2, None, None, 1, 8, 0, 0, 8, 99, 10, 0., 0., 4., 4.,
-                              None, None, None, None, None, None) == 1
+                              None, None, None, 2, None, None, None) == 1
     assert L.piml_relfeat_fwd(None, None, None, None, 2, None, None, 1, 8, 0, 4, 8, 6, 10, 0., 0., 4., 4.,
-                              None, None, None, None, None, None) == 1
+                              None, None, None, 2, None, None, None) == 1
     # empty problems are a no-op success
     assert L.piml_relfeat_fwd(None, None, None, None, 2, None, None, 0, 8, 0, 0, 8, 6, 10, 0., 0., 4., 4.,
-                              None, None, None, None, None, None) == 0
+                              None, None, None, 2, None, None, None) == 0
     assert L.piml_heading_fwd(None, 0, 1, 5, None, None) == 0
 
 

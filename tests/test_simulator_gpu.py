@@ -57,11 +57,13 @@ def test_inference_rollout_matches_reference():
     sim = make_sim(g, sim_args(), 'sd_m/')
     data = load_data(g, 'roll')
     with torch.no_grad():
-        res = sim.get_multiple_rollouts(data, t_start=0, load_model=False)            # HIP-graph replay
-        eager = sim.get_multiple_rollouts(data, t_start=0, load_model=False, use_graph=False)
-    # the captured step replays exactly the kernels of the eager step
-    assert torch.equal(torch.nan_to_num(res.position), torch.nan_to_num(eager.position))
-    assert torch.equal(res.mask_p, eager.mask_p)
+        res = sim.get_multiple_rollouts(data, t_start=0, load_model=False)            # fused + HIP-graph replay
+        eager = sim.get_multiple_rollouts(data, t_start=0, load_model=False, use_graph=False, fused=False)
+        fused = sim.get_multiple_rollouts(data, t_start=0, load_model=False, use_graph=False, fused=True)
+    # the fused integrator kernel and the captured step reproduce the torch-op step bit for bit
+    for other in (eager, fused):
+        for k in ('position', 'velocity', 'acceleration', 'mask_p'):
+            assert torch.equal(torch.nan_to_num(getattr(res, k)), torch.nan_to_num(getattr(other, k))), k
     p, ref = res.position.cpu().numpy(), g['roll/out_position']
     m, mref = res.mask_p.cpu().numpy(), g['roll/out_mask_p']
     # short horizon: tight; the first steps must agree to float32 round-off
@@ -120,11 +122,27 @@ def test_rollout_speed_report():
     sim = make_sim(g, sim_args(), 'sd_m/')
     data = load_data(g, 'roll')
     with torch.no_grad():
-        for graph in (False, True):
-            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
+        for graph, fused in ((False, False), (True, False), (True, True)):
+            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph, fused=fused)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
+            sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph, fused=fused)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(f'rollout N=122 M=100, {data.num_frames} frames, graph={graph}: {data.num_frames / dt:.0f} steps/s')
+            print(f'rollout N=122 M=100, {data.num_frames} frames, graph={graph} fused={fused}: '
+                  f'{data.num_frames / dt:.0f} steps/s')
+
+
+def test_two_stream_forward_equals_single_stream():
+    """The optional side stream for the obstacle branch changes scheduling, not results."""
+    g = golden('rollout')
+    sim = make_sim(g, sim_args(), 'sd_m/')
+    data = load_data(g, 'train_pinnsf_m')
+    args = (data.ped_features[:, 0], data.obs_features[:, 0], data.self_features[:, 0])
+    with torch.no_grad():
+        ref = sim.model(*args)
+        sim.model.obs_stream = torch.cuda.Stream()
+        got = sim.model(*args)
+        torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
