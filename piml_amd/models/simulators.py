@@ -531,13 +531,13 @@ class BaseSimulator(Pedestrians):
     def test_multiple_rollouts(self, data, load_model=True, test_flag=True, reduction='sum'):
         """Roll every clip of `data` (a list of TimeIndexedPedData) from `skip_frames` and score it:
         (loss, mse, mae, ot, mmd) like simulators.py:465-554.  MAE is the mean displacement (the
-        reference has no FDE); the Sinkhorn-OT / MMD figures of the reference (metrics.py:45-273)
-        are outside the accelerated path and reported as None."""
+        reference has no FDE); OT / MMD are the batched restatements in functions/metrics.py."""
         from ..functions import metrics as METRIC
         args = self.args
         self.model.eval()
         clips = data if isinstance(data, list) else [data]
-        loss_sum = mse_sum = mae_sum = 0.0
+        loss_sum = mse_sum = mae_sum = ot_sum = mmd_sum = 0.0
+        frames = 0
         coll = hard = 0.0
         n = 0
         for d in clips:
@@ -555,15 +555,19 @@ class BaseSimulator(Pedestrians):
                 loss = mse + (0 if test_flag else args.val_coll_weight * (c + h))
                 if test_flag:
                     mae_sum += METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='sum')
+                    ot_sum += METRIC.ot_with_time_mask(p_pred, labels, mask, reduction='sum')
+                    mmd_sum += METRIC.mmd_with_time_mask(p_pred, labels, mask, reduction='sum')
                 n += int((mask == 1).sum().item())
+                frames += int((mask.sum(dim=1) > 0).sum().item())
                 loss_sum, mse_sum = loss_sum + loss, mse_sum + mse
-        n = max(n, 1)
+        n, frames = max(n, 1), max(frames, 1)
         loss, mse, mae = loss_sum / n, mse_sum / n, mae_sum / n
+        ot, mmd = ot_sum / frames, mmd_sum / frames
         if test_flag:
             print('---------------------------------------')
-            print('Test loss:{}, test_mse:{}, test_mae:{}, test ot:{}, test mmd:{}'.format(loss, mse, mae, None, None))
+            print('Test loss:{}, test_mse:{}, test_mae:{}, test ot:{}, test mmd:{}'.format(loss, mse, mae, ot, mmd))
         print('test/val collision count hard/soft: {} & {}'.format(hard, coll))
-        return loss, mse, mae, None, None
+        return loss, mse, mae, ot, mmd
 
     def validate(self, val_data):
         if isinstance(val_data, list):

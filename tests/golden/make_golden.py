@@ -390,7 +390,24 @@ def gen_dataset():
     save('dataset', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset)
+def gen_metrics():
+    """Evaluation metrics (metrics.py:16-273) on a perturbed copy of real GC frames."""
+    import functions.metrics as METRIC
+    raw = load_raw(GC_CLIP)
+    q = raw.position[380:440].clone()
+    g = torch.Generator().manual_seed(3)
+    p = q + 0.3 * torch.randn(q.shape, generator=g)
+    mask = raw.mask_p[380:440].clone()
+    out = dict(p=p, q=q, mask=mask)
+    for red in ('sum', 'mean'):
+        out[f'ot_{red}'] = np.float64(METRIC.ot_with_time_mask(p, q, mask, reduction=red))
+        out[f'mmd_{red}'] = np.float64(METRIC.mmd_with_time_mask(p, q, mask, reduction=red))
+        out[f'mae_{red}'] = np.float64(METRIC.mae_with_time_mask(p, q, mask, reduction=red))
+        out[f'coll_{red}'] = np.float64(METRIC.collision_count(q, 0.6, reduction=red))
+    save('metrics', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
