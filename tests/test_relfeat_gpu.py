@@ -155,3 +155,29 @@ def test_relfeat_packed_state_equals_separate(oracle):
     want = torch.cat((p.grad, v.grad, a_.grad), dim=-1)
     assert (state.grad - want).abs().max() <= 1e-5 * max(1.0, want.abs().max().item())
     assert (drow.grad - d.grad[f0:f0 + fc]).abs().max() <= 1e-6
+
+
+def test_relfeat_full_size_cfg4_properties_and_oracle(oracle):
+    """BASELINE.json configs[3] size (16384 agents + 2000 obstacle points, 5 LDS tiles): structural
+    properties that need no reference, then the full bit-exact comparison with the oracle."""
+    from piml_amd import ops
+    N, M = 16384, 2000
+    sc = synthetic_gc_scene(N, M, seed=9)
+    args = (sc['position'], sc['velocity'], sc['acceleration'], sc['destination'], sc['obstacles'])
+    pf, of, df, pi, oi = [t.cpu().numpy() for t in ops.relative_features(*[dev(x) for x in args], return_index=True)]
+    p, o = sc['position'], sc['obstacles']
+    for feat, idx, src, thr in ((pf, pi, p, 4.0), (of, oi, o, 4.0)):
+        live = idx >= 0
+        d = np.linalg.norm(feat[..., :2], axis=-1)
+        assert np.all(d[live] <= thr + 1e-6)                                   # within the attention distance
+        assert np.all(np.diff(np.where(live, d, 1e30), axis=-1) >= -1e-6)      # slots ascend by distance
+        assert np.all(~live | (np.cumsum(~live, axis=-1) == 0))                # empty slots only at the tail
+        assert np.all(feat[~live] == 0)                                        # zero padding
+        rows = np.nonzero(live)
+        assert np.allclose(src[idx[live]] - p[rows[0]], feat[live][:, :2], atol=0)   # gathered = source - focal
+    absent = np.isnan(p[:, 0])
+    assert np.all(pi[absent] == -1) and np.all(oi[absent] == -1) and np.all(df[absent] == 0)
+    ref = oracle.relfeat_fwd(*[x[None] for x in args[:4]], args[4], return_index=True)
+    for got, want in zip((pf, of, df, pi, oi), ref[:5]):
+        want = want.reshape(got.shape)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

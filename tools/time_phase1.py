@@ -15,7 +15,7 @@ for N, M in ((4096, 2000), (16384, 2000), (4096, 0), (16384, 0)):
     for thr in (-1.0, 0.5, 4.0):
         def fwd():
             return L.piml_relfeat_fwd(p.data_ptr(), None, v.data_ptr(), a.data_ptr(), 2, d.data_ptr(), o.data_ptr(), 1, N, Me, 0, N,
-                                      6, 10, cp, cp, thr, thr, pf.data_ptr(), of.data_ptr(), df.data_ptr(), pi.data_ptr(), oi.data_ptr(), st)
+                                      6, 10, cp, cp, thr, thr, pf.data_ptr(), of.data_ptr(), df.data_ptr(), 2, pi.data_ptr(), oi.data_ptr(), st)
         for _ in range(10): fwd()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -18,7 +18,7 @@ for N, M, C in ((122, 100, 1), (1024, 100, 1), (4096, 2000, 1), (16384, 2000, 1)
 
     def fwd():
         return L.piml_relfeat_fwd(p.data_ptr(), None, v.data_ptr(), a.data_ptr(), 2, d.data_ptr(), o.data_ptr(), C, N, Me, 0, N,
-                                  6, 10, cp, co, 4.0, 4.0, pf.data_ptr(), of.data_ptr(), df.data_ptr(), pi.data_ptr(), oi.data_ptr(), st)
+                                  6, 10, cp, co, 4.0, 4.0, pf.data_ptr(), of.data_ptr(), df.data_ptr(), 2, pi.data_ptr(), oi.data_ptr(), st)
     gs = torch.zeros(*p.shape[:-1], 6, device=dev); gd = torch.empty_like(df)
     gp, go = torch.randn_like(pf), torch.randn_like(of)
 
