@@ -95,8 +95,8 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--agents', type=int, default=4096, help='focal agents per GPU')
     ap.add_argument('--obstacles', type=int, default=2000)
     ap.add_argument('--seed', type=int, default=0)

@@ -9,5 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- python3 $R/bench.py $ARGS > $O/l2.log 2>&1
-python3 $R/bench.py $ARGS > $O/bench.json 2> $O/bench.err
+python3 $R/bench.py --cpu-seconds 0 > $O/bench.json 2> $O/bench.err
 tail -c 300 $O/stats.log
