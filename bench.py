@@ -138,7 +138,7 @@ def main():
     _phase('tunableop setup done')
     from piml_amd import ops, _lib
     from piml_amd.models.model import PINNSF_multitask
-    from piml_amd.scenes import synthetic_gc_scene, pair_count, algorithmic_bytes
+    from piml_amd.scenes import synthetic_gc_scene
     from piml_amd.sharded import ShardedScene, allreduce_gradients
 
     n_own, M = args.agents, args.obstacles

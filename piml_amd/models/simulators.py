@@ -24,7 +24,6 @@ import types
 
 import numpy as np
 import torch
-import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops

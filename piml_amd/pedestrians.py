@@ -4,8 +4,6 @@ same method names / arguments / return conventions, backed by the HIP kernels.
 Drop-in point: `BaseSimulator(DATA.Pedestrians)` (src/models/simulators.py:25) and
 `TimeIndexedPedData(Dataset, Pedestrians)` (src/data/data.py:604) inherit from this class.
 """
-import torch
-
 from . import ops
 
 

@@ -3,7 +3,7 @@ reference (tests/golden/make_golden.py).  This is what pins the oracle."""
 import numpy as np
 import pytest
 
-from conftest import bits, canon_idx, golden, golden_names
+from conftest import bits, golden, golden_names
 
 
 @pytest.mark.parametrize('name', golden_names('relfeat_'))
