@@ -73,9 +73,13 @@ class BaseSimulator(Pedestrians):
     def set_ft_model(self, args):
         self.model = self._build(args, True)
 
+    def _capturable(self):
+        return str(self.args.device).startswith('cuda')        # Adam state on the device: graph-capturable
+
     def set_optimizer(self, args):
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=args.learning_rate,
-                                          weight_decay=args.weight_decay)
+                                          weight_decay=args.weight_decay, capturable=self._capturable())
+        self._graphed_steps = {}
 
     def set_ft_optimizer(self, args):
         if args.model == 'pinnsf_res':
@@ -85,11 +89,13 @@ class BaseSimulator(Pedestrians):
             self.optimizer = torch.optim.Adam(
                 [{'params': corr, 'lr': args.learning_rate * args.ft_lr_decay2},
                  {'params': rest, 'lr': args.learning_rate * args.finetune_lr_decay}],
-                lr=args.learning_rate, weight_decay=args.weight_decay)
+                lr=args.learning_rate, weight_decay=args.weight_decay, capturable=self._capturable())
         else:
             self.optimizer = torch.optim.Adam(self.model.parameters(),
                                               lr=args.learning_rate * args.finetune_lr_decay,
-                                              weight_decay=args.weight_decay * args.finetune_wd_aug)
+                                              weight_decay=args.weight_decay * args.finetune_wd_aug,
+                                              capturable=self._capturable())
+        self._graphed_steps = {}
 
     def set_scheduler(self, args):
         self.scheduler = None
@@ -122,7 +128,7 @@ class BaseSimulator(Pedestrians):
         T = pred.shape[1]
         steps = torch.arange(T, device=pred.device, dtype=pred.dtype)
         expo = steps if reverse else (T - 1 - steps)
-        decay = (torch.as_tensor(float(time_decay), device=pred.device, dtype=pred.dtype) ** expo).reshape(1, T, 1, 1)
+        decay = torch.pow(float(time_decay), expo).reshape(1, T, 1, 1)        # scalar base: no host-to-device copy
         return self.reduction((pred - labels) ** 2 * decay, reduction)
 
     def multiple_rollout_collision_avoidance_loss(self, pred, labels, time_decay, reduction='none'):
@@ -320,6 +326,17 @@ class BaseSimulator(Pedestrians):
 
     # ---- HOT LOOP C: differentiable rollout for fine-tuning (simulators.py:659-832) ----
     def test_multiple_rollouts_for_training(self, data, t_start=0):
+        """(loss, mse_loss, collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc,
+        reg_loss) of one batch of rollout windows, differentiable (simulators.py:659-832)."""
+        out, aux = self._training_rollout(data, t_start)
+        assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'  # :745
+        self.collision_count += aux['collisions'].item()
+        self.hard_collision_count += aux['hard_collisions'].item()
+        return out
+
+    def _training_rollout(self, data, t_start=0):
+        """The rollout + losses with no host synchronisation at all (capturable into a HIP graph);
+        returns the 7 loss tensors and the device-side bookkeeping (NaN flag, collision totals)."""
         args = self.args
         dt = data.time_unit
         waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
@@ -393,13 +410,10 @@ class BaseSimulator(Pedestrians):
             pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)       # :772-776, differentiable
             state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]      # :778-779
 
-        assert not bool(nan_seen), f'find nan in epoch : {self.epoch} {self.batch_idx}'  # :745
-
         if args.new_collision_loss_flag:                                      # :782-788
             collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
-        self.collision_count += torch.sum(collisions).item()
-        self.hard_collision_count += torch.sum(hard_collisions).item()
+        aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions)}
 
         pad = [torch.zeros_like(p_steps[0])] * t_start
         p_res = torch.stack(pad + p_steps, dim=1)                             # c, t, n, 2
@@ -431,7 +445,8 @@ class BaseSimulator(Pedestrians):
                                                          reduction='sum') * args.collision_pred_weight
             collision_pred_acc = torch.sum(torch.round(pred_collisions) == true_collision) / true_collision.numel()
             loss = loss + collision_pred_loss
-        return loss, mse_loss, collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc, reg_loss
+        return (loss, mse_loss, collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc,
+                reg_loss), aux
 
     # ---- pointwise evaluation and the Adam loop (simulators.py:291-440) ----
     def test_pointwise(self, data):
@@ -442,13 +457,74 @@ class BaseSimulator(Pedestrians):
             loss = torch.mean(self.loss_func(pred, labels[:, 4:6])).item()
         return loss, loss
 
+    _BATCH_TENSORS = ('ped_features', 'obs_features', 'self_features', 'labels', 'mask_p', 'mask_p_pred', 'position',
+                      'velocity', 'acceleration', 'destination', 'dest_idx', 'waypoints', 'dest_num', 'obstacles',
+                      'abnormal_mask')
+
+    def _graphed_rollout_step(self, batch):
+        """Whole fine-tuning step (zero_grad, T-frame differentiable rollout, losses, backward, Adam)
+        replayed from ONE captured HIP graph.  One graph per batch geometry; the batch is copied into
+        the graph's static input buffers.  Weights / Adam state touched by the warm-up iterations are
+        restored before capture, so training is step-for-step the eager sequence."""
+        key = tuple((k, tuple(getattr(batch, k).shape)) for k in self._BATCH_TENSORS) + (id(self.optimizer),)
+        entry = self._graphed_steps.get(key)
+        if entry is None:
+            static = types.SimpleNamespace(**{k: v for k, v in batch.__dict__.items() if not isinstance(v, torch.Tensor)})
+            for k in self._BATCH_TENSORS:
+                setattr(static, k, getattr(batch, k).clone())
+            params = [p for g in self.optimizer.param_groups for p in g['params']]
+            saved_p = [p.detach().clone() for p in params]
+            saved_s = {id(p): {k: v.clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
+                       for p in params}
+
+            def one_step():
+                self.optimizer.zero_grad(set_to_none=True)
+                out, aux = self._training_rollout(static)
+                out[0].backward()
+                self.optimizer.step()
+                return out, aux
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    one_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():                         # undo the warm-up updates, in place
+                for p, sp in zip(params, saved_p):
+                    p.copy_(sp)
+                    for k, v in self.optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            v.copy_(saved_s[id(p)][k]) if k in saved_s[id(p)] else v.zero_()
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, aux = one_step()
+            entry = (graph, static, out, aux)
+            self._graphed_steps[key] = entry
+        graph, static, out, aux = entry
+        for k in self._BATCH_TENSORS:
+            getattr(static, k).copy_(getattr(batch, k))
+        graph.replay()
+        return out, aux
+
     def train_batch(self, batch_data):
         """One optimiser step on either batch type (the body of simulators.py:314-360).
         Returns the dict of scalar logs of this batch."""
         args = self.args
-        self.optimizer.zero_grad()
         log = {}
-        if hasattr(batch_data, 'mask_p_pred') and hasattr(batch_data, 'waypoints'):       # channelled windows
+        channelled = hasattr(batch_data, 'mask_p_pred') and hasattr(batch_data, 'waypoints')
+        if channelled and getattr(args, 'hip_graph', True) and batch_data.position.is_cuda:
+            out, aux = self._graphed_rollout_step(batch_data)
+            assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'
+            self.collision_count += aux['collisions'].item()
+            self.hard_collision_count += aux['hard_collisions'].item()
+            names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')
+            log.update({k: float(v.detach()) for k, v in zip(names, out)})
+            log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
+            return log
+        self.optimizer.zero_grad()
+        if channelled:                                                                     # channelled windows
             out = self.test_multiple_rollouts_for_training(batch_data)
             loss = out[0]
             names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')

@@ -315,6 +315,9 @@ def collision_detection(position, threshold, real_position=None):
     return coll
 
 
+_THRESHOLDS = {}
+
+
 def collision_counts(position, thresholds):
     """collision_detection(position (S,N,2), thr).sum(-1) for several thresholds in one sweep,
     without the (S,N,N) matrices.  Returns (len(thresholds), S, N)."""
@@ -322,7 +325,10 @@ def collision_counts(position, thresholds):
     if p.dim() != 3:
         raise ValueError('position must be (S, N, 2)')
     S, N = p.shape[0], p.shape[1]
-    thr = torch.tensor([float(t) for t in thresholds], device=p.device, dtype=torch.float32)
+    key = (p.device, tuple(float(t) for t in thresholds))
+    thr = _THRESHOLDS.get(key)
+    if thr is None:                 # cached: a host-to-device copy is not capturable into a graph
+        thr = _THRESHOLDS[key] = torch.tensor(key[1], device=p.device, dtype=torch.float32)
     counts = torch.empty(len(thresholds), S, N, device=p.device, dtype=torch.float32)
     with torch.cuda.device(p.device):
         _lib.check(_lib.lib().piml_collision_counts(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(counts),

@@ -146,3 +146,27 @@ def test_two_stream_forward_equals_single_stream():
         torch.cuda.synchronize()
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_graphed_train_step_equals_eager():
+    """The captured whole fine-tuning step (rollout + losses + backward + Adam) reproduces the eager
+    step sequence: same losses, same weights after several updates."""
+    import time
+    g = golden('rollout')
+    data = load_data(g, 'train_pinnsf_m')
+    runs = {}
+    for graph in (False, True):
+        sim = make_sim(g, sim_args(learning_rate=1e-3, hip_graph=graph), 'train_pinnsf_m/sd/')
+        losses = [sim.train_batch(data)['loss'] for _ in range(6)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            sim.train_batch(data)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        print(f'fine-tune step C=4 T=5 N=122, graph={graph}: {dt * 1e3:.2f} ms/step')
+        runs[graph] = (losses, [p.detach().clone() for p in sim.model.parameters()], sim.collision_count)
+    assert np.allclose(runs[True][0], runs[False][0], rtol=1e-5), (runs[True][0], runs[False][0])
+    assert runs[True][2] == runs[False][2]
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
