@@ -30,6 +30,14 @@
 
 static inline float norm2f(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 
+ORACLE_API void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
