@@ -181,3 +181,50 @@ def test_relfeat_full_size_cfg4_properties_and_oracle(oracle):
     for got, want in zip((pf, of, df, pi, oi), ref[:5]):
         want = want.reshape(got.shape)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_relfeat_fuzz_small_scenes_vs_oracle(oracle):
+    """200 random small scenes with random k / sight angles / thresholds, NaN agents, standing agents
+    and LATTICE positions (many exact distance ties, exercising the lowest-index tie rule), all slices
+    of a batch in one launch: features, indices bit-exact against the oracle."""
+    from piml_amd import ops
+    rng = np.random.default_rng(2024)
+    for case in range(200):
+        N = int(rng.integers(1, 70))
+        M = int(rng.choice([0, 1, 3, 17, 64, 130]))
+        C = int(rng.choice([1, 1, 2, 5]))
+        lattice = case % 3 == 0
+        if lattice:
+            p = rng.integers(0, 6, size=(C, N, 2)).astype(np.float32) * 0.5
+            o = rng.integers(0, 6, size=(max(M, 1), 2)).astype(np.float32) * 0.5 + 0.25
+        else:
+            p = (rng.random((C, N, 2)) * 6).astype(np.float32)
+            o = (rng.random((max(M, 1), 2)) * 6).astype(np.float32)
+        o = o[:M] if M else np.zeros((0, 2), np.float32)
+        v = rng.standard_normal((C, N, 2)).astype(np.float32)
+        if lattice:
+            v = np.round(v)                        # axis-aligned / zero headings: cos exactly on thresholds
+        v[rng.random((C, N)) < 0.15] = 0
+        a = rng.standard_normal((C, N, 2)).astype(np.float32)
+        d = (rng.random((C, N, 2)) * 6).astype(np.float32)
+        absent = rng.random((C, N)) < 0.15
+        p[absent] = np.nan
+        d[absent] = np.nan
+        if case % 7 == 0:
+            a[rng.random((C, N)) < 0.2] = np.nan
+        kw = dict(topk_ped=int(rng.integers(0, 9)), topk_obs=int(rng.integers(0, 13)),
+                  sight_angle_ped=float(rng.choice([0, 45, 90, 100, 180, 270])),
+                  sight_angle_obs=float(rng.choice([30, 90, 120, 180])),
+                  dist_threshold_ped=float(rng.choice([0, 0.5, 1.0, 2.5, 4, 100])),
+                  dist_threshold_obs=float(rng.choice([0.5, 1.5, 4, 100])))
+        if M == 0:
+            o_oracle = np.zeros((0, 2), np.float32)
+        ref = oracle.relfeat_fwd(p[:, None], v[:, None], a[:, None], d[:, None], o, return_index=True, **kw)
+        out = ops.relative_features(dev(p), dev(v), dev(a), dev(d), dev(o), return_index=True, **kw)
+        for got, want in zip(out, ref[:5]):
+            got = got.cpu().numpy()
+            want = want.reshape(got.shape)
+            if got.dtype == np.int32:
+                assert np.array_equal(got, want), (case, N, M, C, kw)
+            else:
+                assert np.array_equal(bits(got), bits(want)), (case, N, M, C, kw)
