@@ -103,6 +103,38 @@ def _phase(msg):
         print(f'[bench +{time.perf_counter() - _T0:7.2f}s] {msg}', file=sys.stderr, flush=True)
 
 
+def secondary_measurements(scene, n, dev, _lib):
+    """Back-to-back launches of the other HIP kernels of the path on the first `n` agents of the scene,
+    timed with HIP events (informational; not part of `value`).  MLAPM byte model: 16 B per pair + 36 B
+    per agent."""
+    from piml_amd import ops
+    ok = ~np.isnan(scene['position'][:n, 0])
+    p, v, v0, d = [torch.tensor(scene[k][:n][ok], device=dev) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    m = p.shape[0]
+    gc = dict(version='GC', tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56)      # src/main_mlapm.py:16
+
+    def timed(fn, reps=50):
+        for _ in range(5):
+            fn()
+        tm = _lib.StreamTimer()
+        tm.start()
+        for _ in range(reps):
+            fn()
+        tm.stop()
+        return tm.elapsed_ms() * 1e3 / reps
+    fwd_us = timed(lambda: ops.mlapm_step(p, v, v0, d, 0.08, 0.3, **gc))
+    leaves = [x.clone().requires_grad_(True) for x in (p, v, v0, d)]
+    act = ops.mlapm_step(*leaves, 0.08, 0.3, **gc)
+    w = torch.ones_like(act)
+    bwd_us = timed(lambda: torch.autograd.grad(act, leaves, w, retain_graph=True), reps=30)
+    bytes_fwd = 16 * m * m + 36 * m
+    return {'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
+                              'pairs_per_s_fwd': m * m / fwd_us * 1e6,
+                              'roofline_frac_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
+                                      'present agents of the same scene; host-inclusive event timing of back-to-back launches'}}
+
+
 def main():
     # stdout must carry exactly ONE JSON line: anything libraries print to fd 1 (e.g. RCCL's version
     # banner) is sent to stderr, and the result is written to the saved stdout at the very end
@@ -119,6 +151,7 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the cpu_baseline leg')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured HIP graph')
+    ap.add_argument('--secondary', type=int, default=1, help='also report MLAPM step / relfeat backward kernel figures')
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
@@ -323,6 +356,11 @@ def main():
     alg_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own   # this rank's launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
+    # ---- secondary figures, measured after (outside) the timed region, rank 0 only ----
+    secondary = None
+    if rank == 0 and args.secondary:
+        secondary = secondary_measurements(scene, n_own, dev, _lib)
+
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r01_relfeat_traffic.json')
     if world == 1 and os.path.exists(tpath):
@@ -355,6 +393,8 @@ def main():
                                  'the sources are LDS/L2 resident, so frac > 1 is possible and HBM traffic '
                                  'is far below the model (see DESIGN.md)'},
         }
+        if secondary is not None:
+            out['secondary'] = secondary
         if args.cpu_seconds > 0 and world == 1:
             out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
         elif world > 1:
