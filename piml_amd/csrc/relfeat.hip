@@ -33,7 +33,8 @@ struct RelfeatArgs {
     int C, N, M, f0, fcnt, kp, ko;
     float cos_p, cos_o, cut2_p, cut2_o, dthr_p, dthr_o;
     float* ped_feat; float* obs_feat; float* dest_feat; int dest_ld; int* ped_idx; int* obs_idx;
-    int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates}
+    int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates,
+                  // 7 phase stamps (cycles): entry, [tile staged, pass done] per pass ..., + 1 pad}
 };
 
 // ---- sorted top-k list, one entry per lane: (distance bits, source index) ----
@@ -115,6 +116,9 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
 
 #ifdef PIML_RELFEAT_STATS
     int st_evals = 0, st_rounds = 0, st_ins = 0, st_cand = 0;
+    unsigned long long st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int st_n = 0;
+    st_t[st_n++] = __builtin_amdgcn_s_memtime();
 #define PIML_STAT(x) x
 #else
 #define PIML_STAT(x)
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                 tile_x[t] = q.x; tile_y[t] = q.y;
             }
             __syncthreads();
+            PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
             if (!alive || k <= 0) continue;
 
             // one extra trip (j0 == tn_pad) appends nothing and flushes the ring, because the
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                 }
             }
         }
+        PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
         const u64 mine = list_d == kEmptyDist ? kEmptyKey : (u64)list_i;
         if (pass == 0) lists[0] = mine; else lists[1] = mine;
     }
@@ -234,8 +240,9 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     if (!has) return;
 #ifdef PIML_RELFEAT_STATS
     if (A.stats && lane == 0) {
-        int* o = A.stats + ((size_t)c * A.fcnt + fl) * 4;
+        int* o = A.stats + ((size_t)c * A.fcnt + fl) * 12;
         o[0] = st_evals; o[1] = st_rounds; o[2] = st_ins; o[3] = st_cand;
+        for (int q = 0; q < 7; ++q) o[4 + q] = (int)(st_t[q] - st_t[0]);   // cycles since kernel entry of this wave
     }
 #endif
 
