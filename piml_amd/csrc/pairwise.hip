@@ -299,6 +299,72 @@ __global__ __launch_bounds__(256) void collision_counts_kernel(const float2* __r
     }
 }
 
+// Fast path of collision_counts for stacks of at most 25 slices (the training rollouts: S = number
+// of windows in the batch): a pair can then collide in at most 25 slices, so the friends rule
+// (sum over slices <= 25, data.py:587-591) never removes anything and every slice is independent.
+// One wavefront per (slice, agent); the slice's positions are staged in an LDS tile
+// (structure-of-arrays, ds_read_b128), all thresholds are counted in one sweep, and "|r| < thr" is
+// decided exactly in the squared domain (largest float whose correctly rounded sqrt is < thr).
+constexpr int kCollTile = 4096;
+constexpr int kCollMaxThr = 4;
+
+__device__ __forceinline__ float sq_below(float thr) {       // max { y : sqrtf(y) < thr }, thr > 0
+    if (!(thr > 0.f)) return -1.f;
+    float y = thr * thr;
+    while (sqrtf(y) >= thr && y > 0.f) y = __uint_as_float(__float_as_uint(y) - 1u);
+    while (sqrtf(__uint_as_float(__float_as_uint(y) + 1u)) < thr) y = __uint_as_float(__float_as_uint(y) + 1u);
+    return sqrtf(y) < thr ? y : -1.f;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
+        const float2* __restrict__ p, int S, int N, const float* __restrict__ thr, int nthr,
+        float* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) float tx[kCollTile], ty[kCollTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bps = (N + WAVES - 1) / WAVES;
+    const int s = blockIdx.x / bps;
+    const int i = (blockIdx.x - s * bps) * WAVES + wave;
+    const bool has = i < N;
+    const float2 pi = p[(size_t)s * N + (has ? i : 0)];
+    float cut[kCollMaxThr];
+#pragma unroll
+    for (int h = 0; h < kCollMaxThr; ++h) cut[h] = h < nthr ? sq_below(thr[h]) : -1.f;
+    int cnt[kCollMaxThr] = {0, 0, 0, 0};
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (int base = 0; base < N; base += kCollTile) {
+        const int tn = min(kCollTile, N - base), tn_pad = (tn + 255) & ~255;
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
+            float2 q = make_float2(qnan, qnan);
+            if (t < tn) q = p[(size_t)s * N + base + t];
+            tx[t] = q.x; ty[t] = q.y;
+        }
+        __syncthreads();
+        if (!has) continue;
+        for (int j0 = 0; j0 < tn_pad; j0 += 256) {
+            const float4 x = *reinterpret_cast<const float4*>(&tx[j0 + 4 * lane]);
+            const float4 y = *reinterpret_cast<const float4*>(&ty[j0 + 4 * lane]);
+            const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d2 = sq2(xs[u] - pi.x, ys[u] - pi.y);            // NaN compares false
+                const bool other = base + j0 + 4 * lane + u != i;             // diagonal: 1 - 1 = 0
+#pragma unroll
+                for (int h = 0; h < kCollMaxThr; ++h) cnt[h] += (other && d2 <= cut[h]) ? 1 : 0;
+            }
+        }
+    }
+    if (!has) return;
+#pragma unroll
+    for (int h = 0; h < kCollMaxThr; ++h) {
+        int c = cnt[h];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0 && h < nthr) counts[((size_t)h * S + s) * N + i] = (float)c;
+    }
+}
+
 // calculate_collision_label (data.py:514-535): any tau in {0,.1,...,.9} with 0 != |dp + dv tau| < 0.5
 __global__ void collision_label_kernel(const float* __restrict__ feat, size_t R, int ld, float* __restrict__ label) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,6 +494,17 @@ PIML_API int piml_collision_counts(const float* position, int S, int N, const fl
     if (S < 0 || N < 0 || n_thresholds < 0) return hipErrorInvalidValue;
     if ((long)S * N * n_thresholds == 0) return hipSuccess;
     if (!position || !thresholds || !counts) return hipErrorInvalidValue;
+    if (S <= 25 && n_thresholds <= kCollMaxThr) {          // independent slices: streaming fast path
+        const int waves = (long)S * N >= 4096 ? 16 : 4;
+        const unsigned grid = (unsigned)(S * ((N + waves - 1) / waves));
+        if (waves == 16)
+            hipLaunchKernelGGL(collision_counts_fast_kernel<16>, dim3(grid), dim3(1024), 0, as_stream(stream),
+                               (const float2*)position, S, N, thresholds, n_thresholds, counts);
+        else
+            hipLaunchKernelGGL(collision_counts_fast_kernel<4>, dim3(grid), dim3(256), 0, as_stream(stream),
+                               (const float2*)position, S, N, thresholds, n_thresholds, counts);
+        return hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)n_thresholds * S * N, as_stream(stream));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(collision_counts_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),

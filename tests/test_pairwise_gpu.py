@@ -141,3 +141,18 @@ def test_calc_acceleration_matches_reference(ver, ds):
         out = calc_acceleration(dev(feat), ver, ds).cpu().numpy()
         ref = g[f'{tag}_{ver}_{ds}']
         assert np.allclose(out, ref, rtol=1e-5, atol=1e-6), np.abs(out - ref).max()
+
+
+def test_collision_counts_fast_path_equals_general_and_oracle(oracle):
+    """S <= 25 takes the streaming kernel, S > 25 the general one (friends rule active): both against
+    the oracle's collision_detection(...).sum(-1), incl. a multi-tile N and thresholds on exact distances."""
+    from piml_amd import ops
+    rng = np.random.default_rng(5)
+    for S, N in ((4, 700), (1, 5000), (25, 130), (26, 130), (40, 90)):
+        p = (rng.integers(0, 40, size=(S, N, 2)) * 0.25).astype(np.float32)        # lattice: d == thr happens
+        p[rng.random((S, N)) < 0.1] = np.nan
+        thr = (0.5, 0.25, 1.0)
+        got = ops.collision_counts(dev(p), thr).cpu().numpy()
+        for h, t in enumerate(thr):
+            want = oracle.collision_detection(p, t).sum(-1)
+            assert np.array_equal(got[h], want), (S, N, t)
