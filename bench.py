@@ -391,6 +391,7 @@ def main():
                          'event_pair_overhead_us': overhead_ms * 1e3, 'kernel_samples': len(kernel_ms_samples),
                          'algorithmic_bytes': alg_bytes,
                          'traffic_source': 'profiles/r01_relfeat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' if traffic else None,
+                         'interval_includes_allgather': bool(use_dist),
                          'note': 'operand-stream byte model (24 B/ped pair + 8 B/obstacle pair + 488 B/focal); '
                                  'the sources are LDS/L2 resident, so frac > 1 is possible and HBM traffic '
                                  'is far below the model (see DESIGN.md)'},

@@ -194,6 +194,9 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                     const unsigned n = min(64u, tail - head);
                     PIML_STAT(++st_evals; st_cand += (int)n;)
                     const bool act = (unsigned)lane < n;
+                    // the ring is written and read by different lanes of THIS wave only: LDS operations of a
+                    // wave complete in order, the barrier below just pins the compiler's ordering
+                    __builtin_amdgcn_wave_barrier();
                     const int jl = act ? (int)ring[(head + lane) & (kRing - 1)] : 0;
                     head = uniform((int)(head + n));
                     const float rx = tile_x[jl] - pix, ry = tile_y[jl] - piy;
