@@ -407,7 +407,47 @@ def gen_metrics():
     save('metrics', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics)
+def gen_rollout_more():
+    """More HOT LOOP C cases: the UCY configuration (tau = 5/6, no obstacles -> 2-point placeholder) and
+    the residual fine-tune network (`--model pinnsf_res` after set_ft_model)."""
+    import models.simulators as SIM
+    out = {}
+    for tag, path, model_name, ds, wins in (('ucy_m', UCY_CLIP, 'pinnsf_m', 'ucy', [100, 230, 360, 500]),
+                                            ('gc_res', GC_CLIP, 'pinnsf_res', 'gc1560', [300, 420])):
+        raw = load_raw(path)
+        args = sim_args(model=model_name, dataset_name=ds, valid_steps=6)
+        full = DATA.TimeIndexedPedData()
+        full.make_dataset(args, raw)
+        full.set_dataset_info(full, raw, list(range(len(full))))
+        cdata = full.to_channeled_time_index_data(args.valid_steps, 'slice')
+        batch = DATA.ChanneledTimeIndexedPedData.slice(cdata, wins)
+        for k in DATA_FIELDS:
+            if torch.is_tensor(getattr(batch, k)):
+                setattr(batch, k, getattr(batch, k).clone())
+        torch.manual_seed(666)
+        sim = SIM.BaseSimulator(args)
+        if model_name == 'pinnsf_res':
+            torch.manual_seed(667)
+            sim.set_ft_model(args)
+        sim.model.eval()
+        sim.collision_count = sim.hard_collision_count = 0
+        sim.epoch = sim.batch_idx = 0
+        for k, v in sim.model.state_dict().items():
+            out[f'{tag}/sd/{k}'] = v.clone()
+        dump_data(tag, batch, out)
+        res = sim.test_multiple_rollouts_for_training(batch)
+        res[0].backward()
+        out[f'{tag}/scalars'] = np.array([float(x.detach()) for x in res], np.float64)
+        out[f'{tag}/counts'] = np.array([sim.collision_count, sim.hard_collision_count], np.float64)
+        gsum = {k: (torch.zeros(()) if p.grad is None else p.grad.abs().sum()) for k, p in sim.model.named_parameters()}
+        for k, p in sim.model.named_parameters():
+            if k.startswith(('ped_encoder.mlp.0', 'obs_encoder.mlp.4', 'ped_predictor', 'corrector.2')):
+                out[f'{tag}/grad/{k}'] = torch.zeros_like(p) if p.grad is None else p.grad.clone()
+        out[f'{tag}/grad_abs_sum'] = np.float64(sum(float(v) for v in gsum.values()))
+    save('rollout_more', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)

@@ -170,3 +170,34 @@ def test_graphed_train_step_equals_eager():
     assert runs[True][2] == runs[False][2]
     for a, b in zip(runs[True][1], runs[False][1]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,model_name,ds,finetune', [('ucy_m', 'pinnsf_m', 'ucy', False),
+                                                        ('gc_res', 'pinnsf_res', 'gc1560', True)])
+def test_training_rollout_more_configs(tag, model_name, ds, finetune):
+    """UCY configuration (tau = 5/6, 2-point obstacle placeholder, k_o = 2) and the residual fine-tune
+    network of `--model pinnsf_res`, against the reference's scalars and gradients."""
+    from piml_amd.models.simulators import BaseSimulator
+    g = golden('rollout_more')
+    args = sim_args(model=model_name, dataset_name=ds, valid_steps=6)
+    sim = BaseSimulator(args)
+    if finetune:
+        sim.set_ft_model(args)
+    sd = {k[len(tag) + 4:]: torch.tensor(g[k]) for k in g.files if k.startswith(f'{tag}/sd/')}
+    sim.model.load_state_dict(sd, strict=True)
+    sim.model.eval()
+    data = load_data(g, tag)
+    out = sim.test_multiple_rollouts_for_training(data)
+    out[0].backward()
+    got = np.array([float(x.detach()) for x in out])
+    assert np.allclose(got, g[f'{tag}/scalars'], rtol=2e-4, atol=1e-6), (got, g[f'{tag}/scalars'])
+    assert [sim.collision_count, sim.hard_collision_count] == list(g[f'{tag}/counts'])
+    named = dict(sim.model.named_parameters())
+    for k in g.files:
+        if k.startswith(f'{tag}/grad/'):
+            ref_g = g[k]
+            p = named[k[len(tag) + 6:]]
+            got_g = np.zeros_like(ref_g) if p.grad is None else p.grad.cpu().numpy()
+            assert np.abs(got_g - ref_g).max() <= 2e-3 * max(np.abs(ref_g).max(), 1e-6), k
+    total = sum(float(p.grad.abs().sum()) for p in named.values() if p.grad is not None)
+    assert np.isclose(total, float(g[f'{tag}/grad_abs_sum']), rtol=2e-3)
