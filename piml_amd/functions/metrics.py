@@ -109,3 +109,23 @@ def mmd_with_time_mask(p, q, mask, kernel_mul=2.0, kernel_num=5, fix_sigma=None,
     if reduction == 'mean':
         return loss.mean().item()
     return loss.tolist()
+
+
+def fde_with_time_mask(p_pred, labels, mask_p_pred, reduction='mean'):
+    """Final displacement error: L2 error at each agent's LAST masked frame of a (t, n, 2) rollout.
+    The reference only reports the mean displacement (its "MAE", = ADE); BASELINE.json's config 5
+    asks for ADE/FDE, so the FDE of the same masks is provided alongside."""
+    m = mask_p_pred == 1                                                     # t, n
+    T = m.shape[0]
+    ar = torch.arange(T, device=m.device).unsqueeze(1)
+    last = torch.where(m, ar, -1).max(0).values                              # n, -1 = never predicted
+    has = last >= 0
+    idx = last.clamp(min=0)
+    cols = torch.arange(m.shape[1], device=m.device)
+    err = torch.norm(p_pred[idx, cols] - labels[idx, cols], p=2, dim=-1)
+    err = torch.where(has, torch.nan_to_num(err), torch.zeros_like(err))
+    if reduction == 'sum':
+        return err.sum().item()
+    if reduction == 'mean':
+        return (err.sum() / has.sum().clamp(min=1)).item()
+    return err
