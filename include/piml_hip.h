@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 4
+#define PIML_HIP_ABI_VERSION 5
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -108,13 +108,15 @@ int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const flo
  *   2 = 'UCY' (with the one-line coll.unsqueeze(-1) fix the shipped code needs for N > 2);
  *   tau, A, B, C, D, theta_deg = self.args[...]; radius, dt = step() arguments.
  * Outputs: action (N, 2) = velocity + force * dt; force (N, 2) optional (NULL to skip).
- * Like the reference, a NaN position poisons every row: filter absent agents first
- * (src/main_mlapm.py:19-25 does).
+ * skip_absent = 0: like the reference, a NaN position poisons every row (its callers filter absent
+ * agents first, src/main_mlapm.py:19-25).  skip_absent = 1: agents with a NaN position are treated
+ * as absent -- they exert no force and their own action is NaN -- which replaces that host-side
+ * compaction and keeps shapes static (graph-capturable simulation loop).
  */
 int piml_mlapm_step_fwd(const float* position, const float* velocity, const float* desired_speed,
                         const float* destination, int N, int variant, float tau, float A, float B,
-                        float C, float D, float theta_deg, float radius, float dt, float* action,
-                        float* force, void* stream);
+                        float C, float D, float theta_deg, float radius, float dt, int skip_absent,
+                        float* action, float* force, void* stream);
 
 /*
  * Analytic gradient of piml_mlapm_step_fwd (what autograd gives through mlapm.py:10-58):

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -22,7 +22,7 @@ SIGNATURES = {
     'piml_heading_fwd': [_p, _i, _i, _i, _p, _p],
     'piml_relfeat_fwd': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                          _p, _p, _p, _i, _p, _p, _p],
-    'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p],
+    'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p, _p],
     'piml_mlapm_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p],
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
     'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],

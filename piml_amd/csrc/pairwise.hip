@@ -18,6 +18,7 @@ struct MlapmParams {
     int variant;                 // 0 raw, 1 GC, 2 UCY (mlapm.py:28-53)
     float tau, A, B, Cc, D, cth, sth, r2;   // cos/sin of theta, 2*radius
     float B2, C2, D2;            // B, C, D pre-multiplied by log2(e): exp(x) = exp2(x * log2 e)
+    int skip_absent;             // 1: sources with a NaN position contribute nothing (absent agents)
 };
 
 // MLAPM is a smooth force law checked to 1e-5 relative (not a discrete selection like relfeat), so
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         if (!has) continue;
         for (int j = lane; j < tn; j += 64) {
             const float4 s = tile[j];
+            if (P.skip_absent && (s.x != s.x || s.y != s.y)) continue;      // absent source
             const float2 t = mlapm_pair(P, s.x - pi.x, s.y - pi.y, s.z - vi.x, s.w - vi.y, vi.x, vi.y, ex, ey);
             sx += t.x; sy += t.y;
         }
@@ -403,8 +405,9 @@ __global__ void calc_acceleration_kernel(const float* __restrict__ rel, size_t R
 }
 
 static MlapmParams make_params(int variant, float tau, float A, float B, float Cc, float D, float theta_deg,
-                               float radius) {
+                               float radius, int skip_absent = 0) {
     MlapmParams P;
+    P.skip_absent = skip_absent;
     P.variant = variant; P.tau = tau; P.A = A; P.B = B; P.Cc = Cc; P.D = D;
     // the reference forms theta = sign * theta / 180 * pi in float32 (mlapm.py:34)
     const float th = theta_deg / 180.f * 3.14159265358979323846f;
@@ -421,12 +424,12 @@ using namespace piml;
 
 PIML_API int piml_mlapm_step_fwd(const float* position, const float* velocity, const float* desired_speed,
                                  const float* destination, int N, int variant, float tau, float A, float B,
-                                 float C, float D, float theta_deg, float radius, float dt, float* action,
-                                 float* force, void* stream) {
+                                 float C, float D, float theta_deg, float radius, float dt, int skip_absent,
+                                 float* action, float* force, void* stream) {
     if (N < 0 || variant < 0 || variant > 2) return hipErrorInvalidValue;
     if (N == 0) return hipSuccess;
     if (!position || !velocity || !desired_speed || !destination || !action) return hipErrorInvalidValue;
-    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
+    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius, skip_absent);
     // big scenes: 16-wave workgroups (the whole (p,v) array is staged once per workgroup)
     if (N >= 4096)
         hipLaunchKernelGGL(mlapm_fwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),

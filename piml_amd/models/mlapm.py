@@ -18,3 +18,47 @@ class MLAPM:
         return ops.mlapm_step(position, velocity, desired_speed, destination, dt, radius, version=a['version'],
                               tau=a['tau'], A=a['A'], B=a['B'], C=a.get('C', 0.0), D=a.get('D', 0.0),
                               theta=a.get('theta', 0.0))
+
+    def rollout(self, position, velocity, desired_speed, destination, dt, radius=0.3, steps=200, use_graph=True):
+        """The simulation loop of src/main_mlapm.py:18-36 on the device: step, explicit Euler
+        `p += v dt`, and agents within `radius` of their destination leave the scene (NaN from the next
+        frame on).  The reference compacts the active agents on the host every step; here absent
+        agents stay in place as NaN rows (`skip_absent`), so shapes are static and one captured
+        HIP-graph step is replayed.  Returns positions and velocities (steps + 1, N, 2)."""
+        import torch
+        a = self.args
+        p, v = position.clone(), velocity.clone()
+        N = p.shape[0]
+        traj_p = torch.full((steps + 1, N, 2), float('nan'), device=p.device)
+        traj_v = torch.full((steps + 1, N, 2), float('nan'), device=p.device)
+        traj_p[0], traj_v[0] = p, v
+        t = torch.ones(1, dtype=torch.long, device=p.device)
+        nan = torch.tensor(float('nan'), device=p.device)
+
+        def one():
+            v_new = ops.mlapm_step(p, v, desired_speed, destination, dt, radius, version=a['version'], tau=a['tau'],
+                                   A=a['A'], B=a['B'], C=a.get('C', 0.0), D=a.get('D', 0.0),
+                                   theta=a.get('theta', 0.0), skip_absent=True)
+            p_new = p + v_new * dt
+            traj_p.index_copy_(0, t, p_new.unsqueeze(0))
+            traj_v.index_copy_(0, t, v_new.unsqueeze(0))
+            arrived = (torch.norm(p_new - destination, dim=-1, keepdim=True) < radius)
+            p.copy_(torch.where(arrived, nan, p_new))
+            v.copy_(torch.where(arrived, nan, v_new))
+            t.add_(1)
+        done = 0
+        with torch.no_grad():
+            if use_graph and p.is_cuda and steps > 4:
+                for _ in range(2):
+                    one()
+                done = 2
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one()
+                for _ in range(steps - done):
+                    g.replay()
+                done = steps
+            for _ in range(steps - done):
+                one()
+        return traj_p, traj_v

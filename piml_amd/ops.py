@@ -231,7 +231,7 @@ MLAPM_VARIANTS = {'raw': 0, 'GC': 1, 'UCY': 2}
 class _MlapmStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, position, velocity, desired_speed, destination, variant, tau, A, B, C, D, theta,
-                radius, dt):
+                radius, dt, skip_absent):
         p = _gpu_f32('position', position)
         v = _gpu_f32('velocity', velocity)
         d = _gpu_f32('destination', destination)
@@ -244,7 +244,8 @@ class _MlapmStep(torch.autograd.Function):
         action = torch.empty_like(p)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().piml_mlapm_step_fwd(_ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau, A, B,
-                                                      C, D, theta, radius, dt, _ptr(action), None, _stream()),
+                                                      C, D, theta, radius, dt, int(skip_absent), _ptr(action), None,
+                                                      _stream()),
                        'piml_mlapm_step_fwd')
         ctx.save_for_backward(p, v, v0, d)
         ctx.params = (variant, tau, A, B, C, D, theta, radius, dt)
@@ -263,17 +264,18 @@ class _MlapmStep(torch.autograd.Function):
             _lib.check(_lib.lib().piml_mlapm_step_bwd(_ptr(g), _ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau,
                                                       A, B, C, D, theta, radius, dt, _ptr(gp), _ptr(gv), _ptr(gv0),
                                                       _ptr(gd), _stream()), 'piml_mlapm_step_bwd')
-        return (gp, gv, gv0.reshape(ctx.v0_shape), gd) + (None,) * 9
+        return (gp, gv, gv0.reshape(ctx.v0_shape), gd) + (None,) * 10
 
 
 def mlapm_step(position, velocity, desired_speed, destination, dt, radius=0.3, version='GC', tau=0.5,
-               A=0.0, B=0.0, C=0.0, D=0.0, theta=0.0):
-    """MLAPM.step (src/models/mlapm.py:10-58) on the GPU; differentiable (analytic backward)."""
+               A=0.0, B=0.0, C=0.0, D=0.0, theta=0.0, skip_absent=False):
+    """MLAPM.step (src/models/mlapm.py:10-58) on the GPU; differentiable (analytic backward; with
+    skip_absent the gradient is only defined for scenes without NaN agents)."""
     if version not in MLAPM_VARIANTS:
         raise NotImplementedError(version)
     return _MlapmStep.apply(position, velocity, desired_speed, destination, MLAPM_VARIANTS[version],
                             float(tau), float(A), float(B), float(C), float(D), float(theta), float(radius),
-                            float(dt))
+                            float(dt), bool(skip_absent))
 
 
 # ------------------------------------------------------------------------------------------

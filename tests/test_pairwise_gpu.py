@@ -156,3 +156,46 @@ def test_collision_counts_fast_path_equals_general_and_oracle(oracle):
         for h, t in enumerate(thr):
             want = oracle.collision_detection(p, t).sum(-1)
             assert np.array_equal(got[h], want), (S, N, t)
+
+
+def test_mlapm_rollout_matches_host_compaction_loop(oracle):
+    """The device-side simulation loop (absent agents kept as NaN rows, one captured step replayed)
+    against the reference's loop structure (src/main_mlapm.py:18-36: compact the active agents on the
+    host, step, Euler, arrival mask) driven by the oracle."""
+    import time
+    g = golden('mlapm')
+    m = mlapm_model(g, 'GC')
+    tau, A, B, C, D, theta = g['GC_params']
+    p0, v0_, spd, dst = g['GC_N7_p'], g['GC_N7_v'], g['GC_N7_v0'], g['GC_N7_dest']
+    steps, dt, radius = 200, 0.08, 0.3
+    traj_p, traj_v = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps)
+    eager_p, _ = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps, use_graph=False)
+    assert torch.equal(torch.nan_to_num(traj_p), torch.nan_to_num(eager_p))
+    # host loop with compaction, as the reference does it
+    N = p0.shape[0]
+    p, v = p0.copy(), v0_.copy()
+    mask = np.ones(N, bool)
+    ref = np.full((steps + 1, N, 2), np.nan, np.float32)
+    ref[0] = p
+    for t in range(1, steps + 1):
+        if not mask.any():
+            break
+        vn = oracle.mlapm_step(p[mask], v[mask], spd[mask], dst[mask], dt, radius, version='GC', tau=tau, A=A, B=B,
+                               C=C, D=D, theta=theta)
+        pn = p[mask] + vn * np.float32(dt)
+        p[mask], v[mask] = pn, vn
+        ref[t][mask] = pn
+        mask &= ~(np.linalg.norm(p - dst, axis=-1) < radius)
+    got = traj_p.cpu().numpy()
+    assert np.array_equal(np.isnan(got[..., 0]), np.isnan(ref[..., 0]))       # same arrival frames
+    assert np.isnan(got[-1]).all()                                            # everybody arrives within 200 steps
+    assert np.nanmax(np.abs(got[:60] - ref[:60])) < 1e-4
+    assert np.nanmax(np.abs(got - ref)) < 5e-3
+    # throughput of the closed-form simulator at the bench scene size
+    sc = synthetic_gc_scene(4096, 0, seed=0, nan_frac=0.02)
+    args = [dev(sc[k]) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    m.rollout(*args, dt, radius, 20)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.rollout(*args, dt, radius, 300)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    print(f'MLAPM GC rollout N=4096: {300 / el:.0f} steps/s')
