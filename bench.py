@@ -208,7 +208,13 @@ def main():
 
     torch.manual_seed(666)
     model = PINNSF_multitask(model_args()).to(dev).eval()   # eval: dropout off, deterministic
-    if args.two_streams:
+    # The obstacle branch of the MLP on a side stream makes two GEMM chains run concurrently inside the
+    # captured graph (+20 %).  Concurrent library GEMMs are only safe with kernels that never wait for
+    # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some of these shapes
+    # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
+    # pre-tuned selections are validated for this; without them the branches stay on one stream.
+    two_streams = bool(args.two_streams) and gemm_tuning == 'tunableop-file'
+    if two_streams:
         model.obs_stream = torch.cuda.Stream()
     params = [p for p in model.parameters()]
     ones = torch.ones(n_own, 2, device=dev)
@@ -273,6 +279,15 @@ def main():
                 rest(*feats)
             static_feats = feats     # the captured step's feature / index buffers stay alive
             graph[0].replay(); graph[1].replay()
+            done = torch.cuda.Event()
+            done.record()
+            t_wait = time.perf_counter()
+            while not done.query():       # watchdog: a replay that never completes must not hang the run
+                if time.perf_counter() - t_wait > 30.0:
+                    print('[bench] FATAL: captured step did not complete within 30 s (deadlocked kernels); '
+                          're-run with --graph 0 or --two-streams 0', file=sys.stderr, flush=True)
+                    os._exit(3)
+                time.sleep(0.001)
             torch.cuda.synchronize()
         except Exception as ex:   # noqa: BLE001 - any capture problem means: run eagerly
             print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
@@ -378,7 +393,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'steps_per_s': args.steps / elapsed,
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if args.two_streams else 1,
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
             'config': {'workload': 'cfg3: synthetic GC scene, forward+backward PINSF step '
                                    '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,

@@ -44,9 +44,11 @@ def _gather_waypoints(waypoints, dest_idx):
 class BaseSimulator(Pedestrians):
     """Same constructor contract as the reference: `args` is the argparse namespace of src/main.py."""
 
-    # below this many (slice, agent) rows the fork / join of a side stream costs more than the overlap
-    # of the two MLP branches gains (measured: 122-agent clip slower, 4096-agent scene 1.3x faster)
-    SIDE_STREAM_MIN_ROWS = 2048
+    # Opt-in (args.mlp_side_stream_rows = minimum number of (slice, agent) rows): run the obstacle branch of
+    # the MLP on a side stream inside captured graphs.  Measured 1.3x on a 4096-agent rollout, slower on
+    # the 122-agent clip.  OFF by default: two library GEMMs running concurrently can deadlock when the
+    # BLAS heuristics pick stream-K style kernels (see bench.py); enable only with validated GEMM selections.
+    SIDE_STREAM_MIN_ROWS = None
 
     def __init__(self, args):
         super().__init__()
@@ -76,6 +78,10 @@ class BaseSimulator(Pedestrians):
 
     def set_ft_model(self, args):
         self.model = self._build(args, True)
+
+    def _side_stream_ok(self, rows):
+        limit = getattr(self.args, 'mlp_side_stream_rows', self.SIDE_STREAM_MIN_ROWS)
+        return limit is not None and rows >= limit
 
     def _capturable(self):
         return str(self.args.device).startswith('cuda')        # Adam state on the device: graph-capturable
@@ -307,7 +313,7 @@ class BaseSimulator(Pedestrians):
         done = 0
         if use_graph and steps > 3:
             try:
-                if st.p.numel() // 2 >= self.SIDE_STREAM_MIN_ROWS:   # obstacle branch in parallel inside the graph
+                if self._side_stream_ok(st.p.numel() // 2):   # obstacle branch in parallel inside the graph
                     self.model.obs_stream = torch.cuda.Stream()
                 for _ in range(2):                        # real frames, also warm every lazy init up
                     step_fn(data, st)
@@ -493,7 +499,7 @@ class BaseSimulator(Pedestrians):
                 return out, aux
             # inside the graph the obstacle branch of the MLP runs on a side stream (parallel chains of
             # small kernels); eager execution keeps a single stream
-            if static.position.numel() // 2 // static.position.shape[1] >= self.SIDE_STREAM_MIN_ROWS:
+            if self._side_stream_ok(static.position.numel() // 2 // static.position.shape[1]):
                 self.model.obs_stream = torch.cuda.Stream()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
