@@ -213,7 +213,10 @@ def main():
     # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some of these shapes
     # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
     # pre-tuned selections are validated for this; without them the branches stay on one stream.
-    two_streams = bool(args.two_streams) and gemm_tuning == 'tunableop-file'
+    # (multi-rank runs keep one stream as well: RCCL kernels + concurrent branches inside a captured graph
+    # could not be validated on the single-GPU development box; --two-streams 2 forces it)
+    two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and not (world > 1)) \
+        or args.two_streams == 2
     if two_streams:
         model.obs_stream = torch.cuda.Stream()
     params = [p for p in model.parameters()]
