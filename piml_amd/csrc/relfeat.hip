@@ -398,7 +398,7 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     // Workgroup size: every workgroup stages the whole source array once, so bigger groups cut
     // L2->LDS traffic, while smaller groups shorten the barrier tails (the per-wave work is
     // data dependent) and spread small launches over more CUs.
-    int waves = rows >= 16384 ? 8 : (rows >= 4096 ? 16 : 4);   // measured on MI355X (tools/time_phase1.py)
+    int waves = rows >= 16384 ? 8 : (rows >= 4096 ? 16 : (rows >= 1024 ? 8 : 4));   // measured (tools/time_*.py)
     if (const char* e = getenv("PIML_RELFEAT_WAVES")) waves = atoi(e);
     const int bpc = (focal_count + waves - 1) / waves;
     const dim3 grid((unsigned)(C * bpc)), block((unsigned)(waves * 64));
