@@ -318,7 +318,7 @@ __device__ __forceinline__ float sq_below(float thr) {       // max { y : sqrtf(
     return sqrtf(y) < thr ? y : -1.f;
 }
 
-template <int WAVES>
+template <int WAVES, int NTHR>
 __global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
         const float2* __restrict__ p, int S, int N, const float* __restrict__ thr, int nthr,
         float* __restrict__ counts) {
@@ -329,10 +329,10 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
     const int i = (blockIdx.x - s * bps) * WAVES + wave;
     const bool has = i < N;
     const float2 pi = p[(size_t)s * N + (has ? i : 0)];
-    float cut[kCollMaxThr];
+    float cut[NTHR];
+    int cnt[NTHR];
 #pragma unroll
-    for (int h = 0; h < kCollMaxThr; ++h) cut[h] = h < nthr ? sq_below(thr[h]) : -1.f;
-    int cnt[kCollMaxThr] = {0, 0, 0, 0};
+    for (int h = 0; h < NTHR; ++h) { cut[h] = sq_below(thr[h]); cnt[h] = 0; }
     const float qnan = __uint_as_float(0x7fc00000u);
     for (int base = 0; base < N; base += kCollTile) {
         const int tn = min(kCollTile, N - base), tn_pad = (tn + 255) & ~255;
@@ -353,17 +353,17 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
                 const float d2 = sq2(xs[u] - pi.x, ys[u] - pi.y);            // NaN compares false
                 const bool other = base + j0 + 4 * lane + u != i;             // diagonal: 1 - 1 = 0
 #pragma unroll
-                for (int h = 0; h < kCollMaxThr; ++h) cnt[h] += (other && d2 <= cut[h]) ? 1 : 0;
+                for (int h = 0; h < NTHR; ++h) cnt[h] += (other && d2 <= cut[h]) ? 1 : 0;
             }
         }
     }
     if (!has) return;
 #pragma unroll
-    for (int h = 0; h < kCollMaxThr; ++h) {
+    for (int h = 0; h < NTHR; ++h) {
         int c = cnt[h];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0 && h < nthr) counts[((size_t)h * S + s) * N + i] = (float)c;
+        if (lane == 0) counts[((size_t)h * S + s) * N + i] = (float)c;
     }
 }
 
@@ -500,12 +500,15 @@ PIML_API int piml_collision_counts(const float* position, int S, int N, const fl
     if (S <= 25 && n_thresholds <= kCollMaxThr) {          // independent slices: streaming fast path
         const int waves = (long)S * N >= 4096 ? 16 : 4;
         const unsigned grid = (unsigned)(S * ((N + waves - 1) / waves));
-        if (waves == 16)
-            hipLaunchKernelGGL(collision_counts_fast_kernel<16>, dim3(grid), dim3(1024), 0, as_stream(stream),
-                               (const float2*)position, S, N, thresholds, n_thresholds, counts);
-        else
-            hipLaunchKernelGGL(collision_counts_fast_kernel<4>, dim3(grid), dim3(256), 0, as_stream(stream),
-                               (const float2*)position, S, N, thresholds, n_thresholds, counts);
+#define PIML_CC_LAUNCH(W, T)                                                                                   \
+    hipLaunchKernelGGL((collision_counts_fast_kernel<W, T>), dim3(grid), dim3(W * 64), 0, as_stream(stream),   \
+                       (const float2*)position, S, N, thresholds, n_thresholds, counts)
+#define PIML_CC_BY_T(W)                                                                                        \
+    switch (n_thresholds) { case 1: PIML_CC_LAUNCH(W, 1); break; case 2: PIML_CC_LAUNCH(W, 2); break;         \
+                            case 3: PIML_CC_LAUNCH(W, 3); break; default: PIML_CC_LAUNCH(W, 4); break; }
+        if (waves == 16) { PIML_CC_BY_T(16) } else { PIML_CC_BY_T(4) }
+#undef PIML_CC_BY_T
+#undef PIML_CC_LAUNCH
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)n_thresholds * S * N, as_stream(stream));
