@@ -176,22 +176,15 @@ def main():
     # PyTorch-ROCm TunableOp: pick the rocBLAS / hipBLASLt solution per GEMM shape of the PINNSF
     # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
     # done here).  A file whose validators do not match this software stack is ignored by torch.
-    tuned = os.path.join(ROOT, 'piml_amd', 'tuning', 'tunableop_gfx950_cfg3.csv')
-    gemm_tuning = 'default'
-    if args.tunableop and os.path.exists(tuned):
-        try:
-            torch.cuda.tunable.enable(True)
-            torch.cuda.tunable.tuning_enable(False)
-            torch.cuda.tunable.record_untuned_enable(False)
-            gemm_tuning = 'tunableop-file' if torch.cuda.tunable.read_file(tuned) else 'default'
-        except Exception as ex:   # noqa: BLE001
-            print(f'[bench] TunableOp results not loaded ({ex})', file=sys.stderr)
+    from piml_amd import tuning
+    gemm_tuning = 'tunableop-file' if (args.tunableop and tuning.load()) else 'default'
 
     _phase('tunableop setup done')
     from piml_amd import ops, _lib
     from piml_amd.models.model import PINNSF_multitask
     from piml_amd.scenes import synthetic_gc_scene
-    from piml_amd.sharded import ShardedScene, allreduce_gradients
+    from piml_amd.sharded import (ShardedScene, allreduce_gradients, flatten_gradients, gather_records_into,
+                                  reduce_scatter_grad, unflatten_gradients)
 
     n_own, M = args.agents, args.obstacles
     N = n_own * world
@@ -213,10 +206,9 @@ def main():
     # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some of these shapes
     # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
     # pre-tuned selections are validated for this; without them the branches stay on one stream.
-    # (multi-rank runs keep one stream as well: RCCL kernels + concurrent branches inside a captured graph
-    # could not be validated on the single-GPU development box; --two-streams 2 forces it)
-    two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and not (world > 1)) \
-        or args.two_streams == 2
+    # (multi-rank runs: the collectives are issued outside the captured graph, so the graph holds the
+    # same kernels as on one GPU and the same rule applies)
+    two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file') or args.two_streams == 2
     if two_streams:
         model.obs_stream = torch.cuda.Stream()
     params = [p for p in model.parameters()]
@@ -236,6 +228,34 @@ def main():
             allreduce_gradients(params, sh.group)
         return acc
 
+    # Sharded + graph: only the COMPUTE of a step is captured; the three collectives (all-gather of the
+    # records, reduce-scatter of d/d(state), all-reduce of the weight gradients) are issued eagerly on
+    # the stream either side of the replay.  `state_all` is the graph's static input: the all-gather
+    # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
+    state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
+    grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
+
+    def features_local():
+        return ops.relative_features_packed(state_all, dest_own, obstacles, b0, n_own, return_index=True)
+
+    def rest_local(pf, of, df, *_idx):
+        own = state_all[b0:b0 + n_own]
+        self_features = torch.cat((df, own[:, 2:4], own[:, 4:6], v0_own), dim=-1)
+        acc = model(pf, of, self_features)[0]
+        acc.backward(ones)
+        bucket[:] = flatten_gradients(params)       # captured: one concatenation into a static bucket
+        return acc
+
+    bucket = [None, None]
+
+    def exchange_forward():
+        gather_records_into(state_all, state_own, sh.group)
+
+    def exchange_backward():
+        reduce_scatter_grad(state_all.grad, sh.group, out=grad_own)
+        dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=sh.group)
+        unflatten_gradients(*bucket)
+
     def step_body(timer=None):
         """One forward + backward pass of the hot path over the scene."""
         if timer is not None:
@@ -247,6 +267,8 @@ def main():
 
     def reset_grads():
         state_own.grad = None
+        if state_all is not None:
+            state_all.grad = None
         for p in params:
             p.grad = None
 
@@ -276,12 +298,17 @@ def main():
             # record events inside a captured graph).  One autograd pass spans both captures.
             g_timer = _lib.StreamTimer()
             graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+            if use_dist:
+                exchange_forward()
+                torch.cuda.synchronize()
             with torch.cuda.graph(graph[0]):
-                feats = features()
+                feats = features_local() if use_dist else features()
             with torch.cuda.graph(graph[1], pool=graph[0].pool()):
-                rest(*feats)
+                (rest_local if use_dist else rest)(*feats)
             static_feats = feats     # the captured step's feature / index buffers stay alive
             graph[0].replay(); graph[1].replay()
+            if use_dist:
+                exchange_backward()
             done = torch.cuda.Event()
             done.record()
             t_wait = time.perf_counter()
@@ -312,23 +339,22 @@ def main():
     def run_step(i, timed):
         if graph is not None:
             sample = timed and i % sample_every == 0
-            if not use_dist:
-                # the forward graph holds exactly one kernel: launch it directly into the captured
-                # buffers.  On sampled steps it is launched twice and the HIP events bracket the
-                # SECOND launch, so the interval holds one kernel behind another kernel rather than
-                # the idle gap that follows the previous graph replay.
-                ops.relative_features_packed_into(static_feats, state_own, dest_own, obstacles, b0, n_own)
-                if sample:
-                    g_timer.start()
-                    ops.relative_features_packed_into(static_feats, state_own, dest_own, obstacles, b0, n_own)
-                    g_timer.stop()
-            else:
-                if sample:
-                    g_timer.start()
-                graph[0].replay()                     # all-gather + relfeat forward
-                if sample:
-                    g_timer.stop()
+            # the forward graph holds exactly one kernel: launch it directly into the captured
+            # buffers.  On sampled steps it is launched twice and the HIP events bracket the
+            # SECOND launch, so the interval holds one kernel behind another kernel rather than
+            # the idle gap that follows the previous graph replay.
+            src = state_own
+            if use_dist:
+                exchange_forward()
+                src = state_all
+            ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
+            if sample:
+                g_timer.start()
+                ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
+                g_timer.stop()
             graph[1].replay()
+            if use_dist:
+                exchange_backward()
             if sample:     # read this step's event pair (syncs on `stop` only)
                 # calibration: an empty start/stop pair right behind the step measures what the two
                 # event records themselves add to an interval on this stream
@@ -409,7 +435,7 @@ def main():
                          'event_pair_overhead_us': overhead_ms * 1e3, 'kernel_samples': len(kernel_ms_samples),
                          'algorithmic_bytes': alg_bytes,
                          'traffic_source': 'profiles/r01_relfeat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' if traffic else None,
-                         'interval_includes_allgather': bool(use_dist),
+                         'interval_includes_allgather': bool(use_dist) and graph is None,
                          'note': 'operand-stream byte model (24 B/ped pair + 8 B/obstacle pair + 488 B/focal); '
                                  'the sources are LDS/L2 resident, so frac > 1 is possible and HBM traffic '
                                  'is far below the model (see DESIGN.md)'},

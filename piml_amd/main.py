@@ -67,6 +67,7 @@ def get_args(argv=None):
     A('--dataset_name', type=str, default='ucy'); A('--true_label_weight', type=float, default=0)
     A('--collision_loss_version', type=str, default='v0')
     A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
+    A('--tunableop', type=int, default=0, help='1: load the pre-tuned GEMM selections (piml_amd/tuning)')
     args = p.parse_args(argv)
     args.model_name_suffix = ''.join(random.sample(list(string.ascii_lowercase) + list(string.digits), 8))
     return args
@@ -82,6 +83,9 @@ def set_exp_configs(args):
 def main(argv=None):
     args = get_args(argv)
     set_exp_configs(args)
+    if args.tunableop:
+        from . import tuning
+        print('pre-tuned GEMM selections loaded:', tuning.load())
     start_time = time.time()
 
     synthetic = DATASET.PointwisePedDataset()

@@ -65,19 +65,57 @@ def all_gather_records(own, group=None):
     return _AllGatherRecords.apply(own, group if group is not None else dist.group.WORLD)
 
 
-def allreduce_gradients(parameters, group=None, average=False):
-    """One flat bucket for all parameter gradients (134 k floats for pinnsf_m = 0.5 MB)."""
+def gather_records_into(full, own, group=None):
+    """Plain (non-autograd) all-gather into a caller-owned (N, w) buffer.  With `reduce_scatter_grad`
+    this is the exchange pair for steps whose compute part is replayed from a captured HIP graph: the
+    two collectives run eagerly on the stream either side of the replay and `full` is the graph's
+    static input (a leaf whose .grad the graph's backward fills)."""
+    with torch.no_grad():
+        dist.all_gather_into_tensor(full.detach(), own.detach().contiguous(), group=group)
+    return full
+
+
+def reduce_scatter_grad(g_full, group=None, out=None):
+    """Sum the ranks' partial (N, w) gradients and return this rank's (n, w) rows."""
+    group = group if group is not None else dist.group.WORLD
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = g_full.shape[0] // world
+    if out is None:
+        out = torch.empty((n,) + tuple(g_full.shape[1:]), device=g_full.device, dtype=g_full.dtype)
+    if _supports_reduce_scatter(group):
+        dist.reduce_scatter_tensor(out, g_full.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    else:   # gloo (CPU tests) has no reduce-scatter
+        summed = g_full.clone()
+        dist.all_reduce(summed, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(summed[rank * n:(rank + 1) * n])
+    return out
+
+
+def flatten_gradients(parameters):
+    """One flat bucket holding all parameter gradients (134 k floats for pinnsf_m = 0.5 MB).
+    Returns (flat, grads); capturable in a HIP graph (one concatenation kernel)."""
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
+        return None, grads
+    return torch.cat([g.reshape(-1) for g in grads]), grads
+
+
+def unflatten_gradients(flat, grads):
+    """Write the reduced bucket back into the .grad tensors (one multi-tensor copy)."""
+    if flat is None:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+def allreduce_gradients(parameters, group=None, average=False):
+    """Bucketed all-reduce (sum, or mean with `average`) of the parameter gradients."""
+    flat, grads = flatten_gradients(parameters)
+    if flat is None:
+        return
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat /= dist.get_world_size(group)
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    unflatten_gradients(flat, grads)
 
 
 class ShardedScene:

@@ -1,0 +1,27 @@
+"""Pre-tuned GEMM selections for the PINNSF MLP (PyTorch-ROCm TunableOp result files).
+
+`tunableop_gfx950_cfg3.csv` was produced once on an MI355X with PYTORCH_TUNABLEOP_TUNING=1 over the
+GEMM shapes of the 4096-agent step (24 576 / 40 960 / 4 096 rows x 6 / 64 / 128 columns, forward
+and backward); tuning takes minutes and is never repeated at run time.  torch ignores a file whose
+validators (torch / ROCm / hipBLASLt / rocBLAS versions, GPU architecture) do not match."""
+import os
+import sys
+
+import torch
+
+DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tunableop_gfx950_cfg3.csv')
+
+
+def load(path=DEFAULT_FILE):
+    """Enable TunableOp in look-up-only mode with the given result file.  Returns True when torch
+    accepted the file (then, and only then, its selections are in effect)."""
+    if not os.path.exists(path):
+        return False
+    try:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.record_untuned_enable(False)
+        return bool(torch.cuda.tunable.read_file(path))
+    except Exception as ex:   # noqa: BLE001 - a missing / changed API means: stay on the defaults
+        print(f'[piml_amd] TunableOp results not loaded ({ex})', file=sys.stderr)
+        return False

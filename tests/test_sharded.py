@@ -97,8 +97,30 @@ def worker(rank, port, q):
         (acc * sh.own(w)).sum().backward()
         params = list(model.parameters())
         allreduce_gradients(params, sh.group)
-        q.put((rank, acc.detach().numpy(), state_own.grad.numpy(),
-               [None if p.grad is None else p.grad.numpy() for p in params]))
+        first = (acc.detach().numpy(), state_own.grad.numpy().copy(),
+                 [None if p.grad is None else p.grad.numpy().copy() for p in params])
+
+        # the same step with the exchange pair used around a captured compute graph (bench.py):
+        # plain all-gather into a static leaf, local forward + backward, reduce-scatter of leaf.grad
+        from piml_amd.sharded import gather_records_into, reduce_scatter_grad
+        for p in params:
+            p.grad = None
+        state_all = torch.zeros(N, 6).requires_grad_(True)
+        gather_records_into(state_all, state_own, sh.group)
+        assert np.array_equal(state_all.detach().numpy(), state.numpy(), equal_nan=True)
+        pf, of, df = feature_fn(state_all, sh.own(dest), obs, sh.begin, sh.count)
+        own = sh.own(state_all)
+        acc2 = model(pf, of, torch.cat((df, own[:, 2:4], own[:, 4:6], sh.own(v0)), -1))[0]
+        (acc2 * sh.own(w)).sum().backward()
+        g_own = reduce_scatter_grad(state_all.grad, sh.group)
+        allreduce_gradients(params, sh.group)
+        assert np.allclose(acc2.detach().numpy(), first[0], rtol=1e-6, atol=1e-7)
+        assert np.allclose(g_own.numpy(), first[1], rtol=1e-5, atol=1e-6)
+        for p, ref in zip(params, first[2]):
+            assert (p.grad is None) == (ref is None)
+            if ref is not None:
+                assert np.allclose(p.grad.numpy(), ref, rtol=1e-5, atol=1e-6)
+        q.put((rank,) + first)
     finally:
         dist.destroy_process_group()
 
