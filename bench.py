@@ -221,7 +221,7 @@ def main():
 
     def rest(pf, of, df, *_idx):
         """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
-        self_features = torch.cat((df, state_own[:, 2:4], state_own[:, 4:6], v0_own), dim=-1)
+        self_features = ops.self_features_packed(df, state_own, v0_own)
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
         if sh is not None:
@@ -239,8 +239,7 @@ def main():
         return ops.relative_features_packed(state_all, dest_own, obstacles, b0, n_own, return_index=True)
 
     def rest_local(pf, of, df, *_idx):
-        own = state_all[b0:b0 + n_own]
-        self_features = torch.cat((df, own[:, 2:4], own[:, 4:6], v0_own), dim=-1)
+        self_features = ops.self_features_packed(df, state_all[b0:b0 + n_own], v0_own)
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
         bucket[:] = flatten_gradients(params)       # captured: one concatenation into a static bucket

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 5
+#define PIML_HIP_ABI_VERSION 6
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -193,6 +193,57 @@ int piml_rollout_step(float* position, float* velocity, float* acceleration, flo
                       float* acceleration_out, float* mask_out, float* self_features_next,
                       const float* desired_speed, const int64_t* frame_counter, int C, int T, int N,
                       float dt, int remove_arrived, void* stream);
+
+/*
+ * Glue of the PINNSF network around its (PyTorch-ROCm / rocBLAS) GEMMs -- SURVEY.md row a8:
+ * "only the desired-force term and k-sum are candidates to fuse".  The GEMMs stay in torch.
+ *
+ * piml_pinnsf_epilogue_fwd/bwd: the tail of every PINNSF.forward,
+ *   predictions = acc_ped + acc_obs + (v0 * dest/|dest| - v) / tau     (src/models/model.py:1289-1294)
+ * on rows of self_features = [dest - p (2), v (2), a (2), v0 (1)] (7 floats, contiguous), with the
+ * reference's guard |dest| == 0 -> |dest| + 0.1.  The per-row norm only (2-D input, or
+ * fix_dest_norm): the channelled dim=1 quirk (Q2) stays a torch expression.  acc_obs may be NULL.
+ * bwd: g_self (rows,7) from g_out (rows,2); d/d(acc_ped) = d/d(acc_obs) = g_out (no kernel).
+ */
+int piml_pinnsf_epilogue_fwd(const float* acc_ped, const float* acc_obs, const float* self_features,
+                             size_t rows, float tau, float* out, void* stream);
+int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_features, size_t rows, float tau,
+                             float* g_self, void* stream);
+
+/*
+ * self_features rows for the model from the packed state: out (rows,7) = [dest_feat (ld dest_ld),
+ * state[:, 2:6] (v, a; interleaved (p,v,a) records, 6 floats), desired_speed] -- the torch.cat at
+ * src/models/simulators.py:648-650 / 777-779.  bwd splits g_self into g_dest (rows,2),
+ * g_state (rows,6; position columns zero) and g_speed (rows).
+ */
+int piml_self_features_fwd(const float* dest_feat, int dest_ld, const float* state, const float* desired_speed,
+                           size_t rows, float* out, void* stream);
+int piml_self_features_bwd(const float* g_self, size_t rows, float* g_dest, float* g_state, float* g_speed,
+                           void* stream);
+
+/*
+ * Backward glue of one Linear(+ReLU) layer: g_pre = g * [y > 0] (y = the layer's output; NULL: no
+ * activation, g_pre is not written) and bias gradient db[c] = sum_r g_pre[r,c], in ONE pass over
+ * g (replaces torch's threshold_backward + column reduce_kernel + its semaphore memset).
+ * g, y, g_pre: (rows, cols) row-major.  Deterministic two-level sum in a fixed order: slabs of rows ->
+ * `partials` (piml_colsum_blocks(rows, cols) * cols floats, caller-owned scratch; may be NULL when
+ * that count is 1), then one small second launch over the partials.  No atomics, no global state.
+ * cols <= 1024 when cols % 4 == 0, else cols <= 256.
+ */
+int piml_colsum_blocks(size_t rows, int cols);
+int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, float* g_pre, float* partials,
+                        float* db, void* stream);
+
+/*
+ * Neighbour-axis sum of the PINNSF processor output (src/models/model.py:1279-1283 with quirk Q3:
+ * processor(x) = scale * x, scale = 2 in eval mode): msgs = scale * e (rows,cols) and
+ * pooled[r / k] = sum over the k rows of one agent of msgs.  bwd: g_e = scale * (g_pooled[r / k] +
+ * g_msgs[r]) with g_msgs optional (NULL).  cols % 4 == 0.
+ */
+int piml_scale_ksum_fwd(const float* e, size_t agents, int k, int cols, float scale, float* msgs, float* pooled,
+                        void* stream);
+int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols, float scale,
+                        float* g_e, void* stream);
 
 /*
  * HIP-event timer for measuring a kernel live on the stream it is launched on, also while

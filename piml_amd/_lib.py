@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -31,6 +31,14 @@ SIGNATURES = {
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                           _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],
+    'piml_pinnsf_epilogue_bwd': [_p, _p, _z, _f, _p, _p],
+    'piml_self_features_fwd': [_p, _i, _p, _p, _z, _p, _p],
+    'piml_self_features_bwd': [_p, _z, _p, _p, _p, _p],
+    'piml_colsum_blocks': [_z, _i],
+    'piml_act_bwd_colsum': [_p, _p, _z, _i, _p, _p, _p, _p],
+    'piml_scale_ksum_fwd': [_p, _z, _i, _i, _f, _p, _p, _p],
+    'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],

@@ -1,0 +1,378 @@
+// Glue kernels around the PINNSF network's GEMMs (which stay rocBLAS / hipBLASLt calls made by
+// PyTorch-ROCm): the desired-force epilogue, the self-feature rows, the neighbour-axis sum and the
+// backward of Linear(+ReLU) minus its two GEMMs.  Reference: src/models/model.py:40-65 (MLP),
+// :1279-1294 (k-sum, desired force); SURVEY.md row a8.  All of them are single-pass, HBM/L2-bound
+// element streams; what they buy is the removal of ~60 launch-bound torch kernels per step.
+#include "common.hpp"
+#include "../../include/piml_hip.h"
+
+namespace piml {
+
+// ---------------------------------------------------------------------------------------------
+// predictions = acc_ped + acc_obs + (v0 * d / t - v) / tau,  t = |d| (+0.1 where |d| == 0)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pinnsf_epilogue_fwd_kernel(const float2* __restrict__ acc_ped,
+                                                                   const float2* __restrict__ acc_obs,
+                                                                   const float* __restrict__ sf, size_t rows, float tau,
+                                                                   float2* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* s = sf + r * 7;
+    const float dx = s[0], dy = s[1], vx = s[2], vy = s[3], v0 = s[6];
+    float t = norm2(dx, dy);
+    t = (t == 0.f) ? t + 0.1f : t;
+    float2 a = acc_ped[r];
+    if (acc_obs) {
+        const float2 o = acc_obs[r];
+        a.x += o.x;
+        a.y += o.y;
+    }
+    out[r] = make_float2(a.x + (v0 * (dx / t) - vx) / tau, a.y + (v0 * (dy / t) - vy) / tau);
+}
+
+// g_self from g_out.  e = d / t; g_e = g v0 / tau; g_d = g_e / t + g_t * d / n  (0 where n == 0),
+// g_t = -(g_e . d) / t^2; g_v = -g / tau; g_a = 0; g_v0 = (g . e) / tau.
+__global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* __restrict__ g_out,
+                                                                   const float* __restrict__ sf, size_t rows, float tau,
+                                                                   float* __restrict__ g_self) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* s = sf + r * 7;
+    const float dx = s[0], dy = s[1], v0 = s[6];
+    const float2 g = g_out[r];
+    const float n = norm2(dx, dy);
+    const float t = (n == 0.f) ? n + 0.1f : n;
+    const float ex = dx / t, ey = dy / t;
+    const float gex = g.x * v0 / tau, gey = g.y * v0 / tau;
+    const float gt = -(gex * dx + gey * dy) / (t * t);
+    float gdx = gex / t, gdy = gey / t;
+    if (n != 0.f) {
+        gdx += gt * (dx / n);
+        gdy += gt * (dy / n);
+    }
+    float* o = g_self + r * 7;
+    o[0] = gdx;
+    o[1] = gdy;
+    o[2] = -g.x / tau;
+    o[3] = -g.y / tau;
+    o[4] = 0.f;
+    o[5] = 0.f;
+    o[6] = (g.x * ex + g.y * ey) / tau;
+}
+
+// ---------------------------------------------------------------------------------------------
+// self_features rows = [dest_feat, v, a, v0]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void self_features_fwd_kernel(const float* __restrict__ dest_feat, int dest_ld,
+                                                                 const float* __restrict__ state,
+                                                                 const float* __restrict__ speed, size_t rows,
+                                                                 float* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* d = dest_feat + r * (size_t)dest_ld;
+    const float* s = state + r * 6;
+    float* o = out + r * 7;
+    o[0] = d[0];
+    o[1] = d[1];
+    o[2] = s[2];
+    o[3] = s[3];
+    o[4] = s[4];
+    o[5] = s[5];
+    o[6] = speed[r];
+}
+
+__global__ __launch_bounds__(256) void self_features_bwd_kernel(const float* __restrict__ g_self, size_t rows,
+                                                                 float2* __restrict__ g_dest,
+                                                                 float* __restrict__ g_state,
+                                                                 float* __restrict__ g_speed) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* g = g_self + r * 7;
+    if (g_dest) g_dest[r] = make_float2(g[0], g[1]);
+    if (g_state) {
+        float* o = g_state + r * 6;
+        o[0] = 0.f;
+        o[1] = 0.f;
+        o[2] = g[2];
+        o[3] = g[3];
+        o[4] = g[4];
+        o[5] = g[5];
+    }
+    if (g_speed) g_speed[r] = g[6];
+}
+
+// ---------------------------------------------------------------------------------------------
+// g_pre = g * [y > 0], db = column sums of g_pre
+// ---------------------------------------------------------------------------------------------
+constexpr int kColsumThreads = 256;
+constexpr int kColsumMaxBlocks = 2048;
+constexpr int kColsumSlabBytes = 16384;     // one slab = 4 float4 (or 16 float) loads per thread
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef float4 type;
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void add(float4& a, const float4& b) {
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    static __device__ __forceinline__ float4 mask(const float4& g, const float4& y) {
+        return make_float4(y.x <= 0.f ? 0.f : g.x, y.y <= 0.f ? 0.f : g.y, y.z <= 0.f ? 0.f : g.z,
+                           y.w <= 0.f ? 0.f : g.w);
+    }
+};
+template <>
+struct Vec<1> {
+    typedef float type;
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ void add(float& a, const float& b) { a += b; }
+    static __device__ __forceinline__ float mask(const float& g, const float& y) { return y <= 0.f ? 0.f : g; }
+};
+
+// Column sums of rows [r0, r1) of a (., lanes * V) matrix; MASK: apply the ReLU mask and store g_pre.
+// Returns this thread's partial (row group `grp`, column lane `lane`).
+template <int V, bool MASK>
+__device__ __forceinline__ typename Vec<V>::type colsum_rows(const float* __restrict__ g, const float* __restrict__ y,
+                                                             float* __restrict__ g_pre, size_t r0, size_t r1,
+                                                             int lanes, int groups, int lane, int grp) {
+    typedef typename Vec<V>::type T;
+    T acc = Vec<V>::zero();
+    const T* gp = reinterpret_cast<const T*>(g);
+    const T* yp = reinterpret_cast<const T*>(y);
+    T* op = reinterpret_cast<T*>(g_pre);
+    size_t r = r0 + grp;
+    const size_t step = (size_t)groups;
+    // four independent rows in flight per thread
+    for (; r + 3 * step < r1; r += 4 * step) {
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gp[(r + u * step) * lanes + lane];
+        if (MASK) {
+            T w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = yp[(r + u * step) * lanes + lane];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = Vec<V>::mask(v[u], w[u]);
+                op[(r + u * step) * lanes + lane] = v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec<V>::add(acc, v[u]);
+    }
+    for (; r < r1; r += step) {
+        T v = gp[r * lanes + lane];
+        if (MASK) {
+            v = Vec<V>::mask(v, yp[r * lanes + lane]);
+            op[r * lanes + lane] = v;
+        }
+        Vec<V>::add(acc, v);
+    }
+    return acc;
+}
+
+// sum the row groups of one block; valid in threads with grp == 0
+template <int V>
+__device__ __forceinline__ typename Vec<V>::type block_groups_sum(typename Vec<V>::type acc,
+                                                                  typename Vec<V>::type* sh, int lanes, int groups,
+                                                                  int lane, int grp, bool active) {
+    typedef typename Vec<V>::type T;
+    __syncthreads();
+    if (active) sh[grp * lanes + lane] = acc;
+    __syncthreads();
+    T s = Vec<V>::zero();
+    if (active && grp == 0)
+        for (int q = 0; q < groups; ++q) Vec<V>::add(s, sh[q * lanes + lane]);
+    return s;
+}
+
+// stage 1: one slab of rows per block -> partials[block] (or db itself when the grid is one block)
+template <int V, bool MASK>
+__global__ __launch_bounds__(kColsumThreads) void act_bwd_colsum_kernel(const float* __restrict__ g,
+                                                                        const float* __restrict__ y, size_t rows,
+                                                                        int cols, size_t rows_per_block,
+                                                                        float* __restrict__ g_pre,
+                                                                        float* __restrict__ partials,
+                                                                        float* __restrict__ db) {
+    typedef typename Vec<V>::type T;
+    __shared__ T sh[kColsumThreads];
+    const int lanes = cols / V;
+    const int groups = kColsumThreads / lanes;
+    const int lane = threadIdx.x % lanes, grp = threadIdx.x / lanes;
+    const bool active = grp < groups;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    const size_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    T acc = Vec<V>::zero();
+    if (active) acc = colsum_rows<V, MASK>(g, y, g_pre, r0, r1, lanes, groups, lane, grp);
+    const T s = block_groups_sum<V>(acc, sh, lanes, groups, lane, grp, active);
+    if (active && grp == 0)
+        reinterpret_cast<T*>(gridDim.x == 1 ? db : partials + (size_t)blockIdx.x * cols)[lane] = s;
+}
+
+// stage 2: block `lane` sums column lane `lane` of the (nb, lanes) partials in a fixed order
+template <int V>
+__global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const float* __restrict__ partials, int nb,
+                                                                       int lanes, float* __restrict__ db) {
+    typedef typename Vec<V>::type T;
+    __shared__ T sh[kColsumThreads];
+    const int lane = blockIdx.x;
+    const T* p = reinterpret_cast<const T*>(partials);
+    T acc = Vec<V>::zero();
+    for (int r = threadIdx.x; r < nb; r += kColsumThreads) Vec<V>::add(acc, p[(size_t)r * lanes + lane]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = kColsumThreads / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) Vec<V>::add(sh[threadIdx.x], sh[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) reinterpret_cast<T*>(db)[lane] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// msgs = scale * e ; pooled[agent] = sum_k msgs[agent, k]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __restrict__ e, size_t agents, int k,
+                                                              int lanes, float scale, float4* __restrict__ msgs,
+                                                              float4* __restrict__ pooled) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t agent = id / lanes;
+    const int lane = (int)(id % lanes);
+    if (agent >= agents) return;
+    const size_t base = agent * k * lanes + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < k; ++j) {
+        float4 v = e[base + (size_t)j * lanes];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        msgs[base + (size_t)j * lanes] = v;
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    pooled[agent * lanes + lane] = s;
+}
+
+__global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __restrict__ g_pooled,
+                                                              const float4* __restrict__ g_msgs, size_t agents, int k,
+                                                              int lanes, float scale, float4* __restrict__ g_e) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t agent = id / lanes;
+    const int lane = (int)(id % lanes);
+    if (agent >= agents) return;
+    const size_t base = agent * k * lanes + lane;
+    const float4 gp = g_pooled ? g_pooled[agent * lanes + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < k; ++j) {
+        float4 v = gp;
+        if (g_msgs) {
+            const float4 m = g_msgs[base + (size_t)j * lanes];
+            v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+        }
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        g_e[base + (size_t)j * lanes] = v;
+    }
+}
+
+inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+}  // namespace piml
+
+using namespace piml;
+
+PIML_API int piml_pinnsf_epilogue_fwd(const float* acc_ped, const float* acc_obs, const float* self_features,
+                                      size_t rows, float tau, float* out, void* stream) {
+    if (rows == 0) return hipSuccess;
+    if (!acc_ped || !self_features || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_fwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(acc_ped), reinterpret_cast<const float2*>(acc_obs),
+                       self_features, rows, tau, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_features, size_t rows, float tau,
+                                      float* g_self, void* stream) {
+    if (rows == 0) return hipSuccess;
+    if (!g_out || !self_features || !g_self) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(g_out), self_features, rows, tau, g_self);
+    return hipGetLastError();
+}
+
+PIML_API int piml_self_features_fwd(const float* dest_feat, int dest_ld, const float* state,
+                                    const float* desired_speed, size_t rows, float* out, void* stream) {
+    if (dest_ld < 2) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!dest_feat || !state || !desired_speed || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(self_features_fwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                       dest_feat, dest_ld, state, desired_speed, rows, out);
+    return hipGetLastError();
+}
+
+PIML_API int piml_self_features_bwd(const float* g_self, size_t rows, float* g_dest, float* g_state, float* g_speed,
+                                    void* stream) {
+    if (rows == 0) return hipSuccess;
+    if (!g_self) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(self_features_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream), g_self,
+                       rows, reinterpret_cast<float2*>(g_dest), g_state, g_speed);
+    return hipGetLastError();
+}
+
+PIML_API int piml_colsum_blocks(size_t rows, int cols) {
+    if (cols <= 0) return 0;
+    size_t slab = kColsumSlabBytes / (sizeof(float) * (size_t)cols);     // rows per block
+    if (slab < 1) slab = 1;
+    size_t b = (rows + slab - 1) / slab;
+    if (b < 1) b = 1;
+    if (b > (size_t)kColsumMaxBlocks) b = kColsumMaxBlocks;
+    return (int)b;
+}
+
+PIML_API int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, float* g_pre,
+                                 float* partials, float* db, void* stream) {
+    if (cols <= 0) return hipErrorInvalidValue;
+    const bool vec = (cols % 4 == 0);
+    if (vec ? cols > 1024 : cols > 256) return hipErrorInvalidValue;
+    if (!db) return hipErrorInvalidValue;
+    if (rows == 0) return hipMemsetAsync(db, 0, sizeof(float) * cols, as_stream(stream));
+    if (!g || (y && !g_pre)) return hipErrorInvalidValue;
+    const int nb = piml_colsum_blocks(rows, cols);
+    if (nb > 1 && !partials) return hipErrorInvalidValue;
+    const size_t rpb = (rows + nb - 1) / nb;
+#define PIML_COLSUM(V, MASK)                                                                                        \
+    hipLaunchKernelGGL((act_bwd_colsum_kernel<V, MASK>), dim3(nb), dim3(kColsumThreads), 0, as_stream(stream), g, y, \
+                       rows, cols, rpb, g_pre, partials, db)
+    if (vec) {
+        if (y) PIML_COLSUM(4, true); else PIML_COLSUM(4, false);
+        if (nb > 1)
+            hipLaunchKernelGGL(colsum_stage2_kernel<4>, dim3(cols / 4), dim3(kColsumThreads), 0, as_stream(stream),
+                               partials, nb, cols / 4, db);
+    } else {
+        if (y) PIML_COLSUM(1, true); else PIML_COLSUM(1, false);
+        if (nb > 1)
+            hipLaunchKernelGGL(colsum_stage2_kernel<1>, dim3(cols), dim3(kColsumThreads), 0, as_stream(stream),
+                               partials, nb, cols, db);
+    }
+#undef PIML_COLSUM
+    return hipGetLastError();
+}
+
+PIML_API int piml_scale_ksum_fwd(const float* e, size_t agents, int k, int cols, float scale, float* msgs,
+                                 float* pooled, void* stream) {
+    if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
+    if (agents == 0) return hipSuccess;
+    if (!e || !msgs || !pooled) return hipErrorInvalidValue;
+    const int lanes = cols / 4;
+    hipLaunchKernelGGL(scale_ksum_fwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(e), agents, k, lanes, scale, reinterpret_cast<float4*>(msgs),
+                       reinterpret_cast<float4*>(pooled));
+    return hipGetLastError();
+}
+
+PIML_API int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols,
+                                 float scale, float* g_e, void* stream) {
+    if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
+    if (agents == 0) return hipSuccess;
+    if (!g_e) return hipErrorInvalidValue;
+    const int lanes = cols / 4;
+    hipLaunchKernelGGL(scale_ksum_bwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(g_pooled), reinterpret_cast<const float4*>(g_msgs), agents, k,
+                       lanes, scale, reinterpret_cast<float4*>(g_e));
+    return hipGetLastError();
+}

@@ -17,8 +17,16 @@ Reference behaviours kept on purpose:
 Deviation: in train mode the reference calls Dropout once per (discarded) block; here only the
 surviving block is evaluated, so the RNG stream differs (eval mode is exact).
 """
+import os
+
 import torch
 import torch.nn as nn
+
+# On the GPU the elementwise / reduction glue around the GEMMs (ReLU backward + bias-gradient sums,
+# processor scaling + neighbour-axis sum, desired-force epilogue) runs as fused HIP kernels
+# (piml_amd/csrc/mlpglue.hip); the GEMMs remain torch.addmm / torch.mm.  PIML_FUSED_GLUE=0 (or
+# setting this flag to False) keeps the plain torch.nn expression of the same arithmetic.
+FUSED_GLUE = os.environ.get('PIML_FUSED_GLUE', '1') != '0'
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -50,8 +58,15 @@ class MLP(nn.Module):
                 (activation if activation is not None else nn.ReLU())
             mods += [nn.Linear(sizes[i], sizes[i + 1]), act]
         self.mlp = nn.Sequential(*mods)
+        self._fusable = all(isinstance(a, (nn.ReLU, nn.Identity)) for a in mods[1::2])
 
     def forward(self, x):
+        if FUSED_GLUE and self._fusable and x.is_cuda and x.dtype == torch.float32:
+            from .. import ops
+            for i in range(0, len(self.mlp), 2):
+                lin = self.mlp[i]
+                x = ops.linear_act(x, lin.weight, lin.bias, isinstance(self.mlp[i + 1], nn.ReLU))
+            return x
         return self.mlp(x)
 
 
@@ -84,6 +99,12 @@ class ResDNN(nn.Module):
 
     def forward(self, x):
         return self.dropout(self.resnet[len(self.hidden_units) - 1](x))
+
+    def pure_scale(self):
+        """2.0 when this module currently computes exactly 2 * x (quirk Q3 with dropout inactive), else None."""
+        if len(self.hidden_units) >= 2 and (not self.training or self.dropout.p == 0):
+            return 2.0
+        return None
 
 
 class attn_pooling(nn.Module):
@@ -152,13 +173,25 @@ class _PINNSFBase(nn.Module):
         dest_direction = self_features[..., :2] / temp
         return (desired_speed * dest_direction - self_features[..., 2:4]) / self.tau
 
+    @staticmethod
+    def _process_and_pool(processor, encoded):
+        """(processor(encoded), its sum over the neighbour axis)."""
+        scale = processor.pure_scale()
+        if FUSED_GLUE and scale is not None and encoded.is_cuda and encoded.shape[-1] % 4 == 0 \
+                and encoded.dtype == torch.float32:
+            from .. import ops
+            return ops.scale_ksum(encoded, scale)
+        emb = processor(encoded)
+        return emb, emb.sum(dim=-2)
+
     def _branch(self, feats, encoder, processor, decoder, predictor):
-        emb = processor(encoder(feats))
         if self.bottleneck:
+            emb = processor(encoder(feats))
             decoded = decoder(emb)
             msgs = predictor(decoded)
             return msgs.sum(dim=-2), msgs, decoded, emb
-        acc = predictor(decoder(emb.sum(dim=-2)))
+        emb, pooled = self._process_and_pool(processor, encoder(feats))
+        acc = predictor(decoder(pooled))
         return acc, emb, None, emb
 
     def forward(self, ped_features, obs_features, self_features):
@@ -172,9 +205,9 @@ class _PINNSFBase(nn.Module):
                                                          self.obs_decoder, self.obs_predictor)
         encoded = self.ped_encoder(ped_features) if self.residual else None
         if self.residual:
-            emb = self.ped_processor(encoded)
+            emb, pooled = self._process_and_pool(self.ped_processor, encoded)
             ped_msgs = emb
-            acc = self.ped_predictor(self.ped_decoder(emb.sum(dim=-2)))
+            acc = self.ped_predictor(self.ped_decoder(pooled))
             decoded = None
         else:
             acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
@@ -187,8 +220,14 @@ class _PINNSFBase(nn.Module):
             else:
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
                                                     self.obs_decoder, self.obs_predictor)
-            acc = acc + acc_o
-        predictions = acc + self.desired_force(self_features)
+        if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
+                and (self_features.dim() == 2 or self.fix_dest_norm):
+            from .. import ops       # per-row norm: one fused kernel (the dim=1 quirk Q2 stays below)
+            predictions = ops.pinnsf_epilogue(acc, acc_o, self_features, self.tau)
+        else:
+            if acc_o is not None:
+                acc = acc + acc_o
+            predictions = acc + self.desired_force(self_features)
         if self.residual:
             r = self.corrector[0](encoded)
             predictions = predictions + self.corrector[2](self.corrector[1](r))

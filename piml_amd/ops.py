@@ -409,3 +409,176 @@ def rollout_step(st, data, a_next, remove_arrived=True):
             st.selff.shape[-1], _ptr(st.new_flag_u8), _ptr(st.p_res), _ptr(st.v_res), _ptr(st.a_res),
             _ptr(st.mask_new), _ptr(st.selff), _ptr(st.desired_speed), _ptr(st.t), C, T, N,
             float(data.time_unit), int(remove_arrived), _stream()), 'piml_rollout_step')
+
+
+# ------------------------------------------------------------------------------------------------
+# Glue around the PINNSF network's GEMMs (piml_amd/csrc/mlpglue.hip).  The GEMMs themselves stay
+# torch.addmm / torch.mm (rocBLAS / hipBLASLt); these operators replace the launch-bound chains of
+# small torch kernels around them.
+# ------------------------------------------------------------------------------------------------
+class _PinnsfEpilogue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acc_ped, acc_obs, self_features, tau):
+        sf = _gpu_f32('self_features', self_features)
+        ap = _gpu_f32('acc_ped', acc_ped)
+        ao = _gpu_f32('acc_obs', acc_obs) if acc_obs is not None else None
+        rows = sf.numel() // 7
+        out = torch.empty_like(ap)
+        with torch.cuda.device(sf.device):
+            _lib.check(_lib.lib().piml_pinnsf_epilogue_fwd(_ptr(ap), _ptr(ao), _ptr(sf), rows, float(tau), _ptr(out),
+                                                           _stream()), 'piml_pinnsf_epilogue_fwd')
+        ctx.save_for_backward(sf)
+        ctx.tau, ctx.has_obs = float(tau), acc_obs is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (sf,) = ctx.saved_tensors
+        g = g.contiguous()
+        g_self = None
+        if ctx.needs_input_grad[2]:
+            g_self = torch.empty_like(sf)
+            with torch.cuda.device(sf.device):
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, ctx.tau,
+                                                               _ptr(g_self), _stream()), 'piml_pinnsf_epilogue_bwd')
+        return g, (g if ctx.has_obs else None), g_self, None
+
+
+def pinnsf_epilogue(acc_ped, acc_obs, self_features, tau):
+    """acc_ped + acc_obs + (v0 * dest/|dest| - v) / tau on rows of self_features (..., 7) with the
+    per-row norm (src/models/model.py:1289-1294); acc_obs may be None."""
+    if self_features.shape[-1] != 7 or acc_ped.shape != self_features.shape[:-1] + (2,):
+        raise ValueError('pinnsf_epilogue: acc (..., 2) and self_features (..., 7) expected')
+    return _PinnsfEpilogue.apply(acc_ped, acc_obs, self_features, tau)
+
+
+class _SelfFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dest_feat, state_rows, desired_speed):
+        d = _gpu_f32('dest_feat', dest_feat)
+        s = _gpu_f32('state_rows', state_rows)
+        w = _gpu_f32('desired_speed', desired_speed)
+        rows = s.shape[0]
+        out = torch.empty(rows, 7, device=s.device, dtype=torch.float32)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().piml_self_features_fwd(_ptr(d), 2, _ptr(s), _ptr(w), rows, _ptr(out), _stream()),
+                       'piml_self_features_fwd')
+        ctx.speed_shape = tuple(desired_speed.shape)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        g = g.contiguous()
+        rows = g.shape[0]
+        need = ctx.needs_input_grad
+        opt = dict(device=g.device, dtype=torch.float32)
+        g_dest = torch.empty(rows, 2, **opt) if need[0] else None
+        g_state = torch.empty(rows, 6, **opt) if need[1] else None
+        g_speed = torch.empty(ctx.speed_shape, **opt) if need[2] else None
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().piml_self_features_bwd(_ptr(g), rows, _ptr(g_dest), _ptr(g_state), _ptr(g_speed),
+                                                         _stream()), 'piml_self_features_bwd')
+        return g_dest, g_state, g_speed
+
+
+def self_features_packed(dest_feat, state_rows, desired_speed):
+    """(n, 7) model input rows [dest - p, v, a, v0] from the focal rows of the packed (p, v, a) state
+    (n, 6) -- the torch.cat at src/models/simulators.py:648-650 as one kernel each way."""
+    n = state_rows.shape[0]
+    if state_rows.dim() != 2 or state_rows.shape[1] != 6 or dest_feat.shape != (n, 2) or desired_speed.numel() != n:
+        raise ValueError('self_features_packed: dest_feat (n,2), state_rows (n,6), desired_speed (n,1) expected')
+    return _SelfFeatures.apply(dest_feat, state_rows, desired_speed)
+
+
+def act_bwd_colsum(g, y=None):
+    """(g_pre, db) with g_pre = g * [y > 0] (g itself when y is None) and db = g_pre.sum(0); g, y (rows, cols).
+    Shapes the kernel does not cover (cols > 1024, or > 256 when cols % 4) use torch's GPU reduction."""
+    g = _gpu_f32('g', g)
+    rows, cols = g.shape
+    if (cols % 4 == 0 and cols > 1024) or (cols % 4 and cols > 256):
+        g_pre = g if y is None else torch.where(y > 0, g, torch.zeros((), device=g.device))
+        return g_pre, g_pre.sum(0)
+    L = _lib.lib()
+    nb = L.piml_colsum_blocks(rows, cols)
+    db = torch.empty(cols, device=g.device, dtype=torch.float32)
+    g_pre = torch.empty_like(g) if y is not None else g
+    partials = torch.empty(nb * cols, device=g.device, dtype=torch.float32) if nb > 1 else None
+    with torch.cuda.device(g.device):
+        _lib.check(L.piml_act_bwd_colsum(_ptr(g), _ptr(y) if y is not None else None, rows, cols,
+                                         _ptr(g_pre) if y is not None else None, _ptr(partials), _ptr(db),
+                                         _stream()), 'piml_act_bwd_colsum')
+    return g_pre, db
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b), act in {identity, relu}: torch.addmm forward; backward = fused
+    (relu mask + bias-gradient column sum) kernel + the two torch.mm GEMMs autograd would issue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2 = x.reshape(-1, x.shape[-1])
+        y = torch.addmm(bias, x2, weight.t())
+        if relu:
+            y = torch.relu_(y)
+        out = y.view(*x.shape[:-1], weight.shape[0])
+        ctx.save_for_backward(x2, weight, out if relu else None)
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x2, weight, y = ctx.saved_tensors
+        g2 = g.reshape(-1, weight.shape[0])
+        g_pre, db = act_bwd_colsum(g2, y.reshape(-1, weight.shape[0]) if y is not None else None)
+        gx = g_pre.mm(weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        gw = g_pre.t().mm(x2) if ctx.needs_input_grad[1] else None
+        return gx, gw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def linear_act(x, weight, bias, relu):
+    """nn.Linear (+ nn.ReLU) with the fused backward glue; x (..., in) float32 on the GPU."""
+    if not x.is_cuda:
+        raise _lib.PimlHipError('linear_act: expected a GPU tensor (piml_amd has no CPU path)')
+    return _LinearAct.apply(x, weight, bias, bool(relu))
+
+
+class _ScaleKSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, scale):
+        e = _gpu_f32('e', e)
+        k, cols = e.shape[-2], e.shape[-1]
+        agents = e.numel() // (k * cols)
+        msgs = torch.empty_like(e)
+        pooled = torch.empty(*e.shape[:-2], cols, device=e.device, dtype=torch.float32)
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), agents, k, cols, float(scale), _ptr(msgs),
+                                                      _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
+        ctx.geom = (agents, k, cols, float(scale), tuple(e.shape))
+        ctx.set_materialize_grads(False)      # an unused output arrives as None, not as a zero tensor
+        return msgs, pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_msgs, g_pooled):
+        agents, k, cols, scale, shape = ctx.geom
+        ref = g_pooled if g_pooled is not None else g_msgs
+        if ref is None:
+            return None, None
+        g_e = torch.empty(shape, device=ref.device, dtype=torch.float32)
+        gm = g_msgs.contiguous() if g_msgs is not None else None
+        gp = g_pooled.contiguous() if g_pooled is not None else None
+        with torch.cuda.device(ref.device):
+            _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e),
+                                                      _stream()), 'piml_scale_ksum_bwd')
+        return g_e, None
+
+
+def scale_ksum(e, scale=2.0):
+    """(scale * e, (scale * e).sum(-2)) for e (..., k, cols), cols % 4 == 0: the eval-mode PINNSF processor
+    (quirk Q3) + neighbour-axis pooling (src/models/model.py:1279-1283) in one pass."""
+    if e.dim() < 2 or e.shape[-1] % 4:
+        raise ValueError('scale_ksum: e (..., k, cols) with cols % 4 == 0 expected')
+    return _ScaleKSum.apply(e, scale)

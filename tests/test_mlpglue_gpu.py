@@ -1,0 +1,226 @@
+"""GPU: the fused glue kernels around the PINNSF GEMMs (piml_amd/csrc/mlpglue.hip) against the plain
+torch expression of the same arithmetic, and the fused model against the reference's golden outputs
+(tests/golden/model.npz, captured from src/models/model.py)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def torch_desired(acc_p, acc_o, sf, tau):
+    """src/models/model.py:1289-1294 (per-row norm)."""
+    v0 = sf[..., -1].unsqueeze(-1)
+    t = torch.norm(sf[..., :2], p=2, dim=-1, keepdim=True)
+    t = torch.where(t == 0, t + 0.1, t)
+    acc = acc_p if acc_o is None else acc_p + acc_o
+    return acc + (v0 * (sf[..., :2] / t) - sf[..., 2:4]) / tau
+
+
+@pytest.mark.parametrize('shape', [(1000,), (3, 257)])
+@pytest.mark.parametrize('with_obs', [True, False])
+def test_pinnsf_epilogue_matches_torch(shape, with_obs):
+    from piml_amd import ops
+    sf = rnd(*shape, 7, seed=1)
+    sf.view(-1, 7)[::7, :2] = 0.0                      # arrived / absent agents: dest - p == 0
+    acc_p, acc_o = rnd(*shape, 2, seed=2), (rnd(*shape, 2, seed=3) if with_obs else None)
+    leaves = [x.clone().requires_grad_(True) for x in (acc_p, sf)] + ([acc_o.clone().requires_grad_(True)] if with_obs else [])
+    ref = torch_desired(leaves[0], leaves[2] if with_obs else None, leaves[1], 0.5)
+    w = rnd(*shape, 2, seed=4)
+    g_ref = torch.autograd.grad(ref, leaves, w)
+    leaves2 = [x.detach().clone().requires_grad_(True) for x in leaves]
+    out = ops.pinnsf_epilogue(leaves2[0], leaves2[2] if with_obs else None, leaves2[1], 0.5)
+    g_out = torch.autograd.grad(out, leaves2, w)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    for a, b in zip(g_out, g_ref):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+
+
+def test_self_features_packed_matches_cat():
+    from piml_amd import ops
+    n = 777
+    dest, state, v0 = rnd(n, 2, seed=1), rnd(n, 6, seed=2), rnd(n, 1, seed=3)
+    a = [x.clone().requires_grad_(True) for x in (dest, state, v0)]
+    ref = torch.cat((a[0], a[1][:, 2:4], a[1][:, 4:6], a[2]), -1)
+    w = rnd(n, 7, seed=4)
+    g_ref = torch.autograd.grad(ref, a, w)
+    b = [x.clone().requires_grad_(True) for x in (dest, state, v0)]
+    out = ops.self_features_packed(*b)
+    g_out = torch.autograd.grad(out, b, w)
+    assert torch.equal(out, ref)
+    for x, y in zip(g_out, g_ref):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('rows,cols', [(24576, 128), (40960, 128), (4096, 64), (4096, 2), (24576, 1), (1, 128),
+                                       (63, 64), (65, 12), (1000, 6), (16385, 256), (300, 1024), (5000, 3), (0, 64),
+                                       (129, 1028), (77, 300)])
+@pytest.mark.parametrize('masked', [True, False])
+def test_act_bwd_colsum(rows, cols, masked):
+    from piml_amd import ops
+    g = rnd(rows, cols, seed=rows + cols)
+    y = torch.relu(rnd(rows, cols, seed=7)) if masked else None
+    g_pre, db = ops.act_bwd_colsum(g, y)
+    want_pre = torch.where(y > 0, g, torch.zeros((), device=DEV)) if masked else g
+    assert torch.equal(g_pre, want_pre)
+    want = want_pre.double().sum(0)
+    tol = 1e-6 * max(1.0, float(want_pre.abs().double().sum(0).max()) if rows else 1.0)
+    assert db.shape == (cols,)
+    assert (db.double() - want).abs().max() <= tol, ((db.double() - want).abs().max(), tol)
+    # deterministic: fixed two-level summation order
+    for _ in range(5):
+        _, again = ops.act_bwd_colsum(g, y)
+        assert torch.equal(again, db)
+
+
+def test_act_bwd_colsum_concurrent_streams():
+    """Two streams launching colsums at the same time (each call owns its scratch)."""
+    from piml_amd import ops
+    g1, g2 = rnd(40960, 128, seed=1), rnd(24576, 128, seed=2)
+    want1, want2 = ops.act_bwd_colsum(g1)[1], ops.act_bwd_colsum(g2)[1]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            outs.append((ops.act_bwd_colsum(g1)[1], want1))
+        with torch.cuda.stream(s2):
+            outs.append((ops.act_bwd_colsum(g2)[1], want2))
+    torch.cuda.synchronize()
+    for got, want in outs:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('shape,out_f,relu', [((4096, 6, 6), 128, True), ((4096, 10, 128), 128, False),
+                                             ((4096, 128), 64, True), ((4096, 64), 2, False), ((5, 7, 3, 16), 12, True)])
+def test_linear_act_matches_torch(shape, out_f, relu):
+    from piml_amd import ops
+    x = rnd(*shape, seed=1)
+    lin = torch.nn.Linear(shape[-1], out_f).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ref = lin(xa)
+    ref = torch.relu(ref) if relu else ref
+    w = rnd(*ref.shape, seed=2)
+    g_ref = torch.autograd.grad(ref, [xa, lin.weight, lin.bias], w)
+    xb = x.clone().requires_grad_(True)
+    out = ops.linear_act(xb, lin.weight, lin.bias, relu)
+    g_out = torch.autograd.grad(out, [xb, lin.weight, lin.bias], w)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    for a, b in zip(g_out, g_ref):
+        scale = max(1.0, float(b.abs().max()))
+        assert (a - b).abs().max() <= 2e-5 * scale, ((a - b).abs().max(), scale)
+
+
+@pytest.mark.parametrize('use', ['pooled', 'both', 'msgs'])
+def test_scale_ksum_matches_torch(use):
+    from piml_amd import ops
+    e = rnd(513, 6, 128, seed=1)
+    ea = e.clone().requires_grad_(True)
+    m_ref = ea + ea
+    p_ref = m_ref.sum(dim=-2)
+    eb = e.clone().requires_grad_(True)
+    m, p = ops.scale_ksum(eb, 2.0)
+    assert torch.equal(m, m_ref)
+    assert torch.allclose(p, p_ref, rtol=1e-5, atol=1e-5)
+    wm, wp = rnd(513, 6, 128, seed=2), rnd(513, 128, seed=3)
+    loss = lambda mm, pp: ((pp * wp).sum() if use != 'msgs' else 0) + ((mm * wm).sum() if use != 'pooled' else 0)
+    (g_ref,) = torch.autograd.grad(loss(m_ref, p_ref), ea)
+    (g_out,) = torch.autograd.grad(loss(m, p), eb)
+    assert torch.allclose(g_out, g_ref, rtol=1e-5, atol=1e-5)
+
+
+# ---- the whole network: fused glue vs the reference's outputs, and vs the unfused torch.nn path ----
+CASES = {
+    'pinnsf_m': ('PINNSF_multitask', {}),
+    'pinnsf_m_gc': ('PINNSF_multitask', dict(dataset_name='gc1560')),
+    'pinnsf_bm': ('PINNSF_bottleneck_multitask', {}),
+    'pinnsf': ('PINNSF', {}),
+    'pinnsf_bottleneck': ('PINNSF_bottleneck', {}),
+    'pinnsf_res': ('PINNSF_residual', {}),
+    'pinnsf_m_p1': ('PINNSF_multitask', dict(processor_hidden_layers=1)),
+}
+
+
+def model_args(**kw):
+    a = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3,
+        processor_hidden_layers=16, decoder_hidden_layers=2, dropout=0.5, activation='relu',
+        dataset_name='ucy', res_hidden_layers=3, correction_hidden_layers=1, time_unit=0.08,
+        collision_threshold=0.5)
+    a.__dict__.update(kw)
+    return a
+
+
+def load_model(name):
+    import piml_amd.models.model as MODEL
+    g = golden('model')
+    cls, kw = CASES[name]
+    m = getattr(MODEL, cls)(model_args(**kw)).eval()
+    sd = {k[len(name) + 4:]: torch.tensor(g[k]) for k in g.files if k.startswith(name + '/sd/')}
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV), g, MODEL
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_fused_model_matches_reference_outputs(name):
+    m, g, MODEL = load_model(name)
+    assert MODEL.FUSED_GLUE
+    with torch.no_grad():
+        for tag, keys in (('n', ('ped', 'obs', 'selff')), ('c', ('pedc', 'obsc', 'selfc'))):
+            outs = m(*[torch.tensor(g[k]).to(DEV) for k in keys])
+            q = 0
+            while f'{name}/out_{tag}{q}' in g.files:
+                ref = g[f'{name}/out_{tag}{q}']
+                got = outs[q].cpu().numpy()
+                assert got.shape == ref.shape
+                scale = max(1.0, np.abs(ref).max())
+                assert np.abs(got - ref).max() <= 2e-5 * scale, (tag, q, np.abs(got - ref).max())
+                q += 1
+            assert q == len(outs)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+@pytest.mark.parametrize('mode', ['rows', 'channelled_fix', 'channelled_quirk'])
+def test_fused_model_equals_unfused(name, mode, monkeypatch):
+    """Outputs and every gradient (parameters and the three inputs) of the fused path against the plain
+    torch.nn path on the GPU; the loss touches all outputs (acc, messages, collision head)."""
+    m, g, MODEL = load_model(name)
+    keys = ('ped', 'obs', 'selff') if mode == 'rows' else ('pedc', 'obsc', 'selfc')
+    m.fix_dest_norm = mode == 'channelled_fix'
+    base = [torch.tensor(g[k]).to(DEV) for k in keys]
+
+    def run(fused):
+        monkeypatch.setattr(MODEL, 'FUSED_GLUE', fused)
+        ins = [x.clone().requires_grad_(True) for x in base]
+        for p in m.parameters():
+            p.grad = None
+        outs = m(*ins)
+        loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device=DEV).view_as(o)).sum() for o in outs)
+        loss.backward()
+        grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+        return [o.detach() for o in outs], [x.grad for x in ins], grads
+
+    o1, i1, p1 = run(True)
+    o0, i0, p0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    for a, b in zip(i1, i0):
+        scale = max(1.0, float(b.abs().max()))
+        assert (a - b).abs().max() <= 1e-4 * scale
+    for k in p0:
+        assert (p0[k] is None) == (p1[k] is None), k
+        if p0[k] is not None:
+            scale = max(1.0, float(p0[k].abs().max()))
+            assert (p1[k] - p0[k]).abs().max() <= 1e-4 * scale, (k, (p1[k] - p0[k]).abs().max(), scale)
