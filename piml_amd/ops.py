@@ -519,9 +519,10 @@ class _LinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x2 = x.reshape(-1, x.shape[-1])
-        y = torch.addmm(bias, x2, weight.t())
-        if relu:
-            y = torch.relu_(y)
+        if relu:    # bias and ReLU both ride in the GEMM's epilogue (hipBLASLt)
+            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+        else:
+            y = torch.addmm(bias, x2, weight.t())
         out = y.view(*x.shape[:-1], weight.shape[0])
         ctx.save_for_backward(x2, weight, out if relu else None)
         ctx.x_shape = x.shape
