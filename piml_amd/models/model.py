@@ -63,10 +63,9 @@ class MLP(nn.Module):
     def forward(self, x):
         if FUSED_GLUE and self._fusable and x.is_cuda and x.dtype == torch.float32:
             from .. import ops
-            for i in range(0, len(self.mlp), 2):
-                lin = self.mlp[i]
-                x = ops.linear_act(x, lin.weight, lin.bias, isinstance(self.mlp[i + 1], nn.ReLU))
-            return x
+            lins = self.mlp[0::2]
+            relus = [isinstance(a, nn.ReLU) for a in self.mlp[1::2]]
+            return ops.mlp_chain(x, relus, *[t for lin in lins for t in (lin.weight, lin.bias)])
         return self.mlp(x)
 
 

@@ -546,6 +546,64 @@ def linear_act(x, weight, bias, relu):
     return _LinearAct.apply(x, weight, bias, bool(relu))
 
 
+class _MLPChain(torch.autograd.Function):
+    """A whole MLP (src/models/model.py:40-65): Linear(+ReLU) layers back to back as ONE autograd node.
+    Forward: one hipBLASLt GEMM per layer with bias (+ReLU) in its epilogue.  Backward, per layer from the
+    last: fused ReLU-mask + bias-gradient kernel, then the input-gradient and weight-gradient GEMMs.
+    (Issuing the weight-gradient GEMMs on a side stream was measured and rejected: inside a captured
+    HIP graph every cross-stream edge costs more than the overlap gains -- 0.51 -> 0.69 ms/step -- and a
+    fork from an already forked stream crashed hipStreamEndCapture on ROCm 7.0.)"""
+
+    @staticmethod
+    def forward(ctx, x, relus, *wb):
+        x2 = x.reshape(-1, x.shape[-1])
+        acts = [x2]
+        for i, relu in enumerate(relus):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            acts.append(torch._addmm_activation(b, acts[-1], w.t(), use_gelu=False) if relu
+                        else torch.addmm(b, acts[-1], w.t()))
+        out = acts[-1].view(*x.shape[:-1], acts[-1].shape[-1])
+        ctx.save_for_backward(*acts[:-1], out, *wb[0::2])
+        ctx.relus, ctx.x_shape = tuple(relus), x.shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        n = len(ctx.relus)
+        saved = ctx.saved_tensors
+        acts, out, weights = saved[:n], saved[n], saved[n + 1:]
+        need = ctx.needs_input_grad
+        g_cur = g.reshape(-1, weights[-1].shape[0])
+        grads = [None] * (2 * n)
+        for i in reversed(range(n)):
+            w = weights[i]
+            y = None
+            if ctx.relus[i]:
+                y = (out if i == n - 1 else acts[i + 1]).reshape(-1, w.shape[0])
+            g_pre, db = act_bwd_colsum(g_cur, y)
+            if need[2 + 2 * i + 1]:
+                grads[2 * i + 1] = db
+            if need[2 + 2 * i]:
+                grads[2 * i] = g_pre.t().mm(acts[i])
+            if i > 0 or need[0]:
+                g_cur = g_pre.mm(w)
+        gx = g_cur.view(ctx.x_shape) if need[0] else None
+        return (gx, None, *grads)
+
+
+def mlp_chain(x, relus, *weights_and_biases):
+    """x (..., in) through Linear(+ReLU) layers; `relus[i]` says whether layer i is followed by a ReLU;
+    weights_and_biases = (w0, b0, w1, b1, ...)."""
+    if not x.is_cuda:
+        raise _lib.PimlHipError('mlp_chain: expected a GPU tensor (piml_amd has no CPU path)')
+    if len(weights_and_biases) != 2 * len(relus):
+        raise ValueError('mlp_chain: one (weight, bias) pair per layer expected')
+    if not relus:
+        return x
+    return _MLPChain.apply(x, tuple(bool(r) for r in relus), *weights_and_biases)
+
+
 class _ScaleKSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, scale):

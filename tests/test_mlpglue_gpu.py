@@ -224,3 +224,35 @@ def test_fused_model_equals_unfused(name, mode, monkeypatch):
         if p0[k] is not None:
             scale = max(1.0, float(p0[k].abs().max()))
             assert (p1[k] - p0[k]).abs().max() <= 1e-4 * scale, (k, (p1[k] - p0[k]).abs().max(), scale)
+
+
+@pytest.mark.parametrize('sizes,relus', [((6, 128, 128, 128), (True, True, False)), ((128, 64, 64), (True, False)),
+                                         ((64, 2), (False,)), ((128, 64, 1), (True, False))])
+def test_mlp_chain_matches_torch(sizes, relus):
+    """One autograd node for a whole MLP."""
+    from piml_amd import ops
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(a, b).to(DEV) for a, b in zip(sizes[:-1], sizes[1:])]
+    x = rnd(4096, 6, sizes[0], seed=1)
+
+    def ref_forward(inp):
+        h = inp
+        for lin, r in zip(lins, relus):
+            h = lin(h)
+            h = torch.relu(h) if r else h
+        return h
+    params = [t for lin in lins for t in (lin.weight, lin.bias)]
+    xa = x.clone().requires_grad_(True)
+    ref = ref_forward(xa)
+    w = rnd(*ref.shape, seed=2)
+    g_ref = torch.autograd.grad(ref, [xa] + params, w)
+    xb = x.clone().requires_grad_(True)
+    out = ops.mlp_chain(xb, relus, *params)
+    g_out = torch.autograd.grad(out, [xb] + params, w)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    for a, b in zip(g_out, g_ref):
+        scale = max(1.0, float(b.abs().max()))
+        assert (a - b).abs().max() <= 2e-5 * scale, ((a - b).abs().max(), scale)
+    # only some gradients requested (frozen weights / no input gradient)
+    (gw_last,) = torch.autograd.grad(ops.mlp_chain(x, relus, *params), [params[-2]], w)
+    assert (gw_last - g_ref[-2]).abs().max() <= 2e-5 * max(1.0, float(g_ref[-2].abs().max()))
