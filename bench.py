@@ -292,20 +292,19 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             reset_grads()
-            # Two graphs per step, split right after the relfeat forward, so that the HIP events
-            # timing that kernel are recorded on the stream BETWEEN the two replays (ROCm cannot
-            # record events inside a captured graph).  One autograd pass spans both captures.
+            # ONE graph holds the step's compute (relfeat forward ... relfeat backward).  ROCm cannot record
+            # events inside a captured graph, so the HIP events that time the relfeat kernel bracket an
+            # extra eager launch of it (same inputs, same output buffers) in front of sampled replays.
             g_timer = _lib.StreamTimer()
-            graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+            graph = torch.cuda.CUDAGraph()
             if use_dist:
                 exchange_forward()
                 torch.cuda.synchronize()
-            with torch.cuda.graph(graph[0]):
+            with torch.cuda.graph(graph):
                 feats = features_local() if use_dist else features()
-            with torch.cuda.graph(graph[1], pool=graph[0].pool()):
                 (rest_local if use_dist else rest)(*feats)
             static_feats = feats     # the captured step's feature / index buffers stay alive
-            graph[0].replay(); graph[1].replay()
+            graph.replay()
             if use_dist:
                 exchange_backward()
             done = torch.cuda.Event()
@@ -338,20 +337,17 @@ def main():
     def run_step(i, timed):
         if graph is not None:
             sample = timed and i % sample_every == 0
-            # the forward graph holds exactly one kernel: launch it directly into the captured
-            # buffers.  On sampled steps it is launched twice and the HIP events bracket the
-            # SECOND launch, so the interval holds one kernel behind another kernel rather than
-            # the idle gap that follows the previous graph replay.
-            src = state_own
             if use_dist:
                 exchange_forward()
-                src = state_all
-            ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
             if sample:
+                # the timed launch runs behind an identical launch, so the interval holds one kernel
+                # behind another kernel rather than the idle gap that follows the previous replay
+                src = state_all if use_dist else state_own
+                ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
                 g_timer.start()
                 ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
                 g_timer.stop()
-            graph[1].replay()
+            graph.replay()
             if use_dist:
                 exchange_backward()
             if sample:     # read this step's event pair (syncs on `stop` only)
