@@ -217,11 +217,11 @@ def main():
     def features():
         """all-gather of the owners' records (N > 1) + relfeat forward (HIP)."""
         state_full = sh.gather_state(state_own) if sh is not None else state_own
-        return ops.relative_features_packed(state_full, dest_own, obstacles, b0, n_own, return_index=True)
+        return ops.relative_features_packed_self(state_full, dest_own, obstacles, v0_own, b0, n_own,
+                                                 return_index=True)
 
-    def rest(pf, of, df, *_idx):
+    def rest(pf, of, self_features, *_idx):
         """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
-        self_features = ops.self_features_packed(df, state_own, v0_own)
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
         if sh is not None:
@@ -236,10 +236,10 @@ def main():
     grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
 
     def features_local():
-        return ops.relative_features_packed(state_all, dest_own, obstacles, b0, n_own, return_index=True)
+        return ops.relative_features_packed_self(state_all, dest_own, obstacles, v0_own, b0, n_own,
+                                                 return_index=True)
 
-    def rest_local(pf, of, df, *_idx):
-        self_features = ops.self_features_packed(df, state_all[b0:b0 + n_own], v0_own)
+    def rest_local(pf, of, self_features, *_idx):
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
         bucket[:] = flatten_gradients(params)       # captured: one concatenation into a static bucket

@@ -213,7 +213,8 @@ int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_features, siz
 /*
  * self_features rows for the model from the packed state: out (rows,7) = [dest_feat (ld dest_ld),
  * state[:, 2:6] (v, a; interleaved (p,v,a) records, 6 floats), desired_speed] -- the torch.cat at
- * src/models/simulators.py:648-650 / 777-779.  bwd splits g_self into g_dest (rows,2),
+ * src/models/simulators.py:648-650 / 777-779.  dest_feat NULL: columns 0-1 of `out` are left as they
+ * are (piml_relfeat_fwd wrote them in place with dest_feat_ld = 7).  bwd splits g_self into g_dest (rows,2),
  * g_state (rows,6; position columns zero) and g_speed (rows).
  */
 int piml_self_features_fwd(const float* dest_feat, int dest_ld, const float* state, const float* desired_speed,

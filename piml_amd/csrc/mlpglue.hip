@@ -69,11 +69,13 @@ __global__ __launch_bounds__(256) void self_features_fwd_kernel(const float* __r
                                                                  float* __restrict__ out) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const float* d = dest_feat + r * (size_t)dest_ld;
     const float* s = state + r * 6;
     float* o = out + r * 7;
-    o[0] = d[0];
-    o[1] = d[1];
+    if (dest_feat) {      // NULL: columns 0-1 were already written in place (piml_relfeat_fwd, dest_feat_ld = 7)
+        const float* d = dest_feat + r * (size_t)dest_ld;
+        o[0] = d[0];
+        o[1] = d[1];
+    }
     o[2] = s[2];
     o[3] = s[3];
     o[4] = s[4];
@@ -297,9 +299,9 @@ PIML_API int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_feat
 
 PIML_API int piml_self_features_fwd(const float* dest_feat, int dest_ld, const float* state,
                                     const float* desired_speed, size_t rows, float* out, void* stream) {
-    if (dest_ld < 2) return hipErrorInvalidValue;
+    if (dest_feat && dest_ld < 2) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
-    if (!dest_feat || !state || !desired_speed || !out) return hipErrorInvalidValue;
+    if (!state || !desired_speed || !out) return hipErrorInvalidValue;
     hipLaunchKernelGGL(self_features_fwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
                        dest_feat, dest_ld, state, desired_speed, rows, out);
     return hipGetLastError();

@@ -74,7 +74,9 @@ def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f
     return ped_feat, obs_feat, dest_feat, ped_idx, obs_idx
 
 
-def _launch_relfeat_bwd(ctx_geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, p_ptr, ld, dest_rows, device):
+def _launch_relfeat_bwd(ctx_geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, p_ptr, ld, dest_rows, device,
+                        g_state=None):
+    """`g_state` given: the kernel accumulates into it (all its writes are atomic adds)."""
     C, N, f0, fcnt, kpe, koe, lead = ctx_geom
 
     def dense(g, shape):
@@ -82,7 +84,8 @@ def _launch_relfeat_bwd(ctx_geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, p_ptr,
     g_ped = dense(g_ped, (*lead, fcnt, kpe, 6))
     g_obs = dense(g_obs, (*lead, fcnt, koe, 6))
     g_dest = dense(g_dest, (*lead, fcnt, 2))
-    g_state = torch.zeros(*lead, N, 6, device=device, dtype=torch.float32)
+    if g_state is None:
+        g_state = torch.zeros(*lead, N, 6, device=device, dtype=torch.float32)
     g_dest_rows = torch.empty(*lead, fcnt, 2, device=device, dtype=torch.float32)
     with torch.cuda.device(device):
         _lib.check(_lib.lib().piml_relfeat_bwd(
@@ -118,6 +121,7 @@ class _RelativeFeatures(torch.autograd.Function):
         ctx.save_for_backward(out[3], out[4], p, d_rows)
         ctx.geom = (C, N, focal_begin, focal_count, out[3].shape[-1], out[4].shape[-1], lead)
         ctx.mark_non_differentiable(out[3], out[4])
+        ctx.set_materialize_grads(False)     # no zero tensors for the index outputs / unused features
         return out
 
     @staticmethod
@@ -157,6 +161,7 @@ class _RelativeFeaturesPacked(torch.autograd.Function):
         ctx.save_for_backward(out[3], out[4], s, d_rows)
         ctx.geom = (C, N, focal_begin, focal_count, out[3].shape[-1], out[4].shape[-1], lead)
         ctx.mark_non_differentiable(out[3], out[4])
+        ctx.set_materialize_grads(False)     # no zero tensors for the index outputs / unused features
         return out
 
     @staticmethod
@@ -167,11 +172,86 @@ class _RelativeFeaturesPacked(torch.autograd.Function):
         return (g_state, g_d_rows) + (None,) * 9
 
 
+class _RelativeFeaturesPackedSelf(torch.autograd.Function):
+    """_RelativeFeaturesPacked for a 2-D (N, 6) state that returns the model's self_features rows
+    (n, 7) = [dest - p, v, a, v0] instead of dest_features: the relfeat kernel writes columns 0-1 in place
+    (dest_feat_ld = 7) and one small kernel the rest; backward seeds the (N, 6) state gradient with the
+    self-feature part and lets the relfeat backward accumulate into it (no zero fill, no add)."""
+
+    @staticmethod
+    def forward(ctx, state, destination_rows, obstacles, desired_speed, focal_begin, focal_count, kp, ko,
+                cos_p, cos_o, dthr_p, dthr_o):
+        s = _gpu_f32('state', state)
+        d_rows = _gpu_f32('destination_rows', destination_rows)
+        o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
+        w = _gpu_f32('desired_speed', desired_speed)
+        if s.dim() != 2 or s.shape[-1] != 6:
+            raise ValueError(f'state must be (N, 6), got {tuple(s.shape)}')
+        N = s.shape[0]
+        if tuple(d_rows.shape) != (focal_count, 2) or w.numel() != focal_count:
+            raise ValueError('destination_rows (n, 2) and desired_speed (n, 1) expected for the focal rows')
+        M = o.shape[0]
+        kpe, koe = min(kp, N), min(ko, M)
+        opt = dict(device=s.device, dtype=torch.float32)
+        sf = torch.empty(focal_count, 7, **opt)
+        outs = (torch.empty(focal_count, kpe, 6, **opt), torch.empty(focal_count, koe, 6, **opt), sf,
+                torch.empty(focal_count, kpe, device=s.device, dtype=torch.int32),
+                torch.empty(focal_count, koe, device=s.device, dtype=torch.int32))
+        base = s.data_ptr()
+        _launch_relfeat_fwd(base, base + 8, base + 16, 6, None, d_rows, o, (), 1, N, focal_begin, focal_count,
+                            kp, ko, cos_p, cos_o, dthr_p, dthr_o, s.device, outs=outs, dest_ld=7)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().piml_self_features_fwd(None, 7, base + 24 * focal_begin, _ptr(w), focal_count,
+                                                         _ptr(sf), _stream()), 'piml_self_features_fwd')
+        ctx.save_for_backward(outs[3], outs[4], s, d_rows)
+        ctx.geom = (1, N, focal_begin, focal_count, kpe, koe, ())
+        ctx.speed_shape = tuple(desired_speed.shape)
+        ctx.mark_non_differentiable(outs[3], outs[4])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_ped, g_obs, g_self, _gi, _go):
+        ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
+        _, N, f0, fcnt, _, _, _ = ctx.geom
+        opt = dict(device=s.device, dtype=torch.float32)
+        g_dest, g_speed = None, None
+        if g_self is None:
+            g_state = torch.zeros(N, 6, **opt)
+        else:
+            g_self = g_self.contiguous()
+            g_state = torch.empty(N, 6, **opt) if fcnt == N else torch.zeros(N, 6, **opt)
+            g_dest = torch.empty(fcnt, 2, **opt)
+            g_speed = torch.empty(ctx.speed_shape, **opt) if ctx.needs_input_grad[3] else None
+            with torch.cuda.device(s.device):
+                _lib.check(_lib.lib().piml_self_features_bwd(_ptr(g_self), fcnt, _ptr(g_dest),
+                                                             g_state.data_ptr() + 24 * f0, _ptr(g_speed),
+                                                             _stream()), 'piml_self_features_bwd')
+        g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, s.data_ptr(), 6,
+                                                d_rows, s.device, g_state=g_state)
+        return (g_state, g_d_rows, None, g_speed) + (None,) * 8
+
+
+def relative_features_packed_self(state, destination_rows, obstacles, desired_speed, focal_begin, focal_count,
+                                  topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, return_index=False):
+    """(ped_features, obs_features, self_features (n, 7)) for the focal rows of a packed (N, 6) state:
+    relative_features_packed + the model's self-feature rows [dest - p, v, a, v0] in one autograd node."""
+    if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
+        raise ValueError(f'topk must be <= {MAX_TOPK}')
+    out = _RelativeFeaturesPackedSelf.apply(state, destination_rows, obstacles, desired_speed, int(focal_begin),
+                                            int(focal_count), int(topk_ped), int(topk_obs),
+                                            cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
+                                            float(dist_threshold_ped), float(dist_threshold_obs))
+    return out if return_index else out[:3]
+
+
 def relative_features_packed_into(outs, state, destination_rows, obstacles, focal_begin, focal_count,
                                   topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
                                   topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4):
     """Forward only, no autograd: recompute into the preallocated `outs` = (ped_features,
-    obs_features, dest_features, ped_idx, obs_idx) of an earlier relative_features_packed call
+    obs_features, dest_features (n, 2) or self_features (n, 7; columns 0-1 are rewritten), ped_idx,
+    obs_idx) of an earlier relative_features_packed / relative_features_packed_self call
     (static buffers of a captured step; bench.py relaunches the kernel between HIP events)."""
     s = _gpu_f32('state', state.detach())
     d_rows = _gpu_f32('destination_rows', destination_rows)
@@ -183,7 +263,7 @@ def relative_features_packed_into(outs, state, destination_rows, obstacles, foca
     _launch_relfeat_fwd(base, base + 8, base + 16, 6, None, d_rows, o, lead, C, N, int(focal_begin),
                         int(focal_count), int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped),
                         cos_threshold(sight_angle_obs), float(dist_threshold_ped), float(dist_threshold_obs),
-                        s.device, outs=tuple(outs))
+                        s.device, outs=tuple(outs), dest_ld=outs[2].shape[-1])
     return outs
 
 

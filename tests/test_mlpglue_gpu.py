@@ -256,3 +256,36 @@ def test_mlp_chain_matches_torch(sizes, relus):
     # only some gradients requested (frozen weights / no input gradient)
     (gw_last,) = torch.autograd.grad(ops.mlp_chain(x, relus, *params), [params[-2]], w)
     assert (gw_last - g_ref[-2]).abs().max() <= 2e-5 * max(1.0, float(g_ref[-2].abs().max()))
+
+
+@pytest.mark.parametrize('f0,fc', [(0, 300), (100, 120)])
+def test_relative_features_packed_self_matches_separate_ops(f0, fc):
+    """relfeat + self-feature rows as one autograd node == relative_features_packed + torch.cat."""
+    from piml_amd import ops
+    from piml_amd.scenes import synthetic_gc_scene
+    sc = synthetic_gc_scene(300, 200, seed=5)
+    rng = np.random.default_rng(1)
+    acc = (rng.standard_normal((300, 2)) * 0.3).astype(np.float32)
+    state = torch.tensor(np.concatenate((sc['position'], sc['velocity'], acc), -1)).to(DEV)
+    dest = torch.tensor(sc['destination'][f0:f0 + fc]).to(DEV)
+    v0 = torch.tensor(sc['desired_speed'][f0:f0 + fc]).to(DEV)
+    obs = torch.tensor(sc['obstacles']).to(DEV)
+    wp, wo, ws = rnd(fc, 6, 6, seed=1), rnd(fc, 10, 6, seed=2), rnd(fc, 7, seed=3)
+
+    sa, da, va = state.clone().requires_grad_(True), dest.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+    pf, of, df = ops.relative_features_packed(sa, da, obs, f0, fc)
+    own = sa[f0:f0 + fc]
+    sf = torch.cat((df, own[:, 2:4], own[:, 4:6], va), -1)
+    g_ref = torch.autograd.grad((pf * wp).sum() + (of * wo).sum() + (sf * ws).sum(), [sa, da, va])
+
+    sb, db_, vb = state.clone().requires_grad_(True), dest.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+    pf2, of2, sf2 = ops.relative_features_packed_self(sb, db_, obs, vb, f0, fc)
+    g_out = torch.autograd.grad((pf2 * wp).sum() + (of2 * wo).sum() + (sf2 * ws).sum(), [sb, db_, vb])
+    for a, b in ((pf2, pf), (of2, of), (sf2, sf)):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    for a, b in zip(g_out, g_ref):
+        assert torch.allclose(torch.nan_to_num(a), torch.nan_to_num(b), rtol=1e-5, atol=1e-6)
+    # only the feature gradients requested (self_features unused downstream)
+    (g_only,) = torch.autograd.grad((ops.relative_features_packed_self(sb, db_, obs, vb, f0, fc)[0] * wp).sum(), [sb])
+    (g_only_ref,) = torch.autograd.grad((ops.relative_features_packed(sa, da, obs, f0, fc)[0] * wp).sum(), [sa])
+    assert torch.allclose(torch.nan_to_num(g_only), torch.nan_to_num(g_only_ref), rtol=1e-5, atol=1e-6)
