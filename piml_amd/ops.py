@@ -681,6 +681,12 @@ def mlp_chain(x, relus, *weights_and_biases):
         raise ValueError('mlp_chain: one (weight, bias) pair per layer expected')
     if not relus:
         return x
+    if not torch.is_grad_enabled():       # inference: no autograd node, just the GEMMs
+        h = x.reshape(-1, x.shape[-1])
+        for i, relu in enumerate(relus):
+            w, b = weights_and_biases[2 * i], weights_and_biases[2 * i + 1]
+            h = torch._addmm_activation(b, h, w.t(), use_gelu=False) if relu else torch.addmm(b, h, w.t())
+        return h.view(*x.shape[:-1], h.shape[-1])
     return _MLPChain.apply(x, tuple(bool(r) for r in relus), *weights_and_biases)
 
 
