@@ -209,6 +209,16 @@ int piml_pinnsf_epilogue_fwd(const float* acc_ped, const float* acc_obs, const f
                              size_t rows, float tau, float* out, void* stream);
 int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_features, size_t rows, float tau,
                              float* g_self, void* stream);
+/*
+ * The same tail for channelled (C, N, 7) input with the reference's literal `dim=1` norm (quirk Q2): the
+ * norm of each destination component is taken over the N AGENTS of slice c,
+ * t[c, comp] = || self_features[c, :, comp] ||_2 (+0.1 where 0), as src/models/model.py:1290 computes it in
+ * the fine-tuning rollouts (src/models/simulators.py:701).  One workgroup per slice.
+ */
+int piml_pinnsf_epilogue_agentnorm_fwd(const float* acc_ped, const float* acc_obs, const float* self_features,
+                                       int C, int N, float tau, float* out, void* stream);
+int piml_pinnsf_epilogue_agentnorm_bwd(const float* g_out, const float* self_features, int C, int N, float tau,
+                                       float* g_self, void* stream);
 
 /*
  * self_features rows for the model from the packed state: out (rows,7) = [dest_feat (ld dest_ld),

@@ -60,6 +60,86 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* 
     o[6] = (g.x * ex + g.y * ey) / tau;
 }
 
+// The same tail for channelled (C, N, 7) input with the reference's dim=1 norm (quirk Q2,
+// src/models/model.py:1290): t[c, comp] = || d[c, :, comp] ||_2 over the AGENTS of slice c, per component.
+// One workgroup per slice: block reductions for the two norms (and, backward, for sum_n g_e d).
+__device__ __forceinline__ float2 block_sum2(float2 v, float2* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v.x = wave_sum(v.x);
+    v.y = wave_sum(v.y);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float2 s = make_float2(0.f, 0.f);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        s.x += sh[w].x;
+        s.y += sh[w].y;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void pinnsf_epilogue_agentnorm_fwd_kernel(const float2* __restrict__ acc_ped,
+                                                                             const float2* __restrict__ acc_obs,
+                                                                             const float* __restrict__ sf, int N,
+                                                                             float tau, float2* __restrict__ out) {
+    __shared__ float2 sh[4];
+    const size_t base = (size_t)blockIdx.x * N;
+    float2 sq = make_float2(0.f, 0.f);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = sf + (base + n) * 7;
+        sq.x += s[0] * s[0];
+        sq.y += s[1] * s[1];
+    }
+    sq = block_sum2(sq, sh);
+    float tx = sqrtf(sq.x), ty = sqrtf(sq.y);
+    tx = (tx == 0.f) ? tx + 0.1f : tx;
+    ty = (ty == 0.f) ? ty + 0.1f : ty;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = sf + (base + n) * 7;
+        float2 a = acc_ped[base + n];
+        if (acc_obs) {
+            const float2 o = acc_obs[base + n];
+            a.x += o.x;
+            a.y += o.y;
+        }
+        out[base + n] = make_float2(a.x + (s[6] * (s[0] / tx) - s[2]) / tau, a.y + (s[6] * (s[1] / ty) - s[3]) / tau);
+    }
+}
+
+__global__ __launch_bounds__(256) void pinnsf_epilogue_agentnorm_bwd_kernel(const float2* __restrict__ g_out,
+                                                                             const float* __restrict__ sf, int N,
+                                                                             float tau, float* __restrict__ g_self) {
+    __shared__ float2 sh[4];
+    const size_t base = (size_t)blockIdx.x * N;
+    float2 sq = make_float2(0.f, 0.f), dot = make_float2(0.f, 0.f);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = sf + (base + n) * 7;
+        const float2 g = g_out[base + n];
+        sq.x += s[0] * s[0];
+        sq.y += s[1] * s[1];
+        dot.x += (g.x * s[6] / tau) * s[0];
+        dot.y += (g.y * s[6] / tau) * s[1];
+    }
+    sq = block_sum2(sq, sh);
+    dot = block_sum2(dot, sh);
+    const float nx = sqrtf(sq.x), ny = sqrtf(sq.y);
+    const float tx = (nx == 0.f) ? nx + 0.1f : nx, ty = (ny == 0.f) ? ny + 0.1f : ny;
+    const float gtx = -dot.x / (tx * tx), gty = -dot.y / (ty * ty);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = sf + (base + n) * 7;
+        const float2 g = g_out[base + n];
+        const float gex = g.x * s[6] / tau, gey = g.y * s[6] / tau;
+        float* o = g_self + (base + n) * 7;
+        o[0] = gex / tx + (nx != 0.f ? gtx * (s[0] / nx) : 0.f);
+        o[1] = gey / ty + (ny != 0.f ? gty * (s[1] / ny) : 0.f);
+        o[2] = -g.x / tau;
+        o[3] = -g.y / tau;
+        o[4] = 0.f;
+        o[5] = 0.f;
+        o[6] = (g.x * (s[0] / tx) + g.y * (s[1] / ty)) / tau;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // self_features rows = [dest_feat, v, a, v0]
 // ---------------------------------------------------------------------------------------------
@@ -294,6 +374,28 @@ PIML_API int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_feat
     if (!g_out || !self_features || !g_self) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pinnsf_epilogue_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(g_out), self_features, rows, tau, g_self);
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_epilogue_agentnorm_fwd(const float* acc_ped, const float* acc_obs,
+                                                const float* self_features, int C, int N, float tau, float* out,
+                                                void* stream) {
+    if (C < 0 || N < 0) return hipErrorInvalidValue;
+    if (C == 0 || N == 0) return hipSuccess;
+    if (!acc_ped || !self_features || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_agentnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(acc_ped), reinterpret_cast<const float2*>(acc_obs),
+                       self_features, N, tau, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_epilogue_agentnorm_bwd(const float* g_out, const float* self_features, int C, int N,
+                                                float tau, float* g_self, void* stream) {
+    if (C < 0 || N < 0) return hipErrorInvalidValue;
+    if (C == 0 || N == 0) return hipSuccess;
+    if (!g_out || !self_features || !g_self) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_agentnorm_bwd_kernel, dim3(C), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(g_out), self_features, N, tau, g_self);
     return hipGetLastError();
 }
 

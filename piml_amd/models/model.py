@@ -220,9 +220,10 @@ class _PINNSFBase(nn.Module):
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
                                                     self.obs_decoder, self.obs_predictor)
         if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
-                and (self_features.dim() == 2 or self.fix_dest_norm):
-            from .. import ops       # per-row norm: one fused kernel (the dim=1 quirk Q2 stays below)
-            predictions = ops.pinnsf_epilogue(acc, acc_o, self_features, self.tau)
+                and (self_features.dim() in (2, 3) or self.fix_dest_norm):
+            from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)
+            quirk = self_features.dim() == 3 and not self.fix_dest_norm
+            predictions = ops.pinnsf_epilogue(acc, acc_o, self_features, self.tau, agent_norm=quirk)
         else:
             if acc_o is not None:
                 acc = acc + acc_o

@@ -498,17 +498,23 @@ def rollout_step(st, data, a_next, remove_arrived=True):
 # ------------------------------------------------------------------------------------------------
 class _PinnsfEpilogue(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, acc_ped, acc_obs, self_features, tau):
+    def forward(ctx, acc_ped, acc_obs, self_features, tau, agent_norm):
         sf = _gpu_f32('self_features', self_features)
         ap = _gpu_f32('acc_ped', acc_ped)
         ao = _gpu_f32('acc_obs', acc_obs) if acc_obs is not None else None
         rows = sf.numel() // 7
         out = torch.empty_like(ap)
         with torch.cuda.device(sf.device):
-            _lib.check(_lib.lib().piml_pinnsf_epilogue_fwd(_ptr(ap), _ptr(ao), _ptr(sf), rows, float(tau), _ptr(out),
-                                                           _stream()), 'piml_pinnsf_epilogue_fwd')
+            if agent_norm:
+                C, N = sf.shape[0], sf.shape[1]
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_agentnorm_fwd(_ptr(ap), _ptr(ao), _ptr(sf), C, N,
+                                                                         float(tau), _ptr(out), _stream()),
+                           'piml_pinnsf_epilogue_agentnorm_fwd')
+            else:
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_fwd(_ptr(ap), _ptr(ao), _ptr(sf), rows, float(tau),
+                                                               _ptr(out), _stream()), 'piml_pinnsf_epilogue_fwd')
         ctx.save_for_backward(sf)
-        ctx.tau, ctx.has_obs = float(tau), acc_obs is not None
+        ctx.tau, ctx.has_obs, ctx.agent_norm = float(tau), acc_obs is not None, bool(agent_norm)
         return out
 
     @staticmethod
@@ -520,17 +526,27 @@ class _PinnsfEpilogue(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             g_self = torch.empty_like(sf)
             with torch.cuda.device(sf.device):
-                _lib.check(_lib.lib().piml_pinnsf_epilogue_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, ctx.tau,
-                                                               _ptr(g_self), _stream()), 'piml_pinnsf_epilogue_bwd')
-        return g, (g if ctx.has_obs else None), g_self, None
+                if ctx.agent_norm:
+                    _lib.check(_lib.lib().piml_pinnsf_epilogue_agentnorm_bwd(_ptr(g), _ptr(sf), sf.shape[0], sf.shape[1],
+                                                                             ctx.tau, _ptr(g_self), _stream()),
+                               'piml_pinnsf_epilogue_agentnorm_bwd')
+                else:
+                    _lib.check(_lib.lib().piml_pinnsf_epilogue_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, ctx.tau,
+                                                                   _ptr(g_self), _stream()),
+                               'piml_pinnsf_epilogue_bwd')
+        return g, (g if ctx.has_obs else None), g_self, None, None
 
 
-def pinnsf_epilogue(acc_ped, acc_obs, self_features, tau):
-    """acc_ped + acc_obs + (v0 * dest/|dest| - v) / tau on rows of self_features (..., 7) with the
-    per-row norm (src/models/model.py:1289-1294); acc_obs may be None."""
+def pinnsf_epilogue(acc_ped, acc_obs, self_features, tau, agent_norm=False):
+    """acc_ped + acc_obs + (v0 * dest/|dest| - v) / tau on rows of self_features (..., 7)
+    (src/models/model.py:1289-1294); acc_obs may be None.  agent_norm=False: the per-row norm |dest|.
+    agent_norm=True (3-D input only): the reference's literal dim=1 norm of channelled input, taken over the
+    agents of each slice, per component (quirk Q2)."""
     if self_features.shape[-1] != 7 or acc_ped.shape != self_features.shape[:-1] + (2,):
         raise ValueError('pinnsf_epilogue: acc (..., 2) and self_features (..., 7) expected')
-    return _PinnsfEpilogue.apply(acc_ped, acc_obs, self_features, tau)
+    if agent_norm and self_features.dim() != 3:
+        raise ValueError('pinnsf_epilogue: agent_norm needs (C, N, 7) input')
+    return _PinnsfEpilogue.apply(acc_ped, acc_obs, self_features, tau, bool(agent_norm))
 
 
 class _SelfFeatures(torch.autograd.Function):

@@ -289,3 +289,28 @@ def test_relative_features_packed_self_matches_separate_ops(f0, fc):
     (g_only,) = torch.autograd.grad((ops.relative_features_packed_self(sb, db_, obs, vb, f0, fc)[0] * wp).sum(), [sb])
     (g_only_ref,) = torch.autograd.grad((ops.relative_features_packed(sa, da, obs, f0, fc)[0] * wp).sum(), [sa])
     assert torch.allclose(torch.nan_to_num(g_only), torch.nan_to_num(g_only_ref), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('C,N', [(4, 122), (1, 1000), (3, 5)])
+def test_pinnsf_epilogue_agent_norm_matches_torch(C, N):
+    """Quirk Q2: the dim=1 norm of channelled input (over the agents of a slice, per component)."""
+    from piml_amd import ops
+    sf = rnd(C, N, 7, seed=1)
+    sf[0, :, 1] = 0.0                                   # a slice whose y-components all vanish: t = 0 -> 0.1
+    acc_p, acc_o = rnd(C, N, 2, seed=2), rnd(C, N, 2, seed=3)
+
+    def ref(ap, ao, s, tau=0.5):
+        v0 = s[..., -1].unsqueeze(-1)
+        t = torch.norm(s[..., :2], p=2, dim=1, keepdim=True)
+        t = torch.where(t == 0, t + 0.1, t)
+        return ap + ao + (v0 * (s[..., :2] / t) - s[..., 2:4]) / tau
+    a = [x.clone().requires_grad_(True) for x in (acc_p, acc_o, sf)]
+    w = rnd(C, N, 2, seed=4)
+    out_ref = ref(*a)
+    g_ref = torch.autograd.grad(out_ref, a, w)
+    b = [x.clone().requires_grad_(True) for x in (acc_p, acc_o, sf)]
+    out = ops.pinnsf_epilogue(b[0], b[1], b[2], 0.5, agent_norm=True)
+    g_out = torch.autograd.grad(out, b, w)
+    assert torch.allclose(out, out_ref, rtol=1e-5, atol=1e-5)
+    for x, y in zip(g_out, g_ref):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-5), (x - y).abs().max()

@@ -1,0 +1,19 @@
+"""Graph-replayed fine-tuning step (HOT LOOP C) on the golden GC batch: time per step; run under
+rocprofv3 --kernel-trace --stats for the kernel mix (development aid)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np, torch
+from test_simulator_gpu import sim_args, load_data, make_sim
+
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollout.npz'), allow_pickle=False)
+data = load_data(g, 'train_pinnsf_m')
+sim = make_sim(g, sim_args(learning_rate=1e-3, hip_graph=True), 'train_pinnsf_m/sd/')
+for _ in range(6):
+    sim.train_batch(data)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+for _ in range(n):
+    sim.train_batch(data)
+torch.cuda.synchronize()
+print(f'fine-tune step (graph): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
