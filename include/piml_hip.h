@@ -195,6 +195,30 @@ int piml_rollout_step(float* position, float* velocity, float* acceleration, flo
                       float dt, int remove_arrived, void* stream);
 
 /*
+ * Differentiable frame step of the fine-tuning rollout, BaseSimulator.test_multiple_rollouts_for_training
+ * between the model call and the feature recomputation (src/models/simulators.py:741-769), one launch:
+ *   v' = v + a dt, p' = p + v dt (lagged Euler), a' = a_pred; waypoint switch when |p - dest| < 0.5 (the
+ *   index is clamped at the last waypoint: nobody leaves the scene here); agents flagged in
+ *   new_flag[c, t_next, i] are re-initialised from the (C,T,N,.) ground-truth series of frame t_next
+ *   (new_flag NULL or t_next >= T: no injection).  nan_flag (optional) is OR-ed with 1 when a_pred has a NaN
+ *   (the assert at :745, kept on the device).  State (C,N,.) in, new state out; waypoints as in
+ *   piml_rollout_step.  bwd: with keep = not re-initialised,
+ *   g_p = keep g_p', g_v = keep (g_v' + dt g_p'), g_a = keep dt g_v', g_a_pred = keep g_a'
+ *   (any g_*_out may be NULL = zero; any output may be NULL = not wanted).
+ */
+int piml_train_step_fwd(const float* position, const float* velocity, const float* acceleration,
+                        const float* a_pred, const float* destination, const int64_t* dest_idx,
+                        const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                        const uint8_t* new_flag, const float* position_series, const float* velocity_series,
+                        const float* acceleration_series, const float* destination_series,
+                        const int64_t* dest_idx_series, int C, int T, int N, int t_next, float dt,
+                        float* position_out, float* velocity_out, float* acceleration_out,
+                        float* destination_out, int64_t* dest_idx_out, int* nan_flag, void* stream);
+int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
+                        const uint8_t* new_flag, int C, int T, int N, int t_next, float dt, float* g_position,
+                        float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
+
+/*
  * Glue of the PINNSF network around its (PyTorch-ROCm / rocBLAS) GEMMs -- SURVEY.md row a8:
  * "only the desired-force term and k-sum are candidates to fuse".  The GEMMs stay in torch.
  *

@@ -625,6 +625,60 @@ __global__ void rollout_step_kernel(const RolloutArgs A) {
     A.p[g] = pn; A.v[g] = vn; A.a[g] = an; A.dest[g] = dn; A.dest_idx[g] = idx;
 }
 
+// ---- differentiable frame step of the fine-tuning rollout (src/models/simulators.py:741-769) ----
+struct TrainStepArgs {
+    const float2 *p, *v, *a, *a_pred, *dest; const long long* dest_idx;
+    const float2* waypoints; int D, wp_per_slice; const long long* dest_num;
+    const unsigned char* new_flag;                       // (C, T, N) or NULL
+    const float2 *pos_s, *vel_s, *acc_s, *dest_s; const long long* dest_idx_s;
+    float2 *p_out, *v_out, *a_out, *dest_out; long long* dest_idx_out; int* nan_flag;
+    int C, T, N, t_next; float dt;
+};
+
+// One thread per (slice, agent): lagged explicit Euler, waypoint switch at 0.5 m (nobody is removed
+// in the training rollout), then agents entering at frame t_next are re-initialised from the series.
+__global__ void train_step_fwd_kernel(const TrainStepArgs A) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)A.C * A.N) return;
+    const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
+    const float2 p = A.p[g], v = A.v[g], a = A.a[g], d = A.dest[g];
+    float2 an = A.a_pred[g];
+    if (A.nan_flag && (an.x != an.x || an.y != an.y)) atomicOr(A.nan_flag, 1);           // :745
+    float2 vn = make_float2(__fadd_rn(v.x, __fmul_rn(a.x, A.dt)), __fadd_rn(v.y, __fmul_rn(a.y, A.dt)));   // :741
+    float2 pn = make_float2(__fadd_rn(p.x, __fmul_rn(v.x, A.dt)), __fadd_rn(p.y, __fmul_rn(v.y, A.dt)));   // :742
+    long long idx = A.dest_idx[g];
+    if (norm2(p.x - d.x, p.y - d.y) < 0.5f) idx += 1;                                    // :748-750
+    if (idx > A.dest_num[i] - 1) idx -= 1;                                               // :751-752
+    float2 dn = A.waypoints[((size_t)(A.wp_per_slice ? c : 0) * A.D + idx) * A.N + i];   // :753-754
+    if (A.new_flag && A.t_next < A.T) {
+        const size_t fn = ((size_t)c * A.T + A.t_next) * A.N + i;
+        if (A.new_flag[fn]) {                                                            // :762-769
+            pn = A.pos_s[fn]; vn = A.vel_s[fn]; an = A.acc_s[fn]; dn = A.dest_s[fn]; idx = A.dest_idx_s[fn];
+        }
+    }
+    A.p_out[g] = pn; A.v_out[g] = vn; A.a_out[g] = an; A.dest_out[g] = dn; A.dest_idx_out[g] = idx;
+}
+
+// keep = agent not re-initialised at t_next:  g_p = keep g_p',  g_v = keep (g_v' + dt g_p'),
+// g_a = keep dt g_v',  g_a_pred = keep g_a'.
+__global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
+                                      const float2* __restrict__ ga_o, const unsigned char* __restrict__ new_flag,
+                                      int C, int T, int N, int t_next, float dt, float2* __restrict__ gp,
+                                      float2* __restrict__ gv, float2* __restrict__ ga,
+                                      float2* __restrict__ ga_pred) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)C * N) return;
+    const int c = (int)(g / N), i = (int)(g - (long long)c * N);
+    bool keep = true;
+    if (new_flag && t_next < T) keep = new_flag[((size_t)c * T + t_next) * N + i] == 0;
+    const float2 z = make_float2(0.f, 0.f);
+    const float2 a = (keep && gp_o) ? gp_o[g] : z, b = (keep && gv_o) ? gv_o[g] : z, e = (keep && ga_o) ? ga_o[g] : z;
+    if (gp) gp[g] = a;
+    if (gv) gv[g] = make_float2(b.x + dt * a.x, b.y + dt * a.y);
+    if (ga) ga[g] = make_float2(dt * b.x, dt * b.y);
+    if (ga_pred) ga_pred[g] = e;
+}
+
 }  // namespace piml
 
 PIML_API int piml_rollout_step(float* position, float* velocity, float* acceleration, float* destination,
@@ -654,5 +708,53 @@ PIML_API int piml_rollout_step(float* position, float* velocity, float* accelera
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::rollout_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        piml::as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_train_step_fwd(const float* position, const float* velocity, const float* acceleration,
+                                 const float* a_pred, const float* destination, const int64_t* dest_idx,
+                                 const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                                 const uint8_t* new_flag, const float* position_series,
+                                 const float* velocity_series, const float* acceleration_series,
+                                 const float* destination_series, const int64_t* dest_idx_series, int C, int T,
+                                 int N, int t_next, float dt, float* position_out, float* velocity_out,
+                                 float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
+                                 int* nan_flag, void* stream) {
+    if (C < 0 || T <= 0 || N < 0 || D <= 0 || t_next < 0) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    if (!position || !velocity || !acceleration || !a_pred || !destination || !dest_idx || !waypoints || !dest_num ||
+        !position_out || !velocity_out || !acceleration_out || !destination_out || !dest_idx_out)
+        return hipErrorInvalidValue;
+    if (new_flag && t_next < T &&
+        (!position_series || !velocity_series || !acceleration_series || !destination_series || !dest_idx_series))
+        return hipErrorInvalidValue;
+    piml::TrainStepArgs A;
+    A.p = (const float2*)position; A.v = (const float2*)velocity; A.a = (const float2*)acceleration;
+    A.a_pred = (const float2*)a_pred; A.dest = (const float2*)destination; A.dest_idx = (const long long*)dest_idx;
+    A.waypoints = (const float2*)waypoints; A.D = D; A.wp_per_slice = waypoints_per_slice;
+    A.dest_num = (const long long*)dest_num; A.new_flag = new_flag;
+    A.pos_s = (const float2*)position_series; A.vel_s = (const float2*)velocity_series;
+    A.acc_s = (const float2*)acceleration_series; A.dest_s = (const float2*)destination_series;
+    A.dest_idx_s = (const long long*)dest_idx_series;
+    A.p_out = (float2*)position_out; A.v_out = (float2*)velocity_out; A.a_out = (float2*)acceleration_out;
+    A.dest_out = (float2*)destination_out; A.dest_idx_out = (long long*)dest_idx_out; A.nan_flag = nan_flag;
+    A.C = C; A.T = T; A.N = N; A.t_next = t_next; A.dt = dt;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::train_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       piml::as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out,
+                                 const float* g_acceleration_out, const uint8_t* new_flag, int C, int T, int N,
+                                 int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration,
+                                 float* g_a_pred, void* stream) {
+    if (C < 0 || T <= 0 || N < 0 || t_next < 0) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::train_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
+                       (const float2*)g_acceleration_out, new_flag, C, T, N, t_next, dt, (float2*)g_position,
+                       (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
     return hipGetLastError();
 }

@@ -49,6 +49,9 @@ class BaseSimulator(Pedestrians):
     # the 122-agent clip.  OFF by default: two library GEMMs running concurrently can deadlock when the
     # BLAS heuristics pick stream-K style kernels (see bench.py); enable only with validated GEMM selections.
     SIDE_STREAM_MIN_ROWS = None
+    # the per-frame integrator / waypoint / injection block of the fine-tuning rollout as one HIP launch each
+    # way (ops.train_rollout_step); False keeps the torch-op expression of the same arithmetic
+    fused_train_step = True
 
     def __init__(self, args):
         super().__init__()
@@ -380,6 +383,15 @@ class BaseSimulator(Pedestrians):
         reg_loss = torch.zeros((), device=dev)
         nan_seen = torch.zeros((), device=dev, dtype=torch.bool)
         bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
+        # channelled (C, T, N, .) batches take the fused frame step (piml_train_step_fwd/bwd)
+        fused_step = self.fused_train_step and p_cur.dim() == 3 and p_cur.is_cuda
+        if fused_step:
+            series = tuple(x.contiguous() for x in (data.position, data.velocity, data.acceleration,
+                                                    data.destination, data.dest_idx.long()))
+            new_flag_u8 = new_flag.contiguous().view(torch.uint8)
+            dest_num_i64 = dest_num.long().to(dev).contiguous()
+            dest_idx = dest_idx.long()
+            nan_flag = torch.zeros((), device=dev, dtype=torch.int32)
 
         for t in range(t_start, T):
             predictions = self.model(*state)                                  # :701
@@ -403,23 +415,29 @@ class BaseSimulator(Pedestrians):
                 loss = loss + reg_loss * gf
 
             a_next = predictions[0]
-            nan_seen = nan_seen | a_next.isnan().any()
-            v_next = v_cur + a_cur * dt                                       # :741-743
-            p_next = p_cur + v_cur * dt
+            if fused_step:
+                # :741-769 as one differentiable launch (integrator, waypoint switch, injection, NaN flag)
+                p_cur, v_cur, a_cur, dest_cur, dest_idx = ops.train_rollout_step(
+                    p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt,
+                    new_flag=new_flag_u8, series=series, t_next=t + 1, nan_flag=nan_flag)
+            else:
+                nan_seen = nan_seen | a_next.isnan().any()
+                v_next = v_cur + a_cur * dt                                   # :741-743
+                p_next = p_cur + v_cur * dt
 
-            near = torch.norm(p_cur - dest_cur, p=2, dim=-1) < 0.5           # :748-754, nobody is removed
-            dest_idx = dest_idx + near.long()
-            dest_idx = dest_idx - (dest_idx > dest_num - 1).long()
-            dest_cur = _gather_waypoints(waypoints, dest_idx)
-            p_cur, v_cur, a_cur = p_next, v_next, a_next
+                near = torch.norm(p_cur - dest_cur, p=2, dim=-1) < 0.5       # :748-754, nobody is removed
+                dest_idx = dest_idx + near.long()
+                dest_idx = dest_idx - (dest_idx > dest_num - 1).long()
+                dest_cur = _gather_waypoints(waypoints, dest_idx)
+                p_cur, v_cur, a_cur = p_next, v_next, a_next
 
-            if t < T - 1:                                                     # :762-769
-                new = new_flag[..., t + 1, :]
-                p_cur = self._inject(new, p_cur, data.position[..., t + 1, :, :])
-                v_cur = self._inject(new, v_cur, data.velocity[..., t + 1, :, :])
-                a_cur = self._inject(new, a_cur, data.acceleration[..., t + 1, :, :])
-                dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
-                dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
+                if t < T - 1:                                                 # :762-769
+                    new = new_flag[..., t + 1, :]
+                    p_cur = self._inject(new, p_cur, data.position[..., t + 1, :, :])
+                    v_cur = self._inject(new, v_cur, data.velocity[..., t + 1, :, :])
+                    a_cur = self._inject(new, a_cur, data.acceleration[..., t + 1, :, :])
+                    dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
+                    dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
 
             pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)       # :772-776, differentiable
             state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]      # :778-779
@@ -427,6 +445,8 @@ class BaseSimulator(Pedestrians):
         if args.new_collision_loss_flag:                                      # :782-788
             collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
+        if fused_step:
+            nan_seen = nan_flag != 0
         aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions)}
 
         pad = [torch.zeros_like(p_steps[0])] * t_start

@@ -126,6 +126,8 @@ class _RelativeFeatures(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ped, g_obs, g_dest, _gi, _go):
+        if g_ped is None and g_obs is None and g_dest is None:
+            return (None,) * 14
         ped_idx, obs_idx, p, d_rows = ctx.saved_tensors
         C, N, f0, fcnt, kpe, koe, lead = ctx.geom
         g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx,
@@ -166,6 +168,8 @@ class _RelativeFeaturesPacked(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ped, g_obs, g_dest, _gi, _go):
+        if g_ped is None and g_obs is None and g_dest is None:
+            return (None,) * 11
         ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
         g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx,
                                                 s.data_ptr(), 6, d_rows, s.device)
@@ -212,6 +216,8 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ped, g_obs, g_self, _gi, _go):
+        if g_ped is None and g_obs is None and g_self is None:
+            return (None,) * 12
         ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
         _, N, f0, fcnt, _, _, _ = ctx.geom
         opt = dict(device=s.device, dtype=torch.float32)
@@ -515,11 +521,14 @@ class _PinnsfEpilogue(torch.autograd.Function):
                                                                _ptr(out), _stream()), 'piml_pinnsf_epilogue_fwd')
         ctx.save_for_backward(sf)
         ctx.tau, ctx.has_obs, ctx.agent_norm = float(tau), acc_obs is not None, bool(agent_norm)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if g is None:       # structurally reachable but nothing flows here: propagate "no gradient", launch nothing
+            return (None,) * 5
         (sf,) = ctx.saved_tensors
         g = g.contiguous()
         g_self = None
@@ -561,11 +570,14 @@ class _SelfFeatures(torch.autograd.Function):
             _lib.check(_lib.lib().piml_self_features_fwd(_ptr(d), 2, _ptr(s), _ptr(w), rows, _ptr(out), _stream()),
                        'piml_self_features_fwd')
         ctx.speed_shape = tuple(desired_speed.shape)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
         g = g.contiguous()
         rows = g.shape[0]
         need = ctx.needs_input_grad
@@ -622,11 +634,14 @@ class _LinearAct(torch.autograd.Function):
         out = y.view(*x.shape[:-1], weight.shape[0])
         ctx.save_for_backward(x2, weight, out if relu else None)
         ctx.x_shape = x.shape
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
         x2, weight, y = ctx.saved_tensors
         g2 = g.reshape(-1, weight.shape[0])
         g_pre, db = act_bwd_colsum(g2, y.reshape(-1, weight.shape[0]) if y is not None else None)
@@ -661,12 +676,15 @@ class _MLPChain(torch.autograd.Function):
         out = acts[-1].view(*x.shape[:-1], acts[-1].shape[-1])
         ctx.save_for_backward(*acts[:-1], out, *wb[0::2])
         ctx.relus, ctx.x_shape = tuple(relus), x.shape
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         n = len(ctx.relus)
+        if g is None:
+            return (None,) * (2 + 2 * n)
         saved = ctx.saved_tensors
         acts, out, weights = saved[:n], saved[n], saved[n + 1:]
         need = ctx.needs_input_grad
@@ -743,3 +761,90 @@ def scale_ksum(e, scale=2.0):
     if e.dim() < 2 or e.shape[-1] % 4:
         raise ValueError('scale_ksum: e (..., k, cols) with cols % 4 == 0 expected')
     return _ScaleKSum.apply(e, scale)
+
+
+class _TrainRolloutStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag):
+        p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
+                                 (('position', p), ('velocity', v), ('acceleration', a), ('a_pred', a_pred),
+                                  ('destination', dest))]
+        C, N = p.shape[0], p.shape[1]
+        D = waypoints.shape[-3]
+        per_slice = int(waypoints.dim() == 4)
+        T = series[0].shape[1] if series is not None else max(int(t_next), 1)
+        opt = dict(device=p.device, dtype=torch.float32)
+        outs = [torch.empty(C, N, 2, **opt) for _ in range(4)]
+        idx_out = torch.empty(C, N, device=p.device, dtype=torch.int64)
+        sp = [None] * 5 if series is None else [_ptr(x) for x in series]
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().piml_train_step_fwd(
+                _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
+                _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
+                float(dt), *[_ptr(o) for o in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
+                _stream()), 'piml_train_step_fwd')
+        ctx.new_flag, ctx.geom = new_flag, (C, T, N, int(t_next), float(dt))
+        ctx.mark_non_differentiable(outs[3], idx_out)
+        ctx.set_materialize_grads(False)
+        return (*outs, idx_out)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gp_o, gv_o, ga_o, _gd, _gi):
+        C, T, N, t_next, dt = ctx.geom
+        ref = next((g for g in (gp_o, gv_o, ga_o) if g is not None), None)
+        if ref is None:
+            return (None,) * 13
+        # an output nobody differentiates contributes nothing: hand autograd None (not zeros) so that it does
+        # not walk into the model call that produced a_pred just to propagate a zero gradient
+        live = (gp_o is not None, gp_o is not None or gv_o is not None, gv_o is not None, ga_o is not None)
+        need = ctx.needs_input_grad
+        gs = [torch.empty(C, N, 2, device=ref.device, dtype=torch.float32) if (need[k] and live[k]) else None
+              for k in range(4)]
+        cont = [None if g is None else g.contiguous() for g in (gp_o, gv_o, ga_o)]
+        with torch.cuda.device(ref.device):
+            _lib.check(_lib.lib().piml_train_step_bwd(
+                *[_ptr(g) for g in cont], _ptr(ctx.new_flag) if ctx.new_flag is not None else None, C, T, N, t_next,
+                dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd')
+        return (*gs,) + (None,) * 9
+
+
+def train_rollout_step(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num,
+                       dt, new_flag=None, series=None, t_next=0, nan_flag=None):
+    """One frame of the fine-tuning rollout between the model call and the feature recomputation
+    (src/models/simulators.py:741-769) as one differentiable node: lagged Euler, waypoint switch, injection of
+    the agents entering at frame `t_next` from `series` = (position, velocity, acceleration, destination,
+    dest_idx) each (C, T, N, .).  State tensors are (C, N, 2); dest_idx (C, N) int64; waypoints (D, N, 2) or
+    (C, D, N, 2); dest_num (N) int64; new_flag (C, T, N) uint8 / bool or None; nan_flag: optional int32
+    scalar tensor that is OR-ed with 1 when a_pred contains a NaN.
+    Returns (position', velocity', acceleration', destination', dest_idx')."""
+    if position.dim() != 3 or position.shape[-1] != 2:
+        raise ValueError('train_rollout_step: (C, N, 2) state expected')
+    if not position.is_cuda:
+        raise _lib.PimlHipError('train_rollout_step: expected GPU tensors (piml_amd has no CPU path)')
+    C, N = position.shape[0], position.shape[1]
+    if dest_idx.dtype != torch.int64 or dest_num.dtype != torch.int64:
+        raise TypeError('train_rollout_step: dest_idx / dest_num must be int64')
+    if tuple(dest_idx.shape) != (C, N) or dest_num.numel() != N:
+        raise ValueError('train_rollout_step: dest_idx (C, N) and dest_num (N) expected')
+    if waypoints.dtype != torch.float32 or waypoints.shape[-2:] != (N, 2) or \
+            (waypoints.dim() == 4 and waypoints.shape[0] != C) or waypoints.dim() not in (3, 4):
+        raise ValueError('train_rollout_step: waypoints (D, N, 2) or (C, D, N, 2) float32 expected')
+    if new_flag is not None:
+        if series is None or len(series) != 5:
+            raise ValueError('train_rollout_step: new_flag needs the five ground-truth series')
+        T = series[0].shape[1]
+        if new_flag.dtype == torch.bool:
+            new_flag = new_flag.view(torch.uint8)
+        if new_flag.dtype != torch.uint8 or tuple(new_flag.shape) != (C, T, N):
+            raise ValueError('train_rollout_step: new_flag must be (C, T, N) bool / uint8')
+        new_flag = new_flag.contiguous()
+        for x, w, dt_ in zip(series, (2, 2, 2, 2, None), (torch.float32,) * 4 + (torch.int64,)):
+            want = (C, T, N) + ((w,) if w else ())
+            if tuple(x.shape) != want or x.dtype != dt_ or not x.is_contiguous():
+                raise ValueError(f'train_rollout_step: series tensor must be contiguous {want} {dt_}')
+    else:
+        series = None
+    return _TrainRolloutStep.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(),
+                                   waypoints.contiguous(), dest_num.contiguous(), new_flag, series, int(t_next),
+                                   float(dt), nan_flag)

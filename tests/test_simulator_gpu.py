@@ -201,3 +201,77 @@ def test_training_rollout_more_configs(tag, model_name, ds, finetune):
             assert np.abs(got_g - ref_g).max() <= 2e-3 * max(np.abs(ref_g).max(), 1e-6), k
     total = sum(float(p.grad.abs().sum()) for p in named.values() if p.grad is not None)
     assert np.isclose(total, float(g[f'{tag}/grad_abs_sum']), rtol=2e-3)
+
+
+@pytest.mark.parametrize('model_name', ['pinnsf_m', 'pinnsf_bm'])
+def test_fused_train_step_equals_torch_ops(model_name):
+    """ops.train_rollout_step (integrator + waypoint switch + injection + NaN flag as one launch each way)
+    against the torch-op expression of the same frame step inside the fine-tuning rollout."""
+    g = golden('rollout')
+    tag = f'train_{model_name}'
+    res = {}
+    for fused in (True, False):
+        sim = make_sim(g, sim_args(model=model_name), f'{tag}/sd/')
+        sim.fused_train_step = fused
+        out = sim.test_multiple_rollouts_for_training(load_data(g, tag))
+        out[0].backward()
+        res[fused] = ([float(x.detach()) for x in out], [None if p.grad is None else p.grad.clone()
+                                                          for p in sim.model.parameters()],
+                      (sim.collision_count, sim.hard_collision_count))
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-7), (res[True][0], res[False][0])
+    assert res[True][2] == res[False][2]
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) <= 1e-4 * scale
+
+
+def test_train_rollout_step_op():
+    """The op alone against torch ops, including the gradient cut at re-initialised agents."""
+    from piml_amd import ops
+    from piml_amd.models.simulators import _gather_waypoints
+    C, T, N, D, dt = 3, 4, 50, 3, 0.08
+    gen = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    series = [r(C, T, N, 2) for _ in range(4)] + [torch.randint(0, D, (C, T, N), generator=gen).to(DEV)]
+    p, v, a, ap = r(C, N, 2), r(C, N, 2), r(C, N, 2), r(C, N, 2)
+    p[0, :5] = float('nan')
+    waypoints = r(C, D, N, 2)
+    dest_idx = torch.randint(0, D, (C, N), generator=gen).to(DEV)
+    dest = _gather_waypoints(waypoints, dest_idx).clone()
+    dest[:, ::3] = p[:, ::3] + 0.1                      # some agents within 0.5 m of their waypoint
+    dest_num = torch.randint(1, D + 1, (N,), generator=gen).to(DEV)
+    dest_idx = torch.minimum(dest_idx, (dest_num - 1).expand(C, N))
+    new_flag = (torch.rand(C, T, N, generator=gen) < 0.2).to(DEV)
+    for t_next in (1, T - 1, T):
+        la = [x.clone().requires_grad_(True) for x in (p, v, a, ap)]
+        vn, pn = la[1] + la[2] * dt, la[0] + la[1] * dt
+        near = torch.norm(la[0] - dest, p=2, dim=-1) < 0.5
+        idx = dest_idx + near.long()
+        idx = idx - (idx > dest_num - 1).long()
+        dn = _gather_waypoints(waypoints, idx)
+        an = la[3]
+        if t_next < T:
+            m = new_flag[:, t_next, :]
+            m2 = m.unsqueeze(-1)
+            pn, vn, an, dn = (torch.where(m2, s[:, t_next], x) for s, x in zip(series[:4], (pn, vn, an, dn)))
+            idx = torch.where(m, series[4][:, t_next], idx)
+        w = [r(C, N, 2) for _ in range(3)]
+        loss = sum((torch.nan_to_num(x) * y).sum() for x, y in zip((pn, vn, an), w))
+        g_ref = torch.autograd.grad(loss, la)
+        lb = [x.clone().requires_grad_(True) for x in (p, v, a, ap)]
+        flag = torch.zeros((), device=DEV, dtype=torch.int32)
+        out = ops.train_rollout_step(lb[0], lb[1], lb[2], lb[3], dest, dest_idx, waypoints, dest_num, dt,
+                                     new_flag=new_flag, series=series, t_next=t_next, nan_flag=flag)
+        for got, want in zip(out, (pn, vn, an, dn, idx)):
+            assert torch.equal(torch.nan_to_num(got.float()), torch.nan_to_num(want.detach().float()))
+        loss2 = sum((torch.nan_to_num(x) * y).sum() for x, y in zip(out[:3], w))
+        g_out = torch.autograd.grad(loss2, lb)
+        for x, y in zip(g_out, g_ref):
+            assert torch.allclose(x, y, rtol=1e-6, atol=1e-6)
+        assert int(flag) == 0
+    ap_nan = ap.clone(); ap_nan[1, 7, 0] = float('nan')
+    flag = torch.zeros((), device=DEV, dtype=torch.int32)
+    ops.train_rollout_step(p, v, a, ap_nan, dest, dest_idx, waypoints, dest_num, dt, nan_flag=flag)
+    assert int(flag) == 1
