@@ -373,16 +373,20 @@ class BaseSimulator(Pedestrians):
         new_flag = (data.mask_p - data.mask_p_pred).long() == 1
 
         dev = p_cur.device
-        zeros_ctn = lambda: torch.zeros(mask_pred.shape, device=dev)         # noqa: E731
-        collisions, hard_collisions = zeros_ctn(), zeros_ctn()
-        label_collisions, label_hard = zeros_ctn(), zeros_ctn()
-        p_steps, a_steps = [], []
+        p_steps, a_steps, cnt_steps, lab_steps = [], [], [], []
         pred_collisions = torch.zeros(data.ped_features[..., 0].shape, device=dev)
         true_collision = torch.zeros(data.ped_features[..., 0].shape, device=dev)
         loss = torch.zeros((), device=dev)
         reg_loss = torch.zeros((), device=dev)
         nan_seen = torch.zeros((), device=dev, dtype=torch.bool)
         bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
+        # `if torch.sum(mask) > 0` of every frame (:707), evaluated once for all frames: the per-frame records
+        # below are gated after the loop in one pass instead of frame by frame
+        gates = mask_pred.sum(dim=(0, 2)) > 0                                 # (T,)
+        gates_f = gates.to(p_cur.dtype)
+        need_label_counts = bool(args.new_collision_loss_flag)                # label collisions are only read there
+        if need_label_counts:
+            lab_frames = labels[..., :2].transpose(0, 1).contiguous()         # (T, C, N, 2): frame t is contiguous
         # channelled (C, T, N, .) batches take the fused frame step (piml_train_step_fwd/bwd)
         fused_step = self.fused_train_step and p_cur.dim() == 3 and p_cur.is_cuda
         if fused_step:
@@ -396,17 +400,13 @@ class BaseSimulator(Pedestrians):
         for t in range(t_start, T):
             predictions = self.model(*state)                                  # :701
             p_msg = predictions[1]
-            gate = (mask_pred[:, t, :].sum() > 0)                             # `if torch.sum(mask) > 0` (:707)
-            gf = gate.to(p_cur.dtype)
+            gf = gates_f[t]
 
-            cnt = ops.collision_counts(p_cur, (thr, thr / 2))                 # :708-715, fused, quirk Q7
-            lab = ops.collision_counts(labels[:, t, :, :2].contiguous(), (thr, thr / 2))   # :717-724
-            collisions[:, t, :] = cnt[0] * gf
-            hard_collisions[:, t, :] = cnt[1] * gf
-            label_collisions[:, t, :] = lab[0] * gf
-            label_hard[:, t, :] = lab[1] * gf
-            p_steps.append(torch.where(gate, p_cur, torch.zeros_like(p_cur)))   # :728-729 (NaN-safe gate)
-            a_steps.append(torch.where(gate, a_cur, torch.zeros_like(a_cur)))
+            cnt_steps.append(ops.collision_counts(p_cur, (thr, thr / 2)))     # :708-715, fused, quirk Q7
+            if need_label_counts:
+                lab_steps.append(ops.collision_counts(lab_frames[t], (thr, thr / 2)))   # :717-724
+            p_steps.append(p_cur)                                             # :728-729
+            a_steps.append(a_cur)
             if bm_head:                                                       # :731-733
                 pred_collisions[:, t] = predictions[-1] * gf
                 true_collision[:, t] = self.calculate_collision_label(state[0]) * gf
@@ -442,7 +442,14 @@ class BaseSimulator(Pedestrians):
             pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)       # :772-776, differentiable
             state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]      # :778-779
 
-        if args.new_collision_loss_flag:                                      # :782-788
+        def frames(steps):
+            """per-frame (2, C, N) count records -> two gated (C, T, N) tensors"""
+            pad = [torch.zeros_like(steps[0])] * t_start
+            allf = torch.stack(pad + steps, dim=2) * gates_f.view(1, 1, -1, 1)    # (2, C, T, N)
+            return allf[0], allf[1]
+        collisions, hard_collisions = frames(cnt_steps)
+        if need_label_counts:                                                 # :782-788
+            label_collisions, label_hard = frames(lab_steps)
             collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
         if fused_step:
@@ -450,10 +457,10 @@ class BaseSimulator(Pedestrians):
         aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions)}
 
         pad = [torch.zeros_like(p_steps[0])] * t_start
+        gate4 = gates.view(1, -1, 1, 1)
         p_res = torch.stack(pad + p_steps, dim=1)                             # c, t, n, 2
-        a_res = torch.stack(pad + a_steps, dim=1)
         keep = (mask_pred != 0).unsqueeze(-1)
-        p_res = torch.where(keep, p_res, torch.zeros_like(p_res))             # :793 delete 'nan'
+        p_res = torch.where(keep & gate4, p_res, torch.zeros_like(p_res))     # :728 gate and :793 delete 'nan'
         labels = torch.where(keep, labels, torch.zeros_like(labels))          # :794
         lab_p = labels[:, :, :, :2]
         mse_loss = self.multiple_rollout_mse_loss(p_res, lab_p, args.time_decay, reduction='sum')
@@ -471,6 +478,8 @@ class BaseSimulator(Pedestrians):
                 abnormal_mask=am) * args.collision_loss_weight * args.hard_collision_penalty
             loss = loss + collision_loss + hard_collision_loss
         if args.teacher_weight > 0:                                           # :821-824
+            a_res = torch.stack(pad + a_steps, dim=1)
+            a_res = torch.where(gate4, a_res, torch.zeros_like(a_res))        # :729 (NaN-safe gate)
             a_mse = self.multiple_rollout_mse_loss(a_res, labels[..., 4:6], args.time_decay, reduction='sum',
                                                    reverse=True)
             loss = loss + a_mse * args.teacher_weight
