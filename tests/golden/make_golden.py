@@ -407,47 +407,63 @@ def gen_metrics():
     save('metrics', **out)
 
 
+def _train_case(out, tag, path, model_name, ds, wins, **overrides):
+    """One batch of rollout windows through the reference's test_multiple_rollouts_for_training."""
+    import models.simulators as SIM
+    raw = load_raw(path)
+    args = sim_args(model=model_name, dataset_name=ds, valid_steps=6, **overrides)
+    full = DATA.TimeIndexedPedData()
+    full.make_dataset(args, raw)
+    full.set_dataset_info(full, raw, list(range(len(full))))
+    cdata = full.to_channeled_time_index_data(args.valid_steps, 'slice')
+    batch = DATA.ChanneledTimeIndexedPedData.slice(cdata, wins)
+    for k in DATA_FIELDS:
+        if torch.is_tensor(getattr(batch, k)):
+            setattr(batch, k, getattr(batch, k).clone())
+    torch.manual_seed(666)
+    sim = SIM.BaseSimulator(args)
+    if model_name == 'pinnsf_res':
+        torch.manual_seed(667)
+        sim.set_ft_model(args)
+    sim.model.eval()
+    sim.collision_count = sim.hard_collision_count = 0
+    sim.epoch = sim.batch_idx = 0
+    for k, v in sim.model.state_dict().items():
+        out[f'{tag}/sd/{k}'] = v.clone()
+    dump_data(tag, batch, out)
+    res = sim.test_multiple_rollouts_for_training(batch)
+    res[0].backward()
+    out[f'{tag}/scalars'] = np.array([float(x.detach()) for x in res], np.float64)
+    out[f'{tag}/counts'] = np.array([sim.collision_count, sim.hard_collision_count], np.float64)
+    gsum = {k: (torch.zeros(()) if p.grad is None else p.grad.abs().sum()) for k, p in sim.model.named_parameters()}
+    for k, p in sim.model.named_parameters():
+        if k.startswith(('ped_encoder.mlp.0', 'obs_encoder.mlp.4', 'ped_predictor', 'corrector.2')):
+            out[f'{tag}/grad/{k}'] = torch.zeros_like(p) if p.grad is None else p.grad.clone()
+    out[f'{tag}/grad_abs_sum'] = np.float64(sum(float(v) for v in gsum.values()))
+
+
 def gen_rollout_more():
     """More HOT LOOP C cases: the UCY configuration (tau = 5/6, no obstacles -> 2-point placeholder) and
     the residual fine-tune network (`--model pinnsf_res` after set_ft_model)."""
-    import models.simulators as SIM
     out = {}
-    for tag, path, model_name, ds, wins in (('ucy_m', UCY_CLIP, 'pinnsf_m', 'ucy', [100, 230, 360, 500]),
-                                            ('gc_res', GC_CLIP, 'pinnsf_res', 'gc1560', [300, 420])):
-        raw = load_raw(path)
-        args = sim_args(model=model_name, dataset_name=ds, valid_steps=6)
-        full = DATA.TimeIndexedPedData()
-        full.make_dataset(args, raw)
-        full.set_dataset_info(full, raw, list(range(len(full))))
-        cdata = full.to_channeled_time_index_data(args.valid_steps, 'slice')
-        batch = DATA.ChanneledTimeIndexedPedData.slice(cdata, wins)
-        for k in DATA_FIELDS:
-            if torch.is_tensor(getattr(batch, k)):
-                setattr(batch, k, getattr(batch, k).clone())
-        torch.manual_seed(666)
-        sim = SIM.BaseSimulator(args)
-        if model_name == 'pinnsf_res':
-            torch.manual_seed(667)
-            sim.set_ft_model(args)
-        sim.model.eval()
-        sim.collision_count = sim.hard_collision_count = 0
-        sim.epoch = sim.batch_idx = 0
-        for k, v in sim.model.state_dict().items():
-            out[f'{tag}/sd/{k}'] = v.clone()
-        dump_data(tag, batch, out)
-        res = sim.test_multiple_rollouts_for_training(batch)
-        res[0].backward()
-        out[f'{tag}/scalars'] = np.array([float(x.detach()) for x in res], np.float64)
-        out[f'{tag}/counts'] = np.array([sim.collision_count, sim.hard_collision_count], np.float64)
-        gsum = {k: (torch.zeros(()) if p.grad is None else p.grad.abs().sum()) for k, p in sim.model.named_parameters()}
-        for k, p in sim.model.named_parameters():
-            if k.startswith(('ped_encoder.mlp.0', 'obs_encoder.mlp.4', 'ped_predictor', 'corrector.2')):
-                out[f'{tag}/grad/{k}'] = torch.zeros_like(p) if p.grad is None else p.grad.clone()
-        out[f'{tag}/grad_abs_sum'] = np.float64(sum(float(v) for v in gsum.values()))
+    _train_case(out, 'ucy_m', UCY_CLIP, 'pinnsf_m', 'ucy', [100, 230, 360, 500])
+    _train_case(out, 'gc_res', GC_CLIP, 'pinnsf_res', 'gc1560', [300, 420])
     save('rollout_more', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more)
+def gen_rollout_flags():
+    """HOT LOOP C with the non-default loss switches on: new_collision_loss_flag (label collisions mask
+    the collision terms), teacher_weight (acceleration MSE), reg_weight (cumulative L1 of the messages), and the
+    bottleneck-multitask collision head (BCE against calculate_collision_label)."""
+    out = {}
+    _train_case(out, 'gc_flags_bm', GC_CLIP, 'pinnsf_bm', 'gc1560', [300, 420, 560], new_collision_loss_flag=1,
+                teacher_weight=0.5, reg_weight=1e-3)
+    _train_case(out, 'gc_flags_m', GC_CLIP, 'pinnsf_m', 'gc1560', [250, 480], new_collision_loss_flag=1,
+                teacher_weight=0.25, reg_weight=1e-4, collision_loss_version='v0')
+    save('rollout_flags', **out)
+
+
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
