@@ -205,6 +205,9 @@ int piml_rollout_step(float* position, float* velocity, float* acceleration, flo
  *   piml_rollout_step.  bwd: with keep = not re-initialised,
  *   g_p = keep g_p', g_v = keep (g_v' + dt g_p'), g_a = keep dt g_v', g_a_pred = keep g_a'
  *   (any g_*_out may be NULL = zero; any output may be NULL = not wanted).
+ * zero_mask (C,N) uint8, optional: when given, NaN components of v' and a' are replaced by 0 -- what the
+ * next Pedestrians.get_relative_features call would do to them in place (src/data/data.py:483-484) -- and
+ * the mask records which (bits 0-1: v'.xy, bits 2-3: a'.xy); bwd passes no gradient through those.
  */
 int piml_train_step_fwd(const float* position, const float* velocity, const float* acceleration,
                         const float* a_pred, const float* destination, const int64_t* dest_idx,
@@ -213,10 +216,11 @@ int piml_train_step_fwd(const float* position, const float* velocity, const floa
                         const float* acceleration_series, const float* destination_series,
                         const int64_t* dest_idx_series, int C, int T, int N, int t_next, float dt,
                         float* position_out, float* velocity_out, float* acceleration_out,
-                        float* destination_out, int64_t* dest_idx_out, int* nan_flag, void* stream);
+                        float* destination_out, int64_t* dest_idx_out, int* nan_flag, uint8_t* zero_mask,
+                        void* stream);
 int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
-                        const uint8_t* new_flag, int C, int T, int N, int t_next, float dt, float* g_position,
-                        float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
+                        const uint8_t* new_flag, const uint8_t* zero_mask, int C, int T, int N, int t_next, float dt,
+                        float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
 
 /*
  * Glue of the PINNSF network around its (PyTorch-ROCm / rocBLAS) GEMMs -- SURVEY.md row a8:

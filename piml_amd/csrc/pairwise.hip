@@ -631,7 +631,7 @@ struct TrainStepArgs {
     const float2* waypoints; int D, wp_per_slice; const long long* dest_num;
     const unsigned char* new_flag;                       // (C, T, N) or NULL
     const float2 *pos_s, *vel_s, *acc_s, *dest_s; const long long* dest_idx_s;
-    float2 *p_out, *v_out, *a_out, *dest_out; long long* dest_idx_out; int* nan_flag;
+    float2 *p_out, *v_out, *a_out, *dest_out; long long* dest_idx_out; int* nan_flag; unsigned char* zero_mask;
     int C, T, N, t_next; float dt;
 };
 
@@ -656,6 +656,14 @@ __global__ void train_step_fwd_kernel(const TrainStepArgs A) {
             pn = A.pos_s[fn]; vn = A.vel_s[fn]; an = A.acc_s[fn]; dn = A.dest_s[fn]; idx = A.dest_idx_s[fn];
         }
     }
+    if (A.zero_mask) {       // the NaN -> 0 that get_relative_features applies to v, a in place (data.py:483-484)
+        unsigned m = 0;
+        if (vn.x != vn.x) { vn.x = 0.f; m |= 1u; }
+        if (vn.y != vn.y) { vn.y = 0.f; m |= 2u; }
+        if (an.x != an.x) { an.x = 0.f; m |= 4u; }
+        if (an.y != an.y) { an.y = 0.f; m |= 8u; }
+        A.zero_mask[g] = (unsigned char)m;
+    }
     A.p_out[g] = pn; A.v_out[g] = vn; A.a_out[g] = an; A.dest_out[g] = dn; A.dest_idx_out[g] = idx;
 }
 
@@ -663,7 +671,8 @@ __global__ void train_step_fwd_kernel(const TrainStepArgs A) {
 // g_a = keep dt g_v',  g_a_pred = keep g_a'.
 __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
                                       const float2* __restrict__ ga_o, const unsigned char* __restrict__ new_flag,
-                                      int C, int T, int N, int t_next, float dt, float2* __restrict__ gp,
+                                      const unsigned char* __restrict__ zero_mask, int C, int T, int N, int t_next,
+                                      float dt, float2* __restrict__ gp,
                                       float2* __restrict__ gv, float2* __restrict__ ga,
                                       float2* __restrict__ ga_pred) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,7 +681,15 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
     bool keep = true;
     if (new_flag && t_next < T) keep = new_flag[((size_t)c * T + t_next) * N + i] == 0;
     const float2 z = make_float2(0.f, 0.f);
-    const float2 a = (keep && gp_o) ? gp_o[g] : z, b = (keep && gv_o) ? gv_o[g] : z, e = (keep && ga_o) ? ga_o[g] : z;
+    const float2 a = (keep && gp_o) ? gp_o[g] : z;
+    float2 b = (keep && gv_o) ? gv_o[g] : z, e = (keep && ga_o) ? ga_o[g] : z;
+    if (zero_mask) {         // components that were NaN and zeroed in the forward pass pass no gradient
+        const unsigned m = zero_mask[g];
+        if (m & 1u) b.x = 0.f;
+        if (m & 2u) b.y = 0.f;
+        if (m & 4u) e.x = 0.f;
+        if (m & 8u) e.y = 0.f;
+    }
     if (gp) gp[g] = a;
     if (gv) gv[g] = make_float2(b.x + dt * a.x, b.y + dt * a.y);
     if (ga) ga[g] = make_float2(dt * b.x, dt * b.y);
@@ -719,7 +736,7 @@ PIML_API int piml_train_step_fwd(const float* position, const float* velocity, c
                                  const float* destination_series, const int64_t* dest_idx_series, int C, int T,
                                  int N, int t_next, float dt, float* position_out, float* velocity_out,
                                  float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
-                                 int* nan_flag, void* stream) {
+                                 int* nan_flag, uint8_t* zero_mask, void* stream) {
     if (C < 0 || T <= 0 || N < 0 || D <= 0 || t_next < 0) return hipErrorInvalidValue;
     if ((long)C * N == 0) return hipSuccess;
     if (!position || !velocity || !acceleration || !a_pred || !destination || !dest_idx || !waypoints || !dest_num ||
@@ -738,6 +755,7 @@ PIML_API int piml_train_step_fwd(const float* position, const float* velocity, c
     A.dest_idx_s = (const long long*)dest_idx_series;
     A.p_out = (float2*)position_out; A.v_out = (float2*)velocity_out; A.a_out = (float2*)acceleration_out;
     A.dest_out = (float2*)destination_out; A.dest_idx_out = (long long*)dest_idx_out; A.nan_flag = nan_flag;
+    A.zero_mask = zero_mask;
     A.C = C; A.T = T; A.N = N; A.t_next = t_next; A.dt = dt;
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::train_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -746,15 +764,15 @@ PIML_API int piml_train_step_fwd(const float* position, const float* velocity, c
 }
 
 PIML_API int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out,
-                                 const float* g_acceleration_out, const uint8_t* new_flag, int C, int T, int N,
-                                 int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration,
-                                 float* g_a_pred, void* stream) {
+                                 const float* g_acceleration_out, const uint8_t* new_flag, const uint8_t* zero_mask,
+                                 int C, int T, int N, int t_next, float dt, float* g_position, float* g_velocity,
+                                 float* g_acceleration, float* g_a_pred, void* stream) {
     if (C < 0 || T <= 0 || N < 0 || t_next < 0) return hipErrorInvalidValue;
     if ((long)C * N == 0) return hipSuccess;
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::train_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
-                       (const float2*)g_acceleration_out, new_flag, C, T, N, t_next, dt, (float2*)g_position,
+                       (const float2*)g_acceleration_out, new_flag, zero_mask, C, T, N, t_next, dt, (float2*)g_position,
                        (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
     return hipGetLastError();
 }

@@ -765,7 +765,8 @@ def scale_ksum(e, scale=2.0):
 
 class _TrainRolloutStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag):
+    def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag,
+                zero_nan):
         p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
                                  (('position', p), ('velocity', v), ('acceleration', a), ('a_pred', a_pred),
                                   ('destination', dest))]
@@ -777,13 +778,14 @@ class _TrainRolloutStep(torch.autograd.Function):
         outs = [torch.empty(C, N, 2, **opt) for _ in range(4)]
         idx_out = torch.empty(C, N, device=p.device, dtype=torch.int64)
         sp = [None] * 5 if series is None else [_ptr(x) for x in series]
+        zero_mask = torch.empty(C, N, device=p.device, dtype=torch.uint8) if zero_nan else None
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().piml_train_step_fwd(
                 _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
                 _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
                 float(dt), *[_ptr(o) for o in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
-                _stream()), 'piml_train_step_fwd')
-        ctx.new_flag, ctx.geom = new_flag, (C, T, N, int(t_next), float(dt))
+                _ptr(zero_mask) if zero_mask is not None else None, _stream()), 'piml_train_step_fwd')
+        ctx.new_flag, ctx.zero_mask, ctx.geom = new_flag, zero_mask, (C, T, N, int(t_next), float(dt))
         ctx.mark_non_differentiable(outs[3], idx_out)
         ctx.set_materialize_grads(False)
         return (*outs, idx_out)
@@ -794,7 +796,7 @@ class _TrainRolloutStep(torch.autograd.Function):
         C, T, N, t_next, dt = ctx.geom
         ref = next((g for g in (gp_o, gv_o, ga_o) if g is not None), None)
         if ref is None:
-            return (None,) * 13
+            return (None,) * 14
         # an output nobody differentiates contributes nothing: hand autograd None (not zeros) so that it does
         # not walk into the model call that produced a_pred just to propagate a zero gradient
         live = (gp_o is not None, gp_o is not None or gv_o is not None, gv_o is not None, ga_o is not None)
@@ -804,19 +806,22 @@ class _TrainRolloutStep(torch.autograd.Function):
         cont = [None if g is None else g.contiguous() for g in (gp_o, gv_o, ga_o)]
         with torch.cuda.device(ref.device):
             _lib.check(_lib.lib().piml_train_step_bwd(
-                *[_ptr(g) for g in cont], _ptr(ctx.new_flag) if ctx.new_flag is not None else None, C, T, N, t_next,
+                *[_ptr(g) for g in cont], _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
+                _ptr(ctx.zero_mask) if ctx.zero_mask is not None else None, C, T, N, t_next,
                 dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd')
-        return (*gs,) + (None,) * 9
+        return (*gs,) + (None,) * 10
 
 
 def train_rollout_step(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num,
-                       dt, new_flag=None, series=None, t_next=0, nan_flag=None):
+                       dt, new_flag=None, series=None, t_next=0, nan_flag=None, zero_nan=False):
     """One frame of the fine-tuning rollout between the model call and the feature recomputation
     (src/models/simulators.py:741-769) as one differentiable node: lagged Euler, waypoint switch, injection of
     the agents entering at frame `t_next` from `series` = (position, velocity, acceleration, destination,
     dest_idx) each (C, T, N, .).  State tensors are (C, N, 2); dest_idx (C, N) int64; waypoints (D, N, 2) or
     (C, D, N, 2); dest_num (N) int64; new_flag (C, T, N) uint8 / bool or None; nan_flag: optional int32
-    scalar tensor that is OR-ed with 1 when a_pred contains a NaN.
+    scalar tensor that is OR-ed with 1 when a_pred contains a NaN.  zero_nan: also apply, to the new
+    velocity / acceleration, the NaN -> 0 that the next get_relative_features call performs in place
+    (src/data/data.py:483-484), with the matching gradient cut.
     Returns (position', velocity', acceleration', destination', dest_idx')."""
     if position.dim() != 3 or position.shape[-1] != 2:
         raise ValueError('train_rollout_step: (C, N, 2) state expected')
@@ -847,4 +852,4 @@ def train_rollout_step(position, velocity, acceleration, a_pred, destination, de
         series = None
     return _TrainRolloutStep.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(),
                                    waypoints.contiguous(), dest_num.contiguous(), new_flag, series, int(t_next),
-                                   float(dt), nan_flag)
+                                   float(dt), nan_flag, bool(zero_nan))

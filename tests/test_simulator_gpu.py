@@ -284,3 +284,32 @@ def test_train_rollout_step_op():
     flag = torch.zeros((), device=DEV, dtype=torch.int32)
     ops.train_rollout_step(p, v, a, ap_nan, dest, dest_idx, waypoints, dest_num, dt, nan_flag=flag)
     assert int(flag) == 1
+
+
+def test_train_rollout_step_zero_nan():
+    """zero_nan = the in-place NaN -> 0 of the next get_relative_features call (data.py:483-484) folded into
+    the step, with its gradient cut."""
+    from piml_amd import ops
+    C, N, D, dt = 2, 40, 2, 0.08
+    gen = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=gen).to(DEV)
+    p, v, a, ap = r(C, N, 2), r(C, N, 2), r(C, N, 2), r(C, N, 2)
+    v[0, 3, 0] = float('nan'); a[1, 5, 1] = float('nan'); ap[0, 7, :] = float('nan')
+    waypoints = r(D, N, 2)
+    dest_idx = torch.zeros(C, N, dtype=torch.int64, device=DEV)
+    dest = waypoints[0].expand(C, N, 2).contiguous()
+    dest_num = torch.full((N,), D, dtype=torch.int64, device=DEV)
+    la = [x.clone().requires_grad_(True) for x in (p, v, a, ap)]
+    vn, pn, an = la[1] + la[2] * dt, la[0] + la[1] * dt, la[3] * 1.0
+    vn = vn.masked_fill(vn.isnan(), 0)
+    an = an.masked_fill(an.isnan(), 0)
+    w = [r(C, N, 2) for _ in range(3)]
+    g_ref = torch.autograd.grad(sum((torch.nan_to_num(x) * y).sum() for x, y in zip((pn, vn, an), w)), la)
+    lb = [x.clone().requires_grad_(True) for x in (p, v, a, ap)]
+    out = ops.train_rollout_step(lb[0], lb[1], lb[2], lb[3], dest, dest_idx, waypoints, dest_num, dt, zero_nan=True)
+    assert not out[1].isnan().any() and not out[2].isnan().any()
+    for got, want in zip(out[:3], (pn, vn, an)):
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want.detach()))
+    g_out = torch.autograd.grad(sum((torch.nan_to_num(x) * y).sum() for x, y in zip(out[:3], w)), lb)
+    for x, y in zip(g_out, g_ref):
+        assert torch.allclose(torch.nan_to_num(x), torch.nan_to_num(y), rtol=1e-6, atol=1e-6)
