@@ -274,6 +274,13 @@ int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, f
                         float* db, void* stream);
 
 /*
+ * out[j] = sum_b parts[b, j] for parts (B, n) row-major, n % 4 == 0, in a fixed order: the reduction step of
+ * the chunked weight-gradient formulation dW = sum_b G_b^T X_b (the per-chunk products are one strided-batched
+ * library GEMM; see ops._MLPChain), replacing the library's split-K GEMM + its reduction kernel.
+ */
+int piml_sum_leading(const float* parts, int B, size_t n, float* out, void* stream);
+
+/*
  * Neighbour-axis sum of the PINNSF processor output (src/models/model.py:1279-1283 with quirk Q3:
  * processor(x) = scale * x, scale = 2 in eval mode): msgs = scale * e (rows,cols) and
  * pooled[r / k] = sum over the k rows of one agent of msgs.  bwd: g_e = scale * (g_pooled[r / k] +

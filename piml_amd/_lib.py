@@ -41,6 +41,7 @@ SIGNATURES = {
     'piml_self_features_bwd': [_p, _z, _p, _p, _p, _p],
     'piml_colsum_blocks': [_z, _i],
     'piml_act_bwd_colsum': [_p, _p, _z, _i, _p, _p, _p, _p],
+    'piml_sum_leading': [_p, _i, _z, _p, _p],
     'piml_scale_ksum_fwd': [_p, _z, _i, _i, _f, _p, _p, _p],
     'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],

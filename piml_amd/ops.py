@@ -657,6 +657,38 @@ def linear_act(x, weight, bias, relu):
     return _LinearAct.apply(x, weight, bias, bool(relu))
 
 
+# Chunked weight gradient: dW = G^T X with K = rows (tens of thousands) and M, N <= 128 is a pure split-K
+# problem; rocBLAS's split-K kernel + reduction needs 28-38 us for the 128 x 128 layers of the bench step.
+# The same product as ONE strided-batched GEMM over 64 row chunks (10-15 us with the tuned selection) + a
+# 3 us sum over the chunks is ~1.7x faster.  Only used when the tuned GEMM selections are in effect
+# (piml_amd.tuning): the default heuristics for these batched shapes are erratic (measured 16-51 us).
+WGRAD_CHUNKS = 64
+WGRAD_MIN_ROWS = 16384
+
+
+def sum_leading(parts):
+    """parts (B, ...) -> parts.sum(0) in a fixed order (HIP); numel of one slice % 4 == 0."""
+    parts = _gpu_f32('parts', parts)
+    out = torch.empty(parts.shape[1:], device=parts.device, dtype=torch.float32)
+    with torch.cuda.device(parts.device):
+        _lib.check(_lib.lib().piml_sum_leading(_ptr(parts), parts.shape[0], out.numel(), _ptr(out), _stream()),
+                   'piml_sum_leading')
+    return out
+
+
+def _weight_grad(g_pre, x):
+    """g_pre (R, out)^T @ x (R, in) -> (out, in)."""
+    from . import tuning
+    R, cout = g_pre.shape
+    cin = x.shape[1]
+    if tuning.LOADED and R >= WGRAD_MIN_ROWS and R % WGRAD_CHUNKS == 0 and cout * cin >= 4096 and (cout * cin) % 4 == 0 \
+            and g_pre.is_contiguous() and x.is_contiguous():
+        B = WGRAD_CHUNKS
+        parts = torch.bmm(g_pre.view(B, R // B, cout).transpose(1, 2), x.view(B, R // B, cin))
+        return sum_leading(parts)
+    return g_pre.t().mm(x)
+
+
 class _MLPChain(torch.autograd.Function):
     """A whole MLP (src/models/model.py:40-65): Linear(+ReLU) layers back to back as ONE autograd node.
     Forward: one hipBLASLt GEMM per layer with bias (+ReLU) in its epilogue.  Backward, per layer from the
@@ -699,7 +731,7 @@ class _MLPChain(torch.autograd.Function):
             if need[2 + 2 * i + 1]:
                 grads[2 * i + 1] = db
             if need[2 + 2 * i]:
-                grads[2 * i] = g_pre.t().mm(acts[i])
+                grads[2 * i] = _weight_grad(g_pre, acts[i])
             if i > 0 or need[0]:
                 g_cur = g_pre.mm(w)
         gx = g_cur.view(ctx.x_shape) if need[0] else None

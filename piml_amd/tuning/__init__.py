@@ -9,6 +9,8 @@ import sys
 
 import torch
 
+LOADED = False      # True once torch accepted a result file: the tuned selections are in effect
+
 DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tunableop_gfx950_cfg3.csv')
 
 
@@ -21,7 +23,9 @@ def load(path=DEFAULT_FILE):
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
         torch.cuda.tunable.record_untuned_enable(False)
-        return bool(torch.cuda.tunable.read_file(path))
+        global LOADED
+        LOADED = bool(torch.cuda.tunable.read_file(path))
+        return LOADED
     except Exception as ex:   # noqa: BLE001 - a missing / changed API means: stay on the defaults
         print(f'[piml_amd] TunableOp results not loaded ({ex})', file=sys.stderr)
         return False

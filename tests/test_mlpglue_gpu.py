@@ -314,3 +314,21 @@ def test_pinnsf_epilogue_agent_norm_matches_torch(C, N):
     assert torch.allclose(out, out_ref, rtol=1e-5, atol=1e-5)
     for x, y in zip(g_out, g_ref):
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-5), (x - y).abs().max()
+
+
+@pytest.mark.parametrize('rows,cin,cout', [(40960, 128, 128), (24576, 128, 128), (16384, 64, 128)])
+def test_chunked_weight_gradient(rows, cin, cout, monkeypatch):
+    """dW as one strided-batched GEMM over 64 row chunks + the HIP chunk sum == G^T X."""
+    from piml_amd import ops, tuning
+    g, x = rnd(rows, cout, seed=1), rnd(rows, cin, seed=2)
+    want = g.double().t().mm(x.double())
+    monkeypatch.setattr(tuning, 'LOADED', True)
+    got = ops._weight_grad(g, x)
+    monkeypatch.setattr(tuning, 'LOADED', False)
+    plain = ops._weight_grad(g, x)
+    scale = float(want.abs().max())
+    assert got.shape == (cout, cin)
+    assert float((got.double() - want).abs().max()) <= 2e-5 * scale      # f32 accumulation over `rows` terms
+    assert float((plain.double() - want).abs().max()) <= 2e-5 * scale
+    parts = rnd(7, 33, 4, seed=3)
+    assert torch.allclose(ops.sum_leading(parts), parts.sum(0), rtol=1e-6, atol=1e-6)
