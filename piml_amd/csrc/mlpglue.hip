@@ -353,25 +353,38 @@ __global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __res
 }
 
 // out[j] = sum_b parts[b, j]: the reduction over row chunks of the chunked weight-gradient GEMM
-// (parts (B, n) row-major, n % 4 == 0); one float4 column lane per thread, fixed summation order.
+// (parts (B, n) row-major, n % 4 == 0).  64 float4 column lanes x 4 chunk groups per block (a fixed
+// summation order: group g takes chunks g, g+4, ...; the groups are added 0..3).
 __global__ __launch_bounds__(256) void sum_leading_kernel(const float4* __restrict__ parts, int B, size_t lanes,
                                                            float4* __restrict__ out) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= lanes) return;
+    __shared__ float4 sh[256];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t j = (size_t)blockIdx.x * 64 + lane;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int b = 0;
-    for (; b + 3 < B; b += 4) {
-        float4 v[4];
+    if (j < lanes) {
+        int b = grp;
+        for (; b + 12 < B; b += 16) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(b + u) * lanes + j];
+            for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(b + 4 * u) * lanes + j];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; b < B; b += 4) {
+            const float4 v = parts[(size_t)b * lanes + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    for (; b < B; ++b) {
-        const float4 v = parts[(size_t)b * lanes + j];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && j < lanes) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = sh[q * 64 + lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[j] = s;
     }
-    out[j] = s;
 }
 
 inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -507,7 +520,7 @@ PIML_API int piml_sum_leading(const float* parts, int B, size_t n, float* out, v
     if (B <= 0 || n % 4) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     if (!parts || !out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sum_leading_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(sum_leading_kernel, dim3(blocks_for(n / 4, 64)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(parts), B, n / 4, reinterpret_cast<float4*>(out));
     return hipGetLastError();
 }
