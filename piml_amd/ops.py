@@ -662,8 +662,7 @@ def linear_act(x, weight, bias, relu):
 # The same product as ONE strided-batched GEMM over 64 row chunks (10-15 us with the tuned selection) + a
 # 3 us sum over the chunks is ~1.7x faster.  Only used when the tuned GEMM selections are in effect
 # (piml_amd.tuning): the default heuristics for these batched shapes are erratic (measured 16-51 us).
-WGRAD_CHUNKS = 64
-WGRAD_MIN_ROWS = 16384
+WGRAD_CHUNKS = ((16384, 64), (2048, 16))     # (minimum rows, chunks): 64 chunks for the encoder layers, 16 for the decoder's
 
 
 def sum_leading(parts):
@@ -681,9 +680,9 @@ def _weight_grad(g_pre, x):
     from . import tuning
     R, cout = g_pre.shape
     cin = x.shape[1]
-    if tuning.LOADED and R >= WGRAD_MIN_ROWS and R % WGRAD_CHUNKS == 0 and cout * cin >= 4096 and (cout * cin) % 4 == 0 \
+    B = next((b for rmin, b in WGRAD_CHUNKS if R >= rmin), 0)
+    if tuning.LOADED and B and R % B == 0 and cout * cin >= 4096 and (cout * cin) % 4 == 0 \
             and g_pre.is_contiguous() and x.is_contiguous():
-        B = WGRAD_CHUNKS
         parts = torch.bmm(g_pre.view(B, R // B, cout).transpose(1, 2), x.view(B, R // B, cin))
         return sum_leading(parts)
     return g_pre.t().mm(x)

@@ -316,7 +316,8 @@ def test_pinnsf_epilogue_agent_norm_matches_torch(C, N):
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-5), (x - y).abs().max()
 
 
-@pytest.mark.parametrize('rows,cin,cout', [(40960, 128, 128), (24576, 128, 128), (16384, 64, 128)])
+@pytest.mark.parametrize('rows,cin,cout', [(40960, 128, 128), (24576, 128, 128), (16384, 64, 128), (4096, 128, 64),
+                                           (4096, 64, 64), (2928, 128, 128)])
 def test_chunked_weight_gradient(rows, cin, cout, monkeypatch):
     """dW as one strided-batched GEMM over 64 row chunks + the HIP chunk sum == G^T X."""
     from piml_amd import ops, tuning

@@ -24,13 +24,18 @@ def timed(fn, reps=200):
     t = _lib.StreamTimer(); t.start()
     for _ in range(reps // 20): g.replay()
     t.stop(); return t.elapsed_ms() * 1e3 / reps
-for rows in (40960, 24576):
-    G = torch.randn(rows, 128, device=dev); X = torch.randn(rows, 128, device=dev)
+shapes = [(40960, 128, 128), (24576, 128, 128), (4096, 128, 64), (4096, 64, 64)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for rows, cin, cout in shapes:
+    G = torch.randn(rows, cout, device=dev); X = torch.randn(rows, cin, device=dev)
+    torch.cuda.tunable.tuning_enable(False)
+    print(f'rows {rows} in {cin} out {cout}: plain mm {timed(lambda: G.t().mm(X)):.1f} us', flush=True)
+    torch.cuda.tunable.tuning_enable(True)
     for B in (8, 16, 32, 64):
-        f = lambda: torch.bmm(G.view(B, rows // B, 128).transpose(1, 2), X.view(B, rows // B, 128))
+        f = lambda: torch.bmm(G.view(B, rows // B, cout).transpose(1, 2), X.view(B, rows // B, cin))
         f(); torch.cuda.synchronize()         # tunes here
         torch.cuda.tunable.tuning_enable(False)
-        print(f'rows {rows} B={B}: bmm alone {timed(f):.1f} us', flush=True)
+        print(f'   B={B}: bmm alone {timed(f):.1f} us', flush=True)
         torch.cuda.tunable.tuning_enable(True)
-torch.cuda.tunable.write_file(out)
-print(open(out).read()[-1500:])
+print(open(out).read()[-2500:] if os.path.exists(out) else 'no file yet (written at exit)')
