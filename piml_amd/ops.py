@@ -681,7 +681,7 @@ def _weight_grad(g_pre, x):
     R, cout = g_pre.shape
     cin = x.shape[1]
     B = next((b for rmin, b in WGRAD_CHUNKS if R >= rmin), 0)
-    if tuning.LOADED and B and R % B == 0 and cout * cin >= 4096 and (cout * cin) % 4 == 0 \
+    if tuning.LOADED and B and R % B == 0 and cout * cin >= 128 and (cout * cin) % 4 == 0 \
             and g_pre.is_contiguous() and x.is_contiguous():
         parts = torch.bmm(g_pre.view(B, R // B, cout).transpose(1, 2), x.view(B, R // B, cin))
         return sum_leading(parts)

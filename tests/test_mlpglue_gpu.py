@@ -317,7 +317,7 @@ def test_pinnsf_epilogue_agent_norm_matches_torch(C, N):
 
 
 @pytest.mark.parametrize('rows,cin,cout', [(40960, 128, 128), (24576, 128, 128), (16384, 64, 128), (4096, 128, 64),
-                                           (4096, 64, 64), (2928, 128, 128)])
+                                           (4096, 64, 64), (2928, 128, 128), (40960, 6, 128), (4096, 64, 2)])
 def test_chunked_weight_gradient(rows, cin, cout, monkeypatch):
     """dW as one strided-batched GEMM over 64 row chunks + the HIP chunk sum == G^T X."""
     from piml_amd import ops, tuning
