@@ -279,6 +279,17 @@ int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, f
  * library GEMM; see ops._MLPChain), replacing the library's split-K GEMM + its reduction kernel.
  */
 int piml_sum_leading(const float* parts, int B, size_t n, float* out, void* stream);
+/*
+ * The two small reductions that close one layer's backward in ONE launch: piml_sum_leading on (parts, B, n,
+ * out) and the second stage of the bias-gradient sum on the `col_partials` (nb, cols) that
+ * piml_act_bwd_colsum_stage1 left behind (same contract as piml_act_bwd_colsum minus its second launch; with
+ * piml_colsum_blocks(rows, cols) == 1 it has already written db and there is nothing left to do).
+ * Either half may be absent (parts NULL / col_partials NULL or nb <= 1).
+ */
+int piml_act_bwd_colsum_stage1(const float* g, const float* y, size_t rows, int cols, float* g_pre, float* partials,
+                               float* db, void* stream);
+int piml_layer_reduce(const float* parts, int B, size_t n, float* out, const float* col_partials, int nb, int cols,
+                      float* db, void* stream);
 
 /*
  * Neighbour-axis sum of the PINNSF processor output (src/models/model.py:1279-1283 with quirk Q3:

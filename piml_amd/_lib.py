@@ -42,6 +42,8 @@ SIGNATURES = {
     'piml_colsum_blocks': [_z, _i],
     'piml_act_bwd_colsum': [_p, _p, _z, _i, _p, _p, _p, _p],
     'piml_sum_leading': [_p, _i, _z, _p, _p],
+    'piml_act_bwd_colsum_stage1': [_p, _p, _z, _i, _p, _p, _p, _p],
+    'piml_layer_reduce': [_p, _i, _z, _p, _p, _i, _i, _p, _p],
     'piml_scale_ksum_fwd': [_p, _z, _i, _i, _f, _p, _p, _p],
     'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],

@@ -294,11 +294,9 @@ __global__ __launch_bounds__(kColsumThreads) void act_bwd_colsum_kernel(const fl
 
 // stage 2: block `lane` sums column lane `lane` of the (nb, lanes) partials in a fixed order
 template <int V>
-__global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const float* __restrict__ partials, int nb,
-                                                                       int lanes, float* __restrict__ db) {
+__device__ __forceinline__ void colsum_stage2_body(const float* __restrict__ partials, int nb, int lanes, int lane,
+                                                   float* __restrict__ db, typename Vec<V>::type* sh) {
     typedef typename Vec<V>::type T;
-    __shared__ T sh[kColsumThreads];
-    const int lane = blockIdx.x;
     const T* p = reinterpret_cast<const T*>(partials);
     T acc = Vec<V>::zero();
     for (int r = threadIdx.x; r < nb; r += kColsumThreads) Vec<V>::add(acc, p[(size_t)r * lanes + lane]);
@@ -309,6 +307,13 @@ __global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const flo
         __syncthreads();
     }
     if (threadIdx.x == 0) reinterpret_cast<T*>(db)[lane] = sh[0];
+}
+
+template <int V>
+__global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const float* __restrict__ partials, int nb,
+                                                                       int lanes, float* __restrict__ db) {
+    __shared__ typename Vec<V>::type sh[kColsumThreads];
+    colsum_stage2_body<V>(partials, nb, lanes, blockIdx.x, db, sh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,11 +360,10 @@ __global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __res
 // out[j] = sum_b parts[b, j]: the reduction over row chunks of the chunked weight-gradient GEMM
 // (parts (B, n) row-major, n % 4 == 0).  64 float4 column lanes x 4 chunk groups per block (a fixed
 // summation order: group g takes chunks g, g+4, ...; the groups are added 0..3).
-__global__ __launch_bounds__(256) void sum_leading_kernel(const float4* __restrict__ parts, int B, size_t lanes,
-                                                           float4* __restrict__ out) {
-    __shared__ float4 sh[256];
+__device__ __forceinline__ void sum_leading_body(const float4* __restrict__ parts, int B, size_t lanes, unsigned block,
+                                                 float4* __restrict__ out, float4* sh) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t j = (size_t)blockIdx.x * 64 + lane;
+    const size_t j = (size_t)block * 64 + lane;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < lanes) {
         int b = grp;
@@ -385,6 +389,21 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(const float4* __restri
         }
         out[j] = s;
     }
+}
+
+// One launch for the two small reductions that close a layer's backward: blocks [0, blocks_a) reduce the
+// weight-gradient chunks, the remaining blocks the bias-gradient partials of act_bwd_colsum's first stage.
+template <int V>
+__global__ __launch_bounds__(256) void layer_reduce_kernel(const float4* __restrict__ parts, int B, size_t lanes,
+                                                            float4* __restrict__ out, unsigned blocks_a,
+                                                            const float* __restrict__ col_partials, int nb,
+                                                            int col_lanes, float* __restrict__ db) {
+    __shared__ float4 sh[256];
+    if (blockIdx.x < blocks_a)
+        sum_leading_body(parts, B, lanes, blockIdx.x, out, sh);
+    else
+        colsum_stage2_body<V>(col_partials, nb, col_lanes, (int)(blockIdx.x - blocks_a), db,
+                              reinterpret_cast<typename Vec<V>::type*>(sh));
 }
 
 inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
@@ -463,8 +482,8 @@ PIML_API int piml_colsum_blocks(size_t rows, int cols) {
     return (int)b;
 }
 
-PIML_API int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, float* g_pre,
-                                 float* partials, float* db, void* stream) {
+static int act_bwd_colsum_launch(const float* g, const float* y, size_t rows, int cols, float* g_pre,
+                                 float* partials, float* db, void* stream, bool second_stage) {
     if (cols <= 0) return hipErrorInvalidValue;
     const bool vec = (cols % 4 == 0);
     if (vec ? cols > 1024 : cols > 256) return hipErrorInvalidValue;
@@ -479,17 +498,27 @@ PIML_API int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, in
                        rows, cols, rpb, g_pre, partials, db)
     if (vec) {
         if (y) PIML_COLSUM(4, true); else PIML_COLSUM(4, false);
-        if (nb > 1)
+        if (nb > 1 && second_stage)
             hipLaunchKernelGGL(colsum_stage2_kernel<4>, dim3(cols / 4), dim3(kColsumThreads), 0, as_stream(stream),
                                partials, nb, cols / 4, db);
     } else {
         if (y) PIML_COLSUM(1, true); else PIML_COLSUM(1, false);
-        if (nb > 1)
+        if (nb > 1 && second_stage)
             hipLaunchKernelGGL(colsum_stage2_kernel<1>, dim3(cols), dim3(kColsumThreads), 0, as_stream(stream),
                                partials, nb, cols, db);
     }
 #undef PIML_COLSUM
     return hipGetLastError();
+}
+
+PIML_API int piml_act_bwd_colsum(const float* g, const float* y, size_t rows, int cols, float* g_pre,
+                                 float* partials, float* db, void* stream) {
+    return act_bwd_colsum_launch(g, y, rows, cols, g_pre, partials, db, stream, true);
+}
+
+PIML_API int piml_act_bwd_colsum_stage1(const float* g, const float* y, size_t rows, int cols, float* g_pre,
+                                        float* partials, float* db, void* stream) {
+    return act_bwd_colsum_launch(g, y, rows, cols, g_pre, partials, db, stream, false);
 }
 
 PIML_API int piml_scale_ksum_fwd(const float* e, size_t agents, int k, int cols, float scale, float* msgs,
@@ -516,11 +545,31 @@ PIML_API int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, siz
     return hipGetLastError();
 }
 
+PIML_API int piml_layer_reduce(const float* parts, int B, size_t n, float* out, const float* col_partials, int nb,
+                               int cols, float* db, void* stream) {
+    const bool have_a = parts != nullptr && B > 0 && n > 0;
+    const bool have_b = col_partials != nullptr && nb > 1;
+    if (have_a && (n % 4 || !out)) return hipErrorInvalidValue;
+    if (have_b && (cols <= 0 || !db || (cols % 4 == 0 ? cols > 1024 : cols > 256))) return hipErrorInvalidValue;
+    if (!have_a && !have_b) return hipSuccess;
+    const unsigned blocks_a = have_a ? blocks_for(n / 4, 64) : 0u;
+    const bool vec = have_b ? (cols % 4 == 0) : true;
+    const int col_lanes = have_b ? (vec ? cols / 4 : cols) : 0;
+    const dim3 grid(blocks_a + (unsigned)col_lanes);
+    if (vec)
+        hipLaunchKernelGGL(layer_reduce_kernel<4>, grid, dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float4*>(parts), B, n / 4, reinterpret_cast<float4*>(out), blocks_a,
+                           col_partials, nb, col_lanes, db);
+    else
+        hipLaunchKernelGGL(layer_reduce_kernel<1>, grid, dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float4*>(parts), B, n / 4, reinterpret_cast<float4*>(out), blocks_a,
+                           col_partials, nb, col_lanes, db);
+    return hipGetLastError();
+}
+
 PIML_API int piml_sum_leading(const float* parts, int B, size_t n, float* out, void* stream) {
     if (B <= 0 || n % 4) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     if (!parts || !out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sum_leading_kernel, dim3(blocks_for(n / 4, 64)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(parts), B, n / 4, reinterpret_cast<float4*>(out));
-    return hipGetLastError();
+    return piml_layer_reduce(parts, B, n, out, nullptr, 0, 0, nullptr, stream);
 }

@@ -600,24 +600,50 @@ def self_features_packed(dest_feat, state_rows, desired_speed):
     return _SelfFeatures.apply(dest_feat, state_rows, desired_speed)
 
 
-def act_bwd_colsum(g, y=None):
+def act_bwd_colsum(g, y=None, defer=False):
     """(g_pre, db) with g_pre = g * [y > 0] (g itself when y is None) and db = g_pre.sum(0); g, y (rows, cols).
-    Shapes the kernel does not cover (cols > 1024, or > 256 when cols % 4) use torch's GPU reduction."""
+    Shapes the kernel does not cover (cols > 1024, or > 256 when cols % 4) use torch's GPU reduction.
+    defer=True returns (g_pre, db, pending): only the first stage is launched and `pending` =
+    (partials, blocks, cols) must be handed to `layer_reduce` (db is complete when pending is None)."""
     g = _gpu_f32('g', g)
     rows, cols = g.shape
     if (cols % 4 == 0 and cols > 1024) or (cols % 4 and cols > 256):
         g_pre = g if y is None else torch.where(y > 0, g, torch.zeros((), device=g.device))
-        return g_pre, g_pre.sum(0)
+        return (g_pre, g_pre.sum(0), None) if defer else (g_pre, g_pre.sum(0))
     L = _lib.lib()
     nb = L.piml_colsum_blocks(rows, cols)
     db = torch.empty(cols, device=g.device, dtype=torch.float32)
     g_pre = torch.empty_like(g) if y is not None else g
     partials = torch.empty(nb * cols, device=g.device, dtype=torch.float32) if nb > 1 else None
+    fn = L.piml_act_bwd_colsum_stage1 if defer else L.piml_act_bwd_colsum
     with torch.cuda.device(g.device):
-        _lib.check(L.piml_act_bwd_colsum(_ptr(g), _ptr(y) if y is not None else None, rows, cols,
-                                         _ptr(g_pre) if y is not None else None, _ptr(partials), _ptr(db),
-                                         _stream()), 'piml_act_bwd_colsum')
+        _lib.check(fn(_ptr(g), _ptr(y) if y is not None else None, rows, cols,
+                      _ptr(g_pre) if y is not None else None, _ptr(partials), _ptr(db), _stream()),
+                   'piml_act_bwd_colsum')
+    if defer:
+        return g_pre, db, ((partials, nb, cols) if nb > 1 else None)
     return g_pre, db
+
+
+def layer_reduce(parts, pending, db):
+    """One launch for the reductions closing a layer's backward: parts (B, ...) -> parts.sum(0) (or None) and
+    the deferred second stage of act_bwd_colsum(..., defer=True) into `db`."""
+    out = None
+    if parts is not None:
+        parts = _gpu_f32('parts', parts)
+        out = torch.empty(parts.shape[1:], device=parts.device, dtype=torch.float32)
+    if parts is None and pending is None:
+        return None
+    cp, nb, cols = pending if pending is not None else (None, 0, 0)
+    dev = parts.device if parts is not None else cp.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().piml_layer_reduce(_ptr(parts) if parts is not None else None,
+                                                parts.shape[0] if parts is not None else 0,
+                                                out.numel() if out is not None else 0,
+                                                _ptr(out) if out is not None else None,
+                                                _ptr(cp) if cp is not None else None, nb, cols,
+                                                _ptr(db) if cp is not None else None, _stream()), 'piml_layer_reduce')
+    return out
 
 
 class _LinearAct(torch.autograd.Function):
@@ -675,8 +701,10 @@ def sum_leading(parts):
     return out
 
 
-def _weight_grad(g_pre, x):
-    """g_pre (R, out)^T @ x (R, in) -> (out, in)."""
+def _weight_grad(g_pre, x, pending=None, db=None):
+    """g_pre (R, out)^T @ x (R, in) -> (out, in); also completes a deferred bias-gradient sum (`pending`, `db`
+    from act_bwd_colsum(..., defer=True)) -- in the same launch as the chunk reduction when the chunked
+    formulation applies."""
     from . import tuning
     R, cout = g_pre.shape
     cin = x.shape[1]
@@ -684,7 +712,9 @@ def _weight_grad(g_pre, x):
     if tuning.LOADED and B and R % B == 0 and cout * cin >= 128 and (cout * cin) % 4 == 0 \
             and g_pre.is_contiguous() and x.is_contiguous():
         parts = torch.bmm(g_pre.view(B, R // B, cout).transpose(1, 2), x.view(B, R // B, cin))
-        return sum_leading(parts)
+        return layer_reduce(parts, pending, db)
+    if pending is not None:
+        layer_reduce(None, pending, db)
     return g_pre.t().mm(x)
 
 
@@ -726,11 +756,13 @@ class _MLPChain(torch.autograd.Function):
             y = None
             if ctx.relus[i]:
                 y = (out if i == n - 1 else acts[i + 1]).reshape(-1, w.shape[0])
-            g_pre, db = act_bwd_colsum(g_cur, y)
+            g_pre, db, pending = act_bwd_colsum(g_cur, y, defer=True)
             if need[2 + 2 * i + 1]:
                 grads[2 * i + 1] = db
             if need[2 + 2 * i]:
-                grads[2 * i] = _weight_grad(g_pre, acts[i])
+                grads[2 * i] = _weight_grad(g_pre, acts[i], pending, db)
+            elif pending is not None:
+                layer_reduce(None, pending, db)
             if i > 0 or need[0]:
                 g_cur = g_pre.mm(w)
         gx = g_cur.view(ctx.x_shape) if need[0] else None

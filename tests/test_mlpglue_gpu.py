@@ -333,3 +333,21 @@ def test_chunked_weight_gradient(rows, cin, cout, monkeypatch):
     assert float((plain.double() - want).abs().max()) <= 2e-5 * scale
     parts = rnd(7, 33, 4, seed=3)
     assert torch.allclose(ops.sum_leading(parts), parts.sum(0), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('rows,cols', [(40960, 128), (4096, 2), (300, 64), (10, 128)])
+@pytest.mark.parametrize('with_parts', [True, False])
+def test_layer_reduce_deferred_colsum(rows, cols, with_parts):
+    """First stage of the bias-gradient sum now, its second stage together with the chunk reduction later."""
+    from piml_amd import ops
+    g = rnd(rows, cols, seed=5)
+    y = torch.relu(rnd(rows, cols, seed=6))
+    want_pre, want_db = ops.act_bwd_colsum(g, y)
+    g_pre, db, pending = ops.act_bwd_colsum(g, y, defer=True)
+    parts = rnd(16, 64, 12, seed=7) if with_parts else None
+    out = ops.layer_reduce(parts, pending, db)
+    assert torch.equal(g_pre, want_pre) and torch.equal(db, want_db)
+    if with_parts:
+        assert torch.allclose(out, parts.sum(0), rtol=1e-6, atol=1e-6)
+    else:
+        assert out is None
