@@ -156,6 +156,7 @@ def main():
     ap.add_argument('--secondary', type=int, default=1, help='also report MLAPM step / relfeat backward kernel figures')
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
+    ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
     ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
     args = ap.parse_args()
 
@@ -183,8 +184,7 @@ def main():
     from piml_amd import ops, _lib
     from piml_amd.models.model import PINNSF_multitask
     from piml_amd.scenes import synthetic_gc_scene
-    from piml_amd.sharded import (ShardedScene, allreduce_gradients, flatten_gradients, gather_records_into,
-                                  reduce_scatter_grad, unflatten_gradients)
+    from piml_amd.sharded import ShardedScene, allreduce_gradients, gather_records_into, unflatten_gradients
 
     n_own, M = args.agents, args.obstacles
     N = n_own * world
@@ -242,7 +242,10 @@ def main():
     def rest_local(pf, of, self_features, *_idx):
         acc = model(pf, of, self_features)[0]
         acc.backward(ones)
-        bucket[:] = flatten_gradients(params)       # captured: one concatenation into a static bucket
+        # captured: ONE concatenation of the (N, 6) state gradient and all weight gradients into a static
+        # bucket, so that the backward exchange is a single latency-bound all-reduce (1.3 MB at 8 GPUs)
+        grads = [p.grad for p in params if p.grad is not None]
+        bucket[:] = [torch.cat([state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
         return acc
 
     bucket = [None, None]
@@ -251,9 +254,9 @@ def main():
         gather_records_into(state_all, state_own, sh.group)
 
     def exchange_backward():
-        reduce_scatter_grad(state_all.grad, sh.group, out=grad_own)
         dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=sh.group)
-        unflatten_gradients(*bucket)
+        grad_own.copy_(bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
+        unflatten_gradients(bucket[0][N * 6:], bucket[1])
 
     def step_body(timer=None):
         """One forward + backward pass of the hot path over the scene."""
@@ -384,6 +387,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- integrity check, outside the timed region: the gradients the replayed step left behind must equal
+    # those of the same step run eagerly through plain autograd (sharded: with the autograd all-gather /
+    # reduce-scatter of piml_amd.sharded), i.e. no work was skipped or mis-wired by the capture ----
+    verify_err = None
+    if graph is not None and args.verify:
+        if use_dist:
+            got_state = grad_own.clone()
+        else:
+            got_state = state_own.grad.clone()
+        got_params = [None if p.grad is None else p.grad.clone() for p in params]
+        reset_grads()
+        step_body()
+        torch.cuda.synchronize()
+
+        def rel(a, b):
+            a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+        verify_err = rel(got_state, state_own.grad)
+        for g, p in zip(got_params, params):
+            if (g is None) != (p.grad is None):
+                verify_err = float('inf')
+            elif g is not None:
+                verify_err = max(verify_err, rel(g, p.grad))
+        if use_dist:
+            t = torch.tensor([verify_err], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            verify_err = float(t.item())
+        if not verify_err < 1e-3:
+            print(f'[bench] FATAL: replayed step and eager autograd step disagree (max rel err {verify_err:.3e})',
+                  file=sys.stderr, flush=True)
+            sys.exit(4)
+    _phase(f'verify done ({verify_err})')
+
     if graph is None:
         kernel_ms_samples = [tm.elapsed_ms() for tm in ev_pairs]
     def median(xs):
@@ -417,7 +453,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'steps_per_s': args.steps / elapsed,
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
             'config': {'workload': 'cfg3: synthetic GC scene, forward+backward PINSF step '
                                    '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
