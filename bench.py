@@ -398,6 +398,9 @@ def main():
             got_state = state_own.grad.clone()
         got_params = [None if p.grad is None else p.grad.clone() for p in params]
         reset_grads()
+        if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+            # the warm-up steps ran on a side stream, this one runs on the default stream: intended
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         step_body()
         torch.cuda.synchronize()
 
