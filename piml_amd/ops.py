@@ -772,12 +772,12 @@ class _MLPChain(torch.autograd.Function):
 def mlp_chain(x, relus, *weights_and_biases):
     """x (..., in) through Linear(+ReLU) layers; `relus[i]` says whether layer i is followed by a ReLU;
     weights_and_biases = (w0, b0, w1, b1, ...)."""
-    if not x.is_cuda:
-        raise _lib.PimlHipError('mlp_chain: expected a GPU tensor (piml_amd has no CPU path)')
     if len(weights_and_biases) != 2 * len(relus):
         raise ValueError('mlp_chain: one (weight, bias) pair per layer expected')
     if not relus:
         return x
+    if not x.is_cuda:
+        raise _lib.PimlHipError('mlp_chain: expected a GPU tensor (piml_amd has no CPU path)')
     if not torch.is_grad_enabled():       # inference: no autograd node, just the GEMMs
         h = x.reshape(-1, x.shape[-1])
         for i, relu in enumerate(relus):

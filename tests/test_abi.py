@@ -53,3 +53,59 @@ def test_ops_refuse_cpu_tensors():
         ops.relative_features(x, x, x, x, torch.zeros(2, 2))
     with pytest.raises(_lib.PimlHipError):
         ops.heading_direction(x)
+
+
+def test_glue_ops_refuse_cpu_tensors_and_validate_arguments():
+    """The glue operators around the MLP have no CPU path either; argument errors are host-side."""
+    import torch
+    from piml_amd import _lib, ops
+    x = torch.zeros(8, 6)
+    w, b = torch.zeros(4, 6), torch.zeros(4)
+    with pytest.raises(_lib.PimlHipError):
+        ops.mlp_chain(x, (True,), w, b)
+    with pytest.raises(_lib.PimlHipError):
+        ops.linear_act(x, w, b, True)
+    with pytest.raises(_lib.PimlHipError):
+        ops.act_bwd_colsum(x)
+    with pytest.raises(_lib.PimlHipError):
+        ops.pinnsf_epilogue(torch.zeros(3, 2), None, torch.zeros(3, 7), 0.5)
+    with pytest.raises(_lib.PimlHipError):
+        ops.train_rollout_step(torch.zeros(1, 3, 2), torch.zeros(1, 3, 2), torch.zeros(1, 3, 2), torch.zeros(1, 3, 2),
+                               torch.zeros(1, 3, 2), torch.zeros(1, 3, dtype=torch.int64), torch.zeros(2, 3, 2),
+                               torch.full((3,), 2, dtype=torch.int64), 0.08)
+    with pytest.raises(ValueError):
+        ops.mlp_chain(x, (True, False), w, b)                    # one (weight, bias) pair per layer
+    with pytest.raises(ValueError):
+        ops.pinnsf_epilogue(torch.zeros(3, 2), None, torch.zeros(3, 6), 0.5)
+    with pytest.raises(ValueError):
+        ops.pinnsf_epilogue(torch.zeros(3, 2), None, torch.zeros(3, 7), 0.5, agent_norm=True)   # needs (C, N, 7)
+    with pytest.raises(ValueError):
+        ops.scale_ksum(torch.zeros(4, 6, 6))                     # cols % 4
+    assert ops.mlp_chain(x, ()) is x                             # an MLP without layers is the identity
+
+
+def test_library_argument_checks_of_glue_entries():
+    """Null / out-of-range arguments are refused by the C ABI before any launch."""
+    from piml_amd import _lib
+    L = _lib.lib()
+    assert L.piml_colsum_blocks(40960, 128) == 1280 and L.piml_colsum_blocks(1, 128) == 1
+    assert L.piml_act_bwd_colsum(None, None, 10, 0, None, None, None, None) == 1       # cols <= 0
+    assert L.piml_act_bwd_colsum(None, None, 10, 2048, None, None, None, None) == 1    # cols too wide
+    assert L.piml_sum_leading(None, 0, 16, None, None) == 1
+    assert L.piml_scale_ksum_fwd(None, 4, 6, 6, 2.0, None, None, None) == 1            # cols % 4
+    assert L.piml_pinnsf_epilogue_fwd(None, None, None, 0, 0.5, None, None) == 0        # empty: no-op
+    assert L.piml_pinnsf_epilogue_fwd(None, None, None, 5, 0.5, None, None) == 1
+    assert L.piml_train_step_bwd(None, None, None, None, None, 0, 1, 5, 0, 0.08, None, None, None, None, None) == 0
+
+
+def test_tuning_file_is_consistent():
+    """The committed TunableOp result file: validators first, then one line per GEMM shape, no duplicates."""
+    from piml_amd import tuning
+    lines = [ln for ln in open(tuning.DEFAULT_FILE).read().splitlines() if ln]
+    vals = [ln for ln in lines if ln.startswith('Validator,')]
+    ops_ = [ln.split(',') for ln in lines if not ln.startswith('Validator,')]
+    assert len(vals) == 5 and lines[:5] == vals
+    assert all(len(f) == 4 and f[0].startswith('Gemm') for f in ops_)
+    keys = [(f[0], f[1]) for f in ops_]
+    assert len(keys) == len(set(keys))
+    assert tuning.LOADED is False                               # nothing is loaded on import
