@@ -195,6 +195,25 @@ int piml_rollout_step(float* position, float* velocity, float* acceleration, flo
                       float dt, int remove_arrived, void* stream);
 
 /*
+ * The hand-written collision handling that closes PINNSF_polar_bottleneck_collision.forward
+ * (`--model pinnsf_pbc`, src/models/model.py:1383-1444), on the k gathered neighbours of every
+ * agent: rows of ped_features (row_stride floats: p_j - p_i, v_j - v_i, ...), the agent's velocity v_i
+ * (self_features[..., 2:4]) and the predicted acceleration.  Reaction radius = collision_threshold +
+ * 1.34 * 2 * time_unit; a neighbour inside it is "head-on" when (v_i . p_ji)(v_j . -p_ji) > 0, else "chasing";
+ * for the nearest of each kind the approaching normal component of the prediction is removed and the
+ * acceleration that cancels the normal closing speed within one time unit is added (step 2, then step 3 on
+ * the result).  bwd is the analytic gradient w.r.t. predictions, velocity and the (p_ji, v_ji) columns of the
+ * two selected neighbour rows (flags / selections are piecewise constant); any gradient output may be NULL.
+ */
+int piml_collision_correction_fwd(const float* predictions, const float* ped_features, const float* velocity,
+                                  size_t rows, int k, int row_stride, float collision_threshold, float time_unit,
+                                  float* out, void* stream);
+int piml_collision_correction_bwd(const float* g_out, const float* predictions, const float* ped_features,
+                                  const float* velocity, size_t rows, int k, int row_stride,
+                                  float collision_threshold, float time_unit, float* g_predictions,
+                                  float* g_ped_features, float* g_velocity, void* stream);
+
+/*
  * Differentiable frame step of the fine-tuning rollout, BaseSimulator.test_multiple_rollouts_for_training
  * between the model call and the feature recomputation (src/models/simulators.py:741-769), one launch:
  *   v' = v + a dt, p' = p + v dt (lagged Euler), a' = a_pred; waypoint switch when |p - dest| < 0.5 (the

@@ -183,3 +183,55 @@ def calc_acceleration(relative_data, equation_version='v0', dataset='gc1560', ep
     lib().oracle_calc_acceleration(_ptr(r), _z(R), _i(r.shape[-1]), _i(int(equation_version[1])),
                                    _f(A), _f(B), _f(Cc), _f(D), _f(th), _f(eps), _ptr(out))
     return out
+
+
+def collision_post_correction(predictions, ped_features, velocity, collision_threshold=0.5, time_unit=0.08):
+    """The hand-written collision handling that closes PINNSF_polar_bottleneck_collision.forward
+    (src/models/model.py:1383-1444), restated in float32 numpy.  predictions (..., N, 2), ped_features
+    (..., N, k, >= 4) = (p_j - p_i, v_j - v_i, ...), velocity (..., N, 2) = v_i (self_features[..., 2:4]).
+    Returns the corrected predictions.  (Deviation: the reference `.squeeze()`s the gathered neighbour, which
+    also drops a size-1 agent / slice axis; here only the neighbour axis is dropped.)"""
+    f32 = np.float32
+    P = np.asarray(predictions, f32).copy()
+    ped = np.asarray(ped_features, f32)
+    vi = np.asarray(velocity, f32)
+    dt = f32(time_unit)
+    R = f32(collision_threshold + 1.34 * 2 * time_unit)                        # :1385
+    pji = np.where(np.isnan(ped[..., :2]), f32(0), ped[..., :2]).astype(f32)    # :1387-1390
+    norm = np.sqrt(pji[..., 1] * pji[..., 1] + pji[..., 0] * pji[..., 0], dtype=f32) + f32(1e-6)   # :1391-1392
+    nji = pji / norm[..., None]                                                  # :1393
+    vji = ped[..., 2:4]
+    vik = np.broadcast_to(vi[..., None, :], vji.shape)                           # :1396
+    vj = vji + vik
+    coll = ((R >= norm) & (norm > f32(1e-4))).astype(f32)                        # :1399
+    with np.errstate(invalid='ignore'):
+        inter = ((vik * pji).sum(-1, dtype=f32) * (vj * (-pji)).sum(-1, dtype=f32)).astype(f32)   # :1404
+    inter = np.where(np.isnan(inter), f32(0), inter)
+    inter = (inter > 0).astype(f32)                                              # :1405-1408
+    enc, chase = coll * inter, coll * (f32(1) - inter)                           # :1409-1410
+
+    def nearest(flag):
+        d = norm * flag
+        d = np.where(d < f32(1e-4), d + f32(100), d)                             # :1414-1415
+        idx = np.argmin(d, axis=-1)                                              # first minimum
+        take = lambda x: np.take_along_axis(x, idx[..., None, None].repeat(x.shape[-1], -1), axis=-2)[..., 0, :]
+        return take(nji), take(vji)
+
+    # step 2: head-on encounters (:1412-1425)
+    n_c, _ = nearest(enc)
+    m = (enc.sum(-1, keepdims=True) > 0).astype(f32)
+    a_c = -(vi * n_c).sum(-1, keepdims=True, dtype=f32) * n_c / dt * m
+    P_ = P * m
+    s = (P_ * n_c).sum(-1, keepdims=True, dtype=f32)
+    s = s * (s > 0)
+    P = P + ((P_ - s * n_c) + a_c)
+    # step 3: chasing (:1427-1442)
+    n_c, v_c = nearest(chase)
+    m = (chase.sum(-1, keepdims=True) > 0).astype(f32)
+    q = (v_c * n_c).sum(-1, keepdims=True, dtype=f32)
+    a_ = q * (q < 0) * n_c / dt * m
+    P_ = P * m
+    s = (P_ * n_c).sum(-1, keepdims=True, dtype=f32)
+    s = s * (s > 0) * (q < 0)
+    P = P + ((P_ - s * n_c) + a_)
+    return P.astype(f32)

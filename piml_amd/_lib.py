@@ -31,6 +31,8 @@ SIGNATURES = {
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                           _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    'piml_collision_correction_fwd': [_p, _p, _p, _z, _i, _i, _f, _f, _p, _p],
+    'piml_collision_correction_bwd': [_p, _p, _p, _p, _z, _i, _i, _f, _f, _p, _p, _p, _p],
     'piml_train_step_fwd': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     'piml_train_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],

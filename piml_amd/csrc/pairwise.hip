@@ -696,6 +696,161 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
     if (ga_pred) ga_pred[g] = e;
 }
 
+// ---- collision post-correction of PINNSF_polar_bottleneck_collision (src/models/model.py:1383-1444) ----
+struct CorrSel {            // what one agent's pass over its k gathered neighbours selects
+    int e, c;               // nearest head-on ("encounter") / chasing neighbour (0 when none)
+    float me, mc;           // 1 when such a neighbour exists
+};
+
+// Classify the k neighbours (rows of `stride` floats: p_j - p_i, v_j - v_i, ...) and pick the nearest of each
+// kind.  collision: reaction radius >= |p_ji| + 1e-6 > 1e-4; head-on when (v_i . p_ji)(v_j . -p_ji) > 0.
+__device__ __forceinline__ CorrSel corr_select(const float* __restrict__ ped, int k, int stride, float2 vi,
+                                               float radius) {
+    CorrSel s;
+    s.e = 0; s.c = 0; s.me = 0.f; s.mc = 0.f;
+    float best_e = 0.f, best_c = 0.f;
+    bool have_e = false, have_c = false;
+    for (int j = 0; j < k; ++j) {
+        const float* f = ped + (size_t)j * stride;
+        const float px = nan_to_zero(f[0]), py = nan_to_zero(f[1]);
+        const float nrm = norm2(px, py) + 1e-6f;
+        if (!(radius >= nrm && nrm > 1e-4f)) continue;
+        const float vjx = f[2] + vi.x, vjy = f[3] + vi.y;
+        float inter = (vi.x * px + vi.y * py) * (vjx * (-px) + vjy * (-py));
+        const bool head_on = inter > 0.f;                    // NaN -> false, as the reference's masking does
+        // torch.min over (distance * flag, +100 where < 1e-4): the first strict minimum among flagged rows;
+        // unflagged rows sit at 100 and only win (index 0) when nothing is flagged
+        if (head_on) {
+            if (!have_e || nrm < best_e) { best_e = nrm; s.e = j; have_e = true; }
+        } else {
+            if (!have_c || nrm < best_c) { best_c = nrm; s.c = j; have_c = true; }
+        }
+    }
+    // a flagged distance >= 100 would lose against the 100 of an unflagged row 0; radius < 100 always
+    s.me = have_e ? 1.f : 0.f;
+    s.mc = have_c ? 1.f : 0.f;
+    return s;
+}
+
+__device__ __forceinline__ float2 corr_normal(const float* f, float& r_out, float2& p_out) {
+    const float px = nan_to_zero(f[0]), py = nan_to_zero(f[1]);
+    const float r = norm2(px, py);
+    r_out = r;
+    p_out = make_float2(px, py);
+    const float d = r + 1e-6f;
+    return make_float2(px / d, py / d);
+}
+
+__global__ void collision_correction_fwd_kernel(const float2* __restrict__ pred, const float* __restrict__ ped,
+                                                const float2* __restrict__ vel, size_t rows, int k, int stride,
+                                                float radius, float dt, float2* __restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows) return;
+    const float* f = ped + g * (size_t)k * stride;
+    const float2 vi = vel[g];
+    float2 P = pred[g];
+    const CorrSel s = corr_select(f, k, stride, vi, radius);
+    float r; float2 p;
+    // step 2: head-on -- remove the approaching normal component, add the acceleration that stops v_i . n within dt
+    {
+        const float2 n = corr_normal(f + (size_t)s.e * stride, r, p);
+        const float u = vi.x * n.x + vi.y * n.y;
+        const float2 ac = make_float2(-u * n.x / dt * s.me, -u * n.y / dt * s.me);
+        float2 Pm = make_float2(P.x * s.me, P.y * s.me);
+        float sn = Pm.x * n.x + Pm.y * n.y;
+        sn = sn > 0.f ? sn : 0.f;
+        Pm = make_float2((Pm.x - sn * n.x) + ac.x, (Pm.y - sn * n.y) + ac.y);
+        P = make_float2(P.x + Pm.x, P.y + Pm.y);
+    }
+    // step 3: chasing -- only when i closes in on j (relative normal speed q < 0)
+    {
+        const float* fc = f + (size_t)s.c * stride;
+        const float2 n = corr_normal(fc, r, p);
+        const float q = fc[2] * n.x + fc[3] * n.y;
+        const float h = q < 0.f ? 1.f : 0.f;
+        const float2 a = make_float2(q * h * n.x / dt * s.mc, q * h * n.y / dt * s.mc);
+        float2 Pm = make_float2(P.x * s.mc, P.y * s.mc);
+        float sn = Pm.x * n.x + Pm.y * n.y;
+        sn = (sn > 0.f ? sn : 0.f) * h;
+        Pm = make_float2((Pm.x - sn * n.x) + a.x, (Pm.y - sn * n.y) + a.y);
+        P = make_float2(P.x + Pm.x, P.y + Pm.y);
+    }
+    out[g] = P;
+}
+
+// gradient of n = p / (|p| + eps) pulled back to p
+__device__ __forceinline__ float2 corr_normal_bwd(float2 gn, float2 p, float r) {
+    if (r == 0.f) return make_float2(gn.x / 1e-6f, gn.y / 1e-6f);      // torch: d|p|/dp = 0 at p = 0
+    const float d = r + 1e-6f;
+    const float pg = p.x * gn.x + p.y * gn.y;
+    const float c = pg / (r * d * d);
+    return make_float2(gn.x / d - p.x * c, gn.y / d - p.y * c);
+}
+
+// Analytic backward: the flags and the selected neighbours are piecewise constant, gradients flow through the
+// two selected normals (p_ji of those rows), v_i, the selected chasing row's v_ji and the predictions.
+__global__ void collision_correction_bwd_kernel(const float2* __restrict__ g_out, const float2* __restrict__ pred,
+                                                const float* __restrict__ ped, const float2* __restrict__ vel,
+                                                size_t rows, int k, int stride, float radius, float dt,
+                                                float2* __restrict__ g_pred, float* __restrict__ g_ped,
+                                                float2* __restrict__ g_vel) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= rows) return;
+    const float* f = ped + g * (size_t)k * stride;
+    const float2 vi = vel[g];
+    const float2 P = pred[g];
+    const float2 G = g_out[g];
+    const CorrSel s = corr_select(f, k, stride, vi, radius);
+    float r1, r2; float2 p1, p2;
+    const float2 n1 = corr_normal(f + (size_t)s.e * stride, r1, p1);
+    const float* fc = f + (size_t)s.c * stride;
+    const float2 n2 = corr_normal(fc, r2, p2);
+    // recompute the forward intermediates
+    const float u = vi.x * n1.x + vi.y * n1.y;
+    const float s1raw = s.me * (P.x * n1.x + P.y * n1.y);
+    const float g1 = s1raw > 0.f ? 1.f : 0.f;
+    const float2 P1 = make_float2((1.f + s.me) * P.x - g1 * s1raw * n1.x - s.me * u * n1.x / dt,
+                                  (1.f + s.me) * P.y - g1 * s1raw * n1.y - s.me * u * n1.y / dt);
+    const float2 w = make_float2(fc[2], fc[3]);
+    const float q = w.x * n2.x + w.y * n2.y;
+    const float h = q < 0.f ? 1.f : 0.f;
+    const float s2raw = s.mc * (P1.x * n2.x + P1.y * n2.y);
+    const float g2 = (s2raw > 0.f ? 1.f : 0.f) * h;
+    // step 3 backward
+    const float Gn2 = G.x * n2.x + G.y * n2.y;
+    const float2 G1 = make_float2((1.f + s.mc) * G.x - g2 * s.mc * Gn2 * n2.x, (1.f + s.mc) * G.y - g2 * s.mc * Gn2 * n2.y);
+    const float2 gw = make_float2(s.mc * h * Gn2 * n2.x / dt, s.mc * h * Gn2 * n2.y / dt);
+    const float P1n2 = P1.x * n2.x + P1.y * n2.y;
+    const float2 gn2 = make_float2(-g2 * s.mc * (Gn2 * P1.x + P1n2 * G.x) + s.mc * h / dt * (Gn2 * w.x + q * G.x),
+                                   -g2 * s.mc * (Gn2 * P1.y + P1n2 * G.y) + s.mc * h / dt * (Gn2 * w.y + q * G.y));
+    // step 2 backward
+    const float G1n1 = G1.x * n1.x + G1.y * n1.y;
+    const float Pn1 = P.x * n1.x + P.y * n1.y;
+    const float2 gP = make_float2((1.f + s.me) * G1.x - g1 * s.me * G1n1 * n1.x, (1.f + s.me) * G1.y - g1 * s.me * G1n1 * n1.y);
+    const float2 gvi = make_float2(-s.me * G1n1 * n1.x / dt, -s.me * G1n1 * n1.y / dt);
+    const float2 gn1 = make_float2(-g1 * s.me * (G1n1 * P.x + Pn1 * G1.x) - s.me / dt * (G1n1 * vi.x + u * G1.x),
+                                   -g1 * s.me * (G1n1 * P.y + Pn1 * G1.y) - s.me / dt * (G1n1 * vi.y + u * G1.y));
+    if (g_pred) g_pred[g] = gP;
+    if (g_vel) g_vel[g] = gvi;
+    if (g_ped) {
+        float* o = g_ped + g * (size_t)k * stride;
+        for (int j = 0; j < k * stride; ++j) o[j] = 0.f;
+        const bool nan1 = f[(size_t)s.e * stride] != f[(size_t)s.e * stride] || f[(size_t)s.e * stride + 1] != f[(size_t)s.e * stride + 1];
+        if (s.me != 0.f && !nan1) {
+            const float2 gp = corr_normal_bwd(gn1, p1, r1);
+            o[(size_t)s.e * stride] += gp.x;
+            o[(size_t)s.e * stride + 1] += gp.y;
+        }
+        if (s.mc != 0.f) {
+            const float2 gp = corr_normal_bwd(gn2, p2, r2);
+            o[(size_t)s.c * stride] += gp.x;
+            o[(size_t)s.c * stride + 1] += gp.y;
+            o[(size_t)s.c * stride + 2] += gw.x;
+            o[(size_t)s.c * stride + 3] += gw.y;
+        }
+    }
+}
+
 }  // namespace piml
 
 PIML_API int piml_rollout_step(float* position, float* velocity, float* acceleration, float* destination,
@@ -774,5 +929,33 @@ PIML_API int piml_train_step_bwd(const float* g_position_out, const float* g_vel
                        piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
                        (const float2*)g_acceleration_out, new_flag, zero_mask, C, T, N, t_next, dt, (float2*)g_position,
                        (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_correction_fwd(const float* predictions, const float* ped_features, const float* velocity,
+                                           size_t rows, int k, int row_stride, float collision_threshold,
+                                           float time_unit, float* out, void* stream) {
+    if (k < 0 || row_stride < 4 || !(time_unit > 0.f)) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!predictions || !velocity || !out || (k > 0 && !ped_features)) return hipErrorInvalidValue;
+    const float radius = (float)((double)collision_threshold + 1.34 * 2 * (double)time_unit);
+    hipLaunchKernelGGL(piml::collision_correction_fwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0,
+                       piml::as_stream(stream), (const float2*)predictions, ped_features, (const float2*)velocity, rows,
+                       k, row_stride, radius, time_unit, (float2*)out);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_correction_bwd(const float* g_out, const float* predictions, const float* ped_features,
+                                           const float* velocity, size_t rows, int k, int row_stride,
+                                           float collision_threshold, float time_unit, float* g_predictions,
+                                           float* g_ped_features, float* g_velocity, void* stream) {
+    if (k < 0 || row_stride < 4 || !(time_unit > 0.f)) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!g_out || !predictions || !velocity || (k > 0 && !ped_features)) return hipErrorInvalidValue;
+    const float radius = (float)((double)collision_threshold + 1.34 * 2 * (double)time_unit);
+    hipLaunchKernelGGL(piml::collision_correction_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0,
+                       piml::as_stream(stream), (const float2*)g_out, (const float2*)predictions, ped_features,
+                       (const float2*)velocity, rows, k, row_stride, radius, time_unit, (float2*)g_predictions,
+                       g_ped_features, (float2*)g_velocity);
     return hipGetLastError();
 }

@@ -268,9 +268,93 @@ class PINNSF_multitask(_PINNSFBase):
     taus = (0.5, 5 / 6)
 
 
+class PINNSF_polar_bottleneck(_PINNSFBase):
+    """model.py:1447+ (`--model pinnsf_pb`): the bottleneck network whose per-neighbour outputs are (r, theta)
+    in the polar frame of the agent's heading; the two branch sums are rotated back with polar_to_cart
+    (src/data/data.py:902-920) before the desired force is added.  tau = 2 for every dataset.
+    The heading of `self_features[..., 2:4]` follows Pedestrians.get_heading_direction (data.py:350-395),
+    including its temporal fill over dim -3 -- the SLICE axis of channelled (C, N, 7) input.  Deviation: entries
+    filled from another frame / slice pass no gradient to that source velocity (they have zero velocity)."""
+    bottleneck = True
+    taus = (2, 2)
+    collision = False
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.tau = 2
+        # the reference reads args.time_unit, which its own main.py never sets (`--model pinnsf_pbc` dies with an
+        # AttributeError there); fall back to the 0.08 s of every shipped dataset
+        self.time_unit = getattr(args, 'time_unit', 0.08)
+        self.collision_threshold = getattr(args, 'collision_threshold', 0.5)
+
+    @staticmethod
+    def _heading(velocity):
+        n = torch.norm(velocity, p=2, dim=-1, keepdim=True)
+        unit = velocity / torch.where(n == 0, n + 0.1, n)
+        if velocity.dim() >= 3 and velocity.is_cuda:                       # temporal fill of zero-velocity entries
+            from .. import ops
+            filled = ops.heading_direction(velocity.detach())
+            unit = torch.where(n == 0, filled, unit)
+        elif velocity.dim() >= 3:
+            raise NotImplementedError('the temporal heading fill of channelled input runs on the GPU only')
+        return unit
+
+    @staticmethod
+    def _polar_to_cart(points, base):
+        """(r, theta) in the frame whose polar axis is `base` (unit vectors) -> (x, y)   (data.py:902-920,
+        with cart_to_polar(base, (1, 0)) of :872-900 inlined: sign(0) = 0 makes a heading on the x axis theta = 0)."""
+        vol = torch.norm(base, p=2, dim=-1, keepdim=True)
+        vol_ = torch.where(vol == 0, vol + 0.1, vol)
+        p = base / vol_
+        theta_b = torch.acos(torch.clamp(base[..., :1] / vol_, -1 + 1e-6, 1 - 1e-6)) * torch.sign(p[..., 1:2])
+        ang = points[..., 1:2] + theta_b
+        return torch.cat((points[..., :1] * torch.cos(ang), points[..., :1] * torch.sin(ang)), dim=-1)
+
+    def forward(self, ped_features, obs_features, self_features):
+        assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'
+        base = self._heading(self_features[..., -5:-3])
+
+        def branch(feats, encoder, processor, decoder, predictor):
+            polar_sum, msgs, _, _ = self._branch(feats, encoder, processor, decoder, predictor)
+            if self.collision:       # pinnsf_pbc: sum the polar messages, rotate the sum (model.py:1365-1367)
+                return self._polar_to_cart(polar_sum, base), msgs
+            cart = self._polar_to_cart(msgs, base.unsqueeze(-2))     # pinnsf_pb: rotate every message (:1507-1510)
+            return cart.sum(dim=-2), cart
+        acc, ped_msgs = branch(ped_features, self.ped_encoder, self.ped_processor, self.ped_decoder,
+                               self.ped_predictor)
+        obs_msgs = None
+        if self.obs_feature_dim > 0:
+            acc_o, obs_msgs = branch(obs_features, self.obs_encoder, self.obs_processor, self.obs_decoder,
+                                     self.obs_predictor)
+            acc = acc + acc_o
+        if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
+                and (self_features.dim() in (2, 3) or self.fix_dest_norm):
+            from .. import ops
+            quirk = self_features.dim() == 3 and not self.fix_dest_norm
+            predictions = ops.pinnsf_epilogue(acc, None, self_features, self.tau, agent_norm=quirk)
+        else:
+            predictions = acc + self.desired_force(self_features)
+        if self.collision:
+            from .. import ops
+            predictions = ops.collision_post_correction(predictions, ped_features, self_features[..., 2:4],
+                                                        self.collision_threshold, self.time_unit)
+        out = [predictions, ped_msgs]
+        if obs_msgs is not None:
+            out.append(obs_msgs)
+        return out
+
+
+class PINNSF_polar_bottleneck_collision(PINNSF_polar_bottleneck):
+    """model.py:1307-1444 (`--model pinnsf_pbc`): PINNSF_polar_bottleneck followed by the hand-written collision
+    handling on the gathered neighbours (ops.collision_post_correction; GPU only)."""
+    collision = True
+
+
 MODEL_TABLE = {   # simulators.py:40-106 (set_model / set_ft_model), PINNSF-family rows
     'pinnsf': (PINNSF, PINNSF), 'pinnsf_res': (PINNSF, PINNSF_residual),
     'pinnsf_bottleneck': (PINNSF_bottleneck, PINNSF_bottleneck),
     'pinnsf_bm': (PINNSF_bottleneck_multitask, PINNSF_bottleneck_multitask),
     'pinnsf_m': (PINNSF_multitask, PINNSF_multitask),
+    'pinnsf_pb': (PINNSF_polar_bottleneck, PINNSF_polar_bottleneck),
+    'pinnsf_pbc': (PINNSF_polar_bottleneck_collision, PINNSF_polar_bottleneck_collision),
 }

@@ -916,3 +916,50 @@ def train_rollout_step(position, velocity, acceleration, a_pred, destination, de
     return _TrainRolloutStep.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(),
                                    waypoints.contiguous(), dest_num.contiguous(), new_flag, series, int(t_next),
                                    float(dt), nan_flag, bool(zero_nan))
+
+
+class _CollisionCorrection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predictions, ped_features, velocity, thr, dt):
+        P = _gpu_f32('predictions', predictions)
+        F = _gpu_f32('ped_features', ped_features)
+        V = _gpu_f32('velocity', velocity)
+        k, stride = F.shape[-2], F.shape[-1]
+        rows = P.numel() // 2
+        out = torch.empty_like(P)
+        with torch.cuda.device(P.device):
+            _lib.check(_lib.lib().piml_collision_correction_fwd(_ptr(P), _ptr(F), _ptr(V), rows, k, stride, float(thr),
+                                                                float(dt), _ptr(out), _stream()),
+                       'piml_collision_correction_fwd')
+        ctx.save_for_backward(P, F, V)
+        ctx.cfg = (rows, k, stride, float(thr), float(dt))
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 5
+        P, F, V = ctx.saved_tensors
+        rows, k, stride, thr, dt = ctx.cfg
+        need = ctx.needs_input_grad
+        gP = torch.empty_like(P) if need[0] else None
+        gF = torch.empty_like(F) if need[1] else None
+        gV = torch.empty_like(V) if need[2] else None
+        with torch.cuda.device(P.device):
+            _lib.check(_lib.lib().piml_collision_correction_bwd(_ptr(g.contiguous()), _ptr(P), _ptr(F), _ptr(V), rows, k,
+                                                                stride, thr, dt, _ptr(gP), _ptr(gF), _ptr(gV),
+                                                                _stream()), 'piml_collision_correction_bwd')
+        return gP, gF, gV, None, None
+
+
+def collision_post_correction(predictions, ped_features, velocity, collision_threshold=0.5, time_unit=0.08):
+    """The hand-written collision handling of `--model pinnsf_pbc` (src/models/model.py:1383-1444):
+    predictions (..., N, 2), ped_features (..., N, k, >= 4), velocity (..., N, 2) -> corrected predictions.
+    Differentiable w.r.t. all three (flags and neighbour selections are piecewise constant)."""
+    if predictions.shape[-1] != 2 or velocity.shape != predictions.shape or ped_features.dim() != predictions.dim() + 1 \
+            or ped_features.shape[:-2] != predictions.shape[:-1] or ped_features.shape[-1] < 4:
+        raise ValueError('collision_post_correction: predictions / velocity (..., N, 2) and ped_features '
+                         '(..., N, k, >= 4) expected')
+    return _CollisionCorrection.apply(predictions, ped_features, velocity, collision_threshold, time_unit)

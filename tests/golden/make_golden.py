@@ -269,6 +269,66 @@ def gen_model():
     save('model', **out)
 
 
+def gen_model_polar():
+    """`--model pinnsf_pb` / `pinnsf_pbc` (src/models/model.py:1307-1460+): polar bottleneck network and the
+    hand-written collision post-correction.  Inputs: the real GC frame and the channelled
+    synthetic case of `model.npz`, plus a DENSE synthetic scene (many neighbours inside the reaction radius)
+    whose features come from the reference's own get_relative_features; for that case also the gradients of a
+    weighted sum of the corrected acceleration w.r.t. the three inputs and two weight tensors."""
+    import models.model as MODEL
+    gm = np.load(os.path.join(HERE, 'model.npz'))
+    cases = {'n': tuple(T(gm[k]) for k in ('ped', 'obs', 'selff')),
+             'c': tuple(T(gm[k]) for k in ('pedc', 'obsc', 'selfc'))}
+    sc = synthetic_gc_scene(300, 100, seed=11)
+    rng = np.random.default_rng(12)
+    pos = (sc['position'] * 0.35).astype(np.float32)                       # ~8x the density: plenty of near misses
+    vel = (sc['velocity'] + rng.standard_normal(sc['velocity'].shape) * 0.4).astype(np.float32)
+    acc = (rng.standard_normal(pos.shape) * 0.3).astype(np.float32)
+    dest = (sc['destination'] * 0.35).astype(np.float32)
+    obs = (sc['obstacles'] * 0.35).astype(np.float32)
+    P = DATA.Pedestrians()
+    pf, of, df = P.get_relative_features(T(pos)[None], T(np.nan_to_num(vel))[None], T(acc)[None], T(dest)[None],
+                                         T(obs), 6, 90, 4, 10, 90, 4)
+    selfd = torch.cat((df[0], T(np.nan_to_num(vel)), T(acc), T(sc['desired_speed'])), dim=-1)
+    cases['d'] = (pf[0], of[0], selfd)
+    out = {}
+    for tag, (a, b, c) in cases.items():
+        out[f'in_{tag}/ped'], out[f'in_{tag}/obs'], out[f'in_{tag}/selff'] = a, b, c
+    for name, cls in (('pinnsf_pb', MODEL.PINNSF_polar_bottleneck), ('pinnsf_pbc', MODEL.PINNSF_polar_bottleneck_collision)):
+        torch.manual_seed(666)
+        m = cls(model_args()).eval()
+        for k, v in m.state_dict().items():
+            out[f'{name}/sd/{k}'] = v
+        with torch.no_grad():
+            for tag, args in cases.items():
+                res = m(*[x.clone() for x in args])
+                for q, r in enumerate(res):
+                    out[f'{name}/out_{tag}{q}'] = r
+                if name == 'pinnsf_pbc':
+                    # the acceleration BEFORE the hand-written correction, from the reference's own submodules
+                    # and coordinate helpers (model.py:1355-1381): pins the correction in isolation
+                    ped, obs, sf = [x.clone() for x in args]
+                    base = DATA.Pedestrians.get_heading_direction(sf[..., -5:-3])
+                    e = m.ped_predictor(m.ped_decoder(m.ped_processor(m.ped_encoder(ped)))).sum(-2)
+                    acc = DATA.TimeIndexedPedDataPolarCoor.polar_to_cart(e, base)
+                    e2 = m.obs_predictor(m.obs_decoder(m.obs_processor(m.obs_encoder(obs)))).sum(-2)
+                    acc = acc + DATA.TimeIndexedPedDataPolarCoor.polar_to_cart(e2, base)
+                    t_ = torch.norm(sf[..., :2], p=2, dim=1, keepdim=True)
+                    t_ = torch.where(t_ == 0, t_ + 0.1, t_)
+                    out[f'{name}/pre_{tag}'] = acc + (sf[..., -1:] * (sf[..., :2] / t_) - sf[..., 2:4]) / m.tau
+        ins = [x.clone().requires_grad_(True) for x in cases['d']]
+        m.zero_grad()
+        res = m(*ins)
+        w = torch.linspace(-1.0, 1.0, res[0].numel()).view_as(res[0])
+        (res[0] * w).sum().backward()
+        for k, x in zip(('ped', 'obs', 'selff'), ins):
+            out[f'{name}/grad_d/{k}'] = torch.nan_to_num(x.grad)
+        for k, p in m.named_parameters():
+            if k in ('ped_predictor.mlp.0.weight', 'obs_encoder.mlp.0.weight', 'ped_encoder.mlp.4.bias'):
+                out[f'{name}/grad_d/param/{k}'] = p.grad.clone()
+    save('model_polar', **out)
+
+
 def sim_args(**kw):
     """The argparse namespace of src/main.py:26-112 (defaults), as far as the simulator reads it."""
     a = model_args(dataset_name='gc1560')
@@ -463,7 +523,7 @@ def gen_rollout_flags():
     save('rollout_flags', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags)
+GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)

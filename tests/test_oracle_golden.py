@@ -99,3 +99,18 @@ def test_calc_acceleration_matches_reference(oracle, ver, ds):
         out = oracle.calc_acceleration(feat, ver, ds)
         ref = g[f'{tag}_{ver}_{ds}']
         assert np.allclose(out, ref, rtol=1e-5, atol=1e-6), np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize('tag', ['n', 'c', 'd'])
+def test_collision_post_correction_matches_reference(oracle, tag):
+    """the hand-written collision handling of PINNSF_polar_bottleneck_collision
+    (model.py:1383-1444) on the reference's own pre-correction acceleration -> the reference's output.
+    'd' is the dense scene where 83 % of the agents are corrected."""
+    g = golden('model_polar')
+    ped, sf = g[f'in_{tag}/ped'], g[f'in_{tag}/selff']
+    pre, ref = g[f'pinnsf_pbc/pre_{tag}'], g[f'pinnsf_pbc/out_{tag}0']
+    got = oracle.collision_post_correction(pre, ped, sf[..., 2:4], 0.5, 0.08)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    if tag == 'd':
+        assert (np.abs(ref - pre).sum(-1) > 0).mean() > 0.5        # the fixture really exercises the correction
