@@ -646,6 +646,14 @@ def layer_reduce(parts, pending, db):
     return out
 
 
+def _addmm_relu(bias, x, w_t):
+    """relu(x @ w_t + bias) with bias and ReLU in the GEMM's epilogue (hipBLASLt) where torch exposes it."""
+    fused = getattr(torch, '_addmm_activation', None)
+    if fused is not None:
+        return fused(bias, x, w_t, use_gelu=False)
+    return torch.relu_(torch.addmm(bias, x, w_t))
+
+
 class _LinearAct(torch.autograd.Function):
     """y = act(x W^T + b), act in {identity, relu}: torch.addmm forward; backward = fused
     (relu mask + bias-gradient column sum) kernel + the two torch.mm GEMMs autograd would issue."""
@@ -654,7 +662,7 @@ class _LinearAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, relu):
         x2 = x.reshape(-1, x.shape[-1])
         if relu:    # bias and ReLU both ride in the GEMM's epilogue (hipBLASLt)
-            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+            y = _addmm_relu(bias, x2, weight.t())
         else:
             y = torch.addmm(bias, x2, weight.t())
         out = y.view(*x.shape[:-1], weight.shape[0])
@@ -732,7 +740,7 @@ class _MLPChain(torch.autograd.Function):
         acts = [x2]
         for i, relu in enumerate(relus):
             w, b = wb[2 * i], wb[2 * i + 1]
-            acts.append(torch._addmm_activation(b, acts[-1], w.t(), use_gelu=False) if relu
+            acts.append(_addmm_relu(b, acts[-1], w.t()) if relu
                         else torch.addmm(b, acts[-1], w.t()))
         out = acts[-1].view(*x.shape[:-1], acts[-1].shape[-1])
         ctx.save_for_backward(*acts[:-1], out, *wb[0::2])
@@ -782,7 +790,7 @@ def mlp_chain(x, relus, *weights_and_biases):
         h = x.reshape(-1, x.shape[-1])
         for i, relu in enumerate(relus):
             w, b = weights_and_biases[2 * i], weights_and_biases[2 * i + 1]
-            h = torch._addmm_activation(b, h, w.t(), use_gelu=False) if relu else torch.addmm(b, h, w.t())
+            h = _addmm_relu(b, h, w.t()) if relu else torch.addmm(b, h, w.t())
         return h.view(*x.shape[:-1], h.shape[-1])
     return _MLPChain.apply(x, tuple(bool(r) for r in relus), *weights_and_biases)
 
