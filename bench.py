@@ -228,8 +228,8 @@ def main():
             allreduce_gradients(params, sh.group)
         return acc
 
-    # Sharded + graph: only the COMPUTE of a step is captured; the three collectives (all-gather of the
-    # records, reduce-scatter of d/d(state), all-reduce of the weight gradients) are issued eagerly on
+    # Sharded + graph: only the COMPUTE of a step is captured; the two collectives (all-gather of the
+    # records before it; ONE all-reduce of [d/d(state), weight gradients] after it) are issued eagerly on
     # the stream either side of the replay.  `state_all` is the graph's static input: the all-gather
     # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
     state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
@@ -462,7 +462,7 @@ def main():
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
                        'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
                        'sharding': 'single GPU' if not use_dist else
-                       f'agent blocks over {world} ranks, all-gather(p,v,a) + reduce-scatter(grad) per step'},
+                       f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
             'roofline': {'bound': 'hbm', 'kernel': 'relfeat_fwd_kernel', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel_us': kernel_ms * 1e3, 'event_interval_us': raw_ms * 1e3,
