@@ -90,11 +90,36 @@ def cpu_baseline(scene, n_agents, n_obs, budget_s):
         if el >= budget_s or n >= 200:
             break
     pairs = n_agents * (n_agents + n_obs)
-    return {'value': pairs * n / el, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'ms_per_step': el / n * 1e3,
-            'sample': f'{n} steps of the same N={n_agents}, M={n_obs} scene: oracle relfeat fwd+bwd '
-                      f'(C restatement, OpenMP) + PINNSF_multitask fwd+bwd in torch-CPU, {cores} of {cores_avail} '
-                      f'hardware threads (fastest of a short sweep)'}
+    out = {'value': pairs * n / el, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+           'ms_per_step': el / n * 1e3,
+           'sample': f'{n} steps of the same N={n_agents}, M={n_obs} scene: oracle relfeat fwd+bwd '
+                     f'(C restatement, OpenMP) + PINNSF_multitask fwd+bwd in torch-CPU, {cores} of {cores_avail} '
+                     f'hardware threads (fastest of a short sweep)'}
+    # second form: the feature step organised the way the reference computes it -- dense N x M
+    # relative tensors, full sort, gather (oracle/dataflow.py) -- forward only, a couple of repetitions
+    try:
+        from oracle import dataflow
+        th = min(cores_avail, 32)
+        torch.set_num_threads(th)
+        t = [torch.tensor(np.nan_to_num(scene[k]) if k in ('velocity', 'acceleration') else scene[k])
+             for k in keys] + [torch.tensor(scene['obstacles'])]
+        with torch.no_grad():
+            dataflow.relative_features(*t)
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 and (reps == 0 or time.perf_counter() - t0 < 6.0):
+                dataflow.relative_features(*t)
+                reps += 1
+            dfl = (time.perf_counter() - t0) / reps
+        out['reference_dataflow'] = {
+            'features_forward_ms': dfl * 1e3, 'pairs_per_s': pairs / dfl, 'threads': th, 'repetitions': reps,
+            'note': 'get_relative_features with the reference\'s dataflow (dense N x M tensors, torch.sort, gather) '
+                    'restated in oracle/dataflow.py, torch-CPU, forward only -- a lower bound for the reference, which '
+                    'also materialises both operands with .repeat and fills headings in a Python loop (it measured '
+                    '2.05 s on 8 cores, BASELINE.md)'}
+    except MemoryError as ex:      # the dense tensors need ~3 GB
+        out['reference_dataflow'] = {'error': str(ex)}
+    torch.set_num_threads(cores)
+    return out
 
 
 _T0 = time.perf_counter()
