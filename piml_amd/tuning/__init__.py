@@ -23,7 +23,8 @@ def load(path=DEFAULT_FILE):
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
         torch.cuda.tunable.record_untuned_enable(False)
-        torch.cuda.tunable.write_file_on_exit(False)      # look-up only: leave no tunableop*.csv behind
+        if hasattr(torch.cuda.tunable, 'write_file_on_exit'):
+            torch.cuda.tunable.write_file_on_exit(False)      # look-up only: leave no tunableop*.csv behind
         global LOADED
         LOADED = bool(torch.cuda.tunable.read_file(path))
         return LOADED
