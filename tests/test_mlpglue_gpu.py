@@ -351,3 +351,24 @@ def test_layer_reduce_deferred_colsum(rows, cols, with_parts):
         assert torch.allclose(out, parts.sum(0), rtol=1e-6, atol=1e-6)
     else:
         assert out is None
+
+
+def test_tuned_gemm_selections_load_on_a_matching_stack():
+    """piml_amd.tuning.load() must accept the committed result file whenever the software stack is the one it
+    was tuned on (a silent rejection doubles the step time: default GEMM selections, single stream)."""
+    from piml_amd import tuning
+    file_vals = {}
+    for ln in open(tuning.DEFAULT_FILE):
+        f = ln.strip().split(',')
+        if f[0] == 'Validator':
+            file_vals[f[1]] = f[2]
+    torch.cuda.tunable.enable(True)
+    have = {k: v for k, v in torch.cuda.tunable.get_validators()}
+    torch.cuda.tunable.enable(False)
+    same_stack = all(have.get(k) == v for k, v in file_vals.items())
+    ok = tuning.load()
+    torch.cuda.tunable.enable(False)
+    tuning.LOADED = False
+    assert isinstance(ok, bool)
+    if same_stack:
+        assert ok, 'tuned GEMM selections were rejected on the stack they were tuned on'
