@@ -204,6 +204,10 @@ def main():
     # done here).  A file whose validators do not match this software stack is ignored by torch.
     from piml_amd import tuning
     gemm_tuning = 'tunableop-file' if (args.tunableop and tuning.load()) else 'default'
+    if args.tunableop and gemm_tuning == 'default':
+        print('[bench] NOTE: the pre-tuned GEMM selections (piml_amd/tuning) were not accepted by this software '
+              'stack: default rocBLAS / hipBLASLt selections, one stream, plain weight-gradient GEMMs',
+              file=sys.stderr, flush=True)
 
     _phase('tunableop setup done')
     from piml_amd import ops, _lib
