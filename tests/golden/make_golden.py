@@ -13,6 +13,13 @@ Fixture families:
                fix applied at import time) + autograd gradients
   calcacc      utils.calc_acceleration
   model_*      PINNSF family forward outputs + state_dicts (seed 666)
+  model_polar  `--model pinnsf_pb` / `pinnsf_pbc`: outputs, the acceleration before the hand-written collision
+               correction (pins SURVEY row a9 in isolation), gradients on a dense scene
+  dataset      TimeIndexedPedData.make_dataset / channelled windows on the shipped clips
+  rollout*     BaseSimulator.get_multiple_rollouts / test_multiple_rollouts_for_training: positions, the seven
+               loss scalars, collision counts, gradients (rollout_more: UCY + pinnsf_res; rollout_flags: the
+               non-default loss switches)
+  metrics      functions.metrics (MAE, OT, MMD, collisions)
 """
 import os
 import sys
