@@ -33,11 +33,15 @@ if __name__ == '__main__':
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
     from test_simulator_gpu import sim_args
     dev = 'cuda:0'
+    tuned = '--tuned' in sys.argv     # pre-tuned GEMM selections + obstacle branch of the MLP on a side stream
+    if tuned:
+        from piml_amd import tuning
+        print('tuned GEMM selections loaded:', tuning.load())
     for N, M in ((122, 100), (1024, 100), (4096, 2000)):
         T = 200
         data = synthetic_rollout_data(N, M, T, dev)
         torch.manual_seed(666)
-        sim = BaseSimulator(sim_args())
+        sim = BaseSimulator(sim_args(**(dict(mlp_side_stream_rows=1024) if tuned else {})))
         sim.model.eval()
         with torch.no_grad():
             for graph in (False, True):
