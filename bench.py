@@ -182,7 +182,10 @@ def main():
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
-    ap.add_argument('--tunableop', type=int, default=1, help='load the pre-tuned GEMM selections for the MLP')
+    ap.add_argument('--tunableop', type=int, default=1,
+                    help='1: load the pre-tuned GEMM selections for the MLP (tuned in-process if this stack rejects the file); '
+                         '0: library defaults; 2: re-tune and write --tune-out; 3: force the in-process tuning')
+    ap.add_argument('--tune-out', type=str, default='gpurun_out/tunableop_retuned.csv', help='result file of --tunableop 2')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -203,11 +206,22 @@ def main():
     # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
     # done here).  A file whose validators do not match this software stack is ignored by torch.
     from piml_amd import tuning
-    gemm_tuning = 'tunableop-file' if (args.tunableop and tuning.load()) else 'default'
-    if args.tunableop and gemm_tuning == 'default':
-        print('[bench] NOTE: the pre-tuned GEMM selections (piml_amd/tuning) were not accepted by this software '
-              'stack: default rocBLAS / hipBLASLt selections, one stream, plain weight-gradient GEMMs',
-              file=sys.stderr, flush=True)
+    if args.tunableop == 2:      # re-tune the GEMM selections on this stack (eager steps; not a measurement)
+        tuning.tune_begin(os.path.abspath(args.tune_out))
+        args.graph, args.two_streams, args.verify, args.secondary, args.cpu_seconds = 0, 0, 0, 0, 0.0
+        args.steps, args.warmup = min(args.steps, 3), min(args.warmup, 1)
+        gemm_tuning = 'tuning'
+    else:
+        gemm_tuning = 'tunableop-file' if (args.tunableop == 1 and tuning.load()) else 'default'
+    autotune = False
+    if args.tunableop == 3 or (args.tunableop == 1 and gemm_tuning == 'default'):
+        # the committed selections belong to another software stack (or --tunableop 3 asks for it): tune the
+        # step's GEMM shapes right here (a few seconds, two eager steps below) and keep ONE stream -- only the
+        # committed selections are validated for running two library GEMMs concurrently
+        print('[bench] NOTE: tuning the GEMM selections for this software stack in-process (the committed '
+              'piml_amd/tuning file was not accepted or --tunableop 3)', file=sys.stderr, flush=True)
+        tuning.tune_begin(os.path.join('/tmp', f'piml_tunableop_autotuned_{os.getpid()}.csv'))
+        autotune, gemm_tuning = True, 'autotuned'
 
     _phase('tunableop setup done')
     from piml_amd import ops, _lib
@@ -308,6 +322,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if autotune:
+        for _ in range(2):
+            reset_grads()
+            step_body()
+        torch.cuda.synchronize()
+        torch.cuda.tunable.tuning_enable(False)
+        reset_grads()
     _phase('scene + model on device')
     # ---- whole-step HIP graph (removes ~60 per-kernel launch gaps); eager fallback ----
     graph, g_timer, static_feats = None, None, None
