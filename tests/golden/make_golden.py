@@ -474,11 +474,11 @@ def gen_metrics():
     save('metrics', **out)
 
 
-def _train_case(out, tag, path, model_name, ds, wins, **overrides):
+def _train_case(out, tag, path, model_name, ds, wins, valid_steps=6, **overrides):
     """One batch of rollout windows through the reference's test_multiple_rollouts_for_training."""
     import models.simulators as SIM
     raw = load_raw(path)
-    args = sim_args(model=model_name, dataset_name=ds, valid_steps=6, **overrides)
+    args = sim_args(model=model_name, dataset_name=ds, valid_steps=valid_steps, **overrides)
     full = DATA.TimeIndexedPedData()
     full.make_dataset(args, raw)
     full.set_dataset_info(full, raw, list(range(len(full))))
@@ -527,6 +527,11 @@ def gen_rollout_flags():
                 teacher_weight=0.5, reg_weight=1e-3)
     _train_case(out, 'gc_flags_m', GC_CLIP, 'pinnsf_m', 'gc1560', [250, 480], new_collision_loss_flag=1,
                 teacher_weight=0.25, reg_weight=1e-4, collision_loss_version='v0')
+    # the loss switches of the shipped UCY experiment (src/configs/exp_configs/piml-ucydata.yaml): collision loss v2
+    # (abnormal-agent mask), time decay 0.9, 10-frame windows, message regulariser, bottleneck collision head
+    _train_case(out, 'ucy_exp_bm', UCY_CLIP, 'pinnsf_bm', 'ucy', [120, 400], valid_steps=10,
+                collision_loss_version='v2', time_decay=0.9, reg_weight=1e-2, collision_pred_weight=5e-2,
+                collision_focus_weight=1, collision_loss_weight=40, hard_collision_penalty=1)
     save('rollout_flags', **out)
 
 

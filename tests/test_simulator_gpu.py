@@ -174,13 +174,18 @@ def test_graphed_train_step_equals_eager():
 
 FLAGS_BM = dict(new_collision_loss_flag=1, teacher_weight=0.5, reg_weight=1e-3)
 FLAGS_M = dict(new_collision_loss_flag=1, teacher_weight=0.25, reg_weight=1e-4)
+# the loss switches of the shipped UCY experiment (src/configs/exp_configs/piml-ucydata.yaml)
+FLAGS_UCY_EXP = dict(valid_steps=10, collision_loss_version='v2', time_decay=0.9, reg_weight=1e-2,
+                     collision_pred_weight=5e-2, collision_focus_weight=1, collision_loss_weight=40,
+                     hard_collision_penalty=1)
 
 
 @pytest.mark.parametrize('fixture,tag,model_name,ds,finetune,extra', [
     ('rollout_more', 'ucy_m', 'pinnsf_m', 'ucy', False, {}),
     ('rollout_more', 'gc_res', 'pinnsf_res', 'gc1560', True, {}),
     ('rollout_flags', 'gc_flags_bm', 'pinnsf_bm', 'gc1560', False, FLAGS_BM),
-    ('rollout_flags', 'gc_flags_m', 'pinnsf_m', 'gc1560', False, FLAGS_M)])
+    ('rollout_flags', 'gc_flags_m', 'pinnsf_m', 'gc1560', False, FLAGS_M),
+    ('rollout_flags', 'ucy_exp_bm', 'pinnsf_bm', 'ucy', False, FLAGS_UCY_EXP)])
 def test_training_rollout_more_configs(fixture, tag, model_name, ds, finetune, extra):
     """UCY configuration (tau = 5/6, 2-point obstacle placeholder, k_o = 2), the residual fine-tune
     network of `--model pinnsf_res`, and the non-default loss switches (label-collision masking, teacher
@@ -188,7 +193,7 @@ def test_training_rollout_more_configs(fixture, tag, model_name, ds, finetune, e
     and gradients."""
     from piml_amd.models.simulators import BaseSimulator
     g = golden(fixture)
-    args = sim_args(model=model_name, dataset_name=ds, valid_steps=6, **extra)
+    args = sim_args(model=model_name, dataset_name=ds, **{'valid_steps': 6, **extra})
     sim = BaseSimulator(args)
     if finetune:
         sim.set_ft_model(args)
