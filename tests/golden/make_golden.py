@@ -532,6 +532,10 @@ def gen_rollout_flags():
     _train_case(out, 'ucy_exp_bm', UCY_CLIP, 'pinnsf_bm', 'ucy', [120, 400], valid_steps=10,
                 collision_loss_version='v2', time_decay=0.9, reg_weight=1e-2, collision_pred_weight=5e-2,
                 collision_focus_weight=1, collision_loss_weight=40, hard_collision_penalty=1)
+    # ... and of the shipped GC experiment (piml-gcdata.yaml: dataset gc2344, heavier collision weights)
+    _train_case(out, 'gc_exp_bm', GC_CLIP, 'pinnsf_bm', 'gc2344', [200, 450], valid_steps=10,
+                collision_loss_version='v2', time_decay=0.9, reg_weight=1e-2, collision_pred_weight=5e-2,
+                collision_focus_weight=1, collision_loss_weight=200, hard_collision_penalty=2)
     save('rollout_flags', **out)
 
 

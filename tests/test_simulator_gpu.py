@@ -185,7 +185,9 @@ FLAGS_UCY_EXP = dict(valid_steps=10, collision_loss_version='v2', time_decay=0.9
     ('rollout_more', 'gc_res', 'pinnsf_res', 'gc1560', True, {}),
     ('rollout_flags', 'gc_flags_bm', 'pinnsf_bm', 'gc1560', False, FLAGS_BM),
     ('rollout_flags', 'gc_flags_m', 'pinnsf_m', 'gc1560', False, FLAGS_M),
-    ('rollout_flags', 'ucy_exp_bm', 'pinnsf_bm', 'ucy', False, FLAGS_UCY_EXP)])
+    ('rollout_flags', 'ucy_exp_bm', 'pinnsf_bm', 'ucy', False, FLAGS_UCY_EXP),
+    ('rollout_flags', 'gc_exp_bm', 'pinnsf_bm', 'gc2344', False,
+     dict(FLAGS_UCY_EXP, collision_loss_weight=200, hard_collision_penalty=2))])
 def test_training_rollout_more_configs(fixture, tag, model_name, ds, finetune, extra):
     """UCY configuration (tau = 5/6, 2-point obstacle placeholder, k_o = 2), the residual fine-tune
     network of `--model pinnsf_res`, and the non-default loss switches (label-collision masking, teacher
