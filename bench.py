@@ -14,7 +14,13 @@ all-gather of the (p,v,a) records and a reduce-scatter of their gradients.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant HIP kernel (relfeat forward)
 with the operand-stream byte model of SURVEY.md 8d; `cpu_baseline` times the CPU oracle
-(C restatement, OpenMP) + the same PINNSF on the host cores on a bounded sample.
+(C restatement, OpenMP) + the same PINNSF on the host cores on a bounded sample, and the feature step in
+the reference's own dataflow (oracle/dataflow.py).
+
+The step is replayed from one captured HIP graph (eager fallback); the MLP's GEMMs use selections pre-tuned
+for this software stack (piml_amd/tuning; tuned in-process in a few seconds when torch rejects the file).
+After the timed region the gradients left behind by the replayed step are compared with an eager autograd
+step (`verified_max_rel_err`); a mismatch is fatal.
 """
 import argparse
 import json
