@@ -390,8 +390,10 @@ def main():
     _phase(f'capture done, mode={mode}')
     kernel_ms_samples, overhead_ms_samples = [], []
     cal_timer = _lib.StreamTimer()
-    ev_pairs = []
-    sample_every = max(1, args.steps // 10)
+    ev_pairs, sample_timers = [], []
+    # ~10 samples, at most one step in five: the events are only READ after the timed region (reading one
+    # synchronises the stream), so a sample costs the timed region two extra kernel launches and nothing else
+    sample_every = max(5, args.steps // 10)
 
     def run_step(i, timed):
         if graph is not None:
@@ -403,18 +405,18 @@ def main():
                 # behind another kernel rather than the idle gap that follows the previous replay
                 src = state_all if use_dist else state_own
                 ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
-                g_timer.start()
+                tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
+                tk.start()
                 ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
-                g_timer.stop()
+                tk.stop()
             graph.replay()
             if use_dist:
                 exchange_backward()
-            if sample:     # read this step's event pair (syncs on `stop` only)
+            if sample:
                 # calibration: an empty start/stop pair right behind the step measures what the two
                 # event records themselves add to an interval on this stream
-                cal_timer.start(); cal_timer.stop()
-                kernel_ms_samples.append(g_timer.elapsed_ms())
-                overhead_ms_samples.append(cal_timer.elapsed_ms())
+                tc.start(); tc.stop()
+                sample_timers.append((tk, tc))
         else:
             reset_grads()
             if timed:
@@ -481,6 +483,9 @@ def main():
 
     if graph is None:
         kernel_ms_samples = [tm.elapsed_ms() for tm in ev_pairs]
+    else:
+        kernel_ms_samples = [tk.elapsed_ms() for tk, _ in sample_timers]
+        overhead_ms_samples = [tc.elapsed_ms() for _, tc in sample_timers]
     def median(xs):
         xs = sorted(xs)
         return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
