@@ -391,9 +391,12 @@ def main():
     kernel_ms_samples, overhead_ms_samples = [], []
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # ~10 samples, at most one step in five: the events are only READ after the timed region (reading one
-    # synchronises the stream), so a sample costs the timed region two extra kernel launches and nothing else
-    sample_every = max(5, args.steps // 10)
+    # ~5 samples, at most one step in five; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
+    # that the cost of the two event records (4-7 us, measured by an empty pair) is a small correction.  The
+    # events are only READ after the timed region (reading one synchronises the stream): a sample costs the
+    # timed region its extra launches and nothing else.
+    TIMED_LAUNCHES = 4
+    sample_every = max(5, args.steps // 5)
 
     def run_step(i, timed):
         if graph is not None:
@@ -407,7 +410,8 @@ def main():
                 ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
                 tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
                 tk.start()
-                ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
+                for _ in range(TIMED_LAUNCHES):
+                    ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
                 tk.stop()
             graph.replay()
             if use_dist:
@@ -490,9 +494,10 @@ def main():
         xs = sorted(xs)
         return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
     # median over the sampled launches: robust against the occasional preempted / cold sample
-    raw_ms = median(kernel_ms_samples)
+    launches_per_sample = TIMED_LAUNCHES if graph is not None else 1
+    raw_ms = median(kernel_ms_samples)                 # interval around `launches_per_sample` launches
     overhead_ms = median(overhead_ms_samples)
-    kernel_ms = max(raw_ms - overhead_ms, 1e-6)
+    kernel_ms = max(raw_ms - overhead_ms, 1e-6) / launches_per_sample
     pairs_step = N * (N + M_eff)                       # all ranks together
     alg_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own   # this rank's launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -528,6 +533,7 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'kernel_us': kernel_ms * 1e3, 'event_interval_us': raw_ms * 1e3,
                          'event_pair_overhead_us': overhead_ms * 1e3, 'kernel_samples': len(kernel_ms_samples),
+                         'launches_per_sample': launches_per_sample,
                          'algorithmic_bytes': alg_bytes,
                          'traffic_source': 'profiles/r01_relfeat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' if traffic else None,
                          'interval_includes_allgather': bool(use_dist) and graph is None,
