@@ -391,12 +391,13 @@ def main():
     kernel_ms_samples, overhead_ms_samples = [], []
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # ~5 samples, at most one step in five; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
+    # up to 5 samples; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
     # that the cost of the two event records (4-7 us, measured by an empty pair) is a small correction.  The
     # events are only READ after the timed region (reading one synchronises the stream): a sample costs the
     # timed region its extra launches and nothing else.
     TIMED_LAUNCHES = 4
-    sample_every = max(5, args.steps // 5)
+    n_samples = max(1, min(5, args.steps // 20))       # 5 launches each: keep their share of a short run small
+    sample_every = -(-args.steps // n_samples)
 
     def run_step(i, timed):
         if graph is not None:
