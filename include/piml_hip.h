@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 6
+#define PIML_HIP_ABI_VERSION 7
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -315,9 +315,12 @@ int piml_layer_reduce(const float* parts, int B, size_t n, float* out, const flo
  * processor(x) = scale * x, scale = 2 in eval mode): msgs = scale * e (rows,cols) and
  * pooled[r / k] = sum over the k rows of one agent of msgs.  bwd: g_e = scale * (g_pooled[r / k] +
  * g_msgs[r]) with g_msgs optional (NULL).  cols % 4 == 0.
+ * bias (cols, optional): msgs = scale * (e + bias) -- the bias of the encoder's last Linear, when that layer was
+ * run as a plain GEMM (its bias-epilogue variant is the slower kernel); the gradient w.r.t. that bias is still
+ * the column sum of g_e, which the layer's own backward computes.
  */
-int piml_scale_ksum_fwd(const float* e, size_t agents, int k, int cols, float scale, float* msgs, float* pooled,
-                        void* stream);
+int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale, float* msgs,
+                        float* pooled, void* stream);
 int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols, float scale,
                         float* g_e, void* stream);
 

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -46,7 +46,7 @@ SIGNATURES = {
     'piml_sum_leading': [_p, _i, _z, _p, _p],
     'piml_act_bwd_colsum_stage1': [_p, _p, _z, _i, _p, _p, _p, _p],
     'piml_layer_reduce': [_p, _i, _z, _p, _p, _i, _i, _p, _p],
-    'piml_scale_ksum_fwd': [_p, _z, _i, _i, _f, _p, _p, _p],
+    'piml_scale_ksum_fwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p],
     'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const flo
 // ---------------------------------------------------------------------------------------------
 // msgs = scale * e ; pooled[agent] = sum_k msgs[agent, k]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __restrict__ e, size_t agents, int k,
+__global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __restrict__ e,
+                                                              const float4* __restrict__ bias, size_t agents, int k,
                                                               int lanes, float scale, float4* __restrict__ msgs,
                                                               float4* __restrict__ pooled) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,9 +328,11 @@ __global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __res
     const int lane = (int)(id % lanes);
     if (agent >= agents) return;
     const size_t base = agent * k * lanes + lane;
+    const float4 b = bias ? bias[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < k; ++j) {
         float4 v = e[base + (size_t)j * lanes];
+        if (bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
         msgs[base + (size_t)j * lanes] = v;
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -521,15 +524,15 @@ PIML_API int piml_act_bwd_colsum_stage1(const float* g, const float* y, size_t r
     return act_bwd_colsum_launch(g, y, rows, cols, g_pre, partials, db, stream, false);
 }
 
-PIML_API int piml_scale_ksum_fwd(const float* e, size_t agents, int k, int cols, float scale, float* msgs,
-                                 float* pooled, void* stream) {
+PIML_API int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale,
+                                 float* msgs, float* pooled, void* stream) {
     if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
     if (agents == 0) return hipSuccess;
     if (!e || !msgs || !pooled) return hipErrorInvalidValue;
     const int lanes = cols / 4;
     hipLaunchKernelGGL(scale_ksum_fwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(e), agents, k, lanes, scale, reinterpret_cast<float4*>(msgs),
-                       reinterpret_cast<float4*>(pooled));
+                       reinterpret_cast<const float4*>(e), reinterpret_cast<const float4*>(bias), agents, k, lanes, scale,
+                       reinterpret_cast<float4*>(msgs), reinterpret_cast<float4*>(pooled));
     return hipGetLastError();
 }
 

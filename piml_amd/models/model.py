@@ -60,12 +60,19 @@ class MLP(nn.Module):
         self.mlp = nn.Sequential(*mods)
         self._fusable = all(isinstance(a, (nn.ReLU, nn.Identity)) for a in mods[1::2])
 
-    def forward(self, x):
-        if FUSED_GLUE and self._fusable and x.is_cuda and x.dtype == torch.float32:
+    def fused_ok(self, x):
+        return FUSED_GLUE and self._fusable and x.is_cuda and x.dtype == torch.float32
+
+    def forward(self, x, defer_last_bias=False):
+        """defer_last_bias (fused GPU path only, last layer without activation): return the output WITHOUT the
+        last layer's bias -- the caller adds `self.mlp[-2].bias` (ops.scale_ksum does, in its own pass)."""
+        if self.fused_ok(x):
             from .. import ops
             lins = self.mlp[0::2]
             relus = [isinstance(a, nn.ReLU) for a in self.mlp[1::2]]
-            return ops.mlp_chain(x, relus, *[t for lin in lins for t in (lin.weight, lin.bias)])
+            return ops.mlp_chain(x, relus, *[t for lin in lins for t in (lin.weight, lin.bias)],
+                                 defer_last_bias=defer_last_bias)
+        assert not defer_last_bias
         return self.mlp(x)
 
 
@@ -173,15 +180,25 @@ class _PINNSFBase(nn.Module):
         return (desired_speed * dest_direction - self_features[..., 2:4]) / self.tau
 
     @staticmethod
-    def _process_and_pool(processor, encoded):
-        """(processor(encoded), its sum over the neighbour axis)."""
+    def _process_and_pool(processor, encoded, bias=None):
+        """(processor(encoded [+ bias]), its sum over the neighbour axis)."""
         scale = processor.pure_scale()
         if FUSED_GLUE and scale is not None and encoded.is_cuda and encoded.shape[-1] % 4 == 0 \
                 and encoded.dtype == torch.float32:
             from .. import ops
-            return ops.scale_ksum(encoded, scale)
+            return ops.scale_ksum(encoded, scale, bias=bias)
+        assert bias is None
         emb = processor(encoded)
         return emb, emb.sum(dim=-2)
+
+    def _encode_process_pool(self, feats, encoder, processor):
+        """encoder -> processor -> k-sum.  On the fused GPU path the encoder's last Linear runs as a plain GEMM
+        (its bias-epilogue variant is the slower library kernel) and its bias is added inside the k-sum pass."""
+        last = encoder.mlp[-2] if len(encoder.mlp) >= 2 else None
+        if last is not None and encoder.fused_ok(feats) and isinstance(encoder.mlp[-1], nn.Identity) \
+                and processor.pure_scale() is not None and last.out_features % 4 == 0:
+            return self._process_and_pool(processor, encoder(feats, defer_last_bias=True), bias=last.bias)
+        return self._process_and_pool(processor, encoder(feats))
 
     def _branch(self, feats, encoder, processor, decoder, predictor):
         if self.bottleneck:
@@ -189,7 +206,7 @@ class _PINNSFBase(nn.Module):
             decoded = decoder(emb)
             msgs = predictor(decoded)
             return msgs.sum(dim=-2), msgs, decoded, emb
-        emb, pooled = self._process_and_pool(processor, encoder(feats))
+        emb, pooled = self._encode_process_pool(feats, encoder, processor)
         acc = predictor(decoder(pooled))
         return acc, emb, None, emb
 

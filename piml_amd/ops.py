@@ -735,13 +735,16 @@ class _MLPChain(torch.autograd.Function):
     fork from an already forked stream crashed hipStreamEndCapture on ROCm 7.0.)"""
 
     @staticmethod
-    def forward(ctx, x, relus, *wb):
+    def forward(ctx, x, relus, defer_last_bias, *wb):
         x2 = x.reshape(-1, x.shape[-1])
         acts = [x2]
+        n = len(relus)
         for i, relu in enumerate(relus):
             w, b = wb[2 * i], wb[2 * i + 1]
-            acts.append(_addmm_relu(b, acts[-1], w.t()) if relu
-                        else torch.addmm(b, acts[-1], w.t()))
+            if defer_last_bias and i == n - 1:       # plain GEMM; the caller adds the bias (scale_ksum)
+                acts.append(acts[-1].mm(w.t()))
+            else:
+                acts.append(_addmm_relu(b, acts[-1], w.t()) if relu else torch.addmm(b, acts[-1], w.t()))
         out = acts[-1].view(*x.shape[:-1], acts[-1].shape[-1])
         ctx.save_for_backward(*acts[:-1], out, *wb[0::2])
         ctx.relus, ctx.x_shape = tuple(relus), x.shape
@@ -753,7 +756,7 @@ class _MLPChain(torch.autograd.Function):
     def backward(ctx, g):
         n = len(ctx.relus)
         if g is None:
-            return (None,) * (2 + 2 * n)
+            return (None,) * (3 + 2 * n)
         saved = ctx.saved_tensors
         acts, out, weights = saved[:n], saved[n], saved[n + 1:]
         need = ctx.needs_input_grad
@@ -765,46 +768,54 @@ class _MLPChain(torch.autograd.Function):
             if ctx.relus[i]:
                 y = (out if i == n - 1 else acts[i + 1]).reshape(-1, w.shape[0])
             g_pre, db, pending = act_bwd_colsum(g_cur, y, defer=True)
-            if need[2 + 2 * i + 1]:
+            if need[3 + 2 * i + 1]:
                 grads[2 * i + 1] = db
-            if need[2 + 2 * i]:
+            if need[3 + 2 * i]:
                 grads[2 * i] = _weight_grad(g_pre, acts[i], pending, db)
             elif pending is not None:
                 layer_reduce(None, pending, db)
             if i > 0 or need[0]:
                 g_cur = g_pre.mm(w)
         gx = g_cur.view(ctx.x_shape) if need[0] else None
-        return (gx, None, *grads)
+        return (gx, None, None, *grads)
 
 
-def mlp_chain(x, relus, *weights_and_biases):
+def mlp_chain(x, relus, *weights_and_biases, defer_last_bias=False):
     """x (..., in) through Linear(+ReLU) layers; `relus[i]` says whether layer i is followed by a ReLU;
-    weights_and_biases = (w0, b0, w1, b1, ...)."""
+    weights_and_biases = (w0, b0, w1, b1, ...).  defer_last_bias: the last layer (which must have no ReLU) is run
+    as a plain GEMM and its bias is NOT added -- the caller adds it (scale_ksum(..., bias=...)); the gradient of
+    that bias is still returned here."""
     if len(weights_and_biases) != 2 * len(relus):
         raise ValueError('mlp_chain: one (weight, bias) pair per layer expected')
     if not relus:
         return x
     if not x.is_cuda:
         raise _lib.PimlHipError('mlp_chain: expected a GPU tensor (piml_amd has no CPU path)')
+    if defer_last_bias and relus[-1]:
+        raise ValueError('mlp_chain: defer_last_bias needs a last layer without ReLU')
     if not torch.is_grad_enabled():       # inference: no autograd node, just the GEMMs
         h = x.reshape(-1, x.shape[-1])
         for i, relu in enumerate(relus):
             w, b = weights_and_biases[2 * i], weights_and_biases[2 * i + 1]
-            h = _addmm_relu(b, h, w.t()) if relu else torch.addmm(b, h, w.t())
+            if defer_last_bias and i == len(relus) - 1:
+                h = h.mm(w.t())
+            else:
+                h = _addmm_relu(b, h, w.t()) if relu else torch.addmm(b, h, w.t())
         return h.view(*x.shape[:-1], h.shape[-1])
-    return _MLPChain.apply(x, tuple(bool(r) for r in relus), *weights_and_biases)
+    return _MLPChain.apply(x, tuple(bool(r) for r in relus), bool(defer_last_bias), *weights_and_biases)
 
 
 class _ScaleKSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e, scale):
+    def forward(ctx, e, scale, bias):
         e = _gpu_f32('e', e)
         k, cols = e.shape[-2], e.shape[-1]
         agents = e.numel() // (k * cols)
         msgs = torch.empty_like(e)
         pooled = torch.empty(*e.shape[:-2], cols, device=e.device, dtype=torch.float32)
+        b = _gpu_f32('bias', bias.detach()) if bias is not None else None
         with torch.cuda.device(e.device):
-            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), agents, k, cols, float(scale), _ptr(msgs),
+            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(b), agents, k, cols, float(scale), _ptr(msgs),
                                                       _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
         ctx.geom = (agents, k, cols, float(scale), tuple(e.shape))
         ctx.set_materialize_grads(False)      # an unused output arrives as None, not as a zero tensor
@@ -816,22 +827,26 @@ class _ScaleKSum(torch.autograd.Function):
         agents, k, cols, scale, shape = ctx.geom
         ref = g_pooled if g_pooled is not None else g_msgs
         if ref is None:
-            return None, None
+            return None, None, None
         g_e = torch.empty(shape, device=ref.device, dtype=torch.float32)
         gm = g_msgs.contiguous() if g_msgs is not None else None
         gp = g_pooled.contiguous() if g_pooled is not None else None
         with torch.cuda.device(ref.device):
             _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e),
                                                       _stream()), 'piml_scale_ksum_bwd')
-        return g_e, None
+        return g_e, None, None
 
 
-def scale_ksum(e, scale=2.0):
-    """(scale * e, (scale * e).sum(-2)) for e (..., k, cols), cols % 4 == 0: the eval-mode PINNSF processor
-    (quirk Q3) + neighbour-axis pooling (src/models/model.py:1279-1283) in one pass."""
+def scale_ksum(e, scale=2.0, bias=None):
+    """(scale * (e + bias), its sum over axis -2) for e (..., k, cols), cols % 4 == 0: the eval-mode PINNSF processor
+    (quirk Q3) + neighbour-axis pooling (src/models/model.py:1279-1283) in one pass.  `bias` (cols, optional) is
+    the deferred bias of the Linear that produced `e` (mlp_chain(..., defer_last_bias=True)); it is a constant
+    here -- its gradient is the column sum of d/d(e), which that layer's backward returns."""
     if e.dim() < 2 or e.shape[-1] % 4:
         raise ValueError('scale_ksum: e (..., k, cols) with cols % 4 == 0 expected')
-    return _ScaleKSum.apply(e, scale)
+    if bias is not None and tuple(bias.shape) != (e.shape[-1],):
+        raise ValueError('scale_ksum: bias (cols,) expected')
+    return _ScaleKSum.apply(e, scale, bias)
 
 
 class _TrainRolloutStep(torch.autograd.Function):

@@ -123,14 +123,17 @@ def test_linear_act_matches_torch(shape, out_f, relu):
 
 
 @pytest.mark.parametrize('use', ['pooled', 'both', 'msgs'])
-def test_scale_ksum_matches_torch(use):
+@pytest.mark.parametrize('with_bias', [False, True])
+def test_scale_ksum_matches_torch(use, with_bias):
     from piml_amd import ops
     e = rnd(513, 6, 128, seed=1)
+    bias = rnd(128, seed=9) if with_bias else None
     ea = e.clone().requires_grad_(True)
-    m_ref = ea + ea
+    eb_ = ea + bias if with_bias else ea
+    m_ref = eb_ + eb_
     p_ref = m_ref.sum(dim=-2)
     eb = e.clone().requires_grad_(True)
-    m, p = ops.scale_ksum(eb, 2.0)
+    m, p = ops.scale_ksum(eb, 2.0, bias=bias)
     assert torch.equal(m, m_ref)
     assert torch.allclose(p, p_ref, rtol=1e-5, atol=1e-5)
     wm, wp = rnd(513, 6, 128, seed=2), rnd(513, 128, seed=3)
@@ -372,3 +375,30 @@ def test_tuned_gemm_selections_load_on_a_matching_stack():
     assert isinstance(ok, bool)
     if same_stack:
         assert ok, 'tuned GEMM selections were rejected on the stack they were tuned on'
+
+
+def test_mlp_chain_deferred_last_bias():
+    """Last layer as a plain GEMM, its bias added by the k-sum pass: same messages / pooled sums / gradients
+    (incl. the deferred bias's own gradient) as the ordinary chain followed by scale_ksum."""
+    from piml_amd import ops
+    torch.manual_seed(5)
+    lins = [torch.nn.Linear(a, b).to(DEV) for a, b in ((6, 128), (128, 128), (128, 128))]
+    relus = (True, True, False)
+    params = [t for lin in lins for t in (lin.weight, lin.bias)]
+    x = rnd(2048, 6, 6, seed=1)
+    wm, wp = rnd(2048, 6, 128, seed=2), rnd(2048, 128, seed=3)
+
+    def run(defer):
+        xa = x.clone().requires_grad_(True)
+        h = ops.mlp_chain(xa, relus, *params, defer_last_bias=defer)
+        m, p = ops.scale_ksum(h, 2.0, bias=lins[-1].bias if defer else None)
+        g = torch.autograd.grad((m * wm).sum() + (p * wp).sum(), [xa] + params)
+        return m.detach(), p.detach(), g
+    m0, p0, g0 = run(False)
+    m1, p1, g1 = run(True)
+    assert torch.allclose(m1, m0, rtol=1e-5, atol=1e-5) and torch.allclose(p1, p0, rtol=1e-5, atol=1e-5)
+    for a, b in zip(g1, g0):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 5e-5 * scale
+    with pytest.raises(ValueError):
+        ops.mlp_chain(x, (True, True, True), *params, defer_last_bias=True)
