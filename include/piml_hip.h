@@ -315,14 +315,18 @@ int piml_layer_reduce(const float* parts, int B, size_t n, float* out, const flo
  * processor(x) = scale * x, scale = 2 in eval mode): msgs = scale * e (rows,cols) and
  * pooled[r / k] = sum over the k rows of one agent of msgs.  bwd: g_e = scale * (g_pooled[r / k] +
  * g_msgs[r]) with g_msgs optional (NULL).  cols % 4 == 0.
+ * col_partials (optional, piml_ksum_blocks(agents, cols) * cols floats, needs 256 % (cols / 4) == 0): per-block
+ * column sums of g_e, i.e. the first stage of the bias gradient of the Linear that produced e (finish with
+ * piml_layer_reduce) -- saves that layer's own pass over g_e.
  * bias (cols, optional): msgs = scale * (e + bias) -- the bias of the encoder's last Linear, when that layer was
  * run as a plain GEMM (its bias-epilogue variant is the slower kernel); the gradient w.r.t. that bias is still
  * the column sum of g_e, which the layer's own backward computes.
  */
 int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale, float* msgs,
                         float* pooled, void* stream);
+int piml_ksum_blocks(size_t agents, int cols);
 int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols, float scale,
-                        float* g_e, void* stream);
+                        float* g_e, float* col_partials, void* stream);
 
 /*
  * HIP-event timer for measuring a kernel live on the stream it is launched on, also while

@@ -47,7 +47,8 @@ SIGNATURES = {
     'piml_act_bwd_colsum_stage1': [_p, _p, _z, _i, _p, _p, _p, _p],
     'piml_layer_reduce': [_p, _i, _z, _p, _p, _i, _i, _p, _p],
     'piml_scale_ksum_fwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p],
-    'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p],
+    'piml_ksum_blocks': [_z, _i],
+    'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],

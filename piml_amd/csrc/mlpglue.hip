@@ -342,21 +342,39 @@ __global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __res
 
 __global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __restrict__ g_pooled,
                                                               const float4* __restrict__ g_msgs, size_t agents, int k,
-                                                              int lanes, float scale, float4* __restrict__ g_e) {
+                                                              int lanes, float scale, float4* __restrict__ g_e,
+                                                              float4* __restrict__ col_partials) {
+    __shared__ float4 sh[256];
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t agent = id / lanes;
     const int lane = (int)(id % lanes);
-    if (agent >= agents) return;
-    const size_t base = agent * k * lanes + lane;
-    const float4 gp = g_pooled ? g_pooled[agent * lanes + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < k; ++j) {
-        float4 v = gp;
-        if (g_msgs) {
-            const float4 m = g_msgs[base + (size_t)j * lanes];
-            v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (agent < agents) {
+        const size_t base = agent * k * lanes + lane;
+        const float4 gp = g_pooled ? g_pooled[agent * lanes + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; ++j) {
+            float4 v = gp;
+            if (g_msgs) {
+                const float4 m = g_msgs[base + (size_t)j * lanes];
+                v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+            }
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            g_e[base + (size_t)j * lanes] = v;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        g_e[base + (size_t)j * lanes] = v;
+    }
+    if (!col_partials) return;
+    // column sums of this block's rows of g_e (lanes divides 256: thread t holds column lane t % lanes) ->
+    // one partial row per block; the bias gradient of the Linear that produced e is their sum
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < lanes) {
+        float4 s = sh[threadIdx.x];
+        for (int q = (int)threadIdx.x + lanes; q < 256; q += lanes) {
+            const float4 v = sh[q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        col_partials[(size_t)blockIdx.x * lanes + threadIdx.x] = s;
     }
 }
 
@@ -536,15 +554,21 @@ PIML_API int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agent
     return hipGetLastError();
 }
 
+PIML_API int piml_ksum_blocks(size_t agents, int cols) {
+    if (cols <= 0 || cols % 4) return 0;
+    return (int)blocks_for(agents * (size_t)(cols / 4), 256);
+}
+
 PIML_API int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols,
-                                 float scale, float* g_e, void* stream) {
+                                 float scale, float* g_e, float* col_partials, void* stream) {
     if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
     if (agents == 0) return hipSuccess;
     if (!g_e) return hipErrorInvalidValue;
     const int lanes = cols / 4;
+    if (col_partials && 256 % lanes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(scale_ksum_bwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(g_pooled), reinterpret_cast<const float4*>(g_msgs), agents, k,
-                       lanes, scale, reinterpret_cast<float4*>(g_e));
+                       lanes, scale, reinterpret_cast<float4*>(g_e), reinterpret_cast<float4*>(col_partials));
     return hipGetLastError();
 }
 

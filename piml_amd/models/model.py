@@ -197,6 +197,12 @@ class _PINNSFBase(nn.Module):
         last = encoder.mlp[-2] if len(encoder.mlp) >= 2 else None
         if last is not None and encoder.fused_ok(feats) and isinstance(encoder.mlp[-1], nn.Identity) \
                 and processor.pure_scale() is not None and last.out_features % 4 == 0:
+            if 256 % (last.out_features // 4) == 0 and feats.dim() >= 3:      # one autograd node for all of it
+                from .. import ops
+                lins = encoder.mlp[0::2]
+                relus = [isinstance(a, nn.ReLU) for a in encoder.mlp[1::2]]
+                return ops.encoder_pool(feats, relus, processor.pure_scale(),
+                                        *[t for lin in lins for t in (lin.weight, lin.bias)])
             return self._process_and_pool(processor, encoder(feats, defer_last_bias=True), bias=last.bias)
         return self._process_and_pool(processor, encoder(feats))
 

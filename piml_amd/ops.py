@@ -726,6 +726,34 @@ def _weight_grad(g_pre, x, pending=None, db=None):
     return g_pre.t().mm(x)
 
 
+def _chain_backward(relus, acts, out, weights, g_last, need_x, need_wb, first=None):
+    """Backward of Linear(+ReLU) layers from the last to the first.  acts[i]: input of layer i (rows, in); out: the
+    last layer's output (only read when it has a ReLU); g_last (rows, out_n).  `first` = (g_pre, db, pending) when
+    the last layer's mask / bias-gradient stage was already produced elsewhere (ops._EncoderPool).
+    Returns (gx (rows, in_0) | None, [gw0, gb0, gw1, gb1, ...])."""
+    n = len(relus)
+    g_cur = g_last
+    grads = [None] * (2 * n)
+    for i in reversed(range(n)):
+        w = weights[i]
+        if first is not None and i == n - 1:
+            g_pre, db, pending = first
+        else:
+            y = None
+            if relus[i]:
+                y = (out if i == n - 1 else acts[i + 1]).reshape(-1, w.shape[0])
+            g_pre, db, pending = act_bwd_colsum(g_cur, y, defer=True)
+        if need_wb[2 * i + 1]:
+            grads[2 * i + 1] = db
+        if need_wb[2 * i]:
+            grads[2 * i] = _weight_grad(g_pre, acts[i], pending, db)
+        elif pending is not None:
+            layer_reduce(None, pending, db)
+        if i > 0 or need_x:
+            g_cur = g_pre.mm(w)
+    return (g_cur if need_x else None), grads
+
+
 class _MLPChain(torch.autograd.Function):
     """A whole MLP (src/models/model.py:40-65): Linear(+ReLU) layers back to back as ONE autograd node.
     Forward: one hipBLASLt GEMM per layer with bias (+ReLU) in its epilogue.  Backward, per layer from the
@@ -760,24 +788,9 @@ class _MLPChain(torch.autograd.Function):
         saved = ctx.saved_tensors
         acts, out, weights = saved[:n], saved[n], saved[n + 1:]
         need = ctx.needs_input_grad
-        g_cur = g.reshape(-1, weights[-1].shape[0])
-        grads = [None] * (2 * n)
-        for i in reversed(range(n)):
-            w = weights[i]
-            y = None
-            if ctx.relus[i]:
-                y = (out if i == n - 1 else acts[i + 1]).reshape(-1, w.shape[0])
-            g_pre, db, pending = act_bwd_colsum(g_cur, y, defer=True)
-            if need[3 + 2 * i + 1]:
-                grads[2 * i + 1] = db
-            if need[3 + 2 * i]:
-                grads[2 * i] = _weight_grad(g_pre, acts[i], pending, db)
-            elif pending is not None:
-                layer_reduce(None, pending, db)
-            if i > 0 or need[0]:
-                g_cur = g_pre.mm(w)
-        gx = g_cur.view(ctx.x_shape) if need[0] else None
-        return (gx, None, None, *grads)
+        gx, grads = _chain_backward(ctx.relus, acts, out, weights, g.reshape(-1, weights[-1].shape[0]), need[0],
+                                    need[3:])
+        return (gx.view(ctx.x_shape) if gx is not None else None, None, None, *grads)
 
 
 def mlp_chain(x, relus, *weights_and_biases, defer_last_bias=False):
@@ -832,9 +845,83 @@ class _ScaleKSum(torch.autograd.Function):
         gm = g_msgs.contiguous() if g_msgs is not None else None
         gp = g_pooled.contiguous() if g_pooled is not None else None
         with torch.cuda.device(ref.device):
-            _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e),
+            _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e), None,
                                                       _stream()), 'piml_scale_ksum_bwd')
         return g_e, None, None
+
+
+class _EncoderPool(torch.autograd.Function):
+    """encoder MLP (last layer without activation) -> scale -> neighbour-axis sum as ONE autograd node
+    (src/models/model.py:1271-1283 with quirk Q3): forward = _MLPChain with the last bias deferred + the scale_ksum
+    kernel; backward = the ksum backward kernel, which also leaves the per-block column sums of d/d(e) -- the first
+    stage of the last layer's bias gradient, so that layer needs no pass of its own over d/d(e) -- then the chain."""
+
+    @staticmethod
+    def forward(ctx, x, relus, scale, *wb):
+        x2 = x.reshape(-1, x.shape[-1])
+        acts = [x2]
+        n = len(relus)
+        for i, relu in enumerate(relus):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            if i == n - 1:
+                acts.append(acts[-1].mm(w.t()))
+            else:
+                acts.append(_addmm_relu(b, acts[-1], w.t()) if relu else torch.addmm(b, acts[-1], w.t()))
+        k, cols = x.shape[-2], acts[-1].shape[-1]
+        e = acts[-1]
+        agents = e.shape[0] // k
+        msgs = torch.empty(*x.shape[:-1], cols, device=x.device, dtype=torch.float32)
+        pooled = torch.empty(*x.shape[:-2], cols, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(wb[-1]), agents, k, cols, float(scale), _ptr(msgs),
+                                                      _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
+        ctx.save_for_backward(*acts[:-1], *wb[0::2])
+        ctx.relus, ctx.x_shape, ctx.geom = tuple(relus), x.shape, (agents, k, cols, float(scale))
+        ctx.set_materialize_grads(False)
+        return msgs, pooled
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_msgs, g_pooled):
+        n = len(ctx.relus)
+        ref = g_pooled if g_pooled is not None else g_msgs
+        if ref is None:
+            return (None,) * (3 + 2 * n)
+        saved = ctx.saved_tensors
+        acts, weights = saved[:n], saved[n:]
+        agents, k, cols, scale = ctx.geom
+        L = _lib.lib()
+        g_e = torch.empty(agents * k, cols, device=ref.device, dtype=torch.float32)
+        nb = L.piml_ksum_blocks(agents, cols)
+        partials = torch.empty(nb * cols, device=ref.device, dtype=torch.float32)
+        gm = g_msgs.contiguous() if g_msgs is not None else None
+        gp = g_pooled.contiguous() if g_pooled is not None else None
+        with torch.cuda.device(ref.device):
+            _lib.check(L.piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e), _ptr(partials),
+                                             _stream()), 'piml_scale_ksum_bwd')
+        if nb > 1:
+            db, pending = torch.empty(cols, device=ref.device, dtype=torch.float32), (partials, nb, cols)
+        else:
+            db, pending = partials, None
+        need = ctx.needs_input_grad
+        gx, grads = _chain_backward(ctx.relus, acts, None, weights, g_e, need[0], need[3:], first=(g_e, db, pending))
+        return (gx.view(ctx.x_shape) if gx is not None else None, None, None, *grads)
+
+
+def encoder_pool(x, relus, scale, *weights_and_biases):
+    """(scale * encoder(x), its sum over the neighbour axis) for x (..., k, in): mlp_chain (last layer without ReLU)
+    + scale_ksum as one autograd node.  Needs cols % 4 == 0 and 256 % (cols / 4) == 0 for the last layer's width."""
+    if not x.is_cuda:
+        raise _lib.PimlHipError('encoder_pool: expected a GPU tensor (piml_amd has no CPU path)')
+    cols = weights_and_biases[-2].shape[0]
+    if len(weights_and_biases) != 2 * len(relus) or not relus or relus[-1] or x.dim() < 3 or cols % 4 \
+            or 256 % (cols // 4):
+        raise ValueError('encoder_pool: (..., k, in) input, one (weight, bias) pair per layer, no ReLU after the '
+                         'last layer, and a last width w with w % 4 == 0 and 256 % (w / 4) == 0 expected')
+    if not torch.is_grad_enabled():
+        return scale_ksum(mlp_chain(x, relus, *weights_and_biases, defer_last_bias=True), scale,
+                          bias=weights_and_biases[-1])
+    return _EncoderPool.apply(_gpu_f32('x', x), tuple(bool(r) for r in relus), float(scale), *weights_and_biases)
 
 
 def scale_ksum(e, scale=2.0, bias=None):

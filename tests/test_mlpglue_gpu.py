@@ -402,3 +402,30 @@ def test_mlp_chain_deferred_last_bias():
         assert float((a - b).abs().max()) <= 5e-5 * scale
     with pytest.raises(ValueError):
         ops.mlp_chain(x, (True, True, True), *params, defer_last_bias=True)
+
+
+@pytest.mark.parametrize('use', ['pooled', 'both'])
+@pytest.mark.parametrize('rows,k,width', [(2048, 6, 128), (513, 10, 64), (3, 6, 128)])
+def test_encoder_pool_matches_chain_plus_ksum(use, rows, k, width):
+    """encoder -> 2x -> k-sum as one node (the ksum backward also yields the last bias gradient's first stage)."""
+    from piml_amd import ops
+    torch.manual_seed(7)
+    lins = [torch.nn.Linear(a, b).to(DEV) for a, b in ((6, width), (width, width), (width, width))]
+    relus = (True, True, False)
+    params = [t for lin in lins for t in (lin.weight, lin.bias)]
+    x = rnd(rows, k, 6, seed=1)
+    wm, wp = rnd(rows, k, width, seed=2), rnd(rows, width, seed=3)
+    loss = lambda m, p: (p * wp).sum() + ((m * wm).sum() if use == 'both' else 0)
+    xa = x.clone().requires_grad_(True)
+    m0, p0 = ops.scale_ksum(ops.mlp_chain(xa, relus, *params), 2.0)
+    g0 = torch.autograd.grad(loss(m0, p0), [xa] + params)
+    xb = x.clone().requires_grad_(True)
+    m1, p1 = ops.encoder_pool(xb, relus, 2.0, *params)
+    g1 = torch.autograd.grad(loss(m1, p1), [xb] + params)
+    assert torch.allclose(m1, m0, rtol=1e-5, atol=1e-5) and torch.allclose(p1, p0, rtol=1e-5, atol=1e-5)
+    for a, b in zip(g1, g0):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 5e-5 * scale, (float((a - b).abs().max()), scale)
+    with torch.no_grad():
+        m2, p2 = ops.encoder_pool(x, relus, 2.0, *params)
+    assert torch.allclose(m2, m0, rtol=1e-5, atol=1e-5) and torch.allclose(p2, p0, rtol=1e-5, atol=1e-5)
