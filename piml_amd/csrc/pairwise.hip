@@ -71,6 +71,51 @@ __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, flo
     return make_float2(s * dx, s * dy);
 }
 
+// Two ordered pairs per lane with packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32): the raw and GC force laws
+// (variants 0, 1).  Same expressions as mlapm_pair, element-wise on 2-vectors; products feeding sums are fused
+// (fma), which the 1e-5 relative bar of this smooth force law allows (the selections are unaffected).
+// (The variant stays a run-time value on purpose: a kernel specialised per variant at compile time measured
+// slower -- GC forward 38.7 us against 26.1 us at N = 4096.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_sel(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+
+__device__ __forceinline__ void mlapm_pair2(const MlapmParams& P, v2f rx, v2f ry, v2f wx, v2f wy, float vix, float viy,
+                                            float ex, float ey, v2f& fx, v2f& fy) {
+    const v2f zero = {0.f, 0.f}, one = {1.f, 1.f};
+    const v2f d2 = pk_fma(ry, ry, rx * rx);
+    const bool p0 = d2.x > 0.f, p1 = d2.y > 0.f;                                  // NaN -> false
+    const v2f rinv = {fast_rsq(d2.x), fast_rsq(d2.y)};
+    const v2f r = pk_sel(p0, p1, d2 * rinv, d2);                                  // :26
+    const v2f dot = pk_fma(v2f{viy, viy}, ry, v2f{vix, vix} * rx);
+    const v2f view = pk_sel(dot.x > 0.f, dot.y > 0.f, one, zero);                 // :27
+    const v2f ninv = pk_sel(p0, p1, rinv, zero);
+    const v2f nx = rx * ninv, ny = ry * ninv;
+    v2f g, dx, dy;
+    if (P.variant == 0) {
+        const v2f a = v2f{P.B2, P.B2} * r;
+        g = v2f{fast_exp2(a.x), fast_exp2(a.y)};                                  // :29
+        dx = nx; dy = ny;
+    } else {
+        const v2f cr = pk_fma(rx, v2f{ey, ey}, -(ry * v2f{ex, ex}));              // :34
+        const v2f st = {cr.x > 0.f ? -P.sth : (cr.x <= 0.f ? P.sth : cr.x),
+                        cr.y > 0.f ? -P.sth : (cr.y <= 0.f ? P.sth : cr.y)};
+        const v2f cth = {P.cth, P.cth};
+        dx = pk_fma(cth, nx, -(st * ny));                                         // :36-39
+        dy = pk_fma(st, nx, cth * ny);
+        const v2f w2 = pk_fma(wy, wy, wx * wx);
+        const v2f ri8 = {fminf(rinv.x, 1e8f), fminf(rinv.y, 1e8f)};
+        const v2f qi8 = {fminf(fast_rsq(w2.x), 1e8f), fminf(fast_rsq(w2.y), 1e8f)};
+        const v2f cs = pk_fma(ry, wy, rx * wx) * ri8 * qi8;                       // :32
+        const v2f a = pk_fma(v2f{P.D2, P.D2} * r, cs, pk_fma(v2f{P.C2, P.C2}, cs, v2f{P.B2, P.B2} * r));
+        g = v2f{fast_exp2(a.x), fast_exp2(a.y)};                                  // :40
+    }
+    const v2f sc = view * v2f{P.A, P.A} * g;
+    fx = sc * dx;
+    fy = sc * dy;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
@@ -85,6 +130,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
     const float en = fmaxf(norm2(ex, ey), 1e-12f);          // :21
     ex /= en; ey /= en;
     float sx = 0.f, sy = 0.f;
+    v2f acc2x = {0.f, 0.f}, acc2y = {0.f, 0.f};
     for (int base = 0; base < N; base += kMlTile) {
         const int tn = min(kMlTile, N - base);
         __syncthreads();
@@ -94,13 +140,30 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         }
         __syncthreads();
         if (!has) continue;
-        for (int j = lane; j < tn; j += 64) {
+        int j = lane;
+        if (P.variant != 2) {
+            // two sources per lane and iteration (j, j + 64), packed arithmetic
+            const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, vix2 = {vi.x, vi.x}, viy2 = {vi.y, vi.y};
+            for (; j + 64 < tn; j += 128) {
+                const float4 a = tile[j], b = tile[j + 64];
+                v2f fx, fy;
+                mlapm_pair2(P, v2f{a.x, b.x} - pix, v2f{a.y, b.y} - piy, v2f{a.z, b.z} - vix2, v2f{a.w, b.w} - viy2,
+                            vi.x, vi.y, ex, ey, fx, fy);
+                if (P.skip_absent) {                                        // absent sources contribute nothing
+                    if (a.x != a.x || a.y != a.y) { fx.x = 0.f; fy.x = 0.f; }
+                    if (b.x != b.x || b.y != b.y) { fx.y = 0.f; fy.y = 0.f; }
+                }
+                acc2x += fx; acc2y += fy;
+            }
+        }
+        for (; j < tn; j += 64) {
             const float4 s = tile[j];
             if (P.skip_absent && (s.x != s.x || s.y != s.y)) continue;      // absent source
             const float2 t = mlapm_pair(P, s.x - pi.x, s.y - pi.y, s.z - vi.x, s.w - vi.y, vi.x, vi.y, ex, ey);
             sx += t.x; sy += t.y;
         }
     }
+    sx += acc2x.x + acc2x.y; sy += acc2y.x + acc2y.y;
     sx = wave_sum(sx); sy = wave_sum(sy);
     if (has && lane == 0) {
         const float v0i = v0[i];
