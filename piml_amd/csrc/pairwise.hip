@@ -306,6 +306,33 @@ __global__ void collision_pairs_kernel(const float2* __restrict__ p, int S, int 
     coll[((size_t)s * N + i) * N + j] = c != c ? 0.f : c;
 }
 
+// The same for N % 4 == 0: four j per thread (one float4 store), kPairRows rows i per block with the four
+// source points kept in registers -- 8192 instead of 262144 workgroups at N = 4096, S = 4.
+constexpr int kPairRows = 8;
+__global__ __launch_bounds__(256) void collision_pairs4_kernel(const float2* __restrict__ p, int S, int N, float thr,
+                                                                int minus_identity, float* __restrict__ coll) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int i0 = blockIdx.y * kPairRows, s = blockIdx.z;
+    if (j >= N) return;
+    const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * N + j);        // p[j], p[j+1]
+    const float4 b = *reinterpret_cast<const float4*>(p + (size_t)s * N + j + 2);    // p[j+2], p[j+3]
+    const float px[4] = {a.x, a.z, b.x, b.z}, py[4] = {a.y, a.w, b.y, b.w};
+    for (int r = 0; r < kPairRows; ++r) {
+        const int i = i0 + r;
+        if (i >= N) break;
+        const float2 pi = p[(size_t)s * N + i];
+        float c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = norm2(px[q] - pi.x, py[q] - pi.y);
+            float v = d != d ? d : (d < thr ? 1.f : 0.f);
+            if (minus_identity && i == j + q) v -= 1.f;
+            c[q] = v != v ? 0.f : v;
+        }
+        *reinterpret_cast<float4*>(coll + ((size_t)s * N + i) * N + j) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+}
+
 // 3-D friends rule (data.py:573-591): pairs whose `base` sum over the leading dim exceeds 25
 // are zeroed in every slice of `coll`.
 __global__ void collision_friends3_kernel(float* __restrict__ coll, const float* __restrict__ base,
@@ -534,8 +561,13 @@ PIML_API int piml_collision_matrix(const float* position, int S, int N, float th
     if (S < 0 || N < 0 || N > 65535 || S > 65535) return hipErrorInvalidValue;
     if ((long)S * N == 0) return hipSuccess;
     if (!position || !coll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(collision_pairs_kernel, dim3((N + 255) / 256, N, S), dim3(256), 0, as_stream(stream),
-                       (const float2*)position, S, N, threshold, minus_identity, coll);
+    if (N % 4 == 0)
+        hipLaunchKernelGGL(collision_pairs4_kernel, dim3((N / 4 + 255) / 256, (N + kPairRows - 1) / kPairRows, S),
+                           dim3(256), 0, as_stream(stream), (const float2*)position, S, N, threshold,
+                           minus_identity, coll);
+    else
+        hipLaunchKernelGGL(collision_pairs_kernel, dim3((N + 255) / 256, N, S), dim3(256), 0, as_stream(stream),
+                           (const float2*)position, S, N, threshold, minus_identity, coll);
     return hipGetLastError();
 }
 

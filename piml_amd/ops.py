@@ -395,8 +395,11 @@ def collision_detection(position, threshold, real_position=None):
             _lib.check(L.piml_collision_friends(_ptr(coll), _ptr(base), 1, coll.shape[0], base.shape[0], N,
                                                 _stream()), 'piml_collision_friends')
         elif position.dim() == 3:
-            _lib.check(L.piml_collision_friends(_ptr(coll), _ptr(coll), 1, coll.shape[0], coll.shape[0], N,
-                                                _stream()), 'piml_collision_friends')
+            # the rule zeroes pairs colliding in MORE than 25 slices: with <= 25 slices (the (c,n,2) calls of
+            # the fine-tuning loop) it cannot trigger and the pass over the matrix is skipped
+            if coll.shape[0] > 25:
+                _lib.check(L.piml_collision_friends(_ptr(coll), _ptr(coll), 1, coll.shape[0], coll.shape[0], N,
+                                                    _stream()), 'piml_collision_friends')
         else:
             _lib.check(L.piml_collision_friends(_ptr(coll), None, coll.shape[0], coll.shape[1], 0, N,
                                                 _stream()), 'piml_collision_friends')
