@@ -228,6 +228,58 @@ __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, 
     by = AE * un * hy;
 }
 
+// mlapm_pair_grad for the raw / GC laws on 2-vectors: element 0 and element 1 are two ordered pairs that may
+// differ in everything (the backward kernel feeds it the two roles of one unordered pair).  Same expressions,
+// packed fp32 arithmetic; a pair outside the view half plane (or at zero distance) yields exact zeros.
+__device__ __forceinline__ void mlapm_pair_grad2(const MlapmParams& P, v2f rx, v2f ry, v2f wx, v2f wy, v2f vix, v2f viy,
+                                                 v2f ex, v2f ey, v2f Gx, v2f Gy, v2f& ax, v2f& ay, v2f& bx, v2f& by) {
+    const v2f zero = {0.f, 0.f};
+    const v2f d2 = pk_fma(ry, ry, rx * rx);
+    const v2f dot = pk_fma(viy, ry, vix * rx);
+    const bool ok0 = (d2.x > 0.f) && (dot.x > 0.f), ok1 = (d2.y > 0.f) && (dot.y > 0.f);
+    const v2f rinv = {fast_rsq(d2.x), fast_rsq(d2.y)};
+    const v2f r = d2 * rinv;
+    const v2f nx = rx * rinv, ny = ry * rinv;
+    v2f ux = Gx, uy = Gy;                                          // R^T G with theta = 0
+    if (P.variant != 0) {
+        const v2f cr = pk_fma(rx, ey, -(ry * ex));
+        const v2f st = {cr.x > 0.f ? -P.sth : P.sth, cr.y > 0.f ? -P.sth : P.sth};
+        const v2f ct = {P.cth, P.cth};
+        ux = pk_fma(ct, Gx, st * Gy);
+        uy = pk_fma(ct, Gy, -(st * Gx));
+    }
+    const v2f un = pk_fma(ux, nx, uy * ny);
+    const v2f Bv = {P.B, P.B};
+    v2f phi2, fx, fy, hx = zero, hy = zero;
+    if (P.variant == 0) {
+        phi2 = v2f{P.B2, P.B2} * r;
+        fx = Bv * nx; fy = Bv * ny;
+    } else {
+        const v2f w2 = pk_fma(wy, wy, wx * wx);
+        const v2f ri8 = {fminf(rinv.x, 1e8f), fminf(rinv.y, 1e8f)};
+        const v2f qi8 = {fminf(fast_rsq(w2.x), 1e8f), fminf(fast_rsq(w2.y), 1e8f)};
+        const v2f n8x = rx * ri8, n8y = ry * ri8, mx = wx * qi8, my = wy * qi8;
+        const v2f cs = pk_fma(n8x, mx, n8y * my);
+        phi2 = pk_fma(v2f{P.D2, P.D2} * r, cs, pk_fma(v2f{P.C2, P.C2}, cs, v2f{P.B2, P.B2} * r));
+        const v2f Dv = {P.D, P.D};
+        const v2f k1 = pk_fma(Dv, r, v2f{P.Cc, P.Cc});
+        const bool r0 = r.x > 1e-8f, r1 = r.y > 1e-8f, q0 = w2.x > 1e-16f, q1 = w2.y > 1e-16f;
+        const v2f csx = pk_sel(r0, r1, pk_fma(-cs, n8x, mx), mx) * ri8;          // d(cs)/d(vr)
+        const v2f csy = pk_sel(r0, r1, pk_fma(-cs, n8y, my), my) * ri8;
+        const v2f dcs = Dv * cs;
+        fx = pk_fma(dcs, nx, pk_fma(k1, csx, Bv * nx));
+        fy = pk_fma(dcs, ny, pk_fma(k1, csy, Bv * ny));
+        hx = k1 * pk_sel(q0, q1, pk_fma(-cs, mx, n8x), n8x) * qi8;                // d(cs)/d(vv)
+        hy = k1 * pk_sel(q0, q1, pk_fma(-cs, my, n8y), n8y) * qi8;
+    }
+    const v2f AE = v2f{-P.A, -P.A} * v2f{fast_exp2(phi2.x), fast_exp2(phi2.y)};
+    const v2f aun = AE * un;
+    ax = pk_sel(ok0, ok1, AE * pk_fma(un, fx, pk_fma(-un, nx, ux) * rinv), zero);
+    ay = pk_sel(ok0, ok1, AE * pk_fma(un, fy, pk_fma(-un, ny, uy) * rinv), zero);
+    bx = pk_sel(ok0, ok1, aun * hx, zero);
+    by = pk_sel(ok0, ok1, aun * hy, zero);
+}
+
 // Backward: one wavefront per agent x accumulates BOTH its focal-side sums (-a_xo, -b_xo) and
 // its source-side sums (+a_ox, +b_ox) by evaluating every pair in both roles, so no atomics
 // and a fixed summation order (bitwise reproducible).
@@ -260,6 +312,18 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_kernel(
         }
         __syncthreads();
         if (!has) continue;
+        if (P.variant != 2) {
+            // both roles of the pair (x focal / o source, o focal / x source) as the two elements of packed vectors
+            for (int j = lane; j < tn; j += 64) {
+                const float4 s = tile_pv[j], t = tile_eg[j];
+                const float rx = s.x - px.x, ry = s.y - px.y, wx = s.z - vx.x, wy = s.w - vx.y;
+                v2f ax, ay, bx, by;
+                mlapm_pair_grad2(P, v2f{rx, -rx}, v2f{ry, -ry}, v2f{wx, -wx}, v2f{wy, -wy}, v2f{vx.x, s.z},
+                                 v2f{vx.y, s.w}, v2f{ex, t.x}, v2f{ey, t.y}, v2f{Gx, t.z}, v2f{Gy, t.w}, ax, ay, bx, by);
+                spx += ax.y - ax.x; spy += ay.y - ay.x; svx += bx.y - bx.x; svy += by.y - by.x;
+            }
+            continue;
+        }
         for (int j = lane; j < tn; j += 64) {
             const float4 s = tile_pv[j], t = tile_eg[j];
             float ax, ay, bx, by;
