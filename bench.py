@@ -165,7 +165,9 @@ def secondary_measurements(scene, n, dev, _lib):
                               'pairs_per_s_fwd': m * m / fwd_us * 1e6,
                               'roofline_frac_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                               'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
-                                      'present agents of the same scene; host-inclusive event timing of back-to-back launches'}}
+                                      'present agents of the same scene; host-inclusive event timing of back-to-back launches (the backward figure '
+                                      'is bound by autograd bookkeeping below ~16k agents; its kernel takes 45-60 us, '
+                                      'profiles/r01_other_kernels.md)'}}
 
 
 def main():
