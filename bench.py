@@ -508,7 +508,10 @@ def main():
     # ---- secondary figures, measured after (outside) the timed region, rank 0 only ----
     secondary = None
     if rank == 0 and args.secondary:
-        secondary = secondary_measurements(scene, n_own, dev, _lib)
+        try:
+            secondary = secondary_measurements(scene, n_own, dev, _lib)
+        except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
+            secondary = {'error': f'{type(ex).__name__}: {ex}'}
 
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r01_relfeat_traffic.json')
@@ -547,7 +550,10 @@ def main():
         if secondary is not None:
             out['secondary'] = secondary
         if args.cpu_seconds > 0 and world == 1:
-            out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
+            try:
+                out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
+            except Exception as ex:   # noqa: BLE001 - e.g. no C compiler for the oracle on this host
+                out['cpu_baseline'] = {'error': f'{type(ex).__name__}: {ex}'}
         elif world > 1:
             out['cpu_baseline'] = None
         sys.stdout.flush()
