@@ -81,4 +81,14 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         if k != 'config':
             f.write(f"- {k}: FETCH_SIZE {v['fetch_size_kib']:.1f} KiB, WRITE_SIZE {v['write_size_kib']:.1f} KiB per launch -> "
                     f"{v['hbm_bytes_per_launch'] / 1e6:.3f} MB (read side x2 per the gfx950 correction), L2 hit rate {v['l2_hit_rate']:.3f}\n")
+    # the glue kernels around the MLP's GEMMs: HBM bytes per launch next to their algorithmic bytes would show
+    # wasted re-reads; they stream L2 / MALL-resident activations, so the HBM side is mostly the write
+    f.write('\nGlue kernels (same PMC passes; averages over all launches of a kernel, i.e. over its layer shapes):\n\n')
+    for kern in sorted(fetch):
+        if 'piml::' not in kern or 'relfeat' in kern or 'mlapm' in kern:
+            continue
+        fk, wk = sum(fetch[kern]) / len(fetch[kern]), sum(write[kern]) / max(len(write[kern]), 1)
+        h, m = sum(hit[kern]) / max(len(hit[kern]), 1), sum(miss[kern]) / max(len(miss[kern]), 1)
+        f.write(f"- `{kern[:60]}`: FETCH_SIZE {fk:.0f} KiB, WRITE_SIZE {wk:.0f} KiB per launch -> "
+                f"{(2 * fk + wk) * 1024 / 1e6:.2f} MB, L2 hit rate {h / max(h + m, 1.0):.3f}\n")
 print(open(os.path.join(dst, f'{tag}_summary.md')).read())
