@@ -1,30 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: agent-pair force evaluations/s and simulated steps/s of one PINSF
-step (forward + backward) on the synthetic 4096-agent GC scene with 2000 obstacle points
-(BASELINE.json configs[2]).
+step (forward + backward) on a synthetic GC scene with 2000 obstacle points.
 
-One step = relfeat forward (HIP) -> PINNSF_multitask forward (PyTorch-ROCm) -> backward with
-upstream gradient ones on the acceleration -> relfeat backward (HIP), with the scene already
-resident in HBM.  pairs/step = N * (N + M).
+One step = relfeat forward (HIP) -> PINNSF_multitask forward -> backward with upstream gradient ones
+on the acceleration -> relfeat backward (HIP), with the scene already resident in HBM.
+pairs/step = N * (N + M).
 
-  python bench.py --gpus N --steps K --warmup W
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): agents are block-sharded
-4096 per GPU (weak scaling in focal agents: the scene has 4096*N agents), with a per-step
-all-gather of the (p,v,a) records and a reduce-scatter of their gradients.
+  python bench.py --gpus G --steps K --warmup W
+G = 1: BASELINE.json configs[2] -- 4096 agents on one MI355X.
+G > 1: BASELINE.json configs[3] -- ONE 16384-agent scene, agent blocks of 16384/G focal agents per rank
+("scaling": "strong"), per-step all-gather of the (p,v,a) records and one all-reduce of [d/d(state), weight
+gradients] over RCCL.  When WORLD_SIZE is not set the script launches itself under torch.distributed.run as a
+child process (before anything touches the GPU) and forwards rank 0's JSON line.  `--scaling weak` keeps
+`--agents` focal agents per GPU instead (scene of agents*G agents).  In strong mode rank 0 also times the same
+scene on ONE GPU after the timed region (`single_gpu_same_scene`), the baseline a strong-scaling efficiency needs.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant HIP kernel (relfeat forward)
-with the operand-stream byte model of SURVEY.md 8d; `cpu_baseline` times the CPU oracle
-(C restatement, OpenMP) + the same PINNSF on the host cores on a bounded sample, and the feature step in
+Rank 0 prints ONE JSON line.  `roofline.frac` is SURVEY.md 8d's step-level contract figure (operand-stream
+bytes of the step / step time / HBM peak); `roofline.kernels` lists the dominant kernels with the fraction of the
+unit that really bounds each (VALU issue for the N-body sweep, f32 MFMA for the MLP).  `cpu_baseline` times the CPU
+oracle (C restatement, OpenMP) + the same PINNSF on the host cores on a bounded sample, and the feature step in
 the reference's own dataflow (oracle/dataflow.py).
 
-The step is replayed from one captured HIP graph (eager fallback); the MLP's GEMMs use selections pre-tuned
-for this software stack (piml_amd/tuning; tuned in-process in a few seconds when torch rejects the file).
-After the timed region the gradients left behind by the replayed step are compared with an eager autograd
-step (`verified_max_rel_err`); a mismatch is fatal.
+The step is replayed from one captured HIP graph (eager fallback).  After the timed region the gradients left
+behind by the replayed step are compared with an eager autograd step (`verified_max_rel_err`); a mismatch is fatal.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -170,18 +174,211 @@ def secondary_measurements(scene, n, dev, _lib):
                                       'profiles/r01_other_kernels.md)'}}
 
 
-def main():
-    # stdout must carry exactly ONE JSON line: anything libraries print to fd 1 (e.g. RCCL's version
-    # banner) is sent to stderr, and the result is written to the saved stdout at the very end
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+F32_MFMA_PEAK_TFS = 157.3   # dense f32 matrix peak (v_mfma_f32_32x32x2_f32), same guide
 
+
+class Step:
+    """The hot path over one rank's agent block of one scene: scene tensors, model, the captured HIP graph of
+    the compute part and (sharded) the eager exchange either side of it."""
+
+    def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph):
+        from piml_amd import ops, _lib
+        from piml_amd.models.model import PINNSF_multitask
+        from piml_amd.sharded import ShardedScene
+        self.ops, self._lib = ops, _lib
+        self.N, self.n_own, self.b0, self.dev, self.group, self.use_dist = N, n_own, b0, dev, group, use_dist
+        self.obstacles = torch.tensor(scene['obstacles'], device=dev)
+        self.M_eff = self.obstacles.shape[0]
+        rows = slice(b0, b0 + n_own)
+        self.state_own = torch.tensor(np.concatenate([scene[k][rows] for k in ('position', 'velocity', 'acceleration')],
+                                                     axis=-1), device=dev).requires_grad_(True)
+        self.dest_own = torch.tensor(scene['destination'][rows], device=dev)
+        self.v0_own = torch.tensor(scene['desired_speed'][rows], device=dev)
+        self.sh = ShardedScene(N, self.obstacles, group=group, force_collectives=True) if use_dist else None
+        torch.manual_seed(666)
+        self.model = PINNSF_multitask(model_args()).to(dev).eval()   # eval: dropout off, deterministic
+        if two_streams:
+            self.model.obs_stream = torch.cuda.Stream()
+        self.params = [p for p in self.model.parameters()]
+        self.ones = torch.ones(n_own, 2, device=dev)
+        # Sharded + graph: only the COMPUTE of a step is captured; the two collectives (all-gather of the
+        # records before it; ONE all-reduce of [d/d(state), weight gradients] after it) are issued eagerly on
+        # the stream either side of the replay.  `state_all` is the graph's static input: the all-gather
+        # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
+        self.state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
+        self.grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
+        self.bucket = [None, None]
+        self.graph, self.static_feats, self.mode = None, None, 'eager'
+        self.want_graph = use_graph
+
+    # ---- eager pieces ----
+    def features(self):
+        """all-gather of the owners' records (sharded) + relfeat forward (HIP)."""
+        state_full = self.sh.gather_state(self.state_own) if self.sh is not None else self.state_own
+        return self.ops.relative_features_packed_self(state_full, self.dest_own, self.obstacles, self.v0_own,
+                                                      self.b0, self.n_own, return_index=True)
+
+    def rest(self, pf, of, self_features, *_idx):
+        """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
+        from piml_amd.sharded import allreduce_gradients
+        acc = self.model(pf, of, self_features)[0]
+        acc.backward(self.ones)
+        if self.sh is not None:
+            allreduce_gradients(self.params, self.group)
+        return acc
+
+    def features_local(self):
+        return self.ops.relative_features_packed_self(self.state_all, self.dest_own, self.obstacles, self.v0_own,
+                                                      self.b0, self.n_own, return_index=True)
+
+    def rest_local(self, pf, of, self_features, *_idx):
+        acc = self.model(pf, of, self_features)[0]
+        acc.backward(self.ones)
+        # captured: ONE concatenation of the (N, 6) state gradient and all weight gradients into a static
+        # bucket, so that the backward exchange is a single latency-bound all-reduce (0.9 MB at 16384 agents)
+        grads = [p.grad for p in self.params if p.grad is not None]
+        self.bucket[:] = [torch.cat([self.state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
+        return acc
+
+    def exchange_forward(self):
+        from piml_amd.sharded import gather_records_into
+        gather_records_into(self.state_all, self.state_own, self.group)
+
+    def exchange_backward(self):
+        from piml_amd.sharded import unflatten_gradients
+        N, b0, n_own = self.N, self.b0, self.n_own
+        dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
+        self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
+        unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
+
+    def step_body(self, timer=None):
+        """One forward + backward pass of the hot path over the scene, eagerly."""
+        if timer is not None:
+            timer.start()
+        feats = self.features()
+        if timer is not None:
+            timer.stop()
+        return self.rest(*feats)
+
+    def reset_grads(self):
+        self.state_own.grad = None
+        if self.state_all is not None:
+            self.state_all.grad = None
+        for p in self.params:
+            p.grad = None
+
+    def barrier(self):
+        if self.use_dist:
+            dist.barrier(group=self.group)
+        torch.cuda.synchronize()
+
+    # ---- whole-step HIP graph (removes ~60 per-kernel launch gaps); eager fallback ----
+    def capture(self):
+        if not self.want_graph:
+            return
+        ok = 1
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.reset_grads()
+                    self.step_body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.reset_grads()
+            # ONE graph holds the step's compute (relfeat forward ... relfeat backward).  ROCm cannot record
+            # events inside a captured graph, so the HIP events that time single kernels bracket extra eager
+            # launches of them (same inputs, same output buffers) in front of sampled replays.
+            graph = torch.cuda.CUDAGraph()
+            if self.use_dist:
+                self.exchange_forward()
+                torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                feats = self.features_local() if self.use_dist else self.features()
+                (self.rest_local if self.use_dist else self.rest)(*feats)
+            self.static_feats = feats     # the captured step's feature / index buffers stay alive
+            graph.replay()
+            if self.use_dist:
+                self.exchange_backward()
+            done = torch.cuda.Event()
+            done.record()
+            t_wait = time.perf_counter()
+            while not done.query():       # watchdog: a replay that never completes must not hang the run
+                if time.perf_counter() - t_wait > 30.0:
+                    print('[bench] FATAL: captured step did not complete within 30 s (deadlocked kernels); '
+                          're-run with --graph 0 or --two-streams 0', file=sys.stderr, flush=True)
+                    os._exit(3)
+                time.sleep(0.001)
+            torch.cuda.synchronize()
+            self.graph = graph
+        except Exception as ex:   # noqa: BLE001 - any capture problem means: run eagerly
+            print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
+                  file=sys.stderr)
+            ok, self.graph = 0, None
+        if self.use_dist:   # all ranks must run the same mode
+            t = torch.tensor([ok], device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            if int(t.item()) == 0:
+                self.graph = None
+        self.mode = 'hipgraph' if self.graph is not None else 'eager'
+
+    def relaunch_relfeat(self):
+        """The relfeat forward kernel of the captured step once more, eagerly, on the same buffers."""
+        src = self.state_all if self.use_dist else self.state_own
+        self.ops.relative_features_packed_into(self.static_feats, src, self.dest_own, self.obstacles, self.b0, self.n_own)
+
+    def run(self):
+        """One step (exchange + compute), the way the timed region runs it."""
+        if self.graph is not None:
+            if self.use_dist:
+                self.exchange_forward()
+            self.graph.replay()
+            if self.use_dist:
+                self.exchange_backward()
+        else:
+            self.reset_grads()
+            self.step_body()
+
+    def time_steps(self, steps, warmup):
+        for _ in range(warmup):
+            self.run()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.run()
+        self.barrier()
+        return time.perf_counter() - t0
+
+
+def self_launch(args):
+    """--gpus G > 1 without a launcher: start torch.distributed.run as a CHILD process (this parent never touches
+    the GPU), one rank per GPU, and hand its exit code back.  Rank 0 of the child writes the JSON line to the
+    inherited stdout."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] launching: ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def median(xs):
+    xs = sorted(xs)
+    return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--agents', type=int, default=4096, help='focal agents per GPU')
+    ap.add_argument('--scaling', choices=('auto', 'strong', 'weak'), default='auto',
+                    help='auto: one GPU = cfg3 (--agents agents); several GPUs = strong scaling of ONE --scene-agents '
+                         'scene (cfg4).  weak: --agents focal agents per GPU')
+    ap.add_argument('--agents', type=int, default=4096, help='focal agents per GPU (one GPU, or --scaling weak)')
+    ap.add_argument('--scene-agents', type=int, default=16384, help='agents of the whole scene under strong scaling')
     ap.add_argument('--obstacles', type=int, default=2000)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the cpu_baseline leg')
@@ -190,18 +387,29 @@ def main():
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
+    ap.add_argument('--strong-baseline', type=int, default=1,
+                    help='strong scaling on several GPUs: rank 0 also times the whole scene on one GPU (outside the timed region)')
     ap.add_argument('--tunableop', type=int, default=1,
                     help='1: load the pre-tuned GEMM selections for the MLP (tuned in-process if this stack rejects the file); '
                          '0: library defaults; 2: re-tune and write --tune-out; 3: force the in-process tuning')
     ap.add_argument('--tune-out', type=str, default='gpurun_out/tunableop_retuned.csv', help='result file of --tunableop 2')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+
+    # stdout must carry exactly ONE JSON line: anything libraries print to fd 1 (e.g. RCCL's version
+    # banner) is sent to stderr, and the result is written to the saved stdout at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run '
-                         f'--nproc-per-node {args.gpus}')
+                         f'--nproc-per-node {args.gpus} (or unset WORLD_SIZE: bench.py launches itself)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or bool(args.force_dist)
@@ -209,6 +417,16 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    scaling = args.scaling if args.scaling != 'auto' else ('strong' if world > 1 else 'weak')
+    if scaling == 'strong':
+        if args.scene_agents % world:
+            raise SystemExit(f'--scene-agents {args.scene_agents} must be divisible by the number of GPUs {world}')
+        N, n_own = args.scene_agents, args.scene_agents // world
+    else:
+        N, n_own = args.agents * world, args.agents
+    M = args.obstacles
+    cfg3_shapes = n_own == 4096        # the row counts the committed GEMM selections were tuned (and validated) for
 
     # PyTorch-ROCm TunableOp: pick the rocBLAS / hipBLASLt solution per GEMM shape of the PINNSF
     # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
@@ -222,7 +440,7 @@ def main():
     else:
         gemm_tuning = 'tunableop-file' if (args.tunableop == 1 and tuning.load()) else 'default'
     autotune = False
-    if args.tunableop == 3 or (args.tunableop == 1 and gemm_tuning == 'default'):
+    if cfg3_shapes and (args.tunableop == 3 or (args.tunableop == 1 and gemm_tuning == 'default')):
         # the committed selections belong to another software stack (or --tunableop 3 asks for it): tune the
         # step's GEMM shapes right here (a few seconds, two eager steps below) and keep ONE stream -- only the
         # committed selections are validated for running two library GEMMs concurrently
@@ -232,219 +450,86 @@ def main():
         autotune, gemm_tuning = True, 'autotuned'
 
     _phase('tunableop setup done')
-    from piml_amd import ops, _lib
-    from piml_amd.models.model import PINNSF_multitask
+    from piml_amd import _lib
     from piml_amd.scenes import synthetic_gc_scene
-    from piml_amd.sharded import ShardedScene, allreduce_gradients, gather_records_into, unflatten_gradients
 
-    n_own, M = args.agents, args.obstacles
-    N = n_own * world
     scene = synthetic_gc_scene(N, M, seed=args.seed)
-    obstacles = torch.tensor(scene['obstacles'], device=dev)
-    M_eff = obstacles.shape[0]
-    sh = ShardedScene(N, obstacles) if use_dist else None
-    b0 = rank * n_own
-    rows = slice(b0, b0 + n_own)
-    state_own = torch.tensor(np.concatenate([scene[k][rows] for k in ('position', 'velocity', 'acceleration')],
-                                            axis=-1), device=dev).requires_grad_(True)
-    dest_own = torch.tensor(scene['destination'][rows], device=dev)
-    v0_own = torch.tensor(scene['desired_speed'][rows], device=dev)
-
-    torch.manual_seed(666)
-    model = PINNSF_multitask(model_args()).to(dev).eval()   # eval: dropout off, deterministic
     # The obstacle branch of the MLP on a side stream makes two GEMM chains run concurrently inside the
-    # captured graph (+20 %).  Concurrent library GEMMs are only safe with kernels that never wait for
-    # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some of these shapes
+    # captured graph.  Concurrent library GEMMs are only safe with kernels that never wait for
+    # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some shapes
     # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
-    # pre-tuned selections are validated for this; without them the branches stay on one stream.
-    # (multi-rank runs: the collectives are issued outside the captured graph, so the graph holds the
-    # same kernels as on one GPU and the same rule applies)
-    two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file') or args.two_streams == 2
-    if two_streams:
-        model.obs_stream = torch.cuda.Stream()
-    params = [p for p in model.parameters()]
-    ones = torch.ones(n_own, 2, device=dev)
-
-    def features():
-        """all-gather of the owners' records (N > 1) + relfeat forward (HIP)."""
-        state_full = sh.gather_state(state_own) if sh is not None else state_own
-        return ops.relative_features_packed_self(state_full, dest_own, obstacles, v0_own, b0, n_own,
-                                                 return_index=True)
-
-    def rest(pf, of, self_features, *_idx):
-        """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
-        acc = model(pf, of, self_features)[0]
-        acc.backward(ones)
-        if sh is not None:
-            allreduce_gradients(params, sh.group)
-        return acc
-
-    # Sharded + graph: only the COMPUTE of a step is captured; the two collectives (all-gather of the
-    # records before it; ONE all-reduce of [d/d(state), weight gradients] after it) are issued eagerly on
-    # the stream either side of the replay.  `state_all` is the graph's static input: the all-gather
-    # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
-    state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
-    grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
-
-    def features_local():
-        return ops.relative_features_packed_self(state_all, dest_own, obstacles, v0_own, b0, n_own,
-                                                 return_index=True)
-
-    def rest_local(pf, of, self_features, *_idx):
-        acc = model(pf, of, self_features)[0]
-        acc.backward(ones)
-        # captured: ONE concatenation of the (N, 6) state gradient and all weight gradients into a static
-        # bucket, so that the backward exchange is a single latency-bound all-reduce (1.3 MB at 8 GPUs)
-        grads = [p.grad for p in params if p.grad is not None]
-        bucket[:] = [torch.cat([state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
-        return acc
-
-    bucket = [None, None]
-
-    def exchange_forward():
-        gather_records_into(state_all, state_own, sh.group)
-
-    def exchange_backward():
-        dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=sh.group)
-        grad_own.copy_(bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
-        unflatten_gradients(bucket[0][N * 6:], bucket[1])
-
-    def step_body(timer=None):
-        """One forward + backward pass of the hot path over the scene."""
-        if timer is not None:
-            timer.start()
-        feats = features()
-        if timer is not None:
-            timer.stop()
-        return rest(*feats)
-
-    def reset_grads():
-        state_own.grad = None
-        if state_all is not None:
-            state_all.grad = None
-        for p in params:
-            p.grad = None
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # pre-tuned selections are validated for the cfg3 row counts only; otherwise the branches stay on one stream.
+    two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and cfg3_shapes) or args.two_streams == 2
+    st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
+              two_streams, bool(args.graph))
+    M_eff = st.M_eff
 
     if autotune:
         for _ in range(2):
-            reset_grads()
-            step_body()
+            st.reset_grads()
+            st.step_body()
         torch.cuda.synchronize()
         torch.cuda.tunable.tuning_enable(False)
-        reset_grads()
+        st.reset_grads()
     _phase('scene + model on device')
-    # ---- whole-step HIP graph (removes ~60 per-kernel launch gaps); eager fallback ----
-    graph, g_timer, static_feats = None, None, None
-    mode = 'eager'
-    if args.graph:
-        ok = 1
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    reset_grads()
-                    step_body()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            reset_grads()
-            # ONE graph holds the step's compute (relfeat forward ... relfeat backward).  ROCm cannot record
-            # events inside a captured graph, so the HIP events that time the relfeat kernel bracket an
-            # extra eager launch of it (same inputs, same output buffers) in front of sampled replays.
-            g_timer = _lib.StreamTimer()
-            graph = torch.cuda.CUDAGraph()
-            if use_dist:
-                exchange_forward()
-                torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                feats = features_local() if use_dist else features()
-                (rest_local if use_dist else rest)(*feats)
-            static_feats = feats     # the captured step's feature / index buffers stay alive
-            graph.replay()
-            if use_dist:
-                exchange_backward()
-            done = torch.cuda.Event()
-            done.record()
-            t_wait = time.perf_counter()
-            while not done.query():       # watchdog: a replay that never completes must not hang the run
-                if time.perf_counter() - t_wait > 30.0:
-                    print('[bench] FATAL: captured step did not complete within 30 s (deadlocked kernels); '
-                          're-run with --graph 0 or --two-streams 0', file=sys.stderr, flush=True)
-                    os._exit(3)
-                time.sleep(0.001)
-            torch.cuda.synchronize()
-        except Exception as ex:   # noqa: BLE001 - any capture problem means: run eagerly
-            print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
-                  file=sys.stderr)
-            ok, graph = 0, None
-        if use_dist:   # all ranks must run the same mode
-            t = torch.tensor([ok], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 0:
-                graph = None
-        mode = 'hipgraph' if graph is not None else 'eager'
-
+    st.capture()
+    mode, graph = st.mode, st.graph
     _phase(f'capture done, mode={mode}')
+
     kernel_ms_samples, overhead_ms_samples = [], []
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # up to 5 samples; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
+    # 5 samples whatever --steps is; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
     # that the cost of the two event records (4-7 us, measured by an empty pair) is a small correction.  The
     # events are only READ after the timed region (reading one synchronises the stream): a sample costs the
-    # timed region its extra launches and nothing else.
-    TIMED_LAUNCHES = 4
-    n_samples = max(1, min(5, args.steps // 20))       # 5 launches each: keep their share of a short run small
-    sample_every = -(-args.steps // n_samples)
+    # timed region its extra launches (3 x ~23 us) and nothing else.
+    TIMED_LAUNCHES = 2
+    n_samples = max(1, min(5, args.steps))
+    sample_at = {round(i * args.steps / n_samples) for i in range(n_samples)}
 
     def run_step(i, timed):
         if graph is not None:
-            sample = timed and i % sample_every == 0
+            sample = timed and i in sample_at
             if use_dist:
-                exchange_forward()
+                st.exchange_forward()
             if sample:
-                # the timed launch runs behind an identical launch, so the interval holds one kernel
+                # the timed launches run behind an identical launch, so the interval holds kernels
                 # behind another kernel rather than the idle gap that follows the previous replay
-                src = state_all if use_dist else state_own
-                ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
+                st.relaunch_relfeat()
                 tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
                 tk.start()
                 for _ in range(TIMED_LAUNCHES):
-                    ops.relative_features_packed_into(static_feats, src, dest_own, obstacles, b0, n_own)
+                    st.relaunch_relfeat()
                 tk.stop()
             graph.replay()
             if use_dist:
-                exchange_backward()
+                st.exchange_backward()
             if sample:
                 # calibration: an empty start/stop pair right behind the step measures what the two
                 # event records themselves add to an interval on this stream
                 tc.start(); tc.stop()
                 sample_timers.append((tk, tc))
         else:
-            reset_grads()
+            st.reset_grads()
             if timed:
                 tm = _lib.StreamTimer()
-                step_body(tm)
+                st.step_body(tm)
                 ev_pairs.append(tm)
-                if i % sample_every == 0:
+                if i in sample_at:
                     cal_timer.start(); cal_timer.stop()
                     torch.cuda.current_stream().synchronize()
                     overhead_ms_samples.append(cal_timer.elapsed_ms())
             else:
-                step_body()
+                st.step_body()
 
     for i in range(args.warmup):
         run_step(i, False)
-    barrier()
+    st.barrier()
     _phase('warmup done')
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_step(i, True)
-    barrier()
+    st.barrier()
     elapsed = time.perf_counter() - t0
     _phase('timed region done')
     if use_dist:
@@ -457,23 +542,20 @@ def main():
     # reduce-scatter of piml_amd.sharded), i.e. no work was skipped or mis-wired by the capture ----
     verify_err = None
     if graph is not None and args.verify:
-        if use_dist:
-            got_state = grad_own.clone()
-        else:
-            got_state = state_own.grad.clone()
-        got_params = [None if p.grad is None else p.grad.clone() for p in params]
-        reset_grads()
+        got_state = (st.grad_own if use_dist else st.state_own.grad).clone()
+        got_params = [None if p.grad is None else p.grad.clone() for p in st.params]
+        st.reset_grads()
         if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
             # the warm-up steps ran on a side stream, this one runs on the default stream: intended
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        step_body()
+        st.step_body()
         torch.cuda.synchronize()
 
         def rel(a, b):
             a, b = torch.nan_to_num(a), torch.nan_to_num(b)
             return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-        verify_err = rel(got_state, state_own.grad)
-        for g, p in zip(got_params, params):
+        verify_err = rel(got_state, st.state_own.grad)
+        for g, p in zip(got_params, st.params):
             if (g is None) != (p.grad is None):
                 verify_err = float('inf')
             elif g is not None:
@@ -493,17 +575,35 @@ def main():
     else:
         kernel_ms_samples = [tk.elapsed_ms() for tk, _ in sample_timers]
         overhead_ms_samples = [tc.elapsed_ms() for _, tc in sample_timers]
-    def median(xs):
-        xs = sorted(xs)
-        return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
     # median over the sampled launches: robust against the occasional preempted / cold sample
     launches_per_sample = TIMED_LAUNCHES if graph is not None else 1
     raw_ms = median(kernel_ms_samples)                 # interval around `launches_per_sample` launches
     overhead_ms = median(overhead_ms_samples)
     kernel_ms = max(raw_ms - overhead_ms, 1e-6) / launches_per_sample
     pairs_step = N * (N + M_eff)                       # all ranks together
-    alg_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own   # this rank's launch
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    ms_per_step = elapsed / args.steps * 1e3
+    # SURVEY.md 8d, the contract figure: operand-stream bytes of ONE step over all ranks (24 B per ped-ped
+    # pair, 8 B per ped-obstacle pair, 488 B per focal agent) / step time / (HBM peak x GPUs)
+    bytes_step = N * (24 * N + 8 * M_eff) + 488 * N
+    achieved = bytes_step / (ms_per_step * 1e-3) / 1e9 / world        # GB/s per GPU
+    kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
+
+    # ---- strong scaling: the same scene on ONE GPU (rank 0, the others wait), outside the timed region ----
+    same_scene_1gpu = None
+    if world > 1 and scaling == 'strong' and args.strong_baseline:
+        if rank == 0:
+            try:
+                one = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph))
+                one.capture()
+                k = max(10, min(args.steps, 50))
+                el1 = one.time_steps(k, 5)
+                same_scene_1gpu = {'ms_per_step': el1 / k * 1e3, 'steps': k, 'launch_mode': one.mode,
+                                   'note': 'the whole scene on one GPU of this node (rank 0, after the timed region): '
+                                           'strong-scaling efficiency = this / (n_gpus x ms_per_step)'}
+                del one
+            except Exception as ex:   # noqa: BLE001 - informational
+                same_scene_1gpu = {'error': f'{type(ex).__name__}: {ex}'}
+        st.barrier()
 
     # ---- secondary figures, measured after (outside) the timed region, rank 0 only ----
     secondary = None
@@ -513,40 +613,54 @@ def main():
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
 
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_relfeat_traffic.json')
-    if world == 1 and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get('config', {}).get('agents_total') == N and tj['config'].get('obstacle_points') == M_eff:
-            traffic = tj['relfeat_fwd_kernel']['hbm_bytes_per_launch']
+    prof = None
+    ppath = os.path.join(ROOT, 'profiles', 'r02_step_counters.json')
+    if world == 1 and os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
+            prof = pj
 
     if rank == 0:
+        kernels = [{'name': 'relfeat_fwd_kernel', 'us': kernel_ms * 1e3, 'share_of_step': kernel_ms / ms_per_step,
+                    'bound': 'valu', 'frac': (prof or {}).get('relfeat_fwd_kernel', {}).get('valu_busy_frac'),
+                    'hbm_bytes': (prof or {}).get('relfeat_fwd_kernel', {}).get('hbm_bytes_per_launch'),
+                    'operand_stream_bytes': kernel_bytes,
+                    'timing': f'HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
+                              f'{launches_per_sample} launches, median, event-pair overhead subtracted',
+                    'event_interval_us': raw_ms * 1e3, 'event_pair_overhead_us': overhead_ms * 1e3,
+                    'frac_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r02_step_counters.json '
+                                   '(rocprofv3 --pmc, separate pass)' if prof else None}]
+        for k in (prof or {}).get('other_kernels', []):
+            kernels.append(k)
         out = {
             'metric': 'agent-pair force evals/sec + simulated steps/sec, 4096-agent GC scene',
             'value': pairs_step * args.steps / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'steps_per_s': args.steps / elapsed,
+            'ms_per_step': ms_per_step, 'steps_per_s': args.steps / elapsed,
             'agent_steps_per_s': N * args.steps / elapsed,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err, 'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
-            'config': {'workload': 'cfg3: synthetic GC scene, forward+backward PINSF step '
-                                   '(HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd in PyTorch-ROCm)',
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
+            'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
+            'config': {'workload': ('cfg3: synthetic 4096-agent GC scene' if (world == 1 and N == 4096) else
+                                    f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
+                                    f'synthetic {N}-agent GC scene ({n_own} focal agents per GPU)') +
+                                   ', forward+backward PINSF step (HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd)',
                        'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
                        'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
                        'sharding': 'single GPU' if not use_dist else
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
-            'roofline': {'bound': 'hbm', 'kernel': 'relfeat_fwd_kernel', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel_us': kernel_ms * 1e3, 'event_interval_us': raw_ms * 1e3,
-                         'event_pair_overhead_us': overhead_ms * 1e3, 'kernel_samples': len(kernel_ms_samples),
-                         'launches_per_sample': launches_per_sample,
-                         'algorithmic_bytes': alg_bytes,
-                         'traffic_source': 'profiles/r01_relfeat_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)' if traffic else None,
-                         'interval_includes_allgather': bool(use_dist) and graph is None,
-                         'note': 'operand-stream byte model (24 B/ped pair + 8 B/obstacle pair + 488 B/focal); '
-                                 'the sources are LDS/L2 resident, so frac > 1 is possible and HBM traffic '
-                                 'is far below the model (see DESIGN.md)'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': (prof or {}).get('step_hbm_bytes'),
+                         'algorithmic_bytes': bytes_step,
+                         'definition': 'SURVEY.md 8d step-level contract: operand-stream bytes of one step (24 B/ped pair + '
+                                       '8 B/obstacle pair + 488 B/focal agent) / ms_per_step / (n_gpus x HBM peak); the sources '
+                                       'are LDS/L2 resident, so real HBM traffic (`traffic`, PMC) is far below this model and '
+                                       'the step is bound by the MLP (f32 MFMA) and VALU issue, see `kernels`',
+                         'kernels': kernels},
         }
+        if same_scene_1gpu is not None:
+            out['single_gpu_same_scene'] = same_scene_1gpu
         if secondary is not None:
             out['secondary'] = secondary
         if args.cpu_seconds > 0 and world == 1:

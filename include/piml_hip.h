@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 7
+#define PIML_HIP_ABI_VERSION 8
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -347,6 +347,47 @@ int piml_timer_destroy(void* event);
  */
 int piml_probe_arith(const float* rx, const float* ry, const float* hx, const float* hy,
                      float* dist, float* cosv, int n, void* stream);
+
+/*
+ * Fused PINNSF encoder on the f32 matrix cores (piml_amd/csrc/encoder.hip): the reference's
+ *   ped_encoder / obs_encoder = MLP(in, [128, 128, 128]) (src/models/model.py:40-65, built at :1232-1236),
+ *   the processor in its effective form `scale * x` (ResDNN with >= 2 "layers" and inactive dropout, :82-119,
+ *   SURVEY quirk Q3) and the neighbour-axis sum (:1279-1283),
+ * i.e. msgs = scale * (W3 relu(W2 relu(W1 x + b1) + b2) + b3) for every neighbour row and pooled = sum over the k
+ * rows of an agent.  Weights use the nn.Linear layout (out, in), row-major.  Up to two encoders (pedestrian and
+ * obstacle branch) run in ONE launch, workgroups split in proportion to their rows.
+ *
+ * fwd:  x (rows, in_dim <= 8) -> msgs (rows, 128); h1 / h2 (rows, 128): post-ReLU activations of layers 1 / 2,
+ *       saved for the backward (NULL for inference).  pooled comes from piml_encoder_ksum.
+ * bwd:  upstream g_pooled (rows / k, 128) and / or g_msgs (rows, 128) (one may be NULL)
+ *       -> g2, g1 (rows, 128): caller-provided scratch, the gradients at the pre-activations of layers 2 and 1;
+ *          g_x (rows, in_dim) or NULL when the inputs need no gradient;
+ *          partials: piml_encoder_workgroups() slots of piml_encoder_partial_floats() floats for THIS branch, slot p
+ *          = [dW3 128x128 | dW2 128x128 | dW1 128x8 (columns >= in_dim are 0) | db3 | db2 | db1] of workgroup p's
+ *          row slab; sum the slots with piml_sum_leading.  (Every slot of the branch is written.)
+ */
+typedef struct piml_encoder_branch {
+    const float* x;
+    long long rows;
+    int in_dim;
+    int k;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    float scale;
+    float *h1, *h2, *msgs;
+    const float *g_pooled, *g_msgs;
+    float *g2, *g1, *g_x;
+    float* partials;
+} piml_encoder_branch;
+
+/* floats of one partial slot */
+int piml_encoder_partial_floats(void);
+/* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve
+ * branch 1): the number of partial slots each branch's `partials` must hold. */
+int piml_encoder_workgroups(const piml_encoder_branch* branches, int nbranches, int* wg_branch0);
+int piml_encoder_fwd(const piml_encoder_branch* branches, int nbranches, void* stream);
+int piml_encoder_bwd(const piml_encoder_branch* branches, int nbranches, void* stream);
+/* pooled (agents, 128) = sum over k consecutive rows of msgs (agents * k, 128) */
+int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,11 +10,21 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
 _i, _f, _p, _z = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+_ll = ctypes.c_longlong
+
+
+class EncoderBranch(ctypes.Structure):
+    """piml_encoder_branch (include/piml_hip.h)."""
+    _fields_ = [('x', _p), ('rows', _ll), ('in_dim', _i), ('k', _i),
+                ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
+                ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
+                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p)]
+
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -54,6 +64,11 @@ SIGNATURES = {
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],
     'piml_timer_destroy': [_p],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
+    'piml_encoder_partial_floats': [],
+    'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
+    'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],
+    'piml_encoder_bwd': [ctypes.POINTER(EncoderBranch), _i, _p],
+    'piml_encoder_ksum': [_p, _ll, _i, _p, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 

@@ -1,0 +1,541 @@
+// Fused PINNSF encoder on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 = an fmaf chain).
+//
+// Reference arithmetic: src/models/model.py:40-65 (MLP = Linear/ReLU chain), :1271-1283 (ped/obs encoder ->
+// processor -> sum over the k neighbours; with >= 2 processor "layers" the processor is 2 * x).
+// One encoder = Linear(in<=8 -> 128) ReLU Linear(128 -> 128) ReLU Linear(128 -> 128), applied to the (agents*k)
+// neighbour rows; msgs = scale * output.  These three layers are 97 % of the network's FLOPs
+// (2 * 65 536 rows * 33.5 k MAC at the 4096-agent scene), run until round 1 as nine library GEMMs + glue passes.
+//
+// Formulation (everything is the TRANSPOSED product, features on the MFMA's M axis, data rows on its N axis):
+//     D[f_out][row] = sum_f W[f_out][f] * act[row][f]          A = weights, B = activations^T
+// A 32x32 accumulator then holds, in lane (row j = lane & 31, half h = lane >> 5), register r, the feature
+// f(r, h) = (r & 3) + 8 (r >> 2) + 4 h of row j -- and that register IS the B operand of the next layer's MFMA
+// (B[k][j]: k = h), provided the A operand carries the weights of the matching input features:
+//     A-fragment (blk, bp, q, u): lane (i, h) = W[32 blk + i][32 bp + 8 q + 4 h + u].
+// So activations never leave the registers between layers (no LDS round trip, no barrier); the weights are staged
+// once per workgroup into LDS as ready-made A-fragments (one ds_read_b128 = the fragments of 4 k-steps) and a wave
+// streams them past its 32-row tile.  Bias rides in as the accumulator's initial value, ReLU is a v_max.
+// Backward: enc_bwd_dx runs the same chain with W^T (g_h = W^T g_pre, masked by the saved activations) and leaves
+// the pre-activation gradients g2, g1 in HBM; enc_bwd_dw is the split-K product dW = G^T H over row slabs
+// (A = G^T read straight from row-major G, B = H), per-workgroup partials, one piml_sum_leading over them.
+#include "common.hpp"
+#include "../../include/piml_hip.h"
+
+namespace piml {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EH = 128;                 // hidden width
+constexpr int ENC_THREADS = 512;        // 8 waves per workgroup: 2 per SIMD
+constexpr int ENC_WAVES = ENC_THREADS / 64;
+constexpr int ENC_PART = 2 * EH * EH + EH * 8 + 3 * EH;      // floats of one workgroup's dW / db partial
+
+struct EncArgs {
+    piml_encoder_branch br[2];
+    int nbr;
+    int wg_split;       // workgroups [0, wg_split) serve branch 0, the rest branch 1
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// LDS image of a 128 x 128 nn.Linear weight (out, in) as A-fragments, float4 index ((blk*4 + bp)*4 + q)*64 + lane:
+//   forward  (TR = false): [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
+//   backward (TR = true):  [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]   (A = W^T: in block blk, out block bp)
+template <bool TR>
+__device__ __forceinline__ void stage_w128(float4* dst, const float* __restrict__ W, int tid) {
+    for (int e = tid; e < 4 * 4 * 4 * 64; e += ENC_THREADS) {
+        const int lane = e & 63, q = (e >> 6) & 3, bp = (e >> 8) & 3, blk = e >> 10;
+        const int i = lane & 31, h = lane >> 5;
+        const int c0 = 32 * bp + 8 * q + 4 * h;
+        float4 v;
+        if (!TR) {
+            v = *reinterpret_cast<const float4*>(W + (size_t)(32 * blk + i) * EH + c0);
+        } else {
+            const float* p = W + (size_t)c0 * EH + 32 * blk + i;
+            v = make_float4(p[0], p[EH], p[2 * EH], p[3 * EH]);
+        }
+        dst[e] = v;
+    }
+}
+
+// features (4 consecutive) held by accumulator registers 4q .. 4q+3 of block blk in lane half h
+__device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 8 * q + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+// LDS (floats): W2 fragments 16384 | W3 fragments 16384 | W1 fragments [blk 4][s 4][lane 64] 1024 | b1 b2 b3 384
+constexpr int FWD_LDS_FLOATS = 16384 * 2 + 1024 + 384;
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+
+    float4* W2f = reinterpret_cast<float4*>(lds);
+    float4* W3f = reinterpret_cast<float4*>(lds + 16384);
+    float* W1f = lds + 32768;
+    float* bias = lds + 32768 + 1024;
+    stage_w128<false>(W2f, J.w2, tid);
+    stage_w128<false>(W3f, J.w3, tid);
+    for (int e = tid; e < 1024; e += ENC_THREADS) {
+        const int l = e & 63, s = (e >> 6) & 3, blk = e >> 8;
+        const int c = 2 * s + (l >> 5);
+        W1f[e] = c < IN ? J.w1[(size_t)(32 * blk + (l & 31)) * IN + c] : 0.f;
+    }
+    for (int e = tid; e < 384; e += ENC_THREADS)
+        bias[e] = e < 128 ? J.b1[e] : (e < 256 ? J.b2[e - 128] : J.b3[e - 256]);
+    __syncthreads();
+
+    const int j = lane & 31, h = lane >> 5;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = 2 * s + h;
+            xb[s] = (valid && c < IN) ? J.x[row * IN + c] : 0.f;
+        }
+        f32x16 a1[4], a2[4];
+        // ---- layer 1: K = in_dim (padded to 8) ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + feat0(blk, q, h));
+                a1[blk][4 * q + 0] = bq.x; a1[blk][4 * q + 1] = bq.y; a1[blk][4 * q + 2] = bq.z; a1[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a1[blk] = mfma32(W1f[(blk * 4 + s) * 64 + lane], xb[s], a1[blk]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[blk][r] = fmaxf(a1[blk][r], 0.f);
+        }
+        if (J.h1 && valid) {
+            float* o = J.h1 + row * EH;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
+                        make_float4(a1[blk][4 * q], a1[blk][4 * q + 1], a1[blk][4 * q + 2], a1[blk][4 * q + 3]);
+        }
+        // ---- layer 2 ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 128 + feat0(blk, q, h));
+                a2[blk][4 * q + 0] = bq.x; a2[blk][4 * q + 1] = bq.y; a2[blk][4 * q + 2] = bq.z; a2[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = W2f[((blk * 4 + bp) * 4 + q) * 64 + lane];
+                    a2[blk] = mfma32(w.x, a1[bp][4 * q + 0], a2[blk]);
+                    a2[blk] = mfma32(w.y, a1[bp][4 * q + 1], a2[blk]);
+                    a2[blk] = mfma32(w.z, a1[bp][4 * q + 2], a2[blk]);
+                    a2[blk] = mfma32(w.w, a1[bp][4 * q + 3], a2[blk]);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[blk][r] = fmaxf(a2[blk][r], 0.f);
+        }
+        if (J.h2 && valid) {
+            float* o = J.h2 + row * EH;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
+                        make_float4(a2[blk][4 * q], a2[blk][4 * q + 1], a2[blk][4 * q + 2], a2[blk][4 * q + 3]);
+        }
+        // ---- layer 3 (no activation), msgs = scale * output; a1 is dead and reused ----
+        const float scale = J.scale;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 256 + feat0(blk, q, h));
+                a1[blk][4 * q + 0] = bq.x; a1[blk][4 * q + 1] = bq.y; a1[blk][4 * q + 2] = bq.z; a1[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = W3f[((blk * 4 + bp) * 4 + q) * 64 + lane];
+                    a1[blk] = mfma32(w.x, a2[bp][4 * q + 0], a1[blk]);
+                    a1[blk] = mfma32(w.y, a2[bp][4 * q + 1], a1[blk]);
+                    a1[blk] = mfma32(w.z, a2[bp][4 * q + 2], a1[blk]);
+                    a1[blk] = mfma32(w.w, a2[bp][4 * q + 3], a1[blk]);
+                }
+            if (valid) {
+                float* o = J.msgs + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
+                        make_float4(scale * a1[blk][4 * q], scale * a1[blk][4 * q + 1], scale * a1[blk][4 * q + 2],
+                                    scale * a1[blk][4 * q + 3]);
+            }
+        }
+    }
+}
+
+// pooled[a][c] = sum over the k rows of agent a of msgs (src/models/model.py:1283 `.sum(dim=-2)`), float4 per thread
+__global__ __launch_bounds__(256) void enc_ksum_kernel(const float4* __restrict__ msgs, long long agents, int k,
+                                                       float4* __restrict__ pooled) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= agents * (EH / 4)) return;
+    const long long a = t / (EH / 4);
+    const int c = (int)(t % (EH / 4));
+    const float4* p = msgs + a * k * (EH / 4) + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < k; ++i) {
+        const float4 v = p[(size_t)i * (EH / 4)];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    pooled[t] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, part 1: the dX chain.  g3[row] = scale * (g_pooled[row / k] + g_msgs[row]) (either may be absent);
+// g_h2 = W3^T g3, g2 = g_h2 * [h2 > 0] (stored); g_h1 = W2^T g2, g1 = g_h1 * [h1 > 0] (stored); g_x = W1^T g1.
+// ---------------------------------------------------------------------------------------------------------
+// LDS (floats): W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments [bp 4][q 4][lane 64] float4 = 4096
+constexpr int DX_LDS_FLOATS = 16384 * 2 + 4096;
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim, K = J.k;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;
+
+    float4* W3t = reinterpret_cast<float4*>(lds);
+    float4* W2t = reinterpret_cast<float4*>(lds + 16384);
+    float4* W1t = reinterpret_cast<float4*>(lds + 32768);
+    stage_w128<true>(W3t, J.w3, tid);
+    stage_w128<true>(W2t, J.w2, tid);
+    const bool want_gx = J.g_x != nullptr;
+    if (want_gx)
+        for (int e = tid; e < 16 * 64; e += ENC_THREADS) {
+            const int l = e & 63, q = (e >> 6) & 3, bp = e >> 8;
+            const int i = l & 31, c0 = 32 * bp + 8 * q + 4 * (l >> 5);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < IN) v = make_float4(J.w1[(size_t)c0 * IN + i], J.w1[(size_t)(c0 + 1) * IN + i],
+                                        J.w1[(size_t)(c0 + 2) * IN + i], J.w1[(size_t)(c0 + 3) * IN + i]);
+            W1t[e] = v;
+        }
+    __syncthreads();
+
+    const int j = lane & 31, h = lane >> 5;
+    const float scale = J.scale;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        f32x16 g[4], d[4];
+        // ---- g3 in registers ----
+        {
+            const float* gp = (J.g_pooled && valid) ? J.g_pooled + (row / K) * EH : nullptr;
+            const float* gm = (J.g_msgs && valid) ? J.g_msgs + row * EH : nullptr;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gp) v = *reinterpret_cast<const float4*>(gp + feat0(blk, q, h));
+                    if (gm) {
+                        const float4 m = *reinterpret_cast<const float4*>(gm + feat0(blk, q, h));
+                        v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+                    }
+                    g[blk][4 * q + 0] = scale * v.x; g[blk][4 * q + 1] = scale * v.y;
+                    g[blk][4 * q + 2] = scale * v.z; g[blk][4 * q + 3] = scale * v.w;
+                }
+        }
+        // ---- g_h2 = W3^T g3, masked by h2 -> g2 ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[blk][r] = 0.f;
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = W3t[((blk * 4 + bp) * 4 + q) * 64 + lane];
+                    d[blk] = mfma32(w.x, g[bp][4 * q + 0], d[blk]);
+                    d[blk] = mfma32(w.y, g[bp][4 * q + 1], d[blk]);
+                    d[blk] = mfma32(w.z, g[bp][4 * q + 2], d[blk]);
+                    d[blk] = mfma32(w.w, g[bp][4 * q + 3], d[blk]);
+                }
+            if (valid) {
+                const float* hp = J.h2 + row * EH;
+                float* o = J.g2 + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+                    d[blk][4 * q + 0] = a.x > 0.f ? d[blk][4 * q + 0] : 0.f;
+                    d[blk][4 * q + 1] = a.y > 0.f ? d[blk][4 * q + 1] : 0.f;
+                    d[blk][4 * q + 2] = a.z > 0.f ? d[blk][4 * q + 2] : 0.f;
+                    d[blk][4 * q + 3] = a.w > 0.f ? d[blk][4 * q + 3] : 0.f;
+                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
+                        make_float4(d[blk][4 * q], d[blk][4 * q + 1], d[blk][4 * q + 2], d[blk][4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[blk][r] = 0.f;
+            }
+        }
+        // ---- g_h1 = W2^T g2, masked by h1 -> g1 (g is dead and reused) ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[blk][r] = 0.f;
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = W2t[((blk * 4 + bp) * 4 + q) * 64 + lane];
+                    g[blk] = mfma32(w.x, d[bp][4 * q + 0], g[blk]);
+                    g[blk] = mfma32(w.y, d[bp][4 * q + 1], g[blk]);
+                    g[blk] = mfma32(w.z, d[bp][4 * q + 2], g[blk]);
+                    g[blk] = mfma32(w.w, d[bp][4 * q + 3], g[blk]);
+                }
+            if (valid) {
+                const float* hp = J.h1 + row * EH;
+                float* o = J.g1 + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+                    g[blk][4 * q + 0] = a.x > 0.f ? g[blk][4 * q + 0] : 0.f;
+                    g[blk][4 * q + 1] = a.y > 0.f ? g[blk][4 * q + 1] : 0.f;
+                    g[blk][4 * q + 2] = a.z > 0.f ? g[blk][4 * q + 2] : 0.f;
+                    g[blk][4 * q + 3] = a.w > 0.f ? g[blk][4 * q + 3] : 0.f;
+                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
+                        make_float4(g[blk][4 * q], g[blk][4 * q + 1], g[blk][4 * q + 2], g[blk][4 * q + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[blk][r] = 0.f;
+            }
+        }
+        // ---- g_x = W1^T g1: one M block (input features padded to 32) ----
+        if (want_gx) {
+            f32x16 gx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = W1t[(bp * 4 + q) * 64 + lane];
+                    gx = mfma32(w.x, g[bp][4 * q + 0], gx);
+                    gx = mfma32(w.y, g[bp][4 * q + 1], gx);
+                    gx = mfma32(w.z, g[bp][4 * q + 2], gx);
+                    gx = mfma32(w.w, g[bp][4 * q + 3], gx);
+                }
+            if (valid) {       // register r of half h holds input feature r + 4 h (r < 4)
+                float* o = J.g_x + row * IN;
+                const float v[4] = {gx[0], gx[1], gx[2], gx[3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r + 4 * h < IN) o[r + 4 * h] = v[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, part 2: weight gradients as split-K products over a workgroup's row slab (K = rows).
+//   dW3[f3][f2] = sum_rows g3[row][f3] h2[row][f2],  dW2 = g2^T h1,  dW1 = g1^T x,  db_l = column sums of g_l.
+// Wave w: M block mb = w & 3 (32 rows of dW), N half nh = w >> 2 (64 columns), every row of the slab.
+// A: lane (i, h) = G[row 2 s + h][32 mb + i] (128-B coalesced, straight from row-major G);
+// B: lane (n, h) = H[row 2 s + h][64 nh + 2 n + {0, 1}] (float2), so accumulator u holds dW[..][64 nh + 2 n + u].
+// Partial of workgroup p (floats): dW3 16384 | dW2 16384 | dW1 128 x 8 | db3 | db2 | db1.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const int p = (int)blockIdx.x - wg0;
+    const long long R = J.rows;
+    const int IN = J.in_dim, K = J.k;
+    long long slab = (R + nwg - 1) / nwg;
+    slab = (slab + 1) & ~1ll;
+    const long long r0 = (long long)p * slab;
+    const long long r1 = r0 + slab < R ? r0 + slab : R;
+    const int mb = wave & 3, nh = wave >> 2;
+    const int i = lane & 31, h = lane >> 5;
+    const float scale = J.scale;
+
+    f32x16 c3[2], c2[2], c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c3[0][r] = 0.f; c3[1][r] = 0.f; c2[0][r] = 0.f; c2[1][r] = 0.f; c1[r] = 0.f; }
+    float s3 = 0.f, s2 = 0.f, s1 = 0.f;
+    const int fa = 32 * mb + i;                 // A column (feature of G)
+    const int fb = 64 * nh + 2 * i;             // first of the two B columns (features of H)
+    // k-steps in batches of DW_U: all loads of a batch are issued before its MFMAs (the operands come from L2 / the
+    // Infinity Cache, several hundred cycles away; the second wave of the SIMD covers the rest)
+    constexpr int DW_U = 4;
+    const float* gpool = J.g_pooled;
+    const float* gmsg = J.g_msgs;
+    for (long long rr = r0; rr < r1; rr += 2 * DW_U) {
+        float a3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U];
+        float2 b3[DW_U], b2[DW_U];
+#pragma unroll
+        for (int u = 0; u < DW_U; ++u) {
+            const long long row = rr + 2 * u + h;
+            const bool ok = row < r1;
+            const long long ro = ok ? row : r0;            // clamped: always a readable row
+            float v = gpool ? gpool[(ro / K) * EH + fa] : 0.f;
+            if (gmsg) v += gmsg[ro * EH + fa];
+            a3[u] = ok ? v * scale : 0.f;
+            const float w2 = J.g2[ro * EH + fa], w1 = J.g1[ro * EH + fa];
+            a2[u] = ok ? w2 : 0.f;
+            a1[u] = ok ? w1 : 0.f;
+            const float2 p3 = *reinterpret_cast<const float2*>(J.h2 + ro * EH + fb);
+            const float2 p2 = *reinterpret_cast<const float2*>(J.h1 + ro * EH + fb);
+            b3[u] = ok ? p3 : make_float2(0.f, 0.f);
+            b2[u] = ok ? p2 : make_float2(0.f, 0.f);
+            bx[u] = (ok && nh == 0 && i < IN) ? J.x[ro * IN + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DW_U; ++u) {
+            c3[0] = mfma32(a3[u], b3[u].x, c3[0]);
+            c3[1] = mfma32(a3[u], b3[u].y, c3[1]);
+            c2[0] = mfma32(a2[u], b2[u].x, c2[0]);
+            c2[1] = mfma32(a2[u], b2[u].y, c2[1]);
+            if (nh == 0) c1 = mfma32(a1[u], bx[u], c1);
+            s3 += a3[u]; s2 += a2[u]; s1 += a1[u];
+        }
+    }
+    float* P = J.partials + (size_t)p * ENC_PART;
+    // accumulator u, register r, lane (n, h): dW[32 mb + (r & 3) + 8 (r >> 2) + 4 h][64 nh + 2 n + u]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int orow = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(P + (size_t)orow * EH + fb) = make_float2(c3[0][r], c3[1][r]);
+        *reinterpret_cast<float2*>(P + 16384 + (size_t)orow * EH + fb) = make_float2(c2[0][r], c2[1][r]);
+        if (nh == 0 && i < 8) P[32768 + orow * 8 + i] = c1[r];      // dW1 row-major (128, 8): column i < in_dim, rest 0
+    }
+    if (nh == 0) {
+        s3 += __shfl_xor(s3, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (h == 0) {
+            P[32768 + 1024 + fa] = s3;
+            P[32768 + 1024 + 128 + fa] = s2;
+            P[32768 + 1024 + 256 + fa] = s1;
+        }
+    }
+}
+
+static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, long long unit) {
+    // workgroups for branch 0, proportional to the rows (each branch gets at least one)
+    if (nbr < 2) return total;
+    const double r0 = (double)br[0].rows, r1 = (double)br[1].rows;
+    int w = (int)(total * r0 / (r0 + r1) + 0.5);
+    if (w < 1) w = 1;
+    if (w > total - 1) w = total - 1;
+    (void)unit;
+    return w;
+}
+
+static bool branch_ok(const piml_encoder_branch& b) {
+    return b.rows > 0 && b.in_dim >= 1 && b.in_dim <= 8 && b.x && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3;
+}
+
+}  // namespace piml
+
+using namespace piml;
+
+PIML_API int piml_encoder_partial_floats(void) { return ENC_PART; }
+
+// workgroups the forward / backward launches use for these branches (partials must hold that many slots per
+// branch: see piml_encoder_bwd)
+PIML_API int piml_encoder_workgroups(const piml_encoder_branch* br, int nbr, int* wg_branch0) {
+    if (!br || nbr < 1 || nbr > 2) return 0;
+    const int total = 256;
+    const int w0 = split_workgroups(br, nbr, total, 1);
+    if (wg_branch0) *wg_branch0 = w0;
+    return total;
+}
+
+PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stream) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    EncArgs A;
+    A.nbr = nbr;
+    for (int i = 0; i < nbr; ++i) {
+        if (!branch_ok(br[i]) || !br[i].msgs) return hipErrorInvalidValue;
+        A.br[i] = br[i];
+    }
+    if (nbr == 1) A.br[1] = br[0];
+    const int total = 256;
+    A.wg_split = split_workgroups(br, nbr, total, 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream) {
+    if (agents == 0) return hipSuccess;
+    if (!msgs || !pooled || agents < 0 || k < 0) return hipErrorInvalidValue;
+    const long long n = agents * (EH / 4);
+    hipLaunchKernelGGL(enc_ksum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4*>(msgs), agents, k, reinterpret_cast<float4*>(pooled));
+    return hipGetLastError();
+}
+
+PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    EncArgs A;
+    A.nbr = nbr;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if (!branch_ok(b) || !b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || b.k < 1 || (!b.g_pooled && !b.g_msgs))
+            return hipErrorInvalidValue;
+        A.br[i] = b;
+    }
+    if (nbr == 1) A.br[1] = br[0];
+    const int total = 256;
+    A.wg_split = split_workgroups(br, nbr, total, 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, as_stream(stream), A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(enc_bwd_dw_kernel, dim3(total), dim3(ENC_THREADS), 0, as_stream(stream), A);
+    return hipGetLastError();
+}

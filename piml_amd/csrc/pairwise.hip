@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void collision_pairs4_kernel(const float2* __r
 
 // 3-D friends rule (data.py:573-591): pairs whose `base` sum over the leading dim exceeds 25
 // are zeroed in every slice of `coll`.
-__global__ void collision_friends3_kernel(float* __restrict__ coll, const float* __restrict__ base,
+// `base` may alias `coll` (the in-place 3-D rule without real_position): no __restrict__ on either.
+__global__ void collision_friends3_kernel(float* coll, const float* base,
                                           int S_coll, int S_base, size_t NN) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= NN) return;
@@ -905,6 +906,7 @@ __global__ void collision_correction_fwd_kernel(const float2* __restrict__ pred,
                                                 float radius, float dt, float2* __restrict__ out) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= rows) return;
+    if (k == 0) { out[g] = pred[g]; return; }          // no gathered neighbours: nothing to correct
     const float* f = ped + g * (size_t)k * stride;
     const float2 vi = vel[g];
     float2 P = pred[g];
@@ -955,6 +957,11 @@ __global__ void collision_correction_bwd_kernel(const float2* __restrict__ g_out
                                                 float2* __restrict__ g_vel) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= rows) return;
+    if (k == 0) {                                      // identity forward: the gradient passes straight through
+        if (g_pred) g_pred[g] = g_out[g];
+        if (g_vel) g_vel[g] = make_float2(0.f, 0.f);
+        return;
+    }
     const float* f = ped + g * (size_t)k * stride;
     const float2 vi = vel[g];
     const float2 P = pred[g];

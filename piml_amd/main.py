@@ -68,6 +68,9 @@ def get_args(argv=None):
     A('--collision_loss_version', type=str, default='v0')
     A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
     A('--tunableop', type=int, default=0, help='1: load the pre-tuned GEMM selections (piml_amd/tuning)')
+    A('--fix_dest_norm', action='store_true',
+      help='desired-force direction normalised per agent for channelled (C, N, 7) input too; the reference reduces '
+           'over dim=1 = the AGENT axis there (src/models/model.py:1290, SURVEY quirk Q2), which stays the default')
     args = p.parse_args(argv)
     args.model_name_suffix = ''.join(random.sample(list(string.ascii_lowercase) + list(string.digits), 8))
     return args
@@ -80,7 +83,12 @@ def set_exp_configs(args):
         torch.cuda.manual_seed_all(args.seed)
 
 
-def main(argv=None):
+LAST_RUN = {}      # the objects of the most recent main() call (tests / notebooks): simulator, histories, args
+
+
+def main(argv=None, init_state=None):
+    """`init_state`: optional state_dict loaded into the freshly built pre-training network (parity tests start
+    from the reference's own initial weights; parameter initialisation consumes the RNG in a different order)."""
     args = get_args(argv)
     set_exp_configs(args)
     if args.tunableop:
@@ -94,7 +102,11 @@ def main(argv=None):
     synthetic.build_dataset(args)
     loaders = LOADER.data_loader(synthetic.train_data, args.batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
     simulator = SIMULATOR.BaseSimulator(args)
+    if init_state is not None:
+        simulator.model.load_state_dict(init_state)
     history = simulator.train(loaders, synthetic.valid_data)
+    LAST_RUN.clear()
+    LAST_RUN.update(args=args, simulator=simulator, pretrain_history=list(history), finetune_history=[], n_train=len(synthetic.train_data))
     if hasattr(synthetic, 'test_data'):
         simulator.test_multiple_rollouts(synthetic.test_data, load_model=False)
 
@@ -103,7 +115,9 @@ def main(argv=None):
         real.load_data(args.ft_data_config)
         real.build_dataset(args)
         ft_loaders = LOADER.data_loader(real.train_data, args.ft_batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
-        history += simulator.finetune(ft_loaders, real.valid_data, real.test_data)
+        ft_history = simulator.finetune(ft_loaders, real.valid_data, real.test_data)
+        LAST_RUN.update(finetune_history=ft_history, finetune_data=real)
+        history += ft_history
     print('Total train time: {}'.format(time.time() - start_time))
 
     vis = DATASET.TimeIndexedPedDatasetforVis()

@@ -10,14 +10,24 @@ class MLAPM:
             raise NotImplementedError(args.get('version'))
 
     def step(self, position, velocity, desired_speed, destination, dt, radius=0.3):
-        """position, velocity, destination: (N, 2); desired_speed: (N, 1).  Returns the new
+        """position, velocity, destination: (N, 2); desired_speed: (N, 1), (N,) or (N, 2).  Returns the new
         velocity `velocity + force * dt` (mlapm.py:10-58).  As in the reference, absent (NaN)
         agents must be filtered out by the caller.  Deviation: version 'UCY' applies the
         one-line `coll.unsqueeze(-1)` fix without which the reference raises for N > 2."""
         a = self.args
-        return ops.mlapm_step(position, velocity, desired_speed, destination, dt, radius, version=a['version'],
-                              tau=a['tau'], A=a['A'], B=a['B'], C=a.get('C', 0.0), D=a.get('D', 0.0),
-                              theta=a.get('theta', 0.0))
+        kw = dict(version=a['version'], tau=a['tau'], A=a['A'], B=a['B'], C=a.get('C', 0.0), D=a.get('D', 0.0),
+                  theta=a.get('theta', 0.0))
+        N = position.shape[0]
+        if desired_speed.dim() == 2 and tuple(desired_speed.shape) == (N, 2):
+            # the reference's own driver passes (N, 2) (src/main_mlapm.py:13): `desired_speed * ed` then uses a
+            # per-component speed.  The kernel takes the x column; the y component's difference is a linear
+            # correction of the desired-force term, (0, (v0y - v0x) * ed_y) / tau * dt (exactly zero for equal columns).
+            import torch.nn.functional as F
+            base = ops.mlapm_step(position, velocity, desired_speed[:, :1], destination, dt, radius, **kw)
+            ed_y = F.normalize(destination - position, dim=-1, p=2)[:, 1]
+            corr = (desired_speed[:, 1] - desired_speed[:, 0]) * ed_y * (dt / a['tau'])
+            return base + F.pad(corr.unsqueeze(-1), (1, 0))
+        return ops.mlapm_step(position, velocity, desired_speed, destination, dt, radius, **kw)
 
     def rollout(self, position, velocity, desired_speed, destination, dt, radius=0.3, steps=200, use_graph=True):
         """The simulation loop of src/main_mlapm.py:18-36 on the device: step, explicit Euler

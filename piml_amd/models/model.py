@@ -27,6 +27,13 @@ import torch.nn as nn
 # (piml_amd/csrc/mlpglue.hip); the GEMMs remain torch.addmm / torch.mm.  PIML_FUSED_GLUE=0 (or
 # setting this flag to False) keeps the plain torch.nn expression of the same arithmetic.
 FUSED_GLUE = os.environ.get('PIML_FUSED_GLUE', '1') != '0'
+# The encoders themselves (Linear(in, 128) ReLU Linear(128, 128) ReLU Linear(128, 128), the processor's `2 x` and the
+# neighbour-axis sum) run as ONE hand-written f32-MFMA kernel per direction for both branches
+# (piml_amd/csrc/encoder.hip, ops.fused_encoders) when the network has the reference's default geometry;
+# PIML_FUSED_ENCODER=0 keeps the library-GEMM chain.  Below FUSED_ENCODER_MIN_ROWS neighbour rows the launch is
+# latency-bound either way and the library chain is kept.
+FUSED_ENCODER = os.environ.get('PIML_FUSED_ENCODER', '1') != '0'
+FUSED_ENCODER_MIN_ROWS = int(os.environ.get('PIML_FUSED_ENCODER_MIN_ROWS', '512'))
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -206,19 +213,48 @@ class _PINNSFBase(nn.Module):
             return self._process_and_pool(processor, encoder(feats, defer_last_bias=True), bias=last.bias)
         return self._process_and_pool(processor, encoder(feats))
 
-    def _branch(self, feats, encoder, processor, decoder, predictor):
+    @staticmethod
+    def _encoder_fusable(feats, encoder, processor):
+        """The fused f32-MFMA encoder kernel covers exactly the reference's default encoder geometry."""
+        if not (FUSED_GLUE and FUSED_ENCODER and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() >= 3):
+            return False
+        lins, acts = encoder.mlp[0::2], encoder.mlp[1::2]
+        return (len(lins) == 3 and 1 <= feats.shape[-1] <= 8 and lins[0].in_features == feats.shape[-1]
+                and all(lin.out_features == 128 for lin in lins) and isinstance(acts[0], nn.ReLU)
+                and isinstance(acts[1], nn.ReLU) and isinstance(acts[2], nn.Identity)
+                and processor.pure_scale() is not None
+                and feats.numel() // feats.shape[-1] >= FUSED_ENCODER_MIN_ROWS)
+
+    def _fused_encoders(self, ped_features, obs_features):
+        """{'ped': (msgs, pooled), 'obs': (...)} for the branches the fused kernel takes (both in one launch)."""
+        cand = [('ped', ped_features, self.ped_encoder, self.ped_processor)]
+        if self.obs_feature_dim > 0:
+            cand.append(('obs', obs_features, self.obs_encoder, self.obs_processor))
+        use = [c for c in cand if self._encoder_fusable(*c[1:])]
+        if not use:
+            return {}
+        from .. import ops
+        res = ops.fused_encoders([dict(x=f, scale=p.pure_scale(), pooled=not self.bottleneck,
+                                       weights=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)])
+                                  for _, f, e, p in use])
+        return {c[0]: r for c, r in zip(use, res)}
+
+    def _branch(self, feats, encoder, processor, decoder, predictor, pre=None):
+        """`pre` = (processor(encoder(feats)), its neighbour-axis sum) when the fused encoder kernel produced them."""
         if self.bottleneck:
-            emb = processor(encoder(feats))
+            emb = pre[0] if pre is not None else processor(encoder(feats))
             decoded = decoder(emb)
             msgs = predictor(decoded)
             return msgs.sum(dim=-2), msgs, decoded, emb
-        emb, pooled = self._encode_process_pool(feats, encoder, processor)
+        emb, pooled = pre if pre is not None else self._encode_process_pool(feats, encoder, processor)
         acc = predictor(decoder(pooled))
         return acc, emb, None, emb
 
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'
-        side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda) else None
+        pre = {} if self.residual else self._fused_encoders(ped_features, obs_features)
+        # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
+        side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None
         acc_o = None
         if self.obs_feature_dim > 0 and side is not None:      # fork: obstacle branch on the side stream
             side.wait_stream(torch.cuda.current_stream())
@@ -233,7 +269,7 @@ class _PINNSFBase(nn.Module):
             decoded = None
         else:
             acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
-                                                       self.ped_decoder, self.ped_predictor)
+                                                       self.ped_decoder, self.ped_predictor, pre=pre.get('ped'))
         out_obs = None
         if self.obs_feature_dim > 0:
             if side is not None:                                 # join
@@ -241,7 +277,7 @@ class _PINNSFBase(nn.Module):
                 out_obs = out_obs_side
             else:
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
-                                                    self.obs_decoder, self.obs_predictor)
+                                                    self.obs_decoder, self.obs_predictor, pre=pre.get('obs'))
         if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
                 and (self_features.dim() in (2, 3) or self.fix_dest_norm):
             from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)

@@ -66,6 +66,7 @@ class BaseSimulator(Pedestrians):
         self.batch_idx = 0
         self.collision_count = 0
         self.hard_collision_count = 0
+        self._checkpoints = {}          # {finetune_flag: best state_dict of that stage}, see save_model
         n_params = int(np.sum([p.numel() for p in self.model.parameters() if p.requires_grad]))
         print('#Trainable Parameters:', n_params)
 
@@ -74,6 +75,7 @@ class BaseSimulator(Pedestrians):
         if args.model not in MODEL.MODEL_TABLE:
             raise NotImplementedError(f'{args.model}: only the PINNSF family is on the accelerated path')
         net = MODEL.MODEL_TABLE[args.model][1 if finetune else 0](args)
+        net.fix_dest_norm = bool(getattr(args, 'fix_dest_norm', False))      # --fix_dest_norm (quirk Q2 off)
         return net.to(args.device)
 
     def set_model(self, args):
@@ -170,24 +172,36 @@ class BaseSimulator(Pedestrians):
             loss = loss * abnormal_mask.reshape(1, 1, -1, 1)
         return self.reduction(loss, reduction)
 
-    # ---- checkpoints (simulators.py:254-289); paths are explicit here ----
+    # ---- checkpoints (simulators.py:254-289) ----
+    # The reference always writes ../saved_model/{exp_name}_{suffix}[_finetuned] and re-reads it (fine-tuning starts
+    # from the best pre-trained weights, every evaluation loads the best ones).  Here the best weights of each stage
+    # are always snapshotted in memory (`self._checkpoints`), and additionally written to `--save_dir` when given.
     def _ckpt_path(self, args, finetune_flag):
-        path = os.path.join(getattr(args, 'save_dir', '../saved_model'), f'{args.exp_name}_{args.model_name_suffix}')
+        path = os.path.join(getattr(args, 'save_dir', '') or '../saved_model', f'{args.exp_name}_{args.model_name_suffix}')
         return path + ('_finetuned' if finetune_flag else '')
 
     def load_model(self, args, set_model=True, finetune_flag=True, load_path=''):
         if set_model:
             (self.set_ft_model if finetune_flag else self.set_model)(args)
-        sd = torch.load(load_path or self._ckpt_path(args, finetune_flag), map_location=args.device)
+        snap = self._checkpoints.get(bool(finetune_flag))
+        if load_path or (snap is None and getattr(args, 'save_dir', None)):
+            sd = torch.load(load_path or self._ckpt_path(args, finetune_flag), map_location=args.device)
+        elif snap is not None:
+            sd = snap
+        else:
+            raise FileNotFoundError('load_model: no checkpoint of the {} stage (nothing saved yet and no --save_dir)'
+                                    .format('fine-tune' if finetune_flag else 'pre-train'))
         if next(iter(sd)).startswith('module.'):           # saved from nn.DataParallel
             sd = {k[7:]: v for k, v in sd.items()}
-        self.model.load_state_dict(sd)
+        self.model.load_state_dict(sd)                     # in place: captured graphs keep reading the same buffers
 
     def save_model(self, args, finetune_flag=True, cpu_version=False):
-        path = self._ckpt_path(args, finetune_flag) + ('_cpu' if cpu_version else '')
-        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
-        sd = self.model.state_dict()
-        torch.save({k: v.cpu() for k, v in sd.items()} if cpu_version else sd, path)
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        self._checkpoints[bool(finetune_flag)] = sd
+        if getattr(args, 'save_dir', None):
+            path = self._ckpt_path(args, finetune_flag) + ('_cpu' if cpu_version else '')
+            os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+            torch.save({k: v.cpu() for k, v in sd.items()} if cpu_version else sd, path)
 
     # ---- shared per-step pieces ----
     def _features(self, p_cur, v_cur, a_cur, dest_cur, obstacles):
@@ -619,40 +633,77 @@ class BaseSimulator(Pedestrians):
         return log
 
     def train(self, train_loaders, val_data=None, test_data=None, validate_fn=None):
-        """Epoch loop with best-validation checkpointing and the reference's patience rule
-        (incl. its swapped patience / ft_patience, simulators.py:393)."""
+        """Epoch loop with best-validation model selection and the reference's patience rule (incl. its swapped
+        patience / ft_patience, simulators.py:393).  As in the reference (simulators.py:291-393) the weights are
+        checkpointed on every validation improvement; in the fine-tune stage the incoming (pre-trained) weights are
+        checkpointed and validated first, so a fine-tuned model is only kept when it beats them.  On return the
+        model holds the BEST weights of this stage (the reference reloads its checkpoint in every consumer:
+        finetune(), test_multiple_rollouts(load_model=True), main.py:166)."""
         args = self.args
         start = time.time()
         best, patience = 1e5, 0
         history = []
+        validating = validate_fn is not None or val_data is not None
+
+        def run_validation():
+            if validate_fn is not None:
+                return validate_fn(self)
+            return self.validate(val_data)[0]
+        saved = False
+        if self.finetune_flag and validating:                        # simulators.py:298-304
+            self.epoch = 0
+            self.save_model(args, self.finetune_flag)
+            saved = True
+            best = run_validation()
+            self.initial_val_loss = best
+            self.initial_val_eval = dict(getattr(self, 'last_eval', {}) or {})
+            if test_data:
+                self.test_multiple_rollouts(test_data, load_model=False, test_flag=True)
         for epoch in range(args.epochs):
             self.epoch, self.collision_count, self.hard_collision_count = epoch, 0, 0
             self.model.train()
-            sums, n = {}, 0
+            sums, n, batches = {}, 0, 0
             for batch_idx, batch in enumerate(train_loaders):
                 self.batch_idx = batch_idx
                 log = self.train_batch(batch)
                 n += log.pop('n')
+                batches += 1
                 for k, v in log.items():
                     sums[k] = sums.get(k, 0.0) + v
                 self.time_iter = time.time() - start
-            epoch_log = {k: v / max(n, 1) for k, v in sums.items()}
+            # per simulated (frame, agent) entry like the reference; its acc_pred is a mean over batches (:367)
+            epoch_log = {k: v / (max(batches, 1) if k == 'acc_pred' else max(n, 1)) for k, v in sums.items()}
             history.append(epoch_log)
             print('Epoch {}:'.format(epoch))
-            print('Time {:.4f} -- Training loss:{}, mse:{}'.format(self.time_iter, epoch_log.get('loss'),
-                                                                  epoch_log.get('mse')))
-            if validate_fn is None and val_data is None:
+            print('Time {:.4f} -- Training loss:{}, mse:{}, coll_pred:{}, acc_pred:{}, coll:{}, hard_coll:{}'.format(
+                self.time_iter, epoch_log.get('loss'), epoch_log.get('mse'), epoch_log.get('collision_pred', 0.0),
+                epoch_log.get('acc_pred', 0.0), epoch_log.get('collision', 0.0), epoch_log.get('hard_collision', 0.0)))
+            if self.finetune_flag:
+                print('training collision count hard/soft: {} & {}'.format(self.hard_collision_count,
+                                                                           self.collision_count))
+                epoch_log['train_collisions'] = (self.hard_collision_count, self.collision_count)
+            if not validating:
                 continue
-            val_loss = validate_fn(self) if validate_fn is not None else self.test_pointwise(val_data)[0]
-            print('Time {:.4f} -- Validation loss:{}'.format(self.time_iter, val_loss))
+            val_loss = run_validation()
+            epoch_log['val_loss'] = val_loss
+            if isinstance(getattr(self, 'last_eval', None), dict) and not self.last_eval.get('test_flag', True):
+                epoch_log['val_eval'] = dict(self.last_eval)
+            if test_data:
+                self.test_multiple_rollouts(test_data, load_model=False, test_flag=True)
+                epoch_log['test_eval'] = dict(self.last_eval)
             if val_loss < best:
+                print('!!!!!!!!!! Model Saved at epoch {} !!!!!!!!!!'.format(epoch))
                 best, patience = val_loss, 0
-                if getattr(args, 'save_dir', None):
-                    self.save_model(args, self.finetune_flag)
+                self.save_model(args, self.finetune_flag)
+                saved = True
+                epoch_log['saved'] = True
             else:
                 patience += 1
                 if patience > (args.patience if self.finetune_flag else args.ft_patience):
                     break
+        self.best_val_loss = best
+        if saved:                                                    # leave the best weights of this stage in place
+            self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
         return history
 
     # ---- rollout evaluation and fine-tuning (simulators.py:395-554) ----
@@ -665,15 +716,34 @@ class BaseSimulator(Pedestrians):
         return torch.where(((mask_p == 1) & (pred_mask_p == 0)).unsqueeze(-1), dest, pred_data)
 
     def test_multiple_rollouts(self, data, load_model=True, test_flag=True, reduction='sum'):
-        """Roll every clip of `data` (a list of TimeIndexedPedData) from `skip_frames` and score it:
-        (loss, mse, mae, ot, mmd) like simulators.py:465-554.  MAE is the mean displacement (the
+        """Roll every clip of `data` (a list of TimeIndexedPedData, or one clip: the reference's other branch) from
+        `skip_frames` and score it: (loss, mse, mae, ot, mmd) like simulators.py:465-554.  MAE is the mean displacement (the
         reference has no FDE); OT / MMD are the batched restatements in functions/metrics.py."""
         from ..functions import metrics as METRIC
         args = self.args
         self.model.eval()
-        clips = data if isinstance(data, list) else [data]
-        loss_sum = mse_sum = mae_sum = ot_sum = mmd_sum = 0.0
-        frames = 0
+        if not isinstance(data, list):
+            # single-clip branch (simulators.py:471-490): predictions shifted by one frame against the labels,
+            # 'mean' reductions over the simulated entries, collisions at a fixed 0.6 m threshold
+            with torch.no_grad():
+                p_pred = self.get_multiple_rollouts(data, t_start=args.skip_frames, load_model=load_model).position
+                p_pred = torch.cat((p_pred[1:], p_pred[-1:]), dim=0)
+                mask = data.mask_p_pred.long()
+                labels = data.labels[..., :2]
+                sel = mask == 1
+                loss = mse = F.mse_loss(p_pred[sel], labels[sel], reduction='mean').item()
+                mae = METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='mean')
+                ot = METRIC.ot_with_time_mask(p_pred, labels, mask, reduction='mean')
+                mmd = METRIC.mmd_with_time_mask(p_pred, labels, mask, reduction='mean')
+                collision = METRIC.collision_count(p_pred, 0.6, reduction='sum')
+            if test_flag:
+                print('---------------------------------------')
+                print('Test loss:{}, test_mse:{}, test_mae:{}, test ot:{}, test mmd:{}'.format(loss, mse, mae, ot, mmd))
+            print('test/val collision count (0.6 m): {}'.format(collision))
+            return loss, mse, mae, ot, mmd
+        clips = data
+        loss_sum = mse_sum = mae_sum = ot_sum = mmd_sum = fde_sum = 0.0
+        frames = fde_n = 0
         coll = hard = 0.0
         n = 0
         for d in clips:
@@ -690,6 +760,8 @@ class BaseSimulator(Pedestrians):
                 mse = torch.where(m, (p_pred - labels) ** 2, torch.zeros_like(p_pred)).sum().item()
                 loss = mse + (0 if test_flag else args.val_coll_weight * (c + h))
                 if test_flag:
+                    fde_sum += METRIC.fde_with_time_mask(p_pred, labels, mask, reduction='sum')
+                    fde_n += int(((mask == 1).sum(dim=0) > 0).sum().item())
                     mae_sum += METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='sum')
                     ot_sum += METRIC.ot_with_time_mask(p_pred, labels, mask, reduction='sum')
                     mmd_sum += METRIC.mmd_with_time_mask(p_pred, labels, mask, reduction='sum')
@@ -703,6 +775,10 @@ class BaseSimulator(Pedestrians):
             print('---------------------------------------')
             print('Test loss:{}, test_mse:{}, test_mae:{}, test ot:{}, test mmd:{}'.format(loss, mse, mae, ot, mmd))
         print('test/val collision count hard/soft: {} & {}'.format(hard, coll))
+        # everything of this evaluation in one place (the reference only prints the collision counts); FDE is this
+        # repository's addition (BASELINE.json configs[4] asks for ADE/FDE; the reference's "MAE" is the ADE)
+        self.last_eval = dict(loss=loss, mse=mse, mae=mae, ot=ot, mmd=mmd, collisions=coll, hard_collisions=hard,
+                              fde=(fde_sum / max(fde_n, 1)) if test_flag else None, test_flag=bool(test_flag))
         return loss, mse, mae, ot, mmd
 
     def validate(self, val_data):
@@ -714,10 +790,19 @@ class BaseSimulator(Pedestrians):
         return val_loss, val_mse
 
     def finetune(self, train_loaders, val_data, test_data, pretrained_state=None):
-        """Rollout fine-tuning (simulators.py:409-428): switch to the fine-tune network / optimiser,
-        load the intersection of the pre-trained weights, train on channelled windows."""
+        """Rollout fine-tuning (simulators.py:395-428): switch to the fine-tune network / optimiser, load the
+        intersection of the BEST pre-trained weights (the reference reads its pre-training checkpoint from disk),
+        validate them first, train on channelled windows, finish on the best fine-tuned weights and test them."""
         args = self.args
-        pretrained = pretrained_state if pretrained_state is not None else self.model.state_dict()
+        if pretrained_state is not None:
+            pretrained = pretrained_state
+        elif self._checkpoints.get(False) is not None:
+            pretrained = self._checkpoints[False]
+        elif getattr(args, 'save_dir', None) and os.path.exists(self._ckpt_path(args, False)):
+            pretrained = torch.load(self._ckpt_path(args, False), map_location=args.device)
+        else:
+            pretrained = self.model.state_dict()                     # fresh simulator: whatever the model holds
+        pretrained = {k: v.detach().clone() for k, v in pretrained.items()}
         self.set_ft_model(args)
         self.set_ft_optimizer(args)
         self.set_ft_scheduler(args)
@@ -725,8 +810,11 @@ class BaseSimulator(Pedestrians):
         own.update({k: v for k, v in pretrained.items() if k in own})
         self.model.load_state_dict(own)
         self.finetune_flag = True
-        history = self.train(train_loaders, validate_fn=(lambda s: s.validate(val_data)[0]) if val_data else None)
+        history = self.train(train_loaders, val_data if val_data else None, test_data,
+                             validate_fn=(lambda s: s.validate(val_data)[0]) if val_data else None)
+        result = None
         if test_data:
-            self.test_multiple_rollouts(test_data, load_model=False)
+            result = self.test_multiple_rollouts(test_data, load_model=False)
         self.finetune_flag = False
+        self.finetune_test_result = result
         return history

@@ -1076,3 +1076,147 @@ def collision_post_correction(predictions, ped_features, velocity, collision_thr
         raise ValueError('collision_post_correction: predictions / velocity (..., N, 2) and ped_features '
                          '(..., N, k, >= 4) expected')
     return _CollisionCorrection.apply(predictions, ped_features, velocity, collision_threshold, time_unit)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused PINNSF encoder on the f32 matrix cores (piml_amd/csrc/encoder.hip): the three Linear layers of
+# ped_encoder / obs_encoder, the processor's `scale * x` and the neighbour-axis sum, forward and backward,
+# for one or two branches per launch.  Replaces nine library GEMMs + their glue passes per branch and step.
+# ------------------------------------------------------------------------------------------------
+ENCODER_HIDDEN = 128
+ENCODER_MAX_IN = 8
+
+
+def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
+                       g_x=None, partials=None):
+    B = _lib.EncoderBranch()
+    B.x, B.rows, B.in_dim, B.k = x2.data_ptr(), x2.shape[0], x2.shape[1], int(k)
+    B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
+    B.scale = float(scale)
+    B.h1, B.h2, B.msgs = _ptr(h1), _ptr(h2), _ptr(msgs)
+    B.g_pooled, B.g_msgs, B.g2, B.g1, B.g_x, B.partials = [_ptr(t) for t in (g_pooled, g_msgs, g2, g1, g_x, partials)]
+    return B
+
+
+class _FusedEncoders(torch.autograd.Function):
+    """inputs: nbr, scales (tuple), want_pooled (tuple), then per branch x (..., k, in) and w1, b1, w2, b2, w3, b3.
+    outputs: per branch msgs (..., k, 128), pooled (..., 128) (a 0-element tensor when not wanted)."""
+
+    @staticmethod
+    def forward(ctx, nbr, scales, want_pooled, need_grad, *tensors):
+        L = _lib.lib()
+        xs = [tensors[7 * b] for b in range(nbr)]
+        wbs = [[_gpu_f32('encoder weight', t.detach()) for t in tensors[7 * b + 1:7 * b + 7]] for b in range(nbr)]
+        dev = xs[0].device
+        x2s, msgs, h1s, h2s, ks = [], [], [], [], []
+        opt = dict(device=dev, dtype=torch.float32)
+        for b in range(nbr):
+            x = _gpu_f32('encoder input', xs[b])
+            x2 = x.reshape(-1, x.shape[-1])
+            R = x2.shape[0]
+            x2s.append(x2)
+            ks.append(x.shape[-2])
+            msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
+            h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
+            h2s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
+        arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b])
+                                           for b in range(nbr)])
+        outs = []
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
+            for b in range(nbr):
+                lead = tuple(xs[b].shape[:-2])
+                if want_pooled[b]:
+                    agents = x2s[b].shape[0] // ks[b]
+                    pooled = torch.empty(agents, ENCODER_HIDDEN, **opt)
+                    _lib.check(L.piml_encoder_ksum(_ptr(msgs[b]), agents, ks[b], _ptr(pooled), _stream()),
+                               'piml_encoder_ksum')
+                    pooled = pooled.view(*lead, ENCODER_HIDDEN)
+                else:
+                    pooled = torch.empty(0, **opt)
+                outs += [msgs[b].view(*lead, ks[b], ENCODER_HIDDEN), pooled]
+        ctx.save_for_backward(*x2s, *[t for t in h1s if t is not None], *[t for t in h2s if t is not None],
+                              *[w for wb in wbs for w in wb])
+        ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        nbr, scales, want_pooled, ks, xshapes, need_grad = ctx.meta
+        nin = 4 + 7 * nbr
+        if not need_grad or all(g is None for g in gouts):
+            return (None,) * nin
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x2s, h1s, h2s = saved[:nbr], saved[nbr:2 * nbr], saved[2 * nbr:3 * nbr]
+        wbs = [saved[3 * nbr + 6 * b:3 * nbr + 6 * b + 6] for b in range(nbr)]
+        dev = x2s[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        live = [b for b in range(nbr) if gouts[2 * b] is not None or (want_pooled[b] and gouts[2 * b + 1] is not None)]
+        grads = [None] * nin
+        if not live:
+            return tuple(grads)
+        part = L.piml_encoder_partial_floats()
+        structs, keep = [], []
+        for b in live:
+            R, in_dim = x2s[b].shape
+            gm = gouts[2 * b]
+            gp = gouts[2 * b + 1] if want_pooled[b] else None
+            gm = _gpu_f32('g_msgs', gm).reshape(R, ENCODER_HIDDEN) if gm is not None else None
+            gp = _gpu_f32('g_pooled', gp).reshape(-1, ENCODER_HIDDEN) if gp is not None else None
+            g2 = torch.empty(R, ENCODER_HIDDEN, **opt)
+            g1 = torch.empty(R, ENCODER_HIDDEN, **opt)
+            gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[4 + 7 * b] else None
+            keep.append((gm, gp, g2, g1, gx))
+            structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], None, h1s[b], h2s[b], gp, gm, g2, g1, gx))
+        arr = (_lib.EncoderBranch * len(live))(*structs)
+        import ctypes
+        w0 = ctypes.c_int(0)
+        total = L.piml_encoder_workgroups(arr, len(live), ctypes.byref(w0))
+        slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
+        parts = [torch.empty(n, part, **opt) for n in slots]
+        for i in range(len(live)):
+            arr[i].partials = parts[i].data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_encoder_bwd(arr, len(live), _stream()), 'piml_encoder_bwd')
+        H = ENCODER_HIDDEN
+        for i, b in enumerate(live):
+            flat = sum_leading(parts[i])
+            in_dim = x2s[b].shape[1]
+            need = ctx.needs_input_grad[4 + 7 * b:4 + 7 * b + 7]
+            o = 4 + 7 * b
+            if need[0]:
+                grads[o] = keep[i][4].view(xshapes[b])
+            dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
+            dW1 = flat[2 * H * H:2 * H * H + 8 * H].view(H, 8)[:, :in_dim]
+            db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
+            for j, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
+                if need[j]:
+                    grads[o + j] = t
+        return tuple(grads)
+
+
+def fused_encoders(branches):
+    """branches: list (1 or 2 entries) of dicts {x (..., k, in<=8), scale, weights: (w1, b1, w2, b2, w3, b3) with the
+    nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool}.  Returns [(msgs (..., k, 128), pooled
+    (..., 128) | None), ...]: msgs = scale * encoder(x), pooled = msgs.sum(-2)  (src/models/model.py:1271-1283)."""
+    if not 1 <= len(branches) <= 2:
+        raise ValueError('fused_encoders: one or two branches')
+    flat = []
+    for br in branches:
+        x, w = br['x'], br['weights']
+        if not x.is_cuda:
+            raise _lib.PimlHipError('fused_encoders: expected GPU tensors (piml_amd has no CPU path)')
+        if x.dim() < 2 or not 1 <= x.shape[-1] <= ENCODER_MAX_IN or len(w) != 6 or \
+                tuple(w[0].shape) != (ENCODER_HIDDEN, x.shape[-1]) or tuple(w[2].shape) != (ENCODER_HIDDEN,) * 2 or \
+                tuple(w[4].shape) != (ENCODER_HIDDEN,) * 2 or any(tuple(w[i].shape) != (ENCODER_HIDDEN,) for i in (1, 3, 5)):
+            raise ValueError('fused_encoders: x (..., k, in <= 8) and Linear(in, 128), Linear(128, 128) x 2 expected')
+        if x.numel() == 0:
+            raise ValueError('fused_encoders: empty input')
+        flat += [x, *w]
+    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in flat)
+    out = _FusedEncoders.apply(len(branches), tuple(float(b['scale']) for b in branches),
+                               tuple(bool(b.get('pooled', True)) for b in branches), need_grad, *flat)
+    return [(out[2 * i], out[2 * i + 1] if branches[i].get('pooled', True) else None) for i in range(len(branches))]

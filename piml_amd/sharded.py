@@ -126,7 +126,10 @@ class ShardedScene:
     the collectives with the gloo backend.
     """
 
-    def __init__(self, n_total, obstacles, group=None, feature_fn=None, **feature_params):
+    def __init__(self, n_total, obstacles, group=None, feature_fn=None, force_collectives=False, **feature_params):
+        # force_collectives: issue the all-gather / reduce-scatter even in a 1-rank group (exercises the RCCL
+        # code path on a single GPU; tests/test_sharded_gpu.py, bench.py --force-dist)
+        self.force_collectives = bool(force_collectives)
         self.group = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
         self.world = dist.get_world_size(self.group) if self.group is not None else 1
         self.rank = dist.get_rank(self.group) if self.group is not None else 0
@@ -142,7 +145,7 @@ class ShardedScene:
 
     def gather_state(self, state_own):
         """(n, 6) owner records -> (N, 6) everyone's records (autograd: reduce-scatter)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return state_own
         return all_gather_records(state_own, self.group)
 

@@ -539,7 +539,158 @@ def gen_rollout_flags():
     save('rollout_flags', **out)
 
 
-GENS = dict(relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
+# ---- cfg5 (BASELINE.json configs[4]): the full pre-train -> fine-tune -> test loop of src/main.py:126-173 ----
+MAINFLOW_CASES = {
+    # flag sets of the shipped experiments (src/configs/exp_configs/piml-gcdata.yaml / piml-ucydata.yaml), with
+    # dropout 0 (deterministic; the RNG stream of dropout cannot be reproduced across devices) and 2 + 2 epochs
+    'gc': dict(
+        dataset_name='gc2344', collision_loss_weight=200, hard_collision_penalty=2, val_coll_weight=30,
+        pretrain=dict(train=['data/synthetic_data/GC_Dataset_ped1-12685_time1000-1060_interp9_xrange5-25_yrange15-35_simulation.npy'],
+                      valid=['data/synthetic_data/GC_Dataset_ped1-12685_time1100-1160_interp9_xrange5-25_yrange15-35_simulation.npy']),
+        finetune=dict(train=['data/GC_Dataset/GC_Dataset_ped1-12685_time1000-1060_interp9_xrange5-25_yrange15-35.npy'],
+                      valid=['data/synthetic_data/GC_Dataset_ped1-12685_time1100-1160_interp9_xrange5-25_yrange15-35_simulation.npy'],
+                      test=['data/synthetic_data/GC_Dataset_ped1-12685_time1000-1060_interp9_xrange5-25_yrange15-35_simulation.npy'])),
+    'ucy': dict(
+        dataset_name='ucy', collision_loss_weight=40, hard_collision_penalty=1, val_coll_weight=10,
+        pretrain=dict(train=['data/synthetic_data/UCY_Dataset_time108-162_timeunit0.08_simulation.npy'],
+                      valid=['data/synthetic_data/UCY_Dataset_time162-216_timeunit0.08_simulation.npy']),
+        finetune=dict(train=['data/UCY_dataset/UCY_Dataset_time162-216_timeunit0.08.npy'],
+                      valid=['data/synthetic_data/UCY_Dataset_time162-216_timeunit0.08_simulation.npy'],
+                      test=['data/synthetic_data/UCY_Dataset_time108-162_timeunit0.08_simulation.npy'])),
+}
+
+
+def mainflow_args(case, **kw):
+    c = MAINFLOW_CASES[case]
+    a = sim_args(model='pinnsf_bm', dataset_name=c['dataset_name'], dropout=0.0, learning_rate=2e-4, finetune_lr_decay=0.02,
+                 batch_size=128, ft_batch_size=32, weight_decay=1e-6, valid_steps=10, time_decay=0.9, epochs=2,
+                 collision_loss_version='v2', collision_pred_weight=5e-2, reg_weight=1e-2, teacher_weight=0,
+                 true_label_weight=0, collision_focus_weight=1, collision_loss_weight=c['collision_loss_weight'],
+                 hard_collision_penalty=c['hard_collision_penalty'], val_coll_weight=c['val_coll_weight'],
+                 patience=25, ft_patience=5, finetune_flag=True, pinnsf_interaction='sim', iter_flag=0, seed=666,
+                 shuffle=False, exp_name='mainflow_' + case, model_name_suffix='golden', training_mode='normal')
+    a.__dict__.update(kw)
+    return a
+
+
+def gen_mainflow(cases=('gc', 'ucy')):
+    """Runs the reference's train -> finetune -> test_multiple_rollouts sequence (the calls of src/main.py:126-173,
+    with `simulator.finetune` on TimeIndexedPedDataset2 windows because main.py:153 reads an undefined
+    args.f_batch_size) and records every number it prints plus the final test rollout."""
+    import contextlib
+    import io
+    import re
+    import shutil
+    import yaml
+    import data.dataset as DATASET
+    import models.simulators as SIM
+    import utils.data_loader as LOADER
+    import functions.metrics as METRIC
+    from piml_amd.functions.metrics import fde_with_time_mask
+    scratch = '/tmp/piml_ref_mainflow'
+    os.makedirs(os.path.join(scratch, 'src'), exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(os.path.join(scratch, 'src'))          # the reference writes checkpoints to ../saved_model
+    float_re = r'([-+0-9.eE]+|nan|inf)'
+    try:
+        for case in cases:
+            out = {}
+            cfg = MAINFLOW_CASES[case]
+            args = mainflow_args(case)
+            yamls = {}
+            for stage in ('pretrain', 'finetune'):
+                path = os.path.join(scratch, f'{case}_{stage}.yaml')
+                yaml.safe_dump({k: [os.path.join(REF, f) for f in v] for k, v in cfg[stage].items()}, open(path, 'w'))
+                yamls[stage] = path
+            log = io.StringIO()
+
+            class Tee(io.TextIOBase):
+                def write(self, x):
+                    log.write(x)
+                    sys.__stdout__.write(x)
+                    return len(x)
+            with contextlib.redirect_stdout(Tee()):
+                np.random.seed(args.seed)
+                torch.manual_seed(args.seed)
+                synthetic = DATASET.PointwisePedDataset()
+                synthetic.load_data(yamls['pretrain'])
+                synthetic.build_dataset(args)
+                np.random.seed(args.seed)
+                state = np.random.get_state()
+                out['perm_head'] = np.random.permutation(len(synthetic.train_data))[:512]
+                np.random.set_state(state)
+                loaders = LOADER.data_loader(synthetic.train_data, args.batch_size, args.seed, shuffle=args.shuffle,
+                                             drop_last=True)
+                torch.manual_seed(args.seed)
+                sim = SIM.BaseSimulator(args)
+                for k, v in sim.model.state_dict().items():
+                    out[f'init/{k}'] = v.clone()
+                print('@@ stage pretrain')
+                sim.train(loaders, synthetic.valid_data)
+                best_pre = torch.load(f'../saved_model/{args.exp_name}_{args.model_name_suffix}')
+                real = DATASET.TimeIndexedPedDataset2()
+                real.load_data(yamls['finetune'])
+                real.build_dataset(args)
+                ft_loaders = LOADER.data_loader(real.train_data, args.ft_batch_size, args.seed, shuffle=args.shuffle,
+                                                drop_last=True)
+                print('@@ stage finetune')
+                sim.finetune(ft_loaders, real.valid_data, real.test_data)
+                best_ft = torch.load(f'../saved_model/{args.exp_name}_{args.model_name_suffix}_finetuned')
+            text = log.getvalue()
+            pre, ft = text.split('@@ stage finetune')
+            pre = pre.split('@@ stage pretrain')[1]
+
+            def grab(txt, pattern):
+                return np.array([[float(x) for x in (m if isinstance(m, tuple) else (m,))]
+                                 for m in re.findall(pattern, txt)], np.float64)
+            out['pre/train'] = grab(pre, r'Training loss:' + float_re + r', mse:' + float_re)            # (epochs, 2)
+            out['pre/val'] = grab(pre, r'Validation loss:' + float_re + r', val_mse:' + float_re)
+            out['pre/saved_epochs'] = grab(pre, r'Model Saved at epoch (\d+)')
+            out['ft/train'] = grab(ft, r'Training loss:' + float_re + r', mse:' + float_re + r', coll_pred:' + float_re +
+                                   r', acc_pred:' + float_re + r', coll:' + float_re + r', hard_coll:' + float_re)
+            out['ft/train_collisions'] = grab(ft, r'training collision count hard/soft: ' + float_re + r' & ' + float_re)
+            out['ft/val'] = grab(ft, r'Validation loss:' + float_re + r', val_mse:' + float_re)  # [before epoch 0, epoch 0, ...]
+            out['ft/saved_epochs'] = grab(ft, r'Model Saved at epoch (\d+)')
+            out['ft/test'] = grab(ft, r'Test loss:' + float_re + r', test_mse:' + float_re + r', test_mae:' + float_re +
+                                  r', test ot:' + float_re + r', test mmd:' + float_re)          # last row = final test
+            out['ft/collisions'] = grab(ft, r'test/val collision count hard/soft: ' + float_re + r' & ' + float_re)
+            for tag, sd in (('best_pre', best_pre), ('best_ft', best_ft)):
+                for k, v in sd.items():
+                    if k.startswith(('ped_encoder.mlp.0', 'ped_encoder.mlp.4', 'obs_encoder.mlp.2', 'ped_predictor',
+                                     'obs_decoder.mlp.0.bias', 'ped_collision_predictor.mlp.2')):
+                        out[f'{tag}/{k}'] = v.clone()
+                out[f'{tag}/l2'] = np.float64(sum(float((v.double() ** 2).sum()) for v in sd.values()) ** 0.5)
+            # final test rollout with the best fine-tuned weights: positions (short horizon) + FDE of the same masks
+            sim.model.load_state_dict(best_ft)
+            sim.model.eval()
+            d = real.test_data[0]
+            with torch.no_grad():
+                pred = sim.get_multiple_rollouts(d, t_start=args.skip_frames, load_model=False)
+                mask = d.mask_p_pred.long()
+                p_pred = sim.post_process(d, pred.position.clone(), pred.mask_p, mask)
+            labels = d.labels[..., :2]
+            out['test/fde'] = np.float64(fde_with_time_mask(p_pred, labels, mask, reduction='mean'))
+            out['test/mae'] = np.float64(METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='mean'))
+            out['test/rollout_head'] = pred.position[:args.skip_frames + 40].clone()
+            out['test/mask_head'] = pred.mask_p[:args.skip_frames + 40].clone()
+            out['log'] = np.array(text)
+            save('mainflow_' + case, **out)
+        # the clips the flow reads travel as data fixtures (inputs), next to the other clips under tests/golden/data
+        dst = os.path.join(HERE, 'data')
+        for case in cases:
+            for stage in ('pretrain', 'finetune'):
+                for files in MAINFLOW_CASES[case][stage].values():
+                    for f in files:
+                        if not os.path.exists(os.path.join(dst, os.path.basename(f))):
+                            shutil.copy(os.path.join(REF, f), dst)
+                ypath = os.path.join(dst, f'mainflow_{case}_{stage}.yaml')
+                yaml.safe_dump({k: [os.path.basename(f) for f in v] for k, v in MAINFLOW_CASES[case][stage].items()},
+                               open(ypath, 'w'))
+    finally:
+        os.chdir(cwd)
+
+
+GENS = dict(mainflow=gen_mainflow, relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)

@@ -1,0 +1,140 @@
+"""GPU: the fused f32-MFMA encoder kernels (piml_amd/csrc/encoder.hip, ops.fused_encoders) against a float64
+restatement of the reference's arithmetic -- src/models/model.py:40-65 (Linear / ReLU chain), :82-119 (processor =
+2 x, quirk Q3), :1279-1283 (sum over the k neighbours) -- for outputs and every gradient.  Tolerance: 1e-5 relative
+to the tensor's largest magnitude (north-star bar); the measured error is printed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+H = 128
+
+
+def make_branch(n, k, in_dim, seed, scale=2.0, x_grad=True, lead=()):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(*lead, n, k, in_dim, generator=g) * 2).to(DEV)
+    x[..., : max(n // 7, 1), k // 2:, :] = 0.0            # zero-padded neighbour rows (quirk Q4)
+    dims = [(H, in_dim), (H,), (H, H), (H,), (H, H), (H,)]
+    w = [(torch.randn(*d, generator=g) * (0.3 if len(d) == 2 else 0.1)).to(DEV).requires_grad_(True) for d in dims]
+    return dict(x=x.requires_grad_(x_grad), scale=scale, weights=w, pooled=True)
+
+
+def reference(br, g_msgs, g_pooled):
+    """float64 autograd of the same network."""
+    x = br['x'].detach().double().requires_grad_(True)
+    w = [t.detach().double().requires_grad_(True) for t in br['weights']]
+    h = torch.relu(x @ w[0].t() + w[1])
+    h = torch.relu(h @ w[2].t() + w[3])
+    msgs = br['scale'] * (h @ w[4].t() + w[5])
+    pooled = msgs.sum(-2)
+    loss = 0
+    if g_msgs is not None:
+        loss = loss + (msgs * g_msgs.double()).sum()
+    if g_pooled is not None:
+        loss = loss + (pooled * g_pooled.double()).sum()
+    loss.backward()
+    return msgs.detach(), pooled.detach(), x.grad, [t.grad for t in w]
+
+
+def relerr(got, want):
+    want = want.to(got.device)
+    return float((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('shapes,upstream', [
+    ([(300, 6, 6)], 'both'), ([(37, 10, 6)], 'pooled'), ([(64, 6, 4)], 'msgs'), ([(1, 1, 1)], 'both'),
+    ([(4096, 6, 6), (4096, 10, 6)], 'pooled'), ([(700, 6, 6), (300, 10, 6)], 'both'), ([(33, 3, 8), (2000, 7, 5)], 'both'),
+])
+def test_fused_encoders_match_float64_reference(shapes, upstream):
+    from piml_amd import ops
+    branches = [make_branch(n, k, d, seed=10 * i + n % 7) for i, (n, k, d) in enumerate(shapes)]
+    outs = ops.fused_encoders(branches)
+    gen = torch.Generator().manual_seed(5)
+    ups, loss = [], 0
+    for (msgs, pooled) in outs:
+        gm = torch.randn(msgs.shape, generator=gen).to(DEV) if upstream in ('both', 'msgs') else None
+        gp = torch.randn(pooled.shape, generator=gen).to(DEV) if upstream in ('both', 'pooled') else None
+        ups.append((gm, gp))
+        if gm is not None:
+            loss = loss + (msgs * gm).sum()
+        if gp is not None:
+            loss = loss + (pooled * gp).sum()
+    loss.backward()
+    worst = {}
+    for br, (msgs, pooled), (gm, gp) in zip(branches, outs, ups):
+        rm, rp, rgx, rgw = reference(br, gm, gp)
+        worst['msgs'] = max(worst.get('msgs', 0), relerr(msgs.detach(), rm))
+        worst['pooled'] = max(worst.get('pooled', 0), relerr(pooled.detach(), rp))
+        worst['g_x'] = max(worst.get('g_x', 0), relerr(br['x'].grad, rgx))
+        for name, t, r in zip(('dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3'), br['weights'], rgw):
+            worst[name] = max(worst.get(name, 0), relerr(t.grad, r))
+    print(f'fused encoder {shapes} upstream={upstream}: max rel err vs float64 ' +
+          ', '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    assert max(worst.values()) <= 1e-5, worst
+
+
+def test_fused_encoders_leading_dims_no_input_grad_and_inference():
+    """(C, N, k, 6) channelled input; inputs without gradient (pointwise training: features are data); no_grad."""
+    from piml_amd import ops
+    br = make_branch(50, 6, 6, seed=3, x_grad=False, lead=(4,))
+    (msgs, pooled), = ops.fused_encoders([br])
+    assert msgs.shape == (4, 50, 6, H) and pooled.shape == (4, 50, H)
+    pooled.square().sum().backward()
+    assert br['x'].grad is None and all(t.grad is not None for t in br['weights'])
+    rm, rp, _, rgw = reference(br, None, 2 * pooled.detach())
+    assert relerr(msgs.detach(), rm) <= 1e-5 and relerr(br['weights'][2].grad, rgw[2]) <= 1e-5
+    with torch.no_grad():
+        (m2, p2), = ops.fused_encoders([br])
+    assert torch.equal(m2, msgs.detach()) and torch.equal(p2, pooled.detach())
+    br2 = dict(br, pooled=False)
+    (m3, p3), = ops.fused_encoders([br2])
+    assert p3 is None and torch.equal(m3.detach(), msgs.detach())
+
+
+def test_fused_encoders_are_deterministic():
+    """No atomics anywhere: two runs give bit-identical outputs and gradients."""
+    from piml_amd import ops
+    res = []
+    for _ in range(2):
+        branches = [make_branch(1000, 6, 6, seed=1), make_branch(1000, 10, 6, seed=2)]
+        outs = ops.fused_encoders(branches)
+        sum((p * p).sum() + m.sum() for m, p in outs).backward()
+        res.append([o.detach() for pair in outs for o in pair] + [b['x'].grad for b in branches] +
+                   [t.grad for b in branches for t in b['weights']])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name', ['PINNSF_multitask', 'PINNSF_bottleneck_multitask', 'PINNSF'])
+def test_models_with_fused_encoder_match_library_chain(name):
+    """Whole networks: fused encoder kernels vs the library-GEMM chain (PIML_FUSED_ENCODER off), outputs and all
+    gradients, at a size where both branches take the fused path."""
+    import types
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16,
+        decoder_hidden_layers=2, dropout=0.5, activation='relu', dataset_name='gc1560')
+    torch.manual_seed(0)
+    net = getattr(MODEL, name)(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    n = 600
+    base = [torch.randn(n, 6, 6, generator=g).to(DEV), torch.randn(n, 10, 6, generator=g).to(DEV),
+            torch.randn(n, 7, generator=g).to(DEV)]
+    res = {}
+    for fused in (True, False):
+        MODEL.FUSED_ENCODER = fused
+        ins = [t.clone().requires_grad_(True) for t in base]
+        net.zero_grad(set_to_none=True)
+        out = net(*ins)
+        (out[0].square().sum() + out[1].sum() * 1e-2 + out[-1].sum()).backward()
+        res[fused] = [o.detach() for o in out] + [t.grad for t in ins] + \
+            [p.grad for p in net.parameters() if p.grad is not None]
+    MODEL.FUSED_ENCODER = True
+    worst = 0.0
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
+    print(f'{name}: fused encoder vs library chain, max rel err {worst:.1e}')
+    assert worst <= 2e-5

@@ -77,7 +77,7 @@ def test_relfeat_focal_block_equals_full(oracle):
             assert torch.equal(a_, b_[f0:f0 + fc])
 
 
-@pytest.mark.parametrize('N,M,C', [(512, 100, None), (2048, 2000, None), (200, 100, 3)])
+@pytest.mark.parametrize('N,M,C', [(512, 100, None), (2048, 2000, None), (200, 100, 3), (4096, 2000, None)])
 def test_relfeat_backward_matches_oracle(oracle, N, M, C):
     from piml_amd import ops
     sc = synthetic_gc_scene(N, M, seed=21, channels=C)
@@ -89,10 +89,13 @@ def test_relfeat_backward_matches_oracle(oracle, N, M, C):
     (pf * gp_).sum().add((of * go_).sum()).add((df * gd_).sum()).backward()
     want = oracle.relfeat_bwd(gp_.cpu().numpy(), go_.cpu().numpy(), gd_.cpu().numpy(), pi.cpu().numpy(),
                               oi.cpu().numpy(), sc['position'], sc['destination'])
+    worst = 0.0
     for got, w in zip((p.grad, v.grad, a_.grad, d.grad), want):
         got = got.cpu().numpy()
         scale = max(1.0, np.abs(w).max())
+        worst = max(worst, np.abs(got - w).max() / scale)
         assert np.abs(got - w).max() <= 1e-5 * scale
+    print(f'relfeat backward N={N} M={M}: max rel err vs oracle {worst:.2e} (bar 1e-5)')
     # absent agents receive no gradient
     absent = np.isnan(sc['position'][..., 0])
     assert np.all(p.grad.cpu().numpy()[absent] == 0)
@@ -181,6 +184,44 @@ def test_relfeat_full_size_cfg4_properties_and_oracle(oracle):
     for got, want in zip((pf, of, df, pi, oi), ref[:5]):
         want = want.reshape(got.shape)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_relfeat_cfg4_sharded_blocks_forward_and_backward(oracle):
+    """BASELINE.json configs[3] in the form the 8 ranks actually launch it: 16384 agents + 2000 obstacle points,
+    rank r's launch = focal rows [r*2048, (r+1)*2048) of the interleaved (N, 6) record buffer (state_ld = 6) that the
+    per-step all-gather produces.  All 8 blocks: forward bit-exact against the oracle's rows, and the SUM of the
+    blocks' partial d/d(state) (what the reduce-scatter adds up) against the oracle's backward of the whole scene."""
+    from piml_amd import ops
+    N, M, G = 16384, 2000, 8
+    n = N // G
+    sc = synthetic_gc_scene(N, M, seed=4)
+    rng = np.random.default_rng(40)
+    acc = (rng.standard_normal((N, 2)) * 0.3).astype(np.float32)
+    args = (sc['position'], sc['velocity'], acc, sc['destination'], sc['obstacles'])
+    ref = oracle.relfeat_fwd(*[x[None] for x in args[:4]], args[4], return_index=True)
+    state = dev(np.concatenate(args[:3], axis=-1)).requires_grad_(True)
+    dest, obs = dev(args[3]), dev(args[4])
+    gw = [rng.standard_normal(ref[i][0].shape).astype(np.float32) for i in range(3)]
+    g_dest_rows = []
+    for r in range(G):
+        rows = slice(r * n, (r + 1) * n)
+        d_rows = dest[rows].clone().requires_grad_(True)
+        out = ops.relative_features_packed(state, d_rows, obs, r * n, n, return_index=True)
+        for got, want in zip(out, ref[:5]):
+            got = got.detach().cpu().numpy()
+            want = want[0][rows].reshape(got.shape)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f'block {r}'
+        sum((o * dev(w[rows])).sum() for o, w in zip(out[:3], gw)).backward()     # accumulates into state.grad
+        g_dest_rows.append(d_rows.grad)
+    want = oracle.relfeat_bwd(gw[0], gw[1], gw[2], ref[3][0], ref[4][0], sc['position'], sc['destination'])
+    got_state = state.grad.cpu().numpy()
+    worst = 0.0
+    for got, w in zip((got_state[:, 0:2], got_state[:, 2:4], got_state[:, 4:6],
+                       torch.cat(g_dest_rows).cpu().numpy()), want):
+        scale = max(1.0, np.abs(w).max())
+        worst = max(worst, np.abs(got - w).max() / scale)
+    print(f'cfg4 sharded blocks: summed d/d(state) vs oracle max rel err {worst:.2e} (bar 1e-5)')
+    assert worst <= 1e-5
 
 
 def test_relfeat_fuzz_small_scenes_vs_oracle(oracle):
