@@ -37,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL / cross-process tensor sharing)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# HIP-graph replay with memset nodes is only correct with the CLR packet capture off (piml_amd/__init__.py)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

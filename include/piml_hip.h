@@ -377,10 +377,15 @@ typedef struct piml_encoder_branch {
     const float *g_pooled, *g_msgs;
     float *g2, *g1, *g_x;
     float* partials;
+    float* packed; /* piml_encoder_pack_floats() floats of caller-provided scratch: the weights re-ordered into MFMA
+                      operand fragments; written by piml_encoder_fwd (or piml_encoder_pack), read by piml_encoder_bwd */
 } piml_encoder_branch;
 
-/* floats of one partial slot */
+/* floats of one partial slot / of one `packed` buffer */
 int piml_encoder_partial_floats(void);
+int piml_encoder_pack_floats(void);
+/* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
+int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve
  * branch 1): the number of partial slots each branch's `partials` must hold. */
 int piml_encoder_workgroups(const piml_encoder_branch* branches, int nbranches, int* wg_branch0);
@@ -388,6 +393,39 @@ int piml_encoder_fwd(const piml_encoder_branch* branches, int nbranches, void* s
 int piml_encoder_bwd(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* pooled (agents, 128) = sum over k consecutive rows of msgs (agents * k, 128) */
 int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream);
+
+/*
+ * Fused PINNSF decoder tail on the f32 matrix cores (piml_amd/csrc/decoder.hip), reference
+ * src/models/model.py:1283-1294 (`pinnsf_m`, same in `pinnsf`):
+ *   pooled = sum over the k neighbour rows of msgs;  acc_branch = predictor(decoder(pooled)) with
+ *   decoder = Linear(128, 64) ReLU Linear(64, 64), predictor = Linear(64, 2);
+ *   acc = acc_ped [+ acc_obs] [+ (v0 * dest / |dest| - v) / tau when self_features (agents, 7) is given].
+ * Both branches have the same number of agents.  Weights: nn.Linear layouts w1 (64,128) b1 (64) w2 (64,64) b2 (64)
+ * w3 (2,64) b3 (2).  fwd writes pooled (agents,128), h1 (agents,64: post-ReLU), d2 (agents,64: decoder output) when
+ * the pointers are given (needed by bwd) and `packed` (piml_decoder_pack_floats() floats, re-used by bwd).
+ * bwd: g_pred (agents,2) -> g_pooled (agents,128) per branch; g_pre2 / g_pre1 (agents,64) are caller scratch;
+ * g_self (agents,7, optional) = gradient of the desired-force term; partials: piml_decoder_workgroups(agents) slots of
+ * piml_decoder_partial_floats() floats per branch = [dW1 64x128 | dW2 64x64 | dW3 2x64 | db1 64 | db2 64 | db3 2 +
+ * 6 pad], to be summed with piml_sum_leading.
+ */
+typedef struct piml_decoder_branch {
+    const float* msgs;
+    long long agents;
+    int k;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    float *pooled, *h1, *d2;
+    float *g_pre2, *g_pre1, *g_pooled;
+    float* partials;
+    float* packed;
+} piml_decoder_branch;
+
+int piml_decoder_pack_floats(void);
+int piml_decoder_partial_floats(void);
+int piml_decoder_workgroups(long long agents);
+int piml_decoder_fwd(const piml_decoder_branch* branches, int nbranches, const float* self_features, float tau,
+                     float* acc, void* stream);
+int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const float* g_pred,
+                     const float* self_features, float tau, float* g_self, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,15 @@ class EncoderBranch(ctypes.Structure):
     _fields_ = [('x', _p), ('rows', _ll), ('in_dim', _i), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
-                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p)]
+                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('packed', _p)]
+
+
+class DecoderBranch(ctypes.Structure):
+    """piml_decoder_branch (include/piml_hip.h)."""
+    _fields_ = [('msgs', _p), ('agents', _ll), ('k', _i),
+                ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
+                ('pooled', _p), ('h1', _p), ('d2', _p), ('g_pre2', _p), ('g_pre1', _p), ('g_pooled', _p),
+                ('partials', _p), ('packed', _p)]
 
 
 # name -> argtypes, in the order of include/piml_hip.h
@@ -65,10 +73,17 @@ SIGNATURES = {
     'piml_timer_destroy': [_p],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
     'piml_encoder_partial_floats': [],
+    'piml_encoder_pack_floats': [],
+    'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_bwd': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_ksum': [_p, _ll, _i, _p, _p],
+    'piml_decoder_pack_floats': [],
+    'piml_decoder_partial_floats': [],
+    'piml_decoder_workgroups': [_ll],
+    'piml_decoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p, _f, _p, _p],
+    'piml_decoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 

@@ -40,24 +40,54 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// LDS image of a 128 x 128 nn.Linear weight (out, in) as A-fragments, float4 index ((blk*4 + bp)*4 + q)*64 + lane:
-//   forward  (TR = false): [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
-//   backward (TR = true):  [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]   (A = W^T: in block blk, out block bp)
-template <bool TR>
-__device__ __forceinline__ void stage_w128(float4* dst, const float* __restrict__ W, int tid) {
-    for (int e = tid; e < 4 * 4 * 4 * 64; e += ENC_THREADS) {
-        const int lane = e & 63, q = (e >> 6) & 3, bp = (e >> 8) & 3, blk = e >> 10;
-        const int i = lane & 31, h = lane >> 5;
-        const int c0 = 32 * bp + 8 * q + 4 * h;
-        float4 v;
-        if (!TR) {
-            v = *reinterpret_cast<const float4*>(W + (size_t)(32 * blk + i) * EH + c0);
-        } else {
-            const float* p = W + (size_t)c0 * EH + 32 * blk + i;
-            v = make_float4(p[0], p[EH], p[2 * EH], p[3 * EH]);
-        }
-        dst[e] = v;
+// A-fragment images of a 128 x 128 nn.Linear weight (out, in), float4 index ((blk*4 + bp)*4 + q)*64 + lane:
+//   forward:       [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
+//   backward (dX): [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]   (A = W^T: in block blk, out block bp)
+// Packed weights of one encoder (floats), written once per step by enc_pack_kernel so that every workgroup stages
+// its LDS image with linear, fully coalesced copies:
+//   [ W2 fragments 16384 | W3 fragments 16384 | W1 fragments 1024 | b1 b2 b3 384 ]        forward image
+//   [ W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments 4096 ]                 dX image
+constexpr int PACK_FWD = 16384 * 2 + 1024 + 384;
+constexpr int PACK_DX = 16384 * 2 + 4096;
+constexpr int PACK_FLOATS = PACK_FWD + PACK_DX;
+
+__device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e) {
+    const int IN = J.in_dim;
+    if (e < 32768 || (e >= PACK_FWD && e < PACK_FWD + 32768)) {
+        const bool tr = e >= PACK_FWD;
+        const int f = tr ? e - PACK_FWD : e;
+        const float* W = (f < 16384) == tr ? J.w3 : J.w2;      // fwd: W2 | W3;  dX: W3^T | W2^T
+        const int g = f & 16383, u = g & 3, lane = (g >> 2) & 63, q = (g >> 8) & 3, bp = (g >> 10) & 3, blk = g >> 12;
+        const int i = lane & 31, c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
+        return tr ? W[(size_t)c * EH + 32 * blk + i] : W[(size_t)(32 * blk + i) * EH + c];
     }
+    if (e < 32768 + 1024) {                                    // W1 fragments [blk][s][lane]
+        const int g = e - 32768, l = g & 63, sidx = (g >> 6) & 3, blk = g >> 8;
+        const int c = 2 * sidx + (l >> 5);
+        return c < IN ? J.w1[(size_t)(32 * blk + (l & 31)) * IN + c] : 0.f;
+    }
+    if (e < PACK_FWD) {
+        const int g = e - 32768 - 1024;
+        return g < 128 ? J.b1[g] : (g < 256 ? J.b2[g - 128] : J.b3[g - 256]);
+    }
+    {                                                          // W1^T fragments [bp][q][lane] float4
+        const int g = e - PACK_FWD - 32768, u = g & 3, l = (g >> 2) & 63, q = (g >> 8) & 3, bp = g >> 10;
+        const int i = l & 31, c = 32 * bp + 8 * q + 4 * (l >> 5) + u;
+        return i < IN ? J.w1[(size_t)c * IN + i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
+    const int b = blockIdx.y;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
+}
+
+__device__ __forceinline__ void stage_linear(float* lds, const float* __restrict__ src, int nfloats, int tid) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(lds);
+    for (int e = tid; e < nfloats / 4; e += ENC_THREADS) d4[e] = s4[e];
 }
 
 // features (4 consecutive) held by accumulator registers 4q .. 4q+3 of block blk in lane half h
@@ -67,7 +97,7 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 // forward
 // ---------------------------------------------------------------------------------------------------------
 // LDS (floats): W2 fragments 16384 | W3 fragments 16384 | W1 fragments [blk 4][s 4][lane 64] 1024 | b1 b2 b3 384
-constexpr int FWD_LDS_FLOATS = 16384 * 2 + 1024 + 384;
+constexpr int FWD_LDS_FLOATS = 16384 * 2 + 1024 + 384;      // = PACK_FWD
 
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
@@ -83,19 +113,11 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
     const long long stride = (long long)nwg * ENC_WAVES;
     if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
 
-    float4* W2f = reinterpret_cast<float4*>(lds);
-    float4* W3f = reinterpret_cast<float4*>(lds + 16384);
-    float* W1f = lds + 32768;
-    float* bias = lds + 32768 + 1024;
-    stage_w128<false>(W2f, J.w2, tid);
-    stage_w128<false>(W3f, J.w3, tid);
-    for (int e = tid; e < 1024; e += ENC_THREADS) {
-        const int l = e & 63, s = (e >> 6) & 3, blk = e >> 8;
-        const int c = 2 * s + (l >> 5);
-        W1f[e] = c < IN ? J.w1[(size_t)(32 * blk + (l & 31)) * IN + c] : 0.f;
-    }
-    for (int e = tid; e < 384; e += ENC_THREADS)
-        bias[e] = e < 128 ? J.b1[e] : (e < 256 ? J.b2[e - 128] : J.b3[e - 256]);
+    const float4* W2f = reinterpret_cast<const float4*>(lds);
+    const float4* W3f = reinterpret_cast<const float4*>(lds + 16384);
+    const float* W1f = lds + 32768;
+    const float* bias = lds + 32768 + 1024;
+    stage_linear(lds, J.packed, PACK_FWD, tid);
     __syncthreads();
 
     const int j = lane & 31, h = lane >> 5;
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(256) void enc_ksum_kernel(const float4* __restrict_
 // g_h2 = W3^T g3, g2 = g_h2 * [h2 > 0] (stored); g_h1 = W2^T g2, g1 = g_h1 * [h1 > 0] (stored); g_x = W1^T g1.
 // ---------------------------------------------------------------------------------------------------------
 // LDS (floats): W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments [bp 4][q 4][lane 64] float4 = 4096
-constexpr int DX_LDS_FLOATS = 16384 * 2 + 4096;
+constexpr int DX_LDS_FLOATS = 16384 * 2 + 4096;               // = PACK_DX
 
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
@@ -229,21 +251,11 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
     const long long stride = (long long)nwg * ENC_WAVES;
     if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;
 
-    float4* W3t = reinterpret_cast<float4*>(lds);
-    float4* W2t = reinterpret_cast<float4*>(lds + 16384);
-    float4* W1t = reinterpret_cast<float4*>(lds + 32768);
-    stage_w128<true>(W3t, J.w3, tid);
-    stage_w128<true>(W2t, J.w2, tid);
+    const float4* W3t = reinterpret_cast<const float4*>(lds);
+    const float4* W2t = reinterpret_cast<const float4*>(lds + 16384);
+    const float4* W1t = reinterpret_cast<const float4*>(lds + 32768);
     const bool want_gx = J.g_x != nullptr;
-    if (want_gx)
-        for (int e = tid; e < 16 * 64; e += ENC_THREADS) {
-            const int l = e & 63, q = (e >> 6) & 3, bp = e >> 8;
-            const int i = l & 31, c0 = 32 * bp + 8 * q + 4 * (l >> 5);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < IN) v = make_float4(J.w1[(size_t)c0 * IN + i], J.w1[(size_t)(c0 + 1) * IN + i],
-                                        J.w1[(size_t)(c0 + 2) * IN + i], J.w1[(size_t)(c0 + 3) * IN + i]);
-            W1t[e] = v;
-        }
+    stage_linear(lds, J.packed + PACK_FWD, PACK_DX, tid);
     __syncthreads();
 
     const int j = lane & 31, h = lane >> 5;
@@ -274,6 +286,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             __builtin_amdgcn_sched_barrier(0);
+            float4 hv[4];                                   // this block's h2 values: in flight during the MFMAs
+            {
+                const float* hp = J.h2 + (valid ? row : 0) * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[blk][r] = 0.f;
 #pragma unroll
@@ -287,11 +305,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                     d[blk] = mfma32(w.w, g[bp][4 * q + 3], d[blk]);
                 }
             if (valid) {
-                const float* hp = J.h2 + row * EH;
                 float* o = J.g2 + row * EH;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 a = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+                    const float4 a = hv[q];
                     d[blk][4 * q + 0] = a.x > 0.f ? d[blk][4 * q + 0] : 0.f;
                     d[blk][4 * q + 1] = a.y > 0.f ? d[blk][4 * q + 1] : 0.f;
                     d[blk][4 * q + 2] = a.z > 0.f ? d[blk][4 * q + 2] : 0.f;
@@ -308,6 +325,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             __builtin_amdgcn_sched_barrier(0);
+            float4 hv[4];
+            {
+                const float* hp = J.h1 + (valid ? row : 0) * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[blk][r] = 0.f;
 #pragma unroll
@@ -321,11 +344,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                     g[blk] = mfma32(w.w, d[bp][4 * q + 3], g[blk]);
                 }
             if (valid) {
-                const float* hp = J.h1 + row * EH;
                 float* o = J.g1 + row * EH;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 a = *reinterpret_cast<const float4*>(hp + feat0(blk, q, h));
+                    const float4 a = hv[q];
                     g[blk][4 * q + 0] = a.x > 0.f ? g[blk][4 * q + 0] : 0.f;
                     g[blk][4 * q + 1] = a.y > 0.f ? g[blk][4 * q + 1] : 0.f;
                     g[blk][4 * q + 2] = a.z > 0.f ? g[blk][4 * q + 2] : 0.f;
@@ -395,39 +417,51 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     float s3 = 0.f, s2 = 0.f, s1 = 0.f;
     const int fa = 32 * mb + i;                 // A column (feature of G)
     const int fb = 64 * nh + 2 * i;             // first of the two B columns (features of H)
-    // k-steps in batches of DW_U: all loads of a batch are issued before its MFMAs (the operands come from L2 / the
-    // Infinity Cache, several hundred cycles away; the second wave of the SIMD covers the rest)
+    // k-steps in batches of DW_U, software-pipelined over two register sets: the loads of batch t+1 are issued
+    // before the MFMAs of batch t (the operands come from L2 / the Infinity Cache, several hundred cycles away)
     constexpr int DW_U = 4;
     const float* gpool = J.g_pooled;
     const float* gmsg = J.g_msgs;
-    for (long long rr = r0; rr < r1; rr += 2 * DW_U) {
-        float a3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U];
-        float2 b3[DW_U], b2[DW_U];
+    struct Batch { float a3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U]; float2 b3[DW_U], b2[DW_U]; };
+    auto load = [&](long long rr, Batch& B) {
 #pragma unroll
         for (int u = 0; u < DW_U; ++u) {
             const long long row = rr + 2 * u + h;
             const bool ok = row < r1;
-            const long long ro = ok ? row : r0;            // clamped: always a readable row
+            const long long ro = ok ? row : r0;            // clamped: always a readable row (r0 < R whenever r0 < r1)
             float v = gpool ? gpool[(ro / K) * EH + fa] : 0.f;
             if (gmsg) v += gmsg[ro * EH + fa];
-            a3[u] = ok ? v * scale : 0.f;
+            B.a3[u] = ok ? v * scale : 0.f;
             const float w2 = J.g2[ro * EH + fa], w1 = J.g1[ro * EH + fa];
-            a2[u] = ok ? w2 : 0.f;
-            a1[u] = ok ? w1 : 0.f;
+            B.a2[u] = ok ? w2 : 0.f;
+            B.a1[u] = ok ? w1 : 0.f;
             const float2 p3 = *reinterpret_cast<const float2*>(J.h2 + ro * EH + fb);
             const float2 p2 = *reinterpret_cast<const float2*>(J.h1 + ro * EH + fb);
-            b3[u] = ok ? p3 : make_float2(0.f, 0.f);
-            b2[u] = ok ? p2 : make_float2(0.f, 0.f);
-            bx[u] = (ok && nh == 0 && i < IN) ? J.x[ro * IN + i] : 0.f;
+            B.b3[u] = ok ? p3 : make_float2(0.f, 0.f);
+            B.b2[u] = ok ? p2 : make_float2(0.f, 0.f);
+            B.bx[u] = (ok && nh == 0 && i < IN) ? J.x[ro * IN + i] : 0.f;
         }
+    };
+    auto fma = [&](const Batch& B) {
 #pragma unroll
         for (int u = 0; u < DW_U; ++u) {
-            c3[0] = mfma32(a3[u], b3[u].x, c3[0]);
-            c3[1] = mfma32(a3[u], b3[u].y, c3[1]);
-            c2[0] = mfma32(a2[u], b2[u].x, c2[0]);
-            c2[1] = mfma32(a2[u], b2[u].y, c2[1]);
-            if (nh == 0) c1 = mfma32(a1[u], bx[u], c1);
-            s3 += a3[u]; s2 += a2[u]; s1 += a1[u];
+            c3[0] = mfma32(B.a3[u], B.b3[u].x, c3[0]);
+            c3[1] = mfma32(B.a3[u], B.b3[u].y, c3[1]);
+            c2[0] = mfma32(B.a2[u], B.b2[u].x, c2[0]);
+            c2[1] = mfma32(B.a2[u], B.b2[u].y, c2[1]);
+            if (nh == 0) c1 = mfma32(B.a1[u], B.bx[u], c1);
+            s3 += B.a3[u]; s2 += B.a2[u]; s1 += B.a1[u];
+        }
+    };
+    if (r0 < r1) {
+        Batch X, Y;
+        load(r0, X);
+        for (long long rr = r0; rr < r1; rr += 4 * DW_U) {
+            load(rr + 2 * DW_U, Y);
+            fma(X);
+            if (rr + 2 * DW_U >= r1) break;
+            load(rr + 4 * DW_U, X);
+            fma(Y);
         }
     }
     float* P = J.partials + (size_t)p * ENC_PART;
@@ -463,7 +497,16 @@ static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, l
 }
 
 static bool branch_ok(const piml_encoder_branch& b) {
-    return b.rows > 0 && b.in_dim >= 1 && b.in_dim <= 8 && b.x && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3;
+    return b.rows > 0 && b.in_dim >= 1 && b.in_dim <= 8 && b.x && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 &&
+           b.packed;
+}
+
+static int fill_args(EncArgs& A, const piml_encoder_branch* br, int nbr) {
+    A.nbr = nbr;
+    for (int i = 0; i < nbr; ++i) A.br[i] = br[i];
+    if (nbr == 1) A.br[1] = br[0];
+    A.wg_split = split_workgroups(br, nbr, 256, 1);
+    return 256;
 }
 
 }  // namespace piml
@@ -482,17 +525,25 @@ PIML_API int piml_encoder_workgroups(const piml_encoder_branch* br, int nbr, int
     return total;
 }
 
+PIML_API int piml_encoder_pack_floats(void) { return PACK_FLOATS; }
+
+PIML_API int piml_encoder_pack(const piml_encoder_branch* br, int nbr, void* stream) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    for (int i = 0; i < nbr; ++i)
+        if (!branch_ok(br[i])) return hipErrorInvalidValue;
+    EncArgs A;
+    fill_args(A, br, nbr);
+    hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
+    return hipGetLastError();
+}
+
 PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stream) {
     if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
-    EncArgs A;
-    A.nbr = nbr;
-    for (int i = 0; i < nbr; ++i) {
+    for (int i = 0; i < nbr; ++i)
         if (!branch_ok(br[i]) || !br[i].msgs) return hipErrorInvalidValue;
-        A.br[i] = br[i];
-    }
-    if (nbr == 1) A.br[1] = br[0];
-    const int total = 256;
-    A.wg_split = split_workgroups(br, nbr, total, 1);
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_kernel),
@@ -515,17 +566,13 @@ PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float
 
 PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) {
     if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
-    EncArgs A;
-    A.nbr = nbr;
     for (int i = 0; i < nbr; ++i) {
         const piml_encoder_branch& b = br[i];
         if (!branch_ok(b) || !b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || b.k < 1 || (!b.g_pooled && !b.g_msgs))
             return hipErrorInvalidValue;
-        A.br[i] = b;
     }
-    if (nbr == 1) A.br[1] = br[0];
-    const int total = 256;
-    A.wg_split = split_workgroups(br, nbr, total, 1);
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_kernel),

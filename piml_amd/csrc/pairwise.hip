@@ -434,25 +434,35 @@ __device__ __forceinline__ bool collide(const float2* __restrict__ p, int N, int
     return norm2(pj.x - pi.x, pj.y - pi.y) < th;           // NaN compares false -> 0
 }
 
-__global__ __launch_bounds__(256) void collision_counts_kernel(const float2* __restrict__ p, int S, int N,
-                                                               const float* __restrict__ thr, int nthr,
-                                                               float* __restrict__ counts) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
+// General path (more than 25 slices, e.g. the (t, N, 2) rollouts of the evaluation): one wavefront per agent i.
+// Pass 1, per block of 64 partners j: the pair's collisions summed over all slices (the friends total).  Pass 2,
+// only for the (few) partners that collide at all and are not friends: lanes take slices and bump a wave-private
+// per-slice counter in LDS.  Every count is written exactly once with a plain store (no atomics, no zero fill).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void collision_counts_kernel(const float2* __restrict__ p, int S, int N,
+                                                                       const float* __restrict__ thr, int nthr,
+                                                                       float* __restrict__ counts) {
+    extern __shared__ float cc_lds[];                       // WAVES x S per-slice counters
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * WAVES + wave;
+    if (i >= N) return;                                     // wave-uniform; no block barrier below
+    float* cnt = cc_lds + (size_t)wave * S;
     for (int h = 0; h < nthr; ++h) {
         const float th = thr[h];
+        for (int s = lane; s < S; s += 64) cnt[s] = 0.f;
         for (int j0 = 0; j0 < N; j0 += 64) {
             const int j = j0 + lane;
             int total = 0;
             for (int s = 0; s < S; ++s) total += collide(p, N, s, i, j, th) ? 1 : 0;
-            if (__builtin_amdgcn_ballot_w64(total > 0) == 0) continue;
-            const bool keep = total <= 25;                  // friends rule, data.py:587-591
-            for (int s = 0; s < S; ++s) {
-                const u64 m = __builtin_amdgcn_ballot_w64(keep && collide(p, N, s, i, j, th));
-                if (m && lane == 0) counts[((size_t)h * S + s) * N + i] += (float)__builtin_popcountll(m);
+            u64 m = __builtin_amdgcn_ballot_w64(total > 0 && total <= 25);     // friends rule, data.py:587-591
+            while (m) {
+                const int jj = j0 + __builtin_ctzll(m);
+                m &= m - 1;
+                for (int s = lane; s < S; s += 64)
+                    if (collide(p, N, s, i, jj, th)) cnt[s] += 1.f;
             }
         }
+        for (int s = lane; s < S; s += 64) counts[((size_t)h * S + s) * N + i] = cnt[s];
     }
 }
 
@@ -671,10 +681,23 @@ PIML_API int piml_collision_counts(const float* position, int S, int N, const fl
 #undef PIML_CC_LAUNCH
         return hipGetLastError();
     }
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(float) * (size_t)n_thresholds * S * N, as_stream(stream));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(collision_counts_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
-                       (const float2*)position, S, N, thresholds, n_thresholds, counts);
+    // wave-private per-slice counters in LDS: 4 agents per block up to 4096 slices (64 KiB), one beyond (40 960 at most)
+    if (S <= 4096) {
+        hipLaunchKernelGGL(collision_counts_kernel<4>, dim3((N + 3) / 4), dim3(256), sizeof(float) * 4 * (size_t)S,
+                           as_stream(stream), (const float2*)position, S, N, thresholds, n_thresholds, counts);
+    } else if (S <= 40960) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(collision_counts_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 40960 * 4);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(collision_counts_kernel<1>, dim3(N), dim3(64), sizeof(float) * (size_t)S, as_stream(stream),
+                           (const float2*)position, S, N, thresholds, n_thresholds, counts);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -68,6 +68,7 @@ def get_args(argv=None):
     A('--collision_loss_version', type=str, default='v0')
     A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
     A('--tunableop', type=int, default=0, help='1: load the pre-tuned GEMM selections (piml_amd/tuning)')
+    A('--hip_graph', type=int, default=1, help='0: run the fine-tuning step eagerly instead of replaying a captured HIP graph')
     A('--fix_dest_norm', action='store_true',
       help='desired-force direction normalised per agent for channelled (C, N, 7) input too; the reference reduces '
            'over dim=1 = the AGENT axis there (src/models/model.py:1290, SURVEY quirk Q2), which stays the default')

@@ -34,6 +34,9 @@ FUSED_GLUE = os.environ.get('PIML_FUSED_GLUE', '1') != '0'
 # latency-bound either way and the library chain is kept.
 FUSED_ENCODER = os.environ.get('PIML_FUSED_ENCODER', '1') != '0'
 FUSED_ENCODER_MIN_ROWS = int(os.environ.get('PIML_FUSED_ENCODER_MIN_ROWS', '512'))
+# ... and for `pinnsf` / `pinnsf_m` the decoder tail too (piml_amd/csrc/decoder.hip): the whole network is one autograd
+# node (ops.fused_pinnsf).  PIML_FUSED_NETWORK=0 keeps the decoders / predictors on library GEMMs.
+FUSED_NETWORK = os.environ.get('PIML_FUSED_NETWORK', '1') != '0'
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -250,8 +253,48 @@ class _PINNSFBase(nn.Module):
         acc = predictor(decoder(pooled))
         return acc, emb, None, emb
 
+    def _fused_network(self, ped_features, obs_features, self_features):
+        """`pinnsf` / `pinnsf_m` with the reference's default geometry: the whole network -- both encoders, processor
+        scale, neighbour-axis sum, decoders, predictors and the desired-force term -- as one autograd node on the fused
+        f32-MFMA kernels (ops.fused_pinnsf).  Returns None when the configuration is not covered."""
+        if self.bottleneck or self.residual or not FUSED_NETWORK:
+            return None
+        cand = [(ped_features, self.ped_encoder, self.ped_processor, self.ped_decoder, self.ped_predictor)]
+        if self.obs_feature_dim > 0:
+            cand.append((obs_features, self.obs_encoder, self.obs_processor, self.obs_decoder, self.obs_predictor))
+        if not (self_features.is_cuda and self_features.dtype == torch.float32):
+            return None
+        for f, e, p, d, q in cand:
+            dl, da = d.mlp[0::2], d.mlp[1::2]
+            if not (self._encoder_fusable(f, e, p) and tuple(f.shape[:-2]) == tuple(self_features.shape[:-1])
+                    and len(dl) == 2 and (dl[0].in_features, dl[0].out_features, dl[1].out_features) == (128, 64, 64)
+                    and isinstance(da[0], nn.ReLU) and isinstance(da[1], nn.Identity) and len(q.mlp) == 2
+                    and (q.mlp[0].in_features, q.mlp[0].out_features) == (64, 2) and isinstance(q.mlp[1], nn.Identity)):
+                return None
+        from .. import ops
+        fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
+        acc, msgs = ops.fused_pinnsf(
+            [dict(x=f, scale=p.pure_scale(), encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
+                  decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
+                  predictor=[q.mlp[0].weight, q.mlp[0].bias]) for f, e, p, d, q in cand],
+            self_features, self.tau, fold_epilogue=fold)
+        if not fold:
+            if self_features.dim() == 3:
+                acc = ops.pinnsf_epilogue(acc, None, self_features, self.tau, agent_norm=True)
+            else:
+                acc = acc + self.desired_force(self_features)
+        out = [acc, msgs[0]]
+        if len(msgs) > 1:
+            out.append(msgs[1])
+        if self.collision_head is not None:        # 'msgs' (pinnsf_m): head on the pedestrian messages
+            out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
+        return out
+
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'
+        fused = self._fused_network(ped_features, obs_features, self_features)
+        if fused is not None:
+            return fused
         pre = {} if self.residual else self._fused_encoders(ped_features, obs_features)
         # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
         side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None

@@ -1088,13 +1088,14 @@ ENCODER_MAX_IN = 8
 
 
 def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
-                       g_x=None, partials=None):
+                       g_x=None, partials=None, packed=None):
     B = _lib.EncoderBranch()
     B.x, B.rows, B.in_dim, B.k = x2.data_ptr(), x2.shape[0], x2.shape[1], int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.scale = float(scale)
     B.h1, B.h2, B.msgs = _ptr(h1), _ptr(h2), _ptr(msgs)
     B.g_pooled, B.g_msgs, B.g2, B.g1, B.g_x, B.partials = [_ptr(t) for t in (g_pooled, g_msgs, g2, g1, g_x, partials)]
+    B.packed = _ptr(packed)
     return B
 
 
@@ -1119,8 +1120,9 @@ class _FusedEncoders(torch.autograd.Function):
             msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
             h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
             h2s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
-        arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b])
-                                           for b in range(nbr)])
+        packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
+        arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b],
+                                                              packed=packed[b]) for b in range(nbr)])
         outs = []
         with torch.cuda.device(dev):
             _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
@@ -1136,7 +1138,7 @@ class _FusedEncoders(torch.autograd.Function):
                     pooled = torch.empty(0, **opt)
                 outs += [msgs[b].view(*lead, ks[b], ENCODER_HIDDEN), pooled]
         ctx.save_for_backward(*x2s, *[t for t in h1s if t is not None], *[t for t in h2s if t is not None],
-                              *[w for wb in wbs for w in wb])
+                              *[w for wb in wbs for w in wb], packed)
         ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -1152,6 +1154,7 @@ class _FusedEncoders(torch.autograd.Function):
         saved = ctx.saved_tensors
         x2s, h1s, h2s = saved[:nbr], saved[nbr:2 * nbr], saved[2 * nbr:3 * nbr]
         wbs = [saved[3 * nbr + 6 * b:3 * nbr + 6 * b + 6] for b in range(nbr)]
+        packed = saved[-1]
         dev = x2s[0].device
         opt = dict(device=dev, dtype=torch.float32)
         live = [b for b in range(nbr) if gouts[2 * b] is not None or (want_pooled[b] and gouts[2 * b + 1] is not None)]
@@ -1170,7 +1173,8 @@ class _FusedEncoders(torch.autograd.Function):
             g1 = torch.empty(R, ENCODER_HIDDEN, **opt)
             gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[4 + 7 * b] else None
             keep.append((gm, gp, g2, g1, gx))
-            structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], None, h1s[b], h2s[b], gp, gm, g2, g1, gx))
+            structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], None, h1s[b], h2s[b], gp, gm, g2, g1, gx,
+                                              packed=packed[b]))
         arr = (_lib.EncoderBranch * len(live))(*structs)
         import ctypes
         w0 = ctypes.c_int(0)
@@ -1220,3 +1224,190 @@ def fused_encoders(branches):
     out = _FusedEncoders.apply(len(branches), tuple(float(b['scale']) for b in branches),
                                tuple(bool(b.get('pooled', True)) for b in branches), need_grad, *flat)
     return [(out[2 * i], out[2 * i + 1] if branches[i].get('pooled', True) else None) for i in range(len(branches))]
+
+
+# ------------------------------------------------------------------------------------------------
+# The whole non-bottleneck PINNSF network (`pinnsf`, `pinnsf_m`) as ONE autograd node on the fused f32-MFMA
+# kernels: encoders (encoder.hip) -> neighbour-axis sum + decoder + predictor + desired force (decoder.hip).
+# ------------------------------------------------------------------------------------------------
+def _dec_branch_struct(msgs, agents, k, wb, packed, pooled=None, h1=None, d2=None, g_pre2=None, g_pre1=None,
+                       g_pooled=None, partials=None):
+    B = _lib.DecoderBranch()
+    B.msgs, B.agents, B.k = msgs.data_ptr(), int(agents), int(k)
+    B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
+    B.pooled, B.h1, B.d2, B.g_pre2, B.g_pre1, B.g_pooled, B.partials = \
+        [_ptr(t) for t in (pooled, h1, d2, g_pre2, g_pre1, g_pooled, partials)]
+    B.packed = _ptr(packed)
+    return B
+
+
+class _FusedPinnsf(torch.autograd.Function):
+    """inputs: need_grad, nbr, scales, tau, fold_epilogue, self_features (..., N, 7), then per branch
+    x (..., N, k, in), encoder w1 b1 w2 b2 w3 b3, decoder w1 b1 w2 b2, predictor w b  (13 tensors).
+    outputs: acc (..., N, 2) (= predictions when fold_epilogue), msgs (..., N, k, 128) per branch."""
+    PER = 13
+
+    @staticmethod
+    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, self_features, *tensors):
+        L = _lib.lib()
+        PER = _FusedPinnsf.PER
+        xs = [tensors[PER * b] for b in range(nbr)]
+        ewb = [[_gpu_f32('encoder weight', t.detach()) for t in tensors[PER * b + 1:PER * b + 7]] for b in range(nbr)]
+        dwb = [[_gpu_f32('decoder weight', t.detach()) for t in tensors[PER * b + 7:PER * b + 13]] for b in range(nbr)]
+        dev = xs[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        H = ENCODER_HIDDEN
+        lead = tuple(xs[0].shape[:-2])
+        agents = 1
+        for d in lead:
+            agents *= d
+        sf = _gpu_f32('self_features', self_features).reshape(agents, 7) if fold_epilogue else None
+        x2s, ks, msgs, h1s, h2s = [], [], [], [], []
+        for b in range(nbr):
+            x = _gpu_f32('encoder input', xs[b])
+            if tuple(x.shape[:-2]) != lead:
+                raise ValueError('fused_pinnsf: both branches must share the leading (..., N) shape')
+            x2s.append(x.reshape(-1, x.shape[-1]))
+            ks.append(x.shape[-2])
+            R = x2s[b].shape[0]
+            msgs.append(torch.empty(R, H, **opt))
+            h1s.append(torch.empty(R, H, **opt) if need_grad else None)
+            h2s.append(torch.empty(R, H, **opt) if need_grad else None)
+        epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
+        dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+        earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
+                                                               packed=epack[b]) for b in range(nbr)])
+        pooled = [torch.empty(agents, H, **opt) if need_grad else None for _ in range(nbr)]
+        dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
+        dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
+        darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
+                                                               dh1[b], dd2[b]) for b in range(nbr)])
+        acc = torch.empty(agents, 2, **opt)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_encoder_fwd(earr, nbr, _stream()), 'piml_encoder_fwd')
+            _lib.check(L.piml_decoder_fwd(darr, nbr, _ptr(sf), float(tau), _ptr(acc), _stream()), 'piml_decoder_fwd')
+        if need_grad:
+            ctx.save_for_backward(*x2s, *h1s, *h2s, *msgs, *pooled, *dh1, *dd2, *[w for wb in ewb for w in wb],
+                                  *[w for wb in dwb for w in wb], epack, dpack, *([sf] if sf is not None else []))
+        ctx.meta = (nbr, tuple(scales), float(tau), bool(fold_epilogue), tuple(ks), [tuple(x.shape) for x in xs],
+                    tuple(self_features.shape), agents, need_grad)
+        ctx.set_materialize_grads(False)
+        return (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_acc, *g_msgs):
+        nbr, scales, tau, fold, ks, xshapes, sf_shape, agents, need_grad = ctx.meta
+        PER = _FusedPinnsf.PER
+        nin = 6 + PER * nbr
+        grads = [None] * nin
+        if not need_grad or (g_acc is None and all(g is None for g in g_msgs)):
+            return tuple(grads)
+        L = _lib.lib()
+        sv = list(ctx.saved_tensors)
+        take = lambda n: [sv.pop(0) for _ in range(n)]
+        x2s, h1s, h2s, msgs, pooled, dh1, dd2 = [take(nbr) for _ in range(7)]
+        ewb = [take(6) for _ in range(nbr)]
+        dwb = [take(6) for _ in range(nbr)]
+        epack, dpack = take(2)
+        sf = sv.pop(0) if fold else None
+        dev = x2s[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        H = ENCODER_HIDDEN
+        g_pooled = [None] * nbr
+        keep = []
+        with torch.cuda.device(dev):
+            # ---- decoder tail ----
+            if g_acc is not None:
+                ga = _gpu_f32('g_acc', g_acc).reshape(agents, 2)
+                want_self = fold and ctx.needs_input_grad[5]
+                g_self = torch.empty(agents, 7, **opt) if want_self else None
+                nwg = L.piml_decoder_workgroups(agents)
+                dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+                structs = []
+                for b in range(nbr):
+                    g_pooled[b] = torch.empty(agents, H, **opt)
+                    gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
+                    keep += [gp2, gp1]
+                    structs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
+                                                      gp2, gp1, g_pooled[b], dparts[b]))
+                darr = (_lib.DecoderBranch * nbr)(*structs)
+                _lib.check(L.piml_decoder_bwd(darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), _stream()),
+                           'piml_decoder_bwd')
+                if want_self:
+                    grads[5] = g_self.view(sf_shape)
+                for b in range(nbr):
+                    flat = sum_leading(dparts[b])
+                    o = 6 + PER * b + 7
+                    need = ctx.needs_input_grad[o:o + 6]
+                    dW1, dW2 = flat[:64 * H].view(64, H), flat[64 * H:64 * H + 4096].view(64, 64)
+                    dW3 = flat[64 * H + 4096:64 * H + 4096 + 128].view(2, 64)
+                    rest = flat[64 * H + 4096 + 128:]
+                    for jx, t in enumerate((dW1, rest[:64], dW2, rest[64:128], dW3, rest[128:130])):
+                        if need[jx]:
+                            grads[o + jx] = t
+            # ---- encoders ----
+            live = [b for b in range(nbr) if g_pooled[b] is not None or g_msgs[b] is not None]
+            if live:
+                part = L.piml_encoder_partial_floats()
+                structs = []
+                for b in live:
+                    R, in_dim = x2s[b].shape
+                    gm = _gpu_f32('g_msgs', g_msgs[b]).reshape(R, H) if g_msgs[b] is not None else None
+                    g2, g1 = torch.empty(R, H, **opt), torch.empty(R, H, **opt)
+                    gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[6 + PER * b] else None
+                    keep.append((gm, g2, g1, gx))
+                    structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], None, h1s[b], h2s[b], g_pooled[b], gm,
+                                                      g2, g1, gx, packed=epack[b]))
+                earr = (_lib.EncoderBranch * len(live))(*structs)
+                import ctypes
+                w0 = ctypes.c_int(0)
+                total = L.piml_encoder_workgroups(earr, len(live), ctypes.byref(w0))
+                slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
+                parts = [torch.empty(n, part, **opt) for n in slots]
+                for i in range(len(live)):
+                    earr[i].partials = parts[i].data_ptr()
+                _lib.check(L.piml_encoder_bwd(earr, len(live), _stream()), 'piml_encoder_bwd')
+                for i, b in enumerate(live):
+                    flat = sum_leading(parts[i])
+                    in_dim = x2s[b].shape[1]
+                    o = 6 + PER * b
+                    need = ctx.needs_input_grad[o:o + 7]
+                    if need[0]:
+                        grads[o] = keep[len(keep) - len(live) + i][3].view(xshapes[b])
+                    dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
+                    dW1 = flat[2 * H * H:2 * H * H + 8 * H].view(H, 8)[:, :in_dim]
+                    db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
+                    for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
+                        if need[jx]:
+                            grads[o + jx] = t
+        return tuple(grads)
+
+
+def fused_pinnsf(branches, self_features, tau, fold_epilogue=True):
+    """The non-bottleneck PINNSF network on the fused kernels.  branches: 1 or 2 dicts {x (..., N, k, in <= 8), scale,
+    encoder: (w1, b1, w2, b2, w3, b3), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b)}.
+    Returns (acc (..., N, 2), [msgs per branch]): acc = sum over branches of predictor(decoder(sum_k msgs)), plus the
+    desired-force term (v0 d/|d| - v) / tau of self_features (..., N, 7) when fold_epilogue."""
+    if not 1 <= len(branches) <= 2:
+        raise ValueError('fused_pinnsf: one or two branches')
+    flat = []
+    for br in branches:
+        x, e, d, p = br['x'], br['encoder'], br['decoder'], br['predictor']
+        if not x.is_cuda:
+            raise _lib.PimlHipError('fused_pinnsf: expected GPU tensors (piml_amd has no CPU path)')
+        H = ENCODER_HIDDEN
+        ok = (x.dim() >= 3 and 1 <= x.shape[-1] <= ENCODER_MAX_IN and x.numel() > 0 and
+              [tuple(t.shape) for t in e] == [(H, x.shape[-1]), (H,), (H, H), (H,), (H, H), (H,)] and
+              [tuple(t.shape) for t in d] == [(64, H), (64,), (64, 64), (64,)] and
+              [tuple(t.shape) for t in p] == [(2, 64), (2,)])
+        if not ok:
+            raise ValueError('fused_pinnsf: unsupported geometry (encoder in<=8 -> 128 x3, decoder 128 -> 64 -> 64, '
+                             'predictor 64 -> 2)')
+        flat += [x, *e, *d, *p]
+    if tuple(self_features.shape[:-1]) != tuple(branches[0]['x'].shape[:-2]) or self_features.shape[-1] != 7:
+        raise ValueError('fused_pinnsf: self_features (..., N, 7) must match the features\' leading shape')
+    need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in flat) or self_features.requires_grad)
+    out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
+                             bool(fold_epilogue), self_features, *flat)
+    return out[0], list(out[1:])

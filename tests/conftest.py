@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')      # see piml_amd/__init__.py (before any GPU call)
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, 'tests', 'golden')

@@ -138,3 +138,44 @@ def test_models_with_fused_encoder_match_library_chain(name):
         worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
     print(f'{name}: fused encoder vs library chain, max rel err {worst:.1e}')
     assert worst <= 2e-5
+
+
+@pytest.mark.parametrize('name,shape', [('PINNSF_multitask', (600,)), ('PINNSF', (600,)), ('PINNSF_multitask', (3, 250)),
+                                        ('PINNSF_multitask', (33,)), ('PINNSF_multitask', (4096,))])
+def test_fused_network_matches_plain_torch(name, shape):
+    """ops.fused_pinnsf (encoders + decoder tail + desired force as one node) vs the plain torch.nn expression of the
+    same network (PIML_FUSED_GLUE off): every output and every gradient, incl. channelled (C, N, .) input with the
+    reference's dim=1 agent norm (quirk Q2) and a ragged last tile."""
+    import types
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16,
+        decoder_hidden_layers=2, dropout=0.5, activation='relu', dataset_name='gc1560')
+    torch.manual_seed(0)
+    net = getattr(MODEL, name)(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    base = [torch.randn(*shape, 6, 6, generator=g).to(DEV), torch.randn(*shape, 10, 6, generator=g).to(DEV),
+            torch.randn(*shape, 7, generator=g).to(DEV)]
+    base[2][..., 0, :2] = 0.0          # |dest| == 0 corner of the desired-force term
+    res = {}
+    old_rows = MODEL.FUSED_ENCODER_MIN_ROWS
+    MODEL.FUSED_ENCODER_MIN_ROWS = 1
+    try:
+        for fused in (True, False):
+            MODEL.FUSED_GLUE = fused
+            ins = [t.clone().requires_grad_(True) for t in base]
+            net.zero_grad(set_to_none=True)
+            out = net(*ins)
+            (out[0].square().sum() + out[1].sum() * 1e-2 + out[2].square().sum() * 1e-3 + out[-1].sum()).backward()
+            res[fused] = [o.detach() for o in out] + [t.grad for t in ins] + \
+                [p.grad for p in net.parameters() if p.grad is not None]
+    finally:
+        MODEL.FUSED_GLUE = True
+        MODEL.FUSED_ENCODER_MIN_ROWS = old_rows
+    worst = 0.0
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
+    print(f'{name} {shape}: fused network vs plain torch, max rel err {worst:.1e}')
+    assert worst <= 2e-5

@@ -1,0 +1,60 @@
+"""GPU: captured HIP graphs must keep replaying correctly after OTHER graphs / eager work ran in between.
+On this ROCm stack that needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set by piml_amd/__init__.py and tests/conftest.py):
+with the packet capture on, memset nodes (torch's multi-block reductions zero their semaphores with hipMemsetAsync)
+are mis-ordered and a replayed reduction returns 0 / garbage.  This is what corrupted the logged losses of the second
+fine-tuning epoch (tests/test_main_gpu.py compares them with the reference)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _capture(fn):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+def test_graph_with_reductions_survives_interleaved_work():
+    assert os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
+    x = torch.rand(1 << 20, device=DEV)
+    want_i, want_f = int((x > 0.5).sum()), float(x.double().sum())
+    ga, outa = _capture(lambda: ((x > 0.5).sum(), x.sum()))
+    y = torch.rand(1 << 20, device=DEV)
+    gb, _ = _capture(lambda: ((y * 2).sum(), (y > 0.1).sum()))
+    for round_ in range(6):
+        if round_ % 2:
+            gb.replay()
+        else:
+            z = torch.rand(1 << 22, device=DEV)
+            (z > 0.3).sum().item()
+        ga.replay()
+        torch.cuda.synchronize()
+        assert int(outa[0]) == want_i and abs(float(outa[1]) - want_f) < 1.0, round_
+
+
+def test_collision_counts_general_path_in_replayed_graph():
+    """More than 25 slices = the general path of piml_collision_counts (one plain store per count, no zero fill):
+    replayed from a graph, interleaved with other work, against the (S, N, N) collision matrices."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(0)
+    p = (torch.rand(40, 150, 2, generator=g) * 6).to(DEV)
+    p[:, ::9] = float('nan')
+    want = torch.stack([ops.collision_detection(p, t).sum(-1) for t in (0.5, 0.25)])
+    gr, out = _capture(lambda: ops.collision_counts(p, (0.5, 0.25)))
+    for _ in range(4):
+        torch.rand(1 << 22, device=DEV).sum().item()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
