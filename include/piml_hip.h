@@ -364,7 +364,7 @@ int piml_probe_arith(const float* rx, const float* ry, const float* hx, const fl
  *          g_x (rows, in_dim) or NULL when the inputs need no gradient;
  *          partials: piml_encoder_workgroups() slots of piml_encoder_partial_floats() floats for THIS branch, slot p
  *          = [dW3 128x128 | dW2 128x128 | dW1 128x8 (columns >= in_dim are 0) | db3 | db2 | db1] of workgroup p's
- *          row slab; sum the slots with piml_sum_leading.  (Every slot of the branch is written.)
+ *          row slab; piml_encoder_bwd sums them into `grads` itself (one extra launch for both branches).
  */
 typedef struct piml_encoder_branch {
     const float* x;
@@ -377,6 +377,7 @@ typedef struct piml_encoder_branch {
     const float *g_pooled, *g_msgs;
     float *g2, *g1, *g_x;
     float* partials;
+    float* grads;  /* bwd out: piml_encoder_partial_floats() floats = the slots of `partials` summed (same layout) */
     float* packed; /* piml_encoder_pack_floats() floats of caller-provided scratch: the weights re-ordered into MFMA
                       operand fragments; written by piml_encoder_fwd (or piml_encoder_pack), read by piml_encoder_bwd */
 } piml_encoder_branch;
@@ -406,7 +407,7 @@ int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled,
  * bwd: g_pred (agents,2) -> g_pooled (agents,128) per branch; g_pre2 / g_pre1 (agents,64) are caller scratch;
  * g_self (agents,7, optional) = gradient of the desired-force term; partials: piml_decoder_workgroups(agents) slots of
  * piml_decoder_partial_floats() floats per branch = [dW1 64x128 | dW2 64x64 | dW3 2x64 | db1 64 | db2 64 | db3 2 +
- * 6 pad], to be summed with piml_sum_leading.
+ * 6 pad]; piml_decoder_bwd sums the slots into `grads` (same layout) itself.
  */
 typedef struct piml_decoder_branch {
     const float* msgs;
@@ -416,6 +417,7 @@ typedef struct piml_decoder_branch {
     float *pooled, *h1, *d2;
     float *g_pre2, *g_pre1, *g_pooled;
     float* partials;
+    float* grads; /* bwd out: piml_decoder_partial_floats() floats, the partial slots summed */
     float* packed;
 } piml_decoder_branch;
 

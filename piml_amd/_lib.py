@@ -23,7 +23,7 @@ class EncoderBranch(ctypes.Structure):
     _fields_ = [('x', _p), ('rows', _ll), ('in_dim', _i), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
-                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('packed', _p)]
+                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p)]
 
 
 class DecoderBranch(ctypes.Structure):
@@ -31,7 +31,7 @@ class DecoderBranch(ctypes.Structure):
     _fields_ = [('msgs', _p), ('agents', _ll), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('pooled', _p), ('h1', _p), ('d2', _p), ('g_pre2', _p), ('g_pre1', _p), ('g_pooled', _p),
-                ('partials', _p), ('packed', _p)]
+                ('partials', _p), ('grads', _p), ('packed', _p)]
 
 
 # name -> argtypes, in the order of include/piml_hip.h

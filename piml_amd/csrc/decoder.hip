@@ -398,6 +398,30 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
     }
 }
 
+__global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
+    __shared__ float4 sh[256];
+    const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const float4* parts = reinterpret_cast<const float4*>(J.partials);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < lanes)
+        for (int q = grp; q < B; q += 4) {
+            const float4 v = parts[(size_t)q * lanes + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && j < lanes) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = sh[q * 64 + lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(J.grads)[j] = s;
+    }
+}
+
 static bool dec_branch_ok(const piml_decoder_branch& b) {
     return b.agents > 0 && b.k >= 1 && b.msgs && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 && b.packed;
 }
@@ -442,7 +466,7 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     for (int i = 0; i < nbr; ++i) {
         const piml_decoder_branch& b = br[i];
         if (!dec_branch_ok(b) || b.agents != br[0].agents || !b.pooled || !b.h1 || !b.d2 || !b.g_pre2 || !b.g_pre1 ||
-            !b.g_pooled || !b.partials)
+            !b.g_pooled || !b.partials || !b.grads)
             return hipErrorInvalidValue;
         A.br[i] = b;
     }
@@ -456,5 +480,7 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     const int per = dec_dw_workgroups(br[0].agents);
     A.wg_split = per;
     hipLaunchKernelGGL(dec_bwd_dw_kernel, dim3(per * nbr), dim3(512), 0, as_stream(stream), A);
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 63) / 64, nbr), dim3(256), 0, as_stream(stream), A, per,
+                       DEC_PART / 4);
     return hipGetLastError();
 }

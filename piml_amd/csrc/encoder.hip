@@ -39,6 +39,11 @@ struct EncArgs {
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// store of 4 consecutive floats of a row (non-temporal stores were measured here: forward 47.9 -> 53.7 us, reverted)
+__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
 
 // A-fragment images of a 128 x 128 nn.Linear weight (out, in), float4 index ((blk*4 + bp)*4 + q)*64 + lane:
 //   forward:       [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
@@ -150,8 +155,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
             for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
-                        make_float4(a1[blk][4 * q], a1[blk][4 * q + 1], a1[blk][4 * q + 2], a1[blk][4 * q + 3]);
+                    store4_stream(o + feat0(blk, q, h), a1[blk][4 * q], a1[blk][4 * q + 1], a1[blk][4 * q + 2], a1[blk][4 * q + 3]);
         }
         // ---- layer 2 ----
 #pragma unroll
@@ -180,8 +184,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
             for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
-                        make_float4(a2[blk][4 * q], a2[blk][4 * q + 1], a2[blk][4 * q + 2], a2[blk][4 * q + 3]);
+                    store4_stream(o + feat0(blk, q, h), a2[blk][4 * q], a2[blk][4 * q + 1], a2[blk][4 * q + 2], a2[blk][4 * q + 3]);
         }
         // ---- layer 3 (no activation), msgs = scale * output; a1 is dead and reused ----
         const float scale = J.scale;
@@ -206,9 +209,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
                 float* o = J.msgs + row * EH;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
-                        make_float4(scale * a1[blk][4 * q], scale * a1[blk][4 * q + 1], scale * a1[blk][4 * q + 2],
-                                    scale * a1[blk][4 * q + 3]);
+                    store4_stream(o + feat0(blk, q, h), scale * a1[blk][4 * q], scale * a1[blk][4 * q + 1], scale * a1[blk][4 * q + 2], scale * a1[blk][4 * q + 3]);
             }
         }
     }
@@ -313,8 +314,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                     d[blk][4 * q + 1] = a.y > 0.f ? d[blk][4 * q + 1] : 0.f;
                     d[blk][4 * q + 2] = a.z > 0.f ? d[blk][4 * q + 2] : 0.f;
                     d[blk][4 * q + 3] = a.w > 0.f ? d[blk][4 * q + 3] : 0.f;
-                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
-                        make_float4(d[blk][4 * q], d[blk][4 * q + 1], d[blk][4 * q + 2], d[blk][4 * q + 3]);
+                    store4_stream(o + feat0(blk, q, h), d[blk][4 * q], d[blk][4 * q + 1], d[blk][4 * q + 2], d[blk][4 * q + 3]);
                 }
             } else {
 #pragma unroll
@@ -352,8 +352,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                     g[blk][4 * q + 1] = a.y > 0.f ? g[blk][4 * q + 1] : 0.f;
                     g[blk][4 * q + 2] = a.z > 0.f ? g[blk][4 * q + 2] : 0.f;
                     g[blk][4 * q + 3] = a.w > 0.f ? g[blk][4 * q + 3] : 0.f;
-                    *reinterpret_cast<float4*>(o + feat0(blk, q, h)) =
-                        make_float4(g[blk][4 * q], g[blk][4 * q + 1], g[blk][4 * q + 2], g[blk][4 * q + 3]);
+                    store4_stream(o + feat0(blk, q, h), g[blk][4 * q], g[blk][4 * q + 1], g[blk][4 * q + 2], g[blk][4 * q + 3]);
                 }
             } else {
 #pragma unroll
@@ -394,75 +393,121 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 // B: lane (n, h) = H[row 2 s + h][64 nh + 2 n + {0, 1}] (float2), so accumulator u holds dW[..][64 nh + 2 n + u].
 // Partial of workgroup p (floats): dW3 16384 | dW2 16384 | dW1 128 x 8 | db3 | db2 | db1.
 // ---------------------------------------------------------------------------------------------------------
+template <bool POOL, bool MSGS>
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int wg0 = b ? A.wg_split : 0;
     const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
-    const int p = (int)blockIdx.x - wg0;
-    const long long R = J.rows;
-    const int IN = J.in_dim, K = J.k;
-    long long slab = (R + nwg - 1) / nwg;
-    slab = (slab + 1) & ~1ll;
-    const long long r0 = (long long)p * slab;
-    const long long r1 = r0 + slab < R ? r0 + slab : R;
+    const unsigned p = (unsigned)((int)blockIdx.x - wg0);
+    const unsigned R = (unsigned)J.rows;                   // rows < 2^24 (checked on the host): 32-bit indexing
+    const unsigned IN = (unsigned)J.in_dim, K = (unsigned)J.k;
+    const unsigned kmagic = (unsigned)((0x100000000ull + K - 1) / K);      // row / K == umulhi(row, kmagic) for row * K < 2^32
+    unsigned slab = (R + nwg - 1) / nwg;
+    slab = (slab + 1) & ~1u;
+    const unsigned r0 = p * slab < R ? p * slab : R;
+    const unsigned r1 = r0 + slab < R ? r0 + slab : R;
     const int mb = wave & 3, nh = wave >> 2;
-    const int i = lane & 31, h = lane >> 5;
+    const unsigned i = lane & 31, h = lane >> 5;
     const float scale = J.scale;
 
     f32x16 c3[2], c2[2], c1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c3[0][r] = 0.f; c3[1][r] = 0.f; c2[0][r] = 0.f; c2[1][r] = 0.f; c1[r] = 0.f; }
     float s3 = 0.f, s2 = 0.f, s1 = 0.f;
-    const int fa = 32 * mb + i;                 // A column (feature of G)
-    const int fb = 64 * nh + 2 * i;             // first of the two B columns (features of H)
-    // k-steps in batches of DW_U, software-pipelined over two register sets: the loads of batch t+1 are issued
-    // before the MFMAs of batch t (the operands come from L2 / the Infinity Cache, several hundred cycles away)
+    const unsigned fa = 32 * mb + i;               // A column (feature of G)
+    const unsigned fb = 64 * nh + 2 * i;           // first of the two B columns (features of H)
+    // k-steps (2 rows each) in batches of DW_U, software-pipelined over two register sets: the loads of batch t+1
+    // are issued before the MFMAs of batch t (operands come from L2 / the Infinity Cache, hundreds of cycles away)
     constexpr int DW_U = 4;
-    const float* gpool = J.g_pooled;
-    const float* gmsg = J.g_msgs;
-    struct Batch { float a3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U]; float2 b3[DW_U], b2[DW_U]; };
-    auto load = [&](long long rr, Batch& B) {
+    const float* __restrict__ gpool = J.g_pooled;
+    const float* __restrict__ gmsg = J.g_msgs;
+    const float* __restrict__ G2 = J.g2;
+    const float* __restrict__ G1 = J.g1;
+    const float* __restrict__ H2 = J.h2;
+    const float* __restrict__ H1 = J.h1;
+    const float* __restrict__ X = J.x;
+    const bool wx = nh == 0 && i < IN;
+    // a batch holds RAW loaded values only: any arithmetic on them here would make the load phase wait for its own
+    // loads (the point is to have them in flight during the previous batch's MFMAs)
+    struct Batch { float p3[DW_U], m3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U]; float2 b3[DW_U], b2[DW_U]; };
+    const unsigned xi = i < IN ? i : 0;            // the x column this lane reads (always in range; masked in fma)
+    // fast path: all 2 * DW_U rows of the batch exist (rr + 2 * DW_U <= R); one address per array, the k-steps are
+    // immediate offsets (2 rows = 1 KiB apart)
+    auto load = [&](unsigned rr, Batch& B) {
+        const unsigned row0 = rr + h;
+        const float* g2p = G2 + row0 * EH + fa;
+        const float* g1p = G1 + row0 * EH + fa;
+        const float* h2p = H2 + row0 * EH + fb;
+        const float* h1p = H1 + row0 * EH + fb;
+        const float* gmp = gmsg + row0 * EH + fa;
+        const float* xp = X + row0 * IN + xi;
 #pragma unroll
         for (int u = 0; u < DW_U; ++u) {
-            const long long row = rr + 2 * u + h;
-            const bool ok = row < r1;
-            const long long ro = ok ? row : r0;            // clamped: always a readable row (r0 < R whenever r0 < r1)
-            float v = gpool ? gpool[(ro / K) * EH + fa] : 0.f;
-            if (gmsg) v += gmsg[ro * EH + fa];
-            B.a3[u] = ok ? v * scale : 0.f;
-            const float w2 = J.g2[ro * EH + fa], w1 = J.g1[ro * EH + fa];
-            B.a2[u] = ok ? w2 : 0.f;
-            B.a1[u] = ok ? w1 : 0.f;
-            const float2 p3 = *reinterpret_cast<const float2*>(J.h2 + ro * EH + fb);
-            const float2 p2 = *reinterpret_cast<const float2*>(J.h1 + ro * EH + fb);
-            B.b3[u] = ok ? p3 : make_float2(0.f, 0.f);
-            B.b2[u] = ok ? p2 : make_float2(0.f, 0.f);
-            B.bx[u] = (ok && nh == 0 && i < IN) ? J.x[ro * IN + i] : 0.f;
+            B.p3[u] = POOL ? gpool[__umulhi(row0 + 2 * u, kmagic) * EH + fa] : 0.f;
+            B.m3[u] = MSGS ? gmp[2 * u * EH] : 0.f;
+            B.a2[u] = g2p[2 * u * EH];
+            B.a1[u] = g1p[2 * u * EH];
+            B.b3[u] = *reinterpret_cast<const float2*>(h2p + 2 * u * EH);
+            B.b2[u] = *reinterpret_cast<const float2*>(h1p + 2 * u * EH);
+            B.bx[u] = xp[2 * u * IN];
         }
     };
     auto fma = [&](const Batch& B) {
 #pragma unroll
         for (int u = 0; u < DW_U; ++u) {
-            c3[0] = mfma32(B.a3[u], B.b3[u].x, c3[0]);
-            c3[1] = mfma32(B.a3[u], B.b3[u].y, c3[1]);
+            const float a3 = (B.p3[u] + B.m3[u]) * scale;
+            c3[0] = mfma32(a3, B.b3[u].x, c3[0]);
+            c3[1] = mfma32(a3, B.b3[u].y, c3[1]);
             c2[0] = mfma32(B.a2[u], B.b2[u].x, c2[0]);
             c2[1] = mfma32(B.a2[u], B.b2[u].y, c2[1]);
-            if (nh == 0) c1 = mfma32(B.a1[u], B.bx[u], c1);
-            s3 += B.a3[u]; s2 += B.a2[u]; s1 += B.a1[u];
+            if (nh == 0) c1 = mfma32(B.a1[u], wx ? B.bx[u] : 0.f, c1);
+            s3 += a3; s2 += B.a2[u]; s1 += B.a1[u];
         }
     };
-    if (r0 < r1) {
-        Batch X, Y;
-        load(r0, X);
-        for (long long rr = r0; rr < r1; rr += 4 * DW_U) {
-            load(rr + 2 * DW_U, Y);
-            fma(X);
-            if (rr + 2 * DW_U >= r1) break;
-            load(rr + 4 * DW_U, X);
-            fma(Y);
+    unsigned rr = r0;
+    if (R >= 2 * DW_U && r0 + 2 * DW_U <= r1) {
+        // no branch between a load phase and the MFMAs that follow it (a join makes hipcc wait for vmcnt(0), i.e. for
+        // the loads just issued).  The prefetch of the batch after the last one reads rows of the NEXT slab (unused);
+        // its start is clamped (a scalar min) so that it stays inside the arrays.
+        Batch Xb, Yb;
+        const unsigned nfull = (r1 - r0) / (2 * DW_U);
+        const unsigned rsafe = R - 2 * DW_U;
+        load(rr, Xb);
+        unsigned t = 0;
+        for (; t + 1 < nfull; t += 2) {
+            load(min(rr + 2 * DW_U, rsafe), Yb);
+            fma(Xb);
+            load(min(rr + 4 * DW_U, rsafe), Xb);
+            fma(Yb);
+            rr += 4 * DW_U;
         }
+        if (t < nfull) {           // odd count: the last full batch is in Xb
+            fma(Xb);
+            rr += 2 * DW_U;
+        }
+    }
+    // ragged tail of the slab (fewer than 2 * DW_U rows): masked k-steps, once
+    for (; rr < r1; rr += 2) {
+        const unsigned row = rr + h;
+        const bool ok = row < r1;
+        const unsigned ro = ok ? row : r0;
+        float v = 0.f;
+        if (POOL) v = gpool[__umulhi(ro, kmagic) * EH + fa];
+        if (MSGS) v += gmsg[ro * EH + fa];
+        const float a3 = ok ? v * scale : 0.f;
+        const float a2 = ok ? G2[ro * EH + fa] : 0.f, a1 = ok ? G1[ro * EH + fa] : 0.f;
+        const float2 z = make_float2(0.f, 0.f);
+        const float2 b3 = ok ? *reinterpret_cast<const float2*>(H2 + ro * EH + fb) : z;
+        const float2 b2 = ok ? *reinterpret_cast<const float2*>(H1 + ro * EH + fb) : z;
+        const float bx = (ok && wx) ? X[ro * IN + xi] : 0.f;
+        c3[0] = mfma32(a3, b3.x, c3[0]);
+        c3[1] = mfma32(a3, b3.y, c3[1]);
+        c2[0] = mfma32(a2, b2.x, c2[0]);
+        c2[1] = mfma32(a2, b2.y, c2[1]);
+        if (nh == 0) c1 = mfma32(a1, bx, c1);
+        s3 += a3; s2 += a2; s1 += a1;
     }
     float* P = J.partials + (size_t)p * ENC_PART;
     // accumulator u, register r, lane (n, h): dW[32 mb + (r & 3) + 8 (r >> 2) + 4 h][64 nh + 2 n + u]
@@ -485,6 +530,43 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     }
 }
 
+// grads[j] = sum over the branch's partial slots, fixed order (group g takes slots g, g+4, ...; groups added 0..3);
+// blockIdx.y = branch.  Replaces one piml_sum_leading launch per branch.
+__global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes) {
+    __shared__ float4 sh[256];
+    const int b = blockIdx.y;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int B = b ? 256 - A.wg_split : (A.nbr > 1 ? A.wg_split : 256);
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const float4* parts = reinterpret_cast<const float4*>(J.partials);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < lanes) {
+        int q = grp;
+        for (; q + 12 < B; q += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(q + 4 * u) * lanes + j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; q < B; q += 4) {
+            const float4 v = parts[(size_t)q * lanes + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && j < lanes) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = sh[q * 64 + lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(J.grads)[j] = s;
+    }
+}
+
 static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, long long unit) {
     // workgroups for branch 0, proportional to the rows (each branch gets at least one)
     if (nbr < 2) return total;
@@ -497,7 +579,7 @@ static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, l
 }
 
 static bool branch_ok(const piml_encoder_branch& b) {
-    return b.rows > 0 && b.in_dim >= 1 && b.in_dim <= 8 && b.x && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 &&
+    return b.rows > 0 && b.rows < (1ll << 24) && b.in_dim >= 1 && b.in_dim <= 8 && b.x && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 &&
            b.packed;
 }
 
@@ -568,7 +650,8 @@ PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stre
     if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
     for (int i = 0; i < nbr; ++i) {
         const piml_encoder_branch& b = br[i];
-        if (!branch_ok(b) || !b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || b.k < 1 || (!b.g_pooled && !b.g_msgs))
+        if (!branch_ok(b) || !b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 ||
+            (!b.g_pooled && !b.g_msgs))
             return hipErrorInvalidValue;
     }
     EncArgs A;
@@ -583,6 +666,28 @@ PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stre
     hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, as_stream(stream), A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(enc_bwd_dw_kernel, dim3(total), dim3(ENC_THREADS), 0, as_stream(stream), A);
+    // both branches of a launch share the kernel variant: a branch without one of the two upstream gradients gets a
+    // zero-filled stand-in from the caller side?  No: variants are chosen per launch only when the branches agree;
+    // otherwise the general (POOL && MSGS) variant is not applicable, so the branches are launched separately.
+    auto launch_dw = [&](const EncArgs& B, int grid) {
+        const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
+        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
+        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
+        else hipLaunchKernelGGL((enc_bwd_dw_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
+    };
+    const bool same = nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) &&
+                                   (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr));
+    if (same) {
+        launch_dw(A, total);
+    } else {                 // different upstream combinations: one launch per branch, each on its own share of the slots
+        for (int i = 0; i < 2; ++i) {
+            EncArgs B = A;
+            B.nbr = 1;
+            B.br[0] = B.br[1] = A.br[i];
+            launch_dw(B, i == 0 ? A.wg_split : total - A.wg_split);
+        }
+    }
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 63) / 64, nbr), dim3(256), 0, as_stream(stream), A,
+                       ENC_PART / 4);
     return hipGetLastError();
 }

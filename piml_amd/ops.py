@@ -1088,14 +1088,14 @@ ENCODER_MAX_IN = 8
 
 
 def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
-                       g_x=None, partials=None, packed=None):
+                       g_x=None, partials=None, packed=None, grads=None):
     B = _lib.EncoderBranch()
     B.x, B.rows, B.in_dim, B.k = x2.data_ptr(), x2.shape[0], x2.shape[1], int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.scale = float(scale)
     B.h1, B.h2, B.msgs = _ptr(h1), _ptr(h2), _ptr(msgs)
     B.g_pooled, B.g_msgs, B.g2, B.g1, B.g_x, B.partials = [_ptr(t) for t in (g_pooled, g_msgs, g2, g1, g_x, partials)]
-    B.packed = _ptr(packed)
+    B.packed, B.grads = _ptr(packed), _ptr(grads)
     return B
 
 
@@ -1181,13 +1181,14 @@ class _FusedEncoders(torch.autograd.Function):
         total = L.piml_encoder_workgroups(arr, len(live), ctypes.byref(w0))
         slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
         parts = [torch.empty(n, part, **opt) for n in slots]
+        flats = [torch.empty(part, **opt) for _ in slots]
         for i in range(len(live)):
-            arr[i].partials = parts[i].data_ptr()
+            arr[i].partials, arr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
         with torch.cuda.device(dev):
             _lib.check(L.piml_encoder_bwd(arr, len(live), _stream()), 'piml_encoder_bwd')
         H = ENCODER_HIDDEN
         for i, b in enumerate(live):
-            flat = sum_leading(parts[i])
+            flat = flats[i]
             in_dim = x2s[b].shape[1]
             need = ctx.needs_input_grad[4 + 7 * b:4 + 7 * b + 7]
             o = 4 + 7 * b
@@ -1231,13 +1232,13 @@ def fused_encoders(branches):
 # kernels: encoders (encoder.hip) -> neighbour-axis sum + decoder + predictor + desired force (decoder.hip).
 # ------------------------------------------------------------------------------------------------
 def _dec_branch_struct(msgs, agents, k, wb, packed, pooled=None, h1=None, d2=None, g_pre2=None, g_pre1=None,
-                       g_pooled=None, partials=None):
+                       g_pooled=None, partials=None, grads=None):
     B = _lib.DecoderBranch()
     B.msgs, B.agents, B.k = msgs.data_ptr(), int(agents), int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.pooled, B.h1, B.d2, B.g_pre2, B.g_pre1, B.g_pooled, B.partials = \
         [_ptr(t) for t in (pooled, h1, d2, g_pre2, g_pre1, g_pooled, partials)]
-    B.packed = _ptr(packed)
+    B.packed, B.grads = _ptr(packed), _ptr(grads)
     return B
 
 
@@ -1324,20 +1325,21 @@ class _FusedPinnsf(torch.autograd.Function):
                 g_self = torch.empty(agents, 7, **opt) if want_self else None
                 nwg = L.piml_decoder_workgroups(agents)
                 dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+                dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
                 structs = []
                 for b in range(nbr):
                     g_pooled[b] = torch.empty(agents, H, **opt)
                     gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
                     keep += [gp2, gp1]
                     structs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
-                                                      gp2, gp1, g_pooled[b], dparts[b]))
+                                                      gp2, gp1, g_pooled[b], dparts[b], dflats[b]))
                 darr = (_lib.DecoderBranch * nbr)(*structs)
                 _lib.check(L.piml_decoder_bwd(darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), _stream()),
                            'piml_decoder_bwd')
                 if want_self:
                     grads[5] = g_self.view(sf_shape)
                 for b in range(nbr):
-                    flat = sum_leading(dparts[b])
+                    flat = dflats[b]
                     o = 6 + PER * b + 7
                     need = ctx.needs_input_grad[o:o + 6]
                     dW1, dW2 = flat[:64 * H].view(64, H), flat[64 * H:64 * H + 4096].view(64, 64)
@@ -1365,11 +1367,12 @@ class _FusedPinnsf(torch.autograd.Function):
                 total = L.piml_encoder_workgroups(earr, len(live), ctypes.byref(w0))
                 slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
                 parts = [torch.empty(n, part, **opt) for n in slots]
+                flats = [torch.empty(part, **opt) for _ in slots]
                 for i in range(len(live)):
-                    earr[i].partials = parts[i].data_ptr()
+                    earr[i].partials, earr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
                 _lib.check(L.piml_encoder_bwd(earr, len(live), _stream()), 'piml_encoder_bwd')
                 for i, b in enumerate(live):
-                    flat = sum_leading(parts[i])
+                    flat = flats[i]
                     in_dim = x2s[b].shape[1]
                     o = 6 + PER * b
                     need = ctx.needs_input_grad[o:o + 7]

@@ -660,6 +660,10 @@ def gen_mainflow(cases=('gc', 'ucy')):
                                      'obs_decoder.mlp.0.bias', 'ped_collision_predictor.mlp.2')):
                         out[f'{tag}/{k}'] = v.clone()
                 out[f'{tag}/l2'] = np.float64(sum(float((v.double() ** 2).sum()) for v in sd.values()) ** 0.5)
+            # the complete best fine-tuned weights: lets the GPU test roll the test clip with EXACTLY the reference's
+            # network, separating rollout parity from the (chaotic) accumulation of training differences
+            for k, v in best_ft.items():
+                out[f'best_ft_full/{k}'] = v.clone()
             # final test rollout with the best fine-tuned weights: positions (short horizon) + FDE of the same masks
             sim.model.load_state_dict(best_ft)
             sim.model.eval()
@@ -673,6 +677,9 @@ def gen_mainflow(cases=('gc', 'ucy')):
             out['test/mae'] = np.float64(METRIC.mae_with_time_mask(p_pred, labels, mask, reduction='mean'))
             out['test/rollout_head'] = pred.position[:args.skip_frames + 40].clone()
             out['test/mask_head'] = pred.mask_p[:args.skip_frames + 40].clone()
+            err = torch.norm(torch.nan_to_num(p_pred - labels), dim=-1) * (mask == 1)
+            out['test/mae_per_frame'] = (err.sum(-1) / (mask == 1).sum(-1).clamp(min=1)).clone()      # (T,)
+            out['test/final_position'] = p_pred[-1].clone()
             out['log'] = np.array(text)
             save('mainflow_' + case, **out)
         # the clips the flow reads travel as data fixtures (inputs), next to the other clips under tests/golden/data

@@ -120,17 +120,38 @@ def test_main_flow_matches_reference_end_to_end(case):
     report['collisions'] = rel(np.array([sim.last_eval['hard_collisions'], sim.last_eval['collisions']]) + 1.0,
                                g['ft/collisions'][-1] + 1.0)
 
-    # ---- short-horizon rollout with the best fine-tuned weights (first 40 simulated frames of the test clip) ----
+    # ---- rollout parity proper: OUR rollout with EXACTLY the reference's best fine-tuned weights (the training
+    # differences above do not enter): short horizon in metres, then the whole-horizon metrics ----
     d = run['finetune_data'].test_data[0]
     skip = run['args'].skip_frames
+    ref_sd = {k[len('best_ft_full/'):]: torch.tensor(g[k]) for k in g.files if k.startswith('best_ft_full/')}
+    own_sd = {k: v.clone() for k, v in sim.model.state_dict().items()}
+    sim.model.load_state_dict(ref_sd)
     with torch.no_grad():
         sim.model.eval()
         pred = sim.get_multiple_rollouts(d, t_start=skip, load_model=False)
+        mask = d.mask_p_pred.long()
+        p_post = sim.post_process(d, pred.position.clone(), pred.mask_p, mask)
+        labels = d.labels[..., :2]
+        rw = dict(mae=METRIC.mae_with_time_mask(p_post, labels, mask, reduction='mean'),
+                  fde=METRIC.fde_with_time_mask(p_post, labels, mask, reduction='mean'),
+                  coll=METRIC.collision_count(pred.position[skip:], run['args'].collision_threshold, reduction='sum'),
+                  hard=METRIC.collision_count(pred.position[skip:], run['args'].collision_threshold / 2, reduction='sum'))
+        err = torch.norm(torch.nan_to_num(p_post - labels), dim=-1) * (mask == 1)
+        mae_t = (err.sum(-1) / (mask == 1).sum(-1).clamp(min=1)).cpu().numpy()
+    sim.model.load_state_dict(own_sd)
     head = torch.nan_to_num(pred.position[:skip + 40]).cpu().numpy()
     want_head = np.nan_to_num(g['test/rollout_head'])
-    err = np.abs(head - want_head).max(axis=(1, 2))
-    report['short_rollout_first10'] = float(err[skip:skip + 10].max())
-    report['short_rollout_first40'] = float(err.max())
+    herr = np.abs(head - want_head).max(axis=(1, 2))
+    report['refweights_rollout_first10_m'] = float(herr[skip:skip + 10].max())
+    report['refweights_rollout_first40_m'] = float(herr.max())
+    report['refweights_mask_head_equal'] = bool(np.array_equal(pred.mask_p[:skip + 40].cpu().numpy() > 0, g['test/mask_head'] > 0))
+    report['refweights_mae'] = rel(rw['mae'], g['test/mae'])
+    report['refweights_fde'] = rel(rw['fde'], g['test/fde'])
+    report['refweights_collisions'] = rel(np.array([rw['hard'], rw['coll']]) + 1.0, g['ft/collisions'][-1] + 1.0)
+    dm = np.abs(mae_t - g['test/mae_per_frame'])
+    report['refweights_mae_per_frame_first100_m'] = float(dm[:skip + 100].max())
+    report['refweights_mae_per_frame_all_m'] = float(dm.max())
 
     print(f'\n[cfg5 {case}] measured deviations from the reference (relative unless noted):')
     for k, v in report.items():
@@ -143,9 +164,12 @@ def test_main_flow_matches_reference_end_to_end(case):
     assert report['pre_train'] <= tol['pre_train'] and report['pre_val'] <= tol['pre_val']
     assert report['ft_train'] <= tol['ft_train']
     assert report['weights_best_pre'] <= tol['weights']
-    assert report['short_rollout_first10'] <= tol['short_rollout']      # metres, 10 frames of closed loop
+    assert report['refweights_rollout_first10_m'] <= tol['short_rollout']      # metres, 10 frames of closed loop
+    assert report['refweights_mask_head_equal']
     if os.environ.get('PIML_CFG5_REPORT_ONLY') == '1':
         return
+    assert report['refweights_mae'] <= tol['mae'] and report['refweights_fde'] <= tol['fde']
+    assert report['refweights_collisions'] <= tol['collisions']
     assert report['val'] <= tol['val']
     assert report['mae'] <= tol['mae'] and report['fde'] <= tol['fde']
     assert report['ot'] <= tol['ot'] and report['mmd'] <= tol['mmd']

@@ -3,7 +3,7 @@
 # separate PMC passes (never combined with --stats/sys traces) for the HBM traffic of the
 # relfeat kernels.  Outputs under gpurun_out/profile_round/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profile_round; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profile_round; rm -rf $O; mkdir -p $O
 ARGS="--steps 50 --warmup 10 --cpu-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
