@@ -363,7 +363,7 @@ int piml_probe_arith(const float* rx, const float* ry, const float* hx, const fl
  *       -> g2, g1 (rows, 128): caller-provided scratch, the gradients at the pre-activations of layers 2 and 1;
  *          g_x (rows, in_dim) or NULL when the inputs need no gradient;
  *          partials: piml_encoder_workgroups() slots of piml_encoder_partial_floats() floats for THIS branch, slot p
- *          = [dW3 128x128 | dW2 128x128 | dW1 128x8 (columns >= in_dim are 0) | db3 | db2 | db1] of workgroup p's
+ *          = [dW3 128x128 | dW2 128x128 | dW1 128 x in_dim (row-major, in a 1024-float field) | db3 | db2 | db1] of workgroup p's
  *          row slab; piml_encoder_bwd sums them into `grads` itself (one extra launch for both branches).
  */
 typedef struct piml_encoder_branch {
@@ -428,6 +428,35 @@ int piml_decoder_fwd(const piml_decoder_branch* branches, int nbranches, const f
                      float* acc, void* stream);
 int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const float* g_pred,
                      const float* self_features, float tau, float* g_self, void* stream);
+
+/*
+ * Collision head of `pinnsf_m` (src/models/model.py:1246, 1296-1300): out[row] = sigmoid(w2 . relu(W1 msgs[row] + b1)
+ * + b2), msgs (rows, 128), W1 (64, 128), w2 (1, 64); forward only.  `packed`: piml_collision_head_pack_floats()
+ * floats of scratch.
+ */
+int piml_collision_head_pack_floats(void);
+int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* packed, float* out, void* stream);
+
+/*
+ * RCCL exchange of agent-block sharding (the reference's only multi-GPU mechanism is
+ * nn.DataParallel, src/models/simulators.py:64-67).  `comm` is an ncclComm_t (as void*): either one the host already
+ * owns, or one made with piml_comm_unique_id (one rank) + piml_comm_init (every rank, after the 128-byte id has been
+ * distributed by the host, e.g. through the torch.distributed store).  RCCL is bound at run time (dlopen of the
+ * librccl already in the process); piml_comm_available() == 0 when there is none.  Return: 0, a hipError_t, or
+ * 10000 + ncclResult_t.
+ *   piml_allgather_state     own (floats_per_rank) -> full (world * floats_per_rank): the (p, v, a) records, 6 floats / agent
+ *   piml_reducescatter_grad  full (world * floats_per_rank) partial d/d(state) -> own (floats_per_rank), summed over ranks
+ *   piml_allreduce_sum       in place, e.g. the flat bucket [d/d(state) | weight gradients]
+ */
+typedef struct piml_comm_id { char internal[128]; } piml_comm_id;
+int piml_comm_available(void);
+int piml_comm_unique_id(piml_comm_id* id);
+int piml_comm_init(void** comm, int world, int rank, const piml_comm_id* id);
+int piml_comm_destroy(void* comm);
+int piml_allgather_state(void* comm, const float* own, size_t floats_per_rank, float* full, void* stream);
+int piml_reducescatter_grad(void* comm, const float* full, float* own, size_t floats_per_rank, void* stream);
+int piml_allreduce_sum(void* comm, float* buf, size_t count, void* stream);
 
 #ifdef __cplusplus
 }

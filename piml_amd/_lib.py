@@ -84,6 +84,15 @@ SIGNATURES = {
     'piml_decoder_workgroups': [_ll],
     'piml_decoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p, _f, _p, _p],
     'piml_decoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _p],
+    'piml_collision_head_pack_floats': [],
+    'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],
+    'piml_comm_available': [],
+    'piml_comm_unique_id': [_p],
+    'piml_comm_init': [ctypes.POINTER(_p), _i, _i, _p],
+    'piml_comm_destroy': [_p],
+    'piml_allgather_state': [_p, _p, _z, _p, _p],
+    'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
+    'piml_allreduce_sum': [_p, _p, _z, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 

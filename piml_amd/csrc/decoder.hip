@@ -28,6 +28,7 @@ constexpr int DP_T2 = DP_T3 + 128;               // [ob 2][bp 2][q 4][lane 64] f
 constexpr int DP_T1 = DP_T2 + 2 * 2 * 4 * 256;   // [blk 4][bp 2][q 4][lane 64] float4  W1^T
 constexpr int DEC_PACK = DP_T1 + 4 * 2 * 4 * 256;
 constexpr int DEC_PART = DD * DH + DD * DD + 2 * DD + DD + DD + 8;     // dW1 | dW2 | dW3 | db1 | db2 | db3 (+pad)
+constexpr int DEC_SLAB = 32;                                           // agents per workgroup of the dW kernel
 
 struct DecArgs {
     piml_decoder_branch br[2];
@@ -89,6 +90,23 @@ __global__ __launch_bounds__(256) void dec_pack_kernel(DecArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
+// pooled[a][:] = sum over the k rows of agent a of msgs (model.py:1283), both branches in one launch (blockIdx.y);
+// one float4 column per thread.  (Summing inside dec_fwd serialises k dependent load rounds in one wave: 23 us.)
+__global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
+    const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= J.agents * (DH / 4)) return;
+    const long long a = t / (DH / 4);
+    const int c = (int)(t % (DH / 4));
+    const float4* p = reinterpret_cast<const float4*>(J.msgs) + a * J.k * (DH / 4) + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < J.k; ++i) {
+        const float4 v = p[(size_t)i * (DH / 4)];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(J.pooled)[t] = s;
+}
+
 __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
     __shared__ float comb[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,30 +120,16 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
         const float4* PK = reinterpret_cast<const float4*>(J.packed);
         const float* bias = J.packed + DP_B;
         f32x16 P[4];
+        {
+            const float* base = J.pooled + (valid ? agent : 0) * DH;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
+            for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) P[blk][r] = 0.f;
-        if (valid) {
-            const float* base = J.msgs + agent * J.k * DH;
-            for (int kk = 0; kk < J.k; ++kk) {
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)kk * DH + dfeat0(blk, q, h));
-                        P[blk][4 * q] += v.x; P[blk][4 * q + 1] += v.y; P[blk][4 * q + 2] += v.z; P[blk][4 * q + 3] += v.w;
-                    }
-            }
-            if (J.pooled) {
-                float* o = J.pooled + agent * DH;
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(o + dfeat0(blk, q, h)) =
-                            make_float4(P[blk][4 * q], P[blk][4 * q + 1], P[blk][4 * q + 2], P[blk][4 * q + 3]);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + dfeat0(blk, q, h));
+                    P[blk][4 * q] = valid ? v.x : 0.f; P[blk][4 * q + 1] = valid ? v.y : 0.f;
+                    P[blk][4 * q + 2] = valid ? v.z : 0.f; P[blk][4 * q + 3] = valid ? v.w : 0.f;
+                }
         }
         // ---- decoder layer 1: 128 -> 64, ReLU ----
         f32x16 a1[2], a2[2];
@@ -340,9 +344,8 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
     const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
     const int p = (int)blockIdx.x - wg0;
     const long long R = J.agents;
-    long long slab = (R + nwg - 1) / nwg;
-    slab = (slab + 1) & ~1ll;
-    const long long r0 = (long long)p * slab;
+    const long long slab = DEC_SLAB;                       // nwg = ceil(agents / DEC_SLAB), see dec_dw_workgroups
+    const long long r0 = (long long)p * slab < R ? (long long)p * slab : R;
     const long long r1 = r0 + slab < R ? r0 + slab : R;
     const int i = lane & 31, h = lane >> 5;
     const int mb1 = w >> 2, nb1 = w & 3, mb2 = (w >> 1) & 1, nb2 = w & 1;
@@ -351,32 +354,30 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    constexpr int U = 4;
-    for (long long rr = r0; rr < r1; rr += 2 * U) {
+    // the slab is at most DEC_SLAB agents = DEC_SLAB / 2 k-steps: every load is issued before the first MFMA
+    constexpr int U = DEC_SLAB / 2;
+    {
         float a1[U], b1[U], a2[U], b2[U], a3[U], b3[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long row = rr + 2 * u + h;
+            const long long row = r0 + 2 * u + h;
             const bool ok = row < r1;
-            const long long ro = ok ? row : r0;
-            const float x1 = J.g_pre1[ro * DD + 32 * mb1 + i], y1 = J.pooled[ro * DH + 32 * nb1 + i];
-            a1[u] = ok ? x1 : 0.f; b1[u] = ok ? y1 : 0.f;
-            a2[u] = b2[u] = a3[u] = b3[u] = 0.f;
-            if (do2) {
-                const float x2 = J.g_pre2[ro * DD + 32 * mb2 + i], y2 = J.h1[ro * DD + 32 * nb2 + i];
-                a2[u] = ok ? x2 : 0.f; b2[u] = ok ? y2 : 0.f;
-            }
-            if (do3) {
-                const float x3 = i < 2 ? A.g_pred[ro * 2 + i] : 0.f, y3 = J.d2[ro * DD + 32 * nb2 + i];
-                a3[u] = ok ? x3 : 0.f; b3[u] = ok ? y3 : 0.f;
-            }
+            const long long ro = ok ? row : (r0 < R ? r0 : 0);
+            a1[u] = J.g_pre1[ro * DD + 32 * mb1 + i];
+            b1[u] = J.pooled[ro * DH + 32 * nb1 + i];
+            a2[u] = do2 ? J.g_pre2[ro * DD + 32 * mb2 + i] : 0.f;
+            b2[u] = do2 ? J.h1[ro * DD + 32 * nb2 + i] : 0.f;
+            a3[u] = (do3 && i < 2) ? A.g_pred[ro * 2 + i] : 0.f;
+            b3[u] = do3 ? J.d2[ro * DD + 32 * nb2 + i] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            c1 = dmfma(a1[u], b1[u], c1);
-            if (do2) c2 = dmfma(a2[u], b2[u], c2);
-            if (do3) c3 = dmfma(a3[u], b3[u], c3);
-            s1 += a1[u]; s2 += a2[u]; s3 += a3[u];
+            const bool ok = r0 + 2 * u + h < r1;
+            const float x1 = ok ? a1[u] : 0.f, x2 = ok ? a2[u] : 0.f, x3 = ok ? a3[u] : 0.f;
+            c1 = dmfma(x1, b1[u], c1);
+            if (do2) c2 = dmfma(x2, b2[u], c2);
+            if (do3) c3 = dmfma(x3, b3[u], c3);
+            s1 += x1; s2 += x2; s3 += x3;
         }
     }
     float* P = J.partials + (size_t)p * DEC_PART;
@@ -422,14 +423,99 @@ __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int l
     }
 }
 
-static bool dec_branch_ok(const piml_decoder_branch& b) {
-    return b.agents > 0 && b.k >= 1 && b.msgs && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 && b.packed;
+// ---------------------------------------------------------------------------------------------------------
+// collision head of `pinnsf_m` (src/models/model.py:1246 `ped_collision_predictor = MLP(128, [64, 1])`, :1296-1300):
+// out[row] = sigmoid(w2 . relu(W1 msgs[row] + b1) + b2) for every neighbour row, forward only (the reference trains the
+// head for `pinnsf_bm` only; a backward through it falls back to torch ops, ops.collision_head).
+// packed: A1 [ob 2][bp 4][q 4][lane 64] float4 | A2 [bp 2][q 4][lane 64] float4 (rows >= 1 are 0) | b1 64 | b2 1 + 3 pad
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HP_A2 = 2 * 4 * 4 * 256;
+constexpr int HP_B = HP_A2 + 2 * 4 * 256;
+constexpr int HEAD_PACK = HP_B + 68;
+
+__global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ packed) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= HEAD_PACK) return;
+    float v;
+    if (e < HP_B) {
+        const bool second = e >= HP_A2;
+        const int f = second ? e - HP_A2 : e;
+        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3, rest = f >> 10;
+        const int bp = second ? rest : (rest & 3), ob = second ? 0 : (rest >> 2);
+        const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
+        v = second ? (i < 1 ? w2[c] : 0.f) : w1[(size_t)i * DH + c];
+    } else {
+        const int g = e - HP_B;
+        v = g < 64 ? b1[g] : (g == 64 ? b2[0] : 0.f);
+    }
+    packed[e] = v;
 }
 
-static int dec_dw_workgroups(long long agents) {
-    long long n = (agents + 63) / 64;
-    return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ msgs, long long rows,
+                                                       const float* __restrict__ packed, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    if (((long long)blockIdx.x * 4 + wave) * 32 >= rows) return;
+    const bool valid = row < rows;
+    const float4* PK = reinterpret_cast<const float4*>(packed);
+    const float* bias = packed + HP_B;
+    f32x16 X[4];
+    {
+        const float* base = msgs + (valid ? row : 0) * DH;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(base + dfeat0(blk, q, h));
+                X[blk][4 * q] = v.x; X[blk][4 * q + 1] = v.y; X[blk][4 * q + 2] = v.z; X[blk][4 * q + 3] = v.w;
+            }
+    }
+    f32x16 a1[2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            a1[ob][4 * q] = bq.x; a1[ob][4 * q + 1] = bq.y; a1[ob][4 * q + 2] = bq.z; a1[ob][4 * q + 3] = bq.w;
+        }
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = PK[((ob * 4 + bp) * 4 + q) * 64 + lane];
+                a1[ob] = dmfma(w.x, X[bp][4 * q + 0], a1[ob]);
+                a1[ob] = dmfma(w.y, X[bp][4 * q + 1], a1[ob]);
+                a1[ob] = dmfma(w.z, X[bp][4 * q + 2], a1[ob]);
+                a1[ob] = dmfma(w.w, X[bp][4 * q + 3], a1[ob]);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[ob][r] = fmaxf(a1[ob][r], 0.f);
+    }
+    f32x16 a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+    if (h == 0) a2[0] = bias[64];
+#pragma unroll
+    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = PK[HP_A2 / 4 + (bp * 4 + q) * 64 + lane];
+            a2 = dmfma(w.x, a1[bp][4 * q + 0], a2);
+            a2 = dmfma(w.y, a1[bp][4 * q + 1], a2);
+            a2 = dmfma(w.z, a1[bp][4 * q + 2], a2);
+            a2 = dmfma(w.w, a1[bp][4 * q + 3], a2);
+        }
+    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-a2[0]));
 }
+
+static bool dec_branch_ok(const piml_decoder_branch& b) {
+    return b.agents > 0 && b.agents < (1ll << 21) && b.k >= 1 && b.msgs && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 && b.packed;
+}
+
+static int dec_dw_workgroups(long long agents) { return (int)((agents + DEC_SLAB - 1) / DEC_SLAB); }
 
 }  // namespace piml
 
@@ -445,7 +531,7 @@ PIML_API int piml_decoder_fwd(const piml_decoder_branch* br, int nbr, const floa
     DecArgs A = {};
     A.nbr = nbr;
     for (int i = 0; i < nbr; ++i) {
-        if (!dec_branch_ok(br[i]) || br[i].agents != br[0].agents) return hipErrorInvalidValue;
+        if (!dec_branch_ok(br[i]) || br[i].agents != br[0].agents || !br[i].pooled) return hipErrorInvalidValue;
         A.br[i] = br[i];
     }
     if (nbr == 1) A.br[1] = br[0];
@@ -453,6 +539,8 @@ PIML_API int piml_decoder_fwd(const piml_decoder_branch* br, int nbr, const floa
     A.tau = tau;
     A.acc = acc;
     hipLaunchKernelGGL(dec_pack_kernel, dim3((DEC_PACK + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
+    hipLaunchKernelGGL(dec_pool_kernel, dim3((unsigned)((br[0].agents * (DH / 4) + 255) / 256), nbr), dim3(256), 0,
+                       as_stream(stream), A);
     const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
     hipLaunchKernelGGL(dec_fwd_kernel, dim3(tiles), dim3(128), 0, as_stream(stream), A);
     return hipGetLastError();
@@ -482,5 +570,20 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     hipLaunchKernelGGL(dec_bwd_dw_kernel, dim3(per * nbr), dim3(512), 0, as_stream(stream), A);
     hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 63) / 64, nbr), dim3(256), 0, as_stream(stream), A, per,
                        DEC_PART / 4);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_head_pack_floats(void) { return HEAD_PACK; }
+
+PIML_API int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, const float* b1, const float* w2,
+                                     const float* b2, float* packed, float* out, void* stream) {
+    if (rows < 0) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!msgs || !w1 || !b1 || !w2 || !b2 || !packed || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_pack_kernel, dim3((HEAD_PACK + 255) / 256), dim3(256), 0, as_stream(stream), w1, b1, w2, b2,
+                       packed);
+    const long long tiles = (rows + 31) / 32;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), msgs, rows,
+                       packed, out);
     return hipGetLastError();
 }

@@ -393,8 +393,16 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 // B: lane (n, h) = H[row 2 s + h][64 nh + 2 n + {0, 1}] (float2), so accumulator u holds dW[..][64 nh + 2 n + u].
 // Partial of workgroup p (floats): dW3 16384 | dW2 16384 | dW1 128 x 8 | db3 | db2 | db1.
 // ---------------------------------------------------------------------------------------------------------
+// The workgroup stages batches of DW_ROWS rows of the five operand arrays (g3 computed on the fly, g2, g1, h2, h1; plus
+// the x rows) into LDS with 16-byte loads -- every global byte is fetched once per workgroup, 1 KiB per wave-instruction --
+// double-buffered: the loads of batch t+1 are in flight during the MFMAs of batch t, one barrier per batch.
+constexpr int DW_ROWS = 16;                                  // rows per batch = 8 k-steps
+constexpr int DW_BUF = 5 * DW_ROWS * EH + DW_ROWS * 8;       // floats of one LDS buffer
+constexpr int DW_LDS_FLOATS = 2 * DW_BUF;
+
 template <bool POOL, bool MSGS>
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
@@ -418,9 +426,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     float s3 = 0.f, s2 = 0.f, s1 = 0.f;
     const unsigned fa = 32 * mb + i;               // A column (feature of G)
     const unsigned fb = 64 * nh + 2 * i;           // first of the two B columns (features of H)
-    // k-steps (2 rows each) in batches of DW_U, software-pipelined over two register sets: the loads of batch t+1
-    // are issued before the MFMAs of batch t (operands come from L2 / the Infinity Cache, hundreds of cycles away)
-    constexpr int DW_U = 4;
     const float* __restrict__ gpool = J.g_pooled;
     const float* __restrict__ gmsg = J.g_msgs;
     const float* __restrict__ G2 = J.g2;
@@ -428,86 +433,68 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     const float* __restrict__ H2 = J.h2;
     const float* __restrict__ H1 = J.h1;
     const float* __restrict__ X = J.x;
-    const bool wx = nh == 0 && i < IN;
-    // a batch holds RAW loaded values only: any arithmetic on them here would make the load phase wait for its own
-    // loads (the point is to have them in flight during the previous batch's MFMAs)
-    struct Batch { float p3[DW_U], m3[DW_U], a2[DW_U], a1[DW_U], bx[DW_U]; float2 b3[DW_U], b2[DW_U]; };
-    const unsigned xi = i < IN ? i : 0;            // the x column this lane reads (always in range; masked in fma)
-    // fast path: all 2 * DW_U rows of the batch exist (rr + 2 * DW_U <= R); one address per array, the k-steps are
-    // immediate offsets (2 rows = 1 KiB apart)
-    auto load = [&](unsigned rr, Batch& B) {
-        const unsigned row0 = rr + h;
-        const float* g2p = G2 + row0 * EH + fa;
-        const float* g1p = G1 + row0 * EH + fa;
-        const float* h2p = H2 + row0 * EH + fb;
-        const float* h1p = H1 + row0 * EH + fb;
-        const float* gmp = gmsg + row0 * EH + fa;
-        const float* xp = X + row0 * IN + xi;
+    // staging role of this thread: row srow of the batch, float4 column sc4 of every array
+    const unsigned srow = tid >> 5, sc4 = (tid & 31) * 4;
+    const unsigned xrow = tid >> 3, xc = tid & 7;            // threads 0..127: the x rows
+    struct Stage { float4 pool, msg, g2, g1, h2, h1; float x; bool ok; };
+    auto stage_load = [&](unsigned rb) -> Stage {            // issue the global loads of the batch starting at row rb
+        Stage S;
+        const unsigned row = rb + srow;
+        S.ok = row < r1;
+        const unsigned ro = S.ok ? row : r0;                 // clamped: a readable row (r0 < R whenever a batch exists)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        S.pool = POOL ? *reinterpret_cast<const float4*>(gpool + __umulhi(ro, kmagic) * EH + sc4) : z;
+        S.msg = MSGS ? *reinterpret_cast<const float4*>(gmsg + ro * EH + sc4) : z;
+        S.g2 = *reinterpret_cast<const float4*>(G2 + ro * EH + sc4);
+        S.g1 = *reinterpret_cast<const float4*>(G1 + ro * EH + sc4);
+        S.h2 = *reinterpret_cast<const float4*>(H2 + ro * EH + sc4);
+        S.h1 = *reinterpret_cast<const float4*>(H1 + ro * EH + sc4);
+        const unsigned xr = rb + xrow;
+        S.x = (tid < DW_ROWS * 8 && xr < r1 && xc < IN) ? X[xr * IN + xc] : 0.f;
+        return S;
+    };
+    auto stage_write = [&](const Stage S, float* buf) {     // registers -> LDS (rows past the slab are zeros)
+        float4* d = reinterpret_cast<float4*>(buf + srow * EH + sc4);
+        const float4 g3 = make_float4((S.pool.x + S.msg.x) * scale, (S.pool.y + S.msg.y) * scale,
+                                      (S.pool.z + S.msg.z) * scale, (S.pool.w + S.msg.w) * scale);
+        auto sel = [&](const float4 v) {             // component-wise (a float4 ?: becomes a select through scratch)
+            return make_float4(S.ok ? v.x : 0.f, S.ok ? v.y : 0.f, S.ok ? v.z : 0.f, S.ok ? v.w : 0.f);
+        };
+        d[0] = sel(g3);
+        d[1 * DW_ROWS * EH / 4] = sel(S.g2);
+        d[2 * DW_ROWS * EH / 4] = sel(S.g1);
+        d[3 * DW_ROWS * EH / 4] = sel(S.h2);
+        d[4 * DW_ROWS * EH / 4] = sel(S.h1);
+        if (tid < DW_ROWS * 8) buf[5 * DW_ROWS * EH + tid] = S.x;
+    };
+    auto compute = [&](const float* buf) {
 #pragma unroll
-        for (int u = 0; u < DW_U; ++u) {
-            B.p3[u] = POOL ? gpool[__umulhi(row0 + 2 * u, kmagic) * EH + fa] : 0.f;
-            B.m3[u] = MSGS ? gmp[2 * u * EH] : 0.f;
-            B.a2[u] = g2p[2 * u * EH];
-            B.a1[u] = g1p[2 * u * EH];
-            B.b3[u] = *reinterpret_cast<const float2*>(h2p + 2 * u * EH);
-            B.b2[u] = *reinterpret_cast<const float2*>(h1p + 2 * u * EH);
-            B.bx[u] = xp[2 * u * IN];
+        for (int ks = 0; ks < DW_ROWS / 2; ++ks) {
+            const float* rowp = buf + (2 * ks + h) * EH;
+            const float a3 = rowp[fa], a2 = rowp[DW_ROWS * EH + fa], a1 = rowp[2 * DW_ROWS * EH + fa];
+            const float2 b3 = *reinterpret_cast<const float2*>(rowp + 3 * DW_ROWS * EH + fb);
+            const float2 b2 = *reinterpret_cast<const float2*>(rowp + 4 * DW_ROWS * EH + fb);
+            c3[0] = mfma32(a3, b3.x, c3[0]);
+            c3[1] = mfma32(a3, b3.y, c3[1]);
+            c2[0] = mfma32(a2, b2.x, c2[0]);
+            c2[1] = mfma32(a2, b2.y, c2[1]);
+            if (nh == 0) c1 = mfma32(a1, buf[5 * DW_ROWS * EH + (2 * ks + h) * 8 + (i & 7)] * (i < 8 ? 1.f : 0.f), c1);
+            s3 += a3; s2 += a2; s1 += a1;
         }
     };
-    auto fma = [&](const Batch& B) {
-#pragma unroll
-        for (int u = 0; u < DW_U; ++u) {
-            const float a3 = (B.p3[u] + B.m3[u]) * scale;
-            c3[0] = mfma32(a3, B.b3[u].x, c3[0]);
-            c3[1] = mfma32(a3, B.b3[u].y, c3[1]);
-            c2[0] = mfma32(B.a2[u], B.b2[u].x, c2[0]);
-            c2[1] = mfma32(B.a2[u], B.b2[u].y, c2[1]);
-            if (nh == 0) c1 = mfma32(B.a1[u], wx ? B.bx[u] : 0.f, c1);
-            s3 += a3; s2 += B.a2[u]; s1 += B.a1[u];
+    if (r0 < r1) {
+        const unsigned nb = (r1 - r0 + DW_ROWS - 1) / DW_ROWS;
+        Stage S = stage_load(r0);
+        stage_write(S, lds);
+        __syncthreads();
+        for (unsigned t = 0; t < nb; ++t) {
+            float* cur = lds + (t & 1) * DW_BUF;
+            float* nxt = lds + ((t + 1) & 1) * DW_BUF;
+            S = stage_load(r0 + (t + 1) * DW_ROWS);         // past the slab: clamped + zeroed, written but never read
+            compute(cur);
+            stage_write(S, nxt);
+            __syncthreads();
         }
-    };
-    unsigned rr = r0;
-    if (R >= 2 * DW_U && r0 + 2 * DW_U <= r1) {
-        // no branch between a load phase and the MFMAs that follow it (a join makes hipcc wait for vmcnt(0), i.e. for
-        // the loads just issued).  The prefetch of the batch after the last one reads rows of the NEXT slab (unused);
-        // its start is clamped (a scalar min) so that it stays inside the arrays.
-        Batch Xb, Yb;
-        const unsigned nfull = (r1 - r0) / (2 * DW_U);
-        const unsigned rsafe = R - 2 * DW_U;
-        load(rr, Xb);
-        unsigned t = 0;
-        for (; t + 1 < nfull; t += 2) {
-            load(min(rr + 2 * DW_U, rsafe), Yb);
-            fma(Xb);
-            load(min(rr + 4 * DW_U, rsafe), Xb);
-            fma(Yb);
-            rr += 4 * DW_U;
-        }
-        if (t < nfull) {           // odd count: the last full batch is in Xb
-            fma(Xb);
-            rr += 2 * DW_U;
-        }
-    }
-    // ragged tail of the slab (fewer than 2 * DW_U rows): masked k-steps, once
-    for (; rr < r1; rr += 2) {
-        const unsigned row = rr + h;
-        const bool ok = row < r1;
-        const unsigned ro = ok ? row : r0;
-        float v = 0.f;
-        if (POOL) v = gpool[__umulhi(ro, kmagic) * EH + fa];
-        if (MSGS) v += gmsg[ro * EH + fa];
-        const float a3 = ok ? v * scale : 0.f;
-        const float a2 = ok ? G2[ro * EH + fa] : 0.f, a1 = ok ? G1[ro * EH + fa] : 0.f;
-        const float2 z = make_float2(0.f, 0.f);
-        const float2 b3 = ok ? *reinterpret_cast<const float2*>(H2 + ro * EH + fb) : z;
-        const float2 b2 = ok ? *reinterpret_cast<const float2*>(H1 + ro * EH + fb) : z;
-        const float bx = (ok && wx) ? X[ro * IN + xi] : 0.f;
-        c3[0] = mfma32(a3, b3.x, c3[0]);
-        c3[1] = mfma32(a3, b3.y, c3[1]);
-        c2[0] = mfma32(a2, b2.x, c2[0]);
-        c2[1] = mfma32(a2, b2.y, c2[1]);
-        if (nh == 0) c1 = mfma32(a1, bx, c1);
-        s3 += a3; s2 += a2; s1 += a1;
     }
     float* P = J.partials + (size_t)p * ENC_PART;
     // accumulator u, register r, lane (n, h): dW[32 mb + (r & 3) + 8 (r >> 2) + 4 h][64 nh + 2 n + u]
@@ -516,7 +503,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
         const int orow = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h;
         *reinterpret_cast<float2*>(P + (size_t)orow * EH + fb) = make_float2(c3[0][r], c3[1][r]);
         *reinterpret_cast<float2*>(P + 16384 + (size_t)orow * EH + fb) = make_float2(c2[0][r], c2[1][r]);
-        if (nh == 0 && i < 8) P[32768 + orow * 8 + i] = c1[r];      // dW1 row-major (128, 8): column i < in_dim, rest 0
+        if (nh == 0 && i < IN) P[32768 + orow * IN + i] = c1[r];    // dW1 row-major (128, in_dim) at the head of its 1024 floats
     }
     if (nh == 0) {
         s3 += __shfl_xor(s3, 32, 64);
@@ -661,6 +648,13 @@ PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stre
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
+        const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, true>),
+                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, false>),
+                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<false, true>)};
+        for (const void* f : dw) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_FLOATS * 4);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, as_stream(stream), A);
@@ -671,9 +665,9 @@ PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stre
     // otherwise the general (POOL && MSGS) variant is not applicable, so the branches are launched separately.
     auto launch_dw = [&](const EncArgs& B, int grid) {
         const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
-        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
-        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
-        else hipLaunchKernelGGL((enc_bwd_dw_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), 0, as_stream(stream), B);
+        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
+        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
+        else hipLaunchKernelGGL((enc_bwd_dw_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
     };
     const bool same = nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) &&
                                    (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr));

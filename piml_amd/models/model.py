@@ -287,7 +287,13 @@ class _PINNSFBase(nn.Module):
         if len(msgs) > 1:
             out.append(msgs[1])
         if self.collision_head is not None:        # 'msgs' (pinnsf_m): head on the pedestrian messages
-            out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
+            head = self.ped_collision_predictor.mlp
+            if len(head) == 4 and (head[0].in_features, head[0].out_features, head[2].out_features) == (128, 64, 1) \
+                    and isinstance(head[1], nn.ReLU) and isinstance(head[3], nn.Identity):
+                out.append(ops.collision_head(msgs[0], head[0].weight, head[0].bias, head[2].weight,
+                                              head[2].bias).squeeze())
+            else:
+                out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
         return out
 
     def forward(self, ped_features, obs_features, self_features):

@@ -1195,7 +1195,7 @@ class _FusedEncoders(torch.autograd.Function):
             if need[0]:
                 grads[o] = keep[i][4].view(xshapes[b])
             dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
-            dW1 = flat[2 * H * H:2 * H * H + 8 * H].view(H, 8)[:, :in_dim]
+            dW1 = flat[2 * H * H:2 * H * H + H * in_dim].view(H, in_dim)
             db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
             for j, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
                 if need[j]:
@@ -1278,7 +1278,7 @@ class _FusedPinnsf(torch.autograd.Function):
         dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
         earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
                                                                packed=epack[b]) for b in range(nbr)])
-        pooled = [torch.empty(agents, H, **opt) if need_grad else None for _ in range(nbr)]
+        pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
         dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
@@ -1379,7 +1379,7 @@ class _FusedPinnsf(torch.autograd.Function):
                     if need[0]:
                         grads[o] = keep[len(keep) - len(live) + i][3].view(xshapes[b])
                     dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
-                    dW1 = flat[2 * H * H:2 * H * H + 8 * H].view(H, 8)[:, :in_dim]
+                    dW1 = flat[2 * H * H:2 * H * H + H * in_dim].view(H, in_dim)
                     db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
                     for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
                         if need[jx]:
@@ -1414,3 +1414,44 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True):
     out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
                              bool(fold_epilogue), self_features, *flat)
     return out[0], list(out[1:])
+
+
+class _CollisionHead(torch.autograd.Function):
+    """sigmoid(MLP(128, [64, 1])(msgs)) per neighbour row: forward on the fused MFMA kernel, backward (rare: the
+    reference trains this head for `pinnsf_bm` only) recomputed with torch ops."""
+
+    @staticmethod
+    def forward(ctx, msgs, w1, b1, w2, b2):
+        m = _gpu_f32('msgs', msgs)
+        rows = m.numel() // ENCODER_HIDDEN
+        L = _lib.lib()
+        out = torch.empty(m.shape[:-1], device=m.device, dtype=torch.float32)
+        packed = torch.empty(L.piml_collision_head_pack_floats(), device=m.device, dtype=torch.float32)
+        wb = [_gpu_f32('head weight', t.detach()) for t in (w1, b1, w2, b2)]
+        with torch.cuda.device(m.device):
+            _lib.check(L.piml_collision_head_fwd(_ptr(m), rows, *[_ptr(t) for t in wb], _ptr(packed), _ptr(out), _stream()),
+                       'piml_collision_head_fwd')
+        ctx.save_for_backward(m, *wb)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 5
+        m, w1, b1, w2, b2 = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in (m, w1, b1, w2, b2)]
+            y = torch.sigmoid(torch.relu(ins[0] @ ins[1].t() + ins[2]) @ ins[3].t() + ins[4]).squeeze(-1)
+            grads = torch.autograd.grad(y, ins, g, allow_unused=True)
+        return tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad))
+
+
+def collision_head(msgs, w1, b1, w2, b2):
+    """sigmoid(Linear(64, 1)(relu(Linear(128, 64)(msgs)))) for msgs (..., 128) -> (...,)   (model.py:1296-1300)."""
+    if not msgs.is_cuda:
+        raise _lib.PimlHipError('collision_head: expected GPU tensors (piml_amd has no CPU path)')
+    if msgs.shape[-1] != ENCODER_HIDDEN or tuple(w1.shape) != (64, ENCODER_HIDDEN) or tuple(w2.shape) != (1, 64) \
+            or tuple(b1.shape) != (64,) or tuple(b2.shape) != (1,):
+        raise ValueError('collision_head: msgs (..., 128), Linear(128, 64), Linear(64, 1) expected')
+    return _CollisionHead.apply(msgs, w1, b1, w2, b2)

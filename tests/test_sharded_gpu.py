@@ -103,3 +103,24 @@ def test_exchange_pair_around_local_step_one_rank_nccl(nccl_group):
     g_own = reduce_scatter_grad(state_all.grad, nccl_group)
     torch.cuda.synchronize()
     assert torch.equal(g_own, state_all.grad)
+
+
+def test_direct_rccl_comm_through_c_abi_one_rank():
+    """piml_comm_* / piml_allgather_state / piml_reducescatter_grad / piml_allreduce_sum (include/piml_hip.h): a
+    communicator owned by libpiml_hip.so, 1 rank on one GPU -- the collectives degenerate to copies, which is what
+    RCCL must deliver."""
+    from piml_amd.rccl import DirectComm
+    torch.cuda.set_device(0)
+    comm = DirectComm()
+    assert (comm.world, comm.rank) == (1, 0)
+    own = torch.randn(2048, 6, device=DEV)
+    full = torch.zeros(2048, 6, device=DEV)
+    comm.all_gather_into(full, own)
+    g = torch.randn(2048, 6, device=DEV)
+    back = comm.reduce_scatter(g)
+    buf = torch.randn(134277 + 2048 * 6, device=DEV)
+    want = buf.clone()
+    comm.all_reduce(buf)
+    torch.cuda.synchronize()
+    assert torch.equal(full, own) and torch.equal(back, g) and torch.equal(buf, want)
+    comm.close()
