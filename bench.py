@@ -183,7 +183,7 @@ class Step:
     """The hot path over one rank's agent block of one scene: scene tensors, model, the captured HIP graph of
     the compute part and (sharded) the eager exchange either side of it."""
 
-    def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph):
+    def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket'):
         from piml_amd import ops, _lib
         from piml_amd.models.model import PINNSF_multitask
         from piml_amd.sharded import ShardedScene
@@ -210,6 +210,10 @@ class Step:
         self.state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
         self.grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
         self.bucket = [None, None]
+        # backward exchange: 'bucket' = ONE all-reduce of [d/d(state) (N, 6) | weight gradients] (the state gradient
+        # travels N/n_own times wider than needed, but it is one latency-bound collective); 'rs' = reduce-scatter of
+        # d/d(state) to the owners + all-reduce of the weight gradients (minimum bytes, two collectives)
+        self.exchange = exchange
         self.graph, self.static_feats, self.mode = None, None, 'eager'
         self.want_graph = use_graph
 
@@ -239,7 +243,10 @@ class Step:
         # captured: ONE concatenation of the (N, 6) state gradient and all weight gradients into a static
         # bucket, so that the backward exchange is a single latency-bound all-reduce (0.9 MB at 16384 agents)
         grads = [p.grad for p in self.params if p.grad is not None]
-        self.bucket[:] = [torch.cat([self.state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
+        if self.exchange == 'bucket':
+            self.bucket[:] = [torch.cat([self.state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
+        else:
+            self.bucket[:] = [torch.cat([g.reshape(-1) for g in grads]), grads]
         return acc
 
     def exchange_forward(self):
@@ -249,9 +256,14 @@ class Step:
     def exchange_backward(self):
         from piml_amd.sharded import unflatten_gradients
         N, b0, n_own = self.N, self.b0, self.n_own
-        dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
-        self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
-        unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
+        if self.exchange == 'bucket':
+            dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
+            self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
+            unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
+        else:
+            dist.reduce_scatter_tensor(self.grad_own, self.state_all.grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
+            unflatten_gradients(self.bucket[0], self.bucket[1])
 
     def step_body(self, timer=None):
         """One forward + backward pass of the hot path over the scene, eagerly."""
@@ -389,6 +401,11 @@ def main():
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
+    ap.add_argument('--exchange', choices=('bucket', 'rs'), default='bucket',
+                    help='backward exchange of the sharded step: one all-reduce of [state gradient | weight gradients] '
+                         '(bucket) or reduce-scatter(state gradient) + all-reduce(weight gradients) (rs)')
+    ap.add_argument('--exchange-compare', type=int, default=1,
+                    help='several GPUs: also time the other --exchange variant after the timed region (informational)')
     ap.add_argument('--strong-baseline', type=int, default=1,
                     help='strong scaling on several GPUs: rank 0 also times the whole scene on one GPU (outside the timed region)')
     ap.add_argument('--tunableop', type=int, default=1,
@@ -463,7 +480,7 @@ def main():
     # pre-tuned selections are validated for the cfg3 row counts only; otherwise the branches stay on one stream.
     two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and cfg3_shapes) or args.two_streams == 2
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
-              two_streams, bool(args.graph))
+              two_streams, bool(args.graph), exchange=args.exchange)
     M_eff = st.M_eff
 
     if autotune:
@@ -590,6 +607,24 @@ def main():
     achieved = bytes_step / (ms_per_step * 1e-3) / 1e9 / world        # GB/s per GPU
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
+    # ---- the other backward-exchange variant, all ranks, outside the timed region (informational) ----
+    exchange_other = None
+    if use_dist and args.exchange_compare and (world > 1 or args.force_dist):
+        other = 'rs' if args.exchange == 'bucket' else 'bucket'
+        try:
+            alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
+                       exchange=other)
+            alt.capture()
+            k = max(10, min(args.steps, 50))
+            el = alt.time_steps(k, 5)
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_other = {'exchange': other, 'ms_per_step': float(t.item()) / k * 1e3, 'steps': k,
+                              'launch_mode': alt.mode}
+            del alt
+        except Exception as ex:   # noqa: BLE001 - informational
+            exchange_other = {'exchange': other, 'error': f'{type(ex).__name__}: {ex}'}
+
     # ---- strong scaling: the same scene on ONE GPU (rank 0, the others wait), outside the timed region ----
     same_scene_1gpu = None
     if world > 1 and scaling == 'strong' and args.strong_baseline:
@@ -661,6 +696,11 @@ def main():
                                        'the step is bound by the MLP (f32 MFMA) and VALU issue, see `kernels`',
                          'kernels': kernels},
         }
+        if use_dist:
+            out['exchange'] = {'backward': args.exchange, 'other_variant': exchange_other,
+                               'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '
+                                       'reduce-scatter(d/d(state)) + all-reduce(weight gradients); forward = one '
+                                       'all-gather of the (p,v,a) records; all issued eagerly around the captured compute'}
         if same_scene_1gpu is not None:
             out['single_gpu_same_scene'] = same_scene_1gpu
         if secondary is not None:

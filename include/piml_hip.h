@@ -103,6 +103,17 @@ int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const flo
                      int kp_eff, int ko_eff, float* g_state, float* g_destination, void* stream);
 
 /*
+ * Deterministic piml_relfeat_bwd (same gradient, no atomics, bit-reproducible; slower -- opt-in): the caller supplies the
+ * neighbour-list entries sorted by source: sorted_keys[e] = slice * N + ped_idx of entry e (C * N for an empty slot),
+ * ascending, and order[e] = row * kp_eff + slot of that entry, in a STABLE order (C * focal_count * kp_eff int64 each).
+ * accumulate != 0: g_state (C, N, 6) is added to instead of overwritten.  Every g_state element is written.
+ */
+int piml_relfeat_bwd_det(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat, const int* ped_idx,
+                         const int* obs_idx, const long long* sorted_keys, const long long* order, const float* position,
+                         int state_ld, const float* destination, int C, int N, int focal_begin, int focal_count,
+                         int kp_eff, int ko_eff, int accumulate, float* g_state, float* g_destination, void* stream);
+
+/*
  * Closed-form social-force step.  Replaces MLAPM.step (src/models/mlapm.py:10-58).
  *   position, velocity, destination (N, 2); desired_speed (N); variant 0 = 'raw', 1 = 'GC',
  *   2 = 'UCY' (with the one-line coll.unsqueeze(-1) fix the shipped code needs for N > 2);

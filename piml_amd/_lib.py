@@ -93,6 +93,7 @@ SIGNATURES = {
     'piml_allgather_state': [_p, _p, _z, _p, _p],
     'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
     'piml_allreduce_sum': [_p, _p, _z, _p],
+    'piml_relfeat_bwd_det': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 

@@ -131,6 +131,20 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
                     P[blk][4 * q + 2] = valid ? v.z : 0.f; P[blk][4 * q + 3] = valid ? v.w : 0.f;
                 }
         }
+        // every weight fragment of the three layers is requested before the first MFMA (72 x 1 KiB per wave, L2-resident):
+        // the chain below then runs at the MFMA rate instead of one L2 round trip per group of four
+        float4 w1f[2][16], w2f[2][8], w3f[8];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) w1f[ob][t] = PK[DP_A1 / 4 + (ob * 16 + t) * 64 + lane];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) w2f[ob][t] = PK[DP_A2 / 4 + (ob * 8 + t) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w3f[t] = PK[DP_A3 / 4 + t * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);       // the loads stay up here
         // ---- decoder layer 1: 128 -> 64, ReLU ----
         f32x16 a1[2], a2[2];
 #pragma unroll
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
             for (int bp = 0; bp < 4; ++bp)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 w = PK[DP_A1 / 4 + ((ob * 4 + bp) * 4 + q) * 64 + lane];
+                    const float4 w = w1f[ob][bp * 4 + q];
                     a1[ob] = dmfma(w.x, P[bp][4 * q + 0], a1[ob]);
                     a1[ob] = dmfma(w.y, P[bp][4 * q + 1], a1[ob]);
                     a1[ob] = dmfma(w.z, P[bp][4 * q + 2], a1[ob]);
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
             for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 w = PK[DP_A2 / 4 + ((ob * 2 + bp) * 4 + q) * 64 + lane];
+                    const float4 w = w2f[ob][bp * 4 + q];
                     a2[ob] = dmfma(w.x, a1[bp][4 * q + 0], a2[ob]);
                     a2[ob] = dmfma(w.y, a1[bp][4 * q + 1], a2[ob]);
                     a2[ob] = dmfma(w.z, a1[bp][4 * q + 2], a2[ob]);
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
         for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = PK[DP_A3 / 4 + (bp * 4 + q) * 64 + lane];
+                const float4 w = w3f[bp * 4 + q];
                 a3 = dmfma(w.x, a2[bp][4 * q + 0], a3);
                 a3 = dmfma(w.y, a2[bp][4 * q + 1], a3);
                 a3 = dmfma(w.z, a2[bp][4 * q + 2], a3);
@@ -248,11 +262,24 @@ __global__ __launch_bounds__(128) void dec_bwd_dx_kernel(DecArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) hv[ob][q] = *reinterpret_cast<const float4*>(hp + dfeat0(ob, q, h));
     }
+    float t3f[2];
+    float4 t2f[2][8], t1f[4][8];          // all W^T fragments requested before the first MFMA
+    t3f[0] = J.packed[DP_T3 + lane];
+    t3f[1] = J.packed[DP_T3 + 64 + lane];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) t2f[ob][t] = PK[DP_T2 / 4 + (ob * 8 + t) * 64 + lane];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) t1f[blk][t] = PK[DP_T1 / 4 + (blk * 8 + t) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g2[ob][r] = 0.f;
-        g2[ob] = dmfma(J.packed[DP_T3 + ob * 64 + lane], bg, g2[ob]);
+        g2[ob] = dmfma(t3f[ob], bg, g2[ob]);
         if (valid) {
             float* o = J.g_pre2 + agent * DD;
 #pragma unroll
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(128) void dec_bwd_dx_kernel(DecArgs A) {
         for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = PK[DP_T2 / 4 + ((ob * 2 + bp) * 4 + q) * 64 + lane];
+                const float4 w = t2f[ob][bp * 4 + q];
                 g1[ob] = dmfma(w.x, g2[bp][4 * q + 0], g1[ob]);
                 g1[ob] = dmfma(w.y, g2[bp][4 * q + 1], g1[ob]);
                 g1[ob] = dmfma(w.z, g2[bp][4 * q + 2], g1[ob]);
@@ -300,7 +327,7 @@ __global__ __launch_bounds__(128) void dec_bwd_dx_kernel(DecArgs A) {
         for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = PK[DP_T1 / 4 + ((blk * 2 + bp) * 4 + q) * 64 + lane];
+                const float4 w = t1f[blk][bp * 4 + q];
                 gpool = dmfma(w.x, g1[bp][4 * q + 0], gpool);
                 gpool = dmfma(w.y, g1[bp][4 * q + 1], gpool);
                 gpool = dmfma(w.z, g1[bp][4 * q + 2], gpool);
@@ -341,7 +368,6 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const int wg0 = b ? A.wg_split : 0;
-    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
     const int p = (int)blockIdx.x - wg0;
     const long long R = J.agents;
     const long long slab = DEC_SLAB;                       // nwg = ceil(agents / DEC_SLAB), see dec_dw_workgroups
@@ -400,14 +426,15 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
 }
 
 __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
+    // 16 float4 columns x 16 slot groups per block (the partials are few MB spread over many slots: wide grid)
     __shared__ float4 sh[256];
     const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + col;
     const float4* parts = reinterpret_cast<const float4*>(J.partials);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < lanes)
-        for (int q = grp; q < B; q += 4) {
+        for (int q = grp; q < B; q += 16) {
             const float4 v = parts[(size_t)q * lanes + j];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -415,8 +442,8 @@ __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int l
     __syncthreads();
     if (grp == 0 && j < lanes) {
 #pragma unroll
-        for (int q = 1; q < 4; ++q) {
-            const float4 v = sh[q * 64 + lane];
+        for (int q = 1; q < 16; ++q) {
+            const float4 v = sh[q * 16 + col];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         reinterpret_cast<float4*>(J.grads)[j] = s;
@@ -473,6 +500,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                 X[blk][4 * q] = v.x; X[blk][4 * q + 1] = v.y; X[blk][4 * q + 2] = v.z; X[blk][4 * q + 3] = v.w;
             }
     }
+    float4 w1f[2][16], w2f[8];           // all weight fragments requested before the first MFMA
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w1f[ob][t] = PK[(ob * 16 + t) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) w2f[t] = PK[HP_A2 / 4 + t * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
     f32x16 a1[2];
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
@@ -485,7 +520,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         for (int bp = 0; bp < 4; ++bp)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = PK[((ob * 4 + bp) * 4 + q) * 64 + lane];
+                const float4 w = w1f[ob][bp * 4 + q];
                 a1[ob] = dmfma(w.x, X[bp][4 * q + 0], a1[ob]);
                 a1[ob] = dmfma(w.y, X[bp][4 * q + 1], a1[ob]);
                 a1[ob] = dmfma(w.z, X[bp][4 * q + 2], a1[ob]);
@@ -502,7 +537,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w = PK[HP_A2 / 4 + (bp * 4 + q) * 64 + lane];
+            const float4 w = w2f[bp * 4 + q];
             a2 = dmfma(w.x, a1[bp][4 * q + 0], a2);
             a2 = dmfma(w.y, a1[bp][4 * q + 1], a2);
             a2 = dmfma(w.z, a1[bp][4 * q + 2], a2);
@@ -568,7 +603,7 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     const int per = dec_dw_workgroups(br[0].agents);
     A.wg_split = per;
     hipLaunchKernelGGL(dec_bwd_dw_kernel, dim3(per * nbr), dim3(512), 0, as_stream(stream), A);
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 63) / 64, nbr), dim3(256), 0, as_stream(stream), A, per,
+    hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, as_stream(stream), A, per,
                        DEC_PART / 4);
     return hipGetLastError();
 }

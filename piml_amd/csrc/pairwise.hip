@@ -28,6 +28,23 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// UCY collision flag (mlapm.py:43-47) with EXACTLY the reference's float32 operations -- it is a discrete decision,
+// so the fast reciprocal / squared-domain shortcuts of the smooth terms do not apply here:
+//   |vr| < 2R  or  |vr + vv| < 2R  or  (0 < tmin < 1 and dmin < 2R),
+//   tmin = -(vr.vv) / (vv.vv),  dmin = sqrt(vr.vr - (vr.vv)^2 / (vv.vv)),  dots = x*x' + y*y' (two products, one add),
+//   norms = torch.norm on 2-vectors = sqrt(fma(y, y, x*x)).  A NaN dmin (negative argument) compares false.
+__device__ __forceinline__ bool ucy_collision(float rx, float ry, float wx, float wy, float two_r) {
+    bool coll = norm2(rx, ry) < two_r;
+    coll |= norm2(__fadd_rn(rx, wx), __fadd_rn(ry, wy)) < two_r;
+    const float rw = __fadd_rn(__fmul_rn(rx, wx), __fmul_rn(ry, wy));
+    const float ww = __fadd_rn(__fmul_rn(wx, wx), __fmul_rn(wy, wy));
+    const float rr = __fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry));
+    const float tmin = __fdiv_rn(-rw, ww);
+    const float dmin = sqrtf(__fsub_rn(rr, __fdiv_rn(__fmul_rn(rw, rw), ww)));
+    coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin < two_r);
+    return coll;
+}
+
 // One ordered pair: focal (vix, viy, ex, ey) at the origin, source at (rx, ry) with
 // relative velocity (wx, wy).  Returns view * A * g * direction (mlapm.py:25-53).
 __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, float ry, float wx, float wy,
@@ -54,15 +71,7 @@ __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, flo
             const float cs = (rx * wx + ry * wy) * fminf(rinv, 1e8f) * fminf(fast_rsq(w2), 1e8f);
             g = fast_exp2(P.B2 * r + P.C2 * cs + P.D2 * r * cs);    // :40
         } else {
-            bool coll = r < P.r2;                                   // :43
-            const float sx = rx + wx, sy = ry + wy;
-            coll |= sx * sx + sy * sy < P.r2 * P.r2;                // :44
-            const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy;
-            const float wwi = fast_rcp(ww);
-            const float tmin = -rw * wwi;                           // :45
-            const float dmin2 = d2 - rw * rw * wwi;                 // :46 (compared squared)
-            // sqrt of a (rounding-)negative argument is NaN in the reference: that branch is then false
-            coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin2 >= 0.f) && (dmin2 < P.r2 * P.r2);   // :47
+            const bool coll = ucy_collision(rx, ry, wx, wy, P.r2);      // :43-47, exact
             g = coll ? fast_exp2(P.B2 * r + P.C2) : 1.f;            // :53 (with coll.unsqueeze(-1), Q8)
             if (r != r) g = r;                                      // NaN poisons like the reference
         }
@@ -210,15 +219,7 @@ __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, 
         hx = k1 * (q_ok ? n8x - cs * mx : n8x) * qi8;              // d(cs)/d(vv)
         hy = k1 * (q_ok ? n8y - cs * my : n8y) * qi8;
     } else {
-        bool coll = r < P.r2;
-        const float sx = rx + wx, sy = ry + wy;
-        coll |= sx * sx + sy * sy < P.r2 * P.r2;
-        const float rw = rx * wx + ry * wy, ww = wx * wx + wy * wy;
-        const float wwi = fast_rcp(ww);
-        const float tmin = -rw * wwi;
-        const float dmin2 = d2 - rw * rw * wwi;
-        coll |= (tmin > 0.f) && (tmin < 1.f) && (dmin2 >= 0.f) && (dmin2 < P.r2 * P.r2);
-        const float cf = coll ? 1.f : 0.f;
+        const float cf = ucy_collision(rx, ry, wx, wy, P.r2) ? 1.f : 0.f;      // the forward's exact flag
         phi2 = (P.B2 * r + P.C2) * cf; fx = P.B * cf * nx; fy = P.B * cf * ny;
     }
     const float AE = -P.A * fast_exp2(phi2);

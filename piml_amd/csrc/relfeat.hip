@@ -330,6 +330,45 @@ __global__ __launch_bounds__(256) void relfeat_bwd_kernel(
     }
 }
 
+// Deterministic variant of relfeat_bwd (no atomics, bit-reproducible): one thread per (source agent, component).
+// The scatter part is a GATHER over the entries of the neighbour lists that name this source: `sorted_keys` are the
+// keys slice * N + source of all (row, slot) entries sorted ascending (empty slots carry the sentinel C * N), `order`
+// their positions row * kpe + slot in the same (stable) order, so every sum runs in one fixed order.
+__global__ __launch_bounds__(256) void relfeat_bwd_det_kernel(
+        const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
+        const int* __restrict__ ped_idx, const int* __restrict__ obs_idx, const long long* __restrict__ sorted_keys,
+        const long long* __restrict__ order, long long nkeys, const float* __restrict__ p, int ld,
+        const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe, int accumulate,
+        float* g_state, float2* g_dest) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long src = t >> 3;
+    const int q = (int)(t & 7);
+    if (src >= (long long)C * N || q >= 6) return;
+    const int c = (int)(src / N), j = (int)(src - (long long)c * N);
+    float sum = 0.f;
+    if (j >= f0 && j < f0 + fcnt) {                       // the row's own term: -(sum of its upstream gradients)
+        const long long row = (long long)c * fcnt + (j - f0);
+        for (int s = 0; s < kpe; ++s)
+            if (ped_idx[row * kpe + s] >= 0) sum -= g_ped[(row * kpe + s) * 6 + q];
+        for (int s = 0; s < koe; ++s)
+            if (obs_idx[row * koe + s] >= 0) sum -= g_obs[(row * koe + s) * 6 + q];
+        if (q < 2) {
+            const float dq = reinterpret_cast<const float*>(dest)[row * 2 + q] - p[src * ld + q];
+            const float gd = dq != dq ? 0.f : reinterpret_cast<const float*>(g_destf)[row * 2 + q];
+            reinterpret_cast<float*>(g_dest)[row * 2 + q] = gd;
+            sum -= gd;
+        }
+    }
+    long long lo = 0, hi = nkeys;                         // first entry with key >= src
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sorted_keys[mid] < src) lo = mid + 1; else hi = mid;
+    }
+    for (long long e = lo; e < nkeys && sorted_keys[e] == src; ++e) sum += g_ped[order[e] * 6 + q];
+    float* o = g_state + src * 6 + q;
+    *o = accumulate ? *o + sum : sum;
+}
+
 // One thread per (slice, agent): two sweeps over time (data.py:363-389), then normalise.
 __global__ void heading_kernel(const float2* __restrict__ vel, int C, int T, int N, float2* __restrict__ out) {
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,6 +464,26 @@ PIML_API int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, 
                        g_ped_feat, g_obs_feat, (const float2*)g_dest_feat, ped_idx, obs_idx,
                        position, state_ld, (const float2*)destination, C, N, focal_begin, focal_count,
                        kp_eff, ko_eff, g_state, (float2*)g_destination);
+    return hipGetLastError();
+}
+
+PIML_API int piml_relfeat_bwd_det(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,
+                                  const int* ped_idx, const int* obs_idx, const long long* sorted_keys,
+                                  const long long* order, const float* position, int state_ld, const float* destination,
+                                  int C, int N, int focal_begin, int focal_count, int kp_eff, int ko_eff, int accumulate,
+                                  float* g_state, float* g_destination, void* stream) {
+    if (C < 0 || N < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
+        kp_eff < 0 || ko_eff < 0 || state_ld < 2 || (state_ld & 1))
+        return hipErrorInvalidValue;
+    if (C == 0 || N == 0) return hipSuccess;
+    if (!g_dest_feat || !position || !destination || !g_state || !g_destination) return hipErrorInvalidValue;
+    const long long nkeys = (long long)C * focal_count * kp_eff;
+    if (nkeys > 0 && (!sorted_keys || !order || !g_ped_feat || !ped_idx)) return hipErrorInvalidValue;
+    const long long threads = (long long)C * N * 8;
+    hipLaunchKernelGGL(relfeat_bwd_det_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       g_ped_feat, g_obs_feat, (const float2*)g_dest_feat, ped_idx, obs_idx, sorted_keys, order, nkeys,
+                       position, state_ld, (const float2*)destination, C, N, focal_begin, focal_count, kp_eff, ko_eff,
+                       accumulate, g_state, (float2*)g_destination);
     return hipGetLastError();
 }
 

@@ -69,6 +69,10 @@ def get_args(argv=None):
     A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
     A('--tunableop', type=int, default=0, help='1: load the pre-tuned GEMM selections (piml_amd/tuning)')
     A('--hip_graph', type=int, default=1, help='0: run the fine-tuning step eagerly instead of replaying a captured HIP graph')
+    A('--inplace_quirk', type=int, default=1,
+      help='1 (default): carry the waypoint indices / first-frame velocity history of a rollout over to the next rollout of '
+           'the same clip or batch, as the reference does through its in-place views (SURVEY quirk Q12); 0: every '
+           'rollout starts from the untouched data')
     A('--fix_dest_norm', action='store_true',
       help='desired-force direction normalised per agent for channelled (C, N, 7) input too; the reference reduces '
            'over dim=1 = the AGENT axis there (src/models/model.py:1290, SURVEY quirk Q2), which stays the default')

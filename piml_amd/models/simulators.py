@@ -15,8 +15,14 @@ Differences from the reference, all behaviour-preserving for a single call:
     arithmetically, the NaN assertion on the predicted acceleration is checked once after the loop;
   * the four `collision_detection(...).sum(-1)` calls per training step (simulators.py:708-724)
     are two fused `ops.collision_counts` launches (no (C,N,N) matrices);
-  * the caller's data tensors are never mutated (the reference advances `data.dest_idx`,
-    `data.self_features` and `data.labels` in place through views).
+  * the caller's data tensors are never mutated -- unless `args.inplace_quirk` is set (the default
+    of `piml_amd.main`): the reference keeps VIEWS into the data object as its rollout state, so every rollout leaves
+    `data.dest_idx[t_start]` = the waypoint indices at the END of that rollout (simulators.py:578, 609-613, 636) and
+    `data.self_features[t_start][2:-3]` = the velocity history after its first frame (:624-626, 639); the next rollout
+    of the same clip / batch then STARTS from those values (agents head for their last waypoint, agents near their
+    original destination leave at once).  Reproducing the reference's numbers over a multi-rollout flow (validation
+    every epoch, batches reused across epochs) needs the same carry-over; it is applied after the rollout, outside
+    every captured graph.
 """
 import os
 import time
@@ -336,13 +342,19 @@ class BaseSimulator(Pedestrians):
         if use_graph is None:
             use_graph = data.position.is_cuda and not torch.is_grad_enabled() and steps > 8
         done = 0
-        if use_graph and steps > 3:
+        quirk = bool(getattr(args, 'inplace_quirk', False)) and steps > 0
+        hist_first = None
+        if quirk:                                         # the first frame on its own: its history is carried over
+            step_fn(data, st)
+            hist_first = st.hist.clone()
+            done = 1
+        if use_graph and steps - done > 3:
             try:
                 if self._side_stream_ok(st.p.numel() // 2):   # obstacle branch in parallel inside the graph
                     self.model.obs_stream = torch.cuda.Stream()
                 for _ in range(2):                        # real frames, also warm every lazy init up
                     step_fn(data, st)
-                done = 2
+                done += 2
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
@@ -358,6 +370,10 @@ class BaseSimulator(Pedestrians):
                 done = int(st.t.item()) - t_start
         for _ in range(steps - done):
             step_fn(data, st)
+        if quirk:                                         # quirk Q12: what the reference's views leave behind
+            with torch.no_grad():
+                data.dest_idx[..., t_start, :] = st.dest_idx.to(data.dest_idx.dtype)
+                data.self_features[..., t_start, :, 2:-3] = hist_first
         return RolloutResult(position=st.p_res, velocity=st.v_res, acceleration=st.a_res,
                              destination=data.destination, waypoints=data.destination, obstacles=data.obstacles,
                              mask_p=st.mask_new, meta_data=getattr(data, 'meta_data', None),
@@ -369,9 +385,18 @@ class BaseSimulator(Pedestrians):
         reg_loss) of one batch of rollout windows, differentiable (simulators.py:659-832)."""
         out, aux = self._training_rollout(data, t_start)
         assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'  # :745
+        self._carry_dest_idx(data, aux)
         self.collision_count += aux['collisions'].item()
         self.hard_collision_count += aux['hard_collisions'].item()
         return out
+
+    def _carry_dest_idx(self, data, aux):
+        """quirk Q12 for the training rollout: `dest_idx_cur` is a view of data.dest_idx[..., t_start, :] in the
+        reference (simulators.py:684, 749-751, 768), so a batch object re-used in the next epoch starts from the
+        waypoint indices its previous rollout ended with."""
+        if getattr(self.args, 'inplace_quirk', False):
+            with torch.no_grad():
+                data.dest_idx[..., aux['t_start'], :] = aux['dest_idx_final'].to(data.dest_idx.dtype)
 
     def _training_rollout(self, data, t_start=0):
         """The rollout + losses with no host synchronisation at all (capturable into a HIP graph);
@@ -481,7 +506,8 @@ class BaseSimulator(Pedestrians):
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
         if fused_step:
             nan_seen = nan_flag != 0
-        aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions)}
+        aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions),
+               'dest_idx_final': dest_idx.detach().clone(), 't_start': t_start}
 
         pad = [torch.zeros_like(p_steps[0])] * t_start
         gate4 = gates.view(1, -1, 1, 1)
@@ -592,6 +618,7 @@ class BaseSimulator(Pedestrians):
         if channelled and getattr(args, 'hip_graph', True) and batch_data.position.is_cuda:
             out, aux = self._graphed_rollout_step(batch_data)
             assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'
+            self._carry_dest_idx(batch_data, aux)
             self.collision_count += aux['collisions'].item()
             self.hard_collision_count += aux['hard_collisions'].item()
             names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')

@@ -11,6 +11,10 @@ import torch
 from . import _lib
 
 MAX_TOPK = 32
+# Opt-in: the relative-feature backward without float atomics (bit-reproducible gradients; the neighbour-list entries are
+# sorted by source with torch.sort(stable=True) and gathered in that fixed order).  Default: the atomic scatter.
+import os as _os
+DETERMINISTIC_BWD = _os.environ.get('PIML_DETERMINISTIC_BWD', '0') == '1'
 
 
 def cos_threshold(angle_deg):
@@ -84,9 +88,23 @@ def _launch_relfeat_bwd(ctx_geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, p_ptr,
     g_ped = dense(g_ped, (*lead, fcnt, kpe, 6))
     g_obs = dense(g_obs, (*lead, fcnt, koe, 6))
     g_dest = dense(g_dest, (*lead, fcnt, 2))
-    if g_state is None:
+    if g_state is None and not DETERMINISTIC_BWD:
         g_state = torch.zeros(*lead, N, 6, device=device, dtype=torch.float32)
     g_dest_rows = torch.empty(*lead, fcnt, 2, device=device, dtype=torch.float32)
+    if DETERMINISTIC_BWD:
+        seeded = g_state is not None
+        if g_state is None:
+            g_state = torch.empty(*lead, N, 6, device=device, dtype=torch.float32)
+        idx = ped_idx.reshape(C, fcnt * kpe).long()
+        base = torch.arange(C, device=device, dtype=torch.long).unsqueeze(1) * N
+        keys = torch.where(idx >= 0, idx + base, torch.full_like(idx, C * N)).reshape(-1)
+        sorted_keys, order = torch.sort(keys, stable=True)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().piml_relfeat_bwd_det(
+                _ptr(g_ped), _ptr(g_obs), _ptr(g_dest), _ptr(ped_idx), _ptr(obs_idx), _ptr(sorted_keys), _ptr(order),
+                p_ptr, ld, _ptr(dest_rows), C, N, f0, fcnt, kpe, koe, int(seeded), _ptr(g_state), _ptr(g_dest_rows),
+                _stream()), 'piml_relfeat_bwd_det')
+        return g_state, g_dest_rows
     with torch.cuda.device(device):
         _lib.check(_lib.lib().piml_relfeat_bwd(
             _ptr(g_ped), _ptr(g_obs), _ptr(g_dest), _ptr(ped_idx), _ptr(obs_idx), p_ptr, ld,

@@ -554,9 +554,13 @@ MAINFLOW_CASES = {
         dataset_name='ucy', collision_loss_weight=40, hard_collision_penalty=1, val_coll_weight=10,
         pretrain=dict(train=['data/synthetic_data/UCY_Dataset_time108-162_timeunit0.08_simulation.npy'],
                       valid=['data/synthetic_data/UCY_Dataset_time162-216_timeunit0.08_simulation.npy']),
+        # valid / test on the REAL clip (no obstacles -> the 2-point placeholder, k_o = 2).  The synthetic UCY clips carry a
+        # single obstacle point: k_o = 1, and the reference's `.squeeze()` calls in get_multiple_rollouts
+        # (simulators.py:647-649) then drop the neighbour axis, its bottleneck model sums the obstacle messages over the
+        # AGENTS (dim=-2 of an (N, 2) tensor) and every rollout blows up (MSE ~300 m^2) -- SURVEY quirk Q13, not reproduced.
         finetune=dict(train=['data/UCY_dataset/UCY_Dataset_time162-216_timeunit0.08.npy'],
-                      valid=['data/synthetic_data/UCY_Dataset_time162-216_timeunit0.08_simulation.npy'],
-                      test=['data/synthetic_data/UCY_Dataset_time108-162_timeunit0.08_simulation.npy'])),
+                      valid=['data/UCY_dataset/UCY_Dataset_time162-216_timeunit0.08.npy'],
+                      test=['data/UCY_dataset/UCY_Dataset_time162-216_timeunit0.08.npy'])),
 }
 
 

@@ -270,3 +270,50 @@ def test_relfeat_fuzz_small_scenes_vs_oracle(oracle):
                 assert np.array_equal(got, want), (case, N, M, C, kw)
             else:
                 assert np.array_equal(bits(got), bits(want)), (case, N, M, C, kw)
+
+
+@pytest.mark.parametrize('N,M,C,packed', [(1500, 300, None, False), (300, 100, 3, False), (2048, 500, None, True)])
+def test_relfeat_backward_deterministic_variant(oracle, N, M, C, packed):
+    """PIML_DETERMINISTIC_BWD / ops.DETERMINISTIC_BWD: the gradient without float atomics (entries sorted by source,
+    gathered in a fixed order): bit-identical between runs, equal to the atomic kernel up to summation order, and
+    within 1e-5 of the oracle."""
+    from piml_amd import ops
+    sc = synthetic_gc_scene(N, M, seed=31, channels=C)
+    rng = np.random.default_rng(7)
+    acc = (rng.standard_normal(sc['position'].shape) * 0.3).astype(np.float32)
+    obs = dev(sc['obstacles'])
+
+    def run():
+        if packed:
+            state = dev(np.concatenate((sc['position'], sc['velocity'], acc), -1)).requires_grad_(True)
+            d = dev(sc['destination']).requires_grad_(True)
+            out = ops.relative_features_packed_self(state, d, obs, dev(sc['desired_speed']), 0, N, return_index=True)
+            leaves = (state, d)
+        else:
+            leaves = tuple(dev(x).requires_grad_(True) for x in (sc['position'], sc['velocity'], acc, sc['destination']))
+            out = ops.relative_features(*leaves, obs, return_index=True)
+        g = torch.Generator().manual_seed(3)
+        w = [torch.randn(t.shape, generator=g).to(DEV) for t in out[:3]]
+        sum((o * x).sum() for o, x in zip(out[:3], w)).backward()
+        return [t.grad.clone() for t in leaves], out, w
+    try:
+        ops.DETERMINISTIC_BWD = True
+        g1, out, w = run()
+        g2, _, _ = run()
+        for a, b in zip(g1, g2):
+            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))          # bit-reproducible
+        ops.DETERMINISTIC_BWD = False
+        g0, _, _ = run()
+    finally:
+        ops.DETERMINISTIC_BWD = False
+    worst = 0.0
+    for a, b in zip(g1, g0):
+        a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1.0)))
+    print(f'deterministic vs atomic relfeat backward N={N}: max rel diff {worst:.1e}')
+    assert worst <= 1e-6
+    if not packed:
+        want = oracle.relfeat_bwd(w[0].cpu().numpy(), w[1].cpu().numpy(), w[2].cpu().numpy(), out[3].cpu().numpy(),
+                                  out[4].cpu().numpy(), sc['position'], sc['destination'])
+        for got, x in zip(g1, want):
+            assert np.abs(np.nan_to_num(got.cpu().numpy()) - x).max() <= 1e-5 * max(1.0, np.abs(x).max())
