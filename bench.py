@@ -163,17 +163,33 @@ def secondary_measurements(scene, n, dev, _lib):
         return tm.elapsed_ms() * 1e3 / reps
     fwd_us = timed(lambda: ops.mlapm_step(p, v, v0, d, 0.08, 0.3, **gc))
     leaves = [x.clone().requires_grad_(True) for x in (p, v, v0, d)]
-    act = ops.mlapm_step(*leaves, 0.08, 0.3, **gc)
-    w = torch.ones_like(act)
-    bwd_us = timed(lambda: torch.autograd.grad(act, leaves, w, retain_graph=True), reps=30)
+    w = torch.ones(m, 2, device=dev)
+
+    def fwd_bwd():
+        act = ops.mlapm_step(*leaves, 0.08, 0.3, **gc)
+        return torch.autograd.grad(act, leaves, w)
+    # forward + analytic backward replayed from ONE captured HIP graph: the figure is the kernels' time, not the
+    # ~100 us of autograd / ctypes bookkeeping an eager backward of a 4096-agent scene costs on the host
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        keep = fwd_bwd()
+    fb_us = timed(graph.replay, reps=30)
+    bwd_us = max(fb_us - fwd_us, 0.0)
+    del keep
     bytes_fwd = 16 * m * m + 36 * m
     return {'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
                               'pairs_per_s_fwd': m * m / fwd_us * 1e6,
                               'roofline_frac_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                               'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
-                                      'present agents of the same scene; host-inclusive event timing of back-to-back launches (the backward figure '
-                                      'is bound by autograd bookkeeping below ~16k agents; its kernel takes 45-60 us, '
-                                      'profiles/r01_other_kernels.md)'}}
+                                      'present agents of the same scene; forward: back-to-back eager launches; backward: (forward + backward '
+                                      'replayed from one captured HIP graph) - forward, HIP events'}}
 
 
 F32_MFMA_PEAK_TFS = 157.3   # dense f32 matrix peak (v_mfma_f32_32x32x2_f32), same guide

@@ -24,9 +24,27 @@ def agent_block(n_total, rank, world):
     """(begin, count) of the agents owned by `rank`; blocks are equal (n_total % world == 0)."""
     if n_total % world:
         raise ValueError(f'n_total={n_total} must be divisible by the world size {world} '
-                         '(pad the scene with NaN-position agents)')
+                         '(pad the scene with absent agents: sharded.pad_scene)')
     n = n_total // world
     return rank * n, n
+
+
+def pad_scene(state, destination, desired_speed, world):
+    """Pad a scene to a multiple of `world` agents with ABSENT agents (NaN position / destination, zero velocity and
+    acceleration -- the reference's own encoding of an agent that is not in the scene, src/data/data.py:141-143), so
+    that equal agent blocks exist for any N.  Absent agents select nobody, are selected by nobody and receive zero
+    gradient, so the padded scene computes exactly the unpadded one.  Returns (state (N', 6), destination (N', 2),
+    desired_speed (N', 1), N)."""
+    n = state.shape[0]
+    pad = (-n) % world
+    if pad == 0:
+        return state, destination, desired_speed, n
+    nan = float('nan')
+    rows = torch.tensor([[nan, nan, 0.0, 0.0, 0.0, 0.0]], dtype=state.dtype, device=state.device).expand(pad, 6)
+    return (torch.cat((state, rows)), torch.cat((destination, torch.full((pad, 2), nan, dtype=destination.dtype,
+                                                                        device=destination.device))),
+            torch.cat((desired_speed, torch.zeros(pad, desired_speed.shape[1], dtype=desired_speed.dtype,
+                                                  device=desired_speed.device))), n)
 
 
 def _supports_reduce_scatter(group):

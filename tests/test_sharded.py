@@ -164,3 +164,25 @@ def test_agent_block_requires_divisibility():
     assert agent_block(16384, 3, 8) == (6144, 2048)
     with pytest.raises(ValueError):
         agent_block(10, 0, 4)
+
+
+def test_pad_scene_keeps_the_result(oracle):
+    """A scene whose agent count is not a multiple of the world size is padded with absent (NaN) agents; the features
+    and gradients of the real agents are unchanged."""
+    from piml_amd.sharded import agent_block, pad_scene
+    state, dest, v0, obs = scene_tensors()
+    state, dest, v0 = state[:61], dest[:61], v0[:61]
+    ps, pd, pv, n = pad_scene(state, dest, v0, 4)
+    assert n == 61 and ps.shape == (64, 6) and agent_block(64, 3, 4) == (48, 16)
+    assert torch.isnan(ps[61:, :2]).all() and (ps[61:, 2:] == 0).all() and torch.isnan(pd[61:]).all()
+    a = state.clone().requires_grad_(True)
+    b = ps.clone().requires_grad_(True)
+    fa = feature_fn(a, dest, obs, 0, 61)
+    fb = feature_fn(b, pd, obs, 0, 64)
+    for x, y in zip(fa, fb):
+        assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y[:61]))
+        assert (torch.nan_to_num(y[61:]) == 0).all()
+    sum(x.sum() for x in fa).backward()
+    sum(torch.nan_to_num(y).sum() for y in fb).backward()
+    assert torch.allclose(torch.nan_to_num(a.grad), torch.nan_to_num(b.grad[:61]), atol=1e-6)
+    assert (torch.nan_to_num(b.grad[61:]) == 0).all()

@@ -10,6 +10,11 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+# Bounds of the differentiable-rollout parity tests against the reference's goldens (BPTT through 5-10 frames of
+# closed loop; float32 round-off compounds through the frames): loss scalars relative, gradients relative to the
+# largest entry of each tensor.  The measured values are printed by every test.
+SCALAR_TOL = 2e-5
+GRAD_TOL = 2e-4
 
 
 def sim_args(**kw):
@@ -91,7 +96,7 @@ def test_training_rollout_matches_reference(model_name):
     out[0].backward()
     got = np.array([float(x.detach()) for x in out])
     ref = g[f'{tag}/scalars']
-    assert np.allclose(got, ref, rtol=2e-4, atol=1e-6), (got, ref)
+    scal = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)))
     assert [sim.collision_count, sim.hard_collision_count] == list(g[f'{tag}/counts'])
     assert torch.equal(torch.nan_to_num(data.labels), torch.nan_to_num(labels_before))   # caller's data untouched
     worst = 0.0
@@ -100,7 +105,10 @@ def test_training_rollout_matches_reference(model_name):
         got_g = np.zeros_like(ref_g) if p.grad is None else p.grad.cpu().numpy()
         scale = max(np.abs(ref_g).max(), 1e-6)
         worst = max(worst, np.abs(got_g - ref_g).max() / scale)
-    assert worst < 2e-3, worst
+    print(f'training rollout {model_name}: scalars max rel err {scal:.2e} (bar {SCALAR_TOL:g}), '
+          f'gradients max err / max|g| {worst:.2e} (bar {GRAD_TOL:g})')
+    assert scal <= SCALAR_TOL, (got, ref)
+    assert worst <= GRAD_TOL, worst
 
 
 def test_train_batch_runs_and_learns():
@@ -206,17 +214,24 @@ def test_training_rollout_more_configs(fixture, tag, model_name, ds, finetune, e
     out = sim.test_multiple_rollouts_for_training(data)
     out[0].backward()
     got = np.array([float(x.detach()) for x in out])
-    assert np.allclose(got, g[f'{tag}/scalars'], rtol=2e-4, atol=1e-6), (got, g[f'{tag}/scalars'])
+    ref = g[f'{tag}/scalars']
+    scal = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)))
     assert [sim.collision_count, sim.hard_collision_count] == list(g[f'{tag}/counts'])
     named = dict(sim.model.named_parameters())
+    worst = 0.0
     for k in g.files:
         if k.startswith(f'{tag}/grad/'):
             ref_g = g[k]
             p = named[k[len(tag) + 6:]]
             got_g = np.zeros_like(ref_g) if p.grad is None else p.grad.cpu().numpy()
-            assert np.abs(got_g - ref_g).max() <= 2e-3 * max(np.abs(ref_g).max(), 1e-6), k
+            worst = max(worst, float(np.abs(got_g - ref_g).max() / max(np.abs(ref_g).max(), 1e-6)))
     total = sum(float(p.grad.abs().sum()) for p in named.values() if p.grad is not None)
-    assert np.isclose(total, float(g[f'{tag}/grad_abs_sum']), rtol=2e-3)
+    tot_err = abs(total - float(g[f'{tag}/grad_abs_sum'])) / float(g[f'{tag}/grad_abs_sum'])
+    print(f'training rollout {tag}: scalars max rel err {scal:.2e} (bar {SCALAR_TOL:g}), gradients max err / max|g| '
+          f'{worst:.2e} (bar {GRAD_TOL:g}), sum|g| rel err {tot_err:.2e}')
+    assert scal <= SCALAR_TOL, (got, ref)
+    assert worst <= GRAD_TOL, worst
+    assert tot_err <= GRAD_TOL
 
 
 @pytest.mark.parametrize('model_name', ['pinnsf_m', 'pinnsf_bm'])
