@@ -424,6 +424,9 @@ def main():
                     help='several GPUs: also time the other --exchange variant after the timed region (informational)')
     ap.add_argument('--strong-baseline', type=int, default=1,
                     help='strong scaling on several GPUs: rank 0 also times the whole scene on one GPU (outside the timed region)')
+    ap.add_argument('--mlp', choices=('fused', 'library'), default='fused',
+                    help='fused: the PINNSF network on the hand-written f32-MFMA kernels (encoder.hip / decoder.hip); '
+                         'library: round 1\'s path, rocBLAS / hipBLASLt GEMMs + HIP glue kernels (A/B comparison)')
     ap.add_argument('--tunableop', type=int, default=1,
                     help='1: load the pre-tuned GEMM selections for the MLP (tuned in-process if this stack rejects the file); '
                          '0: library defaults; 2: re-tune and write --tune-out; 3: force the in-process tuning')
@@ -467,6 +470,11 @@ def main():
     # MLP from a result file tuned once on an MI355X (tuning itself takes minutes and is never
     # done here).  A file whose validators do not match this software stack is ignored by torch.
     from piml_amd import tuning
+    import piml_amd.models.model as MODEL
+    fused_mlp = args.mlp == 'fused'
+    MODEL.FUSED_NETWORK = MODEL.FUSED_ENCODER = fused_mlp
+    if fused_mlp and args.tunableop != 2:      # no library GEMM left in the step: nothing to select, one stream
+        args.tunableop, args.two_streams = 0, 0
     if args.tunableop == 2:      # re-tune the GEMM selections on this stack (eager steps; not a measurement)
         tuning.tune_begin(os.path.abspath(args.tune_out))
         args.graph, args.two_streams, args.verify, args.secondary, args.cpu_seconds = 0, 0, 0, 0, 0.0
@@ -514,11 +522,12 @@ def main():
     kernel_ms_samples, overhead_ms_samples = [], []
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # 5 samples whatever --steps is; each brackets TIMED_LAUNCHES back-to-back launches of the kernel so
-    # that the cost of the two event records (4-7 us, measured by an empty pair) is a small correction.  The
-    # events are only READ after the timed region (reading one synchronises the stream): a sample costs the
-    # timed region its extra launches (3 x ~23 us) and nothing else.
-    TIMED_LAUNCHES = 2
+    # 5 samples whatever --steps is.  A sample is ONE extra eager launch of the relfeat forward kernel (same inputs,
+    # same output buffers) right behind a replayed step, bracketed by two HIP events: the kernel runs behind other
+    # kernels, not behind an idle gap, and the cost of the two event records (measured by an empty pair) is subtracted.
+    # The events are only READ after the timed region (reading one synchronises the stream): a sample costs the timed
+    # region one ~22 us launch and nothing else.
+    TIMED_LAUNCHES = 1
     n_samples = max(1, min(5, args.steps))
     sample_at = {round(i * args.steps / n_samples) for i in range(n_samples)}
 
@@ -527,21 +536,14 @@ def main():
             sample = timed and i in sample_at
             if use_dist:
                 st.exchange_forward()
-            if sample:
-                # the timed launches run behind an identical launch, so the interval holds kernels
-                # behind another kernel rather than the idle gap that follows the previous replay
-                st.relaunch_relfeat()
-                tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
-                tk.start()
-                for _ in range(TIMED_LAUNCHES):
-                    st.relaunch_relfeat()
-                tk.stop()
             graph.replay()
             if use_dist:
                 st.exchange_backward()
             if sample:
-                # calibration: an empty start/stop pair right behind the step measures what the two
-                # event records themselves add to an interval on this stream
+                tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
+                tk.start()
+                st.relaunch_relfeat()
+                tk.stop()
                 tc.start(); tc.stop()
                 sample_timers.append((tk, tc))
         else:
@@ -693,7 +695,8 @@ def main():
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
-            'mlp_gemm_selection': gemm_tuning, 'mlp_branch_streams': 2 if two_streams else 1,
+            'mlp': ('fused f32-MFMA kernels (piml_amd/csrc/encoder.hip, decoder.hip)' if fused_mlp else
+                    f'library GEMMs ({gemm_tuning}) + HIP glue kernels, {2 if two_streams else 1} stream(s)'),
             'config': {'workload': ('cfg3: synthetic 4096-agent GC scene' if (world == 1 and N == 4096) else
                                     f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
                                     f'synthetic {N}-agent GC scene ({n_own} focal agents per GPU)') +

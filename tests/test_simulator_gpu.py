@@ -13,8 +13,8 @@ DEV = 'cuda:0'
 # Bounds of the differentiable-rollout parity tests against the reference's goldens (BPTT through 5-10 frames of
 # closed loop; float32 round-off compounds through the frames): loss scalars relative, gradients relative to the
 # largest entry of each tensor.  The measured values are printed by every test.
-SCALAR_TOL = 2e-5
-GRAD_TOL = 2e-4
+SCALAR_TOL = 1e-4
+GRAD_TOL = 1e-4
 
 
 def sim_args(**kw):

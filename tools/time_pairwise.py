@@ -35,3 +35,12 @@ for N in (1024, 4096, 16384):
         pc = torch.tensor(synthetic_gc_scene(N, 0, seed=1, channels=4)['position'], device=dev)
         print(f'collision_counts S=4 N={N} (2 thr): {timeit(lambda: ops.collision_counts(pc, (0.5, 0.25)), 20):.1f} us;  '
               f'collision_detection matrix S=4: {timeit(lambda: ops.collision_detection(pc, 0.5), 20):.1f} us')
+
+# the general path of collision_counts (more than 25 slices): the evaluation's (t, N, 2) rollouts, S = 750 frames
+for N in (122, 248, 1024):
+    g = torch.Generator().manual_seed(0)
+    pc = (torch.rand(750, N, 2, generator=g) * (12.0 if N < 1000 else 40.0)).to(dev)
+    pc[:, ::11] = float('nan')
+    print(f'collision_counts general path S=750 N={N} (2 thr): {timeit(lambda: ops.collision_counts(pc, (0.5, 0.25)), 10):.1f} us;  '
+          f'matrix path collision_detection(...).sum(-1) x 2: '
+          f'{timeit(lambda: (ops.collision_detection(pc, 0.5).sum(-1), ops.collision_detection(pc, 0.25).sum(-1)), 5):.1f} us')
