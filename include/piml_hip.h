@@ -168,6 +168,15 @@ int piml_collision_counts(const float* position, int S, int N, const float* thre
                           float* counts, void* stream);
 
 /*
+ * The same counts for stacks of MORE than 25 slices (the evaluation's (t, N, 2) rollouts) in parallel form: needs
+ * `totals_zeroed`, n_thresholds * N * N int32 of caller scratch, zero on entry (it holds the per-pair collision totals
+ * of the friends rule afterwards).  n_thresholds <= 4.  piml_collision_counts itself needs no scratch (one wavefront
+ * per agent) and is the slower choice there.
+ */
+int piml_collision_counts_scratch(const float* position, int S, int N, const float* thresholds, int n_thresholds,
+                                  int* totals_zeroed, float* counts, void* stream);
+
+/*
  * Pedestrians.calculate_collision_label (src/data/data.py:514-535): rows of >= 4 floats
  * (dp, dv, ...), `row_stride` floats apart -> label[rows] in {0, 1}.
  */

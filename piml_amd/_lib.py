@@ -45,6 +45,7 @@ SIGNATURES = {
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
     'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
+    'piml_collision_counts_scratch': [_p, _i, _i, _p, _i, _p, _p, _p],
     'piml_collision_label': [_p, _z, _i, _p, _p],
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,

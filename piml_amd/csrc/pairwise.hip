@@ -467,6 +467,66 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_kernel(const floa
     }
 }
 
+constexpr int kCollMaxThr = 4;
+
+// General path, parallel form (more than 25 slices with a scratch buffer): two sweeps over the S x N x N pairs.
+//   K1  totals[h][i][j] += number of slices in which the pair collides (integer atomics: exact in any order);
+//       grid = (j tiles of 64, i tiles of 4, slice chunks of CC_CHUNK), one wavefront per (i, slice chunk), lanes = j
+//   K2  counts[h][s][i] = sum_j collide(s, i, j) and 0 < totals[h][i][j] <= 25 (friends rule, data.py:587-591);
+//       one wavefront per (s, i), lanes stride over j, wave reduction, plain store.
+constexpr int CC_CHUNK = 32;
+
+__global__ __launch_bounds__(256) void collision_totals_kernel(const float2* __restrict__ p, int S, int N,
+                                                               const float* __restrict__ thr, int nthr,
+                                                               int* __restrict__ totals) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane, i = blockIdx.y * 4 + wave;
+    const int s0 = blockIdx.z * CC_CHUNK, s1 = min(S, s0 + CC_CHUNK);
+    if (i >= N || j >= N || i == j) return;
+    int cnt[kCollMaxThr] = {0, 0, 0, 0};
+    for (int s = s0; s < s1; ++s) {
+        const float2 pi = p[(size_t)s * N + i], pj = p[(size_t)s * N + j];
+        const float d = norm2(pj.x - pi.x, pj.y - pi.y);          // NaN compares false
+#pragma unroll
+        for (int h = 0; h < kCollMaxThr; ++h)
+            if (h < nthr) cnt[h] += d < thr[h] ? 1 : 0;
+    }
+#pragma unroll
+    for (int h = 0; h < kCollMaxThr; ++h)
+        if (h < nthr && cnt[h]) atomicAdd(totals + ((size_t)h * N + i) * N + j, cnt[h]);
+}
+
+__global__ __launch_bounds__(256) void collision_counts_from_totals_kernel(const float2* __restrict__ p, int S, int N,
+                                                                           const float* __restrict__ thr, int nthr,
+                                                                           const int* __restrict__ totals,
+                                                                           float* __restrict__ counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w = (long long)blockIdx.x * 4 + wave;           // (s, i)
+    if (w >= (long long)S * N) return;
+    const int s = (int)(w / N), i = (int)(w - (long long)s * N);
+    const float2 pi = p[(size_t)s * N + i];
+    int cnt[kCollMaxThr] = {0, 0, 0, 0};
+    for (int j = lane; j < N; j += 64) {
+        if (j == i) continue;
+        const float2 pj = p[(size_t)s * N + j];
+        const float d = norm2(pj.x - pi.x, pj.y - pi.y);
+#pragma unroll
+        for (int h = 0; h < kCollMaxThr; ++h)
+            if (h < nthr && d < thr[h]) {
+                const int t = totals[((size_t)h * N + i) * N + j];
+                cnt[h] += (t > 0 && t <= 25) ? 1 : 0;
+            }
+    }
+#pragma unroll
+    for (int h = 0; h < kCollMaxThr; ++h) {
+        if (h >= nthr) break;
+        int c = cnt[h];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) counts[((size_t)h * S + s) * N + i] = (float)c;
+    }
+}
+
 // Fast path of collision_counts for stacks of at most 25 slices (the training rollouts: S = number
 // of windows in the batch): a pair can then collide in at most 25 slices, so the friends rule
 // (sum over slices <= 25, data.py:587-591) never removes anything and every slice is independent.
@@ -474,7 +534,6 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_kernel(const floa
 // (structure-of-arrays, ds_read_b128), all thresholds are counted in one sweep, and "|r| < thr" is
 // decided exactly in the squared domain (largest float whose correctly rounded sqrt is < thr).
 constexpr int kCollTile = 4096;
-constexpr int kCollMaxThr = 4;
 
 __device__ __forceinline__ float sq_below(float thr) {       // max { y : sqrtf(y) < thr }, thr > 0
     if (!(thr > 0.f)) return -1.f;
@@ -699,6 +758,19 @@ PIML_API int piml_collision_counts(const float* position, int S, int N, const fl
     } else {
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_counts_scratch(const float* position, int S, int N, const float* thresholds,
+                                           int n_thresholds, int* totals_zeroed, float* counts, void* stream) {
+    if (S < 0 || N < 0 || n_thresholds < 0 || n_thresholds > kCollMaxThr) return hipErrorInvalidValue;
+    if ((long)S * N * n_thresholds == 0) return hipSuccess;
+    if (!position || !thresholds || !counts || !totals_zeroed) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(collision_totals_kernel, dim3((N + 63) / 64, (N + 3) / 4, (S + CC_CHUNK - 1) / CC_CHUNK), dim3(256),
+                       0, as_stream(stream), (const float2*)position, S, N, thresholds, n_thresholds, totals_zeroed);
+    const long long waves = (long long)S * N;
+    hipLaunchKernelGGL(collision_counts_from_totals_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       as_stream(stream), (const float2*)position, S, N, thresholds, n_thresholds, totals_zeroed, counts);
     return hipGetLastError();
 }
 

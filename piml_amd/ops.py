@@ -440,8 +440,14 @@ def collision_counts(position, thresholds):
         thr = _THRESHOLDS[key] = torch.tensor(key[1], device=p.device, dtype=torch.float32)
     counts = torch.empty(len(thresholds), S, N, device=p.device, dtype=torch.float32)
     with torch.cuda.device(p.device):
-        _lib.check(_lib.lib().piml_collision_counts(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(counts),
-                                                    _stream()), 'piml_collision_counts')
+        if S > 25 and len(thresholds) <= 4 and len(thresholds) * N * N <= (1 << 28):
+            # many slices (evaluation rollouts): the two-sweep parallel form with an (nthr, N, N) int32 scratch
+            totals = torch.zeros(len(thresholds), N, N, device=p.device, dtype=torch.int32)
+            _lib.check(_lib.lib().piml_collision_counts_scratch(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(totals),
+                                                                _ptr(counts), _stream()), 'piml_collision_counts_scratch')
+        else:
+            _lib.check(_lib.lib().piml_collision_counts(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(counts),
+                                                        _stream()), 'piml_collision_counts')
     return counts
 
 

@@ -58,3 +58,25 @@ def test_collision_counts_general_path_in_replayed_graph():
         gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, want)
+
+
+def test_collision_counts_both_general_forms_agree():
+    """More than 25 slices: the scratch-free kernel behind piml_collision_counts (one wavefront per agent) and the
+    two-sweep parallel form behind piml_collision_counts_scratch (what ops.collision_counts uses) against the
+    (S, N, N) matrices, on a scene with friends (pairs colliding in more than 25 slices)."""
+    from piml_amd import ops, _lib
+    g = torch.Generator().manual_seed(1)
+    S, N = 60, 90
+    p = (torch.rand(S, N, 2, generator=g) * 5).to(DEV)
+    p[:, 1] = p[:, 0] + 0.1                     # a pair of "friends": colliding in every slice
+    p[::3, 5] = float('nan')
+    thr = (0.5, 0.25, 1.0)
+    want = torch.stack([ops.collision_detection(p, t).sum(-1) for t in thr])
+    assert torch.equal(ops.collision_counts(p, thr), want)
+    t = torch.tensor(thr, device=DEV)
+    out = torch.empty(len(thr), S, N, device=DEV)
+    _lib.check(_lib.lib().piml_collision_counts(p.data_ptr(), S, N, t.data_ptr(), len(thr), out.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), 'piml_collision_counts')
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert float(want[0, :, 0].sum()) == float(want[0, :, 1].sum())      # the friends pair is filtered symmetrically

@@ -51,12 +51,18 @@ COMMON = ['-f', '--device', 'cuda:0', '--model', 'pinnsf_bm', '--dropout', '0.0'
           '--true_label_weight', '0', '--collision_focus_weight', '1', '--patience', '25', '--ft_patience', '5',
           '--seed', '666']
 
-# Bounds.  Training losses: relative.  Rollout metrics: relative, long horizon (chaotic, see module docstring).
+# Bounds (relative unless a name ends in _m = metres), each a small multiple of what is measured on the MI355X
+# (DESIGN.md section 2 lists the measured values).  Two groups:
+#   * `ref_*`: OUR rollout with EXACTLY the reference's fine-tuned weights -- rollout parity proper, tight;
+#   * the rest: the whole flow with our own training, where the <= 1e-5 per-step differences compound through ~260
+#     Adam updates (GC: negligible; UCY: 1e-4 .. 2e-2 on the training scalars, <= 2e-3 on the final metrics).
 TOL = {
-    'gc': dict(pre_train=2e-4, pre_val=2e-4, ft_train=5e-3, weights=2e-3, short_rollout=2e-3,
-               val=0.15, mae=0.10, fde=0.15, ot=0.25, mmd=0.35, collisions=0.35),
-    'ucy': dict(pre_train=2e-4, pre_val=2e-4, ft_train=5e-3, weights=2e-3, short_rollout=2e-3,
-                val=0.15, mae=0.10, fde=0.15, ot=0.25, mmd=0.35, collisions=0.35),
+    'gc': dict(pre_train=1e-6, pre_val=5e-6, ft_train=1e-4, ft_counts=0.0, weights=2e-4, val=2e-2, metrics=3e-4,
+               collisions=0.0, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
+               ref_collisions=0.0),
+    'ucy': dict(pre_train=5e-4, pre_val=3e-3, ft_train=5e-2, ft_counts=3e-2, weights=5e-3, val=1e-2, metrics=5e-3,
+                collisions=2e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
+                ref_collisions=0.0),
 }
 
 
@@ -161,18 +167,21 @@ def test_main_flow_matches_reference_end_to_end(case):
     print(f'    here:      ft val {val_got}, test mse/mae/ot/mmd {ev[1:]}, fde {sim.last_eval["fde"]}, collisions '
           f'hard/soft {[sim.last_eval["hard_collisions"], sim.last_eval["collisions"]]}')
 
-    assert report['pre_train'] <= tol['pre_train'] and report['pre_val'] <= tol['pre_val']
-    assert report['ft_train'] <= tol['ft_train']
-    assert report['weights_best_pre'] <= tol['weights']
-    assert report['refweights_rollout_first10_m'] <= tol['short_rollout']      # metres, 10 frames of closed loop
+    # rollout parity with the reference's weights
     assert report['refweights_mask_head_equal']
-    if os.environ.get('PIML_CFG5_REPORT_ONLY') == '1':
-        return
-    assert report['refweights_mae'] <= tol['mae'] and report['refweights_fde'] <= tol['fde']
-    assert report['refweights_collisions'] <= tol['collisions']
+    assert report['refweights_rollout_first10_m'] <= tol['ref_first10_m']
+    assert report['refweights_rollout_first40_m'] <= tol['ref_first40_m']
+    assert report['refweights_mae_per_frame_all_m'] <= tol['ref_mae_per_frame_m']
+    assert report['refweights_mae'] <= tol['ref_metrics'] and report['refweights_fde'] <= tol['ref_metrics']
+    assert report['refweights_collisions'] <= tol['ref_collisions']
+    # the whole flow
+    assert report['pre_train'] <= tol['pre_train'] and report['pre_val'] <= tol['pre_val']
+    assert report['ft_train'] <= tol['ft_train'] and report['ft_train_collision_counts'] <= tol['ft_counts']
+    assert report['weights_best_pre'] <= tol['weights'] and report['weights_best_ft'] <= tol['weights']
+    assert report['saved_epochs'][0] == report['saved_epochs'][1]          # same model selection
     assert report['val'] <= tol['val']
-    assert report['mae'] <= tol['mae'] and report['fde'] <= tol['fde']
-    assert report['ot'] <= tol['ot'] and report['mmd'] <= tol['mmd']
+    for k in ('test_mse', 'mae', 'fde', 'ot', 'mmd'):
+        assert report[k] <= tol['metrics'], k
     assert report['collisions'] <= tol['collisions']
 
 
