@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 8
+#define PIML_HIP_ABI_VERSION 9
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -82,6 +82,23 @@ int piml_relfeat_fwd(const float* position, const float* heading, const float* v
                      float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
                      float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
                      int32_t* ped_idx, int32_t* obs_idx, void* stream);
+
+/*
+ * piml_relfeat_fwd for ONE scene of packed (N, 6) = (p, v, a) records that also writes the model's self_features rows
+ * [dest - p, v, a, v0] (n, 7) (src/models/simulators.py:169-173 builds them with a torch.cat per frame) and, when
+ * `g_state_zero` (N * 6 floats) is given, clears it for the backward to accumulate into: one launch instead of three.
+ * piml_relfeat_self_bwd is its backward in one launch: g_self (n, 7) = d/d(self_features); ACCUMULATES into the cleared
+ * g_state (N, 6); writes g_destination (n, 2) and g_speed (n, may be NULL).
+ */
+int piml_relfeat_self_fwd(const float* state, const float* destination_rows, const float* obstacles,
+                          const float* desired_speed, int N, int M, int focal_begin, int focal_count, int topk_ped,
+                          int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                          float* ped_feat, float* obs_feat, float* self_features, int32_t* ped_idx, int32_t* obs_idx,
+                          float* g_state_zero, void* stream);
+int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int* ped_idx,
+                          const int* obs_idx, const float* state, const float* destination_rows, int N, int focal_begin,
+                          int focal_count, int kp_eff, int ko_eff, float* g_state, float* g_destination, float* g_speed,
+                          void* stream);
 
 /*
  * Relative features, backward: what autograd computes through gather / repeat / masked
@@ -454,9 +471,48 @@ int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const f
  * + b2), msgs (rows, 128), W1 (64, 128), w2 (1, 64); forward only.  `packed`: piml_collision_head_pack_floats()
  * floats of scratch.
  */
+typedef struct piml_collision_head {
+    const float* msgs; /* (rows, 128) */
+    long long rows;
+    const float *w1, *b1, *w2, *b2;
+    float* packed; /* piml_collision_head_pack_floats() floats */
+    float* out;    /* (rows) */
+} piml_collision_head;
+
 int piml_collision_head_pack_floats(void);
 int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, const float* b1, const float* w2,
                             const float* b2, float* packed, float* out, void* stream);
+
+/*
+ * The whole non-bottleneck PINNSF network (src/models/model.py:1271-1305: both encoders, the decoder tails, the
+ * desired-force epilogue and, for `pinnsf_m`, the collision head) as ONE call that forks its independent stages over
+ * HIP streams and joins them again on `stream` (event fork/join: legal under stream capture, where the forks become
+ * parallel branches of the graph).  Side streams are created per device on first use, outside any capture
+ * (piml_pinnsf_streams_init, idempotent; the first piml_pinnsf_* call does it too).
+ *
+ *   piml_pinnsf_pack   the MFMA operand images of every weight (encoder, decoder, head) -> the `packed` fields,
+ *                      three small launches in a row on `stream`.  Weights that did not change since the last pack
+ *                      (rollouts, evaluation) need no repack: pass PIML_PACKED_VALID to fwd.  A training step hides
+ *                      the packs behind the neighbour search by calling this on a stream of its own, forked before
+ *                      the features are built and joined before piml_pinnsf_fwd.  flags: reserved (0).
+ *   piml_pinnsf_fwd    [decoder + head packs on a side stream | encoder pack] -> encoders -> [collision head on a side
+ *                      stream | pooling -> decoder tails] -> join.  head may be NULL.
+ *   piml_pinnsf_bwd    decoder dX -> [decoder dW + reduction on a side stream | encoder dX -> dW] -> join -> encoder
+ *                      reduction.  Same fields as piml_decoder_bwd / piml_encoder_bwd.
+ * flags: PIML_PACKED_VALID (fwd: skip the packs); PIML_FORK (use the side streams; without it the stages run in program
+ * order on `stream`, which is what a captured HIP graph wants: on ROCm 7.2 every cross-stream edge of a replayed graph
+ * costs more than the ~5 us stage it hides -- measured 0.247 ms/step serial vs 0.295 forked at cfg3).
+ */
+#define PIML_PACKED_VALID 1
+#define PIML_FORK 2
+int piml_pinnsf_streams_init(void);
+int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,
+                     const piml_collision_head* head, int flags, void* stream);
+int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,
+                    const piml_collision_head* head, const float* self_features, float tau, float* acc, int flags,
+                    void* stream);
+int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches, const float* g_pred,
+                    const float* self_features, float tau, float* g_self, int flags, void* stream);
 
 /*
  * RCCL exchange of agent-block sharding (the reference's only multi-GPU mechanism is

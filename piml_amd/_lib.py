@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -33,6 +33,13 @@ class DecoderBranch(ctypes.Structure):
                 ('pooled', _p), ('h1', _p), ('d2', _p), ('g_pre2', _p), ('g_pre1', _p), ('g_pooled', _p),
                 ('partials', _p), ('grads', _p), ('packed', _p)]
 
+
+class CollisionHead(ctypes.Structure):
+    """piml_collision_head (include/piml_hip.h)."""
+    _fields_ = [('msgs', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('packed', _p), ('out', _p)]
+
+
+PACKED_VALID, FORK = 1, 2          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -87,6 +94,12 @@ SIGNATURES = {
     'piml_decoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _p],
     'piml_collision_head_pack_floats': [],
     'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],
+    'piml_pinnsf_streams_init': [],
+    'piml_pinnsf_pack': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),
+                         _i, _p],
+    'piml_pinnsf_fwd': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),
+                        _p, _f, _p, _i, _p],
+    'piml_pinnsf_bwd': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _i, _p],
     'piml_comm_available': [],
     'piml_comm_unique_id': [_p],
     'piml_comm_init': [ctypes.POINTER(_p), _i, _i, _p],
@@ -94,6 +107,8 @@ SIGNATURES = {
     'piml_allgather_state': [_p, _p, _z, _p, _p],
     'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
     'piml_allreduce_sum': [_p, _p, _z, _p],
+    'piml_relfeat_self_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
+    'piml_relfeat_self_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'piml_relfeat_bwd_det': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }

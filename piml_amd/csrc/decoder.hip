@@ -10,24 +10,14 @@
 // the packed global image: a wave owns one 32-agent tile and uses every fragment once, so LDS staging buys nothing).
 // One workgroup = one 32-agent tile, wave 0 = pedestrian branch, wave 1 = obstacle branch, combined through LDS.
 #include "common.hpp"
+#include "pack.hpp"
+#include "stages.hpp"
 #include "../../include/piml_hip.h"
 
 namespace piml {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int DH = 128;        // decoder input width (= encoder width)
-constexpr int DD = 64;         // decoder hidden / output width
-// packed image of one branch (floats)
-constexpr int DP_A1 = 0;                         // [ob 2][bp 4][q 4][lane 64] float4   W1 (64, 128)
-constexpr int DP_A2 = DP_A1 + 2 * 4 * 4 * 256;   // [ob 2][bp 2][q 4][lane 64] float4   W2 (64, 64)
-constexpr int DP_A3 = DP_A2 + 2 * 2 * 4 * 256;   // [bp 2][q 4][lane 64] float4         W3 (2, 64), rows >= 2 are 0
-constexpr int DP_B = DP_A3 + 2 * 4 * 256;        // b1 64 | b2 64 | b3 2 | pad 2
-constexpr int DP_T3 = DP_B + 132;                // [ob 2][lane 64]                     W3^T: lane (i, h) = W3[h][32 ob + i]
-constexpr int DP_T2 = DP_T3 + 128;               // [ob 2][bp 2][q 4][lane 64] float4   W2^T
-constexpr int DP_T1 = DP_T2 + 2 * 2 * 4 * 256;   // [blk 4][bp 2][q 4][lane 64] float4  W1^T
-constexpr int DEC_PACK = DP_T1 + 4 * 2 * 4 * 256;
-constexpr int DEC_PART = DD * DH + DD * DD + 2 * DD + DD + DD + 8;     // dW1 | dW2 | dW3 | db1 | db2 | db3 (+pad)
 constexpr int DEC_SLAB = 32;                                           // agents per workgroup of the dW kernel
 
 struct DecArgs {
@@ -46,40 +36,6 @@ __device__ __forceinline__ f32x16 dmfma(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int dfeat0(int blk, int q, int h) { return 32 * blk + 8 * q + 4 * h; }
 
-__device__ __forceinline__ float dec_pack_value(const piml_decoder_branch& J, int e) {
-    if (e < DP_B) {                 // forward fragments
-        int f = e, rows_in;         // rows_in: input width of the layer
-        const float* W;
-        int nbp, limit_i = 64;
-        if (e < DP_A2) { W = J.w1; rows_in = DH; nbp = 4; }
-        else if (e < DP_A3) { f = e - DP_A2; W = J.w2; rows_in = DD; nbp = 2; }
-        else { f = e - DP_A3; W = J.w3; rows_in = DD; nbp = 2; limit_i = 2; }
-        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3;
-        int rest = f >> 10;
-        const int bp = rest % nbp, ob = rest / nbp;           // ob = 0 for W3
-        const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
-        return i < limit_i ? W[(size_t)i * rows_in + c] : 0.f;
-    }
-    if (e < DP_T3) {
-        const int g = e - DP_B;
-        return g < 64 ? J.b1[g] : (g < 128 ? J.b2[g - 64] : (g < 130 ? J.b3[g - 128] : 0.f));
-    }
-    if (e < DP_T2) {                // W3^T: one k-step (k = h = output component)
-        const int g = e - DP_T3, lane = g & 63, ob = g >> 6;
-        return J.w3[(size_t)(lane >> 5) * DD + 32 * ob + (lane & 31)];
-    }
-    {                               // W2^T, W1^T: [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]
-        const bool t1 = e >= DP_T1;
-        const int f = t1 ? e - DP_T1 : e - DP_T2;
-        const float* W = t1 ? J.w1 : J.w2;
-        const int cols = t1 ? DH : DD;                        // input width of the layer = columns of W
-        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3, rest = f >> 10;
-        const int bp = rest & 1, blk = rest >> 1;
-        const int r = 32 * bp + 8 * q + 4 * (lane >> 5) + u;  // output feature of the layer (row of W)
-        return W[(size_t)r * cols + 32 * blk + (lane & 31)];
-    }
-}
-
 __global__ __launch_bounds__(256) void dec_pack_kernel(DecArgs A) {
     const int b = blockIdx.y;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
@@ -92,9 +48,8 @@ __global__ __launch_bounds__(256) void dec_pack_kernel(DecArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // pooled[a][:] = sum over the k rows of agent a of msgs (model.py:1283), both branches in one launch (blockIdx.y);
 // one float4 column per thread.  (Summing inside dec_fwd serialises k dependent load rounds in one wave: 23 us.)
-__global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
-    const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void dec_pool_body(const piml_decoder_branch& J, long long bx) {
+    const long long t = bx * 256 + threadIdx.x;
     if (t >= J.agents * (DH / 4)) return;
     const long long a = t / (DH / 4);
     const int c = (int)(t % (DH / 4));
@@ -107,125 +62,126 @@ __global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
     reinterpret_cast<float4*>(J.pooled)[t] = s;
 }
 
-__global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
-    __shared__ float comb[64];
+__global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
+    dec_pool_body(blockIdx.y ? A.br[1] : A.br[0], blockIdx.x);
+}
+
+// One 32-agent tile per workgroup, both branches.  The three layers are a dependent chain of 224 MFMAs per branch
+// (7.5 us when one wave runs it): the chain is cut across 4 waves per branch -- wave (ob, kh) owns output block ob and
+// half kh of the contraction of layers 1 and 2 -- with the partial sums exchanged through LDS in accumulator layout
+// (lane = agent, register = feature: exactly the B-operand layout of the next layer, so an exchange is 16 conflict-free
+// ds_write_b32 + 32 ds_read_b32 per lane).  Chain per wave: 32 + 16 + 16 MFMAs and three barriers.
+__global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) {
+    __shared__ float part1[2][2][2][16][64];      // [branch][ob][kh][register][lane]
+    __shared__ float part2[2][2][2][16][64];
+    __shared__ float part3[2][2][2][32];          // [branch][kh][component][agent]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const bool active = wave < A.nbr;
-    const piml_decoder_branch J = wave ? A.br[1] : A.br[0];
+    const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1;
+    const bool active = b < A.nbr;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long agent = (long long)blockIdx.x * 32 + j;
     const bool valid = active && agent < J.agents;
-    float ax = 0.f, ay = 0.f;
+    const float4* PK = reinterpret_cast<const float4*>(J.packed);
+    const float* bias = J.packed + DP_B;
+    float4 w2f[4], w3f[4];
     if (active) {
-        const float4* PK = reinterpret_cast<const float4*>(J.packed);
-        const float* bias = J.packed + DP_B;
-        f32x16 P[4];
-        {
-            const float* base = J.pooled + (valid ? agent : 0) * DH;
+        // ---- layer 1 partial: features of block ob, contraction over input blocks 2 kh, 2 kh + 1 ----
+        float4 pv[2][4], w1f[2][4];
+        const float* base = J.pooled + (valid ? agent : 0) * DH;
 #pragma unroll
-            for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(base + dfeat0(blk, q, h));
-                    P[blk][4 * q] = valid ? v.x : 0.f; P[blk][4 * q + 1] = valid ? v.y : 0.f;
-                    P[blk][4 * q + 2] = valid ? v.z : 0.f; P[blk][4 * q + 3] = valid ? v.w : 0.f;
-                }
-        }
-        // every weight fragment of the three layers is requested before the first MFMA (72 x 1 KiB per wave, L2-resident):
-        // the chain below then runs at the MFMA rate instead of one L2 round trip per group of four
-        float4 w1f[2][16], w2f[2][8], w3f[8];
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) w1f[ob][t] = PK[DP_A1 / 4 + (ob * 16 + t) * 64 + lane];
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) w2f[ob][t] = PK[DP_A2 / 4 + (ob * 8 + t) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) w3f[t] = PK[DP_A3 / 4 + t * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);       // the loads stay up here
-        // ---- decoder layer 1: 128 -> 64, ReLU ----
-        f32x16 a1[2], a2[2];
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
+        for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
-                a1[ob][4 * q] = bq.x; a1[ob][4 * q + 1] = bq.y; a1[ob][4 * q + 2] = bq.z; a1[ob][4 * q + 3] = bq.w;
+                pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
+                w1f[bl][q] = PK[DP_A1 / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
             }
 #pragma unroll
-            for (int bp = 0; bp < 4; ++bp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w = w1f[ob][bp * 4 + q];
-                    a1[ob] = dmfma(w.x, P[bp][4 * q + 0], a1[ob]);
-                    a1[ob] = dmfma(w.y, P[bp][4 * q + 1], a1[ob]);
-                    a1[ob] = dmfma(w.z, P[bp][4 * q + 2], a1[ob]);
-                    a1[ob] = dmfma(w.w, P[bp][4 * q + 3], a1[ob]);
-                }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1[ob][r] = fmaxf(a1[ob][r], 0.f);
+        for (int q = 0; q < 4; ++q) {
+            w2f[q] = PK[DP_A2 / 4 + ((ob * 2 + kh) * 4 + q) * 64 + lane];
+            w3f[q] = PK[DP_A3 / 4 + (kh * 4 + q) * 64 + lane];
         }
-        if (J.h1 && valid) {
+        f32x16 a1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            a1[4 * q] = kh ? 0.f : bq.x; a1[4 * q + 1] = kh ? 0.f : bq.y;
+            a1[4 * q + 2] = kh ? 0.f : bq.z; a1[4 * q + 3] = kh ? 0.f : bq.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);       // every load above is in flight before the first MFMA
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = w1f[bl][q], x = pv[bl][q];
+                a1 = dmfma(w.x, valid ? x.x : 0.f, a1);
+                a1 = dmfma(w.y, valid ? x.y : 0.f, a1);
+                a1 = dmfma(w.z, valid ? x.z : 0.f, a1);
+                a1 = dmfma(w.w, valid ? x.w : 0.f, a1);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part1[b][ob][kh][r][lane] = a1[r];
+    }
+    __syncthreads();
+    if (active) {
+        // ---- layer 2 partial: output block ob, contraction over hidden block kh (= relu of the summed layer-1 block kh) ----
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = fmaxf(part1[b][kh][0][r][lane] + part1[b][kh][1][r][lane], 0.f);
+        if (ob == 0 && J.h1 && valid) {
             float* o = J.h1 + agent * DD;
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) =
-                        make_float4(a1[ob][4 * q], a1[ob][4 * q + 1], a1[ob][4 * q + 2], a1[ob][4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(o + dfeat0(kh, q, h)) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
         }
-        // ---- decoder layer 2: 64 -> 64, no activation ----
+        f32x16 a2;
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bq = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
-                a2[ob][4 * q] = bq.x; a2[ob][4 * q + 1] = bq.y; a2[ob][4 * q + 2] = bq.z; a2[ob][4 * q + 3] = bq.w;
-            }
-#pragma unroll
-            for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w = w2f[ob][bp * 4 + q];
-                    a2[ob] = dmfma(w.x, a1[bp][4 * q + 0], a2[ob]);
-                    a2[ob] = dmfma(w.y, a1[bp][4 * q + 1], a2[ob]);
-                    a2[ob] = dmfma(w.z, a1[bp][4 * q + 2], a2[ob]);
-                    a2[ob] = dmfma(w.w, a1[bp][4 * q + 3], a2[ob]);
-                }
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
+            a2[4 * q] = kh ? 0.f : bq.x; a2[4 * q + 1] = kh ? 0.f : bq.y;
+            a2[4 * q + 2] = kh ? 0.f : bq.z; a2[4 * q + 3] = kh ? 0.f : bq.w;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = w2f[q];
+            a2 = dmfma(w.x, x[4 * q + 0], a2);
+            a2 = dmfma(w.y, x[4 * q + 1], a2);
+            a2 = dmfma(w.z, x[4 * q + 2], a2);
+            a2 = dmfma(w.w, x[4 * q + 3], a2);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part2[b][ob][kh][r][lane] = a2[r];
+    }
+    __syncthreads();
+    if (active && ob == 0) {
+        // ---- predictor partial over decoder-output block kh (M padded to 32: component c = register c of the h = 0 lanes) ----
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = part2[b][kh][0][r][lane] + part2[b][kh][1][r][lane];
         if (J.d2 && valid) {
             float* o = J.d2 + agent * DD;
 #pragma unroll
-            for (int ob = 0; ob < 2; ++ob)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) =
-                        make_float4(a2[ob][4 * q], a2[ob][4 * q + 1], a2[ob][4 * q + 2], a2[ob][4 * q + 3]);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(o + dfeat0(kh, q, h)) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
         }
-        // ---- predictor: 64 -> 2 (M padded to 32; output component c sits in register c of the h = 0 lanes) ----
         f32x16 a3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a3[r] = 0.f;
-        if (h == 0) { a3[0] = bias[128]; a3[1] = bias[129]; }
+        if (h == 0 && kh == 0) { a3[0] = bias[128]; a3[1] = bias[129]; }
 #pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = w3f[bp * 4 + q];
-                a3 = dmfma(w.x, a2[bp][4 * q + 0], a3);
-                a3 = dmfma(w.y, a2[bp][4 * q + 1], a3);
-                a3 = dmfma(w.z, a2[bp][4 * q + 2], a3);
-                a3 = dmfma(w.w, a2[bp][4 * q + 3], a3);
-            }
-        ax = a3[0];
-        ay = a3[1];
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = w3f[q];
+            a3 = dmfma(w.x, y[4 * q + 0], a3);
+            a3 = dmfma(w.y, y[4 * q + 1], a3);
+            a3 = dmfma(w.z, y[4 * q + 2], a3);
+            a3 = dmfma(w.w, y[4 * q + 3], a3);
+        }
+        if (h == 0) { part3[b][kh][0][j] = a3[0]; part3[b][kh][1][j] = a3[1]; }
     }
-    if (wave == 1 && h == 0) { comb[2 * j] = ax; comb[2 * j + 1] = ay; }
     __syncthreads();
     if (wave == 0 && h == 0 && agent < A.br[0].agents) {
-        if (A.nbr > 1) { ax += comb[2 * j]; ay += comb[2 * j + 1]; }
+        float ax = part3[0][0][0][j] + part3[0][1][0][j], ay = part3[0][0][1][j] + part3[0][1][1][j];
+        if (A.nbr > 1) { ax += part3[1][0][0][j] + part3[1][1][0][j]; ay += part3[1][0][1][j] + part3[1][1][1][j]; }
         if (A.self_features) {        // + (v0 * d / t - v) / tau,  t = |d| (+0.1 where |d| == 0)   (model.py:1289-1294)
             const float* s = A.self_features + agent * 7;
             const float dx = s[0], dy = s[1], vx = s[2], vy = s[3], v0 = s[6];
@@ -242,84 +198,83 @@ __global__ __launch_bounds__(128) void dec_fwd_kernel(DecArgs A) {
 // backward, dX chain: g_pred (agents, 2) -> g_pre2 = W3^T g_pred -> g_pre1 = (W2^T g_pre2) * [h1 > 0] ->
 // g_pooled = W1^T g_pre1; wave 0 also writes the desired-force gradient g_self when asked.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void dec_bwd_dx_kernel(DecArgs A) {
+// 4 waves per branch (the chain of 194 MFMAs is cut like dec_fwd_kernel's): wave (ob, kh) computes g_pre2 block kh itself
+// (one MFMA), the partial of g_pre1 block ob over it (16 MFMAs), and after one LDS exchange g_pooled block 2 ob + kh over
+// the complete, masked g_pre1 (32 MFMAs).
+__global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
+    __shared__ float part[2][2][2][16][64];       // [branch][ob][kh][register][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    if (wave >= A.nbr) return;
-    const piml_decoder_branch J = wave ? A.br[1] : A.br[0];
+    const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
+    const bool active = b < A.nbr;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long agent = (long long)blockIdx.x * 32 + j;
-    const bool valid = agent < J.agents;
+    const bool valid = active && agent < J.agents;
     const float4* PK = reinterpret_cast<const float4*>(J.packed);
     float2 gp = make_float2(0.f, 0.f);
-    if (valid) gp = reinterpret_cast<const float2*>(A.g_pred)[agent];
-    const float bg = h ? gp.y : gp.x;
-    f32x16 g2[2], g1[2];
-    float4 hv[2][4];
-    {
+    float4 hv[2][4], t1f[8];
+    if (active) {
+        if (valid) gp = reinterpret_cast<const float2*>(A.g_pred)[agent];
+        const float bg = h ? gp.y : gp.x;
         const float* hp = J.h1 + (valid ? agent : 0) * DD;
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int o2 = 0; o2 < 2; ++o2)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hv[ob][q] = *reinterpret_cast<const float4*>(hp + dfeat0(ob, q, h));
-    }
-    float t3f[2];
-    float4 t2f[2][8], t1f[4][8];          // all W^T fragments requested before the first MFMA
-    t3f[0] = J.packed[DP_T3 + lane];
-    t3f[1] = J.packed[DP_T3 + 64 + lane];
+            for (int q = 0; q < 4; ++q) hv[o2][q] = *reinterpret_cast<const float4*>(hp + dfeat0(o2, q, h));
+        const float t3f = J.packed[DP_T3 + 64 * kh + lane];
+        float4 t2f[4];
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
+        for (int q = 0; q < 4; ++q) t2f[q] = PK[DP_T2 / 4 + (ob * 8 + kh * 4 + q) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) t2f[ob][t] = PK[DP_T2 / 4 + (ob * 8 + t) * 64 + lane];
+        for (int t = 0; t < 8; ++t) t1f[t] = PK[DP_T1 / 4 + (blk * 8 + t) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
+        f32x16 g2, g1;
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) t1f[blk][t] = PK[DP_T1 / 4 + (blk * 8 + t) * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g2[ob][r] = 0.f;
-        g2[ob] = dmfma(t3f[ob], bg, g2[ob]);
-        if (valid) {
+        for (int r = 0; r < 16; ++r) { g2[r] = 0.f; g1[r] = 0.f; }
+        g2 = dmfma(t3f, bg, g2);
+        if (ob == 0 && valid) {
             float* o = J.g_pre2 + agent * DD;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) =
-                    make_float4(g2[ob][4 * q], g2[ob][4 * q + 1], g2[ob][4 * q + 2], g2[ob][4 * q + 3]);
+                *reinterpret_cast<float4*>(o + dfeat0(kh, q, h)) = make_float4(g2[4 * q], g2[4 * q + 1], g2[4 * q + 2], g2[4 * q + 3]);
         }
-    }
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g1[ob][r] = 0.f;
-#pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = t2f[ob][bp * 4 + q];
-                g1[ob] = dmfma(w.x, g2[bp][4 * q + 0], g1[ob]);
-                g1[ob] = dmfma(w.y, g2[bp][4 * q + 1], g1[ob]);
-                g1[ob] = dmfma(w.z, g2[bp][4 * q + 2], g1[ob]);
-                g1[ob] = dmfma(w.w, g2[bp][4 * q + 3], g1[ob]);
-            }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 a = hv[ob][q];
-            g1[ob][4 * q + 0] = (valid && a.x > 0.f) ? g1[ob][4 * q + 0] : 0.f;
-            g1[ob][4 * q + 1] = (valid && a.y > 0.f) ? g1[ob][4 * q + 1] : 0.f;
-            g1[ob][4 * q + 2] = (valid && a.z > 0.f) ? g1[ob][4 * q + 2] : 0.f;
-            g1[ob][4 * q + 3] = (valid && a.w > 0.f) ? g1[ob][4 * q + 3] : 0.f;
+            const float4 w = t2f[q];
+            g1 = dmfma(w.x, g2[4 * q + 0], g1);
+            g1 = dmfma(w.y, g2[4 * q + 1], g1);
+            g1 = dmfma(w.z, g2[4 * q + 2], g1);
+            g1 = dmfma(w.w, g2[4 * q + 3], g1);
         }
-        if (valid) {
-            float* o = J.g_pre1 + agent * DD;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) =
-                    make_float4(g1[ob][4 * q], g1[ob][4 * q + 1], g1[ob][4 * q + 2], g1[ob][4 * q + 3]);
+        for (int r = 0; r < 16; ++r) part[b][ob][kh][r][lane] = g1[r];
+    }
+    __syncthreads();
+    if (!active) return;
+    float g1c[2][16];
+#pragma unroll
+    for (int o2 = 0; o2 < 2; ++o2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = hv[o2][q];
+            const float m[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = part[b][o2][0][4 * q + u][lane] + part[b][o2][1][4 * q + u][lane];
+                g1c[o2][4 * q + u] = (valid && m[u] > 0.f) ? v : 0.f;
+            }
+        }
+    if (blk < 2 && valid) {          // (compile-time register indices: a runtime g1c[blk] becomes a select chain)
+        float* o = J.g_pre1 + agent * DD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v0 = make_float4(g1c[0][4 * q], g1c[0][4 * q + 1], g1c[0][4 * q + 2], g1c[0][4 * q + 3]);
+            const float4 v1 = make_float4(g1c[1][4 * q], g1c[1][4 * q + 1], g1c[1][4 * q + 2], g1c[1][4 * q + 3]);
+            if (blk == 0) *reinterpret_cast<float4*>(o + dfeat0(0, q, h)) = v0;
+            else *reinterpret_cast<float4*>(o + dfeat0(1, q, h)) = v1;
         }
     }
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+    {
         f32x16 gpool;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gpool[r] = 0.f;
@@ -327,11 +282,11 @@ __global__ __launch_bounds__(128) void dec_bwd_dx_kernel(DecArgs A) {
         for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = t1f[blk][bp * 4 + q];
-                gpool = dmfma(w.x, g1[bp][4 * q + 0], gpool);
-                gpool = dmfma(w.y, g1[bp][4 * q + 1], gpool);
-                gpool = dmfma(w.z, g1[bp][4 * q + 2], gpool);
-                gpool = dmfma(w.w, g1[bp][4 * q + 3], gpool);
+                const float4 w = t1f[bp * 4 + q];
+                gpool = dmfma(w.x, g1c[bp][4 * q + 0], gpool);
+                gpool = dmfma(w.y, g1c[bp][4 * q + 1], gpool);
+                gpool = dmfma(w.z, g1c[bp][4 * q + 2], gpool);
+                gpool = dmfma(w.w, g1c[bp][4 * q + 3], gpool);
             }
         if (valid) {
             float* o = J.g_pooled + agent * DH;
@@ -426,66 +381,32 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
 }
 
 __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
-    // 16 float4 columns x 16 slot groups per block (the partials are few MB spread over many slots: wide grid)
-    __shared__ float4 sh[256];
     const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
-    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + col;
-    const float4* parts = reinterpret_cast<const float4*>(J.partials);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < lanes)
-        for (int q = grp; q < B; q += 16) {
-            const float4 v = parts[(size_t)q * lanes + j];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (grp == 0 && j < lanes) {
-#pragma unroll
-        for (int q = 1; q < 16; ++q) {
-            const float4 v = sh[q * 16 + col];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        reinterpret_cast<float4*>(J.grads)[j] = s;
-    }
+    sum_slots_16x16(J.partials, J.grads, B, lanes);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // collision head of `pinnsf_m` (src/models/model.py:1246 `ped_collision_predictor = MLP(128, [64, 1])`, :1296-1300):
 // out[row] = sigmoid(w2 . relu(W1 msgs[row] + b1) + b2) for every neighbour row, forward only (the reference trains the
 // head for `pinnsf_bm` only; a backward through it falls back to torch ops, ops.collision_head).
-// packed: A1 [ob 2][bp 4][q 4][lane 64] float4 | A2 [bp 2][q 4][lane 64] float4 (rows >= 1 are 0) | b1 64 | b2 1 + 3 pad
+// packed: pack.hpp (W1 fragments | b1 | b2 | raw w2 row)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int HP_A2 = 2 * 4 * 4 * 256;
-constexpr int HP_B = HP_A2 + 2 * 4 * 256;
-constexpr int HEAD_PACK = HP_B + 68;
-
 __global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ packed) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= HEAD_PACK) return;
-    float v;
-    if (e < HP_B) {
-        const bool second = e >= HP_A2;
-        const int f = second ? e - HP_A2 : e;
-        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3, rest = f >> 10;
-        const int bp = second ? rest : (rest & 3), ob = second ? 0 : (rest >> 2);
-        const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
-        v = second ? (i < 1 ? w2[c] : 0.f) : w1[(size_t)i * DH + c];
-    } else {
-        const int g = e - HP_B;
-        v = g < 64 ? b1[g] : (g == 64 ? b2[0] : 0.f);
-    }
-    packed[e] = v;
+    if (e < HEAD_PACK) packed[e] = head_pack_value(w1, b1, w2, b2, e);
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ msgs, long long rows,
-                                                       const float* __restrict__ packed, float* __restrict__ out) {
+// One wave per 32-row tile.  Layer 1 (128 -> 64) on the matrix pipe; its fragments stream from the packed image (L2)
+// four at a time, one group ahead, so the kernel keeps < 128 VGPRs (the pooling blocks that share its launch want
+// occupancy).  Layer 2 (64 -> 1) is a dot product per row: 32 FMAs per lane + one cross-half add, not 32 padded MFMAs.
+__device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, long long rows,
+                                              const float* __restrict__ packed, float* __restrict__ out, long long bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const long long row = ((long long)blockIdx.x * 4 + wave) * 32 + j;
-    if (((long long)blockIdx.x * 4 + wave) * 32 >= rows) return;
+    const long long row = (bx * 4 + wave) * 32 + j;
+    if ((bx * 4 + wave) * 32 >= rows) return;
     const bool valid = row < rows;
     const float4* PK = reinterpret_cast<const float4*>(packed);
     const float* bias = packed + HP_B;
@@ -500,50 +421,65 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                 X[blk][4 * q] = v.x; X[blk][4 * q + 1] = v.y; X[blk][4 * q + 2] = v.z; X[blk][4 * q + 3] = v.w;
             }
     }
-    float4 w1f[2][16], w2f[8];           // all weight fragments requested before the first MFMA
+    float4 wb[2][4];
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob)
+    for (int q = 0; q < 4; ++q) wb[0][q] = PK[q * 64 + lane];
+    float dot = 0.f;
+    f32x16 a1;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) w1f[ob][t] = PK[(ob * 16 + t) * 64 + lane];
+    for (int g = 0; g < 8; ++g) {                 // g = ob * 4 + bp: the fragment groups in image order
+        const int ob = g >> 2, bp = g & 3;
+        if (g + 1 < 8) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) w2f[t] = PK[HP_A2 / 4 + t * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
-    f32x16 a1[2];
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
-            a1[ob][4 * q] = bq.x; a1[ob][4 * q + 1] = bq.y; a1[ob][4 * q + 2] = bq.z; a1[ob][4 * q + 3] = bq.w;
+            for (int q = 0; q < 4; ++q) wb[(g + 1) & 1][q] = PK[((g + 1) * 4 + q) * 64 + lane];
         }
-#pragma unroll
-        for (int bp = 0; bp < 4; ++bp)
+        if (bp == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 w = w1f[ob][bp * 4 + q];
-                a1[ob] = dmfma(w.x, X[bp][4 * q + 0], a1[ob]);
-                a1[ob] = dmfma(w.y, X[bp][4 * q + 1], a1[ob]);
-                a1[ob] = dmfma(w.z, X[bp][4 * q + 2], a1[ob]);
-                a1[ob] = dmfma(w.w, X[bp][4 * q + 3], a1[ob]);
+                const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+                a1[4 * q] = bq.x; a1[4 * q + 1] = bq.y; a1[4 * q + 2] = bq.z; a1[4 * q + 3] = bq.w;
             }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[ob][r] = fmaxf(a1[ob][r], 0.f);
-    }
-    f32x16 a2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a2[r] = 0.f;
-    if (h == 0) a2[0] = bias[64];
-#pragma unroll
-    for (int bp = 0; bp < 2; ++bp)
+        }
+        __builtin_amdgcn_sched_barrier(0);       // the next group's loads are issued before this group's MFMAs
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w = w2f[bp * 4 + q];
-            a2 = dmfma(w.x, a1[bp][4 * q + 0], a2);
-            a2 = dmfma(w.y, a1[bp][4 * q + 1], a2);
-            a2 = dmfma(w.z, a1[bp][4 * q + 2], a2);
-            a2 = dmfma(w.w, a1[bp][4 * q + 3], a2);
+            const float4 w = wb[g & 1][q];
+            a1 = dmfma(w.x, X[bp][4 * q + 0], a1);
+            a1 = dmfma(w.y, X[bp][4 * q + 1], a1);
+            a1 = dmfma(w.z, X[bp][4 * q + 2], a1);
+            a1 = dmfma(w.w, X[bp][4 * q + 3], a1);
         }
-    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-a2[0]));
+        if (bp == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w2 = *reinterpret_cast<const float4*>(packed + HP_W2 + dfeat0(ob, q, h));
+                dot += w2.x * fmaxf(a1[4 * q], 0.f) + w2.y * fmaxf(a1[4 * q + 1], 0.f) + w2.z * fmaxf(a1[4 * q + 2], 0.f) +
+                       w2.w * fmaxf(a1[4 * q + 3], 0.f);
+            }
+        }
+    }
+    dot += __shfl_xor(dot, 32, 64);
+    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + bias[64])));
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ msgs, long long rows,
+                                                       const float* __restrict__ packed, float* __restrict__ out) {
+    head_fwd_body(msgs, rows, packed, out, blockIdx.x);
+}
+
+// The two independent consumers of the encoders' messages in one launch (each dependent launch costs ~4.5 us on
+// gfx950): blocks [0, head_blocks) are collision-head tiles (the longer ones first), the rest pooling blocks of
+// branch 0 then branch 1.
+__global__ __launch_bounds__(256) void dec_pool_head_kernel(DecArgs A, piml_collision_head Hd, int head_blocks,
+                                                            int pool_blocks) {
+    const int bx = blockIdx.x;
+    if (bx < head_blocks) {
+        head_fwd_body(Hd.msgs, Hd.rows, Hd.packed, Hd.out, bx);
+    } else {
+        const int p = bx - head_blocks;
+        if (p < pool_blocks) dec_pool_body(A.br[0], p);
+        else dec_pool_body(A.br[1], p - pool_blocks);
+    }
 }
 
 static bool dec_branch_ok(const piml_decoder_branch& b) {
@@ -560,65 +496,139 @@ PIML_API int piml_decoder_pack_floats(void) { return DEC_PACK; }
 PIML_API int piml_decoder_partial_floats(void) { return DEC_PART; }
 PIML_API int piml_decoder_workgroups(long long agents) { return dec_dw_workgroups(agents); }
 
-PIML_API int piml_decoder_fwd(const piml_decoder_branch* br, int nbr, const float* self_features, float tau,
-                              float* acc, void* stream) {
-    if (!br || nbr < 1 || nbr > 2 || !acc) return hipErrorInvalidValue;
-    DecArgs A = {};
+static int head_check(const piml_collision_head* h);
+
+static int dec_fill(DecArgs& A, const piml_decoder_branch* br, int nbr) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    A = DecArgs{};
     A.nbr = nbr;
     for (int i = 0; i < nbr; ++i) {
         if (!dec_branch_ok(br[i]) || br[i].agents != br[0].agents || !br[i].pooled) return hipErrorInvalidValue;
         A.br[i] = br[i];
     }
     if (nbr == 1) A.br[1] = br[0];
+    return hipSuccess;
+}
+
+static int dec_fill_bwd(DecArgs& A, const piml_decoder_branch* br, int nbr, const float* g_pred) {
+    if (!g_pred) return hipErrorInvalidValue;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_decoder_branch& b = br[i];
+        if (!b.h1 || !b.d2 || !b.g_pre2 || !b.g_pre1 || !b.g_pooled || !b.partials || !b.grads) return hipErrorInvalidValue;
+    }
+    A.g_pred = g_pred;
+    return hipSuccess;
+}
+
+int piml::dec_stage_pack(const piml_decoder_branch* br, int nbr, hipStream_t s) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    DecArgs A = {};
+    A.nbr = nbr;
+    for (int i = 0; i < nbr; ++i) {          // the pack reads the weights only (no agents yet)
+        const piml_decoder_branch& b = br[i];
+        if (!b.w1 || !b.b1 || !b.w2 || !b.b2 || !b.w3 || !b.b3 || !b.packed) return hipErrorInvalidValue;
+        A.br[i] = b;
+    }
+    if (nbr == 1) A.br[1] = br[0];
+    hipLaunchKernelGGL(dec_pack_kernel, dim3((DEC_PACK + 255) / 256, nbr), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+int piml::dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s) {
+    DecArgs A;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    hipLaunchKernelGGL(dec_pool_kernel, dim3((unsigned)((br[0].agents * (DH / 4) + 255) / 256), nbr), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+int piml::dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, hipStream_t s) {
+    DecArgs A;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    if (int e = head_check(h)) return e;
+    const int pool_blocks = (int)((br[0].agents * (DH / 4) + 255) / 256);
+    const int head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
+    hipLaunchKernelGGL(dec_pool_head_kernel, dim3((unsigned)(head_blocks + pool_blocks * nbr)), dim3(256), 0, s, A, *h,
+                       head_blocks, pool_blocks);
+    return hipGetLastError();
+}
+
+int piml::dec_stage_fwd(const piml_decoder_branch* br, int nbr, const float* self_features, float tau, float* acc,
+                        hipStream_t s) {
+    DecArgs A;
+    if (!acc) return hipErrorInvalidValue;
+    if (int e = dec_fill(A, br, nbr)) return e;
     A.self_features = self_features;
     A.tau = tau;
     A.acc = acc;
-    hipLaunchKernelGGL(dec_pack_kernel, dim3((DEC_PACK + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
-    hipLaunchKernelGGL(dec_pool_kernel, dim3((unsigned)((br[0].agents * (DH / 4) + 255) / 256), nbr), dim3(256), 0,
-                       as_stream(stream), A);
     const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
-    hipLaunchKernelGGL(dec_fwd_kernel, dim3(tiles), dim3(128), 0, as_stream(stream), A);
+    hipLaunchKernelGGL(dec_fwd_kernel, dim3(tiles), dim3(512), 0, s, A);
     return hipGetLastError();
+}
+
+int piml::dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features,
+                           float tau, float* g_self, hipStream_t s) {
+    DecArgs A;
+    if (int e = dec_fill_bwd(A, br, nbr, g_pred)) return e;
+    A.self_features = self_features;
+    A.tau = tau;
+    A.g_self = g_self;
+    const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
+    hipLaunchKernelGGL(dec_bwd_dx_kernel, dim3(tiles), dim3(512), 0, s, A);
+    return hipGetLastError();
+}
+
+int piml::dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s) {
+    DecArgs A;
+    if (int e = dec_fill_bwd(A, br, nbr, g_pred)) return e;
+    const int per = dec_dw_workgroups(br[0].agents);
+    A.wg_split = per;
+    hipLaunchKernelGGL(dec_bwd_dw_kernel, dim3(per * nbr), dim3(512), 0, s, A);
+    if (reduce)
+        hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, per, DEC_PART / 4);
+    return hipGetLastError();
+}
+
+static int head_check(const piml_collision_head* h) {
+    if (!h || h->rows < 0) return hipErrorInvalidValue;
+    if (h->rows > 0 && (!h->msgs || !h->w1 || !h->b1 || !h->w2 || !h->b2 || !h->packed || !h->out)) return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+int piml::head_stage_pack(const piml_collision_head* h, hipStream_t s) {
+    if (!h || !h->w1 || !h->b1 || !h->w2 || !h->b2 || !h->packed) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_pack_kernel, dim3((HEAD_PACK + 255) / 256), dim3(256), 0, s, h->w1, h->b1, h->w2, h->b2, h->packed);
+    return hipGetLastError();
+}
+
+int piml::head_stage_fwd(const piml_collision_head* h, hipStream_t s) {
+    if (int e = head_check(h)) return e;
+    if (h->rows == 0) return hipSuccess;
+    const long long tiles = (h->rows + 31) / 32;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, h->msgs, h->rows, h->packed, h->out);
+    return hipGetLastError();
+}
+
+PIML_API int piml_decoder_fwd(const piml_decoder_branch* br, int nbr, const float* self_features, float tau,
+                              float* acc, void* stream) {
+    hipStream_t s = as_stream(stream);
+    if (int e = dec_stage_pack(br, nbr, s)) return e;
+    if (int e = dec_stage_pool(br, nbr, s)) return e;
+    return dec_stage_fwd(br, nbr, self_features, tau, acc, s);
 }
 
 PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features,
                               float tau, float* g_self, void* stream) {
-    if (!br || nbr < 1 || nbr > 2 || !g_pred) return hipErrorInvalidValue;
-    DecArgs A = {};
-    A.nbr = nbr;
-    for (int i = 0; i < nbr; ++i) {
-        const piml_decoder_branch& b = br[i];
-        if (!dec_branch_ok(b) || b.agents != br[0].agents || !b.pooled || !b.h1 || !b.d2 || !b.g_pre2 || !b.g_pre1 ||
-            !b.g_pooled || !b.partials || !b.grads)
-            return hipErrorInvalidValue;
-        A.br[i] = b;
-    }
-    if (nbr == 1) A.br[1] = br[0];
-    A.self_features = self_features;
-    A.tau = tau;
-    A.g_pred = g_pred;
-    A.g_self = g_self;
-    const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
-    hipLaunchKernelGGL(dec_bwd_dx_kernel, dim3(tiles), dim3(128), 0, as_stream(stream), A);
-    const int per = dec_dw_workgroups(br[0].agents);
-    A.wg_split = per;
-    hipLaunchKernelGGL(dec_bwd_dw_kernel, dim3(per * nbr), dim3(512), 0, as_stream(stream), A);
-    hipLaunchKernelGGL(dec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, as_stream(stream), A, per,
-                       DEC_PART / 4);
-    return hipGetLastError();
+    hipStream_t s = as_stream(stream);
+    if (int e = dec_stage_bwd_dx(br, nbr, g_pred, self_features, tau, g_self, s)) return e;
+    return dec_stage_bwd_dw(br, nbr, g_pred, true, s);
 }
 
 PIML_API int piml_collision_head_pack_floats(void) { return HEAD_PACK; }
 
 PIML_API int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, const float* b1, const float* w2,
                                      const float* b2, float* packed, float* out, void* stream) {
-    if (rows < 0) return hipErrorInvalidValue;
-    if (rows == 0) return hipSuccess;
-    if (!msgs || !w1 || !b1 || !w2 || !b2 || !packed || !out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_pack_kernel, dim3((HEAD_PACK + 255) / 256), dim3(256), 0, as_stream(stream), w1, b1, w2, b2,
-                       packed);
-    const long long tiles = (rows + 31) / 32;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), msgs, rows,
-                       packed, out);
-    return hipGetLastError();
+    const piml_collision_head h = {msgs, rows, w1, b1, w2, b2, packed, out};
+    if (int e = head_stage_pack(&h, as_stream(stream))) return e;
+    return head_stage_fwd(&h, as_stream(stream));
 }

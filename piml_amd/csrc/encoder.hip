@@ -19,16 +19,16 @@
 // the pre-activation gradients g2, g1 in HBM; enc_bwd_dw is the split-K product dW = G^T H over row slabs
 // (A = G^T read straight from row-major G, B = H), per-workgroup partials, one piml_sum_leading over them.
 #include "common.hpp"
+#include "pack.hpp"
+#include "stages.hpp"
 #include "../../include/piml_hip.h"
 
 namespace piml {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int EH = 128;                 // hidden width
 constexpr int ENC_THREADS = 512;        // 8 waves per workgroup: 2 per SIMD
 constexpr int ENC_WAVES = ENC_THREADS / 64;
-constexpr int ENC_PART = 2 * EH * EH + EH * 8 + 3 * EH;      // floats of one workgroup's dW / db partial
 
 struct EncArgs {
     piml_encoder_branch br[2];
@@ -43,43 +43,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // store of 4 consecutive floats of a row (non-temporal stores were measured here: forward 47.9 -> 53.7 us, reverted)
 __device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
-
-// A-fragment images of a 128 x 128 nn.Linear weight (out, in), float4 index ((blk*4 + bp)*4 + q)*64 + lane:
-//   forward:       [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
-//   backward (dX): [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]   (A = W^T: in block blk, out block bp)
-// Packed weights of one encoder (floats), written once per step by enc_pack_kernel so that every workgroup stages
-// its LDS image with linear, fully coalesced copies:
-//   [ W2 fragments 16384 | W3 fragments 16384 | W1 fragments 1024 | b1 b2 b3 384 ]        forward image
-//   [ W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments 4096 ]                 dX image
-constexpr int PACK_FWD = 16384 * 2 + 1024 + 384;
-constexpr int PACK_DX = 16384 * 2 + 4096;
-constexpr int PACK_FLOATS = PACK_FWD + PACK_DX;
-
-__device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e) {
-    const int IN = J.in_dim;
-    if (e < 32768 || (e >= PACK_FWD && e < PACK_FWD + 32768)) {
-        const bool tr = e >= PACK_FWD;
-        const int f = tr ? e - PACK_FWD : e;
-        const float* W = (f < 16384) == tr ? J.w3 : J.w2;      // fwd: W2 | W3;  dX: W3^T | W2^T
-        const int g = f & 16383, u = g & 3, lane = (g >> 2) & 63, q = (g >> 8) & 3, bp = (g >> 10) & 3, blk = g >> 12;
-        const int i = lane & 31, c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
-        return tr ? W[(size_t)c * EH + 32 * blk + i] : W[(size_t)(32 * blk + i) * EH + c];
-    }
-    if (e < 32768 + 1024) {                                    // W1 fragments [blk][s][lane]
-        const int g = e - 32768, l = g & 63, sidx = (g >> 6) & 3, blk = g >> 8;
-        const int c = 2 * sidx + (l >> 5);
-        return c < IN ? J.w1[(size_t)(32 * blk + (l & 31)) * IN + c] : 0.f;
-    }
-    if (e < PACK_FWD) {
-        const int g = e - 32768 - 1024;
-        return g < 128 ? J.b1[g] : (g < 256 ? J.b2[g - 128] : J.b3[g - 256]);
-    }
-    {                                                          // W1^T fragments [bp][q][lane] float4
-        const int g = e - PACK_FWD - 32768, u = g & 3, l = (g >> 2) & 63, q = (g >> 8) & 3, bp = g >> 10;
-        const int i = l & 31, c = 32 * bp + 8 * q + 4 * (l >> 5) + u;
-        return i < IN ? J.w1[(size_t)c * IN + i] : 0.f;
-    }
 }
 
 __global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
@@ -517,41 +480,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     }
 }
 
-// grads[j] = sum over the branch's partial slots, fixed order (group g takes slots g, g+4, ...; groups added 0..3);
-// blockIdx.y = branch.  Replaces one piml_sum_leading launch per branch.
+// grads = sum over the branch's partial slots (sum_slots_64x4, pack.hpp); blockIdx.y = branch
 __global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes) {
-    __shared__ float4 sh[256];
     const int b = blockIdx.y;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int B = b ? 256 - A.wg_split : (A.nbr > 1 ? A.wg_split : 256);
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const float4* parts = reinterpret_cast<const float4*>(J.partials);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < lanes) {
-        int q = grp;
-        for (; q + 12 < B; q += 16) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(q + 4 * u) * lanes + j];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-        }
-        for (; q < B; q += 4) {
-            const float4 v = parts[(size_t)q * lanes + j];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (grp == 0 && j < lanes) {
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-            const float4 v = sh[q * 64 + lane];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        reinterpret_cast<float4*>(J.grads)[j] = s;
-    }
+    sum_slots_64x4(J.partials, J.grads, B, lanes);
 }
 
 static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, long long unit) {
@@ -596,32 +530,122 @@ PIML_API int piml_encoder_workgroups(const piml_encoder_branch* br, int nbr, int
 
 PIML_API int piml_encoder_pack_floats(void) { return PACK_FLOATS; }
 
-PIML_API int piml_encoder_pack(const piml_encoder_branch* br, int nbr, void* stream) {
+static int enc_check(const piml_encoder_branch* br, int nbr) {
     if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
     for (int i = 0; i < nbr; ++i)
         if (!branch_ok(br[i])) return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+static int enc_bwd_check(const piml_encoder_branch* br, int nbr) {
+    if (int e = enc_check(br, nbr)) return e;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if (!b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 || (!b.g_pooled && !b.g_msgs))
+            return hipErrorInvalidValue;
+    }
+    return hipSuccess;
+}
+
+// dynamic LDS above 64 KB has to be enabled per kernel once per process
+static int enc_set_lds(const void* f, int bytes) {
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    for (int i = 0; i < nbr; ++i) {          // the pack reads the weights only (no rows yet)
+        const piml_encoder_branch& b = br[i];
+        if (b.in_dim < 1 || b.in_dim > 8 || !b.w1 || !b.b1 || !b.w2 || !b.b2 || !b.w3 || !b.b3 || !b.packed) return hipErrorInvalidValue;
+    }
     EncArgs A;
-    fill_args(A, br, nbr);
-    hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
+    A.nbr = nbr;
+    A.br[0] = br[0];
+    A.br[1] = br[nbr - 1];
+    A.wg_split = 0;
+    hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 
-PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stream) {
-    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (int e = enc_check(br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
-        if (!branch_ok(br[i]) || !br[i].msgs) return hipErrorInvalidValue;
+        if (!br[i].msgs) return hipErrorInvalidValue;
     EncArgs A;
     const int total = fill_args(A, br, nbr);
-    hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, as_stream(stream), A);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
+        if (int e = enc_set_lds(reinterpret_cast<const void*>(enc_fwd_kernel), FWD_LDS_FLOATS * 4)) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, as_stream(stream), A);
+    hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, s, A);
     return hipGetLastError();
+}
+
+int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (int e = enc_bwd_check(br, nbr)) return e;
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (int e = enc_set_lds(reinterpret_cast<const void*>(enc_bwd_dx_kernel), DX_LDS_FLOATS * 4)) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, s, A);
+    return hipGetLastError();
+}
+
+int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (int e = enc_bwd_check(br, nbr)) return e;
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, true>),
+                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, false>),
+                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<false, true>)};
+        for (const void* f : dw)
+            if (int e = enc_set_lds(f, DW_LDS_FLOATS * 4)) return e;
+        attr_set = true;
+    }
+    auto launch_dw = [&](const EncArgs& B, int grid) {
+        const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
+        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
+        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
+        else hipLaunchKernelGGL((enc_bwd_dw_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
+    };
+    // the kernel variant (which upstream gradients exist) is per launch: branches that disagree are launched
+    // separately, each on its own share of the partial slots
+    const bool same = nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) &&
+                                   (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr));
+    if (same) {
+        launch_dw(A, total);
+    } else {
+        for (int i = 0; i < 2; ++i) {
+            EncArgs B = A;
+            B.nbr = 1;
+            B.br[0] = B.br[1] = A.br[i];
+            launch_dw(B, i == 0 ? A.wg_split : total - A.wg_split);
+        }
+    }
+    return hipGetLastError();
+}
+
+int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (int e = enc_bwd_check(br, nbr)) return e;
+    EncArgs A;
+    fill_args(A, br, nbr);
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 63) / 64, nbr), dim3(256), 0, s, A, ENC_PART / 4);
+    return hipGetLastError();
+}
+
+PIML_API int piml_encoder_pack(const piml_encoder_branch* br, int nbr, void* stream) {
+    return enc_stage_pack(br, nbr, as_stream(stream));
+}
+
+PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stream) {
+    if (int e = enc_stage_pack(br, nbr, as_stream(stream))) return e;
+    return enc_stage_fwd(br, nbr, as_stream(stream));
 }
 
 PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream) {
@@ -634,54 +658,7 @@ PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float
 }
 
 PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) {
-    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
-    for (int i = 0; i < nbr; ++i) {
-        const piml_encoder_branch& b = br[i];
-        if (!branch_ok(b) || !b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 ||
-            (!b.g_pooled && !b.g_msgs))
-            return hipErrorInvalidValue;
-    }
-    EncArgs A;
-    const int total = fill_args(A, br, nbr);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DX_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
-        const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, true>),
-                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, false>),
-                             reinterpret_cast<const void*>(enc_bwd_dw_kernel<false, true>)};
-        for (const void* f : dw) {
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS_FLOATS * 4);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, as_stream(stream), A);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // both branches of a launch share the kernel variant: a branch without one of the two upstream gradients gets a
-    // zero-filled stand-in from the caller side?  No: variants are chosen per launch only when the branches agree;
-    // otherwise the general (POOL && MSGS) variant is not applicable, so the branches are launched separately.
-    auto launch_dw = [&](const EncArgs& B, int grid) {
-        const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
-        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
-        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
-        else hipLaunchKernelGGL((enc_bwd_dw_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, as_stream(stream), B);
-    };
-    const bool same = nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) &&
-                                   (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr));
-    if (same) {
-        launch_dw(A, total);
-    } else {                 // different upstream combinations: one launch per branch, each on its own share of the slots
-        for (int i = 0; i < 2; ++i) {
-            EncArgs B = A;
-            B.nbr = 1;
-            B.br[0] = B.br[1] = A.br[i];
-            launch_dw(B, i == 0 ? A.wg_split : total - A.wg_split);
-        }
-    }
-    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 63) / 64, nbr), dim3(256), 0, as_stream(stream), A,
-                       ENC_PART / 4);
-    return hipGetLastError();
+    if (int e = enc_stage_bwd_dx(br, nbr, as_stream(stream))) return e;
+    if (int e = enc_stage_bwd_dw(br, nbr, as_stream(stream))) return e;
+    return enc_stage_reduce(br, nbr, as_stream(stream));
 }

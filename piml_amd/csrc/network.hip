@@ -1,0 +1,226 @@
+// The fused PINNSF network as one call: the launch stages of encoder.hip / decoder.hip forked over HIP streams.
+//
+// Replaces the body of PINNSF.forward / its autograd backward (src/models/model.py:1271-1305: ped_encoder /
+// obs_encoder -> sum over neighbours -> decoders -> predictors -> desired force, and the `pinnsf_m` collision head
+// :1296-1300).  The stages of one step are small next to the chip (the decoder tails and the head work on 4096 agents,
+// the packs and reductions on < 1 MB), and every dependent launch on gfx950 pays ~4.5 us for the end-of-kernel
+// write-back + start-of-kernel invalidate of the eight per-XCD L2s.  Stages that do not depend on each other are
+// therefore put on side streams (event fork / join, which stream capture turns into parallel graph branches):
+//
+//   forward    main:  [enc pack] -> encoders ----------------> pooling -> decoder tails -> join
+//              side0: dec pack, head pack ----\                           ^
+//              side1:                          \-> (after encoders) head -/
+//   backward   main:  decoder dX -> encoder dX -> encoder dW ------------> join -> encoder reduction
+//              side0:            \-> decoder dW -> decoder reduction ----/
+//
+// The side streams belong to the library (one pair per device, created on first use outside any capture).
+#include <cstdio>
+#include <mutex>
+
+#include "common.hpp"
+#include "pack.hpp"
+#include "stages.hpp"
+
+namespace piml {
+
+namespace {
+
+struct Side {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t ev[6] = {};
+    bool ok = false;
+};
+
+constexpr int kMaxDevices = 64;
+Side g_side[kMaxDevices];
+std::mutex g_mu;
+
+int side_streams(Side** out) {
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_mu);
+    Side& S = g_side[dev];
+    if (!S.ok) {
+        // creating streams / events is not a capturable operation: fail clearly instead of invalidating the capture
+        for (auto& s : S.s)
+            if (hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) return e;
+        for (auto& ev : S.ev)
+            if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return e;
+        S.ok = true;
+    }
+    *out = &S;
+    return hipSuccess;
+}
+
+// `to` continues after everything enqueued on `from` so far
+int edge(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    if (hipError_t e = hipEventRecord(ev, from)) return e;
+    return hipStreamWaitEvent(to, ev, 0);
+}
+
+// a failing stage names itself on stderr: the hipError_t alone does not say which of the ~10 launches refused
+#define PIML_TRY(x)                                                                        \
+    do {                                                                                   \
+        if (int e_ = (x)) {                                                                \
+            fprintf(stderr, "libpiml_hip: %s -> %d (%s:%d)\n", #x, e_, __FILE__, __LINE__); \
+            return e_;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+}  // namespace
+
+// ---- one launch for every weight image of the network: blockIdx.y = encoder branches, decoder branches, head ----
+struct PackAll {
+    piml_encoder_branch enc[2];
+    piml_decoder_branch dec[2];
+    piml_collision_head head;
+    int nbr, has_head;
+};
+
+__global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (y < A.nbr) {
+        const piml_encoder_branch& J = A.enc[y];
+        if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
+    } else if (y < 2 * A.nbr) {
+        const piml_decoder_branch& J = A.dec[y - A.nbr];
+        if (e < DEC_PACK) J.packed[e] = dec_pack_value(J, e);
+    } else if (e < HEAD_PACK) {
+        A.head.packed[e] = head_pack_value(A.head.w1, A.head.b1, A.head.w2, A.head.b2, e);
+    }
+}
+
+// ---- one launch for every slot sum of the backward pass: blockIdx.y = encoder branches, then decoder branches ----
+struct ReduceAll {
+    const float* parts[4];
+    float* grads[4];
+    int slots[4];
+    int nbr;
+};
+
+__global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) {
+    const int y = blockIdx.y;
+    if (y < A.nbr) {
+        if ((int)blockIdx.x * 64 < ENC_PART / 4) sum_slots_64x4(A.parts[y], A.grads[y], A.slots[y], ENC_PART / 4);
+    } else {
+        if ((int)blockIdx.x * 16 < DEC_PART / 4) sum_slots_16x16(A.parts[y], A.grads[y], A.slots[y], DEC_PART / 4);
+    }
+}
+
+}  // namespace piml
+
+using namespace piml;
+
+PIML_API int piml_pinnsf_streams_init(void) {
+    Side* S;
+    return side_streams(&S);
+}
+
+// One launch on `stream`.  (Not forked internally: a fork nested inside a caller's forked stream crashed
+// hipStreamEndCapture on ROCm 7.2, tools/probe_capture_fork.py.)
+PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
+                              const piml_collision_head* head, int flags, void* stream) {
+    (void)flags;
+    if (!enc || !dec || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    PackAll A = {};
+    A.nbr = nbr;
+    A.has_head = head != nullptr;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& e = enc[i];
+        const piml_decoder_branch& d = dec[i];
+        if (e.in_dim < 1 || e.in_dim > 8 || !e.w1 || !e.b1 || !e.w2 || !e.b2 || !e.w3 || !e.b3 || !e.packed || !d.w1 || !d.b1 ||
+            !d.w2 || !d.b2 || !d.w3 || !d.b3 || !d.packed)
+            return hipErrorInvalidValue;
+        A.enc[i] = e;
+        A.dec[i] = d;
+    }
+    if (head) {
+        if (!head->w1 || !head->b1 || !head->w2 || !head->b2 || !head->packed) return hipErrorInvalidValue;
+        A.head = *head;
+    }
+    constexpr int kMax = PACK_FLOATS > DEC_PACK ? PACK_FLOATS : DEC_PACK;
+    static_assert(HEAD_PACK <= kMax, "grid covers the largest image");
+    hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((kMax + 255) / 256, 2 * nbr + (head ? 1 : 0)), dim3(256), 0,
+                       as_stream(stream), A);
+    return hipGetLastError();
+}
+
+// every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
+static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s) {
+    ReduceAll R = {};
+    R.nbr = nbr;
+    int w0 = 0;
+    const int total = piml_encoder_workgroups(enc, nbr, &w0);
+    const int dslots = piml_decoder_workgroups(dec[0].agents);
+    for (int i = 0; i < nbr; ++i) {
+        R.parts[i] = enc[i].partials;
+        R.grads[i] = enc[i].grads;
+        R.slots[i] = nbr == 1 ? total : (i == 0 ? w0 : total - w0);
+        R.parts[nbr + i] = dec[i].partials;
+        R.grads[nbr + i] = dec[i].grads;
+        R.slots[nbr + i] = dslots;
+    }
+    constexpr int ge = (ENC_PART / 4 + 63) / 64, gd = (DEC_PART / 4 + 15) / 16;
+    hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3(ge > gd ? ge : gd, 2 * nbr), dim3(256), 0, s, R);
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
+                             const piml_collision_head* head, const float* self_features, float tau, float* acc,
+                             int flags, void* stream) {
+    hipStream_t m = as_stream(stream);
+    const bool pack = !(flags & PIML_PACKED_VALID);
+    if (!(flags & PIML_FORK)) {
+        if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
+        PIML_TRY(enc_stage_fwd(enc, nbr, m));
+        if (head && head->rows > 0) PIML_TRY(dec_stage_pool_head(dec, nbr, head, m));
+        else PIML_TRY(dec_stage_pool(dec, nbr, m));
+        return dec_stage_fwd(dec, nbr, self_features, tau, acc, m);
+    }
+    Side* S;
+    PIML_TRY(side_streams(&S));
+    hipStream_t s0 = S->s[0], s1 = S->s[1];
+    if (pack) {
+        PIML_TRY(edge(m, s0, S->ev[0]));
+        PIML_TRY(dec_stage_pack(dec, nbr, s0));
+        if (head) PIML_TRY(head_stage_pack(head, s0));
+        PIML_TRY(hipEventRecord(S->ev[1], s0));
+        PIML_TRY(enc_stage_pack(enc, nbr, m));
+    }
+    PIML_TRY(enc_stage_fwd(enc, nbr, m));
+    if (head) {
+        PIML_TRY(edge(m, s1, S->ev[2]));
+        if (pack) PIML_TRY(hipStreamWaitEvent(s1, S->ev[1], 0));
+        PIML_TRY(head_stage_fwd(head, s1));
+        PIML_TRY(hipEventRecord(S->ev[3], s1));
+    }
+    PIML_TRY(dec_stage_pool(dec, nbr, m));
+    if (pack) PIML_TRY(hipStreamWaitEvent(m, S->ev[1], 0));
+    PIML_TRY(dec_stage_fwd(dec, nbr, self_features, tau, acc, m));
+    if (head) PIML_TRY(hipStreamWaitEvent(m, S->ev[3], 0));
+    return hipSuccess;
+}
+
+PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, const float* g_pred,
+                             const float* self_features, float tau, float* g_self, int flags, void* stream) {
+    hipStream_t m = as_stream(stream);
+    PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
+    if (!(flags & PIML_FORK)) {
+        PIML_TRY(dec_stage_bwd_dw(dec, nbr, g_pred, false, m));
+        PIML_TRY(enc_stage_bwd_dx(enc, nbr, m));
+        PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
+        return reduce_all(enc, dec, nbr, m);
+    }
+    Side* S;
+    PIML_TRY(side_streams(&S));
+    hipStream_t s0 = S->s[0];
+    PIML_TRY(edge(m, s0, S->ev[4]));
+    PIML_TRY(dec_stage_bwd_dw(dec, nbr, g_pred, true, s0));
+    PIML_TRY(hipEventRecord(S->ev[5], s0));
+    PIML_TRY(enc_stage_bwd_dx(enc, nbr, m));
+    PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
+    PIML_TRY(hipStreamWaitEvent(m, S->ev[5], 0));
+    return enc_stage_reduce(enc, nbr, m);
+}

@@ -1,0 +1,174 @@
+// Packed (MFMA operand fragment) images of the PINNSF weights -- layouts and the element -> source-weight maps -- and
+// the slot sums of the weight-gradient partials.  Shared by the component kernels (encoder.hip, decoder.hip) and the
+// one-launch pack / reduction of the whole network (network.hip).  Private to libpiml_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/piml_hip.h"
+
+namespace piml {
+
+constexpr int EH = 128;        // encoder hidden width
+constexpr int DH = 128;        // decoder input width (= encoder width)
+constexpr int DD = 64;         // decoder hidden / output width
+constexpr int ENC_PART = 2 * EH * EH + EH * 8 + 3 * EH;                // floats of one encoder workgroup's dW / db partial
+constexpr int DEC_PART = DD * DH + DD * DD + 2 * DD + DD + DD + 8;     // decoder: dW1 | dW2 | dW3 | db1 | db2 | db3 (+pad)
+
+// A-fragment images of a 128 x 128 nn.Linear weight (out, in), float4 index ((blk*4 + bp)*4 + q)*64 + lane:
+//   forward:       [u] = W[32 blk + i][32 bp + 8 q + 4 h + u]   (out block blk, in block bp)
+//   backward (dX): [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]   (A = W^T: in block blk, out block bp)
+// Packed weights of one encoder (floats), written once per step by enc_pack_kernel so that every workgroup stages
+// its LDS image with linear, fully coalesced copies:
+//   [ W2 fragments 16384 | W3 fragments 16384 | W1 fragments 1024 | b1 b2 b3 384 ]        forward image
+//   [ W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments 4096 ]                 dX image
+constexpr int PACK_FWD = 16384 * 2 + 1024 + 384;
+constexpr int PACK_DX = 16384 * 2 + 4096;
+constexpr int PACK_FLOATS = PACK_FWD + PACK_DX;
+
+__device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e) {
+    const int IN = J.in_dim;
+    if (e < 32768 || (e >= PACK_FWD && e < PACK_FWD + 32768)) {
+        const bool tr = e >= PACK_FWD;
+        const int f = tr ? e - PACK_FWD : e;
+        const float* W = (f < 16384) == tr ? J.w3 : J.w2;      // fwd: W2 | W3;  dX: W3^T | W2^T
+        const int g = f & 16383, u = g & 3, lane = (g >> 2) & 63, q = (g >> 8) & 3, bp = (g >> 10) & 3, blk = g >> 12;
+        const int i = lane & 31, c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
+        return tr ? W[(size_t)c * EH + 32 * blk + i] : W[(size_t)(32 * blk + i) * EH + c];
+    }
+    if (e < 32768 + 1024) {                                    // W1 fragments [blk][s][lane]
+        const int g = e - 32768, l = g & 63, sidx = (g >> 6) & 3, blk = g >> 8;
+        const int c = 2 * sidx + (l >> 5);
+        return c < IN ? J.w1[(size_t)(32 * blk + (l & 31)) * IN + c] : 0.f;
+    }
+    if (e < PACK_FWD) {
+        const int g = e - 32768 - 1024;
+        return g < 128 ? J.b1[g] : (g < 256 ? J.b2[g - 128] : J.b3[g - 256]);
+    }
+    {                                                          // W1^T fragments [bp][q][lane] float4
+        const int g = e - PACK_FWD - 32768, u = g & 3, l = (g >> 2) & 63, q = (g >> 8) & 3, bp = g >> 10;
+        const int i = l & 31, c = 32 * bp + 8 * q + 4 * (l >> 5) + u;
+        return i < IN ? J.w1[(size_t)c * IN + i] : 0.f;
+    }
+}
+
+// packed image of one branch (floats)
+constexpr int DP_A1 = 0;                         // [ob 2][bp 4][q 4][lane 64] float4   W1 (64, 128)
+constexpr int DP_A2 = DP_A1 + 2 * 4 * 4 * 256;   // [ob 2][bp 2][q 4][lane 64] float4   W2 (64, 64)
+constexpr int DP_A3 = DP_A2 + 2 * 2 * 4 * 256;   // [bp 2][q 4][lane 64] float4         W3 (2, 64), rows >= 2 are 0
+constexpr int DP_B = DP_A3 + 2 * 4 * 256;        // b1 64 | b2 64 | b3 2 | pad 2
+constexpr int DP_T3 = DP_B + 132;                // [ob 2][lane 64]                     W3^T: lane (i, h) = W3[h][32 ob + i]
+constexpr int DP_T2 = DP_T3 + 128;               // [ob 2][bp 2][q 4][lane 64] float4   W2^T
+constexpr int DP_T1 = DP_T2 + 2 * 2 * 4 * 256;   // [blk 4][bp 2][q 4][lane 64] float4  W1^T
+constexpr int DEC_PACK = DP_T1 + 4 * 2 * 4 * 256;
+
+__device__ __forceinline__ float dec_pack_value(const piml_decoder_branch& J, int e) {
+    if (e < DP_B) {                 // forward fragments
+        int f = e, rows_in;         // rows_in: input width of the layer
+        const float* W;
+        int nbp, limit_i = 64;
+        if (e < DP_A2) { W = J.w1; rows_in = DH; nbp = 4; }
+        else if (e < DP_A3) { f = e - DP_A2; W = J.w2; rows_in = DD; nbp = 2; }
+        else { f = e - DP_A3; W = J.w3; rows_in = DD; nbp = 2; limit_i = 2; }
+        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3;
+        int rest = f >> 10;
+        const int bp = rest % nbp, ob = rest / nbp;           // ob = 0 for W3
+        const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
+        return i < limit_i ? W[(size_t)i * rows_in + c] : 0.f;
+    }
+    if (e < DP_T3) {
+        const int g = e - DP_B;
+        return g < 64 ? J.b1[g] : (g < 128 ? J.b2[g - 64] : (g < 130 ? J.b3[g - 128] : 0.f));
+    }
+    if (e < DP_T2) {                // W3^T: one k-step (k = h = output component)
+        const int g = e - DP_T3, lane = g & 63, ob = g >> 6;
+        return J.w3[(size_t)(lane >> 5) * DD + 32 * ob + (lane & 31)];
+    }
+    {                               // W2^T, W1^T: [u] = W[32 bp + 8 q + 4 h + u][32 blk + i]
+        const bool t1 = e >= DP_T1;
+        const int f = t1 ? e - DP_T1 : e - DP_T2;
+        const float* W = t1 ? J.w1 : J.w2;
+        const int cols = t1 ? DH : DD;                        // input width of the layer = columns of W
+        const int u = f & 3, lane = (f >> 2) & 63, q = (f >> 8) & 3, rest = f >> 10;
+        const int bp = rest & 1, blk = rest >> 1;
+        const int r = 32 * bp + 8 * q + 4 * (lane >> 5) + u;  // output feature of the layer (row of W)
+        return W[(size_t)r * cols + 32 * blk + (lane & 31)];
+    }
+}
+
+// collision head: A1 [ob 2][bp 4][q 4][lane 64] float4 (W1 fragments) | b1 64 | b2 1 + 3 pad | w2 64 (raw row)
+constexpr int HP_B = 2 * 4 * 4 * 256;
+constexpr int HP_W2 = HP_B + 68;
+constexpr int HEAD_PACK = HP_W2 + 64;
+
+__device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                 const float* __restrict__ w2, const float* __restrict__ b2, int e) {
+    if (e < HP_B) {
+        const int u = e & 3, lane = (e >> 2) & 63, q = (e >> 8) & 3, rest = e >> 10;
+        const int bp = rest & 3, ob = rest >> 2;
+        const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
+        return w1[(size_t)i * DH + c];
+    }
+    if (e >= HP_W2) return w2[e - HP_W2];
+    const int g = e - HP_B;
+    return g < 64 ? b1[g] : (g == 64 ? b2[0] : 0.f);
+}
+
+// ---- sums over per-workgroup partial slots (fixed order: deterministic), one block of 256 threads per column group ----
+// 64 float4 columns x 4 slot groups per block: group g takes slots g, g+4, ...; groups added 0..3  (many slots)
+__device__ __forceinline__ void sum_slots_64x4(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes) {
+    __shared__ float4 sh[256];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const float4* parts = reinterpret_cast<const float4*>(partials);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < lanes) {
+        int q = grp;
+        for (; q + 12 < B; q += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(q + 4 * u) * lanes + j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; q < B; q += 4) {
+            const float4 v = parts[(size_t)q * lanes + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && j < lanes) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float4 v = sh[q * 64 + lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(grads)[j] = s;
+    }
+}
+
+// 16 float4 columns x 16 slot groups per block (few MB spread over many slots: wide grid)
+__device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes) {
+    __shared__ float4 sh[256];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + col;
+    const float4* parts = reinterpret_cast<const float4*>(partials);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < lanes)
+        for (int q = grp; q < B; q += 16) {
+            const float4 v = parts[(size_t)q * lanes + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && j < lanes) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float4 v = sh[q * 16 + col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(grads)[j] = s;
+    }
+}
+
+}  // namespace piml

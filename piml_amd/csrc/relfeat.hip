@@ -33,6 +33,8 @@ struct RelfeatArgs {
     int C, N, M, f0, fcnt, kp, ko;
     float cos_p, cos_o, cut2_p, cut2_o, dthr_p, dthr_o;
     float* ped_feat; float* obs_feat; float* dest_feat; int dest_ld; int* ped_idx; int* obs_idx;
+    const float* speed;   // non-NULL: dest_feat rows are the model's self_features rows [dest - p, v, a, v0] (dest_ld >= 7)
+    float* zero; long zero_n;   // optional: buffer this launch clears (the state gradient its backward accumulates into)
     int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates,
                   // 7 phase stamps (cycles): entry, [tile staged, pass done] per pass ..., + 1 pad}
 };
@@ -80,6 +82,10 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
     unsigned short* ring = ring_all[wave];                  // stays in the LDS address space
+
+    if (A.zero)                                             // a few 100 KB, spread over the whole grid
+        for (long e = (long)blockIdx.x * (WAVES * 64) + threadIdx.x; e < A.zero_n; e += (long)gridDim.x * (WAVES * 64))
+            A.zero[e] = 0.f;
 
     const int bpc = (A.fcnt + WAVES - 1) / WAVES;          // blocks per slice
     const int c = blockIdx.x / bpc;
@@ -286,6 +292,10 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         const float2 d = A.dest[row];
         float* df = A.dest_feat + row * A.dest_ld;          // row stride: 2, or the width of a self_features row
         df[0] = nan_to_zero(d.x - pix); df[1] = nan_to_zero(d.y - piy);                    // :496-497
+        if (A.speed) {                                      // self_features = [dest - p, v, a, v0], raw v and a
+            df[2] = vi2.x; df[3] = vi2.y; df[4] = ai2.x; df[5] = ai2.y;
+            df[6] = A.speed[row];
+        }
     }
 }
 
@@ -297,7 +307,9 @@ __global__ __launch_bounds__(256) void relfeat_bwd_kernel(
         const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
         const int* __restrict__ ped_idx, const int* __restrict__ obs_idx, const float* __restrict__ p, int ld,
         const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
-        float2* g_dest) {
+        float2* g_dest, int gld, float* __restrict__ g_speed) {
+    // gld = 2: g_destf rows are d/d(dest_feat).  gld = 7: they are d/d(self_features) rows; their v / a columns join
+    // the row's own term and column 6 is d/d(desired speed) (g_speed, may be NULL)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)C * fcnt) return;
@@ -322,12 +334,15 @@ __global__ __launch_bounds__(256) void relfeat_bwd_kernel(
     if (s0 == 0 && q < 6) {
         if (q < 2) {
             const float dq = reinterpret_cast<const float*>(dest)[row * 2 + q] - p[ci * ld + q];
-            const float gd = dq != dq ? 0.f : reinterpret_cast<const float*>(g_destf)[row * 2 + q];
+            const float gd = dq != dq ? 0.f : reinterpret_cast<const float*>(g_destf)[row * gld + q];
             reinterpret_cast<float*>(g_dest)[row * 2 + q] = gd;
             own -= gd;
+        } else if (gld == 7) {
+            own += reinterpret_cast<const float*>(g_destf)[row * 7 + q];
         }
         atomicAdd(g_state + ci * 6 + q, own);
     }
+    if (gld == 7 && g_speed && lane == 6) g_speed[row] = reinterpret_cast<const float*>(g_destf)[row * 7 + 6];
 }
 
 // Deterministic variant of relfeat_bwd (no atomics, bit-reproducible): one thread per (source agent, component).
@@ -405,13 +420,13 @@ static float dist2_cutoff(float thr) {
 
 using namespace piml;
 
-PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const float* velocity,
-                              const float* acceleration, int state_ld, const float* destination,
-                              const float* obstacles, int C, int N, int M, int focal_begin,
-                              int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
-                              float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
-                              float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
-                              int32_t* ped_idx, int32_t* obs_idx, void* stream) {
+static int relfeat_launch(const float* position, const float* heading, const float* velocity,
+                          const float* acceleration, int state_ld, const float* destination,
+                          const float* obstacles, int C, int N, int M, int focal_begin,
+                          int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                          float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                          float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
+                          int32_t* ped_idx, int32_t* obs_idx, const float* speed, float* zero, long zero_n, void* stream) {
     if (C < 0 || N < 0 || M < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
         topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK ||
         state_ld < 2 || (state_ld & 1) || dest_feat_ld < 2)
@@ -429,6 +444,7 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     A.dthr_p = dist_thr_ped; A.dthr_o = dist_thr_obs;
     A.ped_feat = ped_feat; A.obs_feat = obs_feat; A.dest_feat = dest_feat; A.dest_ld = dest_feat_ld;
     A.ped_idx = ped_idx; A.obs_idx = obs_idx;
+    A.speed = speed; A.zero = zero; A.zero_n = zero ? zero_n : 0;
     A.stats = nullptr;
 #ifdef PIML_RELFEAT_STATS
     if (const char* e = getenv("PIML_RELFEAT_STATS_PTR")) A.stats = (int*)strtoull(e, nullptr, 0);
@@ -450,6 +466,51 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     return hipGetLastError();
 }
 
+PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const float* velocity,
+                              const float* acceleration, int state_ld, const float* destination,
+                              const float* obstacles, int C, int N, int M, int focal_begin,
+                              int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                              float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                              float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
+                              int32_t* ped_idx, int32_t* obs_idx, void* stream) {
+    return relfeat_launch(position, heading, velocity, acceleration, state_ld, destination, obstacles, C, N, M, focal_begin,
+                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                          obs_feat, dest_feat, dest_feat_ld, ped_idx, obs_idx, nullptr, nullptr, 0, stream);
+}
+
+// One scene of packed (N, 6) = (p, v, a) records: the features of the focal rows AND their self_features rows
+// [dest - p, v, a, v0] (n, 7) in the same launch; `g_state_zero` (N * 6 floats, may be NULL) is cleared on the way for
+// piml_relfeat_self_bwd to accumulate into.
+PIML_API int piml_relfeat_self_fwd(const float* state, const float* destination_rows, const float* obstacles,
+                                   const float* desired_speed, int N, int M, int focal_begin, int focal_count,
+                                   int topk_ped, int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped,
+                                   float dist_thr_obs, float* ped_feat, float* obs_feat, float* self_features,
+                                   int32_t* ped_idx, int32_t* obs_idx, float* g_state_zero, void* stream) {
+    if (focal_count > 0 && (!state || !desired_speed || !self_features)) return hipErrorInvalidValue;
+    return relfeat_launch(state, nullptr, state + 2, state + 4, 6, destination_rows, obstacles, 1, N, M, focal_begin,
+                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                          obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, g_state_zero, (long)N * 6, stream);
+}
+
+// Backward of piml_relfeat_self_fwd in one launch: g_self (n, 7) carries d/d(dest_feat) in columns 0-1, d/d(v, a) of the
+// focal rows in 2-5 and d/d(desired speed) in 6.  ACCUMULATES into g_state (N, 6), which the caller (or the forward's
+// g_state_zero) has cleared; g_destination (n, 2) and g_speed (n, may be NULL) are written.
+PIML_API int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int* ped_idx,
+                                   const int* obs_idx, const float* state, const float* destination_rows, int N,
+                                   int focal_begin, int focal_count, int kp_eff, int ko_eff, float* g_state,
+                                   float* g_destination, float* g_speed, void* stream) {
+    if (N < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N || kp_eff < 0 || ko_eff < 0)
+        return hipErrorInvalidValue;
+    if (focal_count == 0) return hipSuccess;
+    if (!g_self || !state || !destination_rows || !g_state || !g_destination || (kp_eff > 0 && (!g_ped_feat || !ped_idx)) ||
+        (ko_eff > 0 && (!g_obs_feat || !obs_idx)))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
+                       g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,
+                       focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+    return hipGetLastError();
+}
+
 PIML_API int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,
                               const int32_t* ped_idx, const int32_t* obs_idx, const float* position,
                               int state_ld, const float* destination, int C, int N, int focal_begin, int focal_count,
@@ -463,7 +524,7 @@ PIML_API int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, 
     hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream),
                        g_ped_feat, g_obs_feat, (const float2*)g_dest_feat, ped_idx, obs_idx,
                        position, state_ld, (const float2*)destination, C, N, focal_begin, focal_count,
-                       kp_eff, ko_eff, g_state, (float2*)g_destination);
+                       kp_eff, ko_eff, g_state, (float2*)g_destination, 2, (float*)nullptr);
     return hipGetLastError();
 }
 

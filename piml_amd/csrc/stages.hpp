@@ -1,0 +1,29 @@
+// Launch stages of the fused PINNSF network, shared between the per-component C entries (encoder.hip, decoder.hip)
+// and the network-level entries that fork them over HIP streams (network.hip).  Private to libpiml_hip.so.
+// Every function enqueues on `s` only, validates its arguments and returns a hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/piml_hip.h"
+
+namespace piml {
+
+int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
+int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s);            // packed image must be current
+int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
+int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
+int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s);
+
+int dec_stage_pack(const piml_decoder_branch* br, int nbr, hipStream_t s);
+int dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s);
+int dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, hipStream_t s);  // pool + head
+int dec_stage_fwd(const piml_decoder_branch* br, int nbr, const float* self_features, float tau, float* acc,
+                  hipStream_t s);                                                     // after pack + pool
+int dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features, float tau,
+                     float* g_self, hipStream_t s);
+int dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s);   // partials (+ slot sum)
+
+int head_stage_pack(const piml_collision_head* h, hipStream_t s);
+int head_stage_fwd(const piml_collision_head* h, hipStream_t s);                      // packed image must be current
+
+}  // namespace piml

@@ -17,6 +17,7 @@ Reference behaviours kept on purpose:
 Deviation: in train mode the reference calls Dropout once per (discarded) block; here only the
 surviving block is evaluated, so the RNG stream differs (eval mode is exact).
 """
+import contextlib
 import os
 
 import torch
@@ -37,6 +38,7 @@ FUSED_ENCODER_MIN_ROWS = int(os.environ.get('PIML_FUSED_ENCODER_MIN_ROWS', '512'
 # ... and for `pinnsf` / `pinnsf_m` the decoder tail too (piml_amd/csrc/decoder.hip): the whole network is one autograd
 # node (ops.fused_pinnsf).  PIML_FUSED_NETWORK=0 keeps the decoders / predictors on library GEMMs.
 FUSED_NETWORK = os.environ.get('PIML_FUSED_NETWORK', '1') != '0'
+PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -152,6 +154,7 @@ class _PINNSFBase(nn.Module):
         # branch (the two are independent until their accelerations are added; inside a captured
         # HIP graph this becomes two parallel chains of GEMMs that fill the 256 CUs better)
         self.obs_stream = None
+        self._packs = None          # ops.PinnsfPacks of `packed_weights()`
         self.ped_feature_dim = args.ped_feature_dim
         self.obs_feature_dim = args.obs_feature_dim
         self.self_feature_dim = args.self_feature_dim
@@ -273,11 +276,14 @@ class _PINNSFBase(nn.Module):
                 return None
         from .. import ops
         fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
-        acc, msgs = ops.fused_pinnsf(
+        head = self._fusable_head()
+        packs = self._packs if (self._packs is not None and self._packs.active) else None
+        res = ops.fused_pinnsf(
             [dict(x=f, scale=p.pure_scale(), encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
                   predictor=[q.mlp[0].weight, q.mlp[0].bias]) for f, e, p, d, q in cand],
-            self_features, self.tau, fold_epilogue=fold)
+            self_features, self.tau, fold_epilogue=fold, head=head, packs=packs)
+        acc, msgs = res[0], res[1]
         if not fold:
             if self_features.dim() == 3:
                 acc = ops.pinnsf_epilogue(acc, None, self_features, self.tau, agent_norm=True)
@@ -287,14 +293,58 @@ class _PINNSFBase(nn.Module):
         if len(msgs) > 1:
             out.append(msgs[1])
         if self.collision_head is not None:        # 'msgs' (pinnsf_m): head on the pedestrian messages
-            head = self.ped_collision_predictor.mlp
-            if len(head) == 4 and (head[0].in_features, head[0].out_features, head[2].out_features) == (128, 64, 1) \
-                    and isinstance(head[1], nn.ReLU) and isinstance(head[3], nn.Identity):
-                out.append(ops.collision_head(msgs[0], head[0].weight, head[0].bias, head[2].weight,
-                                              head[2].bias).squeeze())
+            if head is not None:
+                out.append(res[2].squeeze())
             else:
                 out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
         return out
+
+    def _fusable_head(self):
+        """(w1, b1, w2, b2) of the `pinnsf_m` collision head when it has the reference geometry MLP(128, [64, 1])."""
+        if self.collision_head != 'msgs':
+            return None
+        head = self.ped_collision_predictor.mlp
+        if len(head) == 4 and (head[0].in_features, head[0].out_features, head[2].out_features) == (128, 64, 1) \
+                and isinstance(head[1], nn.ReLU) and isinstance(head[3], nn.Identity):
+            return (head[0].weight, head[0].bias, head[2].weight, head[2].bias)
+        return None
+
+    def _pack_spec(self):
+        """Weights of the fused network in ops.pinnsf_prepack order, or None when `_fused_network` would not run."""
+        if self.bottleneck or self.residual or not FUSED_NETWORK or not FUSED_ENCODER:
+            return None
+        cand = [(self.ped_encoder, self.ped_decoder, self.ped_predictor)]
+        if self.obs_feature_dim > 0:
+            cand.append((self.obs_encoder, self.obs_decoder, self.obs_predictor))
+        enc_w, dec_w = [], []
+        for e, d, q in cand:
+            el, dl = e.mlp[0::2], d.mlp[0::2]
+            if len(el) != 3 or len(dl) != 2 or len(q.mlp) != 2 or not el[0].weight.is_cuda \
+                    or el[0].weight.dtype != torch.float32 or el[0].in_features > 8:
+                return None
+            enc_w.append([t for lin in el for t in (lin.weight, lin.bias)])
+            dec_w.append([t for lin in dl for t in (lin.weight, lin.bias)] + [q.mlp[0].weight, q.mlp[0].bias])
+        return enc_w, dec_w, self._fusable_head()
+
+    @contextlib.contextmanager
+    def packed_weights(self):
+        """Pack the weights into MFMA operand fragments ONCE for every forward pass inside the block.  For code whose
+        weights do not change inside the block: a rollout (no pack launch per frame), or the frames of one
+        back-propagated training step (the optimizer step comes after the block).  Without it every forward pass packs
+        for itself.  No-op for configurations the fused network does not cover; re-entrant."""
+        spec = self._pack_spec()
+        if spec is None or not PREPACK or (self._packs is not None and self._packs.active):
+            yield
+            return
+        from .. import ops
+        if self._packs is None:
+            self._packs = ops.PinnsfPacks()
+        ops.pinnsf_prepack(self._packs, *spec)
+        self._packs.active = True
+        try:
+            yield
+        finally:
+            self._packs.active = False
 
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'

@@ -196,9 +196,9 @@ class _RelativeFeaturesPacked(torch.autograd.Function):
 
 class _RelativeFeaturesPackedSelf(torch.autograd.Function):
     """_RelativeFeaturesPacked for a 2-D (N, 6) state that returns the model's self_features rows
-    (n, 7) = [dest - p, v, a, v0] instead of dest_features: the relfeat kernel writes columns 0-1 in place
-    (dest_feat_ld = 7) and one small kernel the rest; backward seeds the (N, 6) state gradient with the
-    self-feature part and lets the relfeat backward accumulate into it (no zero fill, no add)."""
+    (n, 7) = [dest - p, v, a, v0] instead of dest_features, all from ONE launch (piml_relfeat_self_fwd); when a
+    gradient will flow, the same launch clears the (N, 6) state-gradient buffer that the ONE backward launch
+    (piml_relfeat_self_bwd: scatter + the rows' own terms + the self-feature columns) accumulates into."""
 
     @staticmethod
     def forward(ctx, state, destination_rows, obstacles, desired_speed, focal_begin, focal_count, kp, ko,
@@ -219,12 +219,13 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
         outs = (torch.empty(focal_count, kpe, 6, **opt), torch.empty(focal_count, koe, 6, **opt), sf,
                 torch.empty(focal_count, kpe, device=s.device, dtype=torch.int32),
                 torch.empty(focal_count, koe, device=s.device, dtype=torch.int32))
-        base = s.data_ptr()
-        _launch_relfeat_fwd(base, base + 8, base + 16, 6, None, d_rows, o, (), 1, N, focal_begin, focal_count,
-                            kp, ko, cos_p, cos_o, dthr_p, dthr_o, s.device, outs=outs, dest_ld=7)
+        need_grad = any(ctx.needs_input_grad[:4]) and not DETERMINISTIC_BWD
+        ctx.g_state = torch.empty(N, 6, **opt) if need_grad else None       # cleared by the launch below
         with torch.cuda.device(s.device):
-            _lib.check(_lib.lib().piml_self_features_fwd(None, 7, base + 24 * focal_begin, _ptr(w), focal_count,
-                                                         _ptr(sf), _stream()), 'piml_self_features_fwd')
+            _lib.check(_lib.lib().piml_relfeat_self_fwd(
+                _ptr(s), _ptr(d_rows), _ptr(o), _ptr(w), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o,
+                dthr_p, dthr_o, _ptr(outs[0]), _ptr(outs[1]), _ptr(sf), _ptr(outs[3]), _ptr(outs[4]),
+                _ptr(ctx.g_state), _stream()), 'piml_relfeat_self_fwd')
         ctx.save_for_backward(outs[3], outs[4], s, d_rows)
         ctx.geom = (1, N, focal_begin, focal_count, kpe, koe, ())
         ctx.speed_shape = tuple(desired_speed.shape)
@@ -237,22 +238,37 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
         if g_ped is None and g_obs is None and g_self is None:
             return (None,) * 12
         ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
-        _, N, f0, fcnt, _, _, _ = ctx.geom
+        _, N, f0, fcnt, kpe, koe, _ = ctx.geom
         opt = dict(device=s.device, dtype=torch.float32)
-        g_dest, g_speed = None, None
-        if g_self is None:
+        if DETERMINISTIC_BWD:                 # sorted, atomics-free path: seed with the self-feature part, then gather
+            g_dest, g_speed = None, None
+            if g_self is None:
+                g_state = torch.zeros(N, 6, **opt)
+            else:
+                g_self = g_self.contiguous()
+                g_state = torch.empty(N, 6, **opt) if fcnt == N else torch.zeros(N, 6, **opt)
+                g_dest = torch.empty(fcnt, 2, **opt)
+                g_speed = torch.empty(ctx.speed_shape, **opt) if ctx.needs_input_grad[3] else None
+                with torch.cuda.device(s.device):
+                    _lib.check(_lib.lib().piml_self_features_bwd(_ptr(g_self), fcnt, _ptr(g_dest),
+                                                                 g_state.data_ptr() + 24 * f0, _ptr(g_speed),
+                                                                 _stream()), 'piml_self_features_bwd')
+            g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, s.data_ptr(), 6,
+                                                    d_rows, s.device, g_state=g_state)
+            return (g_state, g_d_rows, None, g_speed) + (None,) * 8
+
+        def dense(g, shape):
+            return torch.zeros(shape, **opt) if g is None else _gpu_f32('grad', g)
+        g_ped, g_obs, g_self = dense(g_ped, (fcnt, kpe, 6)), dense(g_obs, (fcnt, koe, 6)), dense(g_self, (fcnt, 7))
+        g_state, ctx.g_state = ctx.g_state, None        # the forward's cleared buffer, once; a second backward pass
+        if g_state is None:                             # (retain_graph) clears a fresh one
             g_state = torch.zeros(N, 6, **opt)
-        else:
-            g_self = g_self.contiguous()
-            g_state = torch.empty(N, 6, **opt) if fcnt == N else torch.zeros(N, 6, **opt)
-            g_dest = torch.empty(fcnt, 2, **opt)
-            g_speed = torch.empty(ctx.speed_shape, **opt) if ctx.needs_input_grad[3] else None
-            with torch.cuda.device(s.device):
-                _lib.check(_lib.lib().piml_self_features_bwd(_ptr(g_self), fcnt, _ptr(g_dest),
-                                                             g_state.data_ptr() + 24 * f0, _ptr(g_speed),
-                                                             _stream()), 'piml_self_features_bwd')
-        g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, s.data_ptr(), 6,
-                                                d_rows, s.device, g_state=g_state)
+        g_d_rows = torch.empty(fcnt, 2, **opt)
+        g_speed = torch.empty(ctx.speed_shape, **opt) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().piml_relfeat_self_bwd(
+                _ptr(g_ped), _ptr(g_obs), _ptr(g_self), _ptr(ped_idx), _ptr(obs_idx), _ptr(s), _ptr(d_rows), N, f0, fcnt,
+                kpe, koe, _ptr(g_state), _ptr(g_d_rows), _ptr(g_speed), _stream()), 'piml_relfeat_self_bwd')
         return (g_state, g_d_rows, None, g_speed) + (None,) * 8
 
 
@@ -1266,19 +1282,95 @@ def _dec_branch_struct(msgs, agents, k, wb, packed, pooled=None, h1=None, d2=Non
     return B
 
 
+class PinnsfPacks:
+    """Persistent MFMA operand images of one network's weights (encoder, decoder and head fragments) for callers whose
+    weights stay put over several forward passes: a rollout (every frame of it), or the frames of one back-propagated
+    training step.  `pinnsf_prepack` fills them once; forward passes given `packs=` then skip their own packs (one small
+    launch each).  The caller owns the promise that the weights are not modified between the prepack and the last
+    backward that uses the images (models.model._PINNSFBase.packed_weights is the context manager that keeps it)."""
+
+    def __init__(self):
+        self.epack = self.dpack = self.hpack = None
+        self.sig = None          # data pointers of the packed weights
+        self.active = False
+
+    def __deepcopy__(self, memo):          # images are derived data: a copied model packs for itself
+        return PinnsfPacks()
+
+    def __reduce__(self):
+        return (PinnsfPacks, ())
+
+    def ensure(self, dev):
+        if self.epack is None or self.epack.device != dev:
+            L = _lib.lib()
+            opt = dict(device=dev, dtype=torch.float32)
+            self.epack = torch.empty(2, L.piml_encoder_pack_floats(), **opt)
+            self.dpack = torch.empty(2, L.piml_decoder_pack_floats(), **opt)
+            self.hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt)
+
+
+def _pack_structs(enc_w, dec_w, head_w, packs):
+    nbr = len(enc_w)
+    earr = (_lib.EncoderBranch * nbr)()
+    darr = (_lib.DecoderBranch * nbr)()
+    for b in range(nbr):
+        earr[b].in_dim = enc_w[b][0].shape[1]
+        earr[b].w1, earr[b].b1, earr[b].w2, earr[b].b2, earr[b].w3, earr[b].b3 = [t.data_ptr() for t in enc_w[b]]
+        earr[b].packed = packs.epack[b].data_ptr()
+        darr[b].w1, darr[b].b1, darr[b].w2, darr[b].b2, darr[b].w3, darr[b].b3 = [t.data_ptr() for t in dec_w[b]]
+        darr[b].packed = packs.dpack[b].data_ptr()
+    head = None
+    if head_w is not None:
+        head = _lib.CollisionHead()
+        head.w1, head.b1, head.w2, head.b2 = [t.data_ptr() for t in head_w]
+        head.packed = packs.hpack.data_ptr()
+    return earr, darr, head
+
+
+def _weights_sig(enc_w, dec_w, head_w):
+    return tuple(t.data_ptr() for wb in (*enc_w, *dec_w, *([head_w] if head_w is not None else [])) for t in wb)
+
+
+def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
+    """Pack the weights of a fused PINNSF network into `packs` (one launch on the current stream).
+    enc_w / dec_w: per branch (w1, b1, w2, b2, w3, b3) encoder and (w1, b1, w2, b2, wp, bp) decoder + predictor tensors;
+    head_w: (w1, b1, w2, b2) of the collision head or None."""
+    import ctypes
+    enc_w = [[_gpu_f32('encoder weight', t.detach()) for t in wb] for wb in enc_w]
+    dec_w = [[_gpu_f32('decoder weight', t.detach()) for t in wb] for wb in dec_w]
+    head_w = None if head_w is None else [_gpu_f32('head weight', t.detach()) for t in head_w]
+    dev = enc_w[0][0].device
+    packs.ensure(dev)
+    earr, darr, head = _pack_structs(enc_w, dec_w, head_w, packs)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().piml_pinnsf_pack(earr, darr, len(enc_w), ctypes.byref(head) if head is not None else None,
+                                               0, _stream()), 'piml_pinnsf_pack')
+    packs.sig = _weights_sig(enc_w, dec_w, head_w)
+
+
+# side streams inside piml_pinnsf_fwd / bwd: off by default (cross-stream edges cost more than they hide in a HIP graph)
+FORK_NETWORK = _os.environ.get('PIML_FORK_NETWORK', '0') == '1'
+
+
 class _FusedPinnsf(torch.autograd.Function):
-    """inputs: need_grad, nbr, scales, tau, fold_epilogue, self_features (..., N, 7), then per branch
-    x (..., N, k, in), encoder w1 b1 w2 b2 w3 b3, decoder w1 b1 w2 b2, predictor w b  (13 tensors).
-    outputs: acc (..., N, 2) (= predictions when fold_epilogue), msgs (..., N, k, 128) per branch."""
+    """inputs: need_grad, nbr, scales, tau, fold_epilogue, packs (PinnsfPacks or None), nhead (0 / 1),
+    self_features (..., N, 7), then per branch x (..., N, k, in), encoder w1 b1 w2 b2 w3 b3, decoder w1 b1 w2 b2,
+    predictor w b (13 tensors), then the collision head's w1 b1 w2 b2 when nhead.
+    outputs: acc (..., N, 2) (= predictions when fold_epilogue), msgs (..., N, k, 128) per branch, and with a head
+    sigmoid(head(msgs of branch 0)) (..., N, k)."""
     PER = 13
+    FIRST = 8          # index of the first branch tensor among the inputs
+    SELF = 7           # index of self_features
 
     @staticmethod
-    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, self_features, *tensors):
+    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, packs, nhead, self_features, *tensors):
+        import ctypes
         L = _lib.lib()
         PER = _FusedPinnsf.PER
         xs = [tensors[PER * b] for b in range(nbr)]
         ewb = [[_gpu_f32('encoder weight', t.detach()) for t in tensors[PER * b + 1:PER * b + 7]] for b in range(nbr)]
         dwb = [[_gpu_f32('decoder weight', t.detach()) for t in tensors[PER * b + 7:PER * b + 13]] for b in range(nbr)]
+        hwb = [_gpu_f32('head weight', t.detach()) for t in tensors[PER * nbr:PER * nbr + 4]] if nhead else None
         dev = xs[0].device
         opt = dict(device=dev, dtype=torch.float32)
         H = ENCODER_HIDDEN
@@ -1298,8 +1390,16 @@ class _FusedPinnsf(torch.autograd.Function):
             msgs.append(torch.empty(R, H, **opt))
             h1s.append(torch.empty(R, H, **opt) if need_grad else None)
             h2s.append(torch.empty(R, H, **opt) if need_grad else None)
-        epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
-        dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+        flags = _lib.FORK if FORK_NETWORK else 0
+        if packs is not None:
+            if packs.sig != _weights_sig(ewb, dwb, hwb):
+                raise ValueError('fused_pinnsf: `packs` were filled from other weight tensors (pinnsf_prepack first)')
+            epack, dpack, hpack = packs.epack, packs.dpack, packs.hpack
+            flags |= _lib.PACKED_VALID
+        else:
+            epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
+            dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+            hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt) if nhead else None
         earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
                                                                packed=epack[b]) for b in range(nbr)])
         pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
@@ -1308,25 +1408,38 @@ class _FusedPinnsf(torch.autograd.Function):
         darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
                                                                dh1[b], dd2[b]) for b in range(nbr)])
         acc = torch.empty(agents, 2, **opt)
+        head, coll = None, None
+        if nhead:
+            coll = torch.empty(x2s[0].shape[0], **opt)
+            head = _lib.CollisionHead()
+            head.msgs, head.rows = msgs[0].data_ptr(), x2s[0].shape[0]
+            head.w1, head.b1, head.w2, head.b2 = [t.data_ptr() for t in hwb]
+            head.packed, head.out = hpack.data_ptr(), coll.data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(L.piml_encoder_fwd(earr, nbr, _stream()), 'piml_encoder_fwd')
-            _lib.check(L.piml_decoder_fwd(darr, nbr, _ptr(sf), float(tau), _ptr(acc), _stream()), 'piml_decoder_fwd')
+            _lib.check(L.piml_pinnsf_fwd(earr, darr, nbr, ctypes.byref(head) if head is not None else None, _ptr(sf),
+                                         float(tau), _ptr(acc), flags, _stream()), 'piml_pinnsf_fwd')
         if need_grad:
             ctx.save_for_backward(*x2s, *h1s, *h2s, *msgs, *pooled, *dh1, *dd2, *[w for wb in ewb for w in wb],
-                                  *[w for wb in dwb for w in wb], epack, dpack, *([sf] if sf is not None else []))
+                                  *[w for wb in dwb for w in wb], epack, dpack, *([sf] if sf is not None else []),
+                                  *(hwb if nhead else []))
         ctx.meta = (nbr, tuple(scales), float(tau), bool(fold_epilogue), tuple(ks), [tuple(x.shape) for x in xs],
-                    tuple(self_features.shape), agents, need_grad)
+                    tuple(self_features.shape), agents, need_grad, int(nhead))
         ctx.set_materialize_grads(False)
-        return (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
+        out = (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
+        if nhead:
+            out = out + (coll.view(*lead, ks[0]),)
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_acc, *g_msgs):
-        nbr, scales, tau, fold, ks, xshapes, sf_shape, agents, need_grad = ctx.meta
-        PER = _FusedPinnsf.PER
-        nin = 6 + PER * nbr
+    def backward(ctx, g_acc, *g_rest):
+        nbr, scales, tau, fold, ks, xshapes, sf_shape, agents, need_grad, nhead = ctx.meta
+        PER, FIRST = _FusedPinnsf.PER, _FusedPinnsf.FIRST
+        nin = FIRST + PER * nbr + 4 * nhead
         grads = [None] * nin
-        if not need_grad or (g_acc is None and all(g is None for g in g_msgs)):
+        g_msgs = list(g_rest[:nbr])
+        g_coll = g_rest[nbr] if nhead else None
+        if not need_grad or (g_acc is None and g_coll is None and all(g is None for g in g_msgs)):
             return tuple(grads)
         L = _lib.lib()
         sv = list(ctx.saved_tensors)
@@ -1336,35 +1449,66 @@ class _FusedPinnsf(torch.autograd.Function):
         dwb = [take(6) for _ in range(nbr)]
         epack, dpack = take(2)
         sf = sv.pop(0) if fold else None
+        hwb = take(4) if nhead else None
         dev = x2s[0].device
         opt = dict(device=dev, dtype=torch.float32)
         H = ENCODER_HIDDEN
-        g_pooled = [None] * nbr
+        flags = _lib.FORK if FORK_NETWORK else 0
+        if g_coll is not None:           # rare (the reference trains this head for `pinnsf_bm` only): torch ops
+            with torch.enable_grad():
+                ins = [t.detach().requires_grad_(True) for t in (msgs[0], *hwb)]
+                y = torch.sigmoid(torch.relu(ins[0] @ ins[1].t() + ins[2]) @ ins[3].t() + ins[4]).squeeze(-1)
+                hg = torch.autograd.grad(y, ins, g_coll.reshape(-1), allow_unused=True)
+            o = FIRST + PER * nbr
+            for jx in range(4):
+                if ctx.needs_input_grad[o + jx]:
+                    grads[o + jx] = hg[1 + jx]
+            g_msgs[0] = hg[0] if g_msgs[0] is None else g_msgs[0].reshape(-1, H) + hg[0]
+        live = [b for b in range(nbr) if g_acc is not None or g_msgs[b] is not None]
         keep = []
         with torch.cuda.device(dev):
-            # ---- decoder tail ----
-            if g_acc is not None:
+            part = L.piml_encoder_partial_floats()
+            estructs, g_pooled = [], [None] * nbr
+            for b in live:
+                R, in_dim = x2s[b].shape
+                gm = _gpu_f32('g_msgs', g_msgs[b]).reshape(R, H) if g_msgs[b] is not None else None
+                g2, g1 = torch.empty(R, H, **opt), torch.empty(R, H, **opt)
+                gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[FIRST + PER * b] else None
+                if g_acc is not None:
+                    g_pooled[b] = torch.empty(agents, H, **opt)
+                keep.append((gm, g2, g1, gx))
+                estructs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], None, h1s[b], h2s[b], g_pooled[b], gm,
+                                                   g2, g1, gx, packed=epack[b]))
+            earr = (_lib.EncoderBranch * len(live))(*estructs)
+            import ctypes
+            w0 = ctypes.c_int(0)
+            total = L.piml_encoder_workgroups(earr, len(live), ctypes.byref(w0))
+            slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
+            parts = [torch.empty(n, part, **opt) for n in slots]
+            flats = [torch.empty(part, **opt) for _ in slots]
+            for i in range(len(live)):
+                earr[i].partials, earr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
+            if g_acc is not None:           # decoder tails + encoders: one forked call
                 ga = _gpu_f32('g_acc', g_acc).reshape(agents, 2)
-                want_self = fold and ctx.needs_input_grad[5]
+                want_self = fold and ctx.needs_input_grad[_FusedPinnsf.SELF]
                 g_self = torch.empty(agents, 7, **opt) if want_self else None
                 nwg = L.piml_decoder_workgroups(agents)
                 dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
                 dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
-                structs = []
+                dstructs = []
                 for b in range(nbr):
-                    g_pooled[b] = torch.empty(agents, H, **opt)
                     gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
                     keep += [gp2, gp1]
-                    structs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
-                                                      gp2, gp1, g_pooled[b], dparts[b], dflats[b]))
-                darr = (_lib.DecoderBranch * nbr)(*structs)
-                _lib.check(L.piml_decoder_bwd(darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), _stream()),
-                           'piml_decoder_bwd')
+                    dstructs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
+                                                       gp2, gp1, g_pooled[b], dparts[b], dflats[b]))
+                darr = (_lib.DecoderBranch * nbr)(*dstructs)
+                _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags,
+                                             _stream()), 'piml_pinnsf_bwd')
                 if want_self:
-                    grads[5] = g_self.view(sf_shape)
+                    grads[_FusedPinnsf.SELF] = g_self.view(sf_shape)
                 for b in range(nbr):
                     flat = dflats[b]
-                    o = 6 + PER * b + 7
+                    o = FIRST + PER * b + 7
                     need = ctx.needs_input_grad[o:o + 6]
                     dW1, dW2 = flat[:64 * H].view(64, H), flat[64 * H:64 * H + 4096].view(64, 64)
                     dW3 = flat[64 * H + 4096:64 * H + 4096 + 128].view(2, 64)
@@ -1372,50 +1516,32 @@ class _FusedPinnsf(torch.autograd.Function):
                     for jx, t in enumerate((dW1, rest[:64], dW2, rest[64:128], dW3, rest[128:130])):
                         if need[jx]:
                             grads[o + jx] = t
-            # ---- encoders ----
-            live = [b for b in range(nbr) if g_pooled[b] is not None or g_msgs[b] is not None]
-            if live:
-                part = L.piml_encoder_partial_floats()
-                structs = []
-                for b in live:
-                    R, in_dim = x2s[b].shape
-                    gm = _gpu_f32('g_msgs', g_msgs[b]).reshape(R, H) if g_msgs[b] is not None else None
-                    g2, g1 = torch.empty(R, H, **opt), torch.empty(R, H, **opt)
-                    gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[6 + PER * b] else None
-                    keep.append((gm, g2, g1, gx))
-                    structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], None, h1s[b], h2s[b], g_pooled[b], gm,
-                                                      g2, g1, gx, packed=epack[b]))
-                earr = (_lib.EncoderBranch * len(live))(*structs)
-                import ctypes
-                w0 = ctypes.c_int(0)
-                total = L.piml_encoder_workgroups(earr, len(live), ctypes.byref(w0))
-                slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
-                parts = [torch.empty(n, part, **opt) for n in slots]
-                flats = [torch.empty(part, **opt) for _ in slots]
-                for i in range(len(live)):
-                    earr[i].partials, earr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
+            else:                            # only the messages carry a gradient: the encoders alone
                 _lib.check(L.piml_encoder_bwd(earr, len(live), _stream()), 'piml_encoder_bwd')
-                for i, b in enumerate(live):
-                    flat = flats[i]
-                    in_dim = x2s[b].shape[1]
-                    o = 6 + PER * b
-                    need = ctx.needs_input_grad[o:o + 7]
-                    if need[0]:
-                        grads[o] = keep[len(keep) - len(live) + i][3].view(xshapes[b])
-                    dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
-                    dW1 = flat[2 * H * H:2 * H * H + H * in_dim].view(H, in_dim)
-                    db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
-                    for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
-                        if need[jx]:
-                            grads[o + jx] = t
+            for i, b in enumerate(live):
+                flat = flats[i]
+                in_dim = x2s[b].shape[1]
+                o = FIRST + PER * b
+                need = ctx.needs_input_grad[o:o + 7]
+                if need[0]:
+                    grads[o] = keep[i][3].view(xshapes[b])
+                dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
+                dW1 = flat[2 * H * H:2 * H * H + H * in_dim].view(H, in_dim)
+                db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
+                for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
+                    if need[jx]:
+                        grads[o + jx] = t
         return tuple(grads)
 
 
-def fused_pinnsf(branches, self_features, tau, fold_epilogue=True):
+def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, packs=None):
     """The non-bottleneck PINNSF network on the fused kernels.  branches: 1 or 2 dicts {x (..., N, k, in <= 8), scale,
     encoder: (w1, b1, w2, b2, w3, b3), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b)}.
     Returns (acc (..., N, 2), [msgs per branch]): acc = sum over branches of predictor(decoder(sum_k msgs)), plus the
-    desired-force term (v0 d/|d| - v) / tau of self_features (..., N, 7) when fold_epilogue."""
+    desired-force term (v0 d/|d| - v) / tau of self_features (..., N, 7) when fold_epilogue.
+    head: (w1 (64,128), b1, w2 (1,64), b2) of the `pinnsf_m` collision head; its sigmoid output on the messages of
+    branch 0, (..., N, k), is appended to the result (computed beside the decoder tails on a side stream).
+    packs: a PinnsfPacks filled by pinnsf_prepack from these very weights (skips the in-call packs)."""
     if not 1 <= len(branches) <= 2:
         raise ValueError('fused_pinnsf: one or two branches')
     flat = []
@@ -1432,11 +1558,18 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True):
             raise ValueError('fused_pinnsf: unsupported geometry (encoder in<=8 -> 128 x3, decoder 128 -> 64 -> 64, '
                              'predictor 64 -> 2)')
         flat += [x, *e, *d, *p]
+    if head is not None:
+        if [tuple(t.shape) for t in head] != [(64, ENCODER_HIDDEN), (64,), (1, 64), (1,)]:
+            raise ValueError('fused_pinnsf: head must be (w1 (64,128), b1 (64), w2 (1,64), b2 (1))')
+        flat += list(head)
     if tuple(self_features.shape[:-1]) != tuple(branches[0]['x'].shape[:-2]) or self_features.shape[-1] != 7:
         raise ValueError('fused_pinnsf: self_features (..., N, 7) must match the features\' leading shape')
     need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in flat) or self_features.requires_grad)
     out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
-                             bool(fold_epilogue), self_features, *flat)
+                             bool(fold_epilogue), packs, int(head is not None), self_features, *flat)
+    nbr = len(branches)
+    if head is not None:
+        return out[0], list(out[1:1 + nbr]), out[1 + nbr]
     return out[0], list(out[1:])
 
 

@@ -179,3 +179,100 @@ def test_fused_network_matches_plain_torch(name, shape):
         worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
     print(f'{name} {shape}: fused network vs plain torch, max rel err {worst:.1e}')
     assert worst <= 2e-5
+
+
+def _multitask_net(seed=0):
+    import types
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16,
+        decoder_hidden_layers=2, dropout=0.5, activation='relu', dataset_name='gc1560')
+    torch.manual_seed(seed)
+    return MODEL.PINNSF_multitask(args).to(DEV).eval()
+
+
+def _net_pass(net, base):
+    ins = [t.clone().requires_grad_(True) for t in base]
+    net.zero_grad(set_to_none=True)
+    out = net(*ins)
+    (out[0].square().sum() + out[1].sum() * 1e-2 + out[2].square().sum() * 1e-3).backward()
+    return [o.detach().clone() for o in out] + [t.grad.clone() for t in ins] + \
+        [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+
+def test_network_streams_and_prepack_are_bitwise_neutral():
+    """The network call in program order (default), its forked form (PIML_FORK: side streams inside piml_pinnsf_fwd /
+    bwd) and the prepacked form (`packed_weights()`: one pack per block, skipped in the forward passes) run the same
+    kernels on the same data: every output and gradient is bitwise equal.  A weight update between two `packed_weights()` blocks
+    must be seen by the second one."""
+    from piml_amd import ops
+    net = _multitask_net()
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn(700, 6, 6, generator=g).to(DEV), torch.randn(700, 10, 6, generator=g).to(DEV),
+            torch.randn(700, 7, generator=g).to(DEV)]
+    ref = _net_pass(net, base)
+    assert len(ref) > 20                                     # head output + every weight gradient present
+    old = ops.FORK_NETWORK
+    try:
+        ops.FORK_NETWORK = True
+        serial = _net_pass(net, base)
+    finally:
+        ops.FORK_NETWORK = old
+    with net.packed_weights():
+        packed = _net_pass(net, base)
+        packed2 = _net_pass(net, base)                       # second pass inside the block: no pack at all
+    for name, other in (('forked', serial), ('packed', packed), ('packed, 2nd pass', packed2)):
+        for a, b in zip(ref, other):
+            assert torch.equal(a, b), name
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.01)
+    ref2 = _net_pass(net, base)
+    with net.packed_weights():
+        packed3 = _net_pass(net, base)
+    assert not torch.equal(ref2[0], ref[0])
+    for a, b in zip(ref2, packed3):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
+
+
+def test_prepacked_network_in_a_captured_graph():
+    """`packed_weights()` inside a captured step: the pack is part of the graph, re-run by every replay (so weight
+    updates between replays are seen), and the replay equals the eager pass bitwise."""
+    net = _multitask_net(3)
+    g = torch.Generator().manual_seed(6)
+    base = [torch.randn(512, 6, 6, generator=g).to(DEV), torch.randn(512, 10, 6, generator=g).to(DEV),
+            torch.randn(512, 7, generator=g).to(DEV)]
+    params = [p for p in net.parameters()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            with net.packed_weights():
+                _net_pass(net, base)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    net.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), net.packed_weights():
+        out = net(*base)
+        (out[0].square().sum() + out[1].sum() * 1e-2).backward()
+    for scale in (1.0, 0.97):
+        with torch.no_grad():
+            for p in params:
+                p.mul_(scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [o.detach().clone() for o in out] + [p.grad.clone() for p in params if p.grad is not None]
+        saved = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        eager_out = net(*base)
+        (eager_out[0].square().sum() + eager_out[1].sum() * 1e-2).backward()
+        want = [o.detach() for o in eager_out] + [p.grad for p in params if p.grad is not None]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        for p, gsave in zip(params, saved):
+            p.grad = gsave
