@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void enc_ksum_kernel(const float4* __restrict_
 // backward, part 1: the dX chain.  g3[row] = scale * (g_pooled[row / k] + g_msgs[row]) (either may be absent);
 // g_h2 = W3^T g3, g2 = g_h2 * [h2 > 0] (stored); g_h1 = W2^T g2, g1 = g_h1 * [h1 > 0] (stored); g_x = W1^T g1.
 // ---------------------------------------------------------------------------------------------------------
-// LDS (floats): W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments [bp 4][q 4][lane 64] float4 = 4096
-constexpr int DX_LDS_FLOATS = 16384 * 2 + 4096;               // = PACK_DX
+// LDS (floats): W3^T fragments 16384 | W2^T fragments 16384 | W1 rows [f 128][8] = 1024
+constexpr int DX_LDS_FLOATS = 16384 * 2 + 1024;               // = PACK_DX
 
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 
     const float4* W3t = reinterpret_cast<const float4*>(lds);
     const float4* W2t = reinterpret_cast<const float4*>(lds + 16384);
-    const float4* W1t = reinterpret_cast<const float4*>(lds + 32768);
+    const float4* W1r = reinterpret_cast<const float4*>(lds + 32768);      // row f = float4 2 f, 2 f + 1
     const bool want_gx = J.g_x != nullptr;
     stage_linear(lds, J.packed + PACK_FWD, PACK_DX, tid);
     __syncthreads();
@@ -322,27 +322,40 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                 for (int r = 0; r < 16; ++r) g[blk][r] = 0.f;
             }
         }
-        // ---- g_x = W1^T g1: one M block (input features padded to 32) ----
+        // ---- g_x = W1^T g1 on the vector pipe: the product has in_dim <= 8 output columns, an MFMA would pad them to 32
+        // (64 of the tile's 576 matrix instructions for 1/5 of a block).  Lane (row, h) holds half of the row's g1
+        // features: 8 partial dot products over them (explicit FMAs: the file is built with -ffp-contract=off), the other
+        // half arrives with one cross-half exchange.
         if (want_gx) {
-            f32x16 gx;
+            float gx[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+            for (int c = 0; c < 8; ++c) gx[c] = 0.f;
 #pragma unroll
-            for (int bp = 0; bp < 4; ++bp)
+            for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 w = W1t[(bp * 4 + q) * 64 + lane];
-                    gx = mfma32(w.x, g[bp][4 * q + 0], gx);
-                    gx = mfma32(w.y, g[bp][4 * q + 1], gx);
-                    gx = mfma32(w.z, g[bp][4 * q + 2], gx);
-                    gx = mfma32(w.w, g[bp][4 * q + 3], gx);
-                }
-            if (valid) {       // register r of half h holds input feature r + 4 h (r < 4)
-                float* o = J.g_x + row * IN;
-                const float v[4] = {gx[0], gx[1], gx[2], gx[3]};
+                    __builtin_amdgcn_sched_barrier(0);      // 8 LDS reads in flight per group, not all 128 (spills)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r + 4 * h < IN) o[r + 4 * h] = v[r];
+                    for (int u = 0; u < 4; ++u) {
+                        const int f = feat0(blk, q, h) + u;
+                        const float4 wa = W1r[2 * f], wb = W1r[2 * f + 1];
+                        const float v = g[blk][4 * q + u];
+                        gx[0] = __fmaf_rn(wa.x, v, gx[0]); gx[1] = __fmaf_rn(wa.y, v, gx[1]);
+                        gx[2] = __fmaf_rn(wa.z, v, gx[2]); gx[3] = __fmaf_rn(wa.w, v, gx[3]);
+                        gx[4] = __fmaf_rn(wb.x, v, gx[4]); gx[5] = __fmaf_rn(wb.y, v, gx[5]);
+                        gx[6] = __fmaf_rn(wb.z, v, gx[6]); gx[7] = __fmaf_rn(wb.w, v, gx[7]);
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) gx[c] += __shfl_xor(gx[c], 32, 64);
+            if (valid) {       // half h stores input features 4 h .. 4 h + 3
+                float* o = J.g_x + row * IN + 4 * h;
+                const int left = IN - 4 * h;       // scalar selects (an array select goes through scratch)
+                const float s0 = h ? gx[4] : gx[0], s1 = h ? gx[5] : gx[1], s2 = h ? gx[6] : gx[2], s3 = h ? gx[7] : gx[3];
+                if (left > 0) o[0] = s0;
+                if (left > 1) o[1] = s1;
+                if (left > 2) o[2] = s2;
+                if (left > 3) o[3] = s3;
             }
         }
     }
@@ -383,10 +396,13 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     const unsigned i = lane & 31, h = lane >> 5;
     const float scale = J.scale;
 
-    f32x16 c3[2], c2[2], c1;
+    f32x16 c3[2], c2[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { c3[0][r] = 0.f; c3[1][r] = 0.f; c2[0][r] = 0.f; c2[1][r] = 0.f; c1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { c3[0][r] = 0.f; c3[1][r] = 0.f; c2[0][r] = 0.f; c2[1][r] = 0.f; }
     float s3 = 0.f, s2 = 0.f, s1 = 0.f;
+    // dW1 (128 x in_dim <= 8) on the vector pipe: lane (i, h) of wave (mb, nh) accumulates dW1[32 mb + i][4 nh .. 4 nh + 3]
+    // over the rows of parity h from the g1 value it reads for db1 anyway (an MFMA would pad the 8 columns to 32)
+    float w1a = 0.f, w1b = 0.f, w1c = 0.f, w1d = 0.f;
     const unsigned fa = 32 * mb + i;               // A column (feature of G)
     const unsigned fb = 64 * nh + 2 * i;           // first of the two B columns (features of H)
     const float* __restrict__ gpool = J.g_pooled;
@@ -441,7 +457,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
             c3[1] = mfma32(a3, b3.y, c3[1]);
             c2[0] = mfma32(a2, b2.x, c2[0]);
             c2[1] = mfma32(a2, b2.y, c2[1]);
-            if (nh == 0) c1 = mfma32(a1, buf[5 * DW_ROWS * EH + (2 * ks + h) * 8 + (i & 7)] * (i < 8 ? 1.f : 0.f), c1);
+            const float4 xr = *reinterpret_cast<const float4*>(buf + 5 * DW_ROWS * EH + (2 * ks + h) * 8 + 4 * nh);
+            w1a = __fmaf_rn(a1, xr.x, w1a); w1b = __fmaf_rn(a1, xr.y, w1b);
+            w1c = __fmaf_rn(a1, xr.z, w1c); w1d = __fmaf_rn(a1, xr.w, w1d);
             s3 += a3; s2 += a2; s1 += a1;
         }
     };
@@ -466,7 +484,18 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
         const int orow = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h;
         *reinterpret_cast<float2*>(P + (size_t)orow * EH + fb) = make_float2(c3[0][r], c3[1][r]);
         *reinterpret_cast<float2*>(P + 16384 + (size_t)orow * EH + fb) = make_float2(c2[0][r], c2[1][r]);
-        if (nh == 0 && i < IN) P[32768 + orow * IN + i] = c1[r];    // dW1 row-major (128, in_dim) at the head of its 1024 floats
+    }
+    {   // dW1 row-major (128, in_dim) at the head of its 1024 floats
+        w1a += __shfl_xor(w1a, 32, 64); w1b += __shfl_xor(w1b, 32, 64);
+        w1c += __shfl_xor(w1c, 32, 64); w1d += __shfl_xor(w1d, 32, 64);
+        const unsigned c0 = 4 * nh;
+        float* o = P + 32768 + fa * IN + c0;
+        if (h == 0) {
+            if (c0 + 0 < IN) o[0] = w1a;
+            if (c0 + 1 < IN) o[1] = w1b;
+            if (c0 + 2 < IN) o[2] = w1c;
+            if (c0 + 3 < IN) o[3] = w1d;
+        }
     }
     if (nh == 0) {
         s3 += __shfl_xor(s3, 32, 64);

@@ -20,9 +20,9 @@ constexpr int DEC_PART = DD * DH + DD * DD + 2 * DD + DD + DD + 8;     // decode
 // Packed weights of one encoder (floats), written once per step by enc_pack_kernel so that every workgroup stages
 // its LDS image with linear, fully coalesced copies:
 //   [ W2 fragments 16384 | W3 fragments 16384 | W1 fragments 1024 | b1 b2 b3 384 ]        forward image
-//   [ W3^T fragments 16384 | W2^T fragments 16384 | W1^T fragments 4096 ]                 dX image
+//   [ W3^T fragments 16384 | W2^T fragments 16384 | W1 rows padded to 8 columns 1024 ]    dX image
 constexpr int PACK_FWD = 16384 * 2 + 1024 + 384;
-constexpr int PACK_DX = 16384 * 2 + 4096;
+constexpr int PACK_DX = 16384 * 2 + 1024;
 constexpr int PACK_FLOATS = PACK_FWD + PACK_DX;
 
 __device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e) {
@@ -44,10 +44,9 @@ __device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e)
         const int g = e - 32768 - 1024;
         return g < 128 ? J.b1[g] : (g < 256 ? J.b2[g - 128] : J.b3[g - 256]);
     }
-    {                                                          // W1^T fragments [bp][q][lane] float4
-        const int g = e - PACK_FWD - 32768, u = g & 3, l = (g >> 2) & 63, q = (g >> 8) & 3, bp = g >> 10;
-        const int i = l & 31, c = 32 * bp + 8 * q + 4 * (l >> 5) + u;
-        return i < IN ? J.w1[(size_t)c * IN + i] : 0.f;
+    {                                                          // W1 rows padded to 8 columns: [f][8]
+        const int g = e - PACK_FWD - 32768, f = g >> 3, c = g & 7;
+        return c < IN ? J.w1[(size_t)f * IN + c] : 0.f;
     }
 }
 
