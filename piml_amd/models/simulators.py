@@ -24,6 +24,7 @@ Differences from the reference, all behaviour-preserving for a single call:
     every epoch, batches reused across epochs) needs the same carry-over; it is applied after the rollout, outside
     every captured graph.
 """
+import contextlib
 import os
 import time
 import types
@@ -225,6 +226,11 @@ class BaseSimulator(Pedestrians):
         m = new_mask.unsqueeze(-1) if cur.dim() > new_mask.dim() else new_mask
         return torch.where(m, truth, cur)
 
+    def _packed_weights(self):
+        """`model.packed_weights()` (one weight pack for every forward pass inside the block) where the model has it."""
+        fn = getattr(self.model, 'packed_weights', None)
+        return fn() if fn is not None else contextlib.nullcontext()
+
     # ---- HOT LOOP B: inference rollout (simulators.py:556-657) ----
     def _rollout_state(self, data, t_start):
         """Persistent (static-address) buffers of one rollout; the frame counter lives on the
@@ -334,6 +340,11 @@ class BaseSimulator(Pedestrians):
         args = self.args
         if load_model:
             self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
+        with self._packed_weights():          # the weights do not change during a rollout: packed once, not per frame
+            return self._multiple_rollouts(data, t_start, use_graph, fused)
+
+    def _multiple_rollouts(self, data, t_start, use_graph, fused):
+        args = self.args
         st = self._rollout_state(data, t_start)
         steps = st.T - t_start
         if fused is None:
@@ -401,6 +412,10 @@ class BaseSimulator(Pedestrians):
     def _training_rollout(self, data, t_start=0):
         """The rollout + losses with no host synchronisation at all (capturable into a HIP graph);
         returns the 7 loss tensors and the device-side bookkeeping (NaN flag, collision totals)."""
+        with self._packed_weights():          # one weight pack for all frames of the window (the optimizer steps later)
+            return self._training_rollout_frames(data, t_start)
+
+    def _training_rollout_frames(self, data, t_start):
         args = self.args
         dt = data.time_unit
         waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
