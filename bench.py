@@ -199,7 +199,8 @@ class Step:
     """The hot path over one rank's agent block of one scene: scene tensors, model, the captured HIP graph of
     the compute part and (sharded) the eager exchange either side of it."""
 
-    def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket'):
+    def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
+                 overlap=False):
         from piml_amd import ops, _lib
         from piml_amd.models.model import PINNSF_multitask
         from piml_amd.sharded import ShardedScene
@@ -230,6 +231,11 @@ class Step:
         # travels N/n_own times wider than needed, but it is one latency-bound collective); 'rs' = reduce-scatter of
         # d/d(state) to the owners + all-reduce of the weight gradients (minimum bytes, two collectives)
         self.exchange = exchange
+        # overlap: the captured step is cut in two -- `pre` (weight pack + the part of the neighbour search that reads
+        # only this rank's own records + obstacle branch + self features) is replayed while the all-gather of the other
+        # ranks' records is in flight, `graph` (remote half of the search, MLP forward / backward, relfeat backward) after it
+        self.overlap = bool(overlap) and use_dist
+        self.pre, self.gather_work = None, None
         self.graph, self.static_feats, self.mode = None, None, 'eager'
         self.want_graph = use_graph
 
@@ -253,6 +259,15 @@ class Step:
         return self.ops.relative_features_packed_self(self.state_all, self.dest_own, self.obstacles, self.v0_own,
                                                       self.b0, self.n_own, return_index=True)
 
+    def features_local_part(self):
+        """What needs only this rank's rows of state_all (legal while the all-gather of the other rows is in flight)."""
+        return self.ops.relative_features_local_part(self.state_all, self.dest_own, self.obstacles, self.v0_own,
+                                                     self.b0, self.n_own)
+
+    def features_remote_part(self, local):
+        return self.ops.relative_features_packed_self(self.state_all, self.dest_own, self.obstacles, self.v0_own,
+                                                      self.b0, self.n_own, return_index=True, local=local)
+
     def rest_local(self, pf, of, self_features, *_idx):
         acc = self.model(pf, of, self_features)[0]
         acc.backward(self.ones)
@@ -266,8 +281,11 @@ class Step:
         return acc
 
     def exchange_forward(self):
-        from piml_amd.sharded import gather_records_into
-        gather_records_into(self.state_all, self.state_own, self.group)
+        from piml_amd.sharded import gather_records_into, gather_records_async
+        if self.pre is not None:                  # started, not awaited: `pre` runs under it (run / capture wait for it)
+            self.gather_work = gather_records_async(self.state_all, self.state_own, self.b0, self.group)
+        else:
+            gather_records_into(self.state_all, self.state_own, self.group)
 
     def exchange_backward(self):
         from piml_amd.sharded import unflatten_gradients
@@ -325,10 +343,27 @@ class Step:
             if self.use_dist:
                 self.exchange_forward()
                 torch.cuda.synchronize()
-            with torch.cuda.graph(graph), self.model.packed_weights():
-                feats = self.features_local() if self.use_dist else self.features()
-                (self.rest_local if self.use_dist else self.rest)(*feats)
+            # the process group's watchdog thread polls the events of finished collectives: under the default 'global'
+            # capture mode such a query from another thread invalidates the capture (seen: hipErrorStreamCaptureUnsupported)
+            cap_mode = 'thread_local' if self.use_dist else 'global'
+            if self.overlap:
+                import contextlib
+                pre = torch.cuda.CUDAGraph()
+                with contextlib.ExitStack() as packed:
+                    with torch.cuda.graph(pre, capture_error_mode=cap_mode):
+                        packed.enter_context(self.model.packed_weights())      # the pack launch belongs to `pre`
+                        local = self.features_local_part()
+                    with torch.cuda.graph(graph, pool=pre.pool(), capture_error_mode=cap_mode):
+                        feats = self.features_remote_part(local)
+                        self.rest_local(*feats)
+                self.pre = pre
+            else:
+                with torch.cuda.graph(graph, capture_error_mode=cap_mode), self.model.packed_weights():
+                    feats = self.features_local() if self.use_dist else self.features()
+                    (self.rest_local if self.use_dist else self.rest)(*feats)
             self.static_feats = feats     # the captured step's feature / index buffers stay alive
+            if self.pre is not None:
+                self.pre.replay()
             graph.replay()
             if self.use_dist:
                 self.exchange_backward()
@@ -364,6 +399,9 @@ class Step:
         if self.graph is not None:
             if self.use_dist:
                 self.exchange_forward()
+            if self.pre is not None:
+                self.pre.replay()                 # under the all-gather
+                self.gather_work.wait()           # the stream waits for the other ranks' records
             self.graph.replay()
             if self.use_dist:
                 self.exchange_backward()
@@ -425,6 +463,11 @@ def main():
     ap.add_argument('--exchange', choices=('bucket', 'rs'), default='bucket',
                     help='backward exchange of the sharded step: one all-reduce of [state gradient | weight gradients] '
                          '(bucket) or reduce-scatter(state gradient) + all-reduce(weight gradients) (rs)')
+    ap.add_argument('--overlap', type=int, default=0,
+                    help='sharded + graph: start the all-gather, run the part of the step that needs only the own block '
+                         '(weight pack, local half of the neighbour search, obstacle branch) under it, then the rest.  Off '
+                         'by default: with one rank the second graph launch and the second relfeat launch cost 24 us more '
+                         'than they hide (0.292 vs 0.268 ms/step); both forms are timed and reported under "exchange"')
     ap.add_argument('--exchange-compare', type=int, default=1,
                     help='several GPUs: also time the other --exchange variant after the timed region (informational)')
     ap.add_argument('--strong-baseline', type=int, default=1,
@@ -509,7 +552,7 @@ def main():
     # pre-tuned selections are validated for the cfg3 row counts only; otherwise the branches stay on one stream.
     two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and cfg3_shapes) or args.two_streams == 2
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
-              two_streams, bool(args.graph), exchange=args.exchange)
+              two_streams, bool(args.graph), exchange=args.exchange, overlap=bool(args.overlap))
     M_eff = st.M_eff
 
     if autotune:
@@ -541,6 +584,9 @@ def main():
             sample = timed and i in sample_at
             if use_dist:
                 st.exchange_forward()
+            if st.pre is not None:
+                st.pre.replay()                   # the own-block part of the step, under the all-gather
+                st.gather_work.wait()
             graph.replay()
             if use_dist:
                 st.exchange_backward()
@@ -648,19 +694,21 @@ def main():
     exchange_other = None
     if use_dist and args.exchange_compare and (world > 1 or args.force_dist):
         other = 'rs' if args.exchange == 'bucket' else 'bucket'
-        try:
-            alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
-                       exchange=other)
-            alt.capture()
-            k = max(10, min(args.steps, 50))
-            el = alt.time_steps(k, 5)
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            exchange_other = {'exchange': other, 'ms_per_step': float(t.item()) / k * 1e3, 'steps': k,
-                              'launch_mode': alt.mode}
-            del alt
-        except Exception as ex:   # noqa: BLE001 - informational
-            exchange_other = {'exchange': other, 'error': f'{type(ex).__name__}: {ex}'}
+        exchange_other = []
+        for exch, ovl in ((other, bool(args.overlap)), (args.exchange, not args.overlap)):
+            tag = {'exchange': exch, 'overlap': ovl}
+            try:
+                alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
+                           exchange=exch, overlap=ovl)
+                alt.capture()
+                k = max(10, min(args.steps, 50))
+                el = alt.time_steps(k, 5)
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange_other.append(dict(tag, ms_per_step=float(t.item()) / k * 1e3, steps=k, launch_mode=alt.mode))
+                del alt
+            except Exception as ex:   # noqa: BLE001 - informational
+                exchange_other.append(dict(tag, error=f'{type(ex).__name__}: {ex}'))
 
     # ---- strong scaling: the same scene on ONE GPU (rank 0, the others wait), outside the timed region ----
     same_scene_1gpu = None
@@ -735,10 +783,13 @@ def main():
                          'kernels': kernels},
         }
         if use_dist:
-            out['exchange'] = {'backward': args.exchange, 'other_variant': exchange_other,
+            out['exchange'] = {'backward': args.exchange, 'overlap': bool(st.pre is not None),
+                               'other_variants': exchange_other,
                                'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '
                                        'reduce-scatter(d/d(state)) + all-reduce(weight gradients); forward = one '
-                                       'all-gather of the (p,v,a) records; all issued eagerly around the captured compute'}
+                                       'all-gather of the (p,v,a) records, issued eagerly around the captured compute; overlap = the '
+                                       'all-gather is started, the own-block part of the step (weight pack, local half of '
+                                       'the neighbour search, obstacle branch) replayed under it, then the rest'}
         if same_scene_1gpu is not None:
             out['single_gpu_same_scene'] = same_scene_1gpu
         if secondary is not None:

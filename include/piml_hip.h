@@ -95,6 +95,17 @@ int piml_relfeat_self_fwd(const float* state, const float* destination_rows, con
                           int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
                           float* ped_feat, float* obs_feat, float* self_features, int32_t* ped_idx, int32_t* obs_idx,
                           float* g_state_zero, void* stream);
+/* The same in two launches for agent-block sharding: PIML_RELFEAT_LOCAL reads only the focal block's own records (and the
+ * obstacles), so it can run while the all-gather of the other blocks is in flight; it writes obs_feat, self_features,
+ * obs_idx and leaves its pedestrian list in ped_idx.  PIML_RELFEAT_REMOTE continues from that list over the agents either
+ * side of the block and writes ped_feat / ped_idx.  Bit-identical to the single launch (part 0). */
+#define PIML_RELFEAT_LOCAL 1
+#define PIML_RELFEAT_REMOTE 2
+int piml_relfeat_self_fwd_part(int part, const float* state, const float* destination_rows, const float* obstacles,
+                               const float* desired_speed, int N, int M, int focal_begin, int focal_count, int topk_ped,
+                               int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                               float* ped_feat, float* obs_feat, float* self_features, int32_t* ped_idx,
+                               int32_t* obs_idx, float* g_state_zero, void* stream);
 int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int* ped_idx,
                           const int* obs_idx, const float* state, const float* destination_rows, int N, int focal_begin,
                           int focal_count, int kp_eff, int ko_eff, float* g_state, float* g_destination, float* g_speed,

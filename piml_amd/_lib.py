@@ -108,6 +108,7 @@ SIGNATURES = {
     'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
     'piml_allreduce_sum': [_p, _p, _z, _p],
     'piml_relfeat_self_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
+    'piml_relfeat_self_fwd_part': [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_relfeat_self_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'piml_relfeat_bwd_det': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'piml_relfeat_bwd': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],

@@ -33,11 +33,26 @@ struct RelfeatArgs {
     int C, N, M, f0, fcnt, kp, ko;
     float cos_p, cos_o, cut2_p, cut2_o, dthr_p, dthr_o;
     float* ped_feat; float* obs_feat; float* dest_feat; int dest_ld; int* ped_idx; int* obs_idx;
+    // agent-block sharding runs the launch in two parts so that the first needs no remote data (DESIGN.md "exchange"):
+    //   part LOCAL   agent sources [a_lo[0], a_hi[0]) = the rank's own block, the obstacle pass, dest / self features;
+    //                the pedestrian list found so far goes to ped_idx (no features yet)
+    //   part REMOTE  agent sources = the two ranges either side of the block, the list restored from ped_idx
+    //                (distances recomputed with the same arithmetic), then the pedestrian features
+    // The selection is the k smallest by (distance, index), whatever order the sources arrive in: both parts together
+    // are bit-identical to one launch over [0, N).
+    int a_lo[2], a_hi[2];   // agent-pass source ranges (the second may be empty)
+    int flags;              // kRfPedFeat | kRfObs | kRfDest | kRfPedList | kRfInit
     const float* speed;   // non-NULL: dest_feat rows are the model's self_features rows [dest - p, v, a, v0] (dest_ld >= 7)
     float* zero; long zero_n;   // optional: buffer this launch clears (the state gradient its backward accumulates into)
     int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates,
                   // 7 phase stamps (cycles): entry, [tile staged, pass done] per pass ..., + 1 pad}
 };
+
+constexpr int kRfPedFeat = 1;    // write pedestrian features + indices
+constexpr int kRfObs = 2;        // obstacle pass + its features / indices
+constexpr int kRfDest = 4;       // destination (self) features
+constexpr int kRfPedList = 8;    // write the pedestrian index list only
+constexpr int kRfInit = 16;      // start the pedestrian list from ped_idx
 
 // ---- sorted top-k list, one entry per lane: (distance bits, source index) ----
 // Entries ascend by (distance, index); exact distance ties resolve to the lower index.
@@ -143,13 +158,33 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         const float dthr = pass == 0 ? A.dthr_p : A.dthr_o;
         float cut2 = pass == 0 ? A.cut2_p : A.cut2_o;      // wave-uniform
 
+        if (pass == 1 && !(A.flags & kRfObs)) break;       // (uniform over the launch: no barrier is skipped unevenly)
+
         unsigned list_d = kEmptyDist, list_i = 0;          // lane s: s-th nearest in-view source so far
         unsigned kth_d = kEmptyDist, kth_i = 0;            // wave-uniform copy of lane k-1's entry
         unsigned head = 0, tail = 0;                       // wave-uniform ring cursors
+        if (pass == 0 && (A.flags & kRfInit) && alive && k > 0) {
+            // the list the LOCAL part left in ped_idx (sorted, -1 = empty slot); distances by the arithmetic of phase 2
+            const int j = lane < k ? A.ped_idx[((size_t)c * A.fcnt + fl) * k + lane] : -1;
+            if (j >= 0) {
+                const float2 pj = *reinterpret_cast<const float2*>(src + (size_t)j * sld);
+                list_d = __float_as_uint(norm2(pj.x - pix, pj.y - piy));
+                list_i = (unsigned)j;
+            }
+            kth_d = (unsigned)__builtin_amdgcn_readlane((int)list_d, k - 1);
+            kth_i = (unsigned)__builtin_amdgcn_readlane((int)list_i, k - 1);
+            if (kth_d != kEmptyDist) {
+                const float dk = __uint_as_float(kth_d);
+                cut2 = fminf(cut2, dk * dk * 1.00000095367431640625f);
+            }
+        }
 
 #pragma unroll 1
-        for (int base = 0; base < cnt; base += kTile) {
-            const int tn = min(kTile, cnt - base);
+        for (int rg = 0; rg < 2; ++rg) {
+        const int lo = pass == 0 ? A.a_lo[rg] : 0, hi = pass == 0 ? A.a_hi[rg] : (rg == 0 ? cnt : 0);
+#pragma unroll 1
+        for (int base = lo; base < hi; base += kTile) {
+            const int tn = min(kTile, hi - base);
             const int tn_pad = (tn + 511) & ~511;          // phase 1 reads whole 512-groups
             __syncthreads();                                // previous tile fully consumed
             for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
@@ -241,6 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                 }
             }
         }
+        }
         PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
         const u64 mine = list_d == kEmptyDist ? kEmptyKey : (u64)list_i;
         if (pass == 0) lists[0] = mine; else lists[1] = mine;
@@ -258,7 +294,11 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     // ---- epilogue: gather the k selected sources, write features / indices ----
     const int kpe = min(A.kp, A.N), koe = min(A.ko, A.M);
     const size_t row = (size_t)c * A.fcnt + fl;
-    if (lane < kpe) {
+    if (lane < kpe && (A.flags & kRfPedList)) {
+        const u64 key = lists[0];
+        A.ped_idx[row * kpe + lane] = key == kEmptyKey ? -1 : (int)(unsigned)key;
+    }
+    if (lane < kpe && (A.flags & kRfPedFeat)) {
         const u64 key = lists[0];
         const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
         A.ped_idx[row * kpe + lane] = j;
     }
-    if (lane < koe) {
+    if (lane < koe && (A.flags & kRfObs)) {
         const u64 key = lists[1];
         const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
@@ -288,7 +328,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
         A.obs_idx[row * koe + lane] = j;
     }
-    if (lane == 0) {
+    if (lane == 0 && (A.flags & kRfDest)) {
         const float2 d = A.dest[row];
         float* df = A.dest_feat + row * A.dest_ld;          // row stride: 2, or the width of a self_features row
         df[0] = nan_to_zero(d.x - pix); df[1] = nan_to_zero(d.y - piy);                    // :496-497
@@ -426,15 +466,28 @@ static int relfeat_launch(const float* position, const float* heading, const flo
                           int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                           float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
                           float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
-                          int32_t* ped_idx, int32_t* obs_idx, const float* speed, float* zero, long zero_n, void* stream) {
+                          int32_t* ped_idx, int32_t* obs_idx, const float* speed, float* zero, long zero_n, void* stream,
+                          int part = 0) {
     if (C < 0 || N < 0 || M < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
         topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK ||
         state_ld < 2 || (state_ld & 1) || dest_feat_ld < 2)
         return hipErrorInvalidValue;
     if (C == 0 || focal_count == 0) return hipSuccess;
-    if (!position || !velocity || !acceleration || !destination || !dest_feat || (M > 0 && !obstacles))
+    const int kpe_ = topk_ped < N ? topk_ped : N, koe_ = topk_obs < M ? topk_obs : M;     // an output with k = 0 may be NULL
+    if (part < 0 || part > 2 || !position || !velocity || !acceleration || (kpe_ > 0 && !ped_idx)) return hipErrorInvalidValue;
+    if (part != 2 && (!destination || !dest_feat || (M > 0 && !obstacles) || (koe_ > 0 && (!obs_feat || !obs_idx))))
         return hipErrorInvalidValue;
+    if (part != 1 && kpe_ > 0 && !ped_feat) return hipErrorInvalidValue;
     RelfeatArgs A;
+    A.a_lo[0] = 0; A.a_hi[0] = N; A.a_lo[1] = 0; A.a_hi[1] = 0;
+    A.flags = kRfPedFeat | kRfObs | kRfDest;
+    if (part == 1) {            // LOCAL: the focal block's own agents as sources + everything that needs no remote record
+        A.a_lo[0] = focal_begin; A.a_hi[0] = focal_begin + focal_count;
+        A.flags = kRfObs | kRfDest | kRfPedList;
+    } else if (part == 2) {     // REMOTE: the agents either side of the block, continuing the list of the LOCAL part
+        A.a_lo[0] = 0; A.a_hi[0] = focal_begin; A.a_lo[1] = focal_begin + focal_count; A.a_hi[1] = N;
+        A.flags = kRfPedFeat | kRfInit;
+    }
     A.p = position; A.v = velocity; A.a = acceleration; A.ld = state_ld;
     A.hd = (const float2*)heading; A.dest = (const float2*)destination; A.obs = (const float2*)obstacles;
     A.C = C; A.N = N; A.M = M; A.f0 = focal_begin; A.fcnt = focal_count;
@@ -490,6 +543,23 @@ PIML_API int piml_relfeat_self_fwd(const float* state, const float* destination_
     return relfeat_launch(state, nullptr, state + 2, state + 4, 6, destination_rows, obstacles, 1, N, M, focal_begin,
                           focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
                           obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, g_state_zero, (long)N * 6, stream);
+}
+
+// piml_relfeat_self_fwd in two launches for agent-block sharding (part 1 = PIML_RELFEAT_LOCAL, 2 = PIML_RELFEAT_REMOTE,
+// 0 = the whole thing): LOCAL reads only the focal block's own records (and the obstacles) and can run while the
+// all-gather of the other blocks is in flight; REMOTE continues from the list LOCAL left in ped_idx.  Together the
+// outputs are bit-identical to one launch.
+PIML_API int piml_relfeat_self_fwd_part(int part, const float* state, const float* destination_rows, const float* obstacles,
+                                        const float* desired_speed, int N, int M, int focal_begin, int focal_count,
+                                        int topk_ped, int topk_obs, float cos_thr_ped, float cos_thr_obs,
+                                        float dist_thr_ped, float dist_thr_obs, float* ped_feat, float* obs_feat,
+                                        float* self_features, int32_t* ped_idx, int32_t* obs_idx, float* g_state_zero,
+                                        void* stream) {
+    if (focal_count > 0 && (!state || (part != 2 && (!desired_speed || !self_features)))) return hipErrorInvalidValue;
+    return relfeat_launch(state, nullptr, state + 2, state + 4, 6, destination_rows, obstacles, 1, N, M, focal_begin,
+                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                          obs_feat, self_features, 7, ped_idx, obs_idx, part == 2 ? nullptr : desired_speed,
+                          part == 2 ? nullptr : g_state_zero, (long)N * 6, stream, part);
 }
 
 // Backward of piml_relfeat_self_fwd in one launch: g_self (n, 7) carries d/d(dest_feat) in columns 0-1, d/d(v, a) of the

@@ -202,7 +202,7 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, state, destination_rows, obstacles, desired_speed, focal_begin, focal_count, kp, ko,
-                cos_p, cos_o, dthr_p, dthr_o):
+                cos_p, cos_o, dthr_p, dthr_o, local=None):
         s = _gpu_f32('state', state)
         d_rows = _gpu_f32('destination_rows', destination_rows)
         o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
@@ -215,17 +215,31 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
         M = o.shape[0]
         kpe, koe = min(kp, N), min(ko, M)
         opt = dict(device=s.device, dtype=torch.float32)
-        sf = torch.empty(focal_count, 7, **opt)
-        outs = (torch.empty(focal_count, kpe, 6, **opt), torch.empty(focal_count, koe, 6, **opt), sf,
-                torch.empty(focal_count, kpe, device=s.device, dtype=torch.int32),
-                torch.empty(focal_count, koe, device=s.device, dtype=torch.int32))
         need_grad = any(ctx.needs_input_grad[:4]) and not DETERMINISTIC_BWD
-        ctx.g_state = torch.empty(N, 6, **opt) if need_grad else None       # cleared by the launch below
-        with torch.cuda.device(s.device):
-            _lib.check(_lib.lib().piml_relfeat_self_fwd(
-                _ptr(s), _ptr(d_rows), _ptr(o), _ptr(w), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o,
-                dthr_p, dthr_o, _ptr(outs[0]), _ptr(outs[1]), _ptr(sf), _ptr(outs[3]), _ptr(outs[4]),
-                _ptr(ctx.g_state), _stream()), 'piml_relfeat_self_fwd')
+        if local is None:
+            sf = torch.empty(focal_count, 7, **opt)
+            outs = (torch.empty(focal_count, kpe, 6, **opt), torch.empty(focal_count, koe, 6, **opt), sf,
+                    torch.empty(focal_count, kpe, device=s.device, dtype=torch.int32),
+                    torch.empty(focal_count, koe, device=s.device, dtype=torch.int32))
+            ctx.g_state = torch.empty(N, 6, **opt) if need_grad else None       # cleared by the launch below
+            with torch.cuda.device(s.device):
+                _lib.check(_lib.lib().piml_relfeat_self_fwd(
+                    _ptr(s), _ptr(d_rows), _ptr(o), _ptr(w), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o,
+                    dthr_p, dthr_o, _ptr(outs[0]), _ptr(outs[1]), _ptr(sf), _ptr(outs[3]), _ptr(outs[4]),
+                    _ptr(ctx.g_state), _stream()), 'piml_relfeat_self_fwd')
+        else:                 # the LOCAL part ran earlier (relative_features_local_part): finish with the remote sources
+            geom = (s.data_ptr(), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o, dthr_p, dthr_o)
+            if local.geom != geom:
+                raise ValueError('relative_features_packed_self: `local` was made for another state buffer / geometry')
+            outs = (torch.empty(focal_count, kpe, 6, **opt), local.obs_feat, local.self_features, local.ped_idx,
+                    local.obs_idx)
+            ctx.g_state = local.g_state if need_grad else None
+            local.g_state = None
+            with torch.cuda.device(s.device):
+                _lib.check(_lib.lib().piml_relfeat_self_fwd_part(
+                    2, _ptr(s), None, None, None, N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o,
+                    dthr_p, dthr_o, _ptr(outs[0]), None, None, _ptr(outs[3]), None, None, _stream()),
+                    'piml_relfeat_self_fwd_part(REMOTE)')
         ctx.save_for_backward(outs[3], outs[4], s, d_rows)
         ctx.geom = (1, N, focal_begin, focal_count, kpe, koe, ())
         ctx.speed_shape = tuple(desired_speed.shape)
@@ -236,7 +250,7 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ped, g_obs, g_self, _gi, _go):
         if g_ped is None and g_obs is None and g_self is None:
-            return (None,) * 12
+            return (None,) * 13
         ped_idx, obs_idx, s, d_rows = ctx.saved_tensors
         _, N, f0, fcnt, kpe, koe, _ = ctx.geom
         opt = dict(device=s.device, dtype=torch.float32)
@@ -255,7 +269,7 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
                                                                  _stream()), 'piml_self_features_bwd')
             g_state, g_d_rows = _launch_relfeat_bwd(ctx.geom, g_ped, g_obs, g_dest, ped_idx, obs_idx, s.data_ptr(), 6,
                                                     d_rows, s.device, g_state=g_state)
-            return (g_state, g_d_rows, None, g_speed) + (None,) * 8
+            return (g_state, g_d_rows, None, g_speed) + (None,) * 9
 
         def dense(g, shape):
             return torch.zeros(shape, **opt) if g is None else _gpu_f32('grad', g)
@@ -269,20 +283,69 @@ class _RelativeFeaturesPackedSelf(torch.autograd.Function):
             _lib.check(_lib.lib().piml_relfeat_self_bwd(
                 _ptr(g_ped), _ptr(g_obs), _ptr(g_self), _ptr(ped_idx), _ptr(obs_idx), _ptr(s), _ptr(d_rows), N, f0, fcnt,
                 kpe, koe, _ptr(g_state), _ptr(g_d_rows), _ptr(g_speed), _stream()), 'piml_relfeat_self_bwd')
-        return (g_state, g_d_rows, None, g_speed) + (None,) * 8
+        return (g_state, g_d_rows, None, g_speed) + (None,) * 9
+
+
+class LocalFeatures:
+    """What relative_features_local_part leaves behind for relative_features_packed_self(local=...)."""
+
+    def __init__(self):
+        self.obs_feat = self.self_features = self.ped_idx = self.obs_idx = self.g_state = None
+        self.geom = None
+
+
+def relative_features_local_part(state, destination_rows, obstacles, desired_speed, focal_begin, focal_count,
+                                 topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                                 topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, want_grad=True):
+    """Agent-block sharding, first half of relative_features_packed_self: everything that needs only the focal block's
+    own rows of the packed (N, 6) state -- the neighbour search among the block's own agents, the obstacle branch, the
+    self_features rows -- so that it can be enqueued while the all-gather of the other blocks is still in flight (the
+    rows outside [focal_begin, focal_begin + focal_count) are not read).  No autograd here: pass the result as
+    `local=` to relative_features_packed_self, which finishes with the remote agents and owns the whole gradient."""
+    if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
+        raise ValueError(f'topk must be <= {MAX_TOPK}')
+    s = _gpu_f32('state', state.detach())
+    d_rows = _gpu_f32('destination_rows', destination_rows.detach())
+    o = _gpu_f32('obstacles', obstacles.detach()).reshape(-1, 2)
+    w = _gpu_f32('desired_speed', desired_speed.detach())
+    if s.dim() != 2 or s.shape[-1] != 6:
+        raise ValueError(f'state must be (N, 6), got {tuple(s.shape)}')
+    N, M = s.shape[0], o.shape[0]
+    focal_begin, focal_count, kp, ko = int(focal_begin), int(focal_count), int(topk_ped), int(topk_obs)
+    if tuple(d_rows.shape) != (focal_count, 2) or w.numel() != focal_count:
+        raise ValueError('destination_rows (n, 2) and desired_speed (n, 1) expected for the focal rows')
+    kpe, koe = min(kp, N), min(ko, M)
+    opt = dict(device=s.device, dtype=torch.float32)
+    L = LocalFeatures()
+    L.obs_feat = torch.empty(focal_count, koe, 6, **opt)
+    L.self_features = torch.empty(focal_count, 7, **opt)
+    L.ped_idx = torch.empty(focal_count, kpe, device=s.device, dtype=torch.int32)
+    L.obs_idx = torch.empty(focal_count, koe, device=s.device, dtype=torch.int32)
+    L.g_state = torch.empty(N, 6, **opt) if (want_grad and not DETERMINISTIC_BWD) else None
+    cos_p, cos_o = cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs)
+    L.geom = (s.data_ptr(), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o, float(dist_threshold_ped),
+              float(dist_threshold_obs))
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.lib().piml_relfeat_self_fwd_part(
+            1, _ptr(s), _ptr(d_rows), _ptr(o), _ptr(w), N, M, focal_begin, focal_count, kp, ko, cos_p, cos_o,
+            float(dist_threshold_ped), float(dist_threshold_obs), None, _ptr(L.obs_feat), _ptr(L.self_features),
+            _ptr(L.ped_idx), _ptr(L.obs_idx), _ptr(L.g_state), _stream()), 'piml_relfeat_self_fwd_part(LOCAL)')
+    return L
 
 
 def relative_features_packed_self(state, destination_rows, obstacles, desired_speed, focal_begin, focal_count,
                                   topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
-                                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, return_index=False):
+                                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, return_index=False, local=None):
     """(ped_features, obs_features, self_features (n, 7)) for the focal rows of a packed (N, 6) state:
-    relative_features_packed + the model's self-feature rows [dest - p, v, a, v0] in one autograd node."""
+    relative_features_packed + the model's self-feature rows [dest - p, v, a, v0] in one autograd node.
+    local: the LocalFeatures of relative_features_local_part on the same buffer and geometry; only the remote half of
+    the neighbour search is then left to do (results bit-identical to the one-launch form)."""
     if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
         raise ValueError(f'topk must be <= {MAX_TOPK}')
     out = _RelativeFeaturesPackedSelf.apply(state, destination_rows, obstacles, desired_speed, int(focal_begin),
                                             int(focal_count), int(topk_ped), int(topk_obs),
                                             cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
-                                            float(dist_threshold_ped), float(dist_threshold_obs))
+                                            float(dist_threshold_ped), float(dist_threshold_obs), local)
     return out if return_index else out[:3]
 
 

@@ -83,6 +83,28 @@ def all_gather_records(own, group=None):
     return _AllGatherRecords.apply(own, group if group is not None else dist.group.WORLD)
 
 
+class _AllGatherRecordsAsync(torch.autograd.Function):
+    """_AllGatherRecords whose forward returns before the collective has finished: this rank's rows are already in
+    place in the returned (N, w) buffer (in-place all-gather: they are the send buffer), the other rows arrive when
+    `holder[0].wait()` has been called.  Backward as _AllGatherRecords."""
+
+    @staticmethod
+    def forward(ctx, own, group, holder):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        own = own.contiguous()
+        n = own.shape[0]
+        full = torch.empty((world * n,) + tuple(own.shape[1:]), device=own.device, dtype=own.dtype)
+        mine = full[rank * n:(rank + 1) * n]
+        mine.copy_(own)
+        holder.append(dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1), group=group, async_op=True))
+        ctx.group = group
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        return _AllGatherRecords.backward(ctx, g_full) + (None,)
+
+
 def gather_records_into(full, own, group=None):
     """Plain (non-autograd) all-gather into a caller-owned (N, w) buffer.  With `reduce_scatter_grad`
     this is the exchange pair for steps whose compute part is replayed from a captured HIP graph: the
@@ -91,6 +113,20 @@ def gather_records_into(full, own, group=None):
     with torch.no_grad():
         dist.all_gather_into_tensor(full.detach(), own.detach().contiguous(), group=group)
     return full
+
+
+def gather_records_async(full, own, begin, group=None):
+    """The exchange of `gather_records_into` without waiting for it: this rank's rows are copied into their place in
+    `full` (N, w) on the current stream, then an IN-PLACE all-gather (send buffer = this rank's rows of the receive
+    buffer, which the collective therefore never writes) is started on the backend's own stream.  Returns the work
+    handle: everything that needs only the rank's own rows of `full` -- relative_features_local_part, the weight packs
+    -- can be enqueued before `work.wait()` and runs while the other blocks are in flight."""
+    with torch.no_grad():
+        f = full.detach()
+        n = own.shape[0]
+        mine = f[begin:begin + n]
+        mine.copy_(own.detach())
+        return dist.all_gather_into_tensor(f.view(-1), mine.reshape(-1), group=group, async_op=True)
 
 
 def reduce_scatter_grad(g_full, group=None, out=None):
@@ -172,6 +208,25 @@ class ShardedScene:
         state_full = self.gather_state(state_own)
         return self.feature_fn(state_full, destination_own, self.obstacles, self.begin, self.count,
                                **self.feature_params)
+
+    def model_step_overlapped(self, model, state_own, destination_own, desired_speed_own):
+        """`model_step` with the exchange started first and everything that needs only the own block enqueued under it:
+        the weight pack, the neighbour search among the block's own agents, the obstacle branch and the self features
+        (ops.relative_features_local_part); after the wait, the remote half of the search and the network.  Same
+        results as model_step (the split search is bit-identical; the HIP operators only, no injected feature_fn)."""
+        group = self.group if self.group is not None else dist.group.WORLD
+        holder = []
+        state_full = _AllGatherRecordsAsync.apply(state_own, group, holder)
+        packed = getattr(model, 'packed_weights', None)
+        import contextlib
+        with (packed() if packed is not None else contextlib.nullcontext()):
+            local = ops.relative_features_local_part(state_full, destination_own, self.obstacles, desired_speed_own,
+                                                     self.begin, self.count, **self.feature_params)
+            holder[0].wait()
+            pf, of, self_features = ops.relative_features_packed_self(
+                state_full, destination_own, self.obstacles, desired_speed_own, self.begin, self.count, local=local,
+                **self.feature_params)
+            return model(pf, of, self_features)
 
     def model_step(self, model, state_own, destination_own, desired_speed_own):
         """features -> PINNSF forward for the owned rows (simulators.py:642-652 + :602).

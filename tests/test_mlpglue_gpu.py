@@ -294,6 +294,53 @@ def test_relative_features_packed_self_matches_separate_ops(f0, fc):
     assert torch.allclose(torch.nan_to_num(g_only), torch.nan_to_num(g_only_ref), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('N,M,f0,fc', [(300, 200, 0, 300), (300, 200, 100, 120), (300, 200, 0, 7), (300, 200, 293, 7),
+                                        (5, 3, 1, 3), (16384, 2000, 6144, 2048), (5000, 4500, 4096, 904)])
+def test_relative_features_split_parts_equal_one_launch(N, M, f0, fc):
+    """Agent-block sharding: the LOCAL part (own block's sources + obstacles + self features; reads no row outside the
+    block) followed by the REMOTE part (the other agents, continuing the saved list) is bit-identical to the one-launch
+    form -- features, indices, and the gradients of the one backward launch -- incl. blocks at either end of the scene,
+    k > block size, NaN (absent) agents and the cfg4 shard shape (16384 agents, blocks of 2048)."""
+    from piml_amd import ops
+    from piml_amd.scenes import synthetic_gc_scene
+    sc = synthetic_gc_scene(N, M, seed=9)
+    rng = np.random.default_rng(2)
+    acc = (rng.standard_normal((N, 2)) * 0.3).astype(np.float32)
+    state = torch.tensor(np.concatenate((sc['position'], sc['velocity'], acc), -1)).to(DEV)
+    if N > 100:
+        state[rng.integers(0, N, 5)] = float('nan')                  # absent agents: some focal, some sources
+    dest = torch.tensor(sc['destination'][f0:f0 + fc]).to(DEV)
+    v0 = torch.tensor(sc['desired_speed'][f0:f0 + fc]).to(DEV)
+    obs = torch.tensor(sc['obstacles']).to(DEV)
+    ko = min(10, obs.shape[0])
+    kp = min(6, N)
+    wp, wo, ws = rnd(fc, kp, 6, seed=1), rnd(fc, ko, 6, seed=2), rnd(fc, 7, seed=3)
+
+    sa, va = state.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+    ref = ops.relative_features_packed_self(sa, dest, obs, va, f0, fc, return_index=True)
+    g_ref = torch.autograd.grad((torch.nan_to_num(ref[0]) * wp).sum() + (torch.nan_to_num(ref[1]) * wo).sum() +
+                                (torch.nan_to_num(ref[2]) * ws).sum(), [sa, va])
+
+    sb, vb = state.clone().requires_grad_(True), v0.clone().requires_grad_(True)
+    # the LOCAL part must not depend on rows outside the block: run it on a buffer whose other rows are garbage
+    scratch = torch.full_like(state, 1e30)
+    scratch[f0:f0 + fc] = state[f0:f0 + fc]
+    local_probe = ops.relative_features_local_part(scratch, dest, obs, v0, f0, fc)
+    local = ops.relative_features_local_part(sb, dest, obs, vb, f0, fc)
+    for a, b in ((local.obs_feat, local_probe.obs_feat), (local.self_features, local_probe.self_features),
+                 (local.ped_idx, local_probe.ped_idx), (local.obs_idx, local_probe.obs_idx)):
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
+    out = ops.relative_features_packed_self(sb, dest, obs, vb, f0, fc, return_index=True, local=local)
+    for a, b in zip(out, ref):
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
+    g_out = torch.autograd.grad((torch.nan_to_num(out[0]) * wp).sum() + (torch.nan_to_num(out[1]) * wo).sum() +
+                                (torch.nan_to_num(out[2]) * ws).sum(), [sb, vb])
+    for a, b in zip(g_out, g_ref):
+        assert torch.allclose(torch.nan_to_num(a), torch.nan_to_num(b), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):                                   # a LocalFeatures of another buffer is refused
+        ops.relative_features_packed_self(sa, dest, obs, va, f0, fc, local=local)
+
+
 @pytest.mark.parametrize('C,N', [(4, 122), (1, 1000), (3, 5)])
 def test_pinnsf_epilogue_agent_norm_matches_torch(C, N):
     """Quirk Q2: the dim=1 norm of channelled input (over the agents of a slice, per component)."""

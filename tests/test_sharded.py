@@ -120,6 +120,24 @@ def worker(rank, port, q):
             assert (p.grad is None) == (ref is None)
             if ref is not None:
                 assert np.allclose(p.grad.numpy(), ref, rtol=1e-5, atol=1e-6)
+        # the async in-place exchange of the overlapped step: own rows in place at once, the others after wait();
+        # its autograd form reduce-scatters like the blocking one
+        from piml_amd.sharded import gather_records_async, _AllGatherRecordsAsync
+        buf = torch.full((N, 6), -7.0)
+        work = gather_records_async(buf, state_own, sh.begin, sh.group)
+        assert np.array_equal(buf[sh.begin:sh.begin + sh.count].numpy(), state_own.detach().numpy(), equal_nan=True)
+        work.wait()
+        assert np.array_equal(buf.numpy(), state.numpy(), equal_nan=True)
+        holder = []
+        s2 = state_own.detach().clone().requires_grad_(True)
+        full = _AllGatherRecordsAsync.apply(s2, sh.group, holder)
+        holder[0].wait()
+        assert np.array_equal(full.detach().numpy(), state.numpy(), equal_nan=True)
+        gw = torch.arange(N * 6, dtype=torch.float32).reshape(N, 6) * (rank + 1)
+        (torch.nan_to_num(full) * gw).sum().backward()
+        want = (torch.arange(N * 6, dtype=torch.float32).reshape(N, 6) * sum(range(1, WORLD + 1)))[sh.begin:sh.begin + sh.count]
+        assert np.allclose(torch.nan_to_num(s2.grad).numpy(),
+                           torch.where(torch.isnan(state_own.detach()), torch.zeros_like(want), want).numpy())
         q.put((rank,) + first)
     finally:
         dist.destroy_process_group()

@@ -88,6 +88,39 @@ def test_sharded_model_step_one_rank_nccl_matches_unsharded(nccl_group):
             assert (x - y).abs().max() <= 1e-5 * max(1.0, float(y.abs().max()))
 
 
+def test_overlapped_model_step_one_rank_nccl_matches_serial(nccl_group):
+    """ShardedScene.model_step_overlapped (async in-place all-gather; weight pack + local half of the neighbour search +
+    obstacle branch under it; wait; remote half + network) against model_step: same accelerations bit for bit, same
+    gradients up to the summation order of the relfeat backward's atomics."""
+    from piml_amd.models.model import PINNSF_multitask
+    from piml_amd.sharded import ShardedScene, allreduce_gradients
+    N, M = 2048, 500
+    state, (dest, v0, obs) = _scene(N, M, 4)
+    torch.manual_seed(2)
+    model = PINNSF_multitask(model_args()).to(DEV).eval()
+    w = torch.linspace(-1, 1, N * 2, device=DEV).reshape(N, 2)
+    sh = ShardedScene(N, obs, group=nccl_group, force_collectives=True)
+
+    def run(overlapped):
+        for p in model.parameters():
+            p.grad = None
+        s = state.clone().requires_grad_(True)
+        step = sh.model_step_overlapped if overlapped else sh.model_step
+        acc = step(model, s, dest, v0)[0]
+        (acc * w).sum().backward()
+        allreduce_gradients(list(model.parameters()), nccl_group)
+        torch.cuda.synchronize()
+        return acc.detach(), s.grad.clone(), [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    a1, g1, p1 = run(True)
+    a0, g0, p0 = run(False)
+    assert torch.equal(torch.nan_to_num(a1), torch.nan_to_num(a0))
+    assert (torch.nan_to_num(g1) - torch.nan_to_num(g0)).abs().max() <= 1e-5 * max(1.0, float(torch.nan_to_num(g0).abs().max()))
+    for x, y in zip(p1, p0):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert (x - y).abs().max() <= 1e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_exchange_pair_around_local_step_one_rank_nccl(nccl_group):
     """The eager exchange pair bench.py issues either side of the captured compute graph: all-gather into a static
     (N, 6) leaf, then reduce_scatter_grad of its .grad -- with RCCL, 1 rank."""
