@@ -33,7 +33,7 @@ def build(force=False, verbose=False, extra=()):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + list(extra) + ['-o', LIB] + sources()
+    cmd = [hipcc] + FLAGS + list(extra) + os.environ.get('PIML_HIPCC_EXTRA', '').split() + ['-o', LIB] + sources()
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -52,10 +52,26 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
     if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
 }
 
-__device__ __forceinline__ void stage_linear(float* lds, const float* __restrict__ src, int nfloats, int tid) {
+// Packed image -> LDS, every 16-byte load of the thread issued before the first LDS write.  (As a plain loop this
+// compiled to load / s_waitcnt vmcnt(0) / ds_write per iteration: 17 serialised L2 round trips in front of every
+// workgroup's first MFMA.)
+template <int NFLOATS>
+__device__ __forceinline__ void stage_linear(float* lds, const float* __restrict__ src, int tid) {
+    constexpr int N4 = NFLOATS / 4, ROUNDS = (N4 + ENC_THREADS - 1) / ENC_THREADS;
+    static_assert(NFLOATS % 4 == 0, "float4 granularity");
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(lds);
-    for (int e = tid; e < nfloats / 4; e += ENC_THREADS) d4[e] = s4[e];
+    float4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        v[r] = s4[(r + 1) * ENC_THREADS <= N4 || e < N4 ? e : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        if ((r + 1) * ENC_THREADS <= N4 || e < N4) d4[e] = v[r];
+    }
 }
 
 // features (4 consecutive) held by accumulator registers 4q .. 4q+3 of block blk in lane half h
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
     const float4* W3f = reinterpret_cast<const float4*>(lds + 16384);
     const float* W1f = lds + 32768;
     const float* bias = lds + 32768 + 1024;
-    stage_linear(lds, J.packed, PACK_FWD, tid);
+    stage_linear<PACK_FWD>(lds, J.packed, tid);
     __syncthreads();
 
     const int j = lane & 31, h = lane >> 5;
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
     const float4* W2t = reinterpret_cast<const float4*>(lds + 16384);
     const float4* W1r = reinterpret_cast<const float4*>(lds + 32768);      // row f = float4 2 f, 2 f + 1
     const bool want_gx = J.g_x != nullptr;
-    stage_linear(lds, J.packed + PACK_FWD, PACK_DX, tid);
+    stage_linear<PACK_DX>(lds, J.packed + PACK_FWD, tid);
     __syncthreads();
 
     const int j = lane & 31, h = lane >> 5;
@@ -509,12 +525,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     }
 }
 
-// grads = sum over the branch's partial slots (sum_slots_64x4, pack.hpp); blockIdx.y = branch
+// grads = sum over the branch's partial slots (sum_slots_16x16, pack.hpp); blockIdx.y = branch
 __global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes) {
     const int b = blockIdx.y;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int B = b ? 256 - A.wg_split : (A.nbr > 1 ? A.wg_split : 256);
-    sum_slots_64x4(J.partials, J.grads, B, lanes);
+    sum_slots_16x16(J.partials, J.grads, B, lanes);
 }
 
 static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, long long unit) {
@@ -664,7 +680,7 @@ int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     fill_args(A, br, nbr);
-    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 63) / 64, nbr), dim3(256), 0, s, A, ENC_PART / 4);
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, ENC_PART / 4);
     return hipGetLastError();
 }
 

@@ -102,11 +102,8 @@ struct ReduceAll {
 
 __global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) {
     const int y = blockIdx.y;
-    if (y < A.nbr) {
-        if ((int)blockIdx.x * 64 < ENC_PART / 4) sum_slots_64x4(A.parts[y], A.grads[y], A.slots[y], ENC_PART / 4);
-    } else {
-        if ((int)blockIdx.x * 16 < DEC_PART / 4) sum_slots_16x16(A.parts[y], A.grads[y], A.slots[y], DEC_PART / 4);
-    }
+    const int lanes = y < A.nbr ? ENC_PART / 4 : DEC_PART / 4;
+    if ((int)blockIdx.x * 16 < lanes) sum_slots_16x16(A.parts[y], A.grads[y], A.slots[y], lanes);
 }
 
 }  // namespace piml
@@ -162,7 +159,7 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
         R.grads[nbr + i] = dec[i].grads;
         R.slots[nbr + i] = dslots;
     }
-    constexpr int ge = (ENC_PART / 4 + 63) / 64, gd = (DEC_PART / 4 + 15) / 16;
+    constexpr int ge = (ENC_PART / 4 + 15) / 16, gd = (DEC_PART / 4 + 15) / 16;
     hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3(ge > gd ? ge : gd, 2 * nbr), dim3(256), 0, s, R);
     return hipGetLastError();
 }

@@ -113,40 +113,8 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
 }
 
 // ---- sums over per-workgroup partial slots (fixed order: deterministic), one block of 256 threads per column group ----
-// 64 float4 columns x 4 slot groups per block: group g takes slots g, g+4, ...; groups added 0..3  (many slots)
-__device__ __forceinline__ void sum_slots_64x4(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes) {
-    __shared__ float4 sh[256];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const float4* parts = reinterpret_cast<const float4*>(partials);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < lanes) {
-        int q = grp;
-        for (; q + 12 < B; q += 16) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = parts[(size_t)(q + 4 * u) * lanes + j];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-        }
-        for (; q < B; q += 4) {
-            const float4 v = parts[(size_t)q * lanes + j];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (grp == 0 && j < lanes) {
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-            const float4 v = sh[q * 64 + lane];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        reinterpret_cast<float4*>(grads)[j] = s;
-    }
-}
-
-// 16 float4 columns x 16 slot groups per block (few MB spread over many slots: wide grid)
+// 16 float4 columns x 16 slot groups per block (wide grid); a thread's slots are fetched eight at a time, all loads
+// (clamped, unconditional) issued before the first add: the sums are latency-bound, not bandwidth-bound
 __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes) {
     __shared__ float4 sh[256];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -154,9 +122,18 @@ __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partia
     const float4* parts = reinterpret_cast<const float4*>(partials);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < lanes)
-        for (int q = grp; q < B; q += 16) {
-            const float4 v = parts[(size_t)q * lanes + j];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int q0 = grp; q0 < B; q0 += 16 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + 16 * u;
+                v[u] = parts[(size_t)(q < B ? q : grp) * lanes + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = q0 + 16 * u < B;
+                s.x += ok ? v[u].x : 0.f; s.y += ok ? v[u].y : 0.f; s.z += ok ? v[u].z : 0.f; s.w += ok ? v[u].w : 0.f;
+            }
         }
     sh[threadIdx.x] = s;
     __syncthreads();
