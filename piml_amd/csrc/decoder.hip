@@ -71,31 +71,85 @@ __global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
 // half kh of the contraction of layers 1 and 2 -- with the partial sums exchanged through LDS in accumulator layout
 // (lane = agent, register = feature: exactly the B-operand layout of the next layer, so an exchange is 16 conflict-free
 // ds_write_b32 + 32 ds_read_b32 per lane).  Chain per wave: 32 + 16 + 16 MFMAs and three barriers.
-__global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) {
+// POOL: the neighbour-axis sum (model.py:1283) is done here instead of by dec_pool_kernel: wave (branch, w) sums feature
+// block w of the tile's agents over their k message rows (k x 4 16-byte loads per lane, POOL_ROWS rows = 160 registers in
+// flight at a time -- the reference's k = 6 and k = 10 in ONE round trip --, added in row order like dec_pool_kernel), writes `pooled` for the backward pass and hands the block to the other
+// waves through LDS.
+constexpr int POOL_ROWS = 10;
+
+template <bool POOL>
+__device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
     __shared__ float part1[2][2][2][16][64];      // [branch][ob][kh][register][lane]
     __shared__ float part2[2][2][2][16][64];
     __shared__ float part3[2][2][2][32];          // [branch][kh][component][agent]
+    __shared__ float poolx[POOL ? 2 : 1][POOL ? 4 : 1][POOL ? 16 : 1][64];     // [branch][feature block][register][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1;
     const bool active = b < A.nbr;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
-    const long long agent = (long long)blockIdx.x * 32 + j;
+    const long long agent = tile * 32 + j;
     const bool valid = active && agent < J.agents;
     const float4* PK = reinterpret_cast<const float4*>(J.packed);
     const float* bias = J.packed + DP_B;
-    float4 w2f[4], w3f[4];
+    float4 w2f[4], w3f[4], w1f[2][4];
     if (active) {
-        // ---- layer 1 partial: features of block ob, contraction over input blocks 2 kh, 2 kh + 1 ----
-        float4 pv[2][4], w1f[2][4];
-        const float* base = J.pooled + (valid ? agent : 0) * DH;
 #pragma unroll
         for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
-                w1f[bl][q] = PK[DP_A1 / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
+            for (int q = 0; q < 4; ++q) w1f[bl][q] = PK[DP_A1 / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
+    }
+    if (POOL) {
+        if (active) {
+            const int blk = wave & 3, k = J.k;
+            const float* mp = J.msgs + (valid ? agent : 0) * (long long)k * DH;
+            float4 sum[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r0 = 0; r0 < k; r0 += POOL_ROWS) {
+                float4 v[POOL_ROWS][4];
+#pragma unroll
+                for (int u = 0; u < POOL_ROWS; ++u) {
+                    const int r = r0 + u < k ? r0 + u : 0;             // clamped, unconditional: all loads in flight
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[u][q] = *reinterpret_cast<const float4*>(mp + (long long)r * DH + dfeat0(blk, q, h));
+                }
+#pragma unroll
+                for (int u = 0; u < POOL_ROWS; ++u) {
+                    const bool ok = r0 + u < k;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sum[q].x += ok ? v[u][q].x : 0.f; sum[q].y += ok ? v[u][q].y : 0.f;
+                        sum[q].z += ok ? v[u][q].z : 0.f; sum[q].w += ok ? v[u][q].w : 0.f;
+                    }
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (valid) *reinterpret_cast<float4*>(J.pooled + agent * DH + dfeat0(blk, q, h)) = sum[q];
+                poolx[b][blk][4 * q + 0][lane] = valid ? sum[q].x : 0.f; poolx[b][blk][4 * q + 1][lane] = valid ? sum[q].y : 0.f;
+                poolx[b][blk][4 * q + 2][lane] = valid ? sum[q].z : 0.f; poolx[b][blk][4 * q + 3][lane] = valid ? sum[q].w : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        // ---- layer 1 partial: features of block ob, contraction over input blocks 2 kh, 2 kh + 1 ----
+        float4 pv[2][4];
+        if (POOL) {
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    pv[bl][q] = make_float4(poolx[b][2 * kh + bl][4 * q][lane], poolx[b][2 * kh + bl][4 * q + 1][lane],
+                                            poolx[b][2 * kh + bl][4 * q + 2][lane], poolx[b][2 * kh + bl][4 * q + 3][lane]);
+        } else {
+            const float* base = J.pooled + (valid ? agent : 0) * DH;
+#pragma unroll
+            for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             w2f[q] = PK[DP_A2 / 4 + ((ob * 2 + kh) * 4 + q) * 64 + lane];
@@ -193,6 +247,8 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) {
         reinterpret_cast<float2*>(A.acc)[agent] = make_float2(ax, ay);
     }
 }
+
+__global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<false>(A, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward, dX chain: g_pred (agents, 2) -> g_pre2 = W3^T g_pred -> g_pre1 = (W2^T g_pre2) * [h1 > 0] ->
@@ -401,12 +457,13 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict_
 // One wave per 32-row tile.  Layer 1 (128 -> 64) on the matrix pipe; its fragments stream from the packed image (L2)
 // four at a time, one group ahead, so the kernel keeps < 128 VGPRs (the pooling blocks that share its launch want
 // occupancy).  Layer 2 (64 -> 1) is a dot product per row: 32 FMAs per lane + one cross-half add, not 32 padded MFMAs.
+template <int WAVES = 4>
 __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, long long rows,
                                               const float* __restrict__ packed, float* __restrict__ out, long long bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const long long row = (bx * 4 + wave) * 32 + j;
-    if ((bx * 4 + wave) * 32 >= rows) return;
+    const long long row = (bx * WAVES + wave) * 32 + j;
+    if ((bx * WAVES + wave) * 32 >= rows) return;
     const bool valid = row < rows;
     const float4* PK = reinterpret_cast<const float4*>(packed);
     const float* bias = packed + HP_B;
@@ -550,6 +607,35 @@ int piml::dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml
     const int head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
     hipLaunchKernelGGL(dec_pool_head_kernel, dim3((unsigned)(head_blocks + pool_blocks * nbr)), dim3(256), 0, s, A, *h,
                        head_blocks, pool_blocks);
+    return hipGetLastError();
+}
+
+// The decoder tails (incl. their neighbour-axis sums) and the collision head in ONE launch: both consume the encoders'
+// messages and nothing of each other.  Blocks [0, dec_blocks) are 32-agent decoder tiles, the rest head blocks of
+// 8 x 32 message rows.  21 us at cfg3 (separately: pooling + head 15 us, then the decoder tails 11 us); the decoder tiles
+// alone take as long (their inline pooling pulls 33 MB through 128 CUs), the head blocks ride along for free.
+__global__ __launch_bounds__(512) void dec_fwd_head_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
+    if ((int)blockIdx.x < dec_blocks) dec_fwd_body<true>(A, blockIdx.x);
+    else head_fwd_body<8>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)blockIdx.x - dec_blocks);
+}
+
+int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
+                              float tau, float* acc, hipStream_t s) {
+    DecArgs A;
+    if (!acc) return hipErrorInvalidValue;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    piml_collision_head Hd = {};
+    int head_blocks = 0;
+    if (h && h->rows > 0) {
+        if (int e = head_check(h)) return e;
+        Hd = *h;
+        head_blocks = (int)(((h->rows + 31) / 32 + 7) / 8);
+    }
+    A.self_features = self_features;
+    A.tau = tau;
+    A.acc = acc;
+    const int tiles = (int)((br[0].agents + 31) / 32);
+    hipLaunchKernelGGL(dec_fwd_head_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(512), 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
 

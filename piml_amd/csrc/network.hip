@@ -172,9 +172,7 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
     if (!(flags & PIML_FORK)) {
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
         PIML_TRY(enc_stage_fwd(enc, nbr, m));
-        if (head && head->rows > 0) PIML_TRY(dec_stage_pool_head(dec, nbr, head, m));
-        else PIML_TRY(dec_stage_pool(dec, nbr, m));
-        return dec_stage_fwd(dec, nbr, self_features, tau, acc, m);
+        return dec_stage_fwd_fused(dec, nbr, head, self_features, tau, acc, m);
     }
     Side* S;
     PIML_TRY(side_streams(&S));
