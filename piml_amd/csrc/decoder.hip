@@ -77,28 +77,54 @@ __global__ __launch_bounds__(256) void dec_pool_kernel(DecArgs A) {
 // waves through LDS.
 constexpr int POOL_ROWS = 10;
 
-template <bool POOL>
-__device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
-    __shared__ float part1[2][2][2][16][64];      // [branch][ob][kh][register][lane]
-    __shared__ float part2[2][2][2][16][64];
-    __shared__ float part3[2][2][2][32];          // [branch][kh][component][agent]
-    __shared__ float poolx[POOL ? 2 : 1][POOL ? 4 : 1][POOL ? 16 : 1][64];     // [branch][feature block][register][lane]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// SPLIT: one 4-wave workgroup per (tile, branch) instead of 8 waves per tile -- twice the CUs pull the message rows
+// (the inline pooling is bound by the L1 miss rate of a CU) --; each branch then ADDS its acceleration to `acc`, which
+// the caller has zeroed: two float atomic adds onto zero commute exactly (0 + x = x, x + y = y + x), so the result is
+// still deterministic and equal to the unsplit kernel's (p + d) + o.
+template <bool POOL, bool SPLIT = false>
+__device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, int split_branch = 0) {
+    constexpr int NB = SPLIT ? 1 : 2;
+    __shared__ float part1[NB][2][2][16][64];      // [branch][ob][kh][register][lane]
+    __shared__ float part2[NB][2][2][16][64];
+    __shared__ float part3[NB][2][2][32];          // [branch][kh][component][agent]
+    __shared__ float poolx[POOL ? NB : 1][POOL ? 4 : 1][POOL ? 16 : 1][64];     // [branch][feature block][register][lane]
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
-    const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1;
+    const int b = SPLIT ? split_branch : wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1;
+    const int bi = SPLIT ? 0 : b;                  // index of the branch in the LDS arrays
     const bool active = b < A.nbr;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long agent = tile * 32 + j;
     const bool valid = active && agent < J.agents;
     const float4* PK = reinterpret_cast<const float4*>(J.packed);
     const float* bias = J.packed + DP_B;
-    float4 w2f[4], w3f[4], w1f[2][4];
+    float4 w2f[4], w3f[4], w1f[2][4], b2v[4];
+    float b3x = 0.f, b3y = 0.f;
     if (active) {
 #pragma unroll
         for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
             for (int q = 0; q < 4; ++q) w1f[bl][q] = PK[DP_A1 / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
     }
+    float4 b1v[4];
+    float sfv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // everything the later phases read from memory, requested in one go BEFORE the first barrier (left where they are used,
+    // these loads sit behind the barriers: one exposed L2 round trip per layer)
+    auto late_loads = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b1v[q] = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            w2f[q] = PK[DP_A2 / 4 + ((ob * 2 + kh) * 4 + q) * 64 + lane];
+            w3f[q] = PK[DP_A3 / 4 + (kh * 4 + q) * 64 + lane];
+            b2v[q] = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
+        }
+        b3x = bias[128];
+        b3y = bias[129];
+        if (A.self_features && b == 0 && wave == 0) {          // (wave-uniform condition) the epilogue's desired-force inputs
+            const float* sp = A.self_features + (agent < A.br[0].agents ? agent : 0) * 7;
+            sfv[0] = sp[0]; sfv[1] = sp[1]; sfv[2] = sp[2]; sfv[3] = sp[3]; sfv[4] = sp[6];
+        }
+    };
     if (POOL) {
         if (active) {
             const int blk = wave & 3, k = J.k;
@@ -124,11 +150,13 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
                     }
                 }
             }
+            late_loads();
+            __builtin_amdgcn_sched_barrier(0);       // ... in flight under the LDS exchange and the barrier
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (valid) *reinterpret_cast<float4*>(J.pooled + agent * DH + dfeat0(blk, q, h)) = sum[q];
-                poolx[b][blk][4 * q + 0][lane] = valid ? sum[q].x : 0.f; poolx[b][blk][4 * q + 1][lane] = valid ? sum[q].y : 0.f;
-                poolx[b][blk][4 * q + 2][lane] = valid ? sum[q].z : 0.f; poolx[b][blk][4 * q + 3][lane] = valid ? sum[q].w : 0.f;
+                poolx[bi][blk][4 * q + 0][lane] = valid ? sum[q].x : 0.f; poolx[bi][blk][4 * q + 1][lane] = valid ? sum[q].y : 0.f;
+                poolx[bi][blk][4 * q + 2][lane] = valid ? sum[q].z : 0.f; poolx[bi][blk][4 * q + 3][lane] = valid ? sum[q].w : 0.f;
             }
         }
         __syncthreads();
@@ -141,8 +169,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
             for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    pv[bl][q] = make_float4(poolx[b][2 * kh + bl][4 * q][lane], poolx[b][2 * kh + bl][4 * q + 1][lane],
-                                            poolx[b][2 * kh + bl][4 * q + 2][lane], poolx[b][2 * kh + bl][4 * q + 3][lane]);
+                    pv[bl][q] = make_float4(poolx[bi][2 * kh + bl][4 * q][lane], poolx[bi][2 * kh + bl][4 * q + 1][lane],
+                                            poolx[bi][2 * kh + bl][4 * q + 2][lane], poolx[bi][2 * kh + bl][4 * q + 3][lane]);
         } else {
             const float* base = J.pooled + (valid ? agent : 0) * DH;
 #pragma unroll
@@ -150,15 +178,11 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            w2f[q] = PK[DP_A2 / 4 + ((ob * 2 + kh) * 4 + q) * 64 + lane];
-            w3f[q] = PK[DP_A3 / 4 + (kh * 4 + q) * 64 + lane];
-        }
+        if (!POOL) late_loads();
         f32x16 a1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            const float4 bq = b1v[q];
             a1[4 * q] = kh ? 0.f : bq.x; a1[4 * q + 1] = kh ? 0.f : bq.y;
             a1[4 * q + 2] = kh ? 0.f : bq.z; a1[4 * q + 3] = kh ? 0.f : bq.w;
         }
@@ -174,14 +198,14 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
                 a1 = dmfma(w.w, valid ? x.w : 0.f, a1);
             }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part1[b][ob][kh][r][lane] = a1[r];
+        for (int r = 0; r < 16; ++r) part1[bi][ob][kh][r][lane] = a1[r];
     }
     __syncthreads();
     if (active) {
         // ---- layer 2 partial: output block ob, contraction over hidden block kh (= relu of the summed layer-1 block kh) ----
         float x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = fmaxf(part1[b][kh][0][r][lane] + part1[b][kh][1][r][lane], 0.f);
+        for (int r = 0; r < 16; ++r) x[r] = fmaxf(part1[bi][kh][0][r][lane] + part1[bi][kh][1][r][lane], 0.f);
         if (ob == 0 && J.h1 && valid) {
             float* o = J.h1 + agent * DD;
 #pragma unroll
@@ -191,7 +215,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
         f32x16 a2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
+            const float4 bq = b2v[q];
             a2[4 * q] = kh ? 0.f : bq.x; a2[4 * q + 1] = kh ? 0.f : bq.y;
             a2[4 * q + 2] = kh ? 0.f : bq.z; a2[4 * q + 3] = kh ? 0.f : bq.w;
         }
@@ -204,14 +228,14 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
             a2 = dmfma(w.w, x[4 * q + 3], a2);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part2[b][ob][kh][r][lane] = a2[r];
+        for (int r = 0; r < 16; ++r) part2[bi][ob][kh][r][lane] = a2[r];
     }
     __syncthreads();
     if (active && ob == 0) {
         // ---- predictor partial over decoder-output block kh (M padded to 32: component c = register c of the h = 0 lanes) ----
         float y[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = part2[b][kh][0][r][lane] + part2[b][kh][1][r][lane];
+        for (int r = 0; r < 16; ++r) y[r] = part2[bi][kh][0][r][lane] + part2[bi][kh][1][r][lane];
         if (J.d2 && valid) {
             float* o = J.d2 + agent * DD;
 #pragma unroll
@@ -221,7 +245,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
         f32x16 a3;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a3[r] = 0.f;
-        if (h == 0 && kh == 0) { a3[0] = bias[128]; a3[1] = bias[129]; }
+        if (h == 0 && kh == 0) { a3[0] = b3x; a3[1] = b3y; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 w = w3f[q];
@@ -230,21 +254,30 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile) {
             a3 = dmfma(w.z, y[4 * q + 2], a3);
             a3 = dmfma(w.w, y[4 * q + 3], a3);
         }
-        if (h == 0) { part3[b][kh][0][j] = a3[0]; part3[b][kh][1][j] = a3[1]; }
+        if (h == 0) { part3[bi][kh][0][j] = a3[0]; part3[bi][kh][1][j] = a3[1]; }
     }
     __syncthreads();
     if (wave == 0 && h == 0 && agent < A.br[0].agents) {
+        // sum order (also of the split form): (pedestrian branch + desired force) + obstacle branch
         float ax = part3[0][0][0][j] + part3[0][1][0][j], ay = part3[0][0][1][j] + part3[0][1][1][j];
-        if (A.nbr > 1) { ax += part3[1][0][0][j] + part3[1][1][0][j]; ay += part3[1][0][1][j] + part3[1][1][1][j]; }
-        if (A.self_features) {        // + (v0 * d / t - v) / tau,  t = |d| (+0.1 where |d| == 0)   (model.py:1289-1294)
-            const float* s = A.self_features + agent * 7;
-            const float dx = s[0], dy = s[1], vx = s[2], vy = s[3], v0 = s[6];
+        if (A.self_features && b == 0) {   // + (v0 * d / t - v) / tau,  t = |d| (+0.1 where |d| == 0)   (model.py:1289-1294)
+            const float dx = sfv[0], dy = sfv[1], vx = sfv[2], vy = sfv[3], v0 = sfv[4];
             float t = norm2(dx, dy);
             t = (t == 0.f) ? t + 0.1f : t;
             ax += (v0 * (dx / t) - vx) / A.tau;
             ay += (v0 * (dy / t) - vy) / A.tau;
         }
-        reinterpret_cast<float2*>(A.acc)[agent] = make_float2(ax, ay);
+        if (SPLIT) {
+            if (A.nbr > 1) {
+                atomicAdd(A.acc + 2 * agent, ax);
+                atomicAdd(A.acc + 2 * agent + 1, ay);
+            } else {
+                reinterpret_cast<float2*>(A.acc)[agent] = make_float2(ax, ay);
+            }
+        } else {
+            if (A.nbr > 1) { ax += part3[1][0][0][j] + part3[1][1][0][j]; ay += part3[1][0][1][j] + part3[1][1][1][j]; }
+            reinterpret_cast<float2*>(A.acc)[agent] = make_float2(ax, ay);
+        }
     }
 }
 
@@ -259,7 +292,7 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<
 // the complete, masked g_pre1 (32 MFMAs).
 __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
     __shared__ float part[2][2][2][16][64];       // [branch][ob][kh][register][lane]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
     const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
     const bool active = b < A.nbr;
@@ -269,8 +302,16 @@ __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
     const float4* PK = reinterpret_cast<const float4*>(J.packed);
     float2 gp = make_float2(0.f, 0.f);
     float4 hv[2][4], t1f[8];
+    float sfv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        if (valid) gp = reinterpret_cast<const float2*>(A.g_pred)[agent];
+        // unconditional, clamped loads (a branch around a load makes the compiler wait for it at the join: three serial
+        // round trips at the head of this kernel before the change)
+        gp = reinterpret_cast<const float2*>(A.g_pred)[valid ? agent : 0];
+        if (!valid) gp = make_float2(0.f, 0.f);
+        if (wave == 0 && A.g_self && A.self_features) {        // wave-uniform: the desired-force gradient's inputs
+            const float* sp = A.self_features + (valid ? agent : 0) * 7;
+            sfv[0] = sp[0]; sfv[1] = sp[1]; sfv[4] = sp[6];
+        }
         const float bg = h ? gp.y : gp.x;
         const float* hp = J.h1 + (valid ? agent : 0) * DD;
 #pragma unroll
@@ -354,8 +395,7 @@ __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
     }
     // desired-force backward (pinnsf_epilogue_bwd_kernel's arithmetic), one lane per agent
     if (wave == 0 && h == 0 && valid && A.g_self && A.self_features) {
-        const float* s = A.self_features + agent * 7;
-        const float dx = s[0], dy = s[1], v0 = s[6], tau = A.tau;
+        const float dx = sfv[0], dy = sfv[1], v0 = sfv[4], tau = A.tau;
         const float n = norm2(dx, dy);
         const float t = (n == 0.f) ? n + 0.1f : n;
         const float ex = dx / t, ey = dy / t;
@@ -460,7 +500,7 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict_
 template <int WAVES = 4>
 __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, long long rows,
                                               const float* __restrict__ packed, float* __restrict__ out, long long bx) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
     const long long row = (bx * WAVES + wave) * 32 + j;
     if ((bx * WAVES + wave) * 32 >= rows) return;
@@ -611,12 +651,16 @@ int piml::dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml
 }
 
 // The decoder tails (incl. their neighbour-axis sums) and the collision head in ONE launch: both consume the encoders'
-// messages and nothing of each other.  Blocks [0, dec_blocks) are 32-agent decoder tiles, the rest head blocks of
-// 8 x 32 message rows.  21 us at cfg3 (separately: pooling + head 15 us, then the decoder tails 11 us); the decoder tiles
-// alone take as long (their inline pooling pulls 33 MB through 128 CUs), the head blocks ride along for free.
-__global__ __launch_bounds__(512) void dec_fwd_head_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
-    if ((int)blockIdx.x < dec_blocks) dec_fwd_body<true>(A, blockIdx.x);
-    else head_fwd_body<8>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)blockIdx.x - dec_blocks);
+// messages and nothing of each other.  Blocks [0, dec_blocks) are (32-agent tile, branch) units, the rest head blocks of
+// 4 x 32 message rows.  `acc` must be zero on entry when there are two branches (enc_stage_fwd clears it on the way).
+__global__ __launch_bounds__(256) void dec_fwd_head_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
+    const int bx = blockIdx.x;
+    if (bx < dec_blocks) {
+        if (A.nbr > 1) dec_fwd_body<true, true>(A, bx >> 1, bx & 1);
+        else dec_fwd_body<true, true>(A, bx, 0);
+    } else {
+        head_fwd_body<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+    }
 }
 
 int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
@@ -629,13 +673,13 @@ int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml
     if (h && h->rows > 0) {
         if (int e = head_check(h)) return e;
         Hd = *h;
-        head_blocks = (int)(((h->rows + 31) / 32 + 7) / 8);
+        head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
     }
     A.self_features = self_features;
     A.tau = tau;
     A.acc = acc;
-    const int tiles = (int)((br[0].agents + 31) / 32);
-    hipLaunchKernelGGL(dec_fwd_head_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(512), 0, s, A, Hd, tiles);
+    const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
+    hipLaunchKernelGGL(dec_fwd_head_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
 

@@ -34,6 +34,8 @@ struct EncArgs {
     piml_encoder_branch br[2];
     int nbr;
     int wg_split;       // workgroups [0, wg_split) serve branch 0, the rest branch 1
+    float* zero;        // forward only, optional: a buffer the launch clears on the way (the decoder tails' accumulator)
+    int zero_n;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -95,6 +97,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
     const long long ntiles = (R + 31) >> 5;
     const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
     const long long stride = (long long)nwg * ENC_WAVES;
+    if (A.zero)
+        for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
     if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
 
     const float4* W2f = reinterpret_cast<const float4*>(lds);
@@ -551,6 +555,8 @@ static bool branch_ok(const piml_encoder_branch& b) {
 
 static int fill_args(EncArgs& A, const piml_encoder_branch* br, int nbr) {
     A.nbr = nbr;
+    A.zero = nullptr;
+    A.zero_n = 0;
     for (int i = 0; i < nbr; ++i) A.br[i] = br[i];
     if (nbr == 1) A.br[1] = br[0];
     A.wg_split = split_workgroups(br, nbr, 256, 1);
@@ -608,11 +614,13 @@ int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) 
     A.br[0] = br[0];
     A.br[1] = br[nbr - 1];
     A.wg_split = 0;
+    A.zero = nullptr;
+    A.zero_n = 0;
     hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 
-int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
     if (int e = enc_check(br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
         if (!br[i].msgs) return hipErrorInvalidValue;
@@ -623,6 +631,7 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s) {
         if (int e = enc_set_lds(reinterpret_cast<const void*>(enc_fwd_kernel), FWD_LDS_FLOATS * 4)) return e;
         attr_set = true;
     }
+    if (zero && zero_n > 0 && zero_n < (1ll << 31)) { A.zero = zero; A.zero_n = (int)zero_n; }
     hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, s, A);
     return hipGetLastError();
 }

@@ -171,7 +171,8 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
     const bool pack = !(flags & PIML_PACKED_VALID);
     if (!(flags & PIML_FORK)) {
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
-        PIML_TRY(enc_stage_fwd(enc, nbr, m));
+        // the split decoder tiles accumulate their two branches into `acc`: cleared by the encoder launch
+        PIML_TRY(enc_stage_fwd(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
         return dec_stage_fwd_fused(dec, nbr, head, self_features, tau, acc, m);
     }
     Side* S;

@@ -9,7 +9,8 @@
 namespace piml {
 
 int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
-int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s);            // packed image must be current
+// packed image must be current; `zero` (optional): zero_n floats cleared by the launch
+int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
 int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
 int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s);
