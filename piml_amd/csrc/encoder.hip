@@ -492,7 +492,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
             float* cur = lds + (t & 1) * DW_BUF;
             float* nxt = lds + ((t + 1) & 1) * DW_BUF;
             S = stage_load(r0 + (t + 1) * DW_ROWS);         // past the slab: clamped + zeroed, written but never read
+            // pinned: without the two fences the scheduler lifts stage_write's arithmetic on the freshly loaded registers
+            // in between the first MFMAs, i.e. waits for the NEXT batch's loads (s_waitcnt vmcnt(0) after four MFMAs)
+            // before this batch is computed -- one exposed memory round trip per batch instead of none
+            __builtin_amdgcn_sched_barrier(0);
             compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
             stage_write(S, nxt);
             __syncthreads();
         }
