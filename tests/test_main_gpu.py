@@ -53,15 +53,26 @@ COMMON = ['-f', '--device', 'cuda:0', '--model', 'pinnsf_bm', '--dropout', '0.0'
 
 # Bounds (relative unless a name ends in _m = metres), each a small multiple of what is measured on the MI355X
 # (DESIGN.md section 2 lists the measured values).  Two groups:
-#   * `ref_*`: OUR rollout with EXACTLY the reference's fine-tuned weights -- rollout parity proper, tight;
-#   * the rest: the whole flow with our own training, where the <= 1e-5 per-step differences compound through ~260
-#     Adam updates (GC: negligible; UCY: 1e-4 .. 2e-2 on the training scalars, <= 2e-3 on the final metrics).
+#   * `ref_*`: OUR rollout with EXACTLY the reference's fine-tuned weights -- rollout parity proper, tight (1e-6 m);
+#   * the rest: the whole flow with our own training.  GC: negligible (1e-6 .. 3e-5).  UCY has a DISCONTINUITY: two
+#     float32 implementations that agree to 1e-5 on every single batch (tools/debug_ucy_batches.py: the fused kernels
+#     against this package's library-GEMM path on the same weights, all 131 batches <= 4.5e-5) stay within 2.5e-6 of each
+#     other in weight space for ~110 batches and then jump apart by 2.5e-3 within ten batches
+#     (tools/debug_ucy_diverge.py): a hidden unit that was dead so far gets a pre-activation within an ulp of zero, one
+#     implementation rounds it to +0, the other to a tiny positive value, and Adam turns the first non-zero gradient of
+#     the unit's 128 weights -- whatever its size -- into a full lr-sized step.  The library-GEMM path happens to round
+#     like the reference's CPU GEMM and follows its trajectory to 1e-6 (run this test with PIML_FUSED_ENCODER=0
+#     PIML_FUSED_NETWORK=0: every line below <= 1e-5); the fused kernels (bias as the accumulator's initial value, MFMA
+#     summation order) do not.  `spread_*` prints the distance between the two paths on every run.  Three builds of
+#     round 2 (different MFMA / VALU summation orders) gave for (pre_val, weights, worst metric, collisions):
+#     (1.2e-3, 1.6e-3, 1.2e-3, 7e-3), (2.5e-3, 3e-3, 4e-3, 7e-3), (3.1e-3, 4.1e-3, 1.0e-2, 2.0e-2); the bounds are ~3x
+#     the largest.  The tight checks are the `ref_*` rollouts (reference weights) and the single-step test below.
 TOL = {
     'gc': dict(pre_train=1e-6, pre_val=5e-6, ft_train=1e-4, ft_counts=0.0, weights=2e-4, val=2e-2, metrics=3e-4,
                collisions=0.0, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                ref_collisions=0.0),
-    'ucy': dict(pre_train=5e-4, pre_val=3e-3, ft_train=5e-2, ft_counts=3e-2, weights=5e-3, val=1e-2, metrics=5e-3,
-                collisions=2e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
+    'ucy': dict(pre_train=1e-3, pre_val=1e-2, ft_train=1e-1, ft_counts=3e-2, weights=1.5e-2, val=2e-2, metrics=3e-2,
+                collisions=6e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                 ref_collisions=0.0),
 }
 
@@ -159,6 +170,26 @@ def test_main_flow_matches_reference_end_to_end(case):
     report['refweights_mae_per_frame_first100_m'] = float(dm[:skip + 100].max())
     report['refweights_mae_per_frame_all_m'] = float(dm.max())
 
+    if case == 'ucy':
+        # the same flow on this package's OTHER float32 path (library GEMMs instead of the fused MFMA kernels): how far
+        # two correct implementations drift apart on this chaotic configuration
+        import piml_amd.models.model as MODEL
+        first = dict(mse=ev[1], mae=ev[2], ot=ev[3], mmd=ev[4], fde=sim.last_eval['fde'],
+                     val=val_got.copy(), pre_val=np.array([h['val_loss'] for h in pre]))
+        old_flags = (MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK)
+        MODEL.FUSED_ENCODER = MODEL.FUSED_NETWORK = False
+        try:
+            MAIN.main(argv, init_state=init)
+        finally:
+            MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK = old_flags
+        sim2 = MAIN.LAST_RUN['simulator']
+        ev2 = sim2.finetune_test_result
+        report['spread_metrics(fused vs library path)'] = max(rel(first['mse'], ev2[1]), rel(first['mae'], ev2[2]),
+                                                              rel(first['ot'], ev2[3]), rel(first['mmd'], ev2[4]),
+                                                              rel(first['fde'], sim2.last_eval['fde']))
+        report['spread_pre_val'] = rel(first['pre_val'], [h['val_loss'] for h in MAIN.LAST_RUN['pretrain_history']])
+        report['library_path_vs_reference_metrics'] = max(rel(ev2[1], last[1]), rel(ev2[2], last[2]), rel(ev2[3], last[3]),
+                                                          rel(ev2[4], last[4]))
     print(f'\n[cfg5 {case}] measured deviations from the reference (relative unless noted):')
     for k, v in report.items():
         print(f'    {k:32s} {v}')
@@ -183,6 +214,8 @@ def test_main_flow_matches_reference_end_to_end(case):
     for k in ('test_mse', 'mae', 'fde', 'ot', 'mmd'):
         assert report[k] <= tol['metrics'], k
     assert report['collisions'] <= tol['collisions']
+    if case == 'ucy':       # this package's library-GEMM path follows the reference's trajectory itself (see TOL)
+        assert report['library_path_vs_reference_metrics'] <= 1e-4
 
 
 @pytest.mark.parametrize('case', ['gc', 'ucy'])
