@@ -48,3 +48,18 @@ for i in list(range(0, 12)) + list(range(12, n, 10)):
         if e > worst:
             worst, wk = e, k
     print(f'after batch {i:4d}: max rel weight distance {worst:.2e} ({wk})')
+# where does the jump sit?  (a dead hidden unit waking up in one path only = one COLUMN of the next layer's weight,
+# or one ROW + bias of its own layer)
+for i in range(n):
+    k = 'ped_encoder.mlp.2.weight'
+    a, b = snaps[True][i][k], snaps[False][i][k]
+    d = (a - b).abs() / b.abs().max()
+    if float(d.max()) > 5e-4:
+        big = (d > 1e-4).nonzero()
+        rows, cols = big[:, 0].unique(), big[:, 1].unique()
+        print(f'first batch with a > 5e-4 gap in {k}: {i}; elements > 1e-4: {len(big)} in {len(rows)} rows x {len(cols)} columns;'
+              f' rows {rows.tolist()[:8]} cols {cols.tolist()[:8]}')
+        for kk in ('ped_encoder.mlp.0.weight', 'ped_encoder.mlp.0.bias', 'ped_encoder.mlp.2.bias'):
+            dd = (snaps[True][i][kk] - snaps[False][i][kk]).abs() / snaps[False][i][kk].abs().max()
+            print(f'   same batch, {kk}: max gap {float(dd.max()):.2e} at {dd.argmax().item()}')
+        break

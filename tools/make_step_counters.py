@@ -45,7 +45,7 @@ fetch, write, sq = pmc('fetch'), pmc('write'), pmc('sq')
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 
 # kernels of the captured step (everything bench.py launches per step; MLAPM = secondary figures, excluded)
-STEP = ('enc_', 'dec_', 'head_', 'relfeat_', 'self_features', 'pinnsf_epilogue')
+STEP = ('enc_', 'dec_', 'head_', 'relfeat_', 'self_features', 'pinnsf_')
 FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both branches
     'enc_fwd_kernel': 2 * ROWS * (6 * 128 + 2 * 128 * 128),
     'enc_bwd_dx_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
@@ -54,6 +54,8 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'dec_bwd_dx_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dw_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'head_fwd_kernel': 2 * N * KP * (128 * 64 + 64),
+    # decoder tails of both branches + the collision head on the pedestrian rows, one launch
+    'dec_fwd_head_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2) + 2 * N * KP * (128 * 64 + 64),
 }
 
 
