@@ -468,6 +468,9 @@ def main():
                          '(weight pack, local half of the neighbour search, obstacle branch) under it, then the rest.  Off '
                          'by default: with one rank the second graph launch and the second relfeat launch cost 24 us more '
                          'than they hide (0.292 vs 0.268 ms/step); both forms are timed and reported under "exchange"')
+    ap.add_argument('--leg-timeout', type=float, default=180.0,
+                    help='sharded runs: seconds the informational legs after the timed region may take before the line is '
+                         'written without them')
     ap.add_argument('--exchange-compare', type=int, default=1,
                     help='several GPUs: also time the other --exchange variant after the timed region (informational)')
     ap.add_argument('--strong-baseline', type=int, default=1,
@@ -690,6 +693,79 @@ def main():
     achieved = bytes_step / (ms_per_step * 1e-3) / 1e9 / world        # GB/s per GPU
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
+    prof = None
+    ppath = os.path.join(ROOT, 'profiles', 'r02_step_counters.json')
+    if world == 1 and os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
+            prof = pj
+
+    if True:      # (every rank assembles the line; rank 0 writes it)
+        kernels = [{'name': 'relfeat_fwd_kernel', 'us': kernel_ms * 1e3, 'share_of_step': kernel_ms / ms_per_step,
+                    'bound': 'valu', 'frac': (prof or {}).get('relfeat_fwd_kernel', {}).get('valu_busy_frac'),
+                    'hbm_bytes': (prof or {}).get('relfeat_fwd_kernel', {}).get('hbm_bytes_per_launch'),
+                    'operand_stream_bytes': kernel_bytes,
+                    'timing': f'HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
+                              f'{launches_per_sample} launches, median, event-pair overhead subtracted',
+                    'event_interval_us': raw_ms * 1e3, 'event_pair_overhead_us': overhead_ms * 1e3,
+                    'frac_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r02_step_counters.json '
+                                   '(rocprofv3 --pmc, separate pass)' if prof else None}]
+        for k in (prof or {}).get('other_kernels', []):
+            kernels.append(k)
+        out = {
+            'metric': 'agent-pair force evals/sec + simulated steps/sec, 4096-agent GC scene',
+            'value': pairs_step * args.steps / elapsed, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'spinup_steps': spin_steps,
+            'ms_per_step': ms_per_step, 'steps_per_s': args.steps / elapsed,
+            'agent_steps_per_s': N * args.steps / elapsed,
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
+            'mlp': ('fused f32-MFMA kernels (piml_amd/csrc/encoder.hip, decoder.hip)' if fused_mlp else
+                    f'library GEMMs ({gemm_tuning}) + HIP glue kernels, {2 if two_streams else 1} stream(s)'),
+            'config': {'workload': ('cfg3: synthetic 4096-agent GC scene' if (world == 1 and N == 4096) else
+                                    f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
+                                    f'synthetic {N}-agent GC scene ({n_own} focal agents per GPU)') +
+                                   ', forward+backward PINSF step (HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd)',
+                       'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
+                       'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
+                       'sharding': 'single GPU' if not use_dist else
+                       f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': (prof or {}).get('step_hbm_bytes'),
+                         'algorithmic_bytes': bytes_step,
+                         'definition': 'SURVEY.md 8d step-level contract: operand-stream bytes of one step (24 B/ped pair + '
+                                       '8 B/obstacle pair + 488 B/focal agent) / ms_per_step / (n_gpus x HBM peak); the sources '
+                                       'are LDS/L2 resident, so real HBM traffic (`traffic`, PMC) is far below this model and '
+                                       'the step is bound by the MLP (f32 MFMA) and VALU issue, see `kernels`',
+                         'kernels': kernels},
+        }
+    import threading
+    written = threading.Lock()
+
+    def write_line(note=None):
+        """rank 0 writes THE json line exactly once (normal end, or the watchdog below)."""
+        if not written.acquire(blocking=False):
+            return
+        if note:
+            out['informational_legs'] = note
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+    # The legs below re-capture and re-run the step in other forms on every rank: a mismatch between ranks would hang in
+    # a collective for ever.  They are informational; the headline line must survive them.
+    leg_timer = None
+    if use_dist:
+        def bail():
+            print(f'[bench] informational legs did not finish within {args.leg_timeout:.0f} s: writing the line without '
+                  'them and leaving', file=sys.stderr, flush=True)
+            write_line(f'timed out after {args.leg_timeout:.0f} s')
+            os._exit(0)
+        leg_timer = threading.Timer(args.leg_timeout, bail)
+        leg_timer.daemon = True
+        leg_timer.start()
+
     # ---- the other backward-exchange variant, all ranks, outside the timed region (informational) ----
     exchange_other = None
     if use_dist and args.exchange_compare and (world > 1 or args.force_dist):
@@ -735,74 +811,28 @@ def main():
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
 
-    prof = None
-    ppath = os.path.join(ROOT, 'profiles', 'r02_step_counters.json')
-    if world == 1 and os.path.exists(ppath):
-        pj = json.load(open(ppath))
-        if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
-            prof = pj
-
-    if rank == 0:
-        kernels = [{'name': 'relfeat_fwd_kernel', 'us': kernel_ms * 1e3, 'share_of_step': kernel_ms / ms_per_step,
-                    'bound': 'valu', 'frac': (prof or {}).get('relfeat_fwd_kernel', {}).get('valu_busy_frac'),
-                    'hbm_bytes': (prof or {}).get('relfeat_fwd_kernel', {}).get('hbm_bytes_per_launch'),
-                    'operand_stream_bytes': kernel_bytes,
-                    'timing': f'HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
-                              f'{launches_per_sample} launches, median, event-pair overhead subtracted',
-                    'event_interval_us': raw_ms * 1e3, 'event_pair_overhead_us': overhead_ms * 1e3,
-                    'frac_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r02_step_counters.json '
-                                   '(rocprofv3 --pmc, separate pass)' if prof else None}]
-        for k in (prof or {}).get('other_kernels', []):
-            kernels.append(k)
-        out = {
-            'metric': 'agent-pair force evals/sec + simulated steps/sec, 4096-agent GC scene',
-            'value': pairs_step * args.steps / elapsed, 'unit': 'pairs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'spinup_steps': spin_steps,
-            'ms_per_step': ms_per_step, 'steps_per_s': args.steps / elapsed,
-            'agent_steps_per_s': N * args.steps / elapsed,
-            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
-            'mlp': ('fused f32-MFMA kernels (piml_amd/csrc/encoder.hip, decoder.hip)' if fused_mlp else
-                    f'library GEMMs ({gemm_tuning}) + HIP glue kernels, {2 if two_streams else 1} stream(s)'),
-            'config': {'workload': ('cfg3: synthetic 4096-agent GC scene' if (world == 1 and N == 4096) else
-                                    f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
-                                    f'synthetic {N}-agent GC scene ({n_own} focal agents per GPU)') +
-                                   ', forward+backward PINSF step (HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd)',
-                       'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
-                       'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
-                       'sharding': 'single GPU' if not use_dist else
-                       f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': (prof or {}).get('step_hbm_bytes'),
-                         'algorithmic_bytes': bytes_step,
-                         'definition': 'SURVEY.md 8d step-level contract: operand-stream bytes of one step (24 B/ped pair + '
-                                       '8 B/obstacle pair + 488 B/focal agent) / ms_per_step / (n_gpus x HBM peak); the sources '
-                                       'are LDS/L2 resident, so real HBM traffic (`traffic`, PMC) is far below this model and '
-                                       'the step is bound by the MLP (f32 MFMA) and VALU issue, see `kernels`',
-                         'kernels': kernels},
-        }
-        if use_dist:
-            out['exchange'] = {'backward': args.exchange, 'overlap': bool(st.pre is not None),
-                               'other_variants': exchange_other,
-                               'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '
-                                       'reduce-scatter(d/d(state)) + all-reduce(weight gradients); forward = one '
-                                       'all-gather of the (p,v,a) records, issued eagerly around the captured compute; overlap = the '
-                                       'all-gather is started, the own-block part of the step (weight pack, local half of '
-                                       'the neighbour search, obstacle branch) replayed under it, then the rest'}
-        if same_scene_1gpu is not None:
-            out['single_gpu_same_scene'] = same_scene_1gpu
-        if secondary is not None:
-            out['secondary'] = secondary
-        if args.cpu_seconds > 0 and world == 1:
-            try:
-                out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
-            except Exception as ex:   # noqa: BLE001 - e.g. no C compiler for the oracle on this host
-                out['cpu_baseline'] = {'error': f'{type(ex).__name__}: {ex}'}
-        elif world > 1:
-            out['cpu_baseline'] = None
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if leg_timer is not None:
+        leg_timer.cancel()
+    if use_dist:
+        out['exchange'] = {'backward': args.exchange, 'overlap': bool(st.pre is not None),
+                           'other_variants': exchange_other,
+                           'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '
+                                   'reduce-scatter(d/d(state)) + all-reduce(weight gradients); forward = one '
+                                   'all-gather of the (p,v,a) records, issued eagerly around the captured compute; overlap = the '
+                                   'all-gather is started, the own-block part of the step (weight pack, local half of '
+                                   'the neighbour search, obstacle branch) replayed under it, then the rest'}
+    if same_scene_1gpu is not None:
+        out['single_gpu_same_scene'] = same_scene_1gpu
+    if secondary is not None:
+        out['secondary'] = secondary
+    if rank == 0 and args.cpu_seconds > 0 and world == 1:
+        try:
+            out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)
+        except Exception as ex:   # noqa: BLE001 - e.g. no C compiler for the oracle on this host
+            out['cpu_baseline'] = {'error': f'{type(ex).__name__}: {ex}'}
+    elif world > 1:
+        out['cpu_baseline'] = None
+    write_line()
     if use_dist:
         dist.destroy_process_group()
 

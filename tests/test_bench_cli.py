@@ -48,7 +48,8 @@ def test_committed_step_counters_are_physical():
     j = json.load(open(path))
     assert j['config'] == {'agents_total': 4096, 'obstacle_points': 2000}
     names = [k['name'] for k in j['all_step_kernels']]
-    for need in ('relfeat_fwd_kernel', 'enc_fwd_kernel', 'enc_bwd_dx_kernel', 'enc_bwd_dw_kernel', 'dec_fwd_kernel'):
+    for need in ('relfeat_fwd_kernel', 'enc_fwd_kernel', 'enc_bwd_dx_kernel', 'enc_bwd_dw_kernel', 'dec_fwd_head_kernel',
+                 'pinnsf_reduce_kernel', 'pinnsf_pack_kernel'):
         assert need in names
     for k in j['all_step_kernels']:
         assert k['us'] > 0 and (k.get('frac') is None or 0 <= k['frac'] <= 1), k
