@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<
 // 4 waves per branch (the chain of 194 MFMAs is cut like dec_fwd_kernel's): wave (ob, kh) computes g_pre2 block kh itself
 // (one MFMA), the partial of g_pre1 block ob over it (16 MFMAs), and after one LDS exchange g_pooled block 2 ob + kh over
 // the complete, masked g_pre1 (32 MFMAs).
-__global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
+__device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
     __shared__ float part[2][2][2][16][64];       // [branch][ob][kh][register][lane]
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
         for (int r = 0; r < 16; ++r) part[b][ob][kh][r][lane] = g1[r];
     }
     __syncthreads();
-    if (!active) return;
+    if (active) {
     float g1c[2][16];
 #pragma unroll
     for (int o2 = 0; o2 < 2; ++o2)
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
                     make_float4(gpool[4 * q], gpool[4 * q + 1], gpool[4 * q + 2], gpool[4 * q + 3]);
         }
     }
+    }
     // desired-force backward (pinnsf_epilogue_bwd_kernel's arithmetic), one lane per agent
     if (wave == 0 && h == 0 && valid && A.g_self && A.self_features) {
         const float dx = sfv[0], dy = sfv[1], v0 = sfv[4], tau = A.tau;
@@ -409,17 +410,16 @@ __global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) {
     }
 }
 
+__global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) { dec_bwd_dx_body(A); }
+
 // ---------------------------------------------------------------------------------------------------------
 // backward, weight gradients (K = agents of the workgroup's slab): dW1 = g_pre1^T pooled (64 x 128),
 // dW2 = g_pre2^T h1 (64 x 64), dW3 = g_pred^T d2 (2 x 64), db = column sums.  8 waves: wave w owns block
 // (w >> 2, w & 3) of dW1; waves 0-3 also block (w >> 1, w & 1) of dW2; waves 4, 5 also column block w & 1 of dW3.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+// (branch b, slab p) for the 8 waves of a workgroup; w = wave index
+__device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, int w, int lane) {
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
-    const int wg0 = b ? A.wg_split : 0;
-    const int p = (int)blockIdx.x - wg0;
     const long long R = J.agents;
     const long long slab = DEC_SLAB;                       // nwg = ceil(agents / DEC_SLAB), see dec_dw_workgroups
     const long long r0 = (long long)p * slab < R ? (long long)p * slab : R;
@@ -474,6 +474,22 @@ __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
         if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;           // waves 0 and 2
         if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
     }
+}
+
+__global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
+    const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    dec_bwd_dw_body(A, b, (int)blockIdx.x - (b ? A.wg_split : 0), w, lane);
+}
+
+// dX chain and weight-gradient partials of a 32-agent tile in ONE launch: the dW slab of a workgroup is exactly the tile
+// whose g_pre2 / g_pre1 it has just written (visible to the whole workgroup after the barrier: one CU, one L1).
+__global__ __launch_bounds__(512) void dec_bwd_kernel(DecArgs A) {
+    dec_bwd_dx_body(A);
+    __threadfence_block();
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
+    for (int b = 0; b < A.nbr; ++b) dec_bwd_dw_body(A, b, (int)blockIdx.x, w, lane);
 }
 
 __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
@@ -705,6 +721,19 @@ int piml::dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* 
     A.g_self = g_self;
     const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
     hipLaunchKernelGGL(dec_bwd_dx_kernel, dim3(tiles), dim3(512), 0, s, A);
+    return hipGetLastError();
+}
+
+int piml::dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features,
+                              float tau, float* g_self, hipStream_t s) {
+    DecArgs A;
+    if (int e = dec_fill_bwd(A, br, nbr, g_pred)) return e;
+    A.self_features = self_features;
+    A.tau = tau;
+    A.g_self = g_self;
+    static_assert(DEC_SLAB == 32, "the dW slab of a workgroup is its dX tile");
+    const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
+    hipLaunchKernelGGL(dec_bwd_kernel, dim3(tiles), dim3(512), 0, s, A);
     return hipGetLastError();
 }
 

@@ -202,13 +202,13 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
 PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, const float* g_pred,
                              const float* self_features, float tau, float* g_self, int flags, void* stream) {
     hipStream_t m = as_stream(stream);
-    PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
     if (!(flags & PIML_FORK)) {
-        PIML_TRY(dec_stage_bwd_dw(dec, nbr, g_pred, false, m));
+        PIML_TRY(dec_stage_bwd_fused(dec, nbr, g_pred, self_features, tau, g_self, m));
         PIML_TRY(enc_stage_bwd_dx(enc, nbr, m));
         PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
         return reduce_all(enc, dec, nbr, m);
     }
+    PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
     Side* S;
     PIML_TRY(side_streams(&S));
     hipStream_t s0 = S->s[0];

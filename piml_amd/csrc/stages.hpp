@@ -25,6 +25,9 @@ int dec_stage_fwd(const piml_decoder_branch* br, int nbr, const float* self_feat
                   hipStream_t s);                                                     // after pack + pool
 int dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features, float tau,
                      float* g_self, hipStream_t s);
+// dX chain + weight-gradient partials (no slot sum) in one launch
+int dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features, float tau,
+                        float* g_self, hipStream_t s);
 int dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s);   // partials (+ slot sum)
 
 int head_stage_pack(const piml_collision_head* h, hipStream_t s);
