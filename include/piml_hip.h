@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 9
+#define PIML_HIP_ABI_VERSION 10
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -467,6 +467,10 @@ typedef struct piml_decoder_branch {
     float* partials;
     float* grads; /* bwd out: piml_decoder_partial_floats() floats, the partial slots summed */
     float* packed;
+    /* per-ROW use of the same network (the bottleneck variants, piml_rowdecoder_*): */
+    float* pred;              /* fwd out (rows, 2): predictor output of every row */
+    const float* g_pred_rows; /* bwd in (rows, 2) */
+    const float* g_d2;        /* bwd in (rows, 64) or NULL: extra gradient on the decoder output (the `decoded` collision head) */
 } piml_decoder_branch;
 
 int piml_decoder_pack_floats(void);
@@ -482,6 +486,18 @@ int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const f
  * + b2), msgs (rows, 128), W1 (64, 128), w2 (1, 64); forward only.  `packed`: piml_collision_head_pack_floats()
  * floats of scratch.
  */
+/*
+ * The bottleneck variants (`pinnsf_bottleneck`, `pinnsf_bm`, src/models/model.py:1062-1221) apply decoder + predictor to
+ * every NEIGHBOUR row and sum the (rows, 2) outputs over the neighbour axis afterwards (:1116-1122).  Same kernels, the
+ * rows in the role of the agents: `msgs` = the (rows, 128) embeddings (read directly, no pooling; `pooled` unused),
+ * `agents` = rows of the branch (the two branches may differ), `pred` / `h1` / `d2` per row; backward: `g_pred_rows`
+ * (+ `g_d2`), `g_pooled` = d/d(embeddings) (rows, 128), weight-gradient partials in piml_rowdecoder_slots(rows) slots per
+ * branch (slabs of a multiple of 32 rows), summed into `grads`.  One launch forward, three backward (dX, dW, slot sum).
+ */
+int piml_rowdecoder_slots(long long rows);
+int piml_rowdecoder_fwd(const piml_decoder_branch* branches, int nbranches, void* stream);
+int piml_rowdecoder_bwd(const piml_decoder_branch* branches, int nbranches, void* stream);
+
 typedef struct piml_collision_head {
     const float* msgs; /* (rows, 128) */
     long long rows;

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -31,7 +31,7 @@ class DecoderBranch(ctypes.Structure):
     _fields_ = [('msgs', _p), ('agents', _ll), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('pooled', _p), ('h1', _p), ('d2', _p), ('g_pre2', _p), ('g_pre1', _p), ('g_pooled', _p),
-                ('partials', _p), ('grads', _p), ('packed', _p)]
+                ('partials', _p), ('grads', _p), ('packed', _p), ('pred', _p), ('g_pred_rows', _p), ('g_d2', _p)]
 
 
 class CollisionHead(ctypes.Structure):
@@ -92,6 +92,9 @@ SIGNATURES = {
     'piml_decoder_workgroups': [_ll],
     'piml_decoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p, _f, _p, _p],
     'piml_decoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _p],
+    'piml_rowdecoder_slots': [_ll],
+    'piml_rowdecoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p],
+    'piml_rowdecoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_collision_head_pack_floats': [],
     'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],
     'piml_pinnsf_streams_init': [],

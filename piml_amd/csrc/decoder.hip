@@ -81,7 +81,9 @@ constexpr int POOL_ROWS = 10;
 // (the inline pooling is bound by the L1 miss rate of a CU) --; each branch then ADDS its acceleration to `acc`, which
 // the caller has zeroed: two float atomic adds onto zero commute exactly (0 + x = x, x + y = y + x), so the result is
 // still deterministic and equal to the unsplit kernel's (p + d) + o.
-template <bool POOL, bool SPLIT = false>
+// ROWS (with SPLIT): the bottleneck variants' per-neighbour-row use -- the input rows are the (rows, 128) embeddings
+// themselves (J.msgs), `agents` = rows of THIS branch, and the predictor output of every row goes to J.pred.
+template <bool POOL, bool SPLIT = false, bool ROWS = false>
 __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, int split_branch = 0) {
     constexpr int NB = SPLIT ? 1 : 2;
     __shared__ float part1[NB][2][2][16][64];      // [branch][ob][kh][register][lane]
@@ -172,7 +174,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
                     pv[bl][q] = make_float4(poolx[bi][2 * kh + bl][4 * q][lane], poolx[bi][2 * kh + bl][4 * q + 1][lane],
                                             poolx[bi][2 * kh + bl][4 * q + 2][lane], poolx[bi][2 * kh + bl][4 * q + 3][lane]);
         } else {
-            const float* base = J.pooled + (valid ? agent : 0) * DH;
+            const float* base = (ROWS ? J.msgs : J.pooled) + (valid ? agent : 0) * DH;
 #pragma unroll
             for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
@@ -257,6 +259,12 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
         if (h == 0) { part3[bi][kh][0][j] = a3[0]; part3[bi][kh][1][j] = a3[1]; }
     }
     __syncthreads();
+    if (ROWS) {
+        if ((wave & 3) == 0 && h == 0 && agent < J.agents)
+            reinterpret_cast<float2*>(J.pred)[agent] = make_float2(part3[0][0][0][j] + part3[0][1][0][j],
+                                                                   part3[0][0][1][j] + part3[0][1][1][j]);
+        return;
+    }
     if (wave == 0 && h == 0 && agent < A.br[0].agents) {
         // sum order (also of the split form): (pedestrian branch + desired force) + obstacle branch
         float ax = part3[0][0][0][j] + part3[0][1][0][j], ay = part3[0][0][1][j] + part3[0][1][1][j];
@@ -290,14 +298,19 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<
 // 4 waves per branch (the chain of 194 MFMAs is cut like dec_fwd_kernel's): wave (ob, kh) computes g_pre2 block kh itself
 // (one MFMA), the partial of g_pre1 block ob over it (16 MFMAs), and after one LDS exchange g_pooled block 2 ob + kh over
 // the complete, masked g_pre1 (32 MFMAs).
-__device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
-    __shared__ float part[2][2][2][16][64];       // [branch][ob][kh][register][lane]
+// ROWS: per-neighbour-row use (see dec_fwd_body): one 4-wave workgroup per (tile, branch), g_pred per row from
+// J.g_pred_rows, optional extra gradient J.g_d2 on the decoder output, no desired-force part.
+template <bool ROWS = false>
+__device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile, int rows_branch = 0) {
+    constexpr int NB = ROWS ? 1 : 2;
+    __shared__ float part[NB][2][2][16][64];       // [branch][ob][kh][register][lane]
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
-    const int b = wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
+    const int b = ROWS ? rows_branch : wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
+    const int bi = ROWS ? 0 : b;
     const bool active = b < A.nbr;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
-    const long long agent = (long long)blockIdx.x * 32 + j;
+    const long long agent = tile * 32 + j;
     const bool valid = active && agent < J.agents;
     const float4* PK = reinterpret_cast<const float4*>(J.packed);
     float2 gp = make_float2(0.f, 0.f);
@@ -306,9 +319,14 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
     if (active) {
         // unconditional, clamped loads (a branch around a load makes the compiler wait for it at the join: three serial
         // round trips at the head of this kernel before the change)
-        gp = reinterpret_cast<const float2*>(A.g_pred)[valid ? agent : 0];
+        gp = reinterpret_cast<const float2*>(ROWS ? J.g_pred_rows : A.g_pred)[valid ? agent : 0];
         if (!valid) gp = make_float2(0.f, 0.f);
-        if (wave == 0 && A.g_self && A.self_features) {        // wave-uniform: the desired-force gradient's inputs
+        float4 gd2[4];
+        if (ROWS && J.g_d2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gd2[q] = *reinterpret_cast<const float4*>(J.g_d2 + (valid ? agent : 0) * DD + dfeat0(kh, q, h));
+        }
+        if (!ROWS && wave == 0 && A.g_self && A.self_features) {        // wave-uniform: the desired-force gradient's inputs
             const float* sp = A.self_features + (valid ? agent : 0) * 7;
             sfv[0] = sp[0]; sfv[1] = sp[1]; sfv[4] = sp[6];
         }
@@ -329,6 +347,13 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { g2[r] = 0.f; g1[r] = 0.f; }
         g2 = dmfma(t3f, bg, g2);
+        if (ROWS && J.g_d2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                g2[4 * q] += valid ? gd2[q].x : 0.f; g2[4 * q + 1] += valid ? gd2[q].y : 0.f;
+                g2[4 * q + 2] += valid ? gd2[q].z : 0.f; g2[4 * q + 3] += valid ? gd2[q].w : 0.f;
+            }
+        }
         if (ob == 0 && valid) {
             float* o = J.g_pre2 + agent * DD;
 #pragma unroll
@@ -344,7 +369,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
             g1 = dmfma(w.w, g2[4 * q + 3], g1);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[b][ob][kh][r][lane] = g1[r];
+        for (int r = 0; r < 16; ++r) part[bi][ob][kh][r][lane] = g1[r];
     }
     __syncthreads();
     if (active) {
@@ -357,7 +382,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
             const float m[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float v = part[b][o2][0][4 * q + u][lane] + part[b][o2][1][4 * q + u][lane];
+                const float v = part[bi][o2][0][4 * q + u][lane] + part[bi][o2][1][4 * q + u][lane];
                 g1c[o2][4 * q + u] = (valid && m[u] > 0.f) ? v : 0.f;
             }
         }
@@ -395,7 +420,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
     }
     }
     // desired-force backward (pinnsf_epilogue_bwd_kernel's arithmetic), one lane per agent
-    if (wave == 0 && h == 0 && valid && A.g_self && A.self_features) {
+    if (!ROWS && wave == 0 && h == 0 && valid && A.g_self && A.self_features) {
         const float dx = sfv[0], dy = sfv[1], v0 = sfv[4], tau = A.tau;
         const float n = norm2(dx, dy);
         const float t = (n == 0.f) ? n + 0.1f : n;
@@ -410,20 +435,23 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A) {
     }
 }
 
-__global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) { dec_bwd_dx_body(A); }
+__global__ __launch_bounds__(512) void dec_bwd_dx_kernel(DecArgs A) { dec_bwd_dx_body<false>(A, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------
 // backward, weight gradients (K = agents of the workgroup's slab): dW1 = g_pre1^T pooled (64 x 128),
 // dW2 = g_pre2^T h1 (64 x 64), dW3 = g_pred^T d2 (2 x 64), db = column sums.  8 waves: wave w owns block
 // (w >> 2, w & 3) of dW1; waves 0-3 also block (w >> 1, w & 1) of dW2; waves 4, 5 also column block w & 1 of dW3.
 // ---------------------------------------------------------------------------------------------------------
-// (branch b, slab p) for the 8 waves of a workgroup; w = wave index
-__device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, int w, int lane) {
+// (branch b, slab p) for the 8 waves of a workgroup; w = wave index.  ROWS: the per-neighbour-row use -- the slab is
+// `slab` rows (a multiple of DEC_SLAB), walked in chunks of DEC_SLAB; the layer-1 input rows are J.msgs, g_pred is per row.
+template <bool ROWS = false>
+__device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, int w, int lane, long long slab = DEC_SLAB) {
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long R = J.agents;
-    const long long slab = DEC_SLAB;                       // nwg = ceil(agents / DEC_SLAB), see dec_dw_workgroups
-    const long long r0 = (long long)p * slab < R ? (long long)p * slab : R;
-    const long long r1 = r0 + slab < R ? r0 + slab : R;
+    const long long s0 = (long long)p * slab < R ? (long long)p * slab : R;
+    const long long s1e = s0 + slab < R ? s0 + slab : R;
+    const float* __restrict__ in1 = ROWS ? J.msgs : J.pooled;
+    const float* __restrict__ gpr = ROWS ? J.g_pred_rows : A.g_pred;
     const int i = lane & 31, h = lane >> 5;
     const int mb1 = w >> 2, nb1 = w & 3, mb2 = (w >> 1) & 1, nb2 = w & 1;
     const bool do2 = w < 4, do3 = w == 4 || w == 5;
@@ -431,9 +459,10 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    // the slab is at most DEC_SLAB agents = DEC_SLAB / 2 k-steps: every load is issued before the first MFMA
+    // a chunk is DEC_SLAB agents = DEC_SLAB / 2 k-steps: every load of the chunk is issued before its first MFMA
     constexpr int U = DEC_SLAB / 2;
-    {
+    for (long long r0 = s0; r0 < s1e || r0 == s0; r0 += DEC_SLAB) {
+        const long long r1 = r0 + DEC_SLAB < s1e ? r0 + DEC_SLAB : s1e;
         float a1[U], b1[U], a2[U], b2[U], a3[U], b3[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -441,10 +470,10 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
             const bool ok = row < r1;
             const long long ro = ok ? row : (r0 < R ? r0 : 0);
             a1[u] = J.g_pre1[ro * DD + 32 * mb1 + i];
-            b1[u] = J.pooled[ro * DH + 32 * nb1 + i];
+            b1[u] = in1[ro * DH + 32 * nb1 + i];
             a2[u] = do2 ? J.g_pre2[ro * DD + 32 * mb2 + i] : 0.f;
             b2[u] = do2 ? J.h1[ro * DD + 32 * nb2 + i] : 0.f;
-            a3[u] = (do3 && i < 2) ? A.g_pred[ro * 2 + i] : 0.f;
+            a3[u] = (do3 && i < 2) ? gpr[ro * 2 + i] : 0.f;
             b3[u] = do3 ? J.d2[ro * DD + 32 * nb2 + i] : 0.f;
         }
 #pragma unroll
@@ -479,17 +508,41 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
 __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
     const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
-    dec_bwd_dw_body(A, b, (int)blockIdx.x - (b ? A.wg_split : 0), w, lane);
+    dec_bwd_dw_body<false>(A, b, (int)blockIdx.x - (b ? A.wg_split : 0), w, lane);
 }
 
 // dX chain and weight-gradient partials of a 32-agent tile in ONE launch: the dW slab of a workgroup is exactly the tile
 // whose g_pre2 / g_pre1 it has just written (visible to the whole workgroup after the barrier: one CU, one L1).
 __global__ __launch_bounds__(512) void dec_bwd_kernel(DecArgs A) {
-    dec_bwd_dx_body(A);
+    dec_bwd_dx_body<false>(A, blockIdx.x);
     __threadfence_block();
     __syncthreads();
     const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
-    for (int b = 0; b < A.nbr; ++b) dec_bwd_dw_body(A, b, (int)blockIdx.x, w, lane);
+    for (int b = 0; b < A.nbr; ++b) dec_bwd_dw_body<false>(A, b, (int)blockIdx.x, w, lane);
+}
+
+// ---- the same network per neighbour ROW (bottleneck variants): (tile, branch) workgroups, branches of different sizes ----
+__global__ __launch_bounds__(256) void rowdec_fwd_kernel(DecArgs A, int tiles0) {
+    const int bx = blockIdx.x;
+    if (bx < tiles0) dec_fwd_body<false, true, true>(A, bx, 0);
+    else dec_fwd_body<false, true, true>(A, bx - tiles0, 1);
+}
+
+__global__ __launch_bounds__(256) void rowdec_bwd_dx_kernel(DecArgs A, int tiles0) {
+    const int bx = blockIdx.x;
+    if (bx < tiles0) dec_bwd_dx_body<true>(A, bx, 0);
+    else dec_bwd_dx_body<true>(A, bx - tiles0, 1);
+}
+
+__global__ __launch_bounds__(512) void rowdec_bwd_dw_kernel(DecArgs A, int slots0, long long slab0, long long slab1) {
+    const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
+    const int b = (int)blockIdx.x >= slots0 ? 1 : 0;
+    dec_bwd_dw_body<true>(A, b, (int)blockIdx.x - (b ? slots0 : 0), w, lane, b ? slab1 : slab0);
+}
+
+__global__ __launch_bounds__(256) void rowdec_reduce_kernel(DecArgs A, int B0, int B1, int lanes) {
+    const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
+    sum_slots_16x16(J.partials, J.grads, blockIdx.y ? B1 : B0, lanes);
 }
 
 __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
@@ -781,6 +834,58 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     hipStream_t s = as_stream(stream);
     if (int e = dec_stage_bwd_dx(br, nbr, g_pred, self_features, tau, g_self, s)) return e;
     return dec_stage_bwd_dw(br, nbr, g_pred, true, s);
+}
+
+// slab of the row-wise dW kernel: a multiple of DEC_SLAB rows, at most 256 slots per branch
+static long long rowdec_slab(long long rows) {
+    long long slab = (rows + 255) / 256;
+    slab = (slab + DEC_SLAB - 1) / DEC_SLAB * DEC_SLAB;
+    return slab < DEC_SLAB ? DEC_SLAB : slab;
+}
+
+PIML_API int piml_rowdecoder_slots(long long rows) {
+    if (rows <= 0) return 0;
+    const long long slab = rowdec_slab(rows);
+    return (int)((rows + slab - 1) / slab);
+}
+
+static int rowdec_fill(DecArgs& A, const piml_decoder_branch* br, int nbr, bool bwd) {
+    if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
+    A = DecArgs{};
+    A.nbr = nbr;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_decoder_branch& b = br[i];
+        if (!dec_branch_ok(b) || !b.h1 || !b.d2) return hipErrorInvalidValue;
+        if (!bwd && !b.pred) return hipErrorInvalidValue;
+        if (bwd && (!b.g_pred_rows || !b.g_pre2 || !b.g_pre1 || !b.g_pooled || !b.partials || !b.grads)) return hipErrorInvalidValue;
+        A.br[i] = b;
+    }
+    if (nbr == 1) A.br[1] = br[0];
+    return hipSuccess;
+}
+
+PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) {
+    hipStream_t s = as_stream(stream);
+    DecArgs A;
+    if (int e = rowdec_fill(A, br, nbr, false)) return e;
+    if (int e = dec_stage_pack(br, nbr, s)) return e;
+    const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
+    hipLaunchKernelGGL(rowdec_fwd_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
+    return hipGetLastError();
+}
+
+PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* stream) {
+    hipStream_t s = as_stream(stream);
+    DecArgs A;
+    if (int e = rowdec_fill(A, br, nbr, true)) return e;
+    const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
+    hipLaunchKernelGGL(rowdec_bwd_dx_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
+    const int slots0 = piml_rowdecoder_slots(br[0].agents), slots1 = nbr > 1 ? piml_rowdecoder_slots(br[1].agents) : 0;
+    hipLaunchKernelGGL(rowdec_bwd_dw_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 0, s, A, slots0,
+                       rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
+    hipLaunchKernelGGL(rowdec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, slots0, slots1,
+                       DEC_PART / 4);
+    return hipGetLastError();
 }
 
 PIML_API int piml_collision_head_pack_floats(void) { return HEAD_PACK; }

@@ -38,6 +38,8 @@ FUSED_ENCODER_MIN_ROWS = int(os.environ.get('PIML_FUSED_ENCODER_MIN_ROWS', '512'
 # ... and for `pinnsf` / `pinnsf_m` the decoder tail too (piml_amd/csrc/decoder.hip): the whole network is one autograd
 # node (ops.fused_pinnsf).  PIML_FUSED_NETWORK=0 keeps the decoders / predictors on library GEMMs.
 FUSED_NETWORK = os.environ.get('PIML_FUSED_NETWORK', '1') != '0'
+# bottleneck variants: decoder + predictor per neighbour row on the fused kernels (PIML_FUSED_ROW_DECODER=0: library GEMMs)
+FUSED_ROW_DECODER = os.environ.get('PIML_FUSED_ROW_DECODER', '1') != '0'
 PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
 
 
@@ -245,12 +247,42 @@ class _PINNSFBase(nn.Module):
                                   for _, f, e, p in use])
         return {c[0]: r for c, r in zip(use, res)}
 
-    def _branch(self, feats, encoder, processor, decoder, predictor, pre=None):
-        """`pre` = (processor(encoder(feats)), its neighbour-axis sum) when the fused encoder kernel produced them."""
+    def _fused_row_decoders(self, pre):
+        """Bottleneck variants: decoder + predictor per neighbour row on the fused kernels (ops.fused_row_decoder), for the
+        branches whose embeddings the fused encoder produced -- both in one launch.  {} when not applicable."""
+        if not (self.bottleneck and pre and FUSED_ROW_DECODER):
+            return {}
+        names, brs = [], []
+        for name, d, q in (('ped', self.ped_decoder, self.ped_predictor),
+                           ('obs', getattr(self, 'obs_decoder', None), getattr(self, 'obs_predictor', None))):
+            if name not in pre or d is None:
+                continue
+            emb = pre[name][0]
+            dl, da = d.mlp[0::2], d.mlp[1::2]
+            ok = (emb.is_cuda and emb.dtype == torch.float32 and emb.shape[-1] == 128 and len(dl) == 2
+                  and (dl[0].in_features, dl[0].out_features, dl[1].in_features, dl[1].out_features) == (128, 64, 64, 64)
+                  and isinstance(da[0], nn.ReLU) and isinstance(da[1], nn.Identity) and len(q.mlp) == 2
+                  and (q.mlp[0].in_features, q.mlp[0].out_features) == (64, 2) and isinstance(q.mlp[1], nn.Identity)
+                  and emb.numel() // 128 >= FUSED_ENCODER_MIN_ROWS)
+            if ok:
+                names.append(name)
+                brs.append(dict(emb=emb, decoder=[t for lin in dl for t in (lin.weight, lin.bias)],
+                                predictor=[q.mlp[0].weight, q.mlp[0].bias]))
+        if not brs:
+            return {}
+        from .. import ops
+        return dict(zip(names, ops.fused_row_decoder(brs)))
+
+    def _branch(self, feats, encoder, processor, decoder, predictor, pre=None, rowdec=None):
+        """`pre` = (processor(encoder(feats)), its neighbour-axis sum) when the fused encoder kernel produced them;
+        `rowdec` = (predictor(decoder(emb)), decoder(emb)) when the fused row decoder did."""
         if self.bottleneck:
             emb = pre[0] if pre is not None else processor(encoder(feats))
-            decoded = decoder(emb)
-            msgs = predictor(decoded)
+            if rowdec is not None:
+                msgs, decoded = rowdec
+            else:
+                decoded = decoder(emb)
+                msgs = predictor(decoded)
             return msgs.sum(dim=-2), msgs, decoded, emb
         emb, pooled = pre if pre is not None else self._encode_process_pool(feats, encoder, processor)
         acc = predictor(decoder(pooled))
@@ -352,6 +384,7 @@ class _PINNSFBase(nn.Module):
         if fused is not None:
             return fused
         pre = {} if self.residual else self._fused_encoders(ped_features, obs_features)
+        rowdec = self._fused_row_decoders(pre)
         # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
         side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None
         acc_o = None
@@ -368,7 +401,8 @@ class _PINNSFBase(nn.Module):
             decoded = None
         else:
             acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
-                                                       self.ped_decoder, self.ped_predictor, pre=pre.get('ped'))
+                                                       self.ped_decoder, self.ped_predictor, pre=pre.get('ped'),
+                                                       rowdec=rowdec.get('ped'))
         out_obs = None
         if self.obs_feature_dim > 0:
             if side is not None:                                 # join
@@ -376,7 +410,8 @@ class _PINNSFBase(nn.Module):
                 out_obs = out_obs_side
             else:
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
-                                                    self.obs_decoder, self.obs_predictor, pre=pre.get('obs'))
+                                                    self.obs_decoder, self.obs_predictor, pre=pre.get('obs'),
+                                                    rowdec=rowdec.get('obs'))
         if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
                 and (self_features.dim() in (2, 3) or self.fix_dest_norm):
             from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)

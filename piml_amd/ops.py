@@ -1636,6 +1636,113 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
     return out[0], list(out[1:])
 
 
+class _FusedRowDecoder(torch.autograd.Function):
+    """inputs: nbr, then per branch emb (..., 128), decoder w1 (64,128) b1 w2 (64,64) b2, predictor w (2,64) b  (7 tensors).
+    outputs per branch: pred (..., 2), decoded (..., 64)."""
+    PER = 7
+
+    @staticmethod
+    def forward(ctx, nbr, *tensors):
+        L = _lib.lib()
+        PER = _FusedRowDecoder.PER
+        embs = [_gpu_f32('embedding', tensors[PER * b]) for b in range(nbr)]
+        wbs = [[_gpu_f32('decoder weight', t.detach()) for t in tensors[PER * b + 1:PER * b + 7]] for b in range(nbr)]
+        dev = embs[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        need_grad = any(ctx.needs_input_grad)
+        e2 = [e.reshape(-1, ENCODER_HIDDEN) for e in embs]
+        rows = [e.shape[0] for e in e2]
+        dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+        preds = [torch.empty(r, 2, **opt) for r in rows]
+        h1 = [torch.empty(r, 64, **opt) for r in rows]
+        d2 = [torch.empty(r, 64, **opt) for r in rows]
+        structs = []
+        for b in range(nbr):
+            B = _dec_branch_struct(e2[b], rows[b], 1, wbs[b], dpack[b], None, h1[b], d2[b])
+            B.pred = preds[b].data_ptr()
+            structs.append(B)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_rowdecoder_fwd((_lib.DecoderBranch * nbr)(*structs), nbr, _stream()), 'piml_rowdecoder_fwd')
+        if need_grad:
+            ctx.save_for_backward(*e2, *h1, *d2, *[w for wb in wbs for w in wb], dpack)
+        ctx.meta = (nbr, rows, [tuple(e.shape) for e in embs], need_grad)
+        ctx.set_materialize_grads(False)
+        out = []
+        for b in range(nbr):
+            lead = tuple(embs[b].shape[:-1])
+            out += [preds[b].view(*lead, 2), d2[b].view(*lead, 64)]
+        return tuple(out)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        nbr, rows, eshapes, need_grad = ctx.meta
+        PER = _FusedRowDecoder.PER
+        grads = [None] * (1 + PER * nbr)
+        live = [b for b in range(nbr) if gs[2 * b] is not None or gs[2 * b + 1] is not None]
+        if not need_grad or not live:
+            return tuple(grads)
+        L = _lib.lib()
+        sv = list(ctx.saved_tensors)
+        take = lambda n: [sv.pop(0) for _ in range(n)]
+        e2, h1, d2 = take(nbr), take(nbr), take(nbr)
+        wbs = [take(6) for _ in range(nbr)]
+        dpack = sv.pop(0)
+        dev = e2[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        H = ENCODER_HIDDEN
+        structs, keep, flats, gembs = [], [], [], []
+        for b in live:
+            R = rows[b]
+            gp = _gpu_f32('g_pred', gs[2 * b]).reshape(R, 2) if gs[2 * b] is not None else torch.zeros(R, 2, **opt)
+            gd = _gpu_f32('g_decoded', gs[2 * b + 1]).reshape(R, 64) if gs[2 * b + 1] is not None else None
+            gp2, gp1, gemb = torch.empty(R, 64, **opt), torch.empty(R, 64, **opt), torch.empty(R, H, **opt)
+            parts = torch.empty(L.piml_rowdecoder_slots(R), L.piml_decoder_partial_floats(), **opt)
+            flat = torch.empty(L.piml_decoder_partial_floats(), **opt)
+            B = _dec_branch_struct(e2[b], R, 1, wbs[b], dpack[b], None, h1[b], d2[b], gp2, gp1, gemb, parts, flat)
+            B.g_pred_rows, B.g_d2 = gp.data_ptr(), _ptr(gd)
+            structs.append(B)
+            keep += [gp, gd, gp2, gp1, parts]
+            flats.append(flat)
+            gembs.append(gemb)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_rowdecoder_bwd((_lib.DecoderBranch * len(live))(*structs), len(live), _stream()),
+                       'piml_rowdecoder_bwd')
+        for i, b in enumerate(live):
+            o = 1 + PER * b
+            if ctx.needs_input_grad[o]:
+                grads[o] = gembs[i].view(eshapes[b])
+            flat = flats[i]
+            dW1, dW2 = flat[:64 * H].view(64, H), flat[64 * H:64 * H + 4096].view(64, 64)
+            dW3 = flat[64 * H + 4096:64 * H + 4096 + 128].view(2, 64)
+            rest = flat[64 * H + 4096 + 128:]
+            for jx, t in enumerate((dW1, rest[:64], dW2, rest[64:128], dW3, rest[128:130])):
+                if ctx.needs_input_grad[o + 1 + jx]:
+                    grads[o + 1 + jx] = t
+        return tuple(grads)
+
+
+def fused_row_decoder(branches):
+    """Decoder + predictor of the bottleneck PINNSF variants applied to every neighbour ROW on the fused MFMA kernels
+    (src/models/model.py:1116-1122: `ped_msgs = self.ped_predictor(self.ped_decoder(ped_embeddings))`).
+    branches: 1 or 2 dicts {emb (..., 128), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b)}.
+    Returns per branch (pred (..., 2), decoded (..., 64)); the caller sums pred over the neighbour axis."""
+    if not 1 <= len(branches) <= 2:
+        raise ValueError('fused_row_decoder: one or two branches')
+    flat = []
+    for br in branches:
+        e, d, p = br['emb'], br['decoder'], br['predictor']
+        if not e.is_cuda:
+            raise _lib.PimlHipError('fused_row_decoder: expected GPU tensors (piml_amd has no CPU path)')
+        if e.shape[-1] != ENCODER_HIDDEN or e.numel() == 0 or \
+                [tuple(t.shape) for t in d] != [(64, ENCODER_HIDDEN), (64,), (64, 64), (64,)] or \
+                [tuple(t.shape) for t in p] != [(2, 64), (2,)]:
+            raise ValueError('fused_row_decoder: unsupported geometry (128 -> 64 -> 64, predictor 64 -> 2)')
+        flat += [e, *d, *p]
+    out = _FusedRowDecoder.apply(len(branches), *flat)
+    return [(out[2 * b], out[2 * b + 1]) for b in range(len(branches))]
+
+
 class _CollisionHead(torch.autograd.Function):
     """sigmoid(MLP(128, [64, 1])(msgs)) per neighbour row: forward on the fused MFMA kernel, backward (rare: the
     reference trains this head for `pinnsf_bm` only) recomputed with torch ops."""

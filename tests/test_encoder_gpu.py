@@ -276,3 +276,84 @@ def test_prepacked_network_in_a_captured_graph():
             assert torch.equal(a, b)
         for p, gsave in zip(params, saved):
             p.grad = gsave
+
+
+@pytest.mark.parametrize('rows', [(24576, 40960), (700, 33), (64, 2048)])
+def test_fused_row_decoder_matches_float64(rows):
+    """ops.fused_row_decoder (decoder + predictor of the bottleneck variants per neighbour row: the decoder kernels with
+    the rows in the role of the agents, two branches of different sizes in one launch) against the float64 expression:
+    both outputs, and the gradients for upstream gradients on the predictions AND on the decoder output (the `decoded`
+    collision head of pinnsf_bm), incl. ragged last tiles and multi-chunk dW slabs."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(11)
+    brs, refs = [], []
+    for r in rows:
+        emb = (torch.randn(r, 128, generator=g) * 0.7).to(DEV).requires_grad_(True)
+        ws = [(torch.randn(*shp, generator=g) * 0.15).to(DEV).requires_grad_(True)
+              for shp in ((64, 128), (64,), (64, 64), (64,), (2, 64), (2,))]
+        brs.append(dict(emb=emb, decoder=ws[:4], predictor=ws[4:]))
+    outs = ops.fused_row_decoder(brs)
+    gp = [torch.randn(r, 2, generator=g).to(DEV) for r in rows]
+    gd = [torch.randn(r, 64, generator=g).to(DEV) * 0.1 for r in rows]
+    loss = sum((o[0] * a).sum() + (o[1] * b).sum() for o, a, b in zip(outs, gp, gd))
+    leaves = [t for br in brs for t in (br['emb'], *br['decoder'], *br['predictor'])]
+    grads = torch.autograd.grad(loss, leaves)
+    # float64 reference
+    ref_out, ref_leaves = [], []
+    for br in brs:
+        e, (w1, b1, w2, b2), (wp, bp) = [t.detach().double().requires_grad_(True) for t in (br['emb'],)][0], \
+            [t.detach().double().requires_grad_(True) for t in br['decoder']], \
+            [t.detach().double().requires_grad_(True) for t in br['predictor']]
+        d = torch.relu(e @ w1.t() + b1) @ w2.t() + b2
+        ref_out.append((d @ wp.t() + bp, d))
+        ref_leaves += [e, w1, b1, w2, b2, wp, bp]
+    ref_loss = sum((o[0] * a.double()).sum() + (o[1] * b.double()).sum() for o, a, b in zip(ref_out, gp, gd))
+    ref_grads = torch.autograd.grad(ref_loss, ref_leaves)
+    worst = 0.0
+    for o, ro in zip(outs, ref_out):
+        for a, b in zip(o, ro):
+            worst = max(worst, float((a.double() - b).abs().max() / b.abs().max()))
+    for a, b in zip(grads, ref_grads):
+        worst = max(worst, float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)))
+    print(f'fused_row_decoder rows {rows}: max rel err vs float64 {worst:.1e}')
+    assert worst <= 2e-5
+    # deterministic
+    outs2 = ops.fused_row_decoder(brs)
+    grads2 = torch.autograd.grad(sum((o[0] * a).sum() + (o[1] * b).sum() for o, a, b in zip(outs2, gp, gd)), leaves)
+    for a, b in zip(grads, grads2):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name', ['PINNSF_bottleneck_multitask', 'PINNSF_bottleneck'])
+def test_bottleneck_models_with_fused_row_decoder_match_library_decoders(name):
+    """The bottleneck models on the fused row decoder vs the same models with their decoders on library GEMMs
+    (PIML_FUSED_ROW_DECODER=0): every output and gradient."""
+    import types
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16,
+        decoder_hidden_layers=2, dropout=0.5, activation='relu', dataset_name='gc1560')
+    torch.manual_seed(0)
+    net = getattr(MODEL, name)(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(2)
+    base = [torch.randn(600, 6, 6, generator=g).to(DEV), torch.randn(600, 10, 6, generator=g).to(DEV),
+            torch.randn(600, 7, generator=g).to(DEV)]
+    res = {}
+    try:
+        for fused in (True, False):
+            MODEL.FUSED_ROW_DECODER = fused
+            ins = [t.clone().requires_grad_(True) for t in base]
+            net.zero_grad(set_to_none=True)
+            out = net(*ins)
+            (out[0].square().sum() + out[1].sum() * 1e-2 + out[2].square().sum() * 1e-3 + out[-1].sum()).backward()
+            res[fused] = [o.detach() for o in out] + [t.grad for t in ins] + \
+                [p.grad for p in net.parameters() if p.grad is not None]
+    finally:
+        MODEL.FUSED_ROW_DECODER = True
+    assert len(res[True]) == len(res[False])
+    worst = 0.0
+    for a, b in zip(res[True], res[False]):
+        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
+    print(f'{name}: fused row decoder vs library decoders, max rel err {worst:.1e}')
+    assert worst <= 2e-5

@@ -1,0 +1,27 @@
+"""Forward + backward step of every PINNSF variant at the bench shape (4096 agents, k = 6 / 10), captured graph."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import piml_amd.models.model as MODEL
+from piml_amd.scenes import synthetic_gc_scene
+
+dev = torch.device('cuda:0')
+N, M = 4096, 2000
+scene = synthetic_gc_scene(N, M, seed=0)
+for name in ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNSF_bottleneck'):
+    cls = getattr(MODEL, name)
+    orig = MODEL.PINNSF_multitask
+    MODEL.PINNSF_multitask = cls
+    try:
+        st = bench.Step(scene, N, N, 0, M, dev, None, False, False, True)
+        st.capture()
+        for _ in range(20):
+            st.run()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(200):
+            st.run()
+        torch.cuda.synchronize()
+        print(f'{name:32s} {st.mode}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step')
+    finally:
+        MODEL.PINNSF_multitask = orig
