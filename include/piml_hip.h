@@ -305,6 +305,16 @@ int piml_pinnsf_epilogue_fwd(const float* acc_ped, const float* acc_obs, const f
 int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_features, size_t rows, float tau,
                              float* g_self, void* stream);
 /*
+ * The same tail for the bottleneck variants (src/models/model.py:1116-1134): predictions = sum over the neighbour axis of
+ * the per-row predictor outputs pred_ped (rows, kp, 2) [+ pred_obs (rows, ko, 2), may be NULL] + the desired-force term;
+ * backward: g_self (may be NULL) and the upstream gradient broadcast to every neighbour row (either may be NULL).
+ */
+int piml_pinnsf_epilogue_ksum_fwd(const float* pred_ped, int kp, const float* pred_obs, int ko, const float* self_features,
+                                  size_t rows, float tau, float* out, void* stream);
+int piml_pinnsf_epilogue_ksum_bwd(const float* g_out, const float* self_features, size_t rows, float tau, int kp, int ko,
+                                  float* g_self, float* g_pred_ped, float* g_pred_obs, void* stream);
+
+/*
  * The same tail for channelled (C, N, 7) input with the reference's literal `dim=1` norm (quirk Q2): the
  * norm of each destination component is taken over the N AGENTS of slice c,
  * t[c, comp] = || self_features[c, :, comp] ||_2 (+0.1 where 0), as src/models/model.py:1290 computes it in

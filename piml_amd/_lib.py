@@ -63,6 +63,8 @@ SIGNATURES = {
     'piml_train_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_bwd': [_p, _p, _z, _f, _p, _p],
+    'piml_pinnsf_epilogue_ksum_fwd': [_p, _i, _p, _i, _p, _z, _f, _p, _p],
+    'piml_pinnsf_epilogue_ksum_bwd': [_p, _p, _z, _f, _i, _i, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_agentnorm_fwd': [_p, _p, _p, _i, _i, _f, _p, _p],
     'piml_pinnsf_epilogue_agentnorm_bwd': [_p, _p, _i, _i, _f, _p, _p],
     'piml_self_features_fwd': [_p, _i, _p, _p, _z, _p, _p],

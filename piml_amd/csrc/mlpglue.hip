@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* 
     o[6] = (g.x * ex + g.y * ey) / tau;
 }
 
+// Bottleneck variants: predictions = sum_k pred_ped[a, k] + sum_k pred_obs[a, k] + desired force (one thread per agent;
+// the per-neighbour predictor outputs are summed here instead of by two torch reductions), and its backward: the same
+// upstream gradient broadcast to every neighbour row of the agent + g_self.
+__global__ __launch_bounds__(256) void pinnsf_epilogue_ksum_fwd_kernel(const float2* __restrict__ pred_ped, int kp,
+                                                                        const float2* __restrict__ pred_obs, int ko,
+                                                                        const float* __restrict__ sf, size_t rows, float tau,
+                                                                        float2* __restrict__ out) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* s = sf + r * 7;
+    const float dx = s[0], dy = s[1], vx = s[2], vy = s[3], v0 = s[6];
+    float t = norm2(dx, dy);
+    t = (t == 0.f) ? t + 0.1f : t;
+    float2 a = make_float2(0.f, 0.f), o = make_float2(0.f, 0.f);
+    for (int i = 0; i < kp; ++i) { const float2 v = pred_ped[r * kp + i]; a.x += v.x; a.y += v.y; }
+    if (pred_obs) {
+        for (int i = 0; i < ko; ++i) { const float2 v = pred_obs[r * ko + i]; o.x += v.x; o.y += v.y; }
+        a.x += o.x;
+        a.y += o.y;
+    }
+    out[r] = make_float2(a.x + (v0 * (dx / t) - vx) / tau, a.y + (v0 * (dy / t) - vy) / tau);
+}
+
+__global__ __launch_bounds__(256) void pinnsf_epilogue_ksum_bwd_kernel(const float2* __restrict__ g_out, size_t rows, int kp,
+                                                                        int ko, float2* __restrict__ g_ped,
+                                                                        float2* __restrict__ g_obs) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float2 g = g_out[r];
+    if (g_ped) for (int i = 0; i < kp; ++i) g_ped[r * kp + i] = g;
+    if (g_obs) for (int i = 0; i < ko; ++i) g_obs[r * ko + i] = g;
+}
+
 // The same tail for channelled (C, N, 7) input with the reference's dim=1 norm (quirk Q2,
 // src/models/model.py:1290): t[c, comp] = || d[c, :, comp] ||_2 over the AGENTS of slice c, per component.
 // One workgroup per slice: block reductions for the two norms (and, backward, for sum_n g_e d).
@@ -449,6 +482,31 @@ PIML_API int piml_pinnsf_epilogue_bwd(const float* g_out, const float* self_feat
     if (!g_out || !self_features || !g_self) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pinnsf_epilogue_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(g_out), self_features, rows, tau, g_self);
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_epilogue_ksum_fwd(const float* pred_ped, int kp, const float* pred_obs, int ko,
+                                           const float* self_features, size_t rows, float tau, float* out, void* stream) {
+    if (rows == 0) return hipSuccess;
+    if (!pred_ped || !self_features || !out || kp < 1 || (pred_obs && ko < 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_ksum_fwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(pred_ped), kp, reinterpret_cast<const float2*>(pred_obs), ko,
+                       self_features, rows, tau, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+// g_out (rows, 2) -> g_self (rows, 7) (may be NULL) and the broadcasts g_pred_ped (rows, kp, 2), g_pred_obs (rows, ko, 2)
+PIML_API int piml_pinnsf_epilogue_ksum_bwd(const float* g_out, const float* self_features, size_t rows, float tau, int kp,
+                                           int ko, float* g_self, float* g_pred_ped, float* g_pred_obs, void* stream) {
+    if (rows == 0) return hipSuccess;
+    if (!g_out || !self_features) return hipErrorInvalidValue;
+    if (g_self)
+        hipLaunchKernelGGL(pinnsf_epilogue_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float2*>(g_out), self_features, rows, tau, g_self);
+    if (g_pred_ped || g_pred_obs)
+        hipLaunchKernelGGL(pinnsf_epilogue_ksum_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float2*>(g_out), rows, kp, ko, reinterpret_cast<float2*>(g_pred_ped),
+                           reinterpret_cast<float2*>(g_pred_obs));
     return hipGetLastError();
 }
 

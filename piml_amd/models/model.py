@@ -40,6 +40,8 @@ FUSED_ENCODER_MIN_ROWS = int(os.environ.get('PIML_FUSED_ENCODER_MIN_ROWS', '512'
 FUSED_NETWORK = os.environ.get('PIML_FUSED_NETWORK', '1') != '0'
 # bottleneck variants: decoder + predictor per neighbour row on the fused kernels (PIML_FUSED_ROW_DECODER=0: library GEMMs)
 FUSED_ROW_DECODER = os.environ.get('PIML_FUSED_ROW_DECODER', '1') != '0'
+# ... and their neighbour-axis sums + desired-force term in one launch (PIML_FUSED_KSUM_TAIL=0: torch .sum + the plain epilogue)
+FUSED_KSUM_TAIL = os.environ.get('PIML_FUSED_KSUM_TAIL', '1') != '0'
 PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
 
 
@@ -273,9 +275,10 @@ class _PINNSFBase(nn.Module):
         from .. import ops
         return dict(zip(names, ops.fused_row_decoder(brs)))
 
-    def _branch(self, feats, encoder, processor, decoder, predictor, pre=None, rowdec=None):
+    def _branch(self, feats, encoder, processor, decoder, predictor, pre=None, rowdec=None, want_sum=True):
         """`pre` = (processor(encoder(feats)), its neighbour-axis sum) when the fused encoder kernel produced them;
-        `rowdec` = (predictor(decoder(emb)), decoder(emb)) when the fused row decoder did."""
+        `rowdec` = (predictor(decoder(emb)), decoder(emb)) when the fused row decoder did; want_sum=False: the caller
+        sums the per-neighbour outputs itself (ops.pinnsf_epilogue_ksum)."""
         if self.bottleneck:
             emb = pre[0] if pre is not None else processor(encoder(feats))
             if rowdec is not None:
@@ -283,7 +286,7 @@ class _PINNSFBase(nn.Module):
             else:
                 decoded = decoder(emb)
                 msgs = predictor(decoded)
-            return msgs.sum(dim=-2), msgs, decoded, emb
+            return (msgs.sum(dim=-2) if want_sum else None), msgs, decoded, emb
         emb, pooled = pre if pre is not None else self._encode_process_pool(feats, encoder, processor)
         acc = predictor(decoder(pooled))
         return acc, emb, None, emb
@@ -387,6 +390,9 @@ class _PINNSFBase(nn.Module):
         rowdec = self._fused_row_decoders(pre)
         # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
         side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None
+        # bottleneck variants with a per-row |dest|: neighbour-axis sums + desired force in one launch (ops.pinnsf_epilogue_ksum)
+        ksum_tail = (self.bottleneck and FUSED_GLUE and FUSED_KSUM_TAIL and not self.residual and side is None and self_features.is_cuda
+                     and self_features.dtype == torch.float32 and (self_features.dim() == 2 or self.fix_dest_norm))
         acc_o = None
         if self.obs_feature_dim > 0 and side is not None:      # fork: obstacle branch on the side stream
             side.wait_stream(torch.cuda.current_stream())
@@ -402,7 +408,7 @@ class _PINNSFBase(nn.Module):
         else:
             acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
                                                        self.ped_decoder, self.ped_predictor, pre=pre.get('ped'),
-                                                       rowdec=rowdec.get('ped'))
+                                                       rowdec=rowdec.get('ped'), want_sum=not ksum_tail)
         out_obs = None
         if self.obs_feature_dim > 0:
             if side is not None:                                 # join
@@ -411,8 +417,11 @@ class _PINNSFBase(nn.Module):
             else:
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
                                                     self.obs_decoder, self.obs_predictor, pre=pre.get('obs'),
-                                                    rowdec=rowdec.get('obs'))
-        if FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
+                                                    rowdec=rowdec.get('obs'), want_sum=not ksum_tail)
+        if ksum_tail:
+            from .. import ops
+            predictions = ops.pinnsf_epilogue_ksum(ped_msgs, out_obs, self_features, self.tau)
+        elif FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
                 and (self_features.dim() in (2, 3) or self.fix_dest_norm):
             from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)
             quirk = self_features.dim() == 3 and not self.fix_dest_norm

@@ -652,6 +652,53 @@ class _PinnsfEpilogue(torch.autograd.Function):
         return g, (g if ctx.has_obs else None), g_self, None, None
 
 
+class _PinnsfEpilogueKsum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_ped, pred_obs, self_features, tau):
+        sf = _gpu_f32('self_features', self_features)
+        pp = _gpu_f32('pred_ped', pred_ped)
+        po = _gpu_f32('pred_obs', pred_obs) if pred_obs is not None else None
+        rows = sf.numel() // 7
+        kp, ko = pp.shape[-2], (po.shape[-2] if po is not None else 0)
+        out = torch.empty(*sf.shape[:-1], 2, device=sf.device, dtype=torch.float32)
+        with torch.cuda.device(sf.device):
+            _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_fwd(_ptr(pp), kp, _ptr(po), ko, _ptr(sf), rows, float(tau),
+                                                                _ptr(out), _stream()), 'piml_pinnsf_epilogue_ksum_fwd')
+        ctx.save_for_backward(sf)
+        ctx.meta = (float(tau), kp, ko, tuple(pp.shape), tuple(po.shape) if po is not None else None)
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 4
+        (sf,) = ctx.saved_tensors
+        tau, kp, ko, shp_p, shp_o = ctx.meta
+        g = g.contiguous()
+        opt = dict(device=sf.device, dtype=torch.float32)
+        g_self = torch.empty_like(sf) if ctx.needs_input_grad[2] else None
+        g_pp = torch.empty(shp_p, **opt) if ctx.needs_input_grad[0] else None
+        g_po = torch.empty(shp_o, **opt) if (shp_o is not None and ctx.needs_input_grad[1]) else None
+        with torch.cuda.device(sf.device):
+            _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, tau, kp, ko, _ptr(g_self),
+                                                                _ptr(g_pp), _ptr(g_po), _stream()),
+                       'piml_pinnsf_epilogue_ksum_bwd')
+        return g_pp, g_po, g_self, None
+
+
+def pinnsf_epilogue_ksum(pred_ped, pred_obs, self_features, tau):
+    """Bottleneck variants: sum over the neighbour axis of pred_ped (..., kp, 2) [+ pred_obs (..., ko, 2) or None] + the
+    desired-force term of self_features (..., 7), per-row |dest| (src/models/model.py:1116-1134) -- one launch per direction
+    instead of two reductions, two broadcasts and the epilogue."""
+    if self_features.shape[-1] != 7 or tuple(pred_ped.shape[:-2]) != tuple(self_features.shape[:-1]) or pred_ped.shape[-1] != 2:
+        raise ValueError('pinnsf_epilogue_ksum: pred (..., k, 2) and self_features (..., 7) expected')
+    if pred_obs is not None and (tuple(pred_obs.shape[:-2]) != tuple(self_features.shape[:-1]) or pred_obs.shape[-1] != 2):
+        raise ValueError('pinnsf_epilogue_ksum: pred_obs (..., k, 2) must match self_features')
+    return _PinnsfEpilogueKsum.apply(pred_ped, pred_obs, self_features, tau)
+
+
 def pinnsf_epilogue(acc_ped, acc_obs, self_features, tau, agent_norm=False):
     """acc_ped + acc_obs + (v0 * dest/|dest| - v) / tau on rows of self_features (..., 7)
     (src/models/model.py:1289-1294); acc_obs may be None.  agent_norm=False: the per-row norm |dest|.

@@ -61,8 +61,9 @@ COMMON = ['-f', '--device', 'cuda:0', '--model', 'pinnsf_bm', '--dropout', '0.0'
 #     (tools/debug_ucy_diverge.py): a hidden unit that was dead so far gets a pre-activation within an ulp of zero, one
 #     implementation rounds it to +0, the other to a tiny positive value, and Adam turns the first non-zero gradient of
 #     the unit's 128 weights -- whatever its size -- into a full lr-sized step.  The library-GEMM path happens to round
-#     like the reference's CPU GEMM and follows its trajectory to 1e-6 (run this test with PIML_FUSED_ENCODER=0
-#     PIML_FUSED_NETWORK=0: every line below <= 1e-5); the fused kernels (bias as the accumulator's initial value, MFMA
+#     like the reference's CPU GEMM and follows its trajectory to 1e-6 (PIML_FUSED_ENCODER=0 PIML_FUSED_NETWORK=0
+#     PIML_FUSED_ROW_DECODER=0 PIML_FUSED_KSUM_TAIL=0: every line below <= 1e-5; even summing the neighbour axis in a
+#     different order than torch.sum moves the final metrics by 3e-2); the fused kernels (bias as the accumulator's initial value, MFMA
 #     summation order) do not.  `spread_*` prints the distance between the two paths on every run.  Three builds of
 #     round 2 (different MFMA / VALU summation orders) gave for (pre_val, weights, worst metric, collisions):
 #     (1.2e-3, 1.6e-3, 1.2e-3, 7e-3), (2.5e-3, 3e-3, 4e-3, 7e-3), (3.1e-3, 4.1e-3, 1.0e-2, 2.0e-2); the bounds are ~3x
@@ -176,12 +177,12 @@ def test_main_flow_matches_reference_end_to_end(case):
         import piml_amd.models.model as MODEL
         first = dict(mse=ev[1], mae=ev[2], ot=ev[3], mmd=ev[4], fde=sim.last_eval['fde'],
                      val=val_got.copy(), pre_val=np.array([h['val_loss'] for h in pre]))
-        old_flags = (MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK)
-        MODEL.FUSED_ENCODER = MODEL.FUSED_NETWORK = False
+        old_flags = (MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK, MODEL.FUSED_ROW_DECODER, MODEL.FUSED_KSUM_TAIL)
+        MODEL.FUSED_ENCODER = MODEL.FUSED_NETWORK = MODEL.FUSED_ROW_DECODER = MODEL.FUSED_KSUM_TAIL = False
         try:
             MAIN.main(argv, init_state=init)
         finally:
-            MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK = old_flags
+            MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK, MODEL.FUSED_ROW_DECODER, MODEL.FUSED_KSUM_TAIL = old_flags
         sim2 = MAIN.LAST_RUN['simulator']
         ev2 = sim2.finetune_test_result
         report['spread_metrics(fused vs library path)'] = max(rel(first['mse'], ev2[1]), rel(first['mae'], ev2[2]),
