@@ -534,10 +534,111 @@ __global__ __launch_bounds__(256) void rowdec_bwd_dx_kernel(DecArgs A, int tiles
     else dec_bwd_dx_body<true>(A, bx - tiles0, 1);
 }
 
-__global__ __launch_bounds__(512) void rowdec_bwd_dw_kernel(DecArgs A, int slots0, long long slab0, long long slab1) {
-    const int lane = threadIdx.x & 63, w = uniform((int)(threadIdx.x >> 6));
+// The row-wise weight gradients with LDS staging (the encoder dW kernel's structure): a slab holds hundreds of rows, and
+// the agent-level body above would fetch every chunk with 96 dword loads per lane, several waves fetching the same
+// columns, and wait for each chunk in turn.  Here the workgroup stages 32-row chunks of the five operand arrays with
+// 16-byte loads (every byte once), double-buffered: the loads of chunk t+1 are in flight during the MFMAs of chunk t.
+constexpr int RD_CHUNK = 32;
+constexpr int RD_G1 = 0, RD_G2 = RD_CHUNK * DD, RD_H1 = 2 * RD_CHUNK * DD, RD_D2 = 3 * RD_CHUNK * DD, RD_E = 4 * RD_CHUNK * DD,
+              RD_GP = RD_E + RD_CHUNK * DH, RD_BUF = RD_GP + RD_CHUNK * 2;
+
+__global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int slots0, long long slab0, long long slab1) {
+    extern __shared__ __align__(16) float rd_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = uniform((int)(tid >> 6));
     const int b = (int)blockIdx.x >= slots0 ? 1 : 0;
-    dec_bwd_dw_body<true>(A, b, (int)blockIdx.x - (b ? slots0 : 0), w, lane, b ? slab1 : slab0);
+    const int p = (int)blockIdx.x - (b ? slots0 : 0);
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const long long R = J.agents, slab = b ? slab1 : slab0;
+    const long long s0 = (long long)p * slab < R ? (long long)p * slab : R;
+    const long long s1e = s0 + slab < R ? s0 + slab : R;
+    const int i = lane & 31, h = lane >> 5;
+    const int mb1 = w >> 2, nb1 = w & 3, mb2 = (w >> 1) & 1, nb2 = w & 1;
+    const bool do2 = w < 4, do3 = w == 4 || w == 5;
+    f32x16 c1, c2, c3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // staging role: row srow of the chunk, float4 column sc4 of the 64-wide arrays (and sc4, sc4 + 64 of the embeddings)
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    struct Stage { float4 g1, g2, h1, d2, e0, e1; float gp; bool ok; };
+    auto stage_load = [&](long long rb) -> Stage {
+        Stage S;
+        const long long row = rb + srow;
+        S.ok = row < s1e;
+        const long long ro = S.ok ? row : (s0 < R ? s0 : 0);       // clamped: a readable row
+        S.g1 = *reinterpret_cast<const float4*>(J.g_pre1 + ro * DD + sc4);
+        S.g2 = *reinterpret_cast<const float4*>(J.g_pre2 + ro * DD + sc4);
+        S.h1 = *reinterpret_cast<const float4*>(J.h1 + ro * DD + sc4);
+        S.d2 = *reinterpret_cast<const float4*>(J.d2 + ro * DD + sc4);
+        S.e0 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + sc4);
+        S.e1 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + 64 + sc4);
+        const long long gr = rb + (tid >> 1);                      // threads 0..63: the chunk's (row, component) of g_pred
+        S.gp = J.g_pred_rows[(gr < s1e && tid < 2 * RD_CHUNK ? gr : (s0 < R ? s0 : 0)) * 2 + (tid & 1)];
+        if (!(gr < s1e && tid < 2 * RD_CHUNK)) S.gp = 0.f;
+        return S;
+    };
+    auto stage_write = [&](const Stage S, float* buf) {
+        auto sel = [&](const float4 v) { return make_float4(S.ok ? v.x : 0.f, S.ok ? v.y : 0.f, S.ok ? v.z : 0.f, S.ok ? v.w : 0.f); };
+        *reinterpret_cast<float4*>(buf + RD_G1 + srow * DD + sc4) = sel(S.g1);
+        *reinterpret_cast<float4*>(buf + RD_G2 + srow * DD + sc4) = sel(S.g2);
+        *reinterpret_cast<float4*>(buf + RD_H1 + srow * DD + sc4) = sel(S.h1);
+        *reinterpret_cast<float4*>(buf + RD_D2 + srow * DD + sc4) = sel(S.d2);
+        *reinterpret_cast<float4*>(buf + RD_E + srow * DH + sc4) = sel(S.e0);
+        *reinterpret_cast<float4*>(buf + RD_E + srow * DH + 64 + sc4) = sel(S.e1);
+        if (tid < 2 * RD_CHUNK) buf[RD_GP + tid] = S.gp;
+    };
+    auto compute = [&](const float* buf) {
+#pragma unroll
+        for (int ks = 0; ks < RD_CHUNK / 2; ++ks) {
+            const int row = 2 * ks + h;
+            const float a1 = buf[RD_G1 + row * DD + 32 * mb1 + i], b1 = buf[RD_E + row * DH + 32 * nb1 + i];
+            c1 = dmfma(a1, b1, c1);
+            s1 += a1;
+            if (do2) {
+                const float a2 = buf[RD_G2 + row * DD + 32 * mb2 + i], b2 = buf[RD_H1 + row * DD + 32 * nb2 + i];
+                c2 = dmfma(a2, b2, c2);
+                s2 += a2;
+            }
+            if (do3) {
+                const float a3 = i < 2 ? buf[RD_GP + row * 2 + i] : 0.f, b3 = buf[RD_D2 + row * DD + 32 * nb2 + i];
+                c3 = dmfma(a3, b3, c3);
+                s3 += a3;
+            }
+        }
+    };
+    if (s0 < s1e) {
+        const int nb = (int)((s1e - s0 + RD_CHUNK - 1) / RD_CHUNK);
+        Stage S = stage_load(s0);
+        stage_write(S, rd_lds);
+        __syncthreads();
+        for (int t = 0; t < nb; ++t) {
+            float* cur = rd_lds + (t & 1) * RD_BUF;
+            float* nxt = rd_lds + ((t + 1) & 1) * RD_BUF;
+            S = stage_load(s0 + (long long)(t + 1) * RD_CHUNK);    // past the slab: clamped + zeroed, written but never read
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_write(S, nxt);
+            __syncthreads();
+        }
+    }
+    float* P = J.partials + (size_t)p * DEC_PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+        P[(size_t)(32 * mb1 + ri) * DH + 32 * nb1 + i] = c1[r];
+        if (do2) P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = c2[r];
+        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = c3[r];
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s3 += __shfl_xor(s3, 32, 64);
+    float* Pb = P + DD * DH + DD * DD + 2 * DD;
+    if (h == 0) {
+        if (nb1 == 0) Pb[32 * mb1 + i] = s1;                       // waves 0 and 4
+        if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;           // waves 0 and 2
+        if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
+    }
 }
 
 __global__ __launch_bounds__(256) void rowdec_reduce_kernel(DecArgs A, int B0, int B1, int lanes) {
@@ -836,11 +937,13 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
     return dec_stage_bwd_dw(br, nbr, g_pred, true, s);
 }
 
-// slab of the row-wise dW kernel: a multiple of DEC_SLAB rows, at most 256 slots per branch
+// slab of the row-wise dW kernel: a multiple of DEC_SLAB rows, at least 256 (the workgroup holds ~100 KB of LDS, one per
+// CU: with the reference's 24 576 + 40 960 rows the two branches make 96 + 160 = 256 workgroups, each pipelining 8 chunks),
+// and at most 256 slots per branch
 static long long rowdec_slab(long long rows) {
     long long slab = (rows + 255) / 256;
     slab = (slab + DEC_SLAB - 1) / DEC_SLAB * DEC_SLAB;
-    return slab < DEC_SLAB ? DEC_SLAB : slab;
+    return slab < 256 ? 256 : slab;
 }
 
 PIML_API int piml_rowdecoder_slots(long long rows) {
@@ -881,7 +984,14 @@ PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* s
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
     hipLaunchKernelGGL(rowdec_bwd_dx_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
     const int slots0 = piml_rowdecoder_slots(br[0].agents), slots1 = nbr > 1 ? piml_rowdecoder_slots(br[1].agents) : 0;
-    hipLaunchKernelGGL(rowdec_bwd_dw_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 0, s, A, slots0,
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowdec_bwd_dw_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RD_BUF * 4))
+            return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rowdec_bwd_dw_lds_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 2 * RD_BUF * 4, s, A, slots0,
                        rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
     hipLaunchKernelGGL(rowdec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, slots0, slots1,
                        DEC_PART / 4);
