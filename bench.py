@@ -200,9 +200,9 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False):
+                 overlap=False, model_name='PINNSF_multitask'):
         from piml_amd import ops, _lib
-        from piml_amd.models.model import PINNSF_multitask
+        import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
         self.ops, self._lib = ops, _lib
         self.N, self.n_own, self.b0, self.dev, self.group, self.use_dist = N, n_own, b0, dev, group, use_dist
@@ -215,7 +215,7 @@ class Step:
         self.v0_own = torch.tensor(scene['desired_speed'][rows], device=dev)
         self.sh = ShardedScene(N, self.obstacles, group=group, force_collectives=True) if use_dist else None
         torch.manual_seed(666)
-        self.model = PINNSF_multitask(model_args()).to(dev).eval()   # eval: dropout off, deterministic
+        self.model = getattr(MODEL, model_name)(model_args()).to(dev).eval()   # eval: dropout off, deterministic
         if two_streams:
             self.model.obs_stream = torch.cuda.Stream()
         self.params = [p for p in self.model.parameters()]
@@ -810,6 +810,20 @@ def main():
             secondary = secondary_measurements(scene, n_own, dev, _lib)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
+        if world == 1:       # the same step with the shipped experiments' model (src/configs/exp_configs/piml-*.yaml)
+            try:
+                bm = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), model_name='PINNSF_bottleneck_multitask')
+                bm.capture()
+                k = max(10, min(args.steps, 50))
+                el = bm.time_steps(k, 5)
+                secondary['pinnsf_bm_step'] = {
+                    'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': bm.mode,
+                    'note': '`--model pinnsf_bm` (decoder + predictor per NEIGHBOUR row): the same forward + backward step; '
+                            'fused encoders + fused row decoder (piml_rowdecoder_*), its 64->64->1 collision head on library '
+                            'GEMMs; 1.145 ms/step with the decoders on library GEMMs (PIML_FUSED_ROW_DECODER=0)'}
+                del bm
+            except Exception as ex:   # noqa: BLE001 - informational
+                secondary['pinnsf_bm_step'] = {'error': f'{type(ex).__name__}: {ex}'}
 
     if leg_timer is not None:
         leg_timer.cancel()
