@@ -357,3 +357,57 @@ def test_bottleneck_models_with_fused_row_decoder_match_library_decoders(name):
         worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)))
     print(f'{name}: fused row decoder vs library decoders, max rel err {worst:.1e}')
     assert worst <= 2e-5
+
+
+@pytest.mark.parametrize('nbr,agents,ks,with_head', [(1, 70, (13,), False), (1, 4096, (6,), True), (2, 45, (3, 11), True),
+                                                     (2, 1, (1, 1), False)])
+def test_fused_pinnsf_edge_geometries_match_float64(nbr, agents, ks, with_head):
+    """ops.fused_pinnsf off the beaten path: ONE branch (no obstacle branch: plain store instead of the two-branch atomic
+    combine), more neighbours than the pooling keeps in flight at once (k = 13 > 10), k = 1, a single agent, with and
+    without the collision head -- outputs and every gradient against float64."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(21)
+    tau = 0.5
+
+    def mk(*shape, scale=0.2):
+        return (torch.randn(*shape, generator=g) * scale).to(DEV).requires_grad_(True)
+    brs = []
+    for b in range(nbr):
+        x = mk(agents, ks[b], 6, scale=1.0)
+        brs.append(dict(x=x, scale=2.0, encoder=[mk(128, 6), mk(128), mk(128, 128), mk(128), mk(128, 128), mk(128)],
+                        decoder=[mk(64, 128), mk(64), mk(64, 64), mk(64)], predictor=[mk(2, 64), mk(2)]))
+    sf = mk(agents, 7, scale=1.0)
+    head = [mk(64, 128), mk(64), mk(1, 64), mk(1)] if with_head else None
+    res = ops.fused_pinnsf(brs, sf, tau, fold_epilogue=True, head=head)
+    acc, msgs = res[0], res[1]
+    wa = torch.randn(agents, 2, generator=g).to(DEV)
+    loss = (acc * wa).sum() + sum((m * 1e-2).sum() for m in msgs) + (res[2].sum() if with_head else 0.0)
+    leaves = [sf] + [t for br in brs for t in (br['x'], *br['encoder'], *br['decoder'], *br['predictor'])] + (head or [])
+    grads = torch.autograd.grad(loss, leaves)
+
+    d = lambda t: t.detach().double().requires_grad_(True)
+    sf64 = d(sf)
+    leaves64, acc64, msgs64 = [sf64], 0.0, []
+    for br in brs:
+        x, e, dd, p = d(br['x']), [d(t) for t in br['encoder']], [d(t) for t in br['decoder']], [d(t) for t in br['predictor']]
+        h = torch.relu(x @ e[0].t() + e[1])
+        h = torch.relu(h @ e[2].t() + e[3])
+        m = 2.0 * (h @ e[4].t() + e[5])
+        pooled = m.sum(dim=-2)
+        acc64 = acc64 + (torch.relu(pooled @ dd[0].t() + dd[1]) @ dd[2].t() + dd[3]) @ p[0].t() + p[1]
+        msgs64.append(m)
+        leaves64 += [x, *e, *dd, *p]
+    t = torch.norm(sf64[:, :2], dim=-1, keepdim=True)
+    t = torch.where(t == 0, t + 0.1, t)
+    acc64 = acc64 + (sf64[:, 6:7] * sf64[:, :2] / t - sf64[:, 2:4]) / tau
+    loss64 = (acc64 * wa.double()).sum() + sum((m * 1e-2).sum() for m in msgs64)
+    if with_head:
+        h64 = [d(t) for t in head]
+        loss64 = loss64 + torch.sigmoid(torch.relu(msgs64[0] @ h64[0].t() + h64[1]) @ h64[2].t() + h64[3]).sum()
+        leaves64 += h64
+    grads64 = torch.autograd.grad(loss64, leaves64)
+    worst = float((acc.double() - acc64).abs().max() / acc64.abs().max())
+    for a, b in zip(grads, grads64):
+        worst = max(worst, float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)))
+    print(f'fused_pinnsf nbr={nbr} agents={agents} k={ks} head={with_head}: max rel err vs float64 {worst:.1e}')
+    assert worst <= 2e-5
