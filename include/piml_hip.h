@@ -443,6 +443,9 @@ typedef struct piml_encoder_branch {
 /* floats of one partial slot / of one `packed` buffer */
 int piml_encoder_partial_floats(void);
 int piml_encoder_pack_floats(void);
+/* Up to this many 32-row tiles (both branches together) the forward runs with four waves per tile instead of one (few
+ * rows: rollouts of real clips); the two forms are bitwise identical.  Returns the previous value; < 0 only queries. */
+long long piml_encoder_split_tiles(long long tiles);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve

@@ -84,6 +84,7 @@ SIGNATURES = {
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
     'piml_encoder_partial_floats': [],
     'piml_encoder_pack_floats': [],
+    'piml_encoder_split_tiles': [_ll],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],
@@ -136,6 +137,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = _i
+        L.piml_encoder_split_tiles.restype = _ll
         L.piml_error_string.argtypes = [_i]
         L.piml_error_string.restype = ctypes.c_char_p
         if L.piml_abi_version() != ABI_VERSION:

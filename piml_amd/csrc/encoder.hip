@@ -18,6 +18,8 @@
 // Backward: enc_bwd_dx runs the same chain with W^T (g_h = W^T g_pre, masked by the saved activations) and leaves
 // the pre-activation gradients g2, g1 in HBM; enc_bwd_dw is the split-K product dW = G^T H over row slabs
 // (A = G^T read straight from row-major G, B = H), per-workgroup partials, one piml_sum_leading over them.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "pack.hpp"
 #include "stages.hpp"
@@ -194,6 +196,109 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
                 for (int q = 0; q < 4; ++q)
                     store4_stream(o + feat0(blk, q, h), scale * a1[blk][4 * q], scale * a1[blk][4 * q + 1], scale * a1[blk][4 * q + 2], scale * a1[blk][4 * q + 3]);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward for FEW rows (rollouts of real clips: 100 .. 1000 agents = 60 .. 500 tiles for 2048 wave slots).  With one tile
+// per wave most SIMDs hold one wave or none, and a lone wave issues a 32x32x2 MFMA only every ~135 cycles: the 528-MFMA
+// chain takes 40 us whatever the row count.  Here FOUR waves share a tile -- wave (t, blk) computes output block blk of
+// every layer of tile t, two tiles per workgroup -- and hand the activations over through LDS in accumulator layout
+// (lane = row, register = feature = the B-operand layout of the next layer).  Chain per wave: 4 + 64 + 64 MFMAs.  The
+// weight fragments come straight from the packed image (a wave uses each once: no staging phase); every accumulator sees
+// the k-steps in the order of enc_fwd_kernel, so the outputs are bitwise identical.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void enc_fwd_split_kernel(EncArgs A, int pairs0) {
+    __shared__ float exch[2][2][4][16][64];            // [layer buffer][tile][block][register][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x >= pairs0 ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int t = wave >> 2, blk = wave & 3;
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long tile = ((long long)blockIdx.x - (b ? pairs0 : 0)) * 2 + t;
+    const int j = lane & 31, h = lane >> 5;
+    const long long row = tile * 32 + j;
+    const bool valid = row < R;
+    if (A.zero)
+        for (int e = blockIdx.x * 512 + tid; e < A.zero_n; e += gridDim.x * 512) A.zero[e] = 0.f;
+    const float4* W2g = reinterpret_cast<const float4*>(J.packed);
+    const float4* W3g = reinterpret_cast<const float4*>(J.packed + 16384);
+    const float* W1g = J.packed + 32768;
+    const float* bias = J.packed + 32768 + 1024;
+    float4 wf[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) wf[g] = W2g[(blk * 16 + g) * 64 + lane];           // in flight during layer 1
+    float xb[4], w1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 2 * s + h;
+        xb[s] = (valid && c < IN) ? J.x[(valid ? row : 0) * IN + c] : 0.f;
+        w1[s] = W1g[(blk * 4 + s) * 64 + lane];
+    }
+    float4 bq[3][4];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[l][q] = *reinterpret_cast<const float4*>(bias + 128 * l + feat0(blk, q, h));
+    f32x16 acc;
+    auto init = [&](int l) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[l][q].x; acc[4 * q + 1] = bq[l][q].y; acc[4 * q + 2] = bq[l][q].z; acc[4 * q + 3] = bq[l][q].w; }
+    };
+    auto store = [&](float* dst, float sc) {
+        if (dst && valid) {
+            float* o = dst + row * EH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                store4_stream(o + feat0(blk, q, h), sc * acc[4 * q], sc * acc[4 * q + 1], sc * acc[4 * q + 2], sc * acc[4 * q + 3]);
+        }
+    };
+    // ---- layer 1 ----
+    init(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma32(w1[s], xb[s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = fmaxf(acc[r], 0.f); exch[0][t][blk][r][lane] = acc[r]; }
+    if (J.h1 && valid) {
+        float* o = J.h1 + row * EH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    __syncthreads();
+    // ---- layers 2 and 3 ----
+#pragma unroll
+    for (int l = 1; l < 3; ++l) {
+        float in[4][16];
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) in[bp][r] = exch[l - 1][t][bp][r][lane];
+        init(l);
+        float4 wn[16];
+        if (l == 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) wn[g] = W3g[(blk * 16 + g) * 64 + lane];   // next layer's, under this layer's MFMAs
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int bp = g >> 2, q = g & 3;
+            acc = mfma32(wf[g].x, in[bp][4 * q + 0], acc);
+            acc = mfma32(wf[g].y, in[bp][4 * q + 1], acc);
+            acc = mfma32(wf[g].z, in[bp][4 * q + 2], acc);
+            acc = mfma32(wf[g].w, in[bp][4 * q + 3], acc);
+        }
+        if (l == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = fmaxf(acc[r], 0.f); exch[1][t][blk][r][lane] = acc[r]; }
+            store(J.h2, 1.f);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) wf[g] = wn[g];
+            __syncthreads();
+        } else {
+            store(J.msgs, J.scale);
         }
     }
 }
@@ -625,6 +730,15 @@ int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) 
     return hipGetLastError();
 }
 
+// row tiles (of 32) up to which the forward uses enc_fwd_split_kernel (PIML_ENC_SPLIT_TILES, piml_encoder_split_tiles)
+static long long g_split_tiles = getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 1024;
+
+PIML_API long long piml_encoder_split_tiles(long long tiles) {
+    const long long old = g_split_tiles;
+    if (tiles >= 0) g_split_tiles = tiles;
+    return old;
+}
+
 int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
     if (int e = enc_check(br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
@@ -637,6 +751,12 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
         attr_set = true;
     }
     if (zero && zero_n > 0 && zero_n < (1ll << 31)) { A.zero = zero; A.zero_n = (int)zero_n; }
+    long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
+    if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
+        const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
+        hipLaunchKernelGGL(enc_fwd_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, s, A);
     return hipGetLastError();
 }

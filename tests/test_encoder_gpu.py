@@ -411,3 +411,34 @@ def test_fused_pinnsf_edge_geometries_match_float64(nbr, agents, ks, with_head):
         worst = max(worst, float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)))
     print(f'fused_pinnsf nbr={nbr} agents={agents} k={ks} head={with_head}: max rel err vs float64 {worst:.1e}')
     assert worst <= 2e-5
+
+
+@pytest.mark.parametrize('agents', [1, 37, 122, 1024])
+def test_split_tile_forward_is_bitwise_the_one_wave_forward(agents):
+    """enc_fwd_split_kernel (four waves per 32-row tile, few rows) against enc_fwd_kernel (one wave per tile): every
+    accumulator sees its k-steps in the same order, so the messages, the saved activations (seen through the gradients)
+    and the pooled sums are bitwise identical.  Both branches, ragged tiles, an odd number of tiles."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(31)
+
+    def branch(k):
+        x = torch.randn(agents, k, 6, generator=g).to(DEV).requires_grad_(True)
+        w = [(torch.randn(*d, generator=g) * 0.2).to(DEV).requires_grad_(True)
+             for d in [(128, 6), (128,), (128, 128), (128,), (128, 128), (128,)]]
+        return dict(x=x, scale=2.0, weights=w, pooled=True)
+    brs = [branch(6), branch(10)]
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    res = {}
+    old = L.piml_encoder_split_tiles(-1)
+    try:
+        for split in (True, False):
+            L.piml_encoder_split_tiles(1 << 30 if split else 0)
+            outs = ops.fused_encoders(brs)
+            loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
+            res[split] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
+    finally:
+        L.piml_encoder_split_tiles(old)
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
