@@ -83,6 +83,15 @@ int piml_relfeat_fwd(const float* position, const float* heading, const float* v
                      float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
                      int32_t* ped_idx, int32_t* obs_idx, void* stream);
 
+/* piml_relfeat_fwd + `*tick += 1` (a device-side int64 frame counter the kernel never reads): the captured inference
+ * rollout frame (src/models/simulators.py:595-652) ends with this launch. */
+int piml_relfeat_fwd_tick(const float* position, const float* heading, const float* velocity, const float* acceleration,
+                          int state_ld, const float* destination, const float* obstacles, int C, int N, int M,
+                          int focal_begin, int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                          float cos_thr_obs, float dist_thr_ped, float dist_thr_obs, float* ped_feat, float* obs_feat,
+                          float* dest_feat, int dest_feat_ld, int32_t* ped_idx, int32_t* obs_idx, long long* tick,
+                          void* stream);
+
 /*
  * piml_relfeat_fwd for ONE scene of packed (N, 6) = (p, v, a) records that also writes the model's self_features rows
  * [dest - p, v, a, v0] (n, 7) (src/models/simulators.py:169-173 builds them with a torch.cat per frame) and, when

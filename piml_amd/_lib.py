@@ -113,6 +113,8 @@ SIGNATURES = {
     'piml_allgather_state': [_p, _p, _z, _p, _p],
     'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
     'piml_allreduce_sum': [_p, _p, _z, _p],
+    'piml_relfeat_fwd_tick': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
+                              _p, _p, _p, _i, _p, _p, _p, _p],
     'piml_relfeat_self_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_relfeat_self_fwd_part': [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_relfeat_self_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],

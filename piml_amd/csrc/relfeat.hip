@@ -44,6 +44,7 @@ struct RelfeatArgs {
     int flags;              // kRfPedFeat | kRfObs | kRfDest | kRfPedList | kRfInit
     const float* speed;   // non-NULL: dest_feat rows are the model's self_features rows [dest - p, v, a, v0] (dest_ld >= 7)
     float* zero; long zero_n;   // optional: buffer this launch clears (the state gradient its backward accumulates into)
+    long long* tick;            // optional: device-side frame counter this launch advances by one (it does not read it)
     int* stats;   // PIML_RELFEAT_STATS builds only: per focal row {evals, drain rounds, insertions, candidates,
                   // 7 phase stamps (cycles): entry, [tile staged, pass done] per pass ..., + 1 pad}
 };
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     const int wave = uniform((int)(threadIdx.x >> 6));
     unsigned short* ring = ring_all[wave];                  // stays in the LDS address space
 
+    if (A.tick && blockIdx.x == 0 && threadIdx.x == 0) *A.tick += 1;
     if (A.zero)                                             // a few 100 KB, spread over the whole grid
         for (long e = (long)blockIdx.x * (WAVES * 64) + threadIdx.x; e < A.zero_n; e += (long)gridDim.x * (WAVES * 64))
             A.zero[e] = 0.f;
@@ -470,7 +472,7 @@ static int relfeat_launch(const float* position, const float* heading, const flo
                           float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
                           float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
                           int32_t* ped_idx, int32_t* obs_idx, const float* speed, float* zero, long zero_n, void* stream,
-                          int part = 0) {
+                          int part = 0, long long* tick = nullptr) {
     if (C < 0 || N < 0 || M < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N ||
         topk_ped < 0 || topk_obs < 0 || topk_ped > PIML_MAX_TOPK || topk_obs > PIML_MAX_TOPK ||
         state_ld < 2 || (state_ld & 1) || dest_feat_ld < 2)
@@ -500,7 +502,7 @@ static int relfeat_launch(const float* position, const float* heading, const flo
     A.dthr_p = dist_thr_ped; A.dthr_o = dist_thr_obs;
     A.ped_feat = ped_feat; A.obs_feat = obs_feat; A.dest_feat = dest_feat; A.dest_ld = dest_feat_ld;
     A.ped_idx = ped_idx; A.obs_idx = obs_idx;
-    A.speed = speed; A.zero = zero; A.zero_n = zero ? zero_n : 0;
+    A.speed = speed; A.zero = zero; A.zero_n = zero ? zero_n : 0; A.tick = tick;
     A.stats = nullptr;
 #ifdef PIML_RELFEAT_STATS
     if (const char* e = getenv("PIML_RELFEAT_STATS_PTR")) A.stats = (int*)strtoull(e, nullptr, 0);
@@ -532,6 +534,20 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
     return relfeat_launch(position, heading, velocity, acceleration, state_ld, destination, obstacles, C, N, M, focal_begin,
                           focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
                           obs_feat, dest_feat, dest_feat_ld, ped_idx, obs_idx, nullptr, nullptr, 0, stream);
+}
+
+// piml_relfeat_fwd that also advances a device-side frame counter by one (the captured inference-rollout frame ends with
+// this launch: the increment was a 4 us launch of its own).  The kernel never reads the counter.
+PIML_API int piml_relfeat_fwd_tick(const float* position, const float* heading, const float* velocity,
+                                   const float* acceleration, int state_ld, const float* destination,
+                                   const float* obstacles, int C, int N, int M, int focal_begin,
+                                   int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                                   float cos_thr_obs, float dist_thr_ped, float dist_thr_obs,
+                                   float* ped_feat, float* obs_feat, float* dest_feat, int dest_feat_ld,
+                                   int32_t* ped_idx, int32_t* obs_idx, long long* tick, void* stream) {
+    return relfeat_launch(position, heading, velocity, acceleration, state_ld, destination, obstacles, C, N, M, focal_begin,
+                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                          obs_feat, dest_feat, dest_feat_ld, ped_idx, obs_idx, nullptr, nullptr, 0, stream, 0, tick);
 }
 
 // One scene of packed (N, 6) = (p, v, a) records: the features of the focal rows AND their self_features rows

@@ -279,14 +279,13 @@ class BaseSimulator(Pedestrians):
     def _rollout_step_fused(self, data, st):
         """The same frame as `_rollout_step` in three launches besides the MLP: the fused integrator
         epilogue (piml_rollout_step), the relative-feature kernel writing straight into the state
-        buffers, and the frame-counter increment."""
+        buffers (which also advances the frame counter)."""
         a = self.args
         a_next = self.model(st.pf, st.of, st.selff)[0]
         ops.rollout_step(st, data, a_next.contiguous(), remove_arrived=True)
         ops.relative_features_into((st.pf, st.of, st.selff, st.ped_idx, st.obs_idx), st.p, st.v, st.a, st.dest,
                                    data.obstacles, a.topk_ped, a.sight_angle_ped, a.dist_threshold_ped,
-                                   a.topk_obs, a.sight_angle_obs, a.dist_threshold_obs)
-        st.t.add_(1)
+                                   a.topk_obs, a.sight_angle_obs, a.dist_threshold_obs, tick=st.t)   # + st.t += 1
 
     def _rollout_step(self, data, st):
         """One simulated frame (the body of simulators.py:595-652) on the persistent buffers.
@@ -367,13 +366,20 @@ class BaseSimulator(Pedestrians):
                     step_fn(data, st)
                 done += 2
                 torch.cuda.synchronize()
+                # frames per graph (the frames are identical: device-side counter).  One is the default: eight frames per
+                # launch were measured SLOWER (52 vs 46 us/frame at N = 122, 108 vs 99 at N = 4096) -- the frame is GPU-bound
+                # (40 us of kernels + ~1 us between dependent launches), not bound by the host's graph launches
+                per = max(1, min(int(getattr(args, 'frames_per_graph', 1)), steps - done))
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    step_fn(data, st)
+                    for _ in range(per):
+                        step_fn(data, st)
                 self.model.obs_stream = None
-                for _ in range(steps - done):
+                done += per                                # the capture does not execute: replay it once now
+                graph.replay()
+                for _ in range((steps - done) // per):
                     graph.replay()
-                done = steps
+                done += (steps - done) // per * per
             except RuntimeError as ex:                    # capture unsupported: finish eagerly
                 self.model.obs_stream = None
                 print(f'[piml_amd] rollout graph capture failed ({ex}); continuing eagerly')

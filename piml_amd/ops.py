@@ -54,7 +54,7 @@ def heading_direction(velocity):
 
 
 def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f0, fcnt, kp, ko,
-                        cos_p, cos_o, dthr_p, dthr_o, device, outs=None, dest_ld=2):
+                        cos_p, cos_o, dthr_p, dthr_o, device, outs=None, dest_ld=2, tick=None):
     M = o.shape[0]
     kpe, koe = min(kp, N), min(ko, M)
     if outs is None:
@@ -71,6 +71,14 @@ def _launch_relfeat_fwd(p_ptr, v_ptr, a_ptr, ld, hd, dest_rows, o, lead, C, N, f
             if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or t.device != device:
                 raise ValueError(f'output buffer mismatch: expected {shp} {dt}, got {tuple(t.shape)} {t.dtype}')
     with torch.cuda.device(device):
+        if tick is not None:
+            if tick.dtype != torch.int64 or tick.numel() != 1 or tick.device != device:
+                raise ValueError('tick: a one-element int64 tensor on the same device expected')
+            _lib.check(_lib.lib().piml_relfeat_fwd_tick(
+                p_ptr, _ptr(hd), v_ptr, a_ptr, ld, _ptr(dest_rows), _ptr(o), C, N, M, f0, fcnt,
+                kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat), dest_ld,
+                _ptr(ped_idx), _ptr(obs_idx), _ptr(tick), _stream()), 'piml_relfeat_fwd_tick')
+            return ped_feat, obs_feat, dest_feat, ped_idx, obs_idx
         _lib.check(_lib.lib().piml_relfeat_fwd(
             p_ptr, _ptr(hd), v_ptr, a_ptr, ld, _ptr(dest_rows), _ptr(o), C, N, M, f0, fcnt,
             kp, ko, cos_p, cos_o, dthr_p, dthr_o, _ptr(ped_feat), _ptr(obs_feat), _ptr(dest_feat), dest_ld,
@@ -569,11 +577,11 @@ def calc_acceleration(relative_data, equation_version='v0', dataset='gc1560', ep
 
 def relative_features_into(outs, position, velocity, acceleration, destination, obstacles,
                            topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
-                           topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4):
+                           topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, tick=None):
     """Forward only, no autograd, no allocation: per-step features of (..., N, 2) state into the
     preallocated `outs` = (ped_features, obs_features, self_features, ped_idx, obs_idx), where
     dest_features land in columns 0..1 of the (..., N, F) self_features buffer (row stride F).
-    Used by the captured inference-rollout step."""
+    Used by the captured inference-rollout step; `tick` (one-element int64 tensor) is advanced by one by the same launch."""
     p, v, a, d = [_gpu_f32(n, x) for n, x in (('position', position), ('velocity', velocity),
                                               ('acceleration', acceleration), ('destination', destination))]
     o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
@@ -582,7 +590,7 @@ def relative_features_into(outs, position, velocity, acceleration, destination, 
     C = p.numel() // max(N * 2, 1)
     _launch_relfeat_fwd(_ptr(p), _ptr(v), _ptr(a), 2, None, d, o, lead, C, N, 0, N, int(topk_ped), int(topk_obs),
                         cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs), float(dist_threshold_ped),
-                        float(dist_threshold_obs), p.device, outs=tuple(outs), dest_ld=outs[2].shape[-1])
+                        float(dist_threshold_obs), p.device, outs=tuple(outs), dest_ld=outs[2].shape[-1], tick=tick)
     return outs
 
 
