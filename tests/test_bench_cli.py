@@ -55,3 +55,23 @@ def test_committed_step_counters_are_physical():
         assert k['us'] > 0 and (k.get('frac') is None or 0 <= k['frac'] <= 1), k
     assert 0 < j['relfeat_fwd_kernel']['valu_busy_frac'] <= 1
     assert j['step_hbm_bytes'] > 1e8
+
+
+def test_packed_weights_is_a_noop_without_a_gpu():
+    """`model.packed_weights()` on a CPU model (and on configurations the fused network does not cover) must just run
+    the block: no HIP call, no state left behind."""
+    import types
+    import torch
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=32,
+        processor_hidden_size=32, decoder_hidden_size=16, encoder_hidden_layers=2, processor_hidden_layers=2,
+        decoder_hidden_layers=2, dropout=0.0, activation='relu', dataset_name='gc1560')
+    for name in ('PINNSF_multitask', 'PINNSF_bottleneck_multitask'):
+        net = getattr(MODEL, name)(args).eval()
+        x = [torch.randn(5, 6, 6), torch.randn(5, 10, 6), torch.randn(5, 7)]
+        with net.packed_weights():
+            a = net(*x)[0]
+            with net.packed_weights():          # re-entrant
+                b = net(*x)[0]
+        assert torch.equal(a, b) and (net._packs is None or not net._packs.active)
