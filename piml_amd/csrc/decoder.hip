@@ -734,20 +734,6 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     head_fwd_body(msgs, rows, packed, out, blockIdx.x);
 }
 
-// The two independent consumers of the encoders' messages in one launch (each dependent launch costs ~4.5 us on
-// gfx950): blocks [0, head_blocks) are collision-head tiles (the longer ones first), the rest pooling blocks of
-// branch 0 then branch 1.
-__global__ __launch_bounds__(256) void dec_pool_head_kernel(DecArgs A, piml_collision_head Hd, int head_blocks,
-                                                            int pool_blocks) {
-    const int bx = blockIdx.x;
-    if (bx < head_blocks) {
-        head_fwd_body(Hd.msgs, Hd.rows, Hd.packed, Hd.out, bx);
-    } else {
-        const int p = bx - head_blocks;
-        if (p < pool_blocks) dec_pool_body(A.br[0], p);
-        else dec_pool_body(A.br[1], p - pool_blocks);
-    }
-}
 
 static bool dec_branch_ok(const piml_decoder_branch& b) {
     return b.agents > 0 && b.agents < (1ll << 21) && b.k >= 1 && b.msgs && b.w1 && b.b1 && b.w2 && b.b2 && b.w3 && b.b3 && b.packed;
@@ -806,17 +792,6 @@ int piml::dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s) 
     DecArgs A;
     if (int e = dec_fill(A, br, nbr)) return e;
     hipLaunchKernelGGL(dec_pool_kernel, dim3((unsigned)((br[0].agents * (DH / 4) + 255) / 256), nbr), dim3(256), 0, s, A);
-    return hipGetLastError();
-}
-
-int piml::dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, hipStream_t s) {
-    DecArgs A;
-    if (int e = dec_fill(A, br, nbr)) return e;
-    if (int e = head_check(h)) return e;
-    const int pool_blocks = (int)((br[0].agents * (DH / 4) + 255) / 256);
-    const int head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
-    hipLaunchKernelGGL(dec_pool_head_kernel, dim3((unsigned)(head_blocks + pool_blocks * nbr)), dim3(256), 0, s, A, *h,
-                       head_blocks, pool_blocks);
     return hipGetLastError();
 }
 

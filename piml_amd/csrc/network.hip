@@ -1,11 +1,18 @@
-// The fused PINNSF network as one call: the launch stages of encoder.hip / decoder.hip forked over HIP streams.
+// The fused PINNSF network as one call per direction: the launch stages of encoder.hip / decoder.hip in as few launches
+// as their data dependences allow.
 //
 // Replaces the body of PINNSF.forward / its autograd backward (src/models/model.py:1271-1305: ped_encoder /
 // obs_encoder -> sum over neighbours -> decoders -> predictors -> desired force, and the `pinnsf_m` collision head
-// :1296-1300).  The stages of one step are small next to the chip (the decoder tails and the head work on 4096 agents,
+// :1296-1300).  Most stages of one step are small next to the chip (the decoder tails and the head work on 4096 agents,
 // the packs and reductions on < 1 MB), and every dependent launch on gfx950 pays ~4.5 us for the end-of-kernel
-// write-back + start-of-kernel invalidate of the eight per-XCD L2s.  Stages that do not depend on each other are
-// therefore put on side streams (event fork / join, which stream capture turns into parallel graph branches):
+// write-back + start-of-kernel invalidate of the eight per-XCD L2s.  Default (serial) order, one stream:
+//
+//   pack      ONE launch for every weight image (pinnsf_pack_kernel)                 -- skipped with PIML_PACKED_VALID
+//   forward   encoders (both branches) -> [neighbour-axis sums + decoder tails + desired force + collision head]
+//   backward  [decoder dX chain + dW partials] -> encoder dX -> encoder dW -> ONE slot sum for all four partial sets
+//
+// PIML_FORK (opt-in, measured SLOWER inside captured graphs on ROCm 7.2: every cross-stream edge of a replayed graph
+// costs more than the ~5 us stage it hides) puts the independent stages on library-owned side streams instead:
 //
 //   forward    main:  [enc pack] -> encoders ----------------> pooling -> decoder tails -> join
 //              side0: dec pack, head pack ----\                           ^

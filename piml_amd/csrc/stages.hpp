@@ -17,7 +17,6 @@ int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s);
 
 int dec_stage_pack(const piml_decoder_branch* br, int nbr, hipStream_t s);
 int dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s);
-int dec_stage_pool_head(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, hipStream_t s);  // pool + head
 // pooling + decoder tails + (head may be NULL) the collision head in one launch; after the packs
 int dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
                         float tau, float* acc, hipStream_t s);
