@@ -534,6 +534,246 @@ __global__ __launch_bounds__(256) void rowdec_bwd_dx_kernel(DecArgs A, int tiles
     else dec_bwd_dx_body<true>(A, bx - tiles0, 1);
 }
 
+// ---- many rows (the reference's 65 536 neighbour rows per step): the encoder kernels' structure -- one wave per 32-row
+// tile, the branch's weight fragments staged once per workgroup in LDS, the three layers chained in registers (no LDS
+// exchange, no barrier), tiles strided over 256 workgroups.  The (tile, branch) kernels above cut the chain across four
+// waves for LATENCY (a few hundred tiles); here there are 2048 tiles for 2048 wave slots and the matrix pipe is the
+// limit: 29 -> 21 us forward, 38 -> 24 us dX at the reference's row counts.
+template <int NFLOATS>
+__device__ __forceinline__ void rowdec_stage(float* lds, const float* __restrict__ src, int tid) {
+    constexpr int N4 = NFLOATS / 4, ROUNDS = (N4 + 511) / 512;
+    static_assert(NFLOATS % 4 == 0, "float4 granularity");
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(lds);
+    float4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * 512 + tid;
+        v[r] = s4[e < N4 ? e : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * 512 + tid;
+        if (e < N4) d4[e] = v[r];
+    }
+}
+
+__global__ __launch_bounds__(512) void rowdec_fwd_big_kernel(DecArgs A, int wg_split) {
+    __shared__ __align__(16) float lds[DP_T3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= wg_split) ? 1 : 0;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - wg_split : (A.nbr > 1 ? wg_split : (int)gridDim.x);
+    const long long R = J.agents, ntiles = (R + 31) >> 5;
+    if ((long long)((int)blockIdx.x - wg0) * 8 >= ntiles) return;
+    rowdec_stage<DP_T3>(lds, J.packed, tid);
+    __syncthreads();
+    const float4* F = reinterpret_cast<const float4*>(lds);
+    const float* bias = lds + DP_B;
+    const int j = lane & 31, h = lane >> 5;
+    for (long long tile = (long long)((int)blockIdx.x - wg0) * 8 + wave; tile < ntiles; tile += (long long)nwg * 8) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        f32x16 X[4];
+        {
+            const float* base = J.msgs + (valid ? row : 0) * DH;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + dfeat0(blk, q, h));
+                    X[blk][4 * q] = valid ? v.x : 0.f; X[blk][4 * q + 1] = valid ? v.y : 0.f;
+                    X[blk][4 * q + 2] = valid ? v.z : 0.f; X[blk][4 * q + 3] = valid ? v.w : 0.f;
+                }
+        }
+        f32x16 a1[2], a2[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+                a1[ob][4 * q] = bq.x; a1[ob][4 * q + 1] = bq.y; a1[ob][4 * q + 2] = bq.z; a1[ob][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp) {
+                __builtin_amdgcn_sched_barrier(0);       // a block's fragment reads at a time (hoisting them all spills)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = F[DP_A1 / 4 + ((ob * 4 + bp) * 4 + q) * 64 + lane];
+                    a1[ob] = dmfma(w.x, X[bp][4 * q + 0], a1[ob]);
+                    a1[ob] = dmfma(w.y, X[bp][4 * q + 1], a1[ob]);
+                    a1[ob] = dmfma(w.z, X[bp][4 * q + 2], a1[ob]);
+                    a1[ob] = dmfma(w.w, X[bp][4 * q + 3], a1[ob]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[ob][r] = fmaxf(a1[ob][r], 0.f);
+        }
+        if (valid) {
+            float* o = J.h1 + row * DD;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(a1[ob][4 * q], a1[ob][4 * q + 1], a1[ob][4 * q + 2], a1[ob][4 * q + 3]);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
+                a2[ob][4 * q] = bq.x; a2[ob][4 * q + 1] = bq.y; a2[ob][4 * q + 2] = bq.z; a2[ob][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = F[DP_A2 / 4 + ((ob * 2 + bp) * 4 + q) * 64 + lane];
+                    a2[ob] = dmfma(w.x, a1[bp][4 * q + 0], a2[ob]);
+                    a2[ob] = dmfma(w.y, a1[bp][4 * q + 1], a2[ob]);
+                    a2[ob] = dmfma(w.z, a1[bp][4 * q + 2], a2[ob]);
+                    a2[ob] = dmfma(w.w, a1[bp][4 * q + 3], a2[ob]);
+                }
+            }
+        }
+        if (valid) {
+            float* o = J.d2 + row * DD;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(a2[ob][4 * q], a2[ob][4 * q + 1], a2[ob][4 * q + 2], a2[ob][4 * q + 3]);
+        }
+        f32x16 a3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a3[r] = 0.f;
+        if (h == 0) { a3[0] = bias[128]; a3[1] = bias[129]; }
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = F[DP_A3 / 4 + (bp * 4 + q) * 64 + lane];
+                a3 = dmfma(w.x, a2[bp][4 * q + 0], a3);
+                a3 = dmfma(w.y, a2[bp][4 * q + 1], a3);
+                a3 = dmfma(w.z, a2[bp][4 * q + 2], a3);
+                a3 = dmfma(w.w, a2[bp][4 * q + 3], a3);
+            }
+        }
+        if (h == 0 && valid) reinterpret_cast<float2*>(J.pred)[row] = make_float2(a3[0], a3[1]);
+    }
+}
+
+constexpr int RDX_LDS = DEC_PACK - DP_T3;        // W3^T | W2^T | W1^T fragments
+
+__global__ __launch_bounds__(512) void rowdec_bwd_dx_big_kernel(DecArgs A, int wg_split) {
+    __shared__ __align__(16) float lds[RDX_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= wg_split) ? 1 : 0;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - wg_split : (A.nbr > 1 ? wg_split : (int)gridDim.x);
+    const long long R = J.agents, ntiles = (R + 31) >> 5;
+    if ((long long)((int)blockIdx.x - wg0) * 8 >= ntiles) return;
+    rowdec_stage<RDX_LDS>(lds, J.packed + DP_T3, tid);
+    __syncthreads();
+    const float* T3 = lds;
+    const float4* T2 = reinterpret_cast<const float4*>(lds + (DP_T2 - DP_T3));
+    const float4* T1 = reinterpret_cast<const float4*>(lds + (DP_T1 - DP_T3));
+    const int j = lane & 31, h = lane >> 5;
+    for (long long tile = (long long)((int)blockIdx.x - wg0) * 8 + wave; tile < ntiles; tile += (long long)nwg * 8) {
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        const long long rr = valid ? row : 0;
+        float2 gp = reinterpret_cast<const float2*>(J.g_pred_rows)[rr];
+        if (!valid) gp = make_float2(0.f, 0.f);
+        const float bg = h ? gp.y : gp.x;
+        float4 hv[2][4], gd[2][4];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hv[ob][q] = *reinterpret_cast<const float4*>(J.h1 + rr * DD + dfeat0(ob, q, h));
+                gd[ob][q] = J.g_d2 ? *reinterpret_cast<const float4*>(J.g_d2 + rr * DD + dfeat0(ob, q, h)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        f32x16 g2[2], g1[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g2[ob][r] = 0.f;
+            g2[ob] = dmfma(T3[64 * ob + lane], bg, g2[ob]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                g2[ob][4 * q] += valid ? gd[ob][q].x : 0.f; g2[ob][4 * q + 1] += valid ? gd[ob][q].y : 0.f;
+                g2[ob][4 * q + 2] += valid ? gd[ob][q].z : 0.f; g2[ob][4 * q + 3] += valid ? gd[ob][q].w : 0.f;
+            }
+            if (valid) {
+                float* o = J.g_pre2 + row * DD;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(g2[ob][4 * q], g2[ob][4 * q + 1], g2[ob][4 * q + 2], g2[ob][4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1[ob][r] = 0.f;
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = T2[((ob * 2 + bp) * 4 + q) * 64 + lane];
+                    g1[ob] = dmfma(w.x, g2[bp][4 * q + 0], g1[ob]);
+                    g1[ob] = dmfma(w.y, g2[bp][4 * q + 1], g1[ob]);
+                    g1[ob] = dmfma(w.z, g2[bp][4 * q + 2], g1[ob]);
+                    g1[ob] = dmfma(w.w, g2[bp][4 * q + 3], g1[ob]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = hv[ob][q];
+                g1[ob][4 * q + 0] = (valid && a.x > 0.f) ? g1[ob][4 * q + 0] : 0.f;
+                g1[ob][4 * q + 1] = (valid && a.y > 0.f) ? g1[ob][4 * q + 1] : 0.f;
+                g1[ob][4 * q + 2] = (valid && a.z > 0.f) ? g1[ob][4 * q + 2] : 0.f;
+                g1[ob][4 * q + 3] = (valid && a.w > 0.f) ? g1[ob][4 * q + 3] : 0.f;
+            }
+            if (valid) {
+                float* o = J.g_pre1 + row * DD;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(g1[ob][4 * q], g1[ob][4 * q + 1], g1[ob][4 * q + 2], g1[ob][4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x16 ge;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ge[r] = 0.f;
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = T1[((blk * 2 + bp) * 4 + q) * 64 + lane];
+                    ge = dmfma(w.x, g1[bp][4 * q + 0], ge);
+                    ge = dmfma(w.y, g1[bp][4 * q + 1], ge);
+                    ge = dmfma(w.z, g1[bp][4 * q + 2], ge);
+                    ge = dmfma(w.w, g1[bp][4 * q + 3], ge);
+                }
+            }
+            if (valid) {
+                float* o = J.g_pooled + row * DH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(blk, q, h)) = make_float4(ge[4 * q], ge[4 * q + 1], ge[4 * q + 2], ge[4 * q + 3]);
+            }
+        }
+    }
+}
+
 // The row-wise weight gradients with LDS staging (the encoder dW kernel's structure): a slab holds hundreds of rows, and
 // the agent-level body above would fetch every chunk with 96 dword loads per lane, several waves fetching the same
 // columns, and wait for each chunk in turn.  Here the workgroup stages 32-row chunks of the five operand arrays with
@@ -921,6 +1161,16 @@ static long long rowdec_slab(long long rows) {
     return slab < 256 ? 256 : slab;
 }
 
+// 32-row tiles (both branches) above which the row decoder runs one wave per tile with LDS-staged fragments
+constexpr int kRowdecBigTiles = 1024;
+
+// workgroups of branch 0 in a launch of `total`, proportional to the rows (each branch at least one)
+static int rowdec_wg_split(const piml_decoder_branch* br, int nbr, int total) {
+    if (nbr < 2) return total;
+    int w = (int)(total * (double)br[0].agents / ((double)br[0].agents + (double)br[1].agents) + 0.5);
+    return w < 1 ? 1 : (w > total - 1 ? total - 1 : w);
+}
+
 PIML_API int piml_rowdecoder_slots(long long rows) {
     if (rows <= 0) return 0;
     const long long slab = rowdec_slab(rows);
@@ -948,6 +1198,11 @@ PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* s
     if (int e = rowdec_fill(A, br, nbr, false)) return e;
     if (int e = dec_stage_pack(br, nbr, s)) return e;
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
+    if (tiles0 + tiles1 > kRowdecBigTiles) {       // many rows: one wave per tile, fragments in LDS (rowdec_fwd_big_kernel)
+        const int split = rowdec_wg_split(br, nbr, 256);
+        hipLaunchKernelGGL(rowdec_fwd_big_kernel, dim3(256), dim3(512), 0, s, A, split);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rowdec_fwd_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
     return hipGetLastError();
 }
@@ -957,7 +1212,10 @@ PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* s
     DecArgs A;
     if (int e = rowdec_fill(A, br, nbr, true)) return e;
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
-    hipLaunchKernelGGL(rowdec_bwd_dx_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
+    if (tiles0 + tiles1 > kRowdecBigTiles)
+        hipLaunchKernelGGL(rowdec_bwd_dx_big_kernel, dim3(256), dim3(512), 0, s, A, rowdec_wg_split(br, nbr, 256));
+    else
+        hipLaunchKernelGGL(rowdec_bwd_dx_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
     const int slots0 = piml_rowdecoder_slots(br[0].agents), slots1 = nbr > 1 ? piml_rowdecoder_slots(br[1].agents) : 0;
     static bool attr_set = false;
     if (!attr_set) {
