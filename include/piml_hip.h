@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 10
+#define PIML_HIP_ABI_VERSION 11
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -455,6 +455,11 @@ int piml_encoder_pack_floats(void);
 /* Up to this many 32-row tiles (both branches together) the forward runs with four waves per tile instead of one (few
  * rows: rollouts of real clips); the two forms are bitwise identical.  Returns the previous value; < 0 only queries. */
 long long piml_encoder_split_tiles(long long tiles);
+/* Arithmetic of the two 128 x 128 layers' products.  1 (default): every f32 product as six bf16 x bf16 partial products of
+ * exact three-way splits of both factors, accumulated in f32 (v_mfma_f32_32x32x16_bf16; what is dropped is below one f32
+ * rounding of the product); 0: the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32).  Environment at load time:
+ * PIML_ENC_PRODUCTS=f32.  Returns the previous value; < 0 only queries. */
+int piml_encoder_products(int split_bf16);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     'piml_encoder_partial_floats': [],
     'piml_encoder_pack_floats': [],
     'piml_encoder_split_tiles': [_ll],
+    'piml_encoder_products': [_i],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],

@@ -21,33 +21,12 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "encoder.hpp"
 #include "pack.hpp"
 #include "stages.hpp"
 #include "../../include/piml_hip.h"
 
 namespace piml {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int ENC_THREADS = 512;        // 8 waves per workgroup: 2 per SIMD
-constexpr int ENC_WAVES = ENC_THREADS / 64;
-
-struct EncArgs {
-    piml_encoder_branch br[2];
-    int nbr;
-    int wg_split;       // workgroups [0, wg_split) serve branch 0, the rest branch 1
-    float* zero;        // forward only, optional: a buffer the launch clears on the way (the decoder tails' accumulator)
-    int zero_n;
-};
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// store of 4 consecutive floats of a row (non-temporal stores were measured here: forward 47.9 -> 53.7 us, reverted)
-__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d) {
-    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
 
 __global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
     const int b = blockIdx.y;
@@ -55,31 +34,6 @@ __global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
 }
-
-// Packed image -> LDS, every 16-byte load of the thread issued before the first LDS write.  (As a plain loop this
-// compiled to load / s_waitcnt vmcnt(0) / ds_write per iteration: 17 serialised L2 round trips in front of every
-// workgroup's first MFMA.)
-template <int NFLOATS>
-__device__ __forceinline__ void stage_linear(float* lds, const float* __restrict__ src, int tid) {
-    constexpr int N4 = NFLOATS / 4, ROUNDS = (N4 + ENC_THREADS - 1) / ENC_THREADS;
-    static_assert(NFLOATS % 4 == 0, "float4 granularity");
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    float4* d4 = reinterpret_cast<float4*>(lds);
-    float4 v[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int e = r * ENC_THREADS + tid;
-        v[r] = s4[(r + 1) * ENC_THREADS <= N4 || e < N4 ? e : 0];
-    }
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int e = r * ENC_THREADS + tid;
-        if ((r + 1) * ENC_THREADS <= N4 || e < N4) d4[e] = v[r];
-    }
-}
-
-// features (4 consecutive) held by accumulator registers 4q .. 4q+3 of block blk in lane half h
-__device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 8 * q + 4 * h; }
 
 // ---------------------------------------------------------------------------------------------------------
 // forward
@@ -866,6 +820,22 @@ PIML_API long long piml_encoder_split_tiles(long long tiles) {
     return old;
 }
 
+// products of the two 128 x 128 layers: 1 = split bf16 products (encoder_x3.hip, f32-exact to one rounding per product),
+// 0 = the f32 matrix-core instruction (PIML_ENC_PRODUCTS=f32, piml_encoder_products)
+static int g_x3 = getenv("PIML_ENC_PRODUCTS") && getenv("PIML_ENC_PRODUCTS")[0] == 'b';      // opt-in until the dW stage has its split form too
+
+PIML_API int piml_encoder_products(int x3) {
+    const int old = g_x3;
+    if (x3 >= 0) g_x3 = x3 ? 1 : 0;
+    return old;
+}
+
+static int x3_ready() {
+    static int state = -1;
+    if (state < 0) state = enc_x3_set_attributes();
+    return state;
+}
+
 int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
     if (int e = enc_check(br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
@@ -882,6 +852,11 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
     if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         hipLaunchKernelGGL(enc_fwd_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        return hipGetLastError();
+    }
+    if (g_x3) {
+        if (int e = x3_ready()) return e;
+        enc_x3_launch_fwd(A, total, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, s, A);
@@ -903,6 +878,11 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     if ((tiles[0] + tiles[1]) * 4 <= g_split_tiles * 3) {
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         hipLaunchKernelGGL(enc_bwd_dx_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        return hipGetLastError();
+    }
+    if (g_x3) {
+        if (int e = x3_ready()) return e;
+        enc_x3_launch_bwd_dx(A, total, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, s, A);

@@ -1,0 +1,63 @@
+// Shared by the encoder kernels (encoder.hip: f32 matrix-core products; encoder_x3.hip: split bf16 products).
+// Private to libpiml_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pack.hpp"
+#include "../../include/piml_hip.h"
+
+namespace piml {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ENC_THREADS = 512;        // 8 waves per workgroup: 2 per SIMD
+constexpr int ENC_WAVES = ENC_THREADS / 64;
+
+struct EncArgs {
+    piml_encoder_branch br[2];
+    int nbr;
+    int wg_split;       // workgroups [0, wg_split) serve branch 0, the rest branch 1
+    float* zero;        // forward only, optional: a buffer the launch clears on the way (the decoder tails' accumulator)
+    int zero_n;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// store of 4 consecutive floats of a row (non-temporal stores were measured here: forward 47.9 -> 53.7 us, reverted)
+__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
+// Packed image -> LDS, every 16-byte load of the thread issued before the first LDS write.  (As a plain loop this
+// compiled to load / s_waitcnt vmcnt(0) / ds_write per iteration: 17 serialised L2 round trips in front of every
+// workgroup's first MFMA.)
+template <int NFLOATS>
+__device__ __forceinline__ void stage_linear(float* lds, const float* __restrict__ src, int tid) {
+    constexpr int N4 = NFLOATS / 4, ROUNDS = (N4 + ENC_THREADS - 1) / ENC_THREADS;
+    static_assert(NFLOATS % 4 == 0, "float4 granularity");
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(lds);
+    float4 v[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        v[r] = s4[(r + 1) * ENC_THREADS <= N4 || e < N4 ? e : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        if ((r + 1) * ENC_THREADS <= N4 || e < N4) d4[e] = v[r];
+    }
+}
+
+// features (4 consecutive) held by accumulator registers 4q .. 4q+3 of block blk in lane half h
+__device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 8 * q + 4 * h; }
+
+// encoder_x3.hip: the same stages on split bf16 products (launch only; arguments checked by the callers in encoder.hip)
+int enc_x3_set_attributes();
+void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s);
+void enc_x3_launch_bwd_dx(const EncArgs& A, int total, hipStream_t s);
+
+}  // namespace piml

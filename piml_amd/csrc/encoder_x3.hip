@@ -1,0 +1,474 @@
+// The PINNSF encoder stages on SPLIT bf16 products: every f32 product w * x of the two 128 x 128 layers is evaluated as
+//     (w_hi + w_mid + w_lo) * (x_hi + x_mid + x_lo),   each piece a bf16, the three summing to the f32 value EXACTLY
+// (pack.hpp: split3), keeping the six partial products whose magnitude is >= 2^-16 of the full one:
+//     w_lo x_hi + w_mid x_mid + w_hi x_lo  +  w_mid x_hi + w_hi x_mid  +  w_hi x_hi.
+// A bf16 x bf16 product is exact in f32 and the matrix core accumulates in f32, so what is dropped (w_mid x_lo, w_lo x_mid,
+// w_lo x_lo) is <= 3 * 2^-24 of |w x| per product: the rounding of ONE f32 multiply.  The results sit as close to the
+// float64 product as those of the f32 matrix-core kernels in encoder.hip do (tests/test_encoder_gpu.py measures both) --
+// this is f32 arithmetic carried by v_mfma_f32_32x32x16_bf16, which retires a 32x32x16 block in 32 cycles where
+// v_mfma_f32_32x32x2_f32 needs 8 x 64: six of them per k-block = 192 cycles against 512.
+//
+// Same formulation as encoder.hip (transposed product, a tile's activations stay in registers between layers):
+// accumulator registers 8 s .. 8 s + 7 of block bp, split into their three pieces and packed pairwise, ARE the B operand
+// of k-block kb = 2 bp + s of the next layer (k order inside the block: element t of lane half h = feature
+// 16 kb + 8 (t >> 2) + 4 h + (t & 3)); the weights are packed once per step in that k order, already split.
+// Reference arithmetic: src/models/model.py:40-65, :1271-1283 (see encoder.hip).
+#include "common.hpp"
+#include "encoder.hpp"
+
+namespace piml {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // register arrays of HIP's u32x4 struct were left in scratch
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// the three pieces of a whole 32 x 128 activation tile: B operands of the 8 k-blocks
+struct Pieces {
+    u32x4 hi[8], mid[8], lo[8];
+};
+
+__device__ __forceinline__ void split_tile(const f32x16 (&in)[4], Pieces& P) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const f32x16& a = in[kb >> 1];
+        const int r = 8 * (kb & 1);
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(a[r + 2 * d], a[r + 2 * d + 1], hi[d], mid[d], lo[d]);
+        P.hi[kb] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        P.mid[kb] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+        P.lo[kb] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
+// The six products of one k-block.  The matrix core adds the 16 products of an instruction and the accumulator with the
+// low bits of the aligned addends cut off, not rounded (measured: sums over many rows of x3 results drift by ~0.5 ulp of
+// the accumulator per instruction, all in one direction), so the five small terms (<= 2^-8 of the product) go to a second
+// accumulator, where that cut is 2^-8 smaller still, and only w_hi x_hi -- eight instructions per output, against the 128
+// roundings of an f32 fmaf chain -- touches the main one.  The two are added once per output block.
+__device__ __forceinline__ void kblock_x3(f32x16& acc, f32x16& small, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 xh, u32x4 xm, u32x4 xl) {
+    small = mfma_bf(wl, xh, small);
+    small = mfma_bf(wm, xm, small);
+    small = mfma_bf(wh, xl, small);
+    small = mfma_bf(wm, xh, small);
+    small = mfma_bf(wh, xm, small);
+    acc = mfma_bf(wh, xh, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+// LDS (u32x4 units unless noted): W2 image whole [HM 4096 | LO 2048] | W3 HM of fragments 0 .. 28 [29][2][64] |
+// W1 fragments 1024 floats | b1 b2 b3 384 floats   = 163 328 B of the CU's 163 840.  The W3 LO pieces (one of the six
+// products reads them) and the hi / mid pieces of W3's last three fragments come from the packed image in L2, requested
+// one output block ahead.
+constexpr int X3_FB3 = 29;
+constexpr int X3_FWD_W3 = X3_IMG / 4;                        // u32x4 offset of the W3 HM part
+constexpr int X3_FWD_F32 = X3_IMG + X3_FB3 * 2 * 64 * 4;     // float offset of W1 fragments + biases
+constexpr int X3_FWD_LDS_BYTES = (X3_FWD_F32 + 1024 + 384) * 4;
+static_assert(X3_FWD_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+
+constexpr int W3_N4 = X3_FB3 * 2 * 64, W3_ROUNDS = (W3_N4 + ENC_THREADS - 1) / ENC_THREADS;
+
+__device__ __forceinline__ void load_x(float (&xb)[4], const float* __restrict__ x, long long tile, long long ntiles, long long R,
+                                       int IN, int lane) {
+    const long long row = tile * 32 + (lane & 31);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 2 * s + (lane >> 5);
+        xb[s] = (tile < ntiles && row < R && c < IN) ? x[row * IN + c] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void land_w3(const u32x4 (&w3r)[W3_ROUNDS], float* lds, int tid) {
+    u32x4* dst = reinterpret_cast<u32x4*>(lds) + X3_FWD_W3;
+#pragma unroll
+    for (int r = 0; r < W3_ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        if (e < W3_N4) dst[e] = w3r[r];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if (A.zero)
+        for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+
+    const float* x3 = J.packed + PACK_F32;
+    // the first tile's input row: requested before the staging loads (vmcnt retires in order)
+    float xb[4];
+    load_x(xb, J.x, first, ntiles, R, IN, lane);
+    stage_linear<X3_IMG>(lds, x3, tid);
+    stage_linear<1024 + 384>(lds + X3_FWD_F32, J.packed + 32768, tid);
+    __syncthreads();
+    // W3's LDS part stays in flight (in registers) behind layers 1 and 2 of the first tile
+    u32x4 w3r[W3_ROUNDS];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(x3 + X3_IMG);
+#pragma unroll
+        for (int r = 0; r < W3_ROUNDS; ++r) {
+            const int e = r * ENC_THREADS + tid;
+            w3r[r] = src[e < W3_N4 ? e : 0];
+        }
+    }
+    bool w3_pending = true;
+
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        // the operand addresses are made opaque per tile: as loop invariants the compiler hoists the bias and fragment
+        // reads of the whole tile out of the loop and spills them
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const u32x4* W2hm = reinterpret_cast<const u32x4*>(lds) + lane_t;
+        const u32x4* W2lo = W2hm + X3_HM / 4;
+        const u32x4* W3hm = reinterpret_cast<const u32x4*>(lds) + X3_FWD_W3 + lane_t;
+        const u32x4* W3hm_g = reinterpret_cast<const u32x4*>(x3 + X3_IMG) + lane_t;
+        const u32x4* W3lo_g = W3hm_g + X3_HM / 4;
+        const float* W1f = lds + X3_FWD_F32;
+        const float* bias = W1f + 1024;
+        const int j = lane_t & 31, h = lane_t >> 5;
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        f32x16 a[4];
+        Pieces P;
+        // ---- layer 1: K = in_dim (padded to 8), f32 products (3 % of the tile's matrix cycles) ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + feat0(blk, q, h));
+                a[blk][4 * q + 0] = bq.x; a[blk][4 * q + 1] = bq.y; a[blk][4 * q + 2] = bq.z; a[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[blk] = mfma32(W1f[(blk * 4 + s) * 64 + lane_t], xb[s], a[blk]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[blk][r] = fmaxf(a[blk][r], 0.f);
+        }
+        if (J.h1 && valid) {
+            float* o = J.h1 + row * EH;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4_stream(o + feat0(blk, q, h), a[blk][4 * q], a[blk][4 * q + 1], a[blk][4 * q + 2], a[blk][4 * q + 3]);
+        }
+        split_tile(a, P);
+        // ---- layer 2 (a is dead: reused for the outputs) ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 128 + feat0(blk, q, h));
+                acc[4 * q + 0] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                kblock_x3(acc, sm, W2hm[(fb * 2) * 64], W2hm[(fb * 2 + 1) * 64], W2lo[fb * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+            a[blk] = acc;
+            if (J.h2 && valid) {
+                float* o = J.h2 + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        if (w3_pending) {
+            land_w3(w3r, lds, tid);
+            w3_pending = false;
+        }
+        // ---- layer 3 (no activation), msgs = scale * output ----
+        u32x4 lw[2][8];              // LO pieces of W3, one output block ahead
+        u32x4 tail[6];               // hi / mid of fragments 29 .. 31 (block 3, k-blocks 5 .. 7)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) lw[0][kb] = W3lo_g[kb * 64];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) tail[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
+        load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
+        split_tile(a, P);
+        const float scale = J.scale;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            if (blk < 3) {
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) lw[(blk + 1) & 1][kb] = W3lo_g[((blk + 1) * 8 + kb) * 64];
+            }
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 256 + feat0(blk, q, h));
+                acc[4 * q + 0] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                const u32x4 wh = fb < X3_FB3 ? W3hm[(fb * 2) * 64] : tail[fb < X3_FB3 ? 0 : (fb - X3_FB3) * 2];
+                const u32x4 wm = fb < X3_FB3 ? W3hm[(fb * 2 + 1) * 64] : tail[fb < X3_FB3 ? 0 : (fb - X3_FB3) * 2 + 1];
+                kblock_x3(acc, sm, wh, wm, lw[blk & 1][kb], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+            if (valid) {
+                float* o = J.msgs + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4_stream(o + feat0(blk, q, h), scale * acc[4 * q], scale * acc[4 * q + 1], scale * acc[4 * q + 2], scale * acc[4 * q + 3]);
+            }
+        }
+    }
+    if (w3_pending) land_w3(w3r, lds, tid);       // a wave without a tile: the barrier still counts it
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, part 1: the dX chain (see enc_bwd_dx_kernel in encoder.hip for the arithmetic)
+// ---------------------------------------------------------------------------------------------------------
+// LDS: W3^T image whole [HM 4096 | LO 2048 u32x4] | W2^T HM of fragments 0 .. 29 [30][2][64] u32x4 | W1 rows [f 128][8]
+// floats = 163 840 B, all of the CU's.  W2^T's LO pieces and the hi / mid of its last two fragments come from L2.
+constexpr int X3_FB2T = 30;
+constexpr int X3_DX_W2T = X3_IMG / 4;                         // u32x4 offset of the W2^T HM part
+constexpr int X3_DX_F32 = X3_IMG + X3_FB2T * 2 * 64 * 4;      // float offset of the W1 rows
+constexpr int X3_DX_LDS_BYTES = (X3_DX_F32 + 1024) * 4;
+static_assert(X3_DX_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+constexpr int W2T_N4 = X3_FB2T * 2 * 64, W2T_ROUNDS = (W2T_N4 + ENC_THREADS - 1) / ENC_THREADS;
+
+__device__ __forceinline__ void land_w2t(const u32x4 (&w)[W2T_ROUNDS], float* lds, int tid) {
+    u32x4* dst = reinterpret_cast<u32x4*>(lds) + X3_DX_W2T;
+#pragma unroll
+    for (int r = 0; r < W2T_ROUNDS; ++r) {
+        const int e = r * ENC_THREADS + tid;
+        if (e < W2T_N4) dst[e] = w[r];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim, K = J.k;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;
+
+    const float* x3 = J.packed + PACK_F32;
+    const bool want_gx = J.g_x != nullptr;
+    stage_linear<X3_IMG>(lds, x3 + 2 * X3_IMG, tid);
+    stage_linear<1024>(lds + X3_DX_F32, J.packed + PACK_FWD + 32768, tid);
+    __syncthreads();
+    u32x4 w2r[W2T_ROUNDS];       // W2^T's LDS part: in flight behind the first tile's first layer
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(x3 + 3 * X3_IMG);
+#pragma unroll
+        for (int r = 0; r < W2T_ROUNDS; ++r) {
+            const int e = r * ENC_THREADS + tid;
+            w2r[r] = src[e < W2T_N4 ? e : 0];
+        }
+    }
+    bool w2_pending = true;
+
+    const float scale = J.scale;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        int lane_t = lane;           // opaque per tile (see enc_fwd_x3_kernel)
+        asm volatile("" : "+v"(lane_t));
+        const u32x4* W3hm = reinterpret_cast<const u32x4*>(lds) + lane_t;
+        const u32x4* W3lo = W3hm + X3_HM / 4;
+        const u32x4* W2hm = reinterpret_cast<const u32x4*>(lds) + X3_DX_W2T + lane_t;
+        const u32x4* W2hm_g = reinterpret_cast<const u32x4*>(x3 + 3 * X3_IMG) + lane_t;
+        const u32x4* W2lo_g = W2hm_g + X3_HM / 4;
+        const float4* W1r = reinterpret_cast<const float4*>(lds + X3_DX_F32);      // row f = float4 2 f, 2 f + 1
+        const int j = lane_t & 31, h = lane_t >> 5;
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        f32x16 g[4];
+        Pieces P;
+        // ---- g3 in registers ----
+        {
+            const float* gp = (J.g_pooled && valid) ? J.g_pooled + (row / K) * EH : nullptr;
+            const float* gm = (J.g_msgs && valid) ? J.g_msgs + row * EH : nullptr;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gp) v = *reinterpret_cast<const float4*>(gp + feat0(blk, q, h));
+                    if (gm) {
+                        const float4 m = *reinterpret_cast<const float4*>(gm + feat0(blk, q, h));
+                        v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+                    }
+                    g[blk][4 * q + 0] = scale * v.x; g[blk][4 * q + 1] = scale * v.y;
+                    g[blk][4 * q + 2] = scale * v.z; g[blk][4 * q + 3] = scale * v.w;
+                }
+        }
+        split_tile(g, P);
+        // ---- g_h2 = W3^T g3, masked by h2 -> g2 (g is dead: reused) ----
+        const float* hp2 = J.h2 + (valid ? row : 0) * EH;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            __builtin_amdgcn_sched_barrier(0);
+            float4 hv[4];                                   // this block's h2 values: in flight during the MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp2 + feat0(blk, q, h));
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                kblock_x3(acc, sm, W3hm[(fb * 2) * 64], W3hm[(fb * 2 + 1) * 64], W3lo[fb * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = hv[q];
+                acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
+                acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
+                acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
+                acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+            }
+            g[blk] = acc;
+            if (valid) {
+                float* o = J.g2 + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        if (w2_pending) {
+            land_w2t(w2r, lds, tid);
+            w2_pending = false;
+        }
+        // ---- g_h1 = W2^T g2, masked by h1 -> g1; g_x = W1^T g1 block by block on the vector pipe ----
+        u32x4 lw[2][8];              // LO pieces of W2^T, one output block ahead
+        u32x4 tail[4];               // hi / mid of fragments 30, 31 (block 3, k-blocks 6, 7)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) lw[0][kb] = W2lo_g[kb * 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tail[u] = W2hm_g[(X3_FB2T * 2 + u) * 64];
+        split_tile(g, P);
+        const float* hp1 = J.h1 + (valid ? row : 0) * EH;
+        float gx[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) gx[c] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            __builtin_amdgcn_sched_barrier(0);
+            float4 hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp1 + feat0(blk, q, h));
+            if (blk < 3) {
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) lw[(blk + 1) & 1][kb] = W2lo_g[((blk + 1) * 8 + kb) * 64];
+            }
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                const u32x4 wh = fb < X3_FB2T ? W2hm[(fb * 2) * 64] : tail[fb < X3_FB2T ? 0 : (fb - X3_FB2T) * 2];
+                const u32x4 wm = fb < X3_FB2T ? W2hm[(fb * 2 + 1) * 64] : tail[fb < X3_FB2T ? 0 : (fb - X3_FB2T) * 2 + 1];
+                kblock_x3(acc, sm, wh, wm, lw[blk & 1][kb], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = hv[q];
+                acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
+                acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
+                acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
+                acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+            }
+            if (valid) {
+                float* o = J.g1 + row * EH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+            // lane (row, h) holds half of the row's g1 features: 8 partial dot products over them (explicit FMAs, the
+            // order of enc_bwd_dx_kernel), the other half arrives with one cross-half exchange after the last block
+            if (want_gx) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __builtin_amdgcn_sched_barrier(0);      // 8 LDS reads in flight per group
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int f = feat0(blk, q, h) + u;
+                        const float4 wa = W1r[2 * f], wb = W1r[2 * f + 1];
+                        const float v = acc[4 * q + u];
+                        gx[0] = __fmaf_rn(wa.x, v, gx[0]); gx[1] = __fmaf_rn(wa.y, v, gx[1]);
+                        gx[2] = __fmaf_rn(wa.z, v, gx[2]); gx[3] = __fmaf_rn(wa.w, v, gx[3]);
+                        gx[4] = __fmaf_rn(wb.x, v, gx[4]); gx[5] = __fmaf_rn(wb.y, v, gx[5]);
+                        gx[6] = __fmaf_rn(wb.z, v, gx[6]); gx[7] = __fmaf_rn(wb.w, v, gx[7]);
+                    }
+                }
+            }
+        }
+        if (want_gx) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) gx[c] += __shfl_xor(gx[c], 32, 64);
+            if (valid) {       // half h stores input features 4 h .. 4 h + 3
+                float* o = J.g_x + row * IN + 4 * h;
+                const int left = IN - 4 * h;       // scalar selects (an array select goes through scratch)
+                const float s0 = h ? gx[4] : gx[0], s1 = h ? gx[5] : gx[1], s2 = h ? gx[6] : gx[2], s3 = h ? gx[7] : gx[3];
+                if (left > 0) o[0] = s0;
+                if (left > 1) o[1] = s1;
+                if (left > 2) o[2] = s2;
+                if (left > 3) o[3] = s3;
+            }
+        }
+    }
+    if (w2_pending) land_w2t(w2r, lds, tid);       // a wave without a tile: the barrier still counts it
+}
+
+int enc_x3_set_attributes() {
+    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    X3_DX_LDS_BYTES))
+        return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               X3_FWD_LDS_BYTES);
+}
+
+void enc_x3_launch_bwd_dx(const EncArgs& A, int total, hipStream_t s) {
+    hipLaunchKernelGGL(enc_bwd_dx_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
+}
+
+void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s) {
+    hipLaunchKernelGGL(enc_fwd_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
+}
+
+}  // namespace piml

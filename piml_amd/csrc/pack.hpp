@@ -23,10 +23,56 @@ constexpr int DEC_PART = DD * DH + DD * DD + 2 * DD + DD + DD + 8;     // decode
 //   [ W3^T fragments 16384 | W2^T fragments 16384 | W1 rows padded to 8 columns 1024 ]    dX image
 constexpr int PACK_FWD = 16384 * 2 + 1024 + 384;
 constexpr int PACK_DX = 16384 * 2 + 1024;
-constexpr int PACK_FLOATS = PACK_FWD + PACK_DX;
+constexpr int PACK_F32 = PACK_FWD + PACK_DX;
+
+// ---- split-product ("x3") images: every f32 weight as three bf16 pieces hi + mid + lo = the f32 value exactly ----
+// (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid): 3 x 8 significand bits + round-to-nearest signs cover the 24
+// of an f32.)  A-fragments of v_mfma_f32_32x32x16_bf16: fragment fb = 8 blk + kb = (out block blk, k-block kb), lane
+// (i, h) holds 8 bf16 = one uint4, element t = W[32 blk + i][16 kb + 8 (t >> 2) + 4 h + (t & 3)] -- the k order in which
+// a 32x32 accumulator's registers 8 (kb & 1) .. + 7 of block kb >> 1 hold the features (see encoder.hip).  One image
+// (dwords): [ HM: fb 32 ][ p 2 (hi, mid) ][ lane 64 ][ 4 ]  |  [ LO: fb 32 ][ lane 64 ][ 4 ]; the transposed images hold
+// W^T the same way (blk = input block of W, kb = k-block over W's outputs).
+constexpr int X3_HM = 32 * 2 * 64 * 4;          // 16384 dwords
+constexpr int X3_LO = 32 * 64 * 4;              //  8192 dwords
+constexpr int X3_IMG = X3_HM + X3_LO;           // 24576 dwords = 96 KB
+constexpr int PACK_X3 = 4 * X3_IMG;             // W2 | W3 | W3^T | W2^T
+constexpr int PACK_FLOATS = PACK_F32 + PACK_X3;
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// two f32 -> one dword of two bf16 (round to nearest even; a in the low half)
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+// the three bf16 pieces of two f32 values, packed pairwise; the remainders are exact in f32
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = bf16_pair(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = bf16_pair(ra, rb);
+    lo = bf16_pair(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+}
+
+__device__ __forceinline__ unsigned pack_bits_x3(const piml_encoder_branch& J, int e) {
+    const int img = e / X3_IMG, g = e - img * X3_IMG;
+    const bool tr = img >= 2;
+    const float* W = (img == 0 || img == 3) ? J.w2 : J.w3;
+    const int d = g & 3, lane = (g >> 2) & 63;
+    int p, fb;
+    if (g < X3_HM) { p = (g >> 8) & 1; fb = g >> 9; }
+    else { p = 2; fb = (g - X3_HM) >> 8; }
+    const int blk = fb >> 3, kb = fb & 7, i = 32 * blk + (lane & 31);
+    const int c = 16 * kb + 8 * (d >> 1) + 4 * (lane >> 5) + 2 * (d & 1);       // t = 2 d, 2 d + 1
+    const float a = tr ? W[(size_t)c * EH + i] : W[(size_t)i * EH + c];
+    const float b = tr ? W[(size_t)(c + 1) * EH + i] : W[(size_t)i * EH + c + 1];
+    unsigned hi, mid, lo;
+    split3(a, b, hi, mid, lo);
+    return p == 0 ? hi : (p == 1 ? mid : lo);
+}
 
 __device__ __forceinline__ float pack_value(const piml_encoder_branch& J, int e) {
     const int IN = J.in_dim;
+    if (e >= PACK_F32) return __uint_as_float(pack_bits_x3(J, e - PACK_F32));
     if (e < 32768 || (e >= PACK_FWD && e < PACK_FWD + 32768)) {
         const bool tr = e >= PACK_FWD;
         const int f = tr ? e - PACK_FWD : e;
