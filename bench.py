@@ -571,6 +571,7 @@ def main():
     _phase(f'capture done, mode={mode}')
 
     kernel_ms_samples, overhead_ms_samples = [], []
+    x3_products = bool(_lib.lib().piml_encoder_products(-1))      # split bf16 products (default) or PIML_ENC_PRODUCTS=f32
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
     # 5 samples whatever --steps is.  A sample is ONE extra eager launch of the relfeat forward kernel (same inputs,
@@ -720,7 +721,10 @@ def main():
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
-            'mlp': ('fused f32-MFMA kernels (piml_amd/csrc/encoder.hip, decoder.hip)' if fused_mlp else
+            'mlp': (('fused matrix-core kernels (piml_amd/csrc/encoder_x3.hip: f32 products as six bf16 products of exact '
+                     'three-way splits, f32 accumulation -- closer to float64 than the f32 matrix instruction, '
+                     'tests/test_encoder_gpu.py; decoder.hip: f32 matrix instruction)' if x3_products else
+                     'fused f32-MFMA kernels (piml_amd/csrc/encoder.hip, decoder.hip)') if fused_mlp else
                     f'library GEMMs ({gemm_tuning}) + HIP glue kernels, {2 if two_streams else 1} stream(s)'),
             'config': {'workload': ('cfg3: synthetic 4096-agent GC scene' if (world == 1 and N == 4096) else
                                     f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
@@ -810,6 +814,23 @@ def main():
             secondary = secondary_measurements(scene, n_own, dev, _lib)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
+        if world == 1 and x3_products and fused_mlp:      # the same step with the encoder products on v_mfma_f32_32x32x2_f32
+            try:
+                _lib.lib().piml_encoder_products(0)
+                f32s = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph))
+                f32s.capture()
+                k = max(10, min(args.steps, 50))
+                el = f32s.time_steps(k, 5)
+                secondary['f32_matrix_instruction_step'] = {
+                    'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': f32s.mode,
+                    'note': 'PIML_ENC_PRODUCTS=f32: the encoder layers on v_mfma_f32_32x32x2_f32 (an fmaf chain) instead of '
+                            'split bf16 products; both forms are f32 arithmetic (max error against float64: split 1.5e-7 .. 5e-7, '
+                            'f32 instruction 2.2e-7 .. 5.4e-7 over outputs and gradients, tools/probe_x3.py)'}
+                del f32s
+            except Exception as ex:   # noqa: BLE001 - informational
+                secondary['f32_matrix_instruction_step'] = {'error': f'{type(ex).__name__}: {ex}'}
+            finally:
+                _lib.lib().piml_encoder_products(1)
         if world == 1:       # the same step with the shipped experiments' model (src/configs/exp_configs/piml-*.yaml)
             try:
                 bm = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), model_name='PINNSF_bottleneck_multitask')

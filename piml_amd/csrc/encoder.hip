@@ -822,7 +822,7 @@ PIML_API long long piml_encoder_split_tiles(long long tiles) {
 
 // products of the two 128 x 128 layers: 1 = split bf16 products (encoder_x3.hip, f32-exact to one rounding per product),
 // 0 = the f32 matrix-core instruction (PIML_ENC_PRODUCTS=f32, piml_encoder_products)
-static int g_x3 = getenv("PIML_ENC_PRODUCTS") && getenv("PIML_ENC_PRODUCTS")[0] == 'b';      // opt-in until the dW stage has its split form too
+static int g_x3 = !(getenv("PIML_ENC_PRODUCTS") && getenv("PIML_ENC_PRODUCTS")[0] == 'f');
 
 PIML_API int piml_encoder_products(int x3) {
     const int old = g_x3;
@@ -902,7 +902,10 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
             if (int e = enc_set_lds(f, DW_LDS_FLOATS * 4)) return e;
         attr_set = true;
     }
+    if (g_x3)
+        if (int e = x3_ready()) return e;
     auto launch_dw = [&](const EncArgs& B, int grid) {
+        if (g_x3) return enc_x3_launch_bwd_dw(B, grid, s);
         const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
         if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
         else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);

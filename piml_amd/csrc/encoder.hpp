@@ -59,5 +59,6 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 int enc_x3_set_attributes();
 void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s);
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, hipStream_t s);
+void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
 
 }  // namespace piml

@@ -455,7 +455,215 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
     if (w2_pending) land_w2t(w2r, lds, tid);       // a wave without a tile: the barrier still counts it
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// backward, part 2: dW3 = G3^T H2, dW2 = G2^T H1 (split products), dW1 = G1^T X and the bias gradients (vector pipe),
+// split-K over row slabs, one partial slot per workgroup in enc_bwd_dw_kernel's layout (same slot sum afterwards).
+// ---------------------------------------------------------------------------------------------------------
+// A batch is 16 rows = ONE k-block.  Both operands of a product are data here, so both are split on the way into LDS: a
+// staging thread owns (feature f, row half hh) of a G-side and an H-side array -- eight rows of one column, loaded with
+// eight coalesced dword loads -- and writes their three pieces as the fragment entry of lane (f & 31) + 32 hh of feature
+// block f >> 5 (A operand: G^T, B operand: H; element t of both = row 8 hh + t of the batch).  LDS, per buffer (u32x4):
+// [array 4: G3 G2 H2 H1][piece 3][block 4][lane 64] = 48 KB + the batch's x rows (128 floats); two buffers.
+// Wave (L, iq, jq): layer L (0: dW3, 1: dW2), output blocks {2 iq, 2 iq + 1} x {2 jq, 2 jq + 1}: 24 instructions a batch.
+constexpr int DW_X3_ROWS = 16;
+constexpr int DWX_ARR = 3 * 256;                       // u32x4 of one array's three pieces
+constexpr int DWX_BUF = 4 * DWX_ARR + 32;              // + x rows [16][8] floats
+constexpr int DWX_LDS_BYTES = 2 * DWX_BUF * 16;
+constexpr int DWX_RED = 4 * 128 * 9;                   // floats of the final cross-group exchange (reuses the buffers)
+static_assert(DWX_RED * 4 <= DWX_LDS_BYTES, "exchange fits");
+
+template <bool POOL, bool MSGS>
+__global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const unsigned p = (unsigned)((int)blockIdx.x - wg0);
+    const unsigned R = (unsigned)J.rows;                   // rows < 2^24 (checked on the host): 32-bit indexing
+    const unsigned IN = (unsigned)J.in_dim, K = (unsigned)J.k;
+    const unsigned kmagic = (unsigned)((0x100000000ull + K - 1) / K);      // row / K == umulhi(row, kmagic) for row * K < 2^32
+    unsigned slab = (R + nwg - 1) / nwg;
+    slab = (slab + 1) & ~1u;
+    const unsigned r0 = p * slab < R ? p * slab : R;
+    const unsigned r1 = r0 + slab < R ? r0 + slab : R;
+    const float scale = J.scale;
+    const int L = wave >> 2, iq = (wave >> 1) & 1, jq = wave & 1;
+
+    f32x16 c[2][2], sm[2][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c[u >> 1][u & 1][r] = 0.f; sm[u >> 1][u & 1][r] = 0.f; }
+    // staging role: feature sf, row half sh; waves 0-3 own the G side (G3, G2) and the bias sums, waves 4-7 the H side
+    const unsigned sf = tid & 127, sh = (tid >> 7) & 1;
+    const bool gside = wave < 4;
+    const unsigned slot = (sf >> 5) * 64 + (sf & 31) + 32 * sh;
+    // dW1 / db1 role: feature sf, rows 4 rg .. 4 rg + 3 of the batch
+    const unsigned rg = tid >> 7;
+    float s3 = 0.f, s2 = 0.f, s1 = 0.f;
+    float w1[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) w1[cc] = 0.f;
+    const float* __restrict__ gpool = J.g_pooled;
+    const float* __restrict__ gmsg = J.g_msgs;
+    const float* __restrict__ arr0 = gside ? (POOL ? gpool : gmsg) : J.h2;      // first unit of the thread: G3's source or H2
+    const bool pooled0 = gside && POOL;
+    const float* __restrict__ arr1 = gside ? J.g2 : J.h1;      // second unit
+    const float* __restrict__ G1 = J.g1;
+    const float* __restrict__ X = J.x;
+    const unsigned xrow = tid >> 3, xc = tid & 7;            // threads 0..127: the x rows
+
+    struct Stage { float a[8], m[8], v[8], g1[4], x; };
+    auto stage_load = [&](unsigned rb) -> Stage {            // issue the global loads of the batch starting at row rb
+        Stage S;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned row = rb + 8 * sh + t;
+            const unsigned ro = row < r1 ? row : r0;         // clamped: a readable row (r0 < R whenever a batch exists)
+            // unconditional loads through selected pointers (a branch around a load is awaited at the join)
+            S.a[t] = arr0[(pooled0 ? __umulhi(ro, kmagic) : ro) * EH + sf];
+            S.m[t] = 0.f;
+            if (POOL && MSGS)
+                if (gside) S.m[t] = gmsg[ro * EH + sf];
+            S.v[t] = arr1[ro * EH + sf];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned row = rb + 4 * rg + t;
+            S.g1[t] = G1[(row < r1 ? row : r0) * EH + sf];
+        }
+        const unsigned xr = rb + xrow;
+        S.x = (tid < 128 && xr < r1 && xc < IN) ? X[xr * IN + xc] : 0.f;
+        return S;
+    };
+    float gq[4];                                             // g1 values of the batch in the compute phase
+    auto stage_write = [&](const Stage& S, unsigned rb, float* buf) {     // registers -> split -> LDS (rows past the slab are zeros)
+        u32x4* B = reinterpret_cast<u32x4*>(buf);
+        float u0[8], u1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = rb + 8 * sh + t < r1;
+            const float a = gside ? (S.a[t] + S.m[t]) * scale : S.a[t];
+            u0[t] = ok ? a : 0.f;
+            u1[t] = ok ? S.v[t] : 0.f;
+        }
+        if (gside) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { s3 += u0[t]; s2 += u1[t]; }
+        }
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(u0[2 * d], u0[2 * d + 1], hi[d], mid[d], lo[d]);
+        u32x4* d0 = B + (gside ? 0 : 2) * DWX_ARR + slot;
+        d0[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        d0[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+        d0[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(u1[2 * d], u1[2 * d + 1], hi[d], mid[d], lo[d]);
+        u32x4* d1 = d0 + DWX_ARR;
+        d1[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        d1[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+        d1[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        if (tid < 128) buf[4 * DWX_ARR * 4 + tid] = S.x;
+    };
+    auto take_g1 = [&](const Stage& S, unsigned rb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gq[t] = rb + 4 * rg + t < r1 ? S.g1[t] : 0.f;
+    };
+    auto compute = [&](const float* buf) {
+        const u32x4* B = reinterpret_cast<const u32x4*>(buf);
+        const u32x4* Ap = B + (L ? 1 : 0) * DWX_ARR + (2 * iq) * 64 + lane;
+        const u32x4* Bp = B + (L ? 3 : 2) * DWX_ARR + (2 * jq) * 64 + lane;
+        u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ah[u] = Ap[u * 64]; am[u] = Ap[256 + u * 64]; al[u] = Ap[512 + u * 64];
+            bh[u] = Bp[u * 64]; bm[u] = Bp[256 + u * 64]; bl[u] = Bp[512 + u * 64];
+        }
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) kblock_x3(c[ia][jb], sm[ia][jb], ah[ia], am[ia], al[ia], bh[jb], bm[jb], bl[jb]);
+        // dW1 / db1: rows 4 rg .. 4 rg + 3 of the batch
+        const float4* xr = reinterpret_cast<const float4*>(buf + 4 * DWX_ARR * 4 + rg * 32);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 xa = xr[2 * t], xb = xr[2 * t + 1];
+            const float g = gq[t];
+            w1[0] = __fmaf_rn(g, xa.x, w1[0]); w1[1] = __fmaf_rn(g, xa.y, w1[1]);
+            w1[2] = __fmaf_rn(g, xa.z, w1[2]); w1[3] = __fmaf_rn(g, xa.w, w1[3]);
+            w1[4] = __fmaf_rn(g, xb.x, w1[4]); w1[5] = __fmaf_rn(g, xb.y, w1[5]);
+            w1[6] = __fmaf_rn(g, xb.z, w1[6]); w1[7] = __fmaf_rn(g, xb.w, w1[7]);
+            s1 += g;
+        }
+    };
+    if (r0 < r1) {
+        const unsigned nb = (r1 - r0 + DW_X3_ROWS - 1) / DW_X3_ROWS;
+        {
+            const Stage S = stage_load(r0);
+            stage_write(S, r0, lds);
+            take_g1(S, r0);
+        }
+        __syncthreads();
+        for (unsigned t = 0; t < nb; ++t) {
+            float* cur = lds + (t & 1) * DWX_BUF * 4;
+            float* nxt = lds + ((t + 1) & 1) * DWX_BUF * 4;
+            const unsigned rb = r0 + (t + 1) * DW_X3_ROWS;
+            const Stage S = stage_load(rb);                  // past the slab: clamped + zeroed, written but never read
+            __builtin_amdgcn_sched_barrier(0);               // (see enc_bwd_dw_kernel: the next batch's loads are not awaited here)
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_write(S, rb, nxt);
+            take_g1(S, rb);
+            __syncthreads();
+        }
+    }
+    float* P = J.partials + (size_t)p * ENC_PART;
+    const int n = lane & 31, h = lane >> 5;
+    // accumulator (ia, jb), register r, lane (n, h): dW[32 (2 iq + ia) + (r & 3) + 8 (r >> 2) + 4 h][32 (2 jq + jb) + n]
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = 32 * (2 * iq + ia) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                P[L * 16384 + (size_t)orow * EH + 32 * (2 * jq + jb) + n] = c[ia][jb][r] + sm[ia][jb][r];
+            }
+    // dW1 and the bias gradients: partial sums of the row groups / row halves meet in LDS (the batch buffers are dead)
+    __syncthreads();
+    {
+        float* red = lds + (rg * 128 + sf) * 9;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) red[cc] = w1[cc];
+        red[8] = s1;
+        float* red2 = lds + DWX_RED + (sh * 128 + sf) * 2;
+        if (gside) { red2[0] = s3; red2[1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float acc[9];
+#pragma unroll
+        for (int cc = 0; cc < 9; ++cc)
+            acc[cc] = (lds[(0 * 128 + tid) * 9 + cc] + lds[(1 * 128 + tid) * 9 + cc]) + (lds[(2 * 128 + tid) * 9 + cc] + lds[(3 * 128 + tid) * 9 + cc]);
+        float* o = P + 32768 + tid * IN;                  // dW1 row-major (128, in_dim) at the head of its 1024 floats
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+            if ((unsigned)cc < IN) o[cc] = acc[cc];
+        P[32768 + 1024 + 256 + tid] = acc[8];
+        P[32768 + 1024 + tid] = lds[DWX_RED + tid * 2] + lds[DWX_RED + (128 + tid) * 2];
+        P[32768 + 1024 + 128 + tid] = lds[DWX_RED + tid * 2 + 1] + lds[DWX_RED + (128 + tid) * 2 + 1];
+    }
+}
+
 int enc_x3_set_attributes() {
+    const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true>)};
+    for (const void* f : dw)
+        if (int e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DWX_LDS_BYTES)) return e;
     if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     X3_DX_LDS_BYTES))
         return e;
@@ -465,6 +673,13 @@ int enc_x3_set_attributes() {
 
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, hipStream_t s) {
     hipLaunchKernelGGL(enc_bwd_dx_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
+}
+
+void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, hipStream_t s) {
+    const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
+    if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
+    else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
+    else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
 }
 
 void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s) {

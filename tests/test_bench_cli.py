@@ -48,7 +48,7 @@ def test_committed_step_counters_are_physical():
     j = json.load(open(path))
     assert j['config'] == {'agents_total': 4096, 'obstacle_points': 2000}
     names = [k['name'] for k in j['all_step_kernels']]
-    for need in ('relfeat_fwd_kernel', 'enc_fwd_kernel', 'enc_bwd_dx_kernel', 'enc_bwd_dw_kernel', 'dec_fwd_head_kernel',
+    for need in ('relfeat_fwd_kernel', 'enc_fwd_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw_x3_kernel', 'dec_fwd_head_kernel',
                  'pinnsf_reduce_kernel', 'pinnsf_pack_kernel'):
         assert need in names
     for k in j['all_step_kernels']:

@@ -1,4 +1,5 @@
-"""GPU: the fused f32-MFMA encoder kernels (piml_amd/csrc/encoder.hip, ops.fused_encoders) against a float64
+"""GPU: the fused encoder kernels (piml_amd/csrc/encoder_x3.hip: split bf16 products, the default; encoder.hip: the f32
+matrix instruction; ops.fused_encoders) against a float64
 restatement of the reference's arithmetic -- src/models/model.py:40-65 (Linear / ReLU chain), :82-119 (processor =
 2 x, quirk Q3), :1279-1283 (sum over the k neighbours) -- for outputs and every gradient.  Tolerance: 1e-5 relative
 to the tensor's largest magnitude (north-star bar); the measured error is printed."""
@@ -431,6 +432,7 @@ def test_split_tile_forward_is_bitwise_the_one_wave_forward(agents):
     leaves = [t for br in brs for t in (br['x'], *br['weights'])]
     res = {}
     old = L.piml_encoder_split_tiles(-1)
+    old_products = L.piml_encoder_products(0)        # the four-wave kernels use the f32 matrix instruction: compare like with like
     try:
         for split in (True, False):
             L.piml_encoder_split_tiles(1 << 30 if split else 0)
@@ -439,6 +441,45 @@ def test_split_tile_forward_is_bitwise_the_one_wave_forward(agents):
             res[split] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
     finally:
         L.piml_encoder_split_tiles(old)
+        L.piml_encoder_products(old_products)
     assert len(res[True]) == len(res[False])
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_split_bf16_products_are_f32_arithmetic():
+    """encoder_x3.hip evaluates every f32 product of the two 128 x 128 layers as six bf16 x bf16 partial products of exact
+    three-way splits (hi + mid + lo == the f32 value), accumulated in f32, instead of one v_mfma_f32_32x32x2_f32 step.
+    The claim that this IS f32 arithmetic is measured here: at the bench shape (4096 agents, one-wave kernels, both
+    branches) outputs and every gradient of both forms against float64.  Bars: the split form within 1e-6 of float64 on
+    every tensor (north-star bar: 1e-5) and not further from float64 than 1.5 x the f32 instruction's error + 1e-7."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    shapes = [(4096, 12, 6), (4096, 4, 6)]
+    brs = [make_branch(n, k, d, seed=3 + i) for i, (n, k, d) in enumerate(shapes)]
+    gen = torch.Generator().manual_seed(5)
+    gps = [torch.randn(n, H, generator=gen).to(DEV) for n, _, _ in shapes]
+    refs = [reference(br, None, gp) for br, gp in zip(brs, gps)]
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    names = ('msgs', 'pooled', 'g_x', 'dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3')
+    err = {}
+    old = L.piml_encoder_products(-1)
+    try:
+        for mode in (0, 1):
+            L.piml_encoder_products(mode)
+            outs = ops.fused_encoders(brs)
+            grads = torch.autograd.grad(sum((p * gp).sum() for (m, p), gp in zip(outs, gps)), leaves)
+            worst = dict.fromkeys(names, 0.0)
+            for i, ((m, p), ref) in enumerate(zip(outs, refs)):
+                got = (m.detach(), p.detach(), *grads[7 * i:7 * i + 7])
+                want = (ref[0], ref[1], ref[2], *ref[3])
+                for nm, a, b in zip(names, got, want):
+                    worst[nm] = max(worst[nm], relerr(a, b))
+            err[mode] = worst
+    finally:
+        L.piml_encoder_products(old)
+    for mode, label in ((0, 'f32 instruction'), (1, 'split bf16    ')):
+        print(f'{label}: max rel err vs float64 ' + ', '.join(f'{k} {v:.1e}' for k, v in err[mode].items()))
+    for nm in names:
+        assert err[1][nm] <= 1e-6, (nm, err[1][nm])
+        assert err[1][nm] <= 1.5 * err[0][nm] + 1e-7, (nm, err[1][nm], err[0][nm])

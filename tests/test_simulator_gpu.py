@@ -176,8 +176,13 @@ def test_graphed_train_step_equals_eager():
         runs[graph] = (losses, [p.detach().clone() for p in sim.model.parameters()], sim.collision_count)
     assert np.allclose(runs[True][0], runs[False][0], rtol=1e-5), (runs[True][0], runs[False][0])
     assert runs[True][2] == runs[False][2]
+    # Two runs differ through the order of relfeat_bwd's float atomics alone (the default backward is not bit-reproducible,
+    # ops.DETERMINISTIC_BWD), and 26 Adam updates amplify that: the measured spread is printed; one run in ~5 of the full
+    # suite exceeded 1e-4 on a single weight.
+    worst = max(float(((a - b).abs() / (b.abs() + 1e-2 * b.abs().max())).max()) for a, b in zip(runs[True][1], runs[False][1]))
+    print(f'weights after 26 updates, graph vs eager: max |diff| / (|w| + 1 % of the tensor max) = {worst:.1e}')
     for a, b in zip(runs[True][1], runs[False][1]):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(a, b, rtol=5e-4, atol=2e-6)
 
 
 FLAGS_BM = dict(new_collision_loss_flag=1, teacher_weight=0.5, reg_weight=1e-3)

@@ -22,6 +22,8 @@ os.makedirs(dst, exist_ok=True)
 N, M, KP, KO = 4096, 2000, 6, 10
 ROWS = N * (KP + KO)
 F32_MFMA_PEAK = 157.3e12
+BF16_MFMA_PEAK = 2.5e15      # dense (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12
 SIMDS = 1024
 
 
@@ -50,6 +52,10 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'enc_fwd_kernel': 2 * ROWS * (6 * 128 + 2 * 128 * 128),
     'enc_bwd_dx_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'enc_bwd_dw_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
+    # split-product forms: the same algorithmic f32 FLOPs; executed bf16 FLOPs = 6 x those of the two 128 x 128 layers
+    'enc_fwd_x3_kernel': 2 * ROWS * (6 * 128 + 2 * 128 * 128),
+    'enc_bwd_dx_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
+    'enc_bwd_dw_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'dec_fwd_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dx_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dw_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
@@ -67,7 +73,7 @@ def short(name):
 
 steps_profiled = None
 for r in rows:
-    if 'enc_fwd_kernel' in r['Name']:
+    if 'enc_fwd_kernel' in r['Name'] or 'enc_fwd_x3_kernel' in r['Name']:
         steps_profiled = int(r['Calls'])
 kernels, step_hbm, step_us = [], 0.0, 0.0
 for r in rows:
@@ -80,7 +86,19 @@ for r in rows:
     hbm = 2 * fetch.get(name, {}).get('FETCH_SIZE', 0.0) * 1024 + write.get(name, {}).get('WRITE_SIZE', 0.0) * 1024
     c = sq.get(name, {})
     e = {'name': key, 'us': round(us, 2), 'launches_per_step': round(per_step, 2), 'hbm_bytes': round(hbm)}
-    if key in FLOPS:
+    if key in FLOPS and '_x3_' in key:
+        # f32 arithmetic carried by six bf16 matrix instructions per k-block: priced against BOTH ceilings, the larger
+        # fraction names the bound.  Executed bf16 FLOPs = 6 x the two 128 x 128 layers' (the K <= 8 layer stays f32 / VALU).
+        bf16_flops = 6 * 2 * ROWS * 2 * 128 * 128
+        mfma_frac = bf16_flops / (us * 1e-6) / BF16_MFMA_PEAK
+        hbm_frac = hbm / (us * 1e-6) / HBM_PEAK
+        e.update(bound='hbm' if hbm_frac >= mfma_frac else 'mfma', frac=round(max(hbm_frac, mfma_frac), 3),
+                 hbm_frac=round(hbm_frac, 3), achieved_gbs=round(hbm / us / 1e3, 1),
+                 mfma_frac=round(mfma_frac, 3), executed_bf16_tflops=round(bf16_flops / us / 1e6, 1), peak_bf16_tflops=2500.0,
+                 flops=FLOPS[key], f32_equivalent_tflops=round(FLOPS[key] / us / 1e6, 1))
+        if c.get('SQ_BUSY_CU_CYCLES'):
+            e['mfma_pipe_busy_of_cu_busy'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
+    elif key in FLOPS:
         e.update(bound='mfma', flops=FLOPS[key], achieved_tflops=round(FLOPS[key] / us / 1e6, 1),
                  frac=round(FLOPS[key] / (us * 1e-6) / F32_MFMA_PEAK, 3), peak_tflops=157.3)
         if c.get('SQ_BUSY_CU_CYCLES'):
@@ -115,6 +133,9 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         fr = e.get('frac')
         what = {'mfma': f'{e.get("achieved_tflops")} TF/s = {fr} of 157.3 TF f32 MFMA', 'valu': f'{fr} of the SIMD issue cycles (VALU)',
                 'latency': f'VALU {fr} (launch / latency bound)'}.get(e.get('bound'), '')
+        if '_x3_' in e['name']:
+            what = (f'HBM {e["achieved_gbs"]} GB/s = {e["hbm_frac"]} of 8 TB/s; bf16 matrix pipe {e["executed_bf16_tflops"]} TF/s executed = '
+                    f'{e["mfma_frac"]} of 2.5 PF ({e["f32_equivalent_tflops"]} TF/s of f32 work)')
         f.write(f'| `{e["name"]}` | {e["launches_per_step"]} | {e["us"]} | {e.get("bound", "")} | {what} | {e["hbm_bytes"] / 1e6:.2f} |\n')
     f.write('\nAll kernels (rocprofv3 --stats):\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n')
     for r in rows[:25]:
