@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 11
+#define PIML_HIP_ABI_VERSION 12
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -447,6 +447,10 @@ typedef struct piml_encoder_branch {
     float* grads;  /* bwd out: piml_encoder_partial_floats() floats = the slots of `partials` summed (same layout) */
     float* packed; /* piml_encoder_pack_floats() floats of caller-provided scratch: the weights re-ordered into MFMA
                       operand fragments; written by piml_encoder_fwd (or piml_encoder_pack), read by piml_encoder_bwd */
+    unsigned* relu_mask; /* optional scratch, 256 dwords per 32-row tile (ceil(rows / 32) tiles): the signs of h1 and h2 as
+                      bits.  A forward on the split-product kernels with more than piml_encoder_split_tiles() tiles writes
+                      it, and the backward of the SAME configuration then reads these 2 MB instead of h1 and h2 (2 x 33 MB at
+                      the 4096-agent scene) in its dX chain; pass the same pointer to both, or NULL to both */
 } piml_encoder_branch;
 
 /* floats of one partial slot / of one `packed` buffer */

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 
@@ -23,7 +23,7 @@ class EncoderBranch(ctypes.Structure):
     _fields_ = [('x', _p), ('rows', _ll), ('in_dim', _i), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
-                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p)]
+                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p), ('relu_mask', _p)]
 
 
 class DecoderBranch(ctypes.Structure):

@@ -882,7 +882,10 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     }
     if (g_x3) {
         if (int e = x3_ready()) return e;
-        enc_x3_launch_bwd_dx(A, total, s);
+        // the sign bits exist iff the forward ran on enc_fwd_x3_kernel (same rule as enc_stage_fwd) and was given the buffer
+        bool mask = tiles[0] + tiles[1] > g_split_tiles;
+        for (int i = 0; i < nbr; ++i) mask = mask && br[i].relu_mask != nullptr;
+        enc_x3_launch_bwd_dx(A, total, mask, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, s, A);

@@ -44,6 +44,24 @@ __device__ __forceinline__ void split_tile(const f32x16 (&in)[4], Pieces& P) {
     }
 }
 
+// bit 16 u + r = (register r of block u is positive); two instructions per value (compare into vcc, add-with-carry
+// m = 2 m + vcc), the last register first
+__device__ __forceinline__ unsigned sign_bits(const f32x16& b0, const f32x16& b1) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 15; r >= 0; --r) asm volatile("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(b1[r]) : "vcc");
+#pragma unroll
+    for (int r = 15; r >= 0; --r) asm volatile("v_cmp_gt_f32 vcc, %1, 0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(b0[r]) : "vcc");
+    return m;
+}
+// ReLU in one instruction (fmaxf costs a canonicalising v_max before the v_max)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// keep v where bit `pos` of m is set, else 0 (one bit-field extract to an all-ones / zero word, one and)
+__device__ __forceinline__ float keep_if(float v, unsigned m, int pos) {
+    const int t = __builtin_amdgcn_sbfe(m, pos, 1);
+    return __uint_as_float(__float_as_uint(v) & (unsigned)t);
+}
+
 // The six products of one k-block.  The matrix core adds the 16 products of an instruction and the accumulator with the
 // low bits of the aligned addends cut off, not rounded (measured: sums over many rows of x3 results drift by ~0.5 ulp of
 // the accumulator per instruction, all in one direction), so the five small terms (<= 2^-8 of the product) go to a second
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) a[blk] = mfma32(W1f[(blk * 4 + s) * 64 + lane_t], xb[s], a[blk]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[blk][r] = fmaxf(a[blk][r], 0.f);
+            for (int r = 0; r < 16; ++r) a[blk][r] = relu1(a[blk][r]);
         }
         if (J.h1 && valid) {
             float* o = J.h1 + row * EH;
@@ -166,6 +184,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
                 for (int q = 0; q < 4; ++q)
                     store4_stream(o + feat0(blk, q, h), a[blk][4 * q], a[blk][4 * q + 1], a[blk][4 * q + 2], a[blk][4 * q + 3]);
         }
+        // sign bits for the dX chain (relu_mask): lane (row, h), layer L: bit 16 blk + r of a 64-bit word = register r of block blk > 0
+        uint2* mrow = J.relu_mask ? reinterpret_cast<uint2*>(J.relu_mask) + (tile * 2) * 64 + lane_t : nullptr;
+        if (mrow) mrow[0] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));
         split_tile(a, P);
         // ---- layer 2 (a is dead: reused for the outputs) ----
 #pragma unroll
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += sm[r];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
             a[blk] = acc;
             if (J.h2 && valid) {
                 float* o = J.h2 + row * EH;
@@ -195,6 +216,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
                     store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             }
         }
+        if (mrow) mrow[64] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));
         if (w3_pending) {
             land_w3(w3r, lds, tid);
             w3_pending = false;
@@ -265,6 +287,7 @@ __device__ __forceinline__ void land_w2t(const u32x4 (&w)[W2T_ROUNDS], float* ld
     __syncthreads();
 }
 
+template <bool MASK>
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,6 +333,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
         const bool valid = row < R;
         f32x16 g[4];
         Pieces P;
+        uint2 m2 = make_uint2(0u, 0u), m1 = make_uint2(0u, 0u);      // sign bits of h2, h1 (forward: sign_bits)
+        if (MASK) {
+            const uint2* mrow = reinterpret_cast<const uint2*>(J.relu_mask) + (tile * 2) * 64 + lane_t;
+            m1 = mrow[0];
+            m2 = mrow[64];
+        }
         // ---- g3 in registers ----
         {
             const float* gp = (J.g_pooled && valid) ? J.g_pooled + (row / K) * EH : nullptr;
@@ -335,8 +364,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
         for (int blk = 0; blk < 4; ++blk) {
             __builtin_amdgcn_sched_barrier(0);
             float4 hv[4];                                   // this block's h2 values: in flight during the MFMAs
+            if (!MASK) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp2 + feat0(blk, q, h));
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp2 + feat0(blk, q, h));
+            }
             f32x16 acc, sm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sm[r] = 0.f;
@@ -349,13 +380,19 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+            if (MASK) {       // (rows past the end: their forward inputs were zeros, their gradients are not stored)
+                const unsigned mw = blk < 2 ? m2.x : m2.y;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = hv[q];
-                acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
-                acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
-                acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
-                acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = valid ? keep_if(acc[r], mw, 16 * (blk & 1) + r) : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = hv[q];
+                    acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
+                    acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
+                    acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
+                    acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+                }
             }
             g[blk] = acc;
             if (valid) {
@@ -385,8 +422,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
         for (int blk = 0; blk < 4; ++blk) {
             __builtin_amdgcn_sched_barrier(0);
             float4 hv[4];
+            if (!MASK) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp1 + feat0(blk, q, h));
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp1 + feat0(blk, q, h));
+            }
             if (blk < 3) {
 #pragma unroll
                 for (int kb = 0; kb < 8; ++kb) lw[(blk + 1) & 1][kb] = W2lo_g[((blk + 1) * 8 + kb) * 64];
@@ -405,13 +444,19 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+            if (MASK) {
+                const unsigned mw = blk < 2 ? m1.x : m1.y;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = hv[q];
-                acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
-                acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
-                acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
-                acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = valid ? keep_if(acc[r], mw, 16 * (blk & 1) + r) : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = hv[q];
+                    acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
+                    acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
+                    acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
+                    acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+                }
             }
             if (valid) {
                 float* o = J.g1 + row * EH;
@@ -497,61 +542,83 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c[u >> 1][u & 1][r] = 0.f; sm[u >> 1][u & 1][r] = 0.f; }
     // staging role: feature sf, row half sh; waves 0-3 own the G side (G3, G2) and the bias sums, waves 4-7 the H side
-    const unsigned sf = tid & 127, sh = (tid >> 7) & 1;
+    const unsigned sf = tid & 127, sh = (wave >> 1) & 1;          // sh, rg: wave-uniform (a wave = 64 consecutive features)
     const bool gside = wave < 4;
     const unsigned slot = (sf >> 5) * 64 + (sf & 31) + 32 * sh;
     // dW1 / db1 role: feature sf, rows 4 rg .. 4 rg + 3 of the batch
-    const unsigned rg = tid >> 7;
+    const unsigned rg = wave >> 1;
     float s3 = 0.f, s2 = 0.f, s1 = 0.f;
     float w1[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) w1[cc] = 0.f;
-    const float* __restrict__ gpool = J.g_pooled;
-    const float* __restrict__ gmsg = J.g_msgs;
-    const float* __restrict__ arr0 = gside ? (POOL ? gpool : gmsg) : J.h2;      // first unit of the thread: G3's source or H2
-    const bool pooled0 = gside && POOL;
-    const float* __restrict__ arr1 = gside ? J.g2 : J.h1;      // second unit
-    const float* __restrict__ G1 = J.g1;
-    const float* __restrict__ X = J.x;
-    const unsigned xrow = tid >> 3, xc = tid & 7;            // threads 0..127: the x rows
+    // Every load goes through a buffer resource whose range is this workgroup's slab (base = first row of the slab,
+    // num_records = its bytes) with the row as the SCALAR offset: rows are wave-uniform here (a wave = 64 features of the
+    // same rows), so the addressing costs no vector instruction at all, and a row past the slab gets the offset
+    // num_records, which the hardware range check (offset >= num_records - scalar offset) answers with 0.  (The vector
+    // pipe, not the matrix pipe, was this kernel's first limit: 338 vector instructions per wave and batch with per-lane
+    // addressing, against 24 matrix instructions.)
+    const unsigned srows = r1 - r0, sbytes = srows * EH * 4;
+    auto rsrc = [&](const float* base, unsigned first, unsigned bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + first), 0, (int)bytes, 0x00020000);
+    };
+    const bool pooled0 = gside && POOL;                         // G3 from the per-agent gradient: row / k into the whole array
+    const unsigned pbytes = (R / K) * EH * 4;
+    const float* a0 = gside ? (POOL ? J.g_pooled : J.g_msgs) : J.h2;
+    const __amdgpu_buffer_rsrc_t rs0 = pooled0 ? rsrc(a0, 0, pbytes) : rsrc(a0, r0 * EH, sbytes);
+    const __amdgpu_buffer_rsrc_t rsm = rsrc((POOL && MSGS) ? J.g_msgs : J.g2, r0 * EH, sbytes);
+    const __amdgpu_buffer_rsrc_t rs1 = rsrc(gside ? J.g2 : J.h1, r0 * EH, sbytes);
+    const __amdgpu_buffer_rsrc_t rsg = rsrc(J.g1, r0 * EH, sbytes);
+    const __amdgpu_buffer_rsrc_t rsx = rsrc(J.x, r0 * IN, srows * IN * 4);
+    const unsigned xvoff = (tid < 128 && (unsigned)(tid & 7) < IN) ? ((tid >> 3) * IN + (tid & 7)) * 4 : 0x7fff0000u;
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+    };
 
+    unsigned pidx0 = __umulhi(r0 + 8 * sh, kmagic), prem0 = r0 + 8 * sh - pidx0 * K;      // of row r0 + 8 sh
+    const unsigned q16 = __umulhi(16u, kmagic), m16 = 16u - q16 * K;                       // 16 / k, 16 % k
     struct Stage { float a[8], m[8], v[8], g1[4], x; };
-    auto stage_load = [&](unsigned rb) -> Stage {            // issue the global loads of the batch starting at row rb
+    auto stage_load = [&](unsigned rb_) -> Stage {           // issue the loads of the batch starting at row rb
         Stage S;
+        const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);       // uniform; said so (else: a waterfall loop per scalar offset)
+        // agent (row / k) of the unit's first row, kept incrementally: the batches are requested in row order, 16 rows apart
+        // (a multiply-high per load here, scalar as it is, sent the register allocation into ~200 spills)
+        unsigned pidx = pidx0, prem = prem0;
+        if (POOL) {
+            pidx0 += q16; prem0 += m16;
+            if (prem0 >= K) { prem0 -= K; ++pidx0; }
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const unsigned row = rb + 8 * sh + t;
-            const unsigned ro = row < r1 ? row : r0;         // clamped: a readable row (r0 < R whenever a batch exists)
-            // unconditional loads through selected pointers (a branch around a load is awaited at the join)
-            S.a[t] = arr0[(pooled0 ? __umulhi(ro, kmagic) : ro) * EH + sf];
+            const unsigned row = rb + 8 * sh + t;                       // scalar
+            const unsigned rel = row < r1 ? (row - r0) * (EH * 4) : sbytes;
+            const unsigned off0 = pooled0 ? (row < r1 ? pidx * (EH * 4) : pbytes) : rel;
+            S.a[t] = ld(rs0, sf * 4, off0);
+            if (POOL) {                                                 // row + 1: the agent index steps when the remainder wraps
+                ++prem;
+                if (prem == K) { prem = 0; ++pidx; }
+            }
             S.m[t] = 0.f;
             if (POOL && MSGS)
-                if (gside) S.m[t] = gmsg[ro * EH + sf];
-            S.v[t] = arr1[ro * EH + sf];
+                if (gside) S.m[t] = ld(rsm, sf * 4, rel);
+            S.v[t] = ld(rs1, sf * 4, rel);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const unsigned row = rb + 4 * rg + t;
-            S.g1[t] = G1[(row < r1 ? row : r0) * EH + sf];
+            S.g1[t] = ld(rsg, sf * 4, row < r1 ? (row - r0) * (EH * 4) : sbytes);
         }
-        const unsigned xr = rb + xrow;
-        S.x = (tid < 128 && xr < r1 && xc < IN) ? X[xr * IN + xc] : 0.f;
+        S.x = ld(rsx, xvoff, rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4);
         return S;
     };
     float gq[4];                                             // g1 values of the batch in the compute phase
-    auto stage_write = [&](const Stage& S, unsigned rb, float* buf) {     // registers -> split -> LDS (rows past the slab are zeros)
+    auto stage_write = [&](const Stage& S, float* buf) {     // registers -> split -> LDS
         u32x4* B = reinterpret_cast<u32x4*>(buf);
-        float u0[8], u1[8];
+        float u0[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const bool ok = rb + 8 * sh + t < r1;
-            const float a = gside ? (S.a[t] + S.m[t]) * scale : S.a[t];
-            u0[t] = ok ? a : 0.f;
-            u1[t] = ok ? S.v[t] : 0.f;
-        }
+        for (int t = 0; t < 8; ++t) u0[t] = gside ? (S.a[t] + S.m[t]) * scale : S.a[t];
         if (gside) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { s3 += u0[t]; s2 += u1[t]; }
+            for (int t = 0; t < 8; ++t) { s3 += u0[t]; s2 += S.v[t]; }
         }
         unsigned hi[4], mid[4], lo[4];
 #pragma unroll
@@ -561,16 +628,16 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
         d0[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
         d0[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
 #pragma unroll
-        for (int d = 0; d < 4; ++d) split3(u1[2 * d], u1[2 * d + 1], hi[d], mid[d], lo[d]);
+        for (int d = 0; d < 4; ++d) split3(S.v[2 * d], S.v[2 * d + 1], hi[d], mid[d], lo[d]);
         u32x4* d1 = d0 + DWX_ARR;
         d1[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
         d1[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
         d1[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
         if (tid < 128) buf[4 * DWX_ARR * 4 + tid] = S.x;
     };
-    auto take_g1 = [&](const Stage& S, unsigned rb) {
+    auto take_g1 = [&](const Stage& S) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) gq[t] = rb + 4 * rg + t < r1 ? S.g1[t] : 0.f;
+        for (int t = 0; t < 4; ++t) gq[t] = S.g1[t];
     };
     auto compute = [&](const float* buf) {
         const u32x4* B = reinterpret_cast<const u32x4*>(buf);
@@ -601,22 +668,24 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     };
     if (r0 < r1) {
         const unsigned nb = (r1 - r0 + DW_X3_ROWS - 1) / DW_X3_ROWS;
+        // One batch of loads ahead.  (Measured and dropped: two batches ahead, with the two waves of a SIMD taking the
+        // split / write and the product phase of a barrier interval in opposite order -- 47 us against 42: the kernel moves
+        // its 176 MB at 4.2 TB/s either way, it is bound by the traffic, not by the latency of a batch.)
         {
             const Stage S = stage_load(r0);
-            stage_write(S, r0, lds);
-            take_g1(S, r0);
+            stage_write(S, lds);
+            take_g1(S);
         }
         __syncthreads();
         for (unsigned t = 0; t < nb; ++t) {
             float* cur = lds + (t & 1) * DWX_BUF * 4;
             float* nxt = lds + ((t + 1) & 1) * DWX_BUF * 4;
-            const unsigned rb = r0 + (t + 1) * DW_X3_ROWS;
-            const Stage S = stage_load(rb);                  // past the slab: clamped + zeroed, written but never read
-            __builtin_amdgcn_sched_barrier(0);               // (see enc_bwd_dw_kernel: the next batch's loads are not awaited here)
+            const Stage S2 = stage_load(r0 + (t + 1) * DW_X3_ROWS);
+            __builtin_amdgcn_sched_barrier(0);               // the loads just issued are not awaited before this batch's products
             compute(cur);
             __builtin_amdgcn_sched_barrier(0);
-            stage_write(S, rb, nxt);
-            take_g1(S, rb);
+            stage_write(S2, nxt);
+            take_g1(S2);
             __syncthreads();
         }
     }
@@ -664,15 +733,19 @@ int enc_x3_set_attributes() {
                          reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true>)};
     for (const void* f : dw)
         if (int e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DWX_LDS_BYTES)) return e;
-    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    X3_DX_LDS_BYTES))
+        return e;
+    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     X3_DX_LDS_BYTES))
         return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                X3_FWD_LDS_BYTES);
 }
 
-void enc_x3_launch_bwd_dx(const EncArgs& A, int total, hipStream_t s) {
-    hipLaunchKernelGGL(enc_bwd_dx_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
+void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, hipStream_t s) {
+    if (mask) hipLaunchKernelGGL(enc_bwd_dx_x3_kernel<true>, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
+    else hipLaunchKernelGGL(enc_bwd_dx_x3_kernel<false>, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
 }
 
 void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, hipStream_t s) {

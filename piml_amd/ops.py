@@ -1242,6 +1242,7 @@ def collision_post_correction(predictions, ped_features, velocity, collision_thr
 # for one or two branches per launch.  Replaces nine library GEMMs + their glue passes per branch and step.
 # ------------------------------------------------------------------------------------------------
 ENCODER_HIDDEN = 128
+RELU_MASK = _os.environ.get('PIML_RELU_MASK', '1') != '0'     # sign bits of h1 / h2 for the dX chain (piml_encoder_branch.relu_mask)
 ENCODER_MAX_IN = 8
 
 
@@ -1254,7 +1255,15 @@ def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, 
     B.h1, B.h2, B.msgs = _ptr(h1), _ptr(h2), _ptr(msgs)
     B.g_pooled, B.g_msgs, B.g2, B.g1, B.g_x, B.partials = [_ptr(t) for t in (g_pooled, g_msgs, g2, g1, g_x, partials)]
     B.packed, B.grads = _ptr(packed), _ptr(grads)
+    # the sign bits of h1 / h2 ride behind h2's rows (_h2_buffer): 2 extra rows of 128 floats per 32-row tile
+    R = x2.shape[0]
+    B.relu_mask = (h2.data_ptr() + R * h2.shape[1] * 4) if (RELU_MASK and h2 is not None and h2.shape[0] >= R + 2 * ((R + 31) // 32)) else None
     return B
+
+
+def _h2_buffer(R, opt):
+    """h2 (R, 128) with room behind it for piml_encoder_branch.relu_mask (256 dwords per 32-row tile)."""
+    return torch.empty(R + 2 * ((R + 31) // 32), ENCODER_HIDDEN, **opt)
 
 
 class _FusedEncoders(torch.autograd.Function):
@@ -1277,7 +1286,7 @@ class _FusedEncoders(torch.autograd.Function):
             ks.append(x.shape[-2])
             msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
             h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
-            h2s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
+            h2s.append(_h2_buffer(R, opt) if need_grad else None)
         packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
         arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b],
                                                               packed=packed[b]) for b in range(nbr)])
@@ -1507,7 +1516,7 @@ class _FusedPinnsf(torch.autograd.Function):
             R = x2s[b].shape[0]
             msgs.append(torch.empty(R, H, **opt))
             h1s.append(torch.empty(R, H, **opt) if need_grad else None)
-            h2s.append(torch.empty(R, H, **opt) if need_grad else None)
+            h2s.append(_h2_buffer(R, opt) if need_grad else None)
         flags = _lib.FORK if FORK_NETWORK else 0
         if packs is not None:
             if packs.sig != _weights_sig(ewb, dwb, hwb):

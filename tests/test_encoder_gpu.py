@@ -483,3 +483,23 @@ def test_split_bf16_products_are_f32_arithmetic():
     for nm in names:
         assert err[1][nm] <= 1e-6, (nm, err[1][nm])
         assert err[1][nm] <= 1.5 * err[0][nm] + 1e-7, (nm, err[1][nm], err[0][nm])
+
+
+@pytest.mark.parametrize('shapes', [[(4096, 12, 6), (4096, 4, 6)], [(5000, 7, 5), (33, 3, 8)], [(2440, 6, 6), (2440, 10, 6)]])
+def test_split_product_kernels_are_bit_reproducible(shapes):
+    """Forward + backward of the one-wave split-product kernels (sign-bit masks, ragged last tile, both branches) repeated
+    30 times: every output and gradient bitwise equal to the first run.  (A version of the masked dX chain returned
+    run-to-run different d/dx while every other tensor was right; this is its regression test.)"""
+    from piml_amd import ops
+    brs = [make_branch(n, k, d, seed=10 * i + n % 7) for i, (n, k, d) in enumerate(shapes)]
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    first = None
+    for rep in range(30):
+        outs = ops.fused_encoders(brs)
+        loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
+        res = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
+        if first is None:
+            first = res
+        else:
+            bad = [i for i, (a, b) in enumerate(zip(first, res)) if not torch.equal(a, b)]
+            assert not bad, (rep, bad)

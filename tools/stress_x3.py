@@ -20,5 +20,8 @@ for shapes in ([(122 * 20, 6, 6), (122 * 20, 10, 6)], [(4096, 12, 6), (4096, 4, 
         if first is None:
             first = res
         else:
-            bad += sum(0 if torch.equal(a, b) else 1 for a, b in zip(first, res))
+            diff = [i for i, (a, b) in enumerate(zip(first, res)) if not torch.equal(a, b)]
+            bad += len(diff)
+            if diff and bad < 20:
+                print('   rep', rep, 'differs in tensors', diff, [float((first[i] - res[i]).abs().max()) for i in diff[:4]])
     print(shapes, 'mismatching tensors over 39 repeats:', bad, 'nan:', sum(int(torch.isnan(t).any()) for t in first))
