@@ -668,9 +668,11 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     };
     if (r0 < r1) {
         const unsigned nb = (r1 - r0 + DW_X3_ROWS - 1) / DW_X3_ROWS;
-        // One batch of loads ahead.  (Measured and dropped: two batches ahead, with the two waves of a SIMD taking the
-        // split / write and the product phase of a barrier interval in opposite order -- 47 us against 42: the kernel moves
-        // its 176 MB at 4.2 TB/s either way, it is bound by the traffic, not by the latency of a batch.)
+        // One batch of loads ahead.  Measured and dropped, all within +-2 us of this form (45 us, 175 MB = 3.9 TB/s): two
+        // batches ahead in two register sets (loop unrolled by two, vmcnt(40) waits: the latency of a batch is not the limit);
+        // the two waves of a SIMD taking the split / write and the product phase of a barrier interval in opposite order;
+        // the next batch's split arithmetic scheduled into this batch's products (sched_group_barrier); h1 recomputed from x
+        // instead of read (33 MB less, 64 FMAs per unit more: slower); one scalar offset per 8-row unit + immediates.
         {
             const Stage S = stage_load(r0);
             stage_write(S, lds);
