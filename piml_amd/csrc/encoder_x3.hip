@@ -527,12 +527,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
     const unsigned p = (unsigned)((int)blockIdx.x - wg0);
     const unsigned R = (unsigned)J.rows;                   // rows < 2^24 (checked on the host): 32-bit indexing
-    const unsigned IN = (unsigned)J.in_dim, K = (unsigned)J.k;
-    const unsigned kmagic = (unsigned)((0x100000000ull + K - 1) / K);      // row / K == umulhi(row, kmagic) for row * K < 2^32
+    const unsigned IN = __builtin_amdgcn_readfirstlane((unsigned)J.in_dim), K = __builtin_amdgcn_readfirstlane((unsigned)J.k);
+    const unsigned kmagic = __builtin_amdgcn_readfirstlane((unsigned)((0x100000000ull + K - 1) / K));      // row / K == umulhi(row, kmagic) for row * K < 2^32
     unsigned slab = (R + nwg - 1) / nwg;
     slab = (slab + 1) & ~1u;
-    const unsigned r0 = p * slab < R ? p * slab : R;
-    const unsigned r1 = r0 + slab < R ? r0 + slab : R;
+    // every quantity a scalar offset is built from is declared wave-uniform: what the compiler cannot prove uniform it
+    // wraps into a waterfall loop per load (and shuffles the accumulators around it)
+    const unsigned r0 = __builtin_amdgcn_readfirstlane(p * slab < R ? p * slab : R);
+    const unsigned r1 = __builtin_amdgcn_readfirstlane(r0 + slab < R ? r0 + slab : R);
     const float scale = J.scale;
     const int L = wave >> 2, iq = (wave >> 1) & 1, jq = wave & 1;
 
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
         for (int t = 0; t < 8; ++t) {
             const unsigned row = rb + 8 * sh + t;                       // scalar
             const unsigned rel = row < r1 ? (row - r0) * (EH * 4) : sbytes;
-            const unsigned off0 = pooled0 ? (row < r1 ? pidx * (EH * 4) : pbytes) : rel;
+            const unsigned pi = __builtin_amdgcn_readfirstlane(pidx);     // (the compiler keeps the stepped index on the vector pipe)
+            const unsigned off0 = pooled0 ? (row < r1 ? pi * (EH * 4) : pbytes) : rel;
             S.a[t] = ld(rs0, sf * 4, off0);
             if (POOL) {                                                 // row + 1: the agent index steps when the remainder wraps
                 ++prem;
@@ -668,11 +671,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     };
     if (r0 < r1) {
         const unsigned nb = (r1 - r0 + DW_X3_ROWS - 1) / DW_X3_ROWS;
-        // One batch of loads ahead.  Measured and dropped, all within +-2 us of this form (45 us, 175 MB = 3.9 TB/s): two
-        // batches ahead in two register sets (loop unrolled by two, vmcnt(40) waits: the latency of a batch is not the limit);
-        // the two waves of a SIMD taking the split / write and the product phase of a barrier interval in opposite order;
-        // the next batch's split arithmetic scheduled into this batch's products (sched_group_barrier); h1 recomputed from x
-        // instead of read (33 MB less, 64 FMAs per unit more: slower); one scalar offset per 8-row unit + immediates.
+        // One batch of loads ahead, issued between the products (below).  Phases of a batch by s_memtime (wave 0, before that):
+        // load issue 1 950 cycles, products 1 980, split + LDS writes 1 250, barrier 320.  Measured and dropped, all within
+        // +-3 us of this form (42 us, 175 MB = 4.1 TB/s): loads two batches ahead in two register sets (loop unrolled by two,
+        // vmcnt(40) waits), with and without the next batch's split scheduled into this batch's products; the two waves of a
+        // SIMD taking the split / write and the product phase in opposite order; h1 recomputed from x instead of read
+        // (33 MB less, 64 FMAs per unit more: slower); one scalar offset per 8-row unit + immediates.
         {
             const Stage S = stage_load(r0);
             stage_write(S, lds);
@@ -682,9 +686,18 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
         for (unsigned t = 0; t < nb; ++t) {
             float* cur = lds + (t & 1) * DWX_BUF * 4;
             float* nxt = lds + ((t + 1) & 1) * DWX_BUF * 4;
+            // The next batch's 21 loads are issued BETWEEN this batch's products: as a burst in front of them they took as long
+            // as the products themselves (s_memtime, wave 0: 1 950 cycles of issue, 8 waves' loads queueing at the CU's one
+            // address unit, then 1 980 cycles of products with that unit idle).  Nothing of the loaded values is touched
+            // before the fence below (their arithmetic would be awaited).
             const Stage S2 = stage_load(r0 + (t + 1) * DW_X3_ROWS);
-            __builtin_amdgcn_sched_barrier(0);               // the loads just issued are not awaited before this batch's products
             compute(cur);
+            __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);          // fragment + x reads
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one product
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one load
+            }
             __builtin_amdgcn_sched_barrier(0);
             stage_write(S2, nxt);
             take_g1(S2);
