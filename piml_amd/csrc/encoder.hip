@@ -851,6 +851,11 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
     if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
+        if (g_x3) {
+            if (int e = x3_ready()) return e;
+            enc_x3_launch_fwd_split(A, pairs0, pairs1, s);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(enc_fwd_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
         return hipGetLastError();
     }

@@ -266,6 +266,127 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward for FEW rows (rollouts of real clips: 100 .. 1000 agents): four waves per tile like enc_fwd_split_kernel
+// (encoder.hip; a lone wave per SIMD is bound by the latency of its chain of dependent matrix instructions, here
+// 16 + 48 + 48 of them instead of 400).  Wave (t, blk) computes output block blk of every layer of tile t, two tiles per
+// workgroup; it splits ITS 16 registers of a layer's output and the pieces travel through LDS as ready-made B operands
+// (k-block 2 blk + s = registers 8 s .. 8 s + 7).  The fragments of the wave's output block come straight from the packed
+// image, the next layer's under this layer's products.  Every accumulator sees the k-blocks and the six products in the
+// order of enc_fwd_x3_kernel: bitwise identical outputs.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int X3_SPLIT_LDS_BYTES = 2 * 2 * 4 * 3 * 2 * 64 * 16;       // [layer 2][tile 2][block 4][piece 3][s 2][lane 64] u32x4
+
+__global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pairs0) {
+    extern __shared__ __align__(16) float lds[];
+    u32x4* exch = reinterpret_cast<u32x4*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x >= pairs0 ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int t = wave >> 2, blk = wave & 3;
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long tile = ((long long)blockIdx.x - (b ? pairs0 : 0)) * 2 + t;
+    const int j = lane & 31, h = lane >> 5;
+    const long long row = tile * 32 + j;
+    const bool valid = row < R;
+    if (A.zero)
+        for (int e = blockIdx.x * 512 + tid; e < A.zero_n; e += gridDim.x * 512) A.zero[e] = 0.f;
+    const u32x4* W2hm = reinterpret_cast<const u32x4*>(J.packed + PACK_F32) + lane;
+    const u32x4* W2lo = W2hm + X3_HM / 4;
+    const u32x4* W3hm = reinterpret_cast<const u32x4*>(J.packed + PACK_F32 + X3_IMG) + lane;
+    const u32x4* W3lo = W3hm + X3_HM / 4;
+    const float* W1g = J.packed + 32768;
+    const float* bias = J.packed + 32768 + 1024;
+    u32x4 wf[8][3];                                   // this wave's fragments of the layer: k-block, (hi, mid, lo)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {                  // in flight during layer 1
+        const int fb = blk * 8 + kb;
+        wf[kb][0] = W2hm[(fb * 2) * 64]; wf[kb][1] = W2hm[(fb * 2 + 1) * 64]; wf[kb][2] = W2lo[fb * 64];
+    }
+    float xb[4], w1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 2 * s + h;
+        xb[s] = (valid && c < IN) ? J.x[(valid ? row : 0) * IN + c] : 0.f;
+        w1[s] = W1g[(blk * 4 + s) * 64 + lane];
+    }
+    float4 bq[3][4];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[l][q] = *reinterpret_cast<const float4*>(bias + 128 * l + feat0(blk, q, h));
+    f32x16 acc, sm;
+    auto init = [&](int l) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[l][q].x; acc[4 * q + 1] = bq[l][q].y; acc[4 * q + 2] = bq[l][q].z; acc[4 * q + 3] = bq[l][q].w; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+    };
+    auto store = [&](float* dst, float sc) {
+        if (dst && valid) {
+            float* o = dst + row * EH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                store4_stream(o + feat0(blk, q, h), sc * acc[4 * q], sc * acc[4 * q + 1], sc * acc[4 * q + 2], sc * acc[4 * q + 3]);
+        }
+    };
+    auto hand_over = [&](int l) {                     // this wave's 16 registers, split, as the B operands of k-blocks 2 blk, 2 blk + 1
+        u32x4* dst = exch + ((((l * 2 + t) * 4 + blk) * 3) * 2) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) split3(acc[8 * s + 2 * d], acc[8 * s + 2 * d + 1], hi[d], mid[d], lo[d]);
+            dst[(0 * 2 + s) * 64] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+            dst[(1 * 2 + s) * 64] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+            dst[(2 * 2 + s) * 64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+    // ---- layer 1 (f32 instruction, as in enc_fwd_x3_kernel) ----
+    init(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = mfma32(w1[s], xb[s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+    store(J.h1, 1.f);
+    hand_over(0);
+    __syncthreads();
+    // ---- layers 2 and 3 ----
+#pragma unroll
+    for (int l = 1; l < 3; ++l) {
+        init(l);
+        u32x4 wn[8][3];
+        if (l == 1) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {          // next layer's, under this layer's products
+                const int fb = blk * 8 + kb;
+                wn[kb][0] = W3hm[(fb * 2) * 64]; wn[kb][1] = W3hm[(fb * 2 + 1) * 64]; wn[kb][2] = W3lo[fb * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4* src = exch + (((l - 1) * 2 + t) * 4 * 3 * 2) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const u32x4* e = src + ((kb >> 1) * 3 * 2 + (kb & 1)) * 64;
+            kblock_x3(acc, sm, wf[kb][0], wf[kb][1], wf[kb][2], e[0], e[2 * 64], e[4 * 64]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+        if (l == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
+            store(J.h2, 1.f);
+            hand_over(1);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; wf[kb][2] = wn[kb][2]; }
+            __syncthreads();
+        } else {
+            store(J.msgs, J.scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward, part 1: the dX chain (see enc_bwd_dx_kernel in encoder.hip for the arithmetic)
 // ---------------------------------------------------------------------------------------------------------
 // LDS: W3^T image whole [HM 4096 | LO 2048 u32x4] | W2^T HM of fragments 0 .. 29 [30][2][64] u32x4 | W1 rows [f 128][8]
@@ -743,6 +864,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 }
 
 int enc_x3_set_attributes() {
+    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    X3_SPLIT_LDS_BYTES))
+        return e;
     const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true>),
                          reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false>),
                          reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true>)};
@@ -768,6 +892,10 @@ void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, hipStream_t s) {
     if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
     else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
     else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
+}
+
+void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, hipStream_t s) {
+    hipLaunchKernelGGL(enc_fwd_split_x3_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
 }
 
 void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s) {

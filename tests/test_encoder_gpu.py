@@ -503,3 +503,31 @@ def test_split_product_kernels_are_bit_reproducible(shapes):
         else:
             bad = [i for i, (a, b) in enumerate(zip(first, res)) if not torch.equal(a, b)]
             assert not bad, (rep, bad)
+
+
+@pytest.mark.parametrize('agents', [1, 37, 122, 1024])
+def test_split_tile_x3_forward_is_bitwise_the_one_wave_x3_forward(agents):
+    """enc_fwd_split_x3_kernel (four waves per tile, few rows: the rollouts of real clips) against enc_fwd_x3_kernel: every
+    accumulator sees its k-blocks and the six products of a k-block in the same order, so messages and pooled sums are
+    bitwise identical (inference call: the forward alone)."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(33)
+
+    def branch(k):
+        x = torch.randn(agents, k, 6, generator=g).to(DEV)
+        w = [(torch.randn(*d, generator=g) * 0.2).to(DEV) for d in [(128, 6), (128,), (128, 128), (128,), (128, 128), (128,)]]
+        return dict(x=x, scale=2.0, weights=w, pooled=True)
+    brs = [branch(6), branch(10)]
+    res = {}
+    old, old_products = L.piml_encoder_split_tiles(-1), L.piml_encoder_products(1)
+    try:
+        for split in (True, False):
+            L.piml_encoder_split_tiles(1 << 30 if split else 0)
+            with torch.no_grad():
+                res[split] = [t.clone() for o in ops.fused_encoders(brs) for t in o]
+    finally:
+        L.piml_encoder_split_tiles(old)
+        L.piml_encoder_products(old_products)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
