@@ -142,6 +142,51 @@ def _phase(msg):
         print(f'[bench +{time.perf_counter() - _T0:7.2f}s] {msg}', file=sys.stderr, flush=True)
 
 
+def encoder_products_check(dev, _lib):
+    """Fused encoder forward + backward at the bench's row counts (4096 x 12 and 4096 x 4 neighbour rows, random weights)
+    in both product forms against a float64 evaluation of the same network: max |error| / max |value| per tensor."""
+    from piml_amd import ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    H = 128
+
+    def branch(k):
+        x = (torch.randn(4096, k, 6, generator=g) * 2).to(dev).requires_grad_(True)
+        w = [(torch.randn(*d, generator=g) * (0.3 if len(d) == 2 else 0.1)).to(dev).requires_grad_(True)
+             for d in [(H, 6), (H,), (H, H), (H,), (H, H), (H,)]]
+        return dict(x=x, scale=2.0, weights=w, pooled=True)
+    brs = [branch(12), branch(4)]
+    gps = [torch.randn(4096, H, generator=g).to(dev) for _ in brs]
+    names = ('msgs', 'pooled', 'g_x', 'dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3')
+    refs = []
+    for br, gp in zip(brs, gps):
+        x = br['x'].detach().double().requires_grad_(True)
+        w = [t.detach().double().requires_grad_(True) for t in br['weights']]
+        h = torch.relu(torch.relu(x @ w[0].t() + w[1]) @ w[2].t() + w[3])
+        msgs = 2.0 * (h @ w[4].t() + w[5])
+        pooled = msgs.sum(-2)
+        (pooled * gp.double()).sum().backward()
+        refs.append((msgs.detach(), pooled.detach(), x.grad, *[t.grad for t in w]))
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    out = {}
+    old = L.piml_encoder_products(-1)
+    try:
+        for mode, label in ((1, 'split_bf16_products'), (0, 'f32_matrix_instruction')):
+            L.piml_encoder_products(mode)
+            outs = ops.fused_encoders(brs)
+            grads = torch.autograd.grad(sum((p * gp).sum() for (m, p), gp in zip(outs, gps)), leaves)
+            worst = dict.fromkeys(names, 0.0)
+            for i, ((m, p), ref) in enumerate(zip(outs, refs)):
+                for nm, a, b in zip(names, (m.detach(), p.detach(), *grads[7 * i:7 * i + 7]), ref):
+                    worst[nm] = max(worst[nm], float((a.double() - b).abs().max() / b.abs().max()))
+            out[label] = {k: float(f'{v:.2e}') for k, v in worst.items()}
+    finally:
+        L.piml_encoder_products(old)
+    out['note'] = ('max |error| / max |value| per tensor against float64, both branches at 4096 agents (one-wave kernels); '
+                   'north-star bar 1e-5; tests/test_encoder_gpu.py::test_split_bf16_products_are_f32_arithmetic asserts it')
+    return out
+
+
 def secondary_measurements(scene, n, dev, _lib):
     """Back-to-back launches of the other HIP kernels of the path on the first `n` agents of the scene,
     timed with HIP events (informational; not part of `value`).  MLAPM byte model: 16 B per pair + 36 B
@@ -814,6 +859,11 @@ def main():
             secondary = secondary_measurements(scene, n_own, dev, _lib)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
+        if world == 1 and fused_mlp:      # live evidence that the split products ARE f32 arithmetic: both forms against float64
+            try:
+                secondary['encoder_products_vs_float64'] = encoder_products_check(dev, _lib)
+            except Exception as ex:   # noqa: BLE001 - informational
+                secondary['encoder_products_vs_float64'] = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1 and x3_products and fused_mlp:      # the same step with the encoder products on v_mfma_f32_32x32x2_f32
             try:
                 _lib.lib().piml_encoder_products(0)
