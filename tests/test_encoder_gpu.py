@@ -531,3 +531,21 @@ def test_split_tile_x3_forward_is_bitwise_the_one_wave_x3_forward(agents):
         L.piml_encoder_products(old_products)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shapes', [[(4096, 6, 6), (4096, 10, 6)], [(5000, 7, 5), (33, 3, 8)]])
+def test_sign_bit_masks_equal_the_saved_activations(shapes, monkeypatch):
+    """The dX chain of the split-product kernels masks with the signs of h1 / h2 read as bits (piml_encoder_branch.relu_mask,
+    written by the forward) or, without that buffer, with the saved activations themselves: the same predicate, so every
+    output and gradient is bitwise identical."""
+    from piml_amd import ops
+    res = {}
+    for masks in (True, False):
+        monkeypatch.setattr(ops, 'RELU_MASK', masks)
+        brs = [make_branch(n, k, d, seed=10 * i + n % 7) for i, (n, k, d) in enumerate(shapes)]
+        leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+        outs = ops.fused_encoders(brs)
+        loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
+        res[masks] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
