@@ -416,7 +416,8 @@ int piml_probe_arith(const float* rx, const float* ry, const float* hx, const fl
                      float* dist, float* cosv, int n, void* stream);
 
 /*
- * Fused PINNSF encoder on the f32 matrix cores (piml_amd/csrc/encoder.hip): the reference's
+ * Fused PINNSF encoder on the matrix cores (piml_amd/csrc/encoder_x3.hip: f32 products as split bf16 products, the
+ * default; piml_amd/csrc/encoder.hip: the f32 matrix instruction; see piml_encoder_products): the reference's
  *   ped_encoder / obs_encoder = MLP(in, [128, 128, 128]) (src/models/model.py:40-65, built at :1232-1236),
  *   the processor in its effective form `scale * x` (ResDNN with >= 2 "layers" and inactive dropout, :82-119,
  *   SURVEY quirk Q3) and the neighbour-axis sum (:1279-1283),
