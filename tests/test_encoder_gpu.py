@@ -549,3 +549,31 @@ def test_sign_bit_masks_equal_the_saved_activations(shapes, monkeypatch):
         res[masks] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('xscale,wscale', [(1e-6, 1.0), (1e4, 1.0), (1.0, 1e-4), (1e3, 30.0)])
+def test_split_products_hold_across_magnitudes(xscale, wscale):
+    """The three-way split is exact whatever the magnitude (bf16 has f32's exponent range): inputs of 1e-6 .. 1e4 and
+    weights of 1e-4 .. 30 times the usual scale, outputs and gradients against float64 at the one-wave kernels' row counts.
+    Bar 1e-6 of each tensor's largest magnitude."""
+    from piml_amd import ops
+    shapes = [(4096, 6, 6), (4096, 10, 6)]
+    brs = [make_branch(n, k, d, seed=21 + i) for i, (n, k, d) in enumerate(shapes)]
+    with torch.no_grad():
+        for br in brs:
+            br['x'].mul_(xscale)
+            for w in br['weights'][0::2]:
+                w.mul_(wscale)
+    gen = torch.Generator().manual_seed(9)
+    gps = [torch.randn(n, H, generator=gen).to(DEV) for n, _, _ in shapes]
+    outs = ops.fused_encoders(brs)
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    grads = torch.autograd.grad(sum((p * gp).sum() for (m, p), gp in zip(outs, gps)), leaves)
+    worst = 0.0
+    for i, (br, (m, p), gp) in enumerate(zip(brs, outs, gps)):
+        rm, rp, rgx, rgw = reference(br, None, gp)
+        for a, b in zip((m.detach(), p.detach(), *grads[7 * i:7 * i + 7]), (rm, rp, rgx, *rgw)):
+            assert torch.isfinite(a).all()
+            worst = max(worst, relerr(a, b))
+    print(f'split products, x scale {xscale:g}, weight scale {wscale:g}: max rel err vs float64 {worst:.1e}')
+    assert worst <= 1e-6
