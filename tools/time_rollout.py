@@ -37,7 +37,11 @@ if __name__ == '__main__':
     if tuned:
         from piml_amd import tuning
         print('tuned GEMM selections loaded:', tuning.load())
-    for N, M in ((122, 100), (1024, 100), (4096, 2000)):
+    sizes = ((122, 100), (1024, 100), (4096, 2000))
+    if '--sizes' in sys.argv:         # e.g. --sizes 2048,100,3000,100
+        v = [int(t) for t in sys.argv[sys.argv.index('--sizes') + 1].split(',')]
+        sizes = tuple(zip(v[0::2], v[1::2]))
+    for N, M in sizes:
         T = 200
         data = synthetic_rollout_data(N, M, T, dev)
         torch.manual_seed(666)
