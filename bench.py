@@ -17,7 +17,8 @@ scene on ONE GPU after the timed region (`single_gpu_same_scene`), the baseline 
 
 Rank 0 prints ONE JSON line.  `roofline.frac` is SURVEY.md 8d's step-level contract figure (operand-stream
 bytes of the step / step time / HBM peak); `roofline.kernels` lists the dominant kernels with the fraction of the
-unit that really bounds each (VALU issue for the N-body sweep, f32 MFMA for the MLP).  `cpu_baseline` times the CPU
+unit that really bounds each (VALU issue for the N-body sweep; HBM / the bf16 matrix pipe for the encoder kernels on split
+products, f32 MFMA with PIML_ENC_PRODUCTS=f32).  `cpu_baseline` times the CPU
 oracle (C restatement, OpenMP) + the same PINNSF on the host cores on a bounded sample, and the feature step in
 the reference's own dataflow (oracle/dataflow.py).
 
@@ -521,7 +522,7 @@ def main():
     ap.add_argument('--strong-baseline', type=int, default=1,
                     help='strong scaling on several GPUs: rank 0 also times the whole scene on one GPU (outside the timed region)')
     ap.add_argument('--mlp', choices=('fused', 'library'), default='fused',
-                    help='fused: the PINNSF network on the hand-written f32-MFMA kernels (encoder.hip / decoder.hip); '
+                    help='fused: the PINNSF network on the hand-written matrix-core kernels (encoder_x3.hip / encoder.hip / decoder.hip); '
                          'library: round 1\'s path, rocBLAS / hipBLASLt GEMMs + HIP glue kernels (A/B comparison)')
     ap.add_argument('--tunableop', type=int, default=1,
                     help='1: load the pre-tuned GEMM selections for the MLP (tuned in-process if this stack rejects the file); '
@@ -786,7 +787,7 @@ def main():
                          'definition': 'SURVEY.md 8d step-level contract: operand-stream bytes of one step (24 B/ped pair + '
                                        '8 B/obstacle pair + 488 B/focal agent) / ms_per_step / (n_gpus x HBM peak); the sources '
                                        'are LDS/L2 resident, so real HBM traffic (`traffic`, PMC) is far below this model and '
-                                       'the step is bound by the MLP (f32 MFMA) and VALU issue, see `kernels`',
+                                       'the step is bound by the MLP kernels (HBM traffic of the saved activations / matrix pipe) and VALU issue, see `kernels`',
                          'kernels': kernels},
         }
     import threading
