@@ -246,7 +246,7 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False, model_name='PINNSF_multitask'):
+                 overlap=False, model_name='PINNSF_multitask', train_mode=False):
         from piml_amd import ops, _lib
         import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
@@ -261,7 +261,12 @@ class Step:
         self.v0_own = torch.tensor(scene['desired_speed'][rows], device=dev)
         self.sh = ShardedScene(N, self.obstacles, group=group, force_collectives=True) if use_dist else None
         torch.manual_seed(666)
-        self.model = getattr(MODEL, model_name)(model_args()).to(dev).eval()   # eval: dropout off, deterministic
+        # eval (default): dropout off, the replayed step can be verified against an eager one.  train_mode: model.train()
+        # with the reference's --dropout 0.5 (src/main.py:45, src/models/simulators.py:311): every step draws fresh
+        # keep-masks on the device (ops.dropout_keep_bits inside the captured graph) and the fused kernels apply them
+        self.model = getattr(MODEL, model_name)(model_args()).to(dev).train(bool(train_mode))
+        if train_mode:
+            ops.dropout_state(dev)          # the device-side (seed, call counter) must exist before a capture
         if two_streams:
             self.model.obs_stream = torch.cuda.Stream()
         self.params = [p for p in self.model.parameters()]
@@ -882,6 +887,22 @@ def main():
                 secondary['f32_matrix_instruction_step'] = {'error': f'{type(ex).__name__}: {ex}'}
             finally:
                 _lib.lib().piml_encoder_products(1)
+        if world == 1 and fused_mlp:      # the reference's TRAINING configuration: model.train(), --dropout 0.5
+            for key, mname in (('train_mode_step', 'PINNSF_multitask'), ('train_mode_pinnsf_bm_step', 'PINNSF_bottleneck_multitask')):
+                try:
+                    tr = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), model_name=mname, train_mode=True)
+                    tr.capture()
+                    k = max(10, min(args.steps, 50))
+                    el = tr.time_steps(k, 5)
+                    secondary[key] = {
+                        'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': tr.mode, 'dropout': 0.5,
+                        'note': f'the same forward + backward step with {mname} in train() mode, dropout 0.5 (the reference\'s '
+                                'training configuration, src/main.py:45, src/models/simulators.py:311): two keep-mask launches per '
+                                'step (Philox, device-side call counter) + the mask applied inside the fused encoder kernels '
+                                '(forward epilogue, dX chain, dW staging); parity with injected masks: tests/test_dropout_gpu.py'}
+                    del tr
+                except Exception as ex:   # noqa: BLE001 - informational
+                    secondary[key] = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1:       # the same step with the shipped experiments' model (src/configs/exp_configs/piml-*.yaml)
             try:
                 bm = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), model_name='PINNSF_bottleneck_multitask')

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 12
+#define PIML_HIP_ABI_VERSION 13
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -388,12 +388,27 @@ int piml_layer_reduce(const float* parts, int B, size_t n, float* out, const flo
  * bias (cols, optional): msgs = scale * (e + bias) -- the bias of the encoder's last Linear, when that layer was
  * run as a plain GEMM (its bias-epilogue variant is the slower kernel); the gradient w.r.t. that bias is still
  * the column sum of g_e, which the layer's own backward computes.
+ * keep_bits (optional, piml_dropout_keep_bits layout): the processor's train-mode dropout, msgs = keep * scale * (..)
+ * with scale = 2 / (1 - p) chosen by the caller; bwd: g_e = keep * scale * (..).
  */
-int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale, float* msgs,
-                        float* pooled, void* stream);
+int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale,
+                        const unsigned* keep_bits, float* msgs, float* pooled, void* stream);
 int piml_ksum_blocks(size_t agents, int cols);
 int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols, float scale,
-                        float* g_e, float* col_partials, void* stream);
+                        const unsigned* keep_bits, float* g_e, float* col_partials, void* stream);
+
+/*
+ * Keep-mask of the PINNSF processor's dropout.  The reference's processor is Dropout_p(2 x) in train mode
+ * (src/models/model.py:82-119 with quirk Q3; model.train() at src/models/simulators.py:311; --dropout 0.5 at
+ * src/main.py:45): the fused kernels take the mask as bits -- keep_bits (rows, ceil(cols / 32)) dwords, bit (c & 31)
+ * of word (c >> 5) of a row = feature c of that row is kept -- and the caller folds 1 / (1 - p) into `scale`.
+ *   state: 4 x uint64 on the device: [seed, offset, ticket, unused].  Every call draws the uniforms of call number
+ *          `offset` and advances `offset` by one ON THE DEVICE (last block out), so a call captured into a hipGraph
+ *          draws a fresh mask on every replay.  Philox4x32-10, counter = (offset lo, offset hi, row, c >> 2),
+ *          key = (seed lo, seed hi); feature c takes output word c & 3 and is kept iff that word >= round(p * 2^32).
+ *   p in [0, 1]; p = 1 keeps nothing.
+ */
+int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, float p, unsigned* keep_bits, void* stream);
 
 /*
  * HIP-event timer for measuring a kernel live on the stream it is launched on, also while
@@ -452,6 +467,9 @@ typedef struct piml_encoder_branch {
                       bits.  A forward on the split-product kernels with more than piml_encoder_split_tiles() tiles writes
                       it, and the backward of the SAME configuration then reads these 2 MB instead of h1 and h2 (2 x 33 MB at
                       the 4096-agent scene) in its dX chain; pass the same pointer to both, or NULL to both */
+    const unsigned* keep_bits; /* optional (rows, 4) dwords, piml_dropout_keep_bits layout: the processor's train-mode
+                      dropout.  msgs = keep * scale * (...) in the forward, g3 = keep * scale * (g_pooled + g_msgs) in the
+                      backward (dX chain and dW3 / db3); the caller passes scale = 2 / (1 - p) and the same bits to both */
 } piml_encoder_branch;
 
 /* floats of one partial slot / of one `packed` buffer */

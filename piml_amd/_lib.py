@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -23,7 +23,8 @@ class EncoderBranch(ctypes.Structure):
     _fields_ = [('x', _p), ('rows', _ll), ('in_dim', _i), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
-                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p), ('relu_mask', _p)]
+                ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p), ('relu_mask', _p),
+                ('keep_bits', _p)]
 
 
 class DecoderBranch(ctypes.Structure):
@@ -74,9 +75,10 @@ SIGNATURES = {
     'piml_sum_leading': [_p, _i, _z, _p, _p],
     'piml_act_bwd_colsum_stage1': [_p, _p, _z, _i, _p, _p, _p, _p],
     'piml_layer_reduce': [_p, _i, _z, _p, _p, _i, _i, _p, _p],
-    'piml_scale_ksum_fwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p],
+    'piml_scale_ksum_fwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p, _p],
     'piml_ksum_blocks': [_z, _i],
-    'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p],
+    'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p, _p],
+    'piml_dropout_keep_bits': [_p, _ll, _i, _f, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],

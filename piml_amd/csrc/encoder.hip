@@ -28,6 +28,17 @@
 
 namespace piml {
 
+// Dropout of the processor output (piml_encoder_branch.keep_bits, (rows, 4) dwords: bit c & 31 of word c >> 5 = keep
+// feature c of the row).  Lane (row, h), block blk, register r holds feature 32 blk + (r & 3) + 8 (r >> 2) + 4 h.
+__device__ __forceinline__ void keep_block_f32(f32x16& a, unsigned word, int h) {
+    const unsigned m = word >> (4 * h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = ((m >> ((r & 3) + 8 * (r >> 2))) & 1u) ? a[r] : 0.f;
+}
+__device__ __forceinline__ unsigned keep_word(const unsigned* __restrict__ keep, long long row, int blk, bool valid) {
+    return valid ? keep[row * 4 + blk] : 0u;
+}
+
 __global__ __launch_bounds__(256) void enc_pack_kernel(EncArgs A) {
     const int b = blockIdx.y;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
                     a1[blk] = mfma32(w.z, a2[bp][4 * q + 2], a1[blk]);
                     a1[blk] = mfma32(w.w, a2[bp][4 * q + 3], a1[blk]);
                 }
+            if (J.keep_bits) keep_block_f32(a1[blk], keep_word(J.keep_bits, row, blk, valid), h);
             if (valid) {
                 float* o = J.msgs + row * EH;
 #pragma unroll
@@ -163,6 +175,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_kernel(EncArgs A) {
 // weight fragments come straight from the packed image (a wave uses each once: no staging phase); every accumulator sees
 // the k-steps in the order of enc_fwd_kernel, so the outputs are bitwise identical.
 // ---------------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(512) void enc_fwd_split_kernel(EncArgs A, int pairs0) {
     __shared__ float exch[2][2][4][16][64];            // [layer buffer][tile][block][register][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,6 +265,7 @@ __global__ __launch_bounds__(512) void enc_fwd_split_kernel(EncArgs A, int pairs
             for (int g = 0; g < 16; ++g) wf[g] = wn[g];
             __syncthreads();
         } else {
+            if (DROP) keep_block_f32(acc, keep_word(J.keep_bits, row, blk, valid), h);
             store(J.msgs, J.scale);
         }
     }
@@ -324,6 +338,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
                     g[blk][4 * q + 0] = scale * v.x; g[blk][4 * q + 1] = scale * v.y;
                     g[blk][4 * q + 2] = scale * v.z; g[blk][4 * q + 3] = scale * v.w;
                 }
+            if (J.keep_bits) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) keep_block_f32(g[blk], keep_word(J.keep_bits, row, blk, valid), h);
+            }
         }
         // ---- g_h2 = W3^T g3, masked by h2 -> g2 ----
 #pragma unroll
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_kernel(EncArgs A) {
 // travel through LDS; g_x is computed by the blk = 0 wave of the tile from all four g1 blocks in enc_bwd_dx_kernel's
 // order.  Bitwise identical to enc_bwd_dx_kernel.
 // ---------------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(512) void enc_bwd_dx_split_kernel(EncArgs A, int pairs0) {
     __shared__ float exch[2][2][4][16][64];            // [g2 | g1][tile][block][register][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -486,6 +505,14 @@ __global__ __launch_bounds__(512) void enc_bwd_dx_split_kernel(EncArgs A, int pa
                 in[bp][4 * q + 0] = valid ? scale * v.x : 0.f; in[bp][4 * q + 1] = valid ? scale * v.y : 0.f;
                 in[bp][4 * q + 2] = valid ? scale * v.z : 0.f; in[bp][4 * q + 3] = valid ? scale * v.w : 0.f;
             }
+        if (DROP) {
+#pragma unroll
+            for (int bp = 0; bp < 4; ++bp) {
+                const unsigned m = keep_word(J.keep_bits, rr, bp, valid) >> (4 * h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) in[bp][r] = ((m >> ((r & 3) + 8 * (r >> 2))) & 1u) ? in[bp][r] : 0.f;
+            }
+        }
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {                      // l = 0: g2 = (W3^T g3) * [h2 > 0];  l = 1: g1 = (W2^T g2) * [h1 > 0]
@@ -621,7 +648,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
     // staging role of this thread: row srow of the batch, float4 column sc4 of every array
     const unsigned srow = tid >> 5, sc4 = (tid & 31) * 4;
     const unsigned xrow = tid >> 3, xc = tid & 7;            // threads 0..127: the x rows
-    struct Stage { float4 pool, msg, g2, g1, h2, h1; float x; bool ok; };
+    struct Stage { float4 pool, msg, g2, g1, h2, h1; float x; bool ok; unsigned keep; };
+    const unsigned* __restrict__ KB = J.keep_bits;
     auto stage_load = [&](unsigned rb) -> Stage {            // issue the global loads of the batch starting at row rb
         Stage S;
         const unsigned row = rb + srow;
@@ -634,14 +662,15 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
         S.g1 = *reinterpret_cast<const float4*>(G1 + ro * EH + sc4);
         S.h2 = *reinterpret_cast<const float4*>(H2 + ro * EH + sc4);
         S.h1 = *reinterpret_cast<const float4*>(H1 + ro * EH + sc4);
+        S.keep = KB ? (KB[ro * 4 + (sc4 >> 5)] >> (sc4 & 31)) : 0xfu;          // the four keep bits of this float4 column
         const unsigned xr = rb + xrow;
         S.x = (tid < DW_ROWS * 8 && xr < r1 && xc < IN) ? X[xr * IN + xc] : 0.f;
         return S;
     };
     auto stage_write = [&](const Stage S, float* buf) {     // registers -> LDS (rows past the slab are zeros)
         float4* d = reinterpret_cast<float4*>(buf + srow * EH + sc4);
-        const float4 g3 = make_float4((S.pool.x + S.msg.x) * scale, (S.pool.y + S.msg.y) * scale,
-                                      (S.pool.z + S.msg.z) * scale, (S.pool.w + S.msg.w) * scale);
+        const float4 g3 = make_float4((S.keep & 1u) ? (S.pool.x + S.msg.x) * scale : 0.f, (S.keep & 2u) ? (S.pool.y + S.msg.y) * scale : 0.f,
+                                      (S.keep & 4u) ? (S.pool.z + S.msg.z) * scale : 0.f, (S.keep & 8u) ? (S.pool.w + S.msg.w) * scale : 0.f);
         auto sel = [&](const float4 v) {             // component-wise (a float4 ?: becomes a select through scratch)
             return make_float4(S.ok ? v.x : 0.f, S.ok ? v.y : 0.f, S.ok ? v.z : 0.f, S.ok ? v.w : 0.f);
         };
@@ -776,6 +805,8 @@ static int enc_check(const piml_encoder_branch* br, int nbr) {
     if (!br || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
     for (int i = 0; i < nbr; ++i)
         if (!branch_ok(br[i])) return hipErrorInvalidValue;
+    // dropout is a property of the launch: both branches carry keep_bits or neither does
+    if (nbr == 2 && (br[0].keep_bits != nullptr) != (br[1].keep_bits != nullptr)) return hipErrorInvalidValue;
     return hipSuccess;
 }
 
@@ -847,21 +878,26 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
         if (int e = enc_set_lds(reinterpret_cast<const void*>(enc_fwd_kernel), FWD_LDS_FLOATS * 4)) return e;
         attr_set = true;
     }
-    if (zero && zero_n > 0 && zero_n < (1ll << 31)) { A.zero = zero; A.zero_n = (int)zero_n; }
+    if (zero && zero_n > 0) {
+        if (zero_n >= (1ll << 31)) return hipErrorInvalidValue;       // a clear that cannot be honoured is an error, not a skip
+        A.zero = zero;
+        A.zero_n = (int)zero_n;
+    }
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
     if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         if (g_x3) {
             if (int e = x3_ready()) return e;
-            enc_x3_launch_fwd_split(A, pairs0, pairs1, s);
+            enc_x3_launch_fwd_split(A, pairs0, pairs1, br[0].keep_bits != nullptr, s);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL(enc_fwd_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        if (br[0].keep_bits) hipLaunchKernelGGL(enc_fwd_split_kernel<true>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        else hipLaunchKernelGGL(enc_fwd_split_kernel<false>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
         return hipGetLastError();
     }
     if (g_x3) {
         if (int e = x3_ready()) return e;
-        enc_x3_launch_fwd(A, total, s);
+        enc_x3_launch_fwd(A, total, br[0].keep_bits != nullptr, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(enc_fwd_kernel, dim3(total), dim3(ENC_THREADS), FWD_LDS_FLOATS * 4, s, A);
@@ -882,7 +918,8 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     // the backward form breaks even earlier than the forward, every wave rebuilding the whole g3.)
     if ((tiles[0] + tiles[1]) * 4 <= g_split_tiles * 3) {
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
-        hipLaunchKernelGGL(enc_bwd_dx_split_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        if (br[0].keep_bits) hipLaunchKernelGGL(enc_bwd_dx_split_kernel<true>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
+        else hipLaunchKernelGGL(enc_bwd_dx_split_kernel<false>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
         return hipGetLastError();
     }
     if (g_x3) {
@@ -890,7 +927,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
         // the sign bits exist iff the forward ran on enc_fwd_x3_kernel (same rule as enc_stage_fwd) and was given the buffer
         bool mask = tiles[0] + tiles[1] > g_split_tiles;
         for (int i = 0; i < nbr; ++i) mask = mask && br[i].relu_mask != nullptr;
-        enc_x3_launch_bwd_dx(A, total, mask, s);
+        enc_x3_launch_bwd_dx(A, total, mask, br[0].keep_bits != nullptr, s);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(enc_bwd_dx_kernel, dim3(total), dim3(ENC_THREADS), DX_LDS_FLOATS * 4, s, A);
@@ -913,7 +950,7 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (g_x3)
         if (int e = x3_ready()) return e;
     auto launch_dw = [&](const EncArgs& B, int grid) {
-        if (g_x3) return enc_x3_launch_bwd_dw(B, grid, s);
+        if (g_x3) return enc_x3_launch_bwd_dw(B, grid, B.br[0].keep_bits != nullptr, s);
         const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
         if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
         else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);

@@ -57,9 +57,10 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 
 // encoder_x3.hip: the same stages on split bf16 products (launch only; arguments checked by the callers in encoder.hip)
 int enc_x3_set_attributes();
-void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s);
-void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, hipStream_t s);      // few rows: four waves per tile
-void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
-void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
+// drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
+void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);
+void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
+void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
+void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, bool drop, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
 
 }  // namespace piml

@@ -62,6 +62,16 @@ __device__ __forceinline__ float keep_if(float v, unsigned m, int pos) {
     return __uint_as_float(__float_as_uint(v) & (unsigned)t);
 }
 
+// Dropout of the processor output (piml_encoder_branch.keep_bits: bit c & 31 of word c >> 5 of a row = keep feature c):
+// lane (row, h) holds features 32 blk + (r & 3) + 8 (r >> 2) + 4 h of block blk in register r, so after a shift by 4 h
+// the bit positions are compile-time constants.
+__device__ __forceinline__ void keep_block(f32x16& a, unsigned word, int h) {
+    const unsigned m = word >> (4 * h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = keep_if(a[r], m, (r & 3) + 8 * (r >> 2));
+}
+__device__ __forceinline__ unsigned word_of(const uint4& k, int blk) { return blk == 0 ? k.x : (blk == 1 ? k.y : (blk == 2 ? k.z : k.w)); }
+
 // The six products of one k-block.  The matrix core adds the 16 products of an instruction and the accumulator with the
 // low bits of the aligned addends cut off, not rounded (measured: sums over many rows of x3 results drift by ~0.5 ulp of
 // the accumulator per instruction, all in one direction), so the five small terms (<= 2^-8 of the product) go to a second
@@ -111,6 +121,7 @@ __device__ __forceinline__ void land_w3(const u32x4 (&w3r)[W3_ROUNDS], float* ld
     __syncthreads();
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,6 +240,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) tail[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
         load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
+        uint4 kw = make_uint4(0u, 0u, 0u, 0u);
+        if (DROP && valid) kw = reinterpret_cast<const uint4*>(J.keep_bits)[row];
         split_tile(a, P);
         const float scale = J.scale;
 #pragma unroll
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+            if (DROP) keep_block(acc, word_of(kw, blk), h);
             if (valid) {
                 float* o = J.msgs + row * EH;
 #pragma unroll
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int X3_SPLIT_LDS_BYTES = 2 * 2 * 4 * 3 * 2 * 64 * 16;       // [layer 2][tile 2][block 4][piece 3][s 2][lane 64] u32x4
 
+template <bool DROP>
 __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pairs0) {
     extern __shared__ __align__(16) float lds[];
     u32x4* exch = reinterpret_cast<u32x4*>(lds);
@@ -381,6 +396,7 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
             for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; wf[kb][2] = wn[kb][2]; }
             __syncthreads();
         } else {
+            if (DROP) keep_block(acc, valid ? J.keep_bits[row * 4 + blk] : 0u, h);
             store(J.msgs, J.scale);
         }
     }
@@ -408,7 +424,7 @@ __device__ __forceinline__ void land_w2t(const u32x4 (&w)[W2T_ROUNDS], float* ld
     __syncthreads();
 }
 
-template <bool MASK>
+template <bool MASK, bool DROP>
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -477,6 +493,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
                     g[blk][4 * q + 0] = scale * v.x; g[blk][4 * q + 1] = scale * v.y;
                     g[blk][4 * q + 2] = scale * v.z; g[blk][4 * q + 3] = scale * v.w;
                 }
+            if (DROP) {
+                uint4 kw = make_uint4(0u, 0u, 0u, 0u);
+                if (valid) kw = reinterpret_cast<const uint4*>(J.keep_bits)[row];
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) keep_block(g[blk], word_of(kw, blk), h);
+            }
         }
         split_tile(g, P);
         // ---- g_h2 = W3^T g3, masked by h2 -> g2 (g is dead: reused) ----
@@ -638,7 +660,7 @@ constexpr int DWX_LDS_BYTES = 2 * DWX_BUF * 16;
 constexpr int DWX_RED = 4 * 128 * 9;                   // floats of the final cross-group exchange (reuses the buffers)
 static_assert(DWX_RED * 4 <= DWX_LDS_BYTES, "exchange fits");
 
-template <bool POOL, bool MSGS>
+template <bool POOL, bool MSGS, bool DROP>
 __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -692,6 +714,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
     const __amdgpu_buffer_rsrc_t rs1 = rsrc(gside ? J.g2 : J.h1, r0 * EH, sbytes);
     const __amdgpu_buffer_rsrc_t rsg = rsrc(J.g1, r0 * EH, sbytes);
     const __amdgpu_buffer_rsrc_t rsx = rsrc(J.x, r0 * IN, srows * IN * 4);
+    // dropout: the keep word of (row, feature block sf >> 5), 16 bytes per row (G side only: g3 = keep * scale * (...))
+    const unsigned kbytes = srows * 16;
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned*>(DROP ? J.keep_bits + (size_t)r0 * 4 : nullptr), 0, (int)(DROP ? kbytes : 0u), 0x00020000);
     const unsigned xvoff = (tid < 128 && (unsigned)(tid & 7) < IN) ? ((tid >> 3) * IN + (tid & 7)) * 4 : 0x7fff0000u;
     auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
@@ -699,7 +725,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 
     unsigned pidx0 = __umulhi(r0 + 8 * sh, kmagic), prem0 = r0 + 8 * sh - pidx0 * K;      // of row r0 + 8 sh
     const unsigned q16 = __umulhi(16u, kmagic), m16 = 16u - q16 * K;                       // 16 / k, 16 % k
-    struct Stage { float a[8], m[8], v[8], g1[4], x; };
+    struct Stage { float a[8], m[8], v[8], g1[4], x; unsigned kw[8]; };
     auto stage_load = [&](unsigned rb_) -> Stage {           // issue the loads of the batch starting at row rb
         Stage S;
         const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);       // uniform; said so (else: a waterfall loop per scalar offset)
@@ -725,6 +751,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
             if (POOL && MSGS)
                 if (gside) S.m[t] = ld(rsm, sf * 4, rel);
             S.v[t] = ld(rs1, sf * 4, rel);
+            S.kw[t] = 0u;
+            if (DROP)
+                if (gside) S.kw[t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsk, (int)((sf >> 5) * 4), (int)(row < r1 ? (row - r0) * 16 : kbytes), 0);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -740,6 +769,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
         float u0[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) u0[t] = gside ? (S.a[t] + S.m[t]) * scale : S.a[t];
+        if (DROP && gside) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) u0[t] = ((S.kw[t] >> (sf & 31)) & 1u) ? u0[t] : 0.f;
+        }
         if (gside) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) { s3 += u0[t]; s2 += S.v[t]; }
@@ -864,42 +897,59 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 }
 
 int enc_x3_set_attributes() {
-    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    X3_SPLIT_LDS_BYTES))
-        return e;
-    const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true>)};
+    auto set = [](const void* f, int bytes) { return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<false>), X3_SPLIT_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<true>), X3_SPLIT_LDS_BYTES)) return e;
+    const void* dw[6] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true, true>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false, true>),
+                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true, true>)};
     for (const void* f : dw)
-        if (int e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DWX_LDS_BYTES)) return e;
-    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    X3_DX_LDS_BYTES))
-        return e;
-    if (int e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    X3_DX_LDS_BYTES))
-        return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(enc_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               X3_FWD_LDS_BYTES);
+        if (int e = set(f, DWX_LDS_BYTES)) return e;
+    const void* dx[4] = {reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true, false>),
+                         reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false, true>),
+                         reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true, true>)};
+    for (const void* f : dx)
+        if (int e = set(f, X3_DX_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<true>), X3_FWD_LDS_BYTES)) return e;
+    return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<false>), X3_FWD_LDS_BYTES);
 }
 
-void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, hipStream_t s) {
-    if (mask) hipLaunchKernelGGL(enc_bwd_dx_x3_kernel<true>, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
-    else hipLaunchKernelGGL(enc_bwd_dx_x3_kernel<false>, dim3(total), dim3(ENC_THREADS), X3_DX_LDS_BYTES, s, A);
+// `drop`: every branch of the launch carries keep_bits (checked by the callers: all or none)
+void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s) {
+    const dim3 g(total), b(ENC_THREADS);
+    if (mask && drop) hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<true, true>), g, b, X3_DX_LDS_BYTES, s, A);
+    else if (mask) hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<true, false>), g, b, X3_DX_LDS_BYTES, s, A);
+    else if (drop) hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<false, true>), g, b, X3_DX_LDS_BYTES, s, A);
+    else hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<false, false>), g, b, X3_DX_LDS_BYTES, s, A);
 }
 
-void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, hipStream_t s) {
+void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, bool drop, hipStream_t s) {
     const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
-    if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
-    else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
-    else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true>), dim3(grid), dim3(ENC_THREADS), DWX_LDS_BYTES, s, B);
+    const dim3 g(grid), b(ENC_THREADS);
+    if (drop) {
+        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true, true>), g, b, DWX_LDS_BYTES, s, B);
+        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false, true>), g, b, DWX_LDS_BYTES, s, B);
+        else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true, true>), g, b, DWX_LDS_BYTES, s, B);
+    } else {
+        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true, false>), g, b, DWX_LDS_BYTES, s, B);
+        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false, false>), g, b, DWX_LDS_BYTES, s, B);
+        else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true, false>), g, b, DWX_LDS_BYTES, s, B);
+    }
 }
 
-void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, hipStream_t s) {
-    hipLaunchKernelGGL(enc_fwd_split_x3_kernel, dim3((unsigned)(pairs0 + pairs1)), dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s) {
+    const dim3 g((unsigned)(pairs0 + pairs1));
+    if (drop) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<true>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+    else hipLaunchKernelGGL(enc_fwd_split_x3_kernel<false>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
 }
 
-void enc_x3_launch_fwd(const EncArgs& A, int total, hipStream_t s) {
-    hipLaunchKernelGGL(enc_fwd_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
+void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {
+    if (drop) hipLaunchKernelGGL(enc_fwd_x3_kernel<true>, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
+    else hipLaunchKernelGGL(enc_fwd_x3_kernel<false>, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
 }
 
 }  // namespace piml

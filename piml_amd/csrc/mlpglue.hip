@@ -352,21 +352,29 @@ __global__ __launch_bounds__(kColsumThreads) void colsum_stage2_kernel(const flo
 // ---------------------------------------------------------------------------------------------
 // msgs = scale * e ; pooled[agent] = sum_k msgs[agent, k]
 // ---------------------------------------------------------------------------------------------
+// the four keep bits of float4 lane `lane` of row `row` (piml_dropout_keep_bits layout), applied to v
+__device__ __forceinline__ void keep4(float4& v, const unsigned* __restrict__ keep, size_t row, int words, int lane) {
+    const unsigned m = keep[row * words + (lane >> 3)] >> (4 * (lane & 7));
+    v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+}
+
 __global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __restrict__ e,
                                                               const float4* __restrict__ bias, size_t agents, int k,
-                                                              int lanes, float scale, float4* __restrict__ msgs,
-                                                              float4* __restrict__ pooled) {
+                                                              int lanes, float scale, const unsigned* __restrict__ keep,
+                                                              float4* __restrict__ msgs, float4* __restrict__ pooled) {
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t agent = id / lanes;
     const int lane = (int)(id % lanes);
     if (agent >= agents) return;
     const size_t base = agent * k * lanes + lane;
+    const int words = (lanes + 7) / 8;
     const float4 b = bias ? bias[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < k; ++j) {
         float4 v = e[base + (size_t)j * lanes];
         if (bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        if (keep) keep4(v, keep, agent * k + j, words, lane);
         msgs[base + (size_t)j * lanes] = v;
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -375,12 +383,13 @@ __global__ __launch_bounds__(256) void scale_ksum_fwd_kernel(const float4* __res
 
 __global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __restrict__ g_pooled,
                                                               const float4* __restrict__ g_msgs, size_t agents, int k,
-                                                              int lanes, float scale, float4* __restrict__ g_e,
-                                                              float4* __restrict__ col_partials) {
+                                                              int lanes, float scale, const unsigned* __restrict__ keep,
+                                                              float4* __restrict__ g_e, float4* __restrict__ col_partials) {
     __shared__ float4 sh[256];
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t agent = id / lanes;
     const int lane = (int)(id % lanes);
+    const int words = (lanes + 7) / 8;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (agent < agents) {
         const size_t base = agent * k * lanes + lane;
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(256) void scale_ksum_bwd_kernel(const float4* __res
                 v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
             }
             v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            if (keep) keep4(v, keep, agent * k + j, words, lane);
             g_e[base + (size_t)j * lanes] = v;
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
@@ -601,14 +611,14 @@ PIML_API int piml_act_bwd_colsum_stage1(const float* g, const float* y, size_t r
 }
 
 PIML_API int piml_scale_ksum_fwd(const float* e, const float* bias, size_t agents, int k, int cols, float scale,
-                                 float* msgs, float* pooled, void* stream) {
+                                 const unsigned* keep_bits, float* msgs, float* pooled, void* stream) {
     if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
     if (agents == 0) return hipSuccess;
     if (!e || !msgs || !pooled) return hipErrorInvalidValue;
     const int lanes = cols / 4;
     hipLaunchKernelGGL(scale_ksum_fwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(e), reinterpret_cast<const float4*>(bias), agents, k, lanes, scale,
-                       reinterpret_cast<float4*>(msgs), reinterpret_cast<float4*>(pooled));
+                       keep_bits, reinterpret_cast<float4*>(msgs), reinterpret_cast<float4*>(pooled));
     return hipGetLastError();
 }
 
@@ -618,7 +628,7 @@ PIML_API int piml_ksum_blocks(size_t agents, int cols) {
 }
 
 PIML_API int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agents, int k, int cols,
-                                 float scale, float* g_e, float* col_partials, void* stream) {
+                                 float scale, const unsigned* keep_bits, float* g_e, float* col_partials, void* stream) {
     if (k <= 0 || cols <= 0 || cols % 4) return hipErrorInvalidValue;
     if (agents == 0) return hipSuccess;
     if (!g_e) return hipErrorInvalidValue;
@@ -626,7 +636,7 @@ PIML_API int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, siz
     if (col_partials && 256 % lanes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(scale_ksum_bwd_kernel, dim3(blocks_for(agents * lanes, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4*>(g_pooled), reinterpret_cast<const float4*>(g_msgs), agents, k,
-                       lanes, scale, reinterpret_cast<float4*>(g_e), reinterpret_cast<float4*>(col_partials));
+                       lanes, scale, keep_bits, reinterpret_cast<float4*>(g_e), reinterpret_cast<float4*>(col_partials));
     return hipGetLastError();
 }
 

@@ -1,10 +1,11 @@
 """PINNSF network family (reference src/models/model.py:16-119, 720-792, 950-1305).
 
-The residual MLPs stay plain PyTorch-ROCm modules (rocBLAS GEMMs); the pairwise geometry
-that feeds them is the HIP path (piml_amd.ops).  Class names, constructor `args` fields,
-forward input/output lists and state_dict keys match the reference so its checkpoints load
-unchanged (tests/test_models.py loads reference-initialised state_dicts and reproduces the
-reference's outputs).
+The modules hold the parameters (nn.Linear, so the reference's state_dicts load unchanged); on the GPU their
+arithmetic runs on this package's hand-written matrix-core kernels (piml_amd.ops.fused_pinnsf / fused_encoders /
+fused_row_decoder: encoders, processor incl. its train-mode dropout, neighbour-axis sum, decoders, predictors,
+collision head, desired force) for the reference's default geometry, and on library GEMMs + HIP glue kernels for
+every other geometry.  Class names, constructor `args` fields, forward input/output lists and state_dict keys match
+the reference (tests/test_models.py loads reference-initialised state_dicts and reproduces the reference's outputs).
 
 Reference behaviours kept on purpose:
   Q2  the desired-force normalisation reduces over dim=1 (model.py:1290): the per-agent norm
@@ -15,10 +16,23 @@ Reference behaviours kept on purpose:
       Dropout(2x) and resnet.0's weights are dead (but present in the state_dict).
   Q4  zero-padded neighbour rows still pass through the encoder (bias-driven constants).
 Deviation: in train mode the reference calls Dropout once per (discarded) block; here only the
-surviving block is evaluated, so the RNG stream differs (eval mode is exact).
+surviving block is evaluated, and on the fused GPU path the keep-mask is drawn by this package's own Philox kernel
+(ops.dropout_keep_bits), so the RNG stream differs (eval mode is exact; `ResDNN.keep_bits` injects a given mask).
 """
 import contextlib
+import logging
 import os
+
+_LOG = logging.getLogger('piml_amd')
+_NOTED = set()
+
+
+def _note_fallback(what):
+    """Say ONCE per reason that a GPU forward pass left the hand-written kernels for the library-GEMM path."""
+    if what not in _NOTED:
+        _NOTED.add(what)
+        _LOG.warning('piml_amd: %s -- this forward pass runs on library GEMMs + glue kernels, not on the fused '
+                     'matrix-core kernels', what)
 
 import torch
 import torch.nn as nn
@@ -119,14 +133,38 @@ class ResDNN(nn.Module):
         # the reference passes `use_bn` in ResBlock's dropout slot (model.py:113)
         self.resnet = nn.ModuleList([ResBlock(h[0], h[1:], activation, use_bn) for h in hidden_units])
 
-    def forward(self, x):
-        return self.dropout(self.resnet[len(self.hidden_units) - 1](x))
+    # tests / hosts that draw their own mask: int32 bits (rows, ceil(width / 32)) in ops.dropout_keep_bits' layout, used
+    # by the next train-mode forward passes instead of a fresh draw (both on the fused kernels and in `forward` below)
+    keep_bits = None
 
-    def pure_scale(self):
-        """2.0 when this module currently computes exactly 2 * x (quirk Q3 with dropout inactive), else None."""
-        if len(self.hidden_units) >= 2 and (not self.training or self.dropout.p == 0):
-            return 2.0
-        return None
+    def forward(self, x):
+        out = self.resnet[len(self.hidden_units) - 1](x)
+        if self.keep_bits is not None and self.training and 0 < self.dropout.p:
+            from .. import ops
+            keep = ops.unpack_keep_bits(self.keep_bits, out.shape[-1]).view(out.shape)
+            return out * keep / (1.0 - self.dropout.p) if self.dropout.p < 1 else out * 0.0
+        return self.dropout(out)
+
+    def scales_input(self):
+        """True when this module computes keep * scale * x (quirk Q3: >= 2 "layers" = Dropout(2 x))."""
+        return len(self.hidden_units) >= 2
+
+    def dropout_active(self):
+        return self.training and self.dropout.p > 0
+
+    def fused_spec(self, rows, device):
+        """(scale, keep_bits) of `keep * scale * x` for a (rows, width) input on `device`, or None when this module is
+        not of that form.  keep_bits is None without active dropout (eval mode or p = 0: scale = 2); in train mode it is
+        the injected `self.keep_bits` or a fresh draw (ops.dropout_keep_bits, one small launch) and scale = 2 / (1 - p)."""
+        if not self.scales_input():
+            return None
+        if not self.dropout_active():
+            return 2.0, None
+        p = float(self.dropout.p)
+        width = self.hidden_units[-1][-1]
+        from .. import ops
+        bits = self.keep_bits if self.keep_bits is not None else ops.dropout_keep_bits(rows, width, p, device)
+        return (2.0 / (1.0 - p) if p < 1 else 0.0), bits
 
 
 class attn_pooling(nn.Module):
@@ -199,11 +237,11 @@ class _PINNSFBase(nn.Module):
     @staticmethod
     def _process_and_pool(processor, encoded, bias=None):
         """(processor(encoded [+ bias]), its sum over the neighbour axis)."""
-        scale = processor.pure_scale()
-        if FUSED_GLUE and scale is not None and encoded.is_cuda and encoded.shape[-1] % 4 == 0 \
+        if FUSED_GLUE and processor.scales_input() and encoded.is_cuda and encoded.shape[-1] % 4 == 0 \
                 and encoded.dtype == torch.float32:
             from .. import ops
-            return ops.scale_ksum(encoded, scale, bias=bias)
+            scale, keep = processor.fused_spec(encoded.numel() // encoded.shape[-1], encoded.device)
+            return ops.scale_ksum(encoded, scale, bias=bias, keep_bits=keep)
         assert bias is None
         emb = processor(encoded)
         return emb, emb.sum(dim=-2)
@@ -213,13 +251,14 @@ class _PINNSFBase(nn.Module):
         (its bias-epilogue variant is the slower library kernel) and its bias is added inside the k-sum pass."""
         last = encoder.mlp[-2] if len(encoder.mlp) >= 2 else None
         if last is not None and encoder.fused_ok(feats) and isinstance(encoder.mlp[-1], nn.Identity) \
-                and processor.pure_scale() is not None and last.out_features % 4 == 0:
+                and processor.scales_input() and last.out_features % 4 == 0:
             if 256 % (last.out_features // 4) == 0 and feats.dim() >= 3:      # one autograd node for all of it
                 from .. import ops
                 lins = encoder.mlp[0::2]
                 relus = [isinstance(a, nn.ReLU) for a in encoder.mlp[1::2]]
-                return ops.encoder_pool(feats, relus, processor.pure_scale(),
-                                        *[t for lin in lins for t in (lin.weight, lin.bias)])
+                scale, keep = processor.fused_spec(feats.numel() // feats.shape[-1], feats.device)
+                return ops.encoder_pool(feats, relus, scale, *[t for lin in lins for t in (lin.weight, lin.bias)],
+                                        keep_bits=keep)
             return self._process_and_pool(processor, encoder(feats, defer_last_bias=True), bias=last.bias)
         return self._process_and_pool(processor, encoder(feats))
 
@@ -232,7 +271,7 @@ class _PINNSFBase(nn.Module):
         return (len(lins) == 3 and 1 <= feats.shape[-1] <= 8 and lins[0].in_features == feats.shape[-1]
                 and all(lin.out_features == 128 for lin in lins) and isinstance(acts[0], nn.ReLU)
                 and isinstance(acts[1], nn.ReLU) and isinstance(acts[2], nn.Identity)
-                and processor.pure_scale() is not None
+                and processor.scales_input() and processor.hidden_units[-1][-1] == 128
                 and feats.numel() // feats.shape[-1] >= FUSED_ENCODER_MIN_ROWS)
 
     def _fused_encoders(self, ped_features, obs_features):
@@ -241,12 +280,15 @@ class _PINNSFBase(nn.Module):
         if self.obs_feature_dim > 0:
             cand.append(('obs', obs_features, self.obs_encoder, self.obs_processor))
         use = [c for c in cand if self._encoder_fusable(*c[1:])]
+        if len({p.dropout_active() for _, _, _, p in use}) > 1:       # one launch = dropout on every branch or on none
+            use = use[:1]
         if not use:
             return {}
         from .. import ops
-        res = ops.fused_encoders([dict(x=f, scale=p.pure_scale(), pooled=not self.bottleneck,
+        specs = [p.fused_spec(f.numel() // f.shape[-1], f.device) for _, f, _, p in use]
+        res = ops.fused_encoders([dict(x=f, scale=sp[0], keep_bits=sp[1], pooled=not self.bottleneck,
                                        weights=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)])
-                                  for _, f, e, p in use])
+                                  for (_, f, e, p), sp in zip(use, specs)])
         return {c[0]: r for c, r in zip(use, res)}
 
     def _fused_row_decoders(self, pre):
@@ -309,14 +351,17 @@ class _PINNSFBase(nn.Module):
                     and isinstance(da[0], nn.ReLU) and isinstance(da[1], nn.Identity) and len(q.mlp) == 2
                     and (q.mlp[0].in_features, q.mlp[0].out_features) == (64, 2) and isinstance(q.mlp[1], nn.Identity)):
                 return None
+        if len({p.dropout_active() for _, _, p, _, _ in cand}) > 1:
+            return None
         from .. import ops
         fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
         head = self._fusable_head()
         packs = self._packs if (self._packs is not None and self._packs.active) else None
+        specs = [p.fused_spec(f.numel() // f.shape[-1], f.device) for f, _, p, _, _ in cand]
         res = ops.fused_pinnsf(
-            [dict(x=f, scale=p.pure_scale(), encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
+            [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
-                  predictor=[q.mlp[0].weight, q.mlp[0].bias]) for f, e, p, d, q in cand],
+                  predictor=[q.mlp[0].weight, q.mlp[0].bias]) for (f, e, p, d, q), sp in zip(cand, specs)],
             self_features, self.tau, fold_epilogue=fold, head=head, packs=packs)
         acc, msgs = res[0], res[1]
         if not fold:
@@ -388,6 +433,11 @@ class _PINNSFBase(nn.Module):
             return fused
         pre = {} if self.residual else self._fused_encoders(ped_features, obs_features)
         rowdec = self._fused_row_decoders(pre)
+        if FUSED_GLUE and FUSED_ENCODER and ped_features.is_cuda and not pre and not self.residual and \
+                ped_features.numel() // ped_features.shape[-1] >= FUSED_ENCODER_MIN_ROWS:
+            _note_fallback(f'{type(self).__name__}: geometry / dtype / flags outside the fused encoder kernels '
+                           f'(encoder {[lin.out_features for lin in self.ped_encoder.mlp[0::2]]}, '
+                           f'{len(self.ped_processor.hidden_units)} processor layers, {ped_features.dtype})')
         # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
         side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None
         # bottleneck variants with a per-row |dest|: neighbour-axis sums + desired force in one launch (ops.pinnsf_epilogue_ksum)

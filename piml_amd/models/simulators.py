@@ -583,9 +583,14 @@ class BaseSimulator(Pedestrians):
         replayed from ONE captured HIP graph.  One graph per batch geometry; the batch is copied into
         the graph's static input buffers.  Weights / Adam state touched by the warm-up iterations are
         restored before capture, so training is step-for-step the eager sequence."""
-        key = tuple((k, tuple(getattr(batch, k).shape)) for k in self._BATCH_TENSORS) + (id(self.optimizer),)
+        key = tuple((k, tuple(getattr(batch, k).shape)) for k in self._BATCH_TENSORS) + (id(self.optimizer), self.model.training)
         entry = self._graphed_steps.get(key)
         if entry is None:
+            # train mode: the processors' dropout masks are drawn on the device from a (seed, call counter) state that
+            # the draws advance themselves (ops.dropout_keep_bits), so every replay sees fresh masks; the counter the
+            # warm-up iterations advanced is put back, like the weights
+            drop_state = ops.dropout_state(batch.position.device)
+            drop_calls = drop_state[1].clone()
             static = types.SimpleNamespace(**{k: v for k, v in batch.__dict__.items() if not isinstance(v, torch.Tensor)})
             for k in self._BATCH_TENSORS:
                 setattr(static, k, getattr(batch, k).clone())
@@ -617,6 +622,7 @@ class BaseSimulator(Pedestrians):
                     for k, v in self.optimizer.state.get(p, {}).items():
                         if torch.is_tensor(v):
                             v.copy_(saved_s[id(p)][k]) if k in saved_s[id(p)] else v.zero_()
+                drop_state[1].copy_(drop_calls)
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

@@ -981,17 +981,19 @@ def mlp_chain(x, relus, *weights_and_biases, defer_last_bias=False):
 
 class _ScaleKSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e, scale, bias):
+    def forward(ctx, e, scale, bias, keep_bits):
         e = _gpu_f32('e', e)
         k, cols = e.shape[-2], e.shape[-1]
         agents = e.numel() // (k * cols)
         msgs = torch.empty_like(e)
         pooled = torch.empty(*e.shape[:-2], cols, device=e.device, dtype=torch.float32)
         b = _gpu_f32('bias', bias.detach()) if bias is not None else None
+        keep_bits = _check_keep_bits(keep_bits, agents * k, cols, e.device)
         with torch.cuda.device(e.device):
-            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(b), agents, k, cols, float(scale), _ptr(msgs),
-                                                      _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
+            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(b), agents, k, cols, float(scale), _ptr(keep_bits),
+                                                      _ptr(msgs), _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
         ctx.geom = (agents, k, cols, float(scale), tuple(e.shape))
+        ctx.keep_bits = keep_bits
         ctx.set_materialize_grads(False)      # an unused output arrives as None, not as a zero tensor
         return msgs, pooled
 
@@ -1001,14 +1003,14 @@ class _ScaleKSum(torch.autograd.Function):
         agents, k, cols, scale, shape = ctx.geom
         ref = g_pooled if g_pooled is not None else g_msgs
         if ref is None:
-            return None, None, None
+            return None, None, None, None
         g_e = torch.empty(shape, device=ref.device, dtype=torch.float32)
         gm = g_msgs.contiguous() if g_msgs is not None else None
         gp = g_pooled.contiguous() if g_pooled is not None else None
         with torch.cuda.device(ref.device):
-            _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e), None,
-                                                      _stream()), 'piml_scale_ksum_bwd')
-        return g_e, None, None
+            _lib.check(_lib.lib().piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(ctx.keep_bits),
+                                                      _ptr(g_e), None, _stream()), 'piml_scale_ksum_bwd')
+        return g_e, None, None, None
 
 
 class _EncoderPool(torch.autograd.Function):
@@ -1018,7 +1020,7 @@ class _EncoderPool(torch.autograd.Function):
     stage of the last layer's bias gradient, so that layer needs no pass of its own over d/d(e) -- then the chain."""
 
     @staticmethod
-    def forward(ctx, x, relus, scale, *wb):
+    def forward(ctx, x, relus, scale, keep_bits, *wb):
         x2 = x.reshape(-1, x.shape[-1])
         acts = [x2]
         n = len(relus)
@@ -1033,10 +1035,12 @@ class _EncoderPool(torch.autograd.Function):
         agents = e.shape[0] // k
         msgs = torch.empty(*x.shape[:-1], cols, device=x.device, dtype=torch.float32)
         pooled = torch.empty(*x.shape[:-2], cols, device=x.device, dtype=torch.float32)
+        keep_bits = _check_keep_bits(keep_bits, agents * k, cols, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(wb[-1]), agents, k, cols, float(scale), _ptr(msgs),
-                                                      _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
+            _lib.check(_lib.lib().piml_scale_ksum_fwd(_ptr(e), _ptr(wb[-1]), agents, k, cols, float(scale), _ptr(keep_bits),
+                                                      _ptr(msgs), _ptr(pooled), _stream()), 'piml_scale_ksum_fwd')
         ctx.save_for_backward(*acts[:-1], *wb[0::2])
+        ctx.keep_bits = keep_bits
         ctx.relus, ctx.x_shape, ctx.geom = tuple(relus), x.shape, (agents, k, cols, float(scale))
         ctx.set_materialize_grads(False)
         return msgs, pooled
@@ -1047,7 +1051,7 @@ class _EncoderPool(torch.autograd.Function):
         n = len(ctx.relus)
         ref = g_pooled if g_pooled is not None else g_msgs
         if ref is None:
-            return (None,) * (3 + 2 * n)
+            return (None,) * (4 + 2 * n)
         saved = ctx.saved_tensors
         acts, weights = saved[:n], saved[n:]
         agents, k, cols, scale = ctx.geom
@@ -1058,20 +1062,21 @@ class _EncoderPool(torch.autograd.Function):
         gm = g_msgs.contiguous() if g_msgs is not None else None
         gp = g_pooled.contiguous() if g_pooled is not None else None
         with torch.cuda.device(ref.device):
-            _lib.check(L.piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(g_e), _ptr(partials),
-                                             _stream()), 'piml_scale_ksum_bwd')
+            _lib.check(L.piml_scale_ksum_bwd(_ptr(gp), _ptr(gm), agents, k, cols, scale, _ptr(ctx.keep_bits), _ptr(g_e),
+                                             _ptr(partials), _stream()), 'piml_scale_ksum_bwd')
         if nb > 1:
             db, pending = torch.empty(cols, device=ref.device, dtype=torch.float32), (partials, nb, cols)
         else:
             db, pending = partials, None
         need = ctx.needs_input_grad
-        gx, grads = _chain_backward(ctx.relus, acts, None, weights, g_e, need[0], need[3:], first=(g_e, db, pending))
-        return (gx.view(ctx.x_shape) if gx is not None else None, None, None, *grads)
+        gx, grads = _chain_backward(ctx.relus, acts, None, weights, g_e, need[0], need[4:], first=(g_e, db, pending))
+        return (gx.view(ctx.x_shape) if gx is not None else None, None, None, None, *grads)
 
 
-def encoder_pool(x, relus, scale, *weights_and_biases):
+def encoder_pool(x, relus, scale, *weights_and_biases, keep_bits=None):
     """(scale * encoder(x), its sum over the neighbour axis) for x (..., k, in): mlp_chain (last layer without ReLU)
-    + scale_ksum as one autograd node.  Needs cols % 4 == 0 and 256 % (cols / 4) == 0 for the last layer's width."""
+    + scale_ksum as one autograd node.  Needs cols % 4 == 0 and 256 % (cols / 4) == 0 for the last layer's width.
+    keep_bits: the processor's train-mode dropout mask (dropout_keep_bits layout), see scale_ksum."""
     if not x.is_cuda:
         raise _lib.PimlHipError('encoder_pool: expected a GPU tensor (piml_amd has no CPU path)')
     cols = weights_and_biases[-2].shape[0]
@@ -1081,20 +1086,103 @@ def encoder_pool(x, relus, scale, *weights_and_biases):
                          'last layer, and a last width w with w % 4 == 0 and 256 % (w / 4) == 0 expected')
     if not torch.is_grad_enabled():
         return scale_ksum(mlp_chain(x, relus, *weights_and_biases, defer_last_bias=True), scale,
-                          bias=weights_and_biases[-1])
-    return _EncoderPool.apply(_gpu_f32('x', x), tuple(bool(r) for r in relus), float(scale), *weights_and_biases)
+                          bias=weights_and_biases[-1], keep_bits=keep_bits)
+    return _EncoderPool.apply(_gpu_f32('x', x), tuple(bool(r) for r in relus), float(scale), keep_bits,
+                              *weights_and_biases)
 
 
-def scale_ksum(e, scale=2.0, bias=None):
-    """(scale * (e + bias), its sum over axis -2) for e (..., k, cols), cols % 4 == 0: the eval-mode PINNSF processor
-    (quirk Q3) + neighbour-axis pooling (src/models/model.py:1279-1283) in one pass.  `bias` (cols, optional) is
-    the deferred bias of the Linear that produced `e` (mlp_chain(..., defer_last_bias=True)); it is a constant
-    here -- its gradient is the column sum of d/d(e), which that layer's backward returns."""
+def scale_ksum(e, scale=2.0, bias=None, keep_bits=None):
+    """(keep * scale * (e + bias), its sum over axis -2) for e (..., k, cols), cols % 4 == 0: the PINNSF processor
+    (quirk Q3: Dropout(2 x)) + neighbour-axis pooling (src/models/model.py:1279-1283) in one pass.  `bias` (cols,
+    optional) is the deferred bias of the Linear that produced `e` (mlp_chain(..., defer_last_bias=True)); it is a
+    constant here -- its gradient is the column sum of d/d(e), which that layer's backward returns.  keep_bits
+    (rows, ceil(cols / 32)) int32, optional: the train-mode dropout mask (dropout_keep_bits); the caller folds
+    1 / (1 - p) into `scale`."""
     if e.dim() < 2 or e.shape[-1] % 4:
         raise ValueError('scale_ksum: e (..., k, cols) with cols % 4 == 0 expected')
     if bias is not None and tuple(bias.shape) != (e.shape[-1],):
         raise ValueError('scale_ksum: bias (cols,) expected')
-    return _ScaleKSum.apply(e, scale, bias)
+    return _ScaleKSum.apply(e, scale, bias, keep_bits)
+
+
+# ------------------------------------------------------------------------------------------------
+# Train-mode dropout of the PINNSF processor (reference: ResDNN.forward = Dropout_p(2 x), src/models/model.py:82-119
+# with quirk Q3; model.train() at src/models/simulators.py:311; --dropout 0.5 at src/main.py:45).  The fused kernels
+# take the mask as BITS, (rows, ceil(cols / 32)) int32, bit c & 31 of word c >> 5 = feature c of the row is kept; the
+# caller folds 1 / (1 - p) into the processor's scale.  piml_dropout_keep_bits draws it with Philox4x32-10 from a
+# (seed, call counter) pair that lives on the device and is advanced by the launch itself, so a captured training step
+# draws a fresh mask on every replay.
+# ------------------------------------------------------------------------------------------------
+_DROPOUT_STATE = {}        # device index -> [state tensor (4 x int64: seed, offset, ticket, 0), torch's CUDA seed seen last]
+
+
+def dropout_state(device, seed=None):
+    """The device's dropout state [seed, call counter, ticket, 0] (int64 tensor).  It is seeded from torch's CUDA seed
+    and re-seeded (counter back to 0) whenever that seed changes (torch.manual_seed), or explicitly with `seed`.
+    Inside a stream capture nothing is written from the host."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    torch_seed = int(torch.cuda.initial_seed())
+    ent = _DROPOUT_STATE.get(idx)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None and capturing:
+        raise _lib.PimlHipError('dropout_state: first use inside a stream capture (call ops.dropout_state(device) before)')
+    if ent is None or ((seed is not None or ent[1] != torch_seed) and not capturing):
+        want = int(seed) if seed is not None else torch_seed
+        signed = want - (1 << 64) if want >= (1 << 63) else want
+        st = torch.tensor([signed, 0, 0, 0], dtype=torch.int64, device=device)
+        if ent is None:
+            _DROPOUT_STATE[idx] = [st, torch_seed]
+        else:                       # keep the tensor a captured graph may already hold
+            ent[0].copy_(st)
+            ent[1] = torch_seed
+    return _DROPOUT_STATE[idx][0]
+
+
+def dropout_keep_bits(rows, cols, p, device):
+    """Fresh keep-mask bits (rows, ceil(cols / 32)) int32 for dropout probability p (one launch on the current stream)."""
+    if not 0.0 <= p <= 1.0:
+        raise ValueError('dropout probability has to be between 0 and 1')
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise _lib.PimlHipError('dropout_keep_bits: expected a GPU device (piml_amd has no CPU path)')
+    st = dropout_state(device)
+    bits = torch.empty(rows, (cols + 31) // 32, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().piml_dropout_keep_bits(st.data_ptr(), rows, cols, float(p), _ptr(bits), _stream()),
+                   'piml_dropout_keep_bits')
+    return bits
+
+
+def pack_keep_bits(keep):
+    """bool / 0-1 tensor (..., cols) -> int32 bits (rows, ceil(cols / 32)) in the piml_dropout_keep_bits layout
+    (torch ops; for masks injected by tests or by a host that draws its own)."""
+    cols = keep.shape[-1]
+    k2 = keep.reshape(-1, cols).to(torch.int64)
+    words = (cols + 31) // 32
+    pad = words * 32 - cols
+    if pad:
+        k2 = torch.cat((k2, k2.new_zeros(k2.shape[0], pad)), 1)
+    w = (k2.view(-1, words, 32) << torch.arange(32, device=keep.device, dtype=torch.int64)).sum(-1)
+    w = torch.where(w >= (1 << 31), w - (1 << 32), w)
+    return w.to(torch.int32)
+
+
+def unpack_keep_bits(bits, cols):
+    """int32 bits (rows, words) -> bool (rows, cols)."""
+    b = bits.to(torch.int64) & 0xffffffff
+    out = (b.unsqueeze(-1) >> torch.arange(32, device=bits.device, dtype=torch.int64)) & 1
+    return out.reshape(bits.shape[0], -1)[:, :cols].bool()
+
+
+def _check_keep_bits(keep_bits, rows, cols, device):
+    if keep_bits is None:
+        return None
+    if keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (rows, (cols + 31) // 32) or keep_bits.device != device \
+            or not keep_bits.is_contiguous():
+        raise ValueError(f'keep_bits: contiguous int32 ({rows}, {(cols + 31) // 32}) on {device} expected, got '
+                         f'{keep_bits.dtype} {tuple(keep_bits.shape)} on {keep_bits.device}')
+    return keep_bits
 
 
 class _TrainRolloutStep(torch.autograd.Function):
@@ -1247,8 +1335,9 @@ ENCODER_MAX_IN = 8
 
 
 def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
-                       g_x=None, partials=None, packed=None, grads=None):
+                       g_x=None, partials=None, packed=None, grads=None, keep_bits=None):
     B = _lib.EncoderBranch()
+    B.keep_bits = _ptr(keep_bits)
     B.x, B.rows, B.in_dim, B.k = x2.data_ptr(), x2.shape[0], x2.shape[1], int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.scale = float(scale)
@@ -1271,7 +1360,7 @@ class _FusedEncoders(torch.autograd.Function):
     outputs: per branch msgs (..., k, 128), pooled (..., 128) (a 0-element tensor when not wanted)."""
 
     @staticmethod
-    def forward(ctx, nbr, scales, want_pooled, need_grad, *tensors):
+    def forward(ctx, nbr, scales, want_pooled, need_grad, keeps, *tensors):
         L = _lib.lib()
         xs = [tensors[7 * b] for b in range(nbr)]
         wbs = [[_gpu_f32('encoder weight', t.detach()) for t in tensors[7 * b + 1:7 * b + 7]] for b in range(nbr)]
@@ -1287,9 +1376,10 @@ class _FusedEncoders(torch.autograd.Function):
             msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
             h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
+        keeps = [_check_keep_bits(keeps[b], x2s[b].shape[0], ENCODER_HIDDEN, dev) for b in range(nbr)]
         packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
         arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b],
-                                                              packed=packed[b]) for b in range(nbr)])
+                                                              packed=packed[b], keep_bits=keeps[b]) for b in range(nbr)])
         outs = []
         with torch.cuda.device(dev):
             _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
@@ -1307,6 +1397,7 @@ class _FusedEncoders(torch.autograd.Function):
         ctx.save_for_backward(*x2s, *[t for t in h1s if t is not None], *[t for t in h2s if t is not None],
                               *[w for wb in wbs for w in wb], packed)
         ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
+        ctx.keeps = keeps
         ctx.set_materialize_grads(False)
         return tuple(outs)
 
@@ -1314,7 +1405,7 @@ class _FusedEncoders(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gouts):
         nbr, scales, want_pooled, ks, xshapes, need_grad = ctx.meta
-        nin = 4 + 7 * nbr
+        nin = 5 + 7 * nbr
         if not need_grad or all(g is None for g in gouts):
             return (None,) * nin
         L = _lib.lib()
@@ -1338,10 +1429,10 @@ class _FusedEncoders(torch.autograd.Function):
             gp = _gpu_f32('g_pooled', gp).reshape(-1, ENCODER_HIDDEN) if gp is not None else None
             g2 = torch.empty(R, ENCODER_HIDDEN, **opt)
             g1 = torch.empty(R, ENCODER_HIDDEN, **opt)
-            gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[4 + 7 * b] else None
+            gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[5 + 7 * b] else None
             keep.append((gm, gp, g2, g1, gx))
             structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], None, h1s[b], h2s[b], gp, gm, g2, g1, gx,
-                                              packed=packed[b]))
+                                              packed=packed[b], keep_bits=ctx.keeps[b]))
         arr = (_lib.EncoderBranch * len(live))(*structs)
         import ctypes
         w0 = ctypes.c_int(0)
@@ -1357,8 +1448,8 @@ class _FusedEncoders(torch.autograd.Function):
         for i, b in enumerate(live):
             flat = flats[i]
             in_dim = x2s[b].shape[1]
-            need = ctx.needs_input_grad[4 + 7 * b:4 + 7 * b + 7]
-            o = 4 + 7 * b
+            need = ctx.needs_input_grad[5 + 7 * b:5 + 7 * b + 7]
+            o = 5 + 7 * b
             if need[0]:
                 grads[o] = keep[i][4].view(xshapes[b])
             dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
@@ -1372,8 +1463,10 @@ class _FusedEncoders(torch.autograd.Function):
 
 def fused_encoders(branches):
     """branches: list (1 or 2 entries) of dicts {x (..., k, in<=8), scale, weights: (w1, b1, w2, b2, w3, b3) with the
-    nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool}.  Returns [(msgs (..., k, 128), pooled
-    (..., 128) | None), ...]: msgs = scale * encoder(x), pooled = msgs.sum(-2)  (src/models/model.py:1271-1283)."""
+    nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool, keep_bits: optional int32 (rows, 4), the
+    processor's train-mode dropout mask (dropout_keep_bits; fold 1 / (1 - p) into `scale`; all branches or none)}.
+    Returns [(msgs (..., k, 128), pooled (..., 128) | None), ...]: msgs = keep * scale * encoder(x),
+    pooled = msgs.sum(-2)  (src/models/model.py:1271-1283)."""
     if not 1 <= len(branches) <= 2:
         raise ValueError('fused_encoders: one or two branches')
     flat = []
@@ -1389,8 +1482,11 @@ def fused_encoders(branches):
             raise ValueError('fused_encoders: empty input')
         flat += [x, *w]
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in flat)
+    keeps = tuple(b.get('keep_bits') for b in branches)
+    if any(k is None for k in keeps) and not all(k is None for k in keeps):
+        raise ValueError('fused_encoders: keep_bits for every branch or for none')
     out = _FusedEncoders.apply(len(branches), tuple(float(b['scale']) for b in branches),
-                               tuple(bool(b.get('pooled', True)) for b in branches), need_grad, *flat)
+                               tuple(bool(b.get('pooled', True)) for b in branches), need_grad, keeps, *flat)
     return [(out[2 * i], out[2 * i + 1] if branches[i].get('pooled', True) else None) for i in range(len(branches))]
 
 
@@ -1486,11 +1582,11 @@ class _FusedPinnsf(torch.autograd.Function):
     outputs: acc (..., N, 2) (= predictions when fold_epilogue), msgs (..., N, k, 128) per branch, and with a head
     sigmoid(head(msgs of branch 0)) (..., N, k)."""
     PER = 13
-    FIRST = 8          # index of the first branch tensor among the inputs
-    SELF = 7           # index of self_features
+    FIRST = 9          # index of the first branch tensor among the inputs
+    SELF = 8           # index of self_features
 
     @staticmethod
-    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, packs, nhead, self_features, *tensors):
+    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, packs, nhead, keeps, self_features, *tensors):
         import ctypes
         L = _lib.lib()
         PER = _FusedPinnsf.PER
@@ -1527,8 +1623,9 @@ class _FusedPinnsf(torch.autograd.Function):
             epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
             dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
             hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt) if nhead else None
+        keeps = [_check_keep_bits(keeps[b], x2s[b].shape[0], H, dev) for b in range(nbr)]
         earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
-                                                               packed=epack[b]) for b in range(nbr)])
+                                                               packed=epack[b], keep_bits=keeps[b]) for b in range(nbr)])
         pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
         dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
@@ -1551,6 +1648,7 @@ class _FusedPinnsf(torch.autograd.Function):
                                   *(hwb if nhead else []))
         ctx.meta = (nbr, tuple(scales), float(tau), bool(fold_epilogue), tuple(ks), [tuple(x.shape) for x in xs],
                     tuple(self_features.shape), agents, need_grad, int(nhead))
+        ctx.keeps = keeps
         ctx.set_materialize_grads(False)
         out = (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
         if nhead:
@@ -1605,7 +1703,7 @@ class _FusedPinnsf(torch.autograd.Function):
                     g_pooled[b] = torch.empty(agents, H, **opt)
                 keep.append((gm, g2, g1, gx))
                 estructs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], None, h1s[b], h2s[b], g_pooled[b], gm,
-                                                   g2, g1, gx, packed=epack[b]))
+                                                   g2, g1, gx, packed=epack[b], keep_bits=ctx.keeps[b]))
             earr = (_lib.EncoderBranch * len(live))(*estructs)
             import ctypes
             w0 = ctypes.c_int(0)
@@ -1663,7 +1761,8 @@ class _FusedPinnsf(torch.autograd.Function):
 
 def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, packs=None):
     """The non-bottleneck PINNSF network on the fused kernels.  branches: 1 or 2 dicts {x (..., N, k, in <= 8), scale,
-    encoder: (w1, b1, w2, b2, w3, b3), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b)}.
+    encoder: (w1, b1, w2, b2, w3, b3), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b),
+    keep_bits: optional int32 (rows, 4) train-mode dropout mask of the processor (see fused_encoders)}.
     Returns (acc (..., N, 2), [msgs per branch]): acc = sum over branches of predictor(decoder(sum_k msgs)), plus the
     desired-force term (v0 d/|d| - v) / tau of self_features (..., N, 7) when fold_epilogue.
     head: (w1 (64,128), b1, w2 (1,64), b2) of the `pinnsf_m` collision head; its sigmoid output on the messages of
@@ -1692,8 +1791,11 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
     if tuple(self_features.shape[:-1]) != tuple(branches[0]['x'].shape[:-2]) or self_features.shape[-1] != 7:
         raise ValueError('fused_pinnsf: self_features (..., N, 7) must match the features\' leading shape')
     need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in flat) or self_features.requires_grad)
+    keeps = tuple(b.get('keep_bits') for b in branches)
+    if any(k is None for k in keeps) and not all(k is None for k in keeps):
+        raise ValueError('fused_pinnsf: keep_bits for every branch or for none')
     out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
-                             bool(fold_epilogue), packs, int(head is not None), self_features, *flat)
+                             bool(fold_epilogue), packs, int(head is not None), keeps, self_features, *flat)
     nbr = len(branches)
     if head is not None:
         return out[0], list(out[1:1 + nbr]), out[1 + nbr]
