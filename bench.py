@@ -526,6 +526,10 @@ def main():
                     help='several GPUs: also time the other --exchange variant after the timed region (informational)')
     ap.add_argument('--strong-baseline', type=int, default=1,
                     help='strong scaling on several GPUs: rank 0 also times the whole scene on one GPU (outside the timed region)')
+    ap.add_argument('--train-mode', type=int, default=0,
+                    help='1: the model of the timed step in train() mode with the reference\'s --dropout 0.5 (fresh keep-masks '
+                         'drawn on the device every step); the replayed step is then not compared with an eager one '
+                         '(different masks).  Default 0: eval(); the train-mode step is reported under secondary.train_mode_step')
     ap.add_argument('--mlp', choices=('fused', 'library'), default='fused',
                     help='fused: the PINNSF network on the hand-written matrix-core kernels (encoder_x3.hip / encoder.hip / decoder.hip); '
                          'library: round 1\'s path, rocBLAS / hipBLASLt GEMMs + HIP glue kernels (A/B comparison)')
@@ -605,8 +609,11 @@ def main():
     # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
     # pre-tuned selections are validated for the cfg3 row counts only; otherwise the branches stay on one stream.
     two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and cfg3_shapes) or args.two_streams == 2
+    if args.train_mode:
+        args.verify = 0
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
-              two_streams, bool(args.graph), exchange=args.exchange, overlap=bool(args.overlap))
+              two_streams, bool(args.graph), exchange=args.exchange, overlap=bool(args.overlap),
+              train_mode=bool(args.train_mode))
     M_eff = st.M_eff
 
     if autotune:
@@ -772,6 +779,7 @@ def main():
             'agent_steps_per_s': N * args.steps / elapsed,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
+            'model_mode': 'train() dropout 0.5' if args.train_mode else 'eval()',
             'mlp': (('fused matrix-core kernels (piml_amd/csrc/encoder_x3.hip: f32 products as six bf16 products of exact '
                      'three-way splits, f32 accumulation -- closer to float64 than the f32 matrix instruction, '
                      'tests/test_encoder_gpu.py; decoder.hip: f32 matrix instruction)' if x3_products else
@@ -897,9 +905,10 @@ def main():
                     secondary[key] = {
                         'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': tr.mode, 'dropout': 0.5,
                         'note': f'the same forward + backward step with {mname} in train() mode, dropout 0.5 (the reference\'s '
-                                'training configuration, src/main.py:45, src/models/simulators.py:311): two keep-mask launches per '
-                                'step (Philox, device-side call counter) + the mask applied inside the fused encoder kernels '
-                                '(forward epilogue, dX chain, dW staging); parity with injected masks: tests/test_dropout_gpu.py'}
+                                'training configuration, src/main.py:45, src/models/simulators.py:311): the encoder forward kernel draws '
+                                'the keep-masks itself (Philox4x32-10, one call per row, device-side draw counter: a fresh mask on every '
+                                'replay), applies them in its epilogue and leaves them as bits for the dX chain and the dW staging; '
+                                'parity with injected masks and bit-exact masks: tests/test_dropout_gpu.py'}
                     del tr
                 except Exception as ex:   # noqa: BLE001 - informational
                     secondary[key] = {'error': f'{type(ex).__name__}: {ex}'}

@@ -402,13 +402,17 @@ int piml_scale_ksum_bwd(const float* g_pooled, const float* g_msgs, size_t agent
  * (src/models/model.py:82-119 with quirk Q3; model.train() at src/models/simulators.py:311; --dropout 0.5 at
  * src/main.py:45): the fused kernels take the mask as bits -- keep_bits (rows, ceil(cols / 32)) dwords, bit (c & 31)
  * of word (c >> 5) of a row = feature c of that row is kept -- and the caller folds 1 / (1 - p) into `scale`.
- *   state: 4 x uint64 on the device: [seed, offset, ticket, unused].  Every call draws the uniforms of call number
- *          `offset` and advances `offset` by one ON THE DEVICE (last block out), so a call captured into a hipGraph
- *          draws a fresh mask on every replay.  Philox4x32-10, counter = (offset lo, offset hi, row, c >> 2),
- *          key = (seed lo, seed hi); feature c takes output word c & 3 and is kept iff that word >= round(p * 2^32).
+ *   state: 4 x uint64 on the device: [seed, offset, ticket, unused].  Every call draws with draw number `offset` and
+ *          advances `offset` by one ON THE DEVICE (last block out), so a call captured into a hipGraph draws a fresh
+ *          mask on every replay.  Philox4x32-10, counter = (offset lo, offset hi, row, (stream_id << 16) | sub),
+ *          key = (seed lo, seed hi).  p == 0.5: keep word w of a row = output word w & 3 of the call
+ *          sub = 0xFFFF - (w >> 2) (one call per 128 features).  Other p: feature c takes 16 bits -- call sub = c >> 3,
+ *          output word (c >> 1) & 3, half c & 1 -- and is kept iff they are >= round(p * 65536).
+ *   stream_id (0 .. 65535) tells masks of the same draw apart (the two branches of one encoder launch use 0 and 1).
  *   p in [0, 1]; p = 1 keeps nothing.
  */
-int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, float p, unsigned* keep_bits, void* stream);
+int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, float p, int stream_id, unsigned* keep_bits,
+                           void* stream);
 
 /*
  * HIP-event timer for measuring a kernel live on the stream it is launched on, also while
@@ -467,9 +471,15 @@ typedef struct piml_encoder_branch {
                       bits.  A forward on the split-product kernels with more than piml_encoder_split_tiles() tiles writes
                       it, and the backward of the SAME configuration then reads these 2 MB instead of h1 and h2 (2 x 33 MB at
                       the 4096-agent scene) in its dX chain; pass the same pointer to both, or NULL to both */
-    const unsigned* keep_bits; /* optional (rows, 4) dwords, piml_dropout_keep_bits layout: the processor's train-mode
+    unsigned* keep_bits; /* optional (rows, 4) dwords, piml_dropout_keep_bits layout: the processor's train-mode
                       dropout.  msgs = keep * scale * (...) in the forward, g3 = keep * scale * (g_pooled + g_msgs) in the
                       backward (dX chain and dW3 / db3); the caller passes scale = 2 / (1 - p) and the same bits to both */
+    unsigned long long* drop_state; /* forward only, optional: a piml_dropout_keep_bits state.  Non-NULL: the forward DRAWS the
+                      mask of this launch (stream_id = index of the branch) with probability drop_p and leaves it in keep_bits
+                      for the backward: for drop_p == 0.5 on the split-product kernels inside the forward kernel itself (one
+                      Philox call per row, no extra launch), otherwise by one generator launch for all branches in front of it.
+                      The draw counter advances once per launch.  Same state for every branch.  NULL: keep_bits is given */
+    float drop_p;
 } piml_encoder_branch;
 
 /* floats of one partial slot / of one `packed` buffer */

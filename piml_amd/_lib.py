@@ -24,7 +24,7 @@ class EncoderBranch(ctypes.Structure):
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
                 ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p), ('relu_mask', _p),
-                ('keep_bits', _p)]
+                ('keep_bits', _p), ('drop_state', _p), ('drop_p', _f)]
 
 
 class DecoderBranch(ctypes.Structure):
@@ -78,7 +78,7 @@ SIGNATURES = {
     'piml_scale_ksum_fwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p, _p],
     'piml_ksum_blocks': [_z, _i],
     'piml_scale_ksum_bwd': [_p, _p, _z, _i, _i, _f, _p, _p, _p, _p],
-    'piml_dropout_keep_bits': [_p, _ll, _i, _f, _p, _p],
+    'piml_dropout_keep_bits': [_p, _ll, _i, _f, _i, _p, _p],
     'piml_timer_create': [ctypes.POINTER(_p)],
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],

@@ -1,77 +1,100 @@
 // Keep-mask bits of the PINNSF processor's train-mode dropout (reference: ResDNN.forward = Dropout_p(2 x),
 // src/models/model.py:82-119 with SURVEY quirk Q3; model.train() at src/models/simulators.py:311, --dropout 0.5 at
 // src/main.py:45).  The fused encoder kernels apply the mask in their epilogue / at the head of their backward chain
-// (encoder_x3.hip, encoder.hip, mlpglue.hip: scale_ksum); this file only draws it.
-//
-// Philox4x32-10 (Salmon et al., SC'11), counter = (offset lo, offset hi, row, c >> 2), key = (seed lo, seed hi): one
-// call yields the uniforms of four consecutive features.  The call counter `offset` lives on the device and is advanced
-// by the launch itself, so a launch captured into a hipGraph draws a fresh mask on every replay.
+// (encoder_x3.hip, encoder.hip, mlpglue.hip: scale_ksum); the split-product forward kernels draw the p = 0.5 mask
+// themselves (one Philox call per row); this file is the stand-alone generator for every other case.  Stream: philox.hpp.
 #include "common.hpp"
+#include "philox.hpp"
+#include "stages.hpp"
 #include "../../include/piml_hip.h"
 
 namespace piml {
 
-struct U4 { unsigned x, y, z, w; };
+struct DropJob {
+    unsigned* bits;
+    long long rows;
+    unsigned stream;
+};
+struct DropArgs {
+    DropJob job[2];
+    int njobs;
+    long long n0;            // threads of job 0
+    u64* state;
+    int words, cols;
+    unsigned thresh16;       // keep iff 16 random bits >= thresh16 (0 .. 65536)
+    int fair;                // p == 0.5: one call per 128 features
+};
 
-__device__ __forceinline__ U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+// one thread per (row, word of 32 features)
+__global__ __launch_bounds__(256) void dropout_keep_bits_kernel(DropArgs A) {
+    const u64 seed = A.state[0], off = A.state[1];
+    long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int j = (A.njobs > 1 && id >= A.n0) ? 1 : 0;
+    if (j) id -= A.n0;
+    const DropJob J = A.job[j];
+    if (id < J.rows * A.words) {
+        const unsigned row = (unsigned)(id / A.words), w = (unsigned)(id % A.words);
+        unsigned m = 0;
+        if (A.fair) {
+            const PhiloxOut r = philox4x32_10((unsigned)off, (unsigned)(off >> 32), row, (J.stream << 16) | (0xFFFFu - (w >> 2)),
+                                              (unsigned)seed, (unsigned)(seed >> 32));
+            const unsigned q = w & 3;
+            m = q == 0 ? r.x : (q == 1 ? r.y : (q == 2 ? r.z : r.w));
+        } else {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+            for (int i = 0; i < 4; ++i) {                        // call i: features 32 w + 8 i .. + 7
+                const PhiloxOut r = philox4x32_10((unsigned)off, (unsigned)(off >> 32), row, (J.stream << 16) | (w * 4 + i),
+                                                  (unsigned)seed, (unsigned)(seed >> 32));
+                const unsigned v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    m |= ((v[u] & 0xFFFFu) >= A.thresh16 ? 1u : 0u) << (8 * i + 2 * u);
+                    m |= ((v[u] >> 16) >= A.thresh16 ? 1u : 0u) << (8 * i + 2 * u + 1);
+                }
+            }
+        }
+        const int left = A.cols - 32 * (int)w;                  // features past `cols` are never kept
+        if (left < 32) m &= (1u << left) - 1u;
+        J.bits[id] = m;
     }
-    return c;
+    __syncthreads();
+    if (threadIdx.x == 0) dropout_advance(A.state, off, gridDim.x);
 }
 
-// one thread per (row, word of 32 features): eight Philox calls
-__global__ __launch_bounds__(256) void dropout_keep_bits_kernel(u64* __restrict__ state, long long rows, int words, int cols,
-                                                                u64 thresh, unsigned* __restrict__ bits) {
-    const u64 seed = state[0], off = state[1];
-    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (id < rows * words) {
-        const unsigned row = (unsigned)(id / words), w = (unsigned)(id % words);
-        unsigned m = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const U4 r = philox4x32_10(U4{(unsigned)off, (unsigned)(off >> 32), row, w * 8 + i}, (unsigned)seed, (unsigned)(seed >> 32));
-            m |= ((u64)r.x >= thresh ? 1u : 0u) << (4 * i);
-            m |= ((u64)r.y >= thresh ? 2u : 0u) << (4 * i);
-            m |= ((u64)r.z >= thresh ? 4u : 0u) << (4 * i);
-            m |= ((u64)r.w >= thresh ? 8u : 0u) << (4 * i);
-        }
-        const int left = cols - 32 * (int)w;                    // features past `cols` are never kept
-        if (left < 32) m &= (1u << left) - 1u;
-        bits[id] = m;
+// keep-masks of up to two branches in ONE launch (streams 0 and 1 of the same draw)
+int dropout_stage(u64* state, const long long* rows, unsigned* const* bits, const unsigned* streams, int njobs, int cols, float p,
+                  hipStream_t s) {
+    if (!state || njobs < 1 || njobs > 2 || cols <= 0 || !(p >= 0.f && p <= 1.f)) return hipErrorInvalidValue;
+    DropArgs A = {};
+    A.njobs = njobs;
+    A.state = state;
+    A.cols = cols;
+    A.words = (cols + 31) / 32;
+    A.fair = p == kFairP;
+    const double t = (double)p * 65536.0;
+    A.thresh16 = (unsigned)(t + 0.5);
+    long long total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (rows[i] <= 0 || rows[i] >= (1ll << 32) || !bits[i]) return hipErrorInvalidValue;
+        A.job[i] = DropJob{bits[i], rows[i], streams[i]};
+        if (i == 0) A.n0 = rows[i] * A.words;
+        total += rows[i] * A.words;
     }
-    // the last block out advances the call counter (every block has read `off` before it takes its ticket)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned* ticket = reinterpret_cast<unsigned*>(state + 2);
-        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-            state[1] = off + 1;
-            *ticket = 0;
-            __threadfence();
-        }
-    }
+    if (njobs == 1) A.job[1] = A.job[0];
+    hipLaunchKernelGGL(dropout_keep_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A);
+    return hipGetLastError();
 }
 
 }  // namespace piml
 
 using namespace piml;
 
-PIML_API int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, float p, unsigned* keep_bits, void* stream) {
-    if (rows < 0 || cols <= 0 || !(p >= 0.f && p <= 1.f) || rows >= (1ll << 32)) return hipErrorInvalidValue;
+PIML_API int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, float p, int stream_id, unsigned* keep_bits,
+                                    void* stream) {
+    if (rows < 0 || cols <= 0 || !(p >= 0.f && p <= 1.f) || rows >= (1ll << 32) || stream_id < 0 || stream_id > 0xFFFF)
+        return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     if (!state || !keep_bits) return hipErrorInvalidValue;
-    const int words = (cols + 31) / 32;
-    double t = (double)p * 4294967296.0;
-    u64 thresh = (u64)(t + 0.5);
-    if (thresh > 4294967296ull) thresh = 4294967296ull;
-    const long long n = rows * words;
-    hipLaunchKernelGGL(dropout_keep_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<u64*>(state), rows, words, cols, thresh, keep_bits);
-    return hipGetLastError();
+    const unsigned sid = (unsigned)stream_id;
+    return dropout_stage(reinterpret_cast<u64*>(state), &rows, &keep_bits, &sid, 1, cols, p, as_stream(stream));
 }

@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "encoder.hpp"
 #include "pack.hpp"
+#include "philox.hpp"
 #include "stages.hpp"
 #include "../../include/piml_hip.h"
 
@@ -777,6 +778,7 @@ static int fill_args(EncArgs& A, const piml_encoder_branch* br, int nbr) {
     A.nbr = nbr;
     A.zero = nullptr;
     A.zero_n = 0;
+    A.gen_state = nullptr;
     for (int i = 0; i < nbr; ++i) A.br[i] = br[i];
     if (nbr == 1) A.br[1] = br[0];
     A.wg_split = split_workgroups(br, nbr, 256, 1);
@@ -838,6 +840,7 @@ int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) 
     A.wg_split = 0;
     A.zero = nullptr;
     A.zero_n = 0;
+    A.gen_state = nullptr;
     hipLaunchKernelGGL(enc_pack_kernel, dim3((PACK_FLOATS + 255) / 256, nbr), dim3(256), 0, s, A);
     return hipGetLastError();
 }
@@ -882,6 +885,23 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
         if (zero_n >= (1ll << 31)) return hipErrorInvalidValue;       // a clear that cannot be honoured is an error, not a skip
         A.zero = zero;
         A.zero_n = (int)zero_n;
+    }
+    // Train-mode dropout drawn by this call (piml_encoder_branch.drop_state): p = 0.5 on the split-product kernels inside the
+    // forward kernel, everything else by one generator launch for all branches in front of it
+    if (br[0].drop_state) {
+        for (int i = 0; i < nbr; ++i)
+            if (br[i].drop_state != br[0].drop_state || br[i].drop_p != br[0].drop_p || !br[i].keep_bits) return hipErrorInvalidValue;
+        if (g_x3 && br[0].drop_p == kFairP) {
+            A.gen_state = br[0].drop_state;
+        } else {
+            long long rows[2];
+            unsigned* bits[2];
+            unsigned streams[2] = {0u, 1u};
+            for (int i = 0; i < nbr; ++i) { rows[i] = br[i].rows; bits[i] = br[i].keep_bits; }
+            if (int e = dropout_stage(br[0].drop_state, rows, bits, streams, nbr, EH, br[0].drop_p, s)) return e;
+        }
+    } else if (nbr > 1 && br[1].drop_state) {
+        return hipErrorInvalidValue;
     }
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
     if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)

@@ -19,6 +19,7 @@ struct EncArgs {
     int wg_split;       // workgroups [0, wg_split) serve branch 0, the rest branch 1
     float* zero;        // forward only, optional: a buffer the launch clears on the way (the decoder tails' accumulator)
     int zero_n;
+    unsigned long long* gen_state;   // forward only: non-NULL = the kernel draws the p = 0.5 keep-masks itself (philox.hpp)
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -58,7 +59,7 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 // encoder_x3.hip: the same stages on split bf16 products (launch only; arguments checked by the callers in encoder.hip)
 int enc_x3_set_attributes();
 // drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
-void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);
+void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);   // A.gen_state: draw the masks in the kernel
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
 void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, bool drop, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers

@@ -15,6 +15,7 @@
 // Reference arithmetic: src/models/model.py:40-65, :1271-1283 (see encoder.hip).
 #include "common.hpp"
 #include "encoder.hpp"
+#include "philox.hpp"
 
 namespace piml {
 
@@ -121,7 +122,9 @@ __device__ __forceinline__ void land_w3(const u32x4 (&w3r)[W3_ROUNDS], float* ld
     __syncthreads();
 }
 
-template <bool DROP>
+// DROP: 0 = no dropout, 1 = keep_bits given, 2 = the kernel draws the p = 0.5 mask itself (one Philox call per row, philox.hpp)
+// and leaves it in keep_bits for the backward
+template <int DROP>
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,7 +139,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     const long long stride = (long long)nwg * ENC_WAVES;
     if (A.zero)
         for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
-    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+    unsigned long long gseed = 0, goff = 0;
+    if (DROP == 2) { gseed = A.gen_state[0]; goff = A.gen_state[1]; }
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) {               // whole workgroup idle
+        if (DROP == 2 && tid == 0) dropout_advance(A.gen_state, goff, gridDim.x);
+        return;
+    }
 
     const float* x3 = J.packed + PACK_F32;
     // the first tile's input row: requested before the staging loads (vmcnt retires in order)
@@ -241,8 +249,13 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
         for (int u = 0; u < 6; ++u) tail[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
         load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
         uint4 kw = make_uint4(0u, 0u, 0u, 0u);
-        if (DROP && valid) kw = reinterpret_cast<const uint4*>(J.keep_bits)[row];
+        if (DROP == 1 && valid) kw = reinterpret_cast<const uint4*>(J.keep_bits)[row];
         split_tile(a, P);
+        if (DROP == 2) {          // `a` is dead here (64 free registers).  Both lane halves of a row draw the same words; half 0 records them
+            const PhiloxOut r = keep_words_fair(gseed, goff, (unsigned)row, (unsigned)b);
+            kw = make_uint4(r.x, r.y, r.z, r.w);
+            if (valid && h == 0) reinterpret_cast<uint4*>(J.keep_bits)[row] = kw;
+        }
         const float scale = J.scale;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
@@ -277,6 +290,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
         }
     }
     if (w3_pending) land_w3(w3r, lds, tid);       // a wave without a tile: the barrier still counts it
+    if (DROP == 2 && tid == 0) dropout_advance(A.gen_state, goff, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int X3_SPLIT_LDS_BYTES = 2 * 2 * 4 * 3 * 2 * 64 * 16;       // [layer 2][tile 2][block 4][piece 3][s 2][lane 64] u32x4
 
-template <bool DROP>
+template <int DROP>        // as in enc_fwd_x3_kernel
 __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pairs0) {
     extern __shared__ __align__(16) float lds[];
     u32x4* exch = reinterpret_cast<u32x4*>(lds);
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
     const bool valid = row < R;
     if (A.zero)
         for (int e = blockIdx.x * 512 + tid; e < A.zero_n; e += gridDim.x * 512) A.zero[e] = 0.f;
+    const unsigned long long goff = DROP == 2 ? A.gen_state[1] : 0ull;
     const u32x4* W2hm = reinterpret_cast<const u32x4*>(J.packed + PACK_F32) + lane;
     const u32x4* W2lo = W2hm + X3_HM / 4;
     const u32x4* W3hm = reinterpret_cast<const u32x4*>(J.packed + PACK_F32 + X3_IMG) + lane;
@@ -396,10 +411,17 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
             for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; wf[kb][2] = wn[kb][2]; }
             __syncthreads();
         } else {
-            if (DROP) keep_block(acc, valid ? J.keep_bits[row * 4 + blk] : 0u, h);
+            if (DROP == 1) keep_block(acc, valid ? J.keep_bits[row * 4 + blk] : 0u, h);
+            if (DROP == 2) {                     // the four waves of a tile draw the same call; wave blk takes and records word blk
+                const PhiloxOut r = keep_words_fair(A.gen_state[0], goff, (unsigned)row, (unsigned)b);
+                const unsigned word = blk == 0 ? r.x : (blk == 1 ? r.y : (blk == 2 ? r.z : r.w));
+                if (valid && h == 0) J.keep_bits[row * 4 + blk] = word;
+                keep_block(acc, word, h);
+            }
             store(J.msgs, J.scale);
         }
     }
+    if (DROP == 2 && tid == 0) dropout_advance(A.gen_state, goff, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -898,8 +920,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 
 int enc_x3_set_attributes() {
     auto set = [](const void* f, int bytes) { return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
-    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<false>), X3_SPLIT_LDS_BYTES)) return e;
-    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<true>), X3_SPLIT_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<0>), X3_SPLIT_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<1>), X3_SPLIT_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<2>), X3_SPLIT_LDS_BYTES)) return e;
     const void* dw[6] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true, false>),
                          reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false, false>),
                          reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true, false>),
@@ -914,8 +937,9 @@ int enc_x3_set_attributes() {
                          reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true, true>)};
     for (const void* f : dx)
         if (int e = set(f, X3_DX_LDS_BYTES)) return e;
-    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<true>), X3_FWD_LDS_BYTES)) return e;
-    return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<false>), X3_FWD_LDS_BYTES);
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<2>), X3_FWD_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<1>), X3_FWD_LDS_BYTES)) return e;
+    return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<0>), X3_FWD_LDS_BYTES);
 }
 
 // `drop`: every branch of the launch carries keep_bits (checked by the callers: all or none)
@@ -943,13 +967,16 @@ void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, bool drop, hipStream_t s) 
 
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s) {
     const dim3 g((unsigned)(pairs0 + pairs1));
-    if (drop) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<true>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
-    else hipLaunchKernelGGL(enc_fwd_split_x3_kernel<false>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+    if (drop && A.gen_state) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<2>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+    else if (drop) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<1>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+    else hipLaunchKernelGGL(enc_fwd_split_x3_kernel<0>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
 }
 
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {
-    if (drop) hipLaunchKernelGGL(enc_fwd_x3_kernel<true>, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
-    else hipLaunchKernelGGL(enc_fwd_x3_kernel<false>, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
+    const dim3 g(total), b(ENC_THREADS);
+    if (drop && A.gen_state) hipLaunchKernelGGL(enc_fwd_x3_kernel<2>, g, b, X3_FWD_LDS_BYTES, s, A);
+    else if (drop) hipLaunchKernelGGL(enc_fwd_x3_kernel<1>, g, b, X3_FWD_LDS_BYTES, s, A);
+    else hipLaunchKernelGGL(enc_fwd_x3_kernel<0>, g, b, X3_FWD_LDS_BYTES, s, A);
 }
 
 }  // namespace piml

@@ -29,6 +29,10 @@ int dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_p
                         float* g_self, hipStream_t s);
 int dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s);   // partials (+ slot sum)
 
+// keep-masks of up to two row sets in ONE launch (one draw, streams[i] tells them apart); advances the draw counter
+int dropout_stage(unsigned long long* state, const long long* rows, unsigned* const* bits, const unsigned* streams, int njobs,
+                  int cols, float p, hipStream_t s);
+
 int head_stage_pack(const piml_collision_head* h, hipStream_t s);
 int head_stage_fwd(const piml_collision_head* h, hipStream_t s);                      // packed image must be current
 

@@ -152,19 +152,24 @@ class ResDNN(nn.Module):
     def dropout_active(self):
         return self.training and self.dropout.p > 0
 
-    def fused_spec(self, rows, device):
-        """(scale, keep_bits) of `keep * scale * x` for a (rows, width) input on `device`, or None when this module is
-        not of that form.  keep_bits is None without active dropout (eval mode or p = 0: scale = 2); in train mode it is
-        the injected `self.keep_bits` or a fresh draw (ops.dropout_keep_bits, one small launch) and scale = 2 / (1 - p)."""
+    def fused_spec(self, rows, device, in_launch=False, stream_id=0):
+        """(scale, keep) of `keep * scale * x` for a (rows, width) input on `device`, or None when this module is not of
+        that form.  keep is None without active dropout (eval mode or p = 0: scale = 2).  In train mode scale = 2 / (1 - p)
+        and keep is the injected `self.keep_bits`, or a fresh draw: bits from ops.dropout_keep_bits (one small launch), or
+        -- in_launch=True, for ops.fused_encoders / fused_pinnsf -- the request ('draw', p) that makes the encoder launch
+        draw the mask itself."""
         if not self.scales_input():
             return None
         if not self.dropout_active():
             return 2.0, None
         p = float(self.dropout.p)
-        width = self.hidden_units[-1][-1]
+        scale = 2.0 / (1.0 - p) if p < 1 else 0.0
+        if self.keep_bits is not None:
+            return scale, self.keep_bits
+        if in_launch:
+            return scale, ('draw', p)
         from .. import ops
-        bits = self.keep_bits if self.keep_bits is not None else ops.dropout_keep_bits(rows, width, p, device)
-        return (2.0 / (1.0 - p) if p < 1 else 0.0), bits
+        return scale, ops.dropout_keep_bits(rows, self.hidden_units[-1][-1], p, device, stream_id)
 
 
 class attn_pooling(nn.Module):
@@ -285,11 +290,19 @@ class _PINNSFBase(nn.Module):
         if not use:
             return {}
         from .. import ops
-        specs = [p.fused_spec(f.numel() // f.shape[-1], f.device) for _, f, _, p in use]
+        specs = self._launch_specs([(p, f) for _, f, _, p in use])
         res = ops.fused_encoders([dict(x=f, scale=sp[0], keep_bits=sp[1], pooled=not self.bottleneck,
                                        weights=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)])
                                   for (_, f, e, p), sp in zip(use, specs)])
         return {c[0]: r for c, r in zip(use, res)}
+
+    @staticmethod
+    def _launch_specs(pairs):
+        """fused_spec of every (processor, features) branch of ONE encoder launch: the launch draws the masks itself unless
+        any branch carries injected bits (then the others get theirs from the stand-alone generator: one kind per launch)."""
+        injected = any(p.keep_bits is not None for p, _ in pairs)
+        return [p.fused_spec(f.numel() // f.shape[-1], f.device, in_launch=not injected, stream_id=i)
+                for i, (p, f) in enumerate(pairs)]
 
     def _fused_row_decoders(self, pre):
         """Bottleneck variants: decoder + predictor per neighbour row on the fused kernels (ops.fused_row_decoder), for the
@@ -357,7 +370,7 @@ class _PINNSFBase(nn.Module):
         fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
         head = self._fusable_head()
         packs = self._packs if (self._packs is not None and self._packs.active) else None
-        specs = [p.fused_spec(f.numel() // f.shape[-1], f.device) for f, _, p, _, _ in cand]
+        specs = self._launch_specs([(p, f) for f, _, p, _, _ in cand])
         res = ops.fused_pinnsf(
             [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],

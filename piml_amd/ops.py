@@ -1139,8 +1139,9 @@ def dropout_state(device, seed=None):
     return _DROPOUT_STATE[idx][0]
 
 
-def dropout_keep_bits(rows, cols, p, device):
-    """Fresh keep-mask bits (rows, ceil(cols / 32)) int32 for dropout probability p (one launch on the current stream)."""
+def dropout_keep_bits(rows, cols, p, device, stream_id=0):
+    """Fresh keep-mask bits (rows, ceil(cols / 32)) int32 for dropout probability p (one launch on the current stream;
+    advances the device's draw counter).  stream_id tells masks of the same draw apart (include/piml_hip.h)."""
     if not 0.0 <= p <= 1.0:
         raise ValueError('dropout probability has to be between 0 and 1')
     device = torch.device(device)
@@ -1149,8 +1150,8 @@ def dropout_keep_bits(rows, cols, p, device):
     st = dropout_state(device)
     bits = torch.empty(rows, (cols + 31) // 32, dtype=torch.int32, device=device)
     with torch.cuda.device(device):
-        _lib.check(_lib.lib().piml_dropout_keep_bits(st.data_ptr(), rows, cols, float(p), _ptr(bits), _stream()),
-                   'piml_dropout_keep_bits')
+        _lib.check(_lib.lib().piml_dropout_keep_bits(st.data_ptr(), rows, cols, float(p), int(stream_id), _ptr(bits),
+                                                     _stream()), 'piml_dropout_keep_bits')
     return bits
 
 
@@ -1173,6 +1174,17 @@ def unpack_keep_bits(bits, cols):
     b = bits.to(torch.int64) & 0xffffffff
     out = (b.unsqueeze(-1) >> torch.arange(32, device=bits.device, dtype=torch.int64)) & 1
     return out.reshape(bits.shape[0], -1)[:, :cols].bool()
+
+
+def _resolve_keep(keep, rows, cols, device):
+    """A branch's `keep_bits` entry -> (bits tensor | None, draw_p | None): None = no dropout; a tensor = given bits;
+    ('draw', p) = the forward launch draws the mask with probability p into a fresh buffer."""
+    if isinstance(keep, tuple) and len(keep) == 2 and keep[0] == 'draw':
+        p = float(keep[1])
+        if not 0.0 <= p <= 1.0:
+            raise ValueError('dropout probability has to be between 0 and 1')
+        return torch.empty(rows, (cols + 31) // 32, dtype=torch.int32, device=device), p
+    return _check_keep_bits(keep, rows, cols, device), None
 
 
 def _check_keep_bits(keep_bits, rows, cols, device):
@@ -1335,9 +1347,11 @@ ENCODER_MAX_IN = 8
 
 
 def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
-                       g_x=None, partials=None, packed=None, grads=None, keep_bits=None):
+                       g_x=None, partials=None, packed=None, grads=None, keep_bits=None, draw_p=None):
     B = _lib.EncoderBranch()
     B.keep_bits = _ptr(keep_bits)
+    if draw_p is not None:            # the forward draws the mask itself (into keep_bits) from the device's dropout state
+        B.drop_state, B.drop_p = dropout_state(x2.device).data_ptr(), float(draw_p)
     B.x, B.rows, B.in_dim, B.k = x2.data_ptr(), x2.shape[0], x2.shape[1], int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.scale = float(scale)
@@ -1376,10 +1390,11 @@ class _FusedEncoders(torch.autograd.Function):
             msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
             h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
-        keeps = [_check_keep_bits(keeps[b], x2s[b].shape[0], ENCODER_HIDDEN, dev) for b in range(nbr)]
+        keeps, draws = zip(*[_resolve_keep(keeps[b], x2s[b].shape[0], ENCODER_HIDDEN, dev) for b in range(nbr)])
         packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
         arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b],
-                                                              packed=packed[b], keep_bits=keeps[b]) for b in range(nbr)])
+                                                              packed=packed[b], keep_bits=keeps[b], draw_p=draws[b])
+                                           for b in range(nbr)])
         outs = []
         with torch.cuda.device(dev):
             _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
@@ -1463,8 +1478,9 @@ class _FusedEncoders(torch.autograd.Function):
 
 def fused_encoders(branches):
     """branches: list (1 or 2 entries) of dicts {x (..., k, in<=8), scale, weights: (w1, b1, w2, b2, w3, b3) with the
-    nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool, keep_bits: optional int32 (rows, 4), the
-    processor's train-mode dropout mask (dropout_keep_bits; fold 1 / (1 - p) into `scale`; all branches or none)}.
+    nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool, keep_bits: optional, the processor's
+    train-mode dropout: int32 bits (rows, 4) (dropout_keep_bits layout) or ('draw', p) = the forward launch draws the mask
+    itself from the device's dropout state (fold 1 / (1 - p) into `scale`; the same kind for every branch)}.
     Returns [(msgs (..., k, 128), pooled (..., 128) | None), ...]: msgs = keep * scale * encoder(x),
     pooled = msgs.sum(-2)  (src/models/model.py:1271-1283)."""
     if not 1 <= len(branches) <= 2:
@@ -1483,8 +1499,8 @@ def fused_encoders(branches):
         flat += [x, *w]
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in flat)
     keeps = tuple(b.get('keep_bits') for b in branches)
-    if any(k is None for k in keeps) and not all(k is None for k in keeps):
-        raise ValueError('fused_encoders: keep_bits for every branch or for none')
+    if len({(k is None, isinstance(k, tuple)) for k in keeps}) > 1:
+        raise ValueError('fused_encoders: the same kind of keep_bits (none / given bits / drawn) for every branch')
     out = _FusedEncoders.apply(len(branches), tuple(float(b['scale']) for b in branches),
                                tuple(bool(b.get('pooled', True)) for b in branches), need_grad, keeps, *flat)
     return [(out[2 * i], out[2 * i + 1] if branches[i].get('pooled', True) else None) for i in range(len(branches))]
@@ -1623,9 +1639,10 @@ class _FusedPinnsf(torch.autograd.Function):
             epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
             dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
             hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt) if nhead else None
-        keeps = [_check_keep_bits(keeps[b], x2s[b].shape[0], H, dev) for b in range(nbr)]
+        keeps, draws = zip(*[_resolve_keep(keeps[b], x2s[b].shape[0], H, dev) for b in range(nbr)])
         earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
-                                                               packed=epack[b], keep_bits=keeps[b]) for b in range(nbr)])
+                                                               packed=epack[b], keep_bits=keeps[b], draw_p=draws[b])
+                                            for b in range(nbr)])
         pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
         dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
@@ -1792,8 +1809,8 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
         raise ValueError('fused_pinnsf: self_features (..., N, 7) must match the features\' leading shape')
     need_grad = torch.is_grad_enabled() and (any(t.requires_grad for t in flat) or self_features.requires_grad)
     keeps = tuple(b.get('keep_bits') for b in branches)
-    if any(k is None for k in keeps) and not all(k is None for k in keeps):
-        raise ValueError('fused_pinnsf: keep_bits for every branch or for none')
+    if len({(k is None, isinstance(k, tuple)) for k in keeps}) > 1:
+        raise ValueError('fused_pinnsf: the same kind of keep_bits (none / given bits / drawn) for every branch')
     out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
                              bool(fold_epilogue), packs, int(head is not None), keeps, self_features, *flat)
     nbr = len(branches)

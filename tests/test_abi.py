@@ -93,8 +93,8 @@ def test_library_argument_checks_of_glue_entries():
     assert L.piml_act_bwd_colsum(None, None, 10, 2048, None, None, None, None) == 1    # cols too wide
     assert L.piml_sum_leading(None, 0, 16, None, None) == 1
     assert L.piml_scale_ksum_fwd(None, None, 4, 6, 6, 2.0, None, None, None, None) == 1      # cols % 4
-    assert L.piml_dropout_keep_bits(None, 8, 128, 1.5, None, None) == 1                  # p outside [0, 1]
-    assert L.piml_dropout_keep_bits(None, 0, 128, 0.5, None, None) == 0                  # empty: no-op
+    assert L.piml_dropout_keep_bits(None, 8, 128, 1.5, 0, None, None) == 1                  # p outside [0, 1]
+    assert L.piml_dropout_keep_bits(None, 0, 128, 0.5, 0, None, None) == 0                  # empty: no-op
     assert L.piml_pinnsf_epilogue_fwd(None, None, None, 0, 0.5, None, None) == 0        # empty: no-op
     assert L.piml_pinnsf_epilogue_fwd(None, None, None, 5, 0.5, None, None) == 1
     assert L.piml_train_step_bwd(None, None, None, None, None, 0, 1, 5, 0, 0.08, None, None, None, None, None) == 0

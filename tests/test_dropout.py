@@ -21,13 +21,17 @@ def test_philox_known_answers():
 
 
 def test_keep_mask_statistics_and_offsets():
-    for p in (0.5, 0.1, 0.9):
+    for p in (0.5, 0.1, 0.9, 0.3):
         m = philox_ref.keep_mask(666, 0, 4096, 128, p)
-        assert abs(m.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / m.size)
+        assert abs(m.mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / m.size) + 1e-5
     a, b = philox_ref.keep_mask(666, 0, 64, 128, 0.5), philox_ref.keep_mask(666, 1, 64, 128, 0.5)
-    assert (a != b).mean() > 0.4                          # another call, another mask
+    assert (a != b).mean() > 0.4                          # another draw, another mask
+    c = philox_ref.keep_mask(666, 0, 64, 128, 0.5, stream=1)
+    assert (a != c).mean() > 0.4                          # another stream of the same draw, another mask
     assert philox_ref.keep_mask(1, 0, 8, 128, 1.0).sum() == 0 and philox_ref.keep_mask(1, 0, 8, 128, 0.0).all()
-    assert np.array_equal(philox_ref.keep_mask(5, 3, 16, 100, 0.5), philox_ref.keep_mask(5, 3, 16, 128, 0.5)[:, :100])
+    for p in (0.5, 0.3):                                  # narrower layers take the leading features of the same stream
+        assert np.array_equal(philox_ref.keep_mask(5, 3, 16, 100, p), philox_ref.keep_mask(5, 3, 16, 128, p)[:, :100])
+    assert philox_ref.keep_bits(5, 3, 16, 200, 0.5).shape == (16, 7)
 
 
 def test_bit_layout_round_trip():

@@ -24,18 +24,55 @@ def model_args(**kw):
     return types.SimpleNamespace(**a)
 
 
-@pytest.mark.parametrize('rows,cols,p', [(100, 128, 0.5), (4097, 128, 0.3), (33, 100, 0.5), (7, 128, 1.0), (7, 128, 0.0)])
+@pytest.mark.parametrize('rows,cols,p', [(100, 128, 0.5), (4097, 128, 0.3), (33, 100, 0.5), (33, 200, 0.25), (7, 128, 1.0),
+                                         (7, 128, 0.0)])
 def test_keep_bits_equal_the_philox_restatement(rows, cols, p):
     from piml_amd import ops
     st = ops.dropout_state(DEV, seed=1234)
-    st[1] = 5                                               # call counter
+    st[1] = 5                                               # draw counter
     torch.cuda.synchronize()
     for call in range(3):                                    # the launch advances the counter itself
-        bits = ops.dropout_keep_bits(rows, cols, p, DEV)
-        want = philox_ref.keep_bits(1234, 5 + call, rows, cols, p)
+        bits = ops.dropout_keep_bits(rows, cols, p, DEV, stream_id=call)
+        want = philox_ref.keep_bits(1234, 5 + call, rows, cols, p, stream=call)
         assert np.array_equal(bits.cpu().numpy(), want), f'call {call}'
     assert int(st[1]) == 8 and int(st[2]) == 0
     ops.dropout_state(DEV, seed=int(torch.cuda.initial_seed()))
+
+
+@pytest.mark.parametrize('n,p,products', [(4096, 0.5, 'x3'), (150, 0.5, 'x3'), (4096, 0.25, 'x3'), (150, 0.25, 'x3'),
+                                          (4096, 0.5, 'f32'), (150, 0.5, 'f32')])
+def test_masks_drawn_by_the_encoder_launch_equal_the_restatement(n, p, products):
+    """('draw', p): the forward launch draws the masks itself -- for p = 0.5 on the split-product kernels INSIDE the forward
+    kernel (one-wave and four-waves-per-tile forms), otherwise by one generator launch in front of it.  Either way the
+    dropped features of the messages are exactly those of the numpy restatement (branch b = stream b of draw `offset`),
+    the kept ones equal the eval-mode messages / (1 - p), and the draw counter advances by one per launch."""
+    from piml_amd import _lib, ops
+    old = _lib.lib().piml_encoder_products(1 if products == 'x3' else 0)
+    try:
+        g = torch.Generator().manual_seed(7)
+        H = 128
+
+        def branch(k, keep):
+            x = torch.randn(n, k, 6, generator=torch.Generator().manual_seed(k)).to(DEV)
+            w = [(torch.randn(*d, generator=torch.Generator().manual_seed(3 + i)) * (0.3 if len(d) == 2 else 0.1)).to(DEV)
+                 for i, d in enumerate([(H, 6), (H,), (H, H), (H,), (H, H), (H,)])]
+            return dict(x=x, scale=2.0 / (1 - p), weights=w, pooled=True, keep_bits=keep)
+        st = ops.dropout_state(DEV, seed=4321)
+        st[1] = 11
+        with torch.no_grad():
+            drawn = ops.fused_encoders([branch(6, ('draw', p)), branch(10, ('draw', p))])
+            plain = ops.fused_encoders([branch(6, None), branch(10, None)])
+        torch.cuda.synchronize()
+        assert int(st[1]) == 12
+        for b, k in enumerate((6, 10)):
+            keep = torch.from_numpy(philox_ref.keep_mask(4321, 11, n * k, H, p, stream=b)).to(DEV).view(n, k, H)
+            m, ref = drawn[b][0], plain[b][0]                   # plain carries scale 2 / (1 - p) too
+            assert bool((m[~keep] == 0).all())
+            assert torch.equal(m[keep], ref[keep])
+            assert torch.allclose(drawn[b][1], (ref * keep).sum(-2), rtol=1e-5, atol=1e-5)
+    finally:
+        _lib.lib().piml_encoder_products(old)
+        ops.dropout_state(DEV, seed=int(torch.cuda.initial_seed()))
 
 
 def test_keep_fraction_and_graph_replays_draw_fresh_masks():
