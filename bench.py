@@ -374,7 +374,11 @@ class Step:
 
     # ---- whole-step HIP graph (removes ~60 per-kernel launch gaps); eager fallback ----
     def capture(self):
+        import piml_amd
         if not self.want_graph:
+            return
+        if not piml_amd.hip_graphs_safe():      # DEBUG_CLR_GRAPH_PACKET_CAPTURE could not be set in time: replays are not trusted
+            print('[bench] HIP-graph capture disabled (piml_amd.hip_graphs_safe() is False); running eagerly', file=sys.stderr)
             return
         ok = 1
         try:

@@ -58,7 +58,8 @@ class MLAPM:
             t.add_(1)
         done = 0
         with torch.no_grad():
-            if use_graph and p.is_cuda and steps > 4:
+            from .. import hip_graphs_safe
+            if use_graph and p.is_cuda and steps > 4 and hip_graphs_safe():
                 for _ in range(2):
                     one()
                 done = 2

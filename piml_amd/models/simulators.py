@@ -351,6 +351,8 @@ class BaseSimulator(Pedestrians):
         step_fn = self._rollout_step_fused if fused else self._rollout_step
         if use_graph is None:
             use_graph = data.position.is_cuda and not torch.is_grad_enabled() and steps > 8
+        from .. import hip_graphs_safe
+        use_graph = bool(use_graph) and hip_graphs_safe()       # a process that cannot trust replays runs eagerly
         done = 0
         quirk = bool(getattr(args, 'inplace_quirk', False)) and steps > 0
         hist_first = None
@@ -642,7 +644,8 @@ class BaseSimulator(Pedestrians):
         args = self.args
         log = {}
         channelled = hasattr(batch_data, 'mask_p_pred') and hasattr(batch_data, 'waypoints')
-        if channelled and getattr(args, 'hip_graph', True) and batch_data.position.is_cuda:
+        from .. import hip_graphs_safe
+        if channelled and getattr(args, 'hip_graph', True) and batch_data.position.is_cuda and hip_graphs_safe():
             out, aux = self._graphed_rollout_step(batch_data)
             assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'
             self._carry_dest_idx(batch_data, aux)

@@ -1530,7 +1530,7 @@ class PinnsfPacks:
 
     def __init__(self):
         self.epack = self.dpack = self.hpack = None
-        self.sig = None          # data pointers of the packed weights
+        self.sig = None          # (data pointer, version) of the packed weights
         self.active = False
 
     def __deepcopy__(self, memo):          # images are derived data: a copied model packs for itself
@@ -1567,7 +1567,9 @@ def _pack_structs(enc_w, dec_w, head_w, packs):
 
 
 def _weights_sig(enc_w, dec_w, head_w):
-    return tuple(t.data_ptr() for wb in (*enc_w, *dec_w, *([head_w] if head_w is not None else [])) for t in wb)
+    """(storage address, in-place modification count) of every packed weight: an optimizer step or load_state_dict between the
+    prepack and a forward pass that uses the images changes the count and is refused (stale operand images)."""
+    return tuple((t.data_ptr(), t._version) for wb in (*enc_w, *dec_w, *([head_w] if head_w is not None else [])) for t in wb)
 
 
 def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
@@ -1632,7 +1634,8 @@ class _FusedPinnsf(torch.autograd.Function):
         flags = _lib.FORK if FORK_NETWORK else 0
         if packs is not None:
             if packs.sig != _weights_sig(ewb, dwb, hwb):
-                raise ValueError('fused_pinnsf: `packs` were filled from other weight tensors (pinnsf_prepack first)')
+                raise ValueError('fused_pinnsf: `packs` were filled from other weight tensors, or the weights were modified in '
+                                 'place since (optimizer step / load_state_dict inside a packed_weights() block): pinnsf_prepack first')
             epack, dpack, hpack = packs.epack, packs.dpack, packs.hpack
             flags |= _lib.PACKED_VALID
         else:

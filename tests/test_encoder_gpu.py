@@ -235,6 +235,12 @@ def test_network_streams_and_prepack_are_bitwise_neutral():
     assert not torch.equal(ref2[0], ref[0])
     for a, b in zip(ref2, packed3):
         assert torch.equal(a, b)
+    # an in-place weight change INSIDE a block (optimizer step, load_state_dict) leaves stale operand images: refused
+    with net.packed_weights():
+        with torch.no_grad():
+            net.ped_encoder.mlp[2].weight.mul_(1.5)
+        with pytest.raises(ValueError, match='modified in place'):
+            net(*base)
     torch.cuda.synchronize()
 
 
