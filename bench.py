@@ -246,11 +246,13 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False, model_name='PINNSF_multitask', train_mode=False):
+                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None):
         from piml_amd import ops, _lib
         import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
-        self.ops, self._lib = ops, _lib
+        # ops_module: a stand-in with the feature operators' contracts (tests/test_bench_step_dist.py drives the exchange
+        # bookkeeping of this class on CPU ranks over gloo with the oracle behind it); the product uses piml_amd.ops
+        self.ops, self._lib = (ops_module if ops_module is not None else ops), _lib
         self.N, self.n_own, self.b0, self.dev, self.group, self.use_dist = N, n_own, b0, dev, group, use_dist
         self.obstacles = torch.tensor(scene['obstacles'], device=dev)
         self.M_eff = self.obstacles.shape[0]
@@ -266,7 +268,7 @@ class Step:
         # keep-masks on the device (ops.dropout_keep_bits inside the captured graph) and the fused kernels apply them
         self.model = getattr(MODEL, model_name)(model_args()).to(dev).train(bool(train_mode))
         if train_mode:
-            ops.dropout_state(dev)          # the device-side (seed, call counter) must exist before a capture
+            self.ops.dropout_state(dev)     # the device-side (seed, call counter) must exist before a capture
         if two_streams:
             self.model.obs_stream = torch.cuda.Stream()
         self.params = [p for p in self.model.parameters()]
@@ -339,14 +341,14 @@ class Step:
             gather_records_into(self.state_all, self.state_own, self.group)
 
     def exchange_backward(self):
-        from piml_amd.sharded import unflatten_gradients
+        from piml_amd.sharded import reduce_scatter_grad, unflatten_gradients
         N, b0, n_own = self.N, self.b0, self.n_own
         if self.exchange == 'bucket':
             dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
             unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
         else:
-            dist.reduce_scatter_tensor(self.grad_own, self.state_all.grad, op=dist.ReduceOp.SUM, group=self.group)
+            reduce_scatter_grad(self.state_all.grad, self.group, out=self.grad_own)      # (all-reduce + slice on gloo: CPU tests)
             dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             unflatten_gradients(self.bucket[0], self.bucket[1])
 
@@ -488,6 +490,46 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+# Latency + bytes model of the two backward exchanges over xGMI (one hop, fully connected): a collective costs ALPHA_US
+# of launch + link latency, an all-reduce moves 2 (w - 1) / w of its bytes per rank, a reduce-scatter (w - 1) / w, each over
+# the w - 1 links of ~50 GB/s effective at these message sizes.  `bucket` is ONE all-reduce of (6 N + P) floats, `rs` a
+# reduce-scatter of 6 N floats + an all-reduce of P floats: fewer bytes, one more latency.  (Constants are estimates: no
+# multi-GPU node is available to the builder; every sharded run times both forms and reports them under "exchange".)
+ALPHA_US, LINK_GBS = 12.0, 50.0
+
+
+def exchange_cost_us(kind, n_agents, n_params, world):
+    if world < 2:
+        return 0.0
+    f = (world - 1) / world
+    per_us = LINK_GBS * 1e3 * (world - 1)                    # bytes per microsecond over all links of a rank
+    sb, pb = 6 * n_agents * 4, n_params * 4
+    if kind == 'bucket':
+        return ALPHA_US + 2 * f * (sb + pb) / per_us
+    return 2 * ALPHA_US + (f * sb + 2 * f * pb) / per_us
+
+
+def choose_exchange(n_agents, n_params, world):
+    return min(('bucket', 'rs'), key=lambda k: exchange_cost_us(k, n_agents, n_params, world))
+
+
+def pad_scene_np(scene, world):
+    """The scene padded to a multiple of `world` agents with ABSENT agents (NaN position / destination: the reference's own
+    encoding, src/data/data.py:141-143; piml_amd.sharded.pad_scene): they select nobody, nobody selects them, their
+    gradient is zero -- the padded scene computes exactly the unpadded one.  Returns (scene, padded agent count)."""
+    n = scene['position'].shape[0]
+    pad = (-n) % world
+    if pad == 0:
+        return scene, n
+    out = dict(scene)
+    for k in ('position', 'destination'):
+        out[k] = np.concatenate([scene[k], np.full((pad, 2), np.nan, np.float32)])
+    for k in ('velocity', 'acceleration'):
+        out[k] = np.concatenate([scene[k], np.zeros((pad, 2), np.float32)])
+    out['desired_speed'] = np.concatenate([scene['desired_speed'], np.zeros((pad, scene['desired_speed'].shape[1]), np.float32)])
+    return out, n + pad
+
+
 def median(xs):
     xs = sorted(xs)
     return 0.0 if not xs else (xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]))
@@ -515,9 +557,10 @@ def main():
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
-    ap.add_argument('--exchange', choices=('bucket', 'rs'), default='bucket',
+    ap.add_argument('--exchange', choices=('auto', 'bucket', 'rs'), default='auto',
                     help='backward exchange of the sharded step: one all-reduce of [state gradient | weight gradients] '
-                         '(bucket) or reduce-scatter(state gradient) + all-reduce(weight gradients) (rs)')
+                         '(bucket) or reduce-scatter(state gradient) + all-reduce(weight gradients) (rs); auto = the cheaper '
+                         'one under choose_exchange()\'s latency + bytes model (the other one is timed after the timed region)')
     ap.add_argument('--overlap', type=int, default=0,
                     help='sharded + graph: start the all-gather, run the part of the step that needs only the own block '
                          '(weight pack, local half of the neighbour search, obstacle branch) under it, then the rest.  Off '
@@ -567,12 +610,13 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     scaling = args.scaling if args.scaling != 'auto' else ('strong' if world > 1 else 'weak')
-    if scaling == 'strong':
-        if args.scene_agents % world:
-            raise SystemExit(f'--scene-agents {args.scene_agents} must be divisible by the number of GPUs {world}')
-        N, n_own = args.scene_agents, args.scene_agents // world
+    if scaling == 'strong':      # any agent count: the scene is padded with absent agents up to a multiple of the world size
+        N_real = args.scene_agents
+        N = N_real + (-N_real) % world
+        n_own = N // world
     else:
-        N, n_own = args.agents * world, args.agents
+        N_real = N = args.agents * world
+        n_own = args.agents
     M = args.obstacles
     cfg3_shapes = n_own == 4096        # the row counts the committed GEMM selections were tuned (and validated) for
 
@@ -606,7 +650,15 @@ def main():
     from piml_amd import _lib
     from piml_amd.scenes import synthetic_gc_scene
 
-    scene = synthetic_gc_scene(N, M, seed=args.seed)
+    scene, N_padded = pad_scene_np(synthetic_gc_scene(N_real, M, seed=args.seed), world if scaling == 'strong' else 1)
+    assert N_padded == N
+    if args.exchange == 'auto':
+        torch.manual_seed(666)
+        n_params = sum(p.numel() for p in getattr(MODEL, 'PINNSF_multitask')(model_args()).parameters())
+        args.exchange = choose_exchange(N, n_params, world) if use_dist else 'bucket'
+        exchange_why = {k: round(exchange_cost_us(k, N, n_params, world), 2) for k in ('bucket', 'rs')}
+    else:
+        exchange_why = None
     # The obstacle branch of the MLP on a side stream makes two GEMM chains run concurrently inside the
     # captured graph.  Concurrent library GEMMs are only safe with kernels that never wait for
     # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some shapes
@@ -748,11 +800,11 @@ def main():
     raw_ms = median(kernel_ms_samples)                 # interval around `launches_per_sample` launches
     overhead_ms = median(overhead_ms_samples)
     kernel_ms = max(raw_ms - overhead_ms, 1e-6) / launches_per_sample
-    pairs_step = N * (N + M_eff)                       # all ranks together
+    pairs_step = N_real * (N_real + M_eff)             # all ranks together (absent padding agents are not counted)
     ms_per_step = elapsed / args.steps * 1e3
     # SURVEY.md 8d, the contract figure: operand-stream bytes of ONE step over all ranks (24 B per ped-ped
     # pair, 8 B per ped-obstacle pair, 488 B per focal agent) / step time / (HBM peak x GPUs)
-    bytes_step = N * (24 * N + 8 * M_eff) + 488 * N
+    bytes_step = N_real * (24 * N_real + 8 * M_eff) + 488 * N_real
     achieved = bytes_step / (ms_per_step * 1e-3) / 1e9 / world        # GB/s per GPU
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
@@ -780,7 +832,7 @@ def main():
             'value': pairs_step * args.steps / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'spinup_steps': spin_steps,
             'ms_per_step': ms_per_step, 'steps_per_s': args.steps / elapsed,
-            'agent_steps_per_s': N * args.steps / elapsed,
+            'agent_steps_per_s': N_real * args.steps / elapsed,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'launch_mode': mode, 'verified_max_rel_err': verify_err,
             'model_mode': 'train() dropout 0.5' if args.train_mode else 'eval()',
@@ -793,7 +845,7 @@ def main():
                                     f'cfg4: synthetic {N}-agent GC scene sharded over {world} GPUs' if scaling == 'strong' else
                                     f'synthetic {N}-agent GC scene ({n_own} focal agents per GPU)') +
                                    ', forward+backward PINSF step (HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd)',
-                       'agents_per_gpu': n_own, 'agents_total': N, 'obstacle_points': M_eff,
+                       'agents_per_gpu': n_own, 'agents_total': N_real, 'obstacle_points': M_eff,
                        'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
                        'sharding': 'single GPU' if not use_dist else
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
@@ -935,6 +987,7 @@ def main():
         leg_timer.cancel()
     if use_dist:
         out['exchange'] = {'backward': args.exchange, 'overlap': bool(st.pre is not None),
+                           'model_cost_us': exchange_why, 'padded_agents': N - N_real,
                            'other_variants': exchange_other,
                            'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '
                                    'reduce-scatter(d/d(state)) + all-reduce(weight gradients); forward = one '
