@@ -188,10 +188,12 @@ def encoder_products_check(dev, _lib):
     return out
 
 
-def secondary_measurements(scene, n, dev, _lib):
+def secondary_measurements(scene, n, dev, _lib, prof=None):
     """Back-to-back launches of the other HIP kernels of the path on the first `n` agents of the scene,
-    timed with HIP events (informational; not part of `value`).  MLAPM byte model: 16 B per pair + 36 B
-    per agent."""
+    timed with HIP events (informational; not part of `value`).  MLAPM operand-stream model: 16 B per pair + 36 B
+    per agent -- a rate of LDS-resident operands, not HBM traffic and not a fraction of anything; the
+    unit that bounds the kernel is the vector pipe (rsq / rcp / exp2 + ~60 VALU instructions per pair), reported as the
+    VALU-issue share of the SIMD cycles from the committed PMC pass."""
     from piml_amd import ops
     ok = ~np.isnan(scene['position'][:n, 0])
     p, v, v0, d = [torch.tensor(scene[k][:n][ok], device=dev) for k in ('position', 'velocity', 'desired_speed', 'destination')]
@@ -232,7 +234,12 @@ def secondary_measurements(scene, n, dev, _lib):
     bytes_fwd = 16 * m * m + 36 * m
     return {'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
                               'pairs_per_s_fwd': m * m / fwd_us * 1e6,
-                              'roofline_frac_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              'operand_stream_gbs_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9,
+                              'bound': 'valu',
+                              'valu_busy_frac_fwd': ((prof or {}).get('mlapm') or {}).get('fwd_valu_busy_frac'),
+                              'valu_busy_frac_bwd': ((prof or {}).get('mlapm') or {}).get('bwd_valu_busy_frac'),
+                              'valu_busy_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r03_step_counters.json '
+                                                  '(rocprofv3 --pmc, committed: static)' if (prof or {}).get('mlapm') else None,
                               'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
                                       'present agents of the same scene; forward: back-to-back eager launches; backward: (forward + backward '
                                       'replayed from one captured HIP graph) - forward, HIP events'}}
@@ -445,6 +452,31 @@ class Step:
             if int(t.item()) == 0:
                 self.graph = None
         self.mode = 'hipgraph' if self.graph is not None else 'eager'
+
+    def trace_stages(self, samples=5, queue=24):
+        """Live time of every launch stage of the step: `queue` replays of the captured step keep the GPU busy, then the same
+        step runs EAGERLY with the library's stage trace open (piml_trace_*: a HIP event behind every stage launch).  The
+        interval between two marks is the GPU time of the later stage.  Median over `samples`.  Single-GPU steps only."""
+        import ctypes
+        per = {}
+        cal = ctypes.c_char_p(b'event_pair_overhead')
+        for _ in range(samples):
+            for _ in range(queue):
+                self.run()
+            self.reset_grads()
+            tr = self._lib.StageTrace()
+            tr.start()
+            self.step_body()
+            # two marks with nothing in between: what an interval costs by itself (subtracted below, like the relfeat sample's)
+            self._lib.lib().piml_trace_mark(cal, torch.cuda.current_stream().cuda_stream)
+            self._lib.lib().piml_trace_mark(cal, torch.cuda.current_stream().cuda_stream)
+            marks = tr.stop()
+            over = marks[-1][1] if marks and marks[-1][0] == 'event_pair_overhead' else 0.0
+            for name, us in marks[:-2]:
+                per.setdefault(name, []).append(max(us - over, 0.0))
+            per.setdefault('event_pair_overhead', []).append(over)
+            torch.cuda.synchronize()
+        return {k: median(v) for k, v in per.items()}
 
     def relaunch_relfeat(self):
         """The relfeat forward kernel of the captured step once more, eagerly, on the same buffers."""
@@ -809,24 +841,65 @@ def main():
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
     prof = None
-    ppath = os.path.join(ROOT, 'profiles', 'r02_step_counters.json')
+    ppath = os.path.join(ROOT, 'profiles', 'r03_step_counters.json')
     if world == 1 and os.path.exists(ppath):
         pj = json.load(open(ppath))
         if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
             prof = pj
+    prof_src = 'profiles/r03_step_counters.json (rocprofv3 --pmc passes of the same command, committed: STATIC, not measured in this run)'
+
+    # every launch stage of the step, timed LIVE (outside the timed region): HIP events between the stage launches of an
+    # eager step queued behind replays of the captured one (Step.trace_stages)
+    stage_us = {}
+    if world == 1 and fused_mlp and graph is not None and not use_dist:
+        try:
+            stage_us = st.trace_stages()
+        except Exception as ex:   # noqa: BLE001 - informational
+            print(f'[bench] stage trace unavailable ({type(ex).__name__}: {ex})', file=sys.stderr)
+    _phase('stage trace done')
+    x3 = '_x3' if x3_products else ''
+    stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
+                    'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
+                    'enc_bwd_dw': f'enc_bwd_dw{x3}_kernel', 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
+    static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
+    live_src = ('live: HIP events between the stage launches of an eager step queued behind 24 replays of the captured '
+                f'step, median of 5, minus the cost of an empty event interval ({stage_us.get("event_pair_overhead", 0.0):.1f} us) '
+                '(piml_trace_*); includes the dispatch gap in front of the kernel, which rocprofv3\'s kernel duration does not')
 
     if True:      # (every rank assembles the line; rank 0 writes it)
         kernels = [{'name': 'relfeat_fwd_kernel', 'us': kernel_ms * 1e3, 'share_of_step': kernel_ms / ms_per_step,
+                    'us_source': f'live: HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
+                                 f'{launches_per_sample} launches, median, event-pair overhead subtracted',
+                    'us_stage_trace': stage_us.get('relfeat_fwd'),
                     'bound': 'valu', 'frac': (prof or {}).get('relfeat_fwd_kernel', {}).get('valu_busy_frac'),
+                    'frac_source': ('SQ_ACTIVE_INST_VALU share of the SIMD cycles, ' + prof_src) if prof else None,
                     'hbm_bytes': (prof or {}).get('relfeat_fwd_kernel', {}).get('hbm_bytes_per_launch'),
+                    'hbm_bytes_source': prof_src if prof else None,
                     'operand_stream_bytes': kernel_bytes,
-                    'timing': f'HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
-                              f'{launches_per_sample} launches, median, event-pair overhead subtracted',
-                    'event_interval_us': raw_ms * 1e3, 'event_pair_overhead_us': overhead_ms * 1e3,
-                    'frac_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r02_step_counters.json '
-                                   '(rocprofv3 --pmc, separate pass)' if prof else None}]
-        for k in (prof or {}).get('other_kernels', []):
-            kernels.append(k)
+                    'event_interval_us': raw_ms * 1e3, 'event_pair_overhead_us': overhead_ms * 1e3}]
+        for stage, us in sorted(stage_us.items(), key=lambda kv: -kv[1]):
+            if stage in ('relfeat_fwd', 'event_pair_overhead'):
+                continue
+            kname = stage_kernel.get(stage, stage)
+            e = {'name': kname, 'us': us, 'share_of_step': us / (ms_per_step * 1e3), 'us_source': live_src}
+            sk = static.get(kname)
+            if sk:       # counters are static; every fraction is recomputed from the LIVE duration
+                e['hbm_bytes'] = sk.get('hbm_bytes')
+                e['hbm_frac'] = sk['hbm_bytes'] / (us * 1e-6) / (HBM_PEAK_GBS * 1e9) if sk.get('hbm_bytes') else None
+                if '_x3_' in kname and sk.get('flops'):
+                    bf16 = 6.0 * sk['flops'] * (2 * 128 * 128) / (2 * 128 * 128 + 6 * 128)      # executed: 6 x the two 128 x 128 layers
+                    e['mfma_frac'] = bf16 / (us * 1e-6) / 2.5e15
+                    e['bound'] = 'hbm' if (e['hbm_frac'] or 0) >= e['mfma_frac'] else 'mfma'
+                    e['frac'] = max(e['hbm_frac'] or 0, e['mfma_frac'])
+                elif sk.get('flops'):
+                    e['bound'], e['frac'] = 'mfma', sk['flops'] / (us * 1e-6) / (F32_MFMA_PEAK_TFS * 1e12)
+                else:
+                    e['bound'], e['valu_busy_frac'] = sk.get('bound'), sk.get('frac')
+                e['counters_source'] = prof_src
+            kernels.append(e)
+        if not stage_us:      # no live trace (sharded / eager / library MLP): the committed profile's entries, marked as such
+            for k in (prof or {}).get('other_kernels', []):
+                kernels.append(dict(k, us_source=prof_src))
         out = {
             'metric': 'agent-pair force evals/sec + simulated steps/sec, 4096-agent GC scene',
             'value': pairs_step * args.steps / elapsed, 'unit': 'pairs/s',
@@ -926,7 +999,7 @@ def main():
     secondary = None
     if rank == 0 and args.secondary:
         try:
-            secondary = secondary_measurements(scene, n_own, dev, _lib)
+            secondary = secondary_measurements(scene, n_own, dev, _lib, prof)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1 and fused_mlp:      # live evidence that the split products ARE f32 arithmetic: both forms against float64

@@ -426,6 +426,18 @@ int piml_timer_elapsed_ms(void* start, void* stop, float* ms);
 int piml_timer_destroy(void* event);
 
 /*
+ * Stage trace (measurement plumbing, bench.py's live per-kernel times): between piml_trace_begin and piml_trace_end every
+ * launch stage of the library records a HIP event behind its launch on the launch stream (never inside a stream
+ * capture); piml_trace_mark adds a mark of the caller's (`name` must stay valid until piml_trace_end; the first mark is
+ * the start).  piml_trace_end closes the trace, waits for the last mark and returns the number n of intervals:
+ * us[i] = microseconds between mark i and mark i + 1, names = the '\n'-separated names of marks 1 .. n.  At most 64
+ * marks.  Meaningful only when the stream is kept busy in front of the traced launches (else host gaps are included).
+ */
+int piml_trace_begin(void);
+int piml_trace_mark(const char* name, void* stream);
+int piml_trace_end(char* names, int names_cap, float* us, int us_cap);
+
+/*
  * Diagnostic (tests only): evaluates, per element, the exact float32 arithmetic of the
  * neighbour-selection predicates -- dist = |r| as torch.norm computes it and
  * cos = torch.cosine_similarity(r, h) (src/data/data.py:434, 439-440) -- so that it can be

@@ -83,6 +83,9 @@ SIGNATURES = {
     'piml_timer_record': [_p, _p],
     'piml_timer_elapsed_ms': [_p, _p, ctypes.POINTER(_f)],
     'piml_timer_destroy': [_p],
+    'piml_trace_begin': [],
+    'piml_trace_mark': [ctypes.c_char_p, _p],
+    'piml_trace_end': [ctypes.c_char_p, _i, ctypes.POINTER(_f), _i],
     'piml_probe_arith': [_p, _p, _p, _p, _p, _p, _i, _p],
     'piml_encoder_partial_floats': [],
     'piml_encoder_pack_floats': [],
@@ -154,6 +157,24 @@ def lib():
 def check(err, what):
     if err != 0:
         raise PimlHipError(f'{what} failed: hipError {err} ({lib().piml_error_string(err).decode()})')
+
+
+class StageTrace:
+    """piml_trace_*: live time of every launch stage between `start()` and `stop()` on torch's current stream.
+    stop() -> [(stage name, microseconds), ...] in launch order."""
+    _START = ctypes.c_char_p(b'start')
+
+    def start(self):
+        check(lib().piml_trace_begin(), 'piml_trace_begin')
+        lib().piml_trace_mark(self._START, torch.cuda.current_stream().cuda_stream)
+
+    def stop(self):
+        names = ctypes.create_string_buffer(4096)
+        us = (_f * 64)()
+        n = lib().piml_trace_end(names, 4096, us, 64)
+        if n < 0:
+            check(-n, 'piml_trace_end')
+        return list(zip(names.value.decode().split('\n')[:n], [float(us[i]) for i in range(n)]))
 
 
 class StreamTimer:

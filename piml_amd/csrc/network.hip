@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "pack.hpp"
 #include "stages.hpp"
+#include "trace.hpp"
 
 namespace piml {
 
@@ -148,6 +149,7 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
     static_assert(HEAD_PACK <= kMax, "grid covers the largest image");
     hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((kMax + 255) / 256, 2 * nbr + (head ? 1 : 0)), dim3(256), 0,
                        as_stream(stream), A);
+    trace_mark("pinnsf_pack", as_stream(stream));
     return hipGetLastError();
 }
 
@@ -180,7 +182,10 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
         // the split decoder tiles accumulate their two branches into `acc`: cleared by the encoder launch
         PIML_TRY(enc_stage_fwd(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
-        return dec_stage_fwd_fused(dec, nbr, head, self_features, tau, acc, m);
+        trace_mark("enc_fwd", m);
+        PIML_TRY(dec_stage_fwd_fused(dec, nbr, head, self_features, tau, acc, m));
+        trace_mark("dec_fwd_head", m);
+        return hipSuccess;
     }
     Side* S;
     PIML_TRY(side_streams(&S));
@@ -211,9 +216,14 @@ PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_
     hipStream_t m = as_stream(stream);
     if (!(flags & PIML_FORK)) {
         PIML_TRY(dec_stage_bwd_fused(dec, nbr, g_pred, self_features, tau, g_self, m));
+        trace_mark("dec_bwd", m);
         PIML_TRY(enc_stage_bwd_dx(enc, nbr, m));
+        trace_mark("enc_bwd_dx", m);
         PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
-        return reduce_all(enc, dec, nbr, m);
+        trace_mark("enc_bwd_dw", m);
+        PIML_TRY(reduce_all(enc, dec, nbr, m));
+        trace_mark("pinnsf_reduce", m);
+        return hipSuccess;
     }
     PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
     Side* S;

@@ -15,6 +15,7 @@
 //
 // No N x N intermediate exists; v / a are touched only for the k selected neighbours.
 #include "common.hpp"
+#include "trace.hpp"
 #include "../../include/piml_hip.h"
 
 #include <cmath>
@@ -559,9 +560,11 @@ PIML_API int piml_relfeat_self_fwd(const float* state, const float* destination_
                                    float dist_thr_obs, float* ped_feat, float* obs_feat, float* self_features,
                                    int32_t* ped_idx, int32_t* obs_idx, float* g_state_zero, void* stream) {
     if (focal_count > 0 && (!state || !desired_speed || !self_features)) return hipErrorInvalidValue;
-    return relfeat_launch(state, nullptr, state + 2, state + 4, 6, destination_rows, obstacles, 1, N, M, focal_begin,
-                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
-                          obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, g_state_zero, (long)N * 6, stream);
+    const int e = relfeat_launch(state, nullptr, state + 2, state + 4, 6, destination_rows, obstacles, 1, N, M, focal_begin,
+                                 focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                                 obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, g_state_zero, (long)N * 6, stream);
+    trace_mark("relfeat_fwd", as_stream(stream));
+    return e;
 }
 
 // piml_relfeat_self_fwd in two launches for agent-block sharding (part 1 = PIML_RELFEAT_LOCAL, 2 = PIML_RELFEAT_REMOTE,
@@ -597,6 +600,7 @@ PIML_API int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_f
     hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
                        g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,
                        focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+    trace_mark("relfeat_bwd", as_stream(stream));
     return hipGetLastError();
 }
 

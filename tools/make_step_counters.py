@@ -110,6 +110,18 @@ for r in rows:
     kernels.append(e)
     step_hbm += hbm * per_step
     step_us += us * per_step
+# MLAPM (secondary figures): VALU-issue share of the SIMD cycles from its own PMC pass
+mlapm = None
+try:
+    mp = pmc('mlapm')
+    mlapm = {}
+    for kname, c in mp.items():
+        for tagk in ('fwd', 'bwd'):
+            if f'mlapm_{tagk}_kernel' in kname and c.get('SQ_BUSY_CU_CYCLES'):
+                mlapm[f'{tagk}_valu_busy_frac'] = round(4 * c['SQ_ACTIVE_INST_VALU'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
+                mlapm[f'{tagk}_valu_insts_per_wave'] = round(c.get('SQ_INSTS_VALU', 0.0) / max(c.get('SQ_WAVES', 1.0), 1.0), 1)
+except (IndexError, FileNotFoundError):
+    pass
 kernels.sort(key=lambda e: -e['us'] * e['launches_per_step'])
 rel = next(e for e in kernels if e['name'] == 'relfeat_fwd_kernel')
 out = {
@@ -118,6 +130,7 @@ out = {
     'bench_line': {k: bench[k] for k in ('value', 'ms_per_step')},
     'step_hbm_bytes': round(step_hbm), 'step_kernel_us_sum': round(step_us, 1),
     'relfeat_fwd_kernel': {'hbm_bytes_per_launch': rel['hbm_bytes'], 'valu_busy_frac': rel.get('frac')},
+    'mlapm': mlapm,
     'other_kernels': [e for e in kernels if e['name'] != 'relfeat_fwd_kernel'][:6],
     'all_step_kernels': kernels,
 }

@@ -9,5 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq -- python3 $R/bench.py $ARGS > $O/sq.log 2>&1
+# the MLAPM kernels (secondary figures of the bench line): SIMD occupancy in a pass of their own
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/mlapm -- python3 $R/tools/mlapm_gc_4096.py > $O/mlapm.log 2>&1
 python3 $R/bench.py --cpu-seconds 0 > $O/bench.json 2> $O/bench.err
 tail -c 300 $O/stats.log
