@@ -701,7 +701,101 @@ def gen_mainflow(cases=('gc', 'ucy')):
         os.chdir(cwd)
 
 
-GENS = dict(mainflow=gen_mainflow, relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
+def gen_mainflow_pointwise(cases=('gc', 'ucy'),
+                           init_batches={'gc': (0, 19, 38, 57, 76, 99), 'ucy': (0, 19, 38, 57, 76, 95, 114, 130)},
+                           traj_batches={'gc': (99,), 'ucy': (100, 120, 130)}):
+    """Single pointwise pre-training steps of the cfg5 flow (src/models/simulators.py:327-360: MSE + message regulariser
+    + BCE of the bottleneck collision head), by the reference's own classes:
+      b{i}/...     batch i of the first epoch evaluated at the INITIAL weights (= mainflow_*.npz init/): inputs, the three
+                   loss terms, the predicted accelerations, every parameter gradient;
+      traj{i}/...  batch i along the reference's OWN first-epoch trajectory: the weights it holds when it reaches that batch
+                   (captured in front of its optimizer.step), the gradients it computed there, inputs, losses, predictions
+                   -- for UCY these sit either side of the batch (~110) where two float32 implementations drift apart."""
+    import yaml
+    import torch.nn.functional as F
+    import data.dataset as DATASET
+    import models.simulators as SIM
+    import utils.data_loader as LOADER
+    scratch = '/tmp/piml_ref_mainflow'
+    os.makedirs(os.path.join(scratch, 'src'), exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(os.path.join(scratch, 'src'))
+
+    class Done(Exception):
+        pass
+    try:
+        for case in cases:
+            cfg = MAINFLOW_CASES[case]
+            args = mainflow_args(case, epochs=1)
+            path = os.path.join(scratch, f'{case}_pretrain.yaml')
+            yaml.safe_dump({k: [os.path.join(REF, f) for f in v] for k, v in cfg['pretrain'].items()}, open(path, 'w'))
+            np.random.seed(args.seed)
+            torch.manual_seed(args.seed)
+            synthetic = DATASET.PointwisePedDataset()
+            synthetic.load_data(path)
+            synthetic.build_dataset(args)
+            np.random.seed(args.seed)
+            loaders = LOADER.data_loader(synthetic.train_data, args.batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
+            torch.manual_seed(args.seed)
+            sim = SIM.BaseSimulator(args)
+            committed = np.load(os.path.join(HERE, f'mainflow_{case}.npz'))
+            for k, v in sim.model.state_dict().items():       # the same initial weights as the whole-flow fixture
+                assert np.array_equal(v.numpy(), committed[f'init/{k}']), k
+            out = {}
+
+            def terms(batch):
+                ped, obs, selff, labels = batch
+                pred = sim.model(ped, obs, selff)
+                mse = F.mse_loss(pred[0], labels[:, 4:6], reduction='sum')
+                reg = sim.l1_reg_loss(pred[1], args.reg_weight, 'sum')
+                bce = F.binary_cross_entropy(pred[-1], labels[:, 6:], reduction='sum')
+                return pred, mse, reg, bce
+
+            def record(tag, batch, pred, mse, reg, bce):
+                ped, obs, selff, labels = batch
+                out[f'{tag}/ped'], out[f'{tag}/obs'], out[f'{tag}/selff'], out[f'{tag}/labels'] = ped, obs, selff, labels
+                out[f'{tag}/losses'] = np.array([float(mse), float(reg), float(bce)], np.float64)
+                out[f'{tag}/acc'] = pred[0].detach().clone()
+            sim.model.train()
+            for bi in init_batches[case]:
+                sim.model.zero_grad(set_to_none=True)
+                pred, mse, reg, bce = terms(loaders[bi])
+                (mse + reg + bce).backward()
+                record(f'b{bi}', loaders[bi], pred, mse, reg, bce)
+                for k, p_ in sim.model.named_parameters():
+                    if p_.grad is not None:
+                        out[f'b{bi}/grad/{k}'] = p_.grad.clone()
+            sim.model.zero_grad(set_to_none=True)
+            # the reference's own loop (sim.train), interrupted in front of the optimizer step of the wanted batches
+            want = sorted(traj_batches.get(case, ()))
+            count = [0]
+            real_step = sim.optimizer.step
+
+            def step(*a, **kw):
+                b = count[0]
+                if b in want:
+                    for k, p_ in sim.model.named_parameters():
+                        out[f'traj{b}/weights/{k}'] = p_.detach().clone()
+                        if p_.grad is not None:
+                            out[f'traj{b}/grad/{k}'] = p_.grad.clone()
+                    with torch.no_grad():
+                        record(f'traj{b}', loaders[b], *terms(loaders[b]))
+                    if b == want[-1]:
+                        raise Done
+                count[0] += 1
+                return real_step(*a, **kw)
+            sim.optimizer.step = step
+            try:
+                if want:
+                    sim.train(loaders, synthetic.valid_data)
+            except Done:
+                pass
+            save('mainflow_pointwise_' + case, **out)
+    finally:
+        os.chdir(cwd)
+
+
+GENS = dict(mainflow_pointwise=gen_mainflow_pointwise, mainflow=gen_mainflow, relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
