@@ -73,6 +73,12 @@ def get_args(argv=None):
       help='1 (default): carry the waypoint indices / first-frame velocity history of a rollout over to the next rollout of '
            'the same clip or batch, as the reference does through its in-place views (SURVEY quirk Q12); 0: every '
            'rollout starts from the untouched data')
+    A('--library_gemm', type=int, default=0,
+      help='1: run the networks on library GEMMs + HIP glue kernels instead of the fused matrix-core kernels.  Both are '
+           'float32 and agree to 1e-5 per step (tests/test_ucy_gpu.py); over a whole training run a hidden unit waking up '
+           'one batch earlier in one of them shifts the trajectory (DESIGN.md section 2).  The library path happens to '
+           'round like the reference\'s CPU GEMM and reproduces its printed UCY numbers to 1e-6: use it to REPRODUCE a '
+           'reference run digit for digit, the default (0) to train fast')
     A('--fix_dest_norm', action='store_true',
       help='desired-force direction normalised per agent for channelled (C, N, 7) input too; the reference reduces '
            'over dim=1 = the AGENT axis there (src/models/model.py:1290, SURVEY quirk Q2), which stays the default')
@@ -96,6 +102,9 @@ def main(argv=None, init_state=None):
     from the reference's own initial weights; parameter initialisation consumes the RNG in a different order)."""
     args = get_args(argv)
     set_exp_configs(args)
+    if args.library_gemm:
+        import piml_amd.models.model as _M
+        _M.FUSED_ENCODER = _M.FUSED_NETWORK = _M.FUSED_ROW_DECODER = _M.FUSED_KSUM_TAIL = False
     if args.tunableop:
         from . import tuning
         print('pre-tuned GEMM selections loaded:', tuning.load())

@@ -66,13 +66,17 @@ COMMON = ['-f', '--device', 'cuda:0', '--model', 'pinnsf_bm', '--dropout', '0.0'
 #     different order than torch.sum moves the final metrics by 3e-2); the fused kernels (bias as the accumulator's initial value, MFMA
 #     summation order) do not.  `spread_*` prints the distance between the two paths on every run.  Three builds of
 #     round 2 (different MFMA / VALU summation orders) gave for (pre_val, weights, worst metric, collisions):
-#     (1.2e-3, 1.6e-3, 1.2e-3, 7e-3), (2.5e-3, 3e-3, 4e-3, 7e-3), (3.1e-3, 4.1e-3, 1.0e-2, 2.0e-2); the bounds are ~3x
-#     the largest.  The tight checks are the `ref_*` rollouts (reference weights) and the single-step test below.
+#     (1.2e-3, 1.6e-3, 1.2e-3, 7e-3), (2.5e-3, 3e-3, 4e-3, 7e-3), (3.1e-3, 4.1e-3, 1.0e-2, 2.0e-2); round 3 (split products the
+#     default): (8.7e-4, 2.2e-3, 1.2e-3, 6.7e-3), ft_train 1.6e-2.  The bounds are ~3x the largest seen, ft_train / weights
+#     tightened in round 3.  The mechanism itself is asserted in tests/test_ucy_gpu.py (gradients on the same weights agree
+#     on all 131 batches to 4.4e-5; the trajectories separate at ONE hidden unit), the per-step arithmetic against the
+#     reference in the single-step test below (incl. the reference's own weights at batches 100 / 120 / 130).
+#     `python -m piml_amd.main --library_gemm 1` trains on the path that reproduces the reference's numbers to 1e-6.
 TOL = {
     'gc': dict(pre_train=1e-6, pre_val=5e-6, ft_train=1e-4, ft_counts=0.0, weights=2e-4, val=2e-2, metrics=3e-4,
                collisions=0.0, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                ref_collisions=0.0),
-    'ucy': dict(pre_train=1e-3, pre_val=1e-2, ft_train=1e-1, ft_counts=3e-2, weights=1.5e-2, val=2e-2, metrics=3e-2,
+    'ucy': dict(pre_train=1e-3, pre_val=1e-2, ft_train=6e-2, ft_counts=3e-2, weights=1.2e-2, val=2e-2, metrics=3e-2,
                 collisions=6e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                 ref_collisions=0.0),
 }
@@ -178,9 +182,9 @@ def test_main_flow_matches_reference_end_to_end(case):
         first = dict(mse=ev[1], mae=ev[2], ot=ev[3], mmd=ev[4], fde=sim.last_eval['fde'],
                      val=val_got.copy(), pre_val=np.array([h['val_loss'] for h in pre]))
         old_flags = (MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK, MODEL.FUSED_ROW_DECODER, MODEL.FUSED_KSUM_TAIL)
-        MODEL.FUSED_ENCODER = MODEL.FUSED_NETWORK = MODEL.FUSED_ROW_DECODER = MODEL.FUSED_KSUM_TAIL = False
         try:
-            MAIN.main(argv, init_state=init)
+            MAIN.main(argv + ['--library_gemm', '1'], init_state=init)
+            assert not (MODEL.FUSED_ENCODER or MODEL.FUSED_NETWORK or MODEL.FUSED_ROW_DECODER or MODEL.FUSED_KSUM_TAIL)
         finally:
             MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK, MODEL.FUSED_ROW_DECODER, MODEL.FUSED_KSUM_TAIL = old_flags
         sim2 = MAIN.LAST_RUN['simulator']

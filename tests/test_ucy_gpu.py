@@ -77,7 +77,7 @@ def test_fused_and_library_gradients_agree_on_every_pretraining_batch():
             try:
                 sim.model.zero_grad(set_to_none=True)
                 pred = sim.model(ped, obs, selff)
-                loss = F.mse_loss(pred[0], labels[:, 4:6], reduction='sum') + sim.l1_reg_loss(pred[1], sim.args.reg_weight, 'sum') + \\
+                loss = F.mse_loss(pred[0], labels[:, 4:6], reduction='sum') + sim.l1_reg_loss(pred[1], sim.args.reg_weight, 'sum') + \
                     F.binary_cross_entropy(pred[-1], labels[:, 6:], reduction='sum')
                 loss.backward()
                 res[fused] = (float(loss), {k: p.grad.double().clone() for k, p in sim.model.named_parameters() if p.grad is not None})
@@ -98,7 +98,7 @@ def test_fused_and_library_gradients_agree_on_every_pretraining_batch():
     _pretrain_epoch(hook)
     assert len(rows) == 131
     top = sorted(rows, reverse=True)[:3]
-    print('\\n[ucy] fused vs library-path gradients on the same weights, 131 batches: worst '
+    print('\n[ucy] fused vs library-path gradients on the same weights, 131 batches: worst '
           + '; '.join(f'{e:.1e} (batch {b}, {k})' for e, b, k, _ in top)
           + f'; median {np.median([r[0] for r in rows]):.1e}; worst loss difference {max(r[3] for r in rows):.1e}')
     assert top[0][0] <= 1e-4 and max(r[3] for r in rows) <= 1e-5
@@ -126,7 +126,7 @@ def test_the_two_trajectories_separate_at_one_hidden_unit():
         return (a - b).abs() / b.abs().max().clamp_min(1e-30)
     dist = [max(float(gap(i, k).max()) for k in snaps[True][i]) for i in range(n)]
     first = next((i for i, d in enumerate(dist) if d > 5e-4), None)
-    print(f'\\n[ucy] distance between the fused and the library-path weight trajectories: after 10 batches {dist[9]:.1e}, '
+    print(f'\n[ucy] distance between the fused and the library-path weight trajectories: after 10 batches {dist[9]:.1e}, '
           f'50 {dist[49]:.1e}, 100 {dist[99]:.1e}, 131 {dist[-1]:.1e}; first batch with a gap > 5e-4: {first}')
     assert max(dist[:40]) <= 1e-4                      # no drift while no unit changes state
     if first is None:                                  # this build happens to round alike over the whole epoch
