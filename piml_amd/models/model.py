@@ -444,9 +444,25 @@ class _PINNSFBase(nn.Module):
         fused = self._fused_network(ped_features, obs_features, self_features)
         if fused is not None:
             return fused
-        pre = {} if self.residual else self._fused_encoders(ped_features, obs_features)
+        encoded = None
+        if self.residual:
+            # pinnsf_res (model.py:1024-1059): the corrector reads the pedestrian encoder's RAW output, so that encoder runs
+            # on the fused kernels with scale 1 and no mask (its own launch) and the processor is the glue pass
+            # (ops.scale_ksum, mask-aware); the obstacle branch takes the standard fused path
+            pre = {}
+            if self._encoder_fusable(ped_features, self.ped_encoder, self.ped_processor):
+                from .. import ops
+                encoded = ops.fused_encoders([dict(x=ped_features, scale=1.0, pooled=False,
+                                                   weights=[t for lin in self.ped_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])[0][0]
+            if self.obs_feature_dim > 0 and self._encoder_fusable(obs_features, self.obs_encoder, self.obs_processor):
+                from .. import ops
+                spec = self._launch_specs([(self.obs_processor, obs_features)])[0]
+                pre['obs'] = ops.fused_encoders([dict(x=obs_features, scale=spec[0], keep_bits=spec[1], pooled=True,
+                                                      weights=[t for lin in self.obs_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])[0]
+        else:
+            pre = self._fused_encoders(ped_features, obs_features)
         rowdec = self._fused_row_decoders(pre)
-        if FUSED_GLUE and FUSED_ENCODER and ped_features.is_cuda and not pre and not self.residual and \
+        if FUSED_GLUE and FUSED_ENCODER and ped_features.is_cuda and not pre and encoded is None and \
                 ped_features.numel() // ped_features.shape[-1] >= FUSED_ENCODER_MIN_ROWS:
             _note_fallback(f'{type(self).__name__}: geometry / dtype / flags outside the fused encoder kernels '
                            f'(encoder {[lin.out_features for lin in self.ped_encoder.mlp[0::2]]}, '
@@ -462,7 +478,8 @@ class _PINNSFBase(nn.Module):
             with torch.cuda.stream(side):
                 acc_o, out_obs_side, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
                                                          self.obs_decoder, self.obs_predictor)
-        encoded = self.ped_encoder(ped_features) if self.residual else None
+        if self.residual and encoded is None:
+            encoded = self.ped_encoder(ped_features)
         if self.residual:
             emb, pooled = self._process_and_pool(self.ped_processor, encoded)
             ped_msgs = emb

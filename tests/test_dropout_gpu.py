@@ -193,6 +193,41 @@ def test_train_mode_fused_kernels_match_torch_nn_with_the_same_mask(name, n, p):
     assert worst <= 1e-5
 
 
+@pytest.mark.parametrize('train', [False, True])
+def test_pinnsf_res_encoders_on_the_fused_kernels(train):
+    """`--model pinnsf_res` (src/models/model.py:973-1059): its corrector reads the pedestrian encoder's raw output, so that
+    encoder runs on the fused kernels with scale 1 (own launch) + the mask-aware processor pass, the obstacle branch on the
+    standard fused path; against the plain torch.nn expression, eval mode and train mode with injected masks."""
+    import piml_amd.models.model as MODEL
+    from piml_amd import ops
+    torch.manual_seed(0)
+    net = MODEL.PINNSF_residual(model_args(res_hidden_layers=3, dropout=0.5)).to(DEV).train(train)
+    g = torch.Generator().manual_seed(11)
+    n = 700
+    base = [torch.randn(n, 6, 6, generator=g).to(DEV), torch.randn(n, 10, 6, generator=g).to(DEV), torch.randn(n, 7, generator=g).to(DEV)]
+    for proc, rows in ((net.ped_processor, n * 6), (net.obs_processor, n * 10), (net.corrector[0], n * 6)):
+        proc.keep_bits = ops.pack_keep_bits(torch.rand(rows, 128, generator=g) >= 0.5).to(DEV)
+    avoid_relu_kinks(net, base)
+    with torch.no_grad():
+        probe = net(*base)
+    weights = [torch.randn(o.shape, generator=g).to(DEV) * (1.0 if i == 0 else 1e-2) for i, o in enumerate(probe)]
+    launches = []
+    real = ops.fused_encoders
+    ops.fused_encoders = lambda brs: (launches.append(len(brs)), real(brs))[1]
+    res = {}
+    try:
+        for fused in (True, False):
+            MODEL.FUSED_GLUE = fused
+            res[fused] = _passes(net, base, weights)
+    finally:
+        MODEL.FUSED_GLUE = True
+        ops.fused_encoders = real
+    assert launches == [1, 1]                               # both encoders took the fused kernels (one launch each)
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) for a, b in zip(res[True], res[False]))
+    print(f'pinnsf_res train={train}: fused encoders vs torch.nn, max rel err {worst:.1e}')
+    assert worst <= 1e-5
+
+
 @pytest.mark.parametrize('products', ['x3', 'f32'])
 def test_train_mode_f32_instruction_kernels_match_too(products):
     """Both product forms of the encoder kernels carry the mask (piml_encoder_products)."""

@@ -9,9 +9,13 @@ from piml_amd.scenes import synthetic_gc_scene
 dev = torch.device('cuda:0')
 N, M = 4096, 2000
 scene = synthetic_gc_scene(N, M, seed=0)
-for name in ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNSF_bottleneck'):
+import types
+_margs = bench.model_args
+bench.model_args = lambda: types.SimpleNamespace(**dict(_margs().__dict__, res_hidden_layers=3))
+for name in ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNSF_bottleneck', 'PINNSF_residual'):
+  for train in (False, True):
     try:
-        st = bench.Step(scene, N, N, 0, M, dev, None, False, False, True, model_name=name)
+        st = bench.Step(scene, N, N, 0, M, dev, None, False, False, True, model_name=name, train_mode=train)
         st.capture()
         for _ in range(20):
             st.run()
@@ -19,6 +23,6 @@ for name in ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNS
         for _ in range(200):
             st.run()
         torch.cuda.synchronize()
-        print(f'{name:32s} {st.mode}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step')
+        print(f'{name:32s} {"train() dropout 0.5" if train else "eval()":20s} {st.mode}: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step', flush=True)
     except Exception as ex:   # noqa
         print(name, 'failed:', ex)
