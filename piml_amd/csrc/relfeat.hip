@@ -88,17 +88,31 @@ __device__ __forceinline__ void list_insert(unsigned& ld, unsigned& li, unsigned
     li = moves ? (below_moves ? up_i : ni) : li;
 }
 
-template <int WAVES>
+constexpr int kObsTile = 2048;     // RES: obstacle points resident next to the agent tile (16 KiB)
+
+// LDS (dynamic): agent tile x | y (kTile floats each), the waves' candidate rings, and -- RES -- the obstacle tile x | y.
+template <int WAVES, bool RES>
+constexpr int relfeat_lds_bytes() { return (2 * kTile + WAVES * kRing / 2 + (RES ? 2 * kObsTile : 0)) * 4; }
+
+// RES ("both tiles resident"): when the agent sources fit one tile and the obstacle points fit kObsTile, both are staged up
+// front and the only barrier of the launch is the one behind that staging.  Otherwise every pass re-stages the shared tile
+// behind a workgroup barrier, i.e. all 16 waves wait for the slowest pedestrian pass before the obstacle pass can start:
+// measured at the 4096-agent scene (in-kernel stamps, tools/relfeat_stats.py) a median wave spent 7.5 k of its 32.6 k cycles
+// in that wait (per-row work is data dependent: 18 k median, 26 k max for the pedestrian pass).
+template <int WAVES, bool RES>
 __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatArgs A) {
-    // source tile, structure-of-arrays so that a lane fetches 4 consecutive points per
+    // source tiles, structure-of-arrays so that a lane fetches 4 consecutive points per
     // ds_read_b128 (x) + ds_read_b128 (y)
-    __shared__ __attribute__((aligned(16))) float tile_x[kTile];
-    __shared__ __attribute__((aligned(16))) float tile_y[kTile];
-    __shared__ unsigned short ring_all[WAVES][kRing];
+    extern __shared__ __attribute__((aligned(16))) float rf_lds[];
+    float* const agent_x = rf_lds;
+    float* const agent_y = rf_lds + kTile;
+    unsigned short* const ring_base = reinterpret_cast<unsigned short*>(rf_lds + 2 * kTile);
+    float* const obs_x = RES ? rf_lds + 2 * kTile + WAVES * kRing / 2 : agent_x;
+    float* const obs_y = RES ? obs_x + kObsTile : agent_y;
 
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
-    unsigned short* ring = ring_all[wave];                  // stays in the LDS address space
+    unsigned short* ring = ring_base + wave * kRing;        // stays in the LDS address space
 
     if (A.tick && blockIdx.x == 0 && threadIdx.x == 0) *A.tick += 1;
     if (A.zero)                                             // a few 100 KB, spread over the whole grid
@@ -134,7 +148,6 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     }
     const float n2c = fmaxf(norm2(hx, hy), 1e-8f);
     const float h0 = __fdiv_rn(hx, n2c), h1 = __fdiv_rn(hy, n2c);
-    const float qnan = __uint_as_float(0x7fc00000u);
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f pix2 = {pix, pix}, piy2 = {piy, piy};
 
@@ -147,6 +160,25 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
 #else
 #define PIML_STAT(x)
 #endif
+    const float qnan = __uint_as_float(0x7fc00000u);
+    // global -> LDS tile (x | y), rows past `tn` padded with NaN (never pass the cut-off)
+    auto stage = [&](const float* __restrict__ src, int sld, int base, int tn, int tn_pad, float* tx, float* ty) {
+        // (issuing all of a thread's loads before the first LDS write, as the encoder's weight staging does, was
+        // measured here and is slower: 23.0 vs 22.4 us at cfg3, 10.2 vs 8.8 us at N = 122 -- the tile is small and
+        // the extra registers / redundant clamped loads cost more than the serial round trips)
+        for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
+            float2 q = make_float2(qnan, qnan);
+            if (t < tn) q = *reinterpret_cast<const float2*>(src + (size_t)(base + t) * sld);
+            tx[t] = q.x; ty[t] = q.y;
+        }
+    };
+    if (RES) {
+        const int n0 = A.a_hi[0] - A.a_lo[0];
+        stage(A.p + (size_t)c * A.N * ld, ld, A.a_lo[0], n0, (n0 + 511) & ~511, agent_x, agent_y);
+        stage((const float*)A.obs, 2, 0, A.M, (A.M + 511) & ~511, obs_x, obs_y);
+        __syncthreads();
+        PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
+    }
     u64 lists[2] = {kEmptyKey, kEmptyKey};
     // Runtime loop and a single evaluation site: the exact-evaluation / drain code exists once
     // in the binary, so it stays resident in the instruction cache (inlining it at every
@@ -162,6 +194,8 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         float cut2 = pass == 0 ? A.cut2_p : A.cut2_o;      // wave-uniform
 
         if (pass == 1 && !(A.flags & kRfObs)) break;       // (uniform over the launch: no barrier is skipped unevenly)
+        float* const tile_x = pass == 0 ? agent_x : obs_x;
+        float* const tile_y = pass == 0 ? agent_y : obs_y;
 
         unsigned list_d = kEmptyDist, list_i = 0;          // lane s: s-th nearest in-view source so far
         unsigned kth_d = kEmptyDist, kth_i = 0;            // wave-uniform copy of lane k-1's entry
@@ -189,17 +223,12 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         for (int base = lo; base < hi; base += kTile) {
             const int tn = min(kTile, hi - base);
             const int tn_pad = (tn + 511) & ~511;          // phase 1 reads whole 512-groups
-            __syncthreads();                                // previous tile fully consumed
-            // (issuing all of a thread's loads before the first LDS write, as the encoder's weight staging does, was
-            // measured here and is slower: 23.0 vs 22.4 us at cfg3, 10.2 vs 8.8 us at N = 122 -- the tile is small and
-            // the extra registers / redundant clamped loads cost more than the serial round trips)
-            for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
-                float2 q = make_float2(qnan, qnan);         // NaN never passes the cut-off
-                if (t < tn) q = *reinterpret_cast<const float2*>(src + (size_t)(base + t) * sld);
-                tile_x[t] = q.x; tile_y[t] = q.y;
+            if (!RES) {
+                __syncthreads();                            // previous tile fully consumed
+                stage(src, sld, base, tn, tn_pad, tile_x, tile_y);
+                __syncthreads();
+                PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
             }
-            __syncthreads();
-            PIML_STAT(if (st_n < 7) st_t[st_n++] = __builtin_amdgcn_s_memtime();)
             if (!alive || k <= 0) continue;
 
             // one extra trip (j0 == tn_pad) appends nothing and flushes the ring, because the
@@ -466,6 +495,17 @@ static float dist2_cutoff(float thr) {
 
 using namespace piml;
 
+template <int W, bool R>
+static void relfeat_go(dim3 grid, dim3 block, void* stream, const RelfeatArgs& A) {
+    constexpr int bytes = relfeat_lds_bytes<W, R>();
+    relfeat_fwd_kernel<W, R><<<grid, block, bytes, as_stream(stream)>>>(A);
+}
+template <int W>
+static int relfeat_attr() {
+    constexpr int bytes = relfeat_lds_bytes<W, true>();
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(relfeat_fwd_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 static int relfeat_launch(const float* position, const float* heading, const float* velocity,
                           const float* acceleration, int state_ld, const float* destination,
                           const float* obstacles, int C, int N, int M, int focal_begin,
@@ -516,10 +556,26 @@ static int relfeat_launch(const float* position, const float* heading, const flo
     if (const char* e = getenv("PIML_RELFEAT_WAVES")) waves = atoi(e);
     const int bpc = (focal_count + waves - 1) / waves;
     const dim3 grid((unsigned)(C * bpc)), block((unsigned)(waves * 64));
-    switch (waves) {
-        case 16: hipLaunchKernelGGL(relfeat_fwd_kernel<16>, grid, block, 0, as_stream(stream), A); break;
-        case 8: hipLaunchKernelGGL(relfeat_fwd_kernel<8>, grid, block, 0, as_stream(stream), A); break;
-        case 4: hipLaunchKernelGGL(relfeat_fwd_kernel<4>, grid, block, 0, as_stream(stream), A); break;
+    // both tiles resident (one barrier per launch) when the agent sources are one tile and the obstacle pass exists and fits
+    static const bool res_off = getenv("PIML_RELFEAT_RESIDENT") && atoi(getenv("PIML_RELFEAT_RESIDENT")) == 0;
+    const bool res = !res_off && (A.flags & kRfObs) && M > 0 && M <= kObsTile && A.a_hi[1] == A.a_lo[1] &&
+                     A.a_hi[0] - A.a_lo[0] <= kTile && A.ko > 0;
+    if (res) {
+        static int attr = -1;      // dynamic LDS above 64 KB has to be enabled per kernel once per process
+        if (attr < 0) {
+            attr = relfeat_attr<16>();
+            if (!attr) attr = relfeat_attr<8>();
+            if (!attr) attr = relfeat_attr<4>();
+        }
+        if (attr) return attr;
+    }
+    switch (waves * 2 + (res ? 1 : 0)) {
+        case 33: relfeat_go<16, true>(grid, block, stream, A); break;
+        case 32: relfeat_go<16, false>(grid, block, stream, A); break;
+        case 17: relfeat_go<8, true>(grid, block, stream, A); break;
+        case 16: relfeat_go<8, false>(grid, block, stream, A); break;
+        case 9: relfeat_go<4, true>(grid, block, stream, A); break;
+        case 8: relfeat_go<4, false>(grid, block, stream, A); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
