@@ -864,6 +864,9 @@ PIML_API int piml_encoder_products(int x3) {
     return old;
 }
 
+// PIML_ENC_DX_SPLIT=f32: the few-rows dX chain on the f32 matrix instruction even with split products elsewhere (A/B)
+static const bool g_dx_split_f32 = getenv("PIML_ENC_DX_SPLIT") && getenv("PIML_ENC_DX_SPLIT")[0] == 'f';
+
 static int x3_ready() {
     static int state = -1;
     if (state < 0) state = enc_x3_set_attributes();
@@ -938,6 +941,11 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     // the backward form breaks even earlier than the forward, every wave rebuilding the whole g3.)
     if ((tiles[0] + tiles[1]) * 4 <= g_split_tiles * 3) {
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
+        if (g_x3 && !g_dx_split_f32) {
+            if (int e = x3_ready()) return e;
+            enc_x3_launch_bwd_dx_split(A, pairs0, pairs1, br[0].keep_bits != nullptr, s);
+            return hipGetLastError();
+        }
         if (br[0].keep_bits) hipLaunchKernelGGL(enc_bwd_dx_split_kernel<true>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
         else hipLaunchKernelGGL(enc_bwd_dx_split_kernel<false>, dim3((unsigned)(pairs0 + pairs1)), dim3(512), 0, s, A, pairs0);
         return hipGetLastError();

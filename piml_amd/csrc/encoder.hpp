@@ -61,6 +61,7 @@ int enc_x3_set_attributes();
 // drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);   // A.gen_state: draw the masks in the kernel
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
+void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
 void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, bool drop, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
 

@@ -666,6 +666,168 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// dX chain for FEW rows (the fine-tuning loop on real clips, src/models/simulators.py:659-832: 100 .. 1000 agents): four
+// waves per tile like enc_fwd_split_x3_kernel.  Wave (t, blk) owns block blk of g3, g2 and g1 of tile t: it builds ITS 16
+// registers of g3 (loads, scale, keep mask), splits them and hands the pieces over through LDS as ready-made B operands;
+// after the barrier every wave runs the eight k-blocks of its output block of W3^T g3, masks with h2, stores g2, hands
+// the split block over again, and likewise for g1 = (W2^T g2) * [h1 > 0].  g_x = W1^T g1 by the blk = 0 wave of the tile
+// from all four g1 blocks (f32, through LDS) in enc_bwd_dx_x3_kernel's order.  Every accumulator sees the k-blocks and
+// the six products in the order of enc_bwd_dx_x3_kernel: bitwise identical gradients.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int X3_DXS_G1 = X3_SPLIT_LDS_BYTES;                             // byte offset of the g1 exchange [tile 2][block 4][16][64] floats
+constexpr int X3_DXS_LDS_BYTES = X3_SPLIT_LDS_BYTES + 2 * 4 * 16 * 64 * 4;
+static_assert(X3_DXS_LDS_BYTES <= 160 * 1024, "fits the CU");
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void enc_bwd_dx_split_x3_kernel(EncArgs A, int pairs0) {
+    extern __shared__ __align__(16) float lds[];
+    u32x4* exch = reinterpret_cast<u32x4*>(lds);
+    float* g1x = lds + X3_DXS_G1 / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x >= pairs0 ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int t = wave >> 2, blk = wave & 3;
+    const long long R = J.rows;
+    const int IN = J.in_dim, K = J.k;
+    const long long tile = ((long long)blockIdx.x - (b ? pairs0 : 0)) * 2 + t;
+    const int j = lane & 31, h = lane >> 5;
+    const long long row = tile * 32 + j;
+    const bool valid = row < R;
+    const long long rr = valid ? row : 0;
+    const float scale = J.scale;
+    const float* x3 = J.packed + PACK_F32;
+    const u32x4* W3hm = reinterpret_cast<const u32x4*>(x3 + 2 * X3_IMG) + lane;
+    const u32x4* W3lo = W3hm + X3_HM / 4;
+    const u32x4* W2hm = reinterpret_cast<const u32x4*>(x3 + 3 * X3_IMG) + lane;
+    const u32x4* W2lo = W2hm + X3_HM / 4;
+    const float4* W1r = reinterpret_cast<const float4*>(J.packed + PACK_FWD + 32768);      // row f = float4 2 f, 2 f + 1
+    u32x4 wf[8][3];                                   // this wave's fragments of the layer: k-block, (hi, mid, lo)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const int fb = blk * 8 + kb;
+        wf[kb][0] = W3hm[(fb * 2) * 64]; wf[kb][1] = W3hm[(fb * 2 + 1) * 64]; wf[kb][2] = W3lo[fb * 64];
+    }
+    float4 hv[4];                                     // this block's h2 values (ReLU mask of the first layer of the chain)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(J.h2 + rr * EH + feat0(blk, q, h));
+    f32x16 acc, sm;
+    // ---- this wave's block of g3 ----
+    {
+        const float* gp = J.g_pooled ? J.g_pooled + (rr / K) * EH : nullptr;
+        const float* gm = J.g_msgs ? J.g_msgs + rr * EH : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gp) v = *reinterpret_cast<const float4*>(gp + feat0(blk, q, h));
+            if (gm) {
+                const float4 m = *reinterpret_cast<const float4*>(gm + feat0(blk, q, h));
+                v.x += m.x; v.y += m.y; v.z += m.z; v.w += m.w;
+            }
+            acc[4 * q + 0] = valid ? scale * v.x : 0.f; acc[4 * q + 1] = valid ? scale * v.y : 0.f;
+            acc[4 * q + 2] = valid ? scale * v.z : 0.f; acc[4 * q + 3] = valid ? scale * v.w : 0.f;
+        }
+        if (DROP) keep_block(acc, valid ? J.keep_bits[rr * 4 + blk] : 0u, h);
+    }
+    auto hand_over = [&](int l) {                     // this wave's 16 registers, split, as the B operands of k-blocks 2 blk, 2 blk + 1
+        u32x4* dst = exch + ((((l * 2 + t) * 4 + blk) * 3) * 2) * 64 + lane;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) split3(acc[8 * s_ + 2 * d], acc[8 * s_ + 2 * d + 1], hi[d], mid[d], lo[d]);
+            dst[(0 * 2 + s_) * 64] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+            dst[(1 * 2 + s_) * 64] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+            dst[(2 * 2 + s_) * 64] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+    hand_over(0);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {                      // l = 0: g2 = (W3^T g3) * [h2 > 0];  l = 1: g1 = (W2^T g2) * [h1 > 0]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; sm[r] = 0.f; }
+        u32x4 wn[8][2];                                // (hi, mid) of the next layer; its lo pieces follow once wf's are dead
+        float4 hn[4];
+        if (l == 0) {                                  // the next layer's operands travel under this layer's products
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                wn[kb][0] = W2hm[(fb * 2) * 64]; wn[kb][1] = W2hm[(fb * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hn[q] = *reinterpret_cast<const float4*>(J.h1 + rr * EH + feat0(blk, q, h));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4* src = exch + ((l * 2 + t) * 4 * 3 * 2) * 64 + lane;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const u32x4* e = src + ((kb >> 1) * 3 * 2 + (kb & 1)) * 64;
+            kblock_x3(acc, sm, wf[kb][0], wf[kb][1], wf[kb][2], e[0], e[2 * 64], e[4 * 64]);
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) wf[kb][2] = W2lo[(blk * 8 + kb) * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += sm[r];
+        float* dst = (l == 0 ? J.g2 : J.g1) + rr * EH;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 a = hv[q];
+            acc[4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] : 0.f;
+            acc[4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] : 0.f;
+            acc[4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] : 0.f;
+            acc[4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] : 0.f;
+            if (valid) store4_stream(dst + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+        if (l == 0) {
+            hand_over(1);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = hn[q];
+        } else if (J.g_x) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1x[((t * 4 + blk) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+    }
+    // ---- g_x = W1^T g1, by one wave of the tile, in enc_bwd_dx_x3_kernel's order ----
+    if (blk == 0 && J.g_x) {
+        float gx[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) gx[c] = 0.f;
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = feat0(bp, q, h) + u;
+                    const float4 wa = W1r[2 * f], wb = W1r[2 * f + 1];
+                    const float v = g1x[((t * 4 + bp) * 16 + 4 * q + u) * 64 + lane];
+                    gx[0] = __fmaf_rn(wa.x, v, gx[0]); gx[1] = __fmaf_rn(wa.y, v, gx[1]);
+                    gx[2] = __fmaf_rn(wa.z, v, gx[2]); gx[3] = __fmaf_rn(wa.w, v, gx[3]);
+                    gx[4] = __fmaf_rn(wb.x, v, gx[4]); gx[5] = __fmaf_rn(wb.y, v, gx[5]);
+                    gx[6] = __fmaf_rn(wb.z, v, gx[6]); gx[7] = __fmaf_rn(wb.w, v, gx[7]);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) gx[c] += __shfl_xor(gx[c], 32, 64);
+        if (valid) {
+            float* o = J.g_x + row * IN + 4 * h;
+            const int left = IN - 4 * h;
+            const float s0 = h ? gx[4] : gx[0], s1 = h ? gx[5] : gx[1], s2 = h ? gx[6] : gx[2], s3 = h ? gx[7] : gx[3];
+            if (left > 0) o[0] = s0;
+            if (left > 1) o[1] = s1;
+            if (left > 2) o[2] = s2;
+            if (left > 3) o[3] = s3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // backward, part 2: dW3 = G3^T H2, dW2 = G2^T H1 (split products), dW1 = G1^T X and the bias gradients (vector pipe),
 // split-K over row slabs, one partial slot per workgroup in enc_bwd_dw_kernel's layout (same slot sum afterwards).
 // ---------------------------------------------------------------------------------------------------------
@@ -920,6 +1082,8 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
 
 int enc_x3_set_attributes() {
     auto set = [](const void* f, int bytes) { return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    if (int e = set(reinterpret_cast<const void*>(enc_bwd_dx_split_x3_kernel<false>), X3_DXS_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_bwd_dx_split_x3_kernel<true>), X3_DXS_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<0>), X3_SPLIT_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<1>), X3_SPLIT_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<2>), X3_SPLIT_LDS_BYTES)) return e;
@@ -963,6 +1127,12 @@ void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, bool drop, hipStream_t s) 
         else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false, false>), g, b, DWX_LDS_BYTES, s, B);
         else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true, false>), g, b, DWX_LDS_BYTES, s, B);
     }
+}
+
+void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s) {
+    const dim3 g((unsigned)(pairs0 + pairs1));
+    if (drop) hipLaunchKernelGGL(enc_bwd_dx_split_x3_kernel<true>, g, dim3(512), X3_DXS_LDS_BYTES, s, A, pairs0);
+    else hipLaunchKernelGGL(enc_bwd_dx_split_x3_kernel<false>, g, dim3(512), X3_DXS_LDS_BYTES, s, A, pairs0);
 }
 
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s) {

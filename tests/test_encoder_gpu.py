@@ -539,6 +539,39 @@ def test_split_tile_x3_forward_is_bitwise_the_one_wave_x3_forward(agents):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('agents,drop', [(1, False), (37, False), (122, True), (700, False), (1024, True)])
+def test_split_tile_x3_backward_is_bitwise_the_one_wave_x3_backward(agents, drop):
+    """enc_bwd_dx_split_x3_kernel (four waves per tile: the dX chain of the fine-tuning loop on real clips) against
+    enc_bwd_dx_x3_kernel: same k-block order, same six products, same masks -- every gradient is bitwise identical, with and
+    without a dropout keep-mask, with upstream gradients on the messages and on the pooled sums."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(35)
+
+    def branch(k):
+        x = torch.randn(agents, k, 6, generator=g).to(DEV).requires_grad_(True)
+        w = [(torch.randn(*d, generator=g) * 0.2).to(DEV).requires_grad_(True)
+             for d in [(128, 6), (128,), (128, 128), (128,), (128, 128), (128,)]]
+        keep = ops.pack_keep_bits(torch.rand(agents * k, 128, generator=g) >= 0.5).to(DEV) if drop else None
+        return dict(x=x, scale=4.0 if drop else 2.0, weights=w, pooled=True, keep_bits=keep)
+    brs = [branch(6), branch(10)]
+    leaves = [t for br in brs for t in (br['x'], *br['weights'])]
+    res = {}
+    old, old_products = L.piml_encoder_split_tiles(-1), L.piml_encoder_products(1)
+    try:
+        for split in (True, False):
+            L.piml_encoder_split_tiles(1 << 30 if split else 0)
+            outs = ops.fused_encoders(brs)
+            loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
+            res[split] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
+    finally:
+        L.piml_encoder_split_tiles(old)
+        L.piml_encoder_products(old_products)
+    assert len(res[True]) == len(res[False]) == 4 + 14
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('shapes', [[(4096, 6, 6), (4096, 10, 6)], [(5000, 7, 5), (33, 3, 8)]])
 def test_sign_bit_masks_equal_the_saved_activations(shapes, monkeypatch):
     """The dX chain of the split-product kernels masks with the signs of h1 / h2 read as bits (piml_encoder_branch.relu_mask,
