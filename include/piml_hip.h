@@ -583,6 +583,32 @@ int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, 
                             const float* b2, float* packed, float* out, void* stream);
 
 /*
+ * Collision head of `pinnsf_bm`, forward and backward (piml_amd/csrc/head64.hip).  Reference: src/models/model.py:1183
+ * `ped_collision_predictor = MLP(64, [64, 1])`, :1214-1215 `sigmoid(...)` on the decoder output of every pedestrian
+ * neighbour row; trained with BCE against the 1-s collision labels (src/models/simulators.py:348-355).
+ *   out[row] = sigmoid(w2 . relu(W1 x[row] + b1) + b2),   x (rows, 64), W1 (64, 64), w2 (1, 64), nn.Linear layouts.
+ * fwd: x -> out (rows), hidden (rows, 64: post-ReLU, saved for bwd; NULL for inference).
+ * bwd: g_out (rows), out, hidden, x -> g_x (rows, 64; NULL = not wanted); partials = piml_head64_slots(rows) slots of
+ *      piml_head64_partial_floats() floats of scratch; grads (same layout as one slot) = [dW1 64x64 | db1 64 | dw2 64 |
+ *      db2 1 | 3 pad].  Two launches (tiles + slot sum), no atomics.
+ */
+typedef struct piml_head64 {
+    const float* x;
+    long long rows;
+    const float *w1, *b1, *w2, *b2;
+    float* hidden;
+    float* out;
+    const float* g_out;
+    float* g_x;
+    float* partials;
+    float* grads;
+} piml_head64;
+int piml_head64_partial_floats(void);
+int piml_head64_slots(long long rows);
+int piml_head64_fwd(const piml_head64* head, void* stream);
+int piml_head64_bwd(const piml_head64* head, void* stream);
+
+/*
  * The whole non-bottleneck PINNSF network (src/models/model.py:1271-1305: both encoders, the decoder tails, the
  * desired-force epilogue and, for `pinnsf_m`, the collision head) as ONE call that forks its independent stages over
  * HIP streams and joins them again on `stream` (event fork/join: legal under stream capture, where the forks become

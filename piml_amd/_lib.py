@@ -40,6 +40,12 @@ class CollisionHead(ctypes.Structure):
     _fields_ = [('msgs', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('packed', _p), ('out', _p)]
 
 
+class Head64(ctypes.Structure):
+    """piml_head64 (include/piml_hip.h)."""
+    _fields_ = [('x', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('hidden', _p), ('out', _p),
+                ('g_out', _p), ('g_x', _p), ('partials', _p), ('grads', _p)]
+
+
 PACKED_VALID, FORK = 1, 2          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
@@ -106,6 +112,10 @@ SIGNATURES = {
     'piml_rowdecoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_collision_head_pack_floats': [],
     'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],
+    'piml_head64_partial_floats': [],
+    'piml_head64_slots': [_ll],
+    'piml_head64_fwd': [ctypes.POINTER(Head64), _p],
+    'piml_head64_bwd': [ctypes.POINTER(Head64), _p],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_pack': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),
                          _i, _p],

@@ -518,7 +518,16 @@ class _PINNSFBase(nn.Module):
             out.append(out_obs)
         if self.collision_head is not None:
             src = ped_msgs if self.collision_head == 'msgs' else decoded
-            out.append(torch.sigmoid(self.ped_collision_predictor(src)).squeeze())
+            head = self.ped_collision_predictor.mlp
+            if self.collision_head == 'decoded' and FUSED_GLUE and FUSED_ROW_DECODER and src.is_cuda \
+                    and src.dtype == torch.float32 and src.shape[-1] == 64 and len(head) == 4 \
+                    and (head[0].in_features, head[0].out_features, head[2].out_features) == (64, 64, 1) \
+                    and isinstance(head[1], nn.ReLU) and isinstance(head[3], nn.Identity) and src.numel() > 0:
+                from .. import ops       # `pinnsf_bm`: the head on hand-written kernels, forward and backward
+                pc = ops.collision_head64(src, head[0].weight, head[0].bias, head[2].weight, head[2].bias)
+                out.append(pc.unsqueeze(-1).squeeze())
+            else:
+                out.append(torch.sigmoid(self.ped_collision_predictor(src)).squeeze())
         return out
 
 

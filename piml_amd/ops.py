@@ -1960,6 +1960,72 @@ class _CollisionHead(torch.autograd.Function):
         return tuple(gr if need else None for gr, need in zip(grads, ctx.needs_input_grad))
 
 
+class _CollisionHead64(torch.autograd.Function):
+    """sigmoid(Linear(64, 1)(relu(Linear(64, 64)(x)))) per row on the f32 matrix cores, forward and backward
+    (piml_head64_fwd / bwd): the collision head of `pinnsf_bm` on the row decoder's output."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        L = _lib.lib()
+        x2 = _gpu_f32('x', x).reshape(-1, 64)
+        wb = [_gpu_f32('head weight', t.detach()) for t in (w1, b1, w2, b2)]
+        rows = x2.shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        opt = dict(device=x2.device, dtype=torch.float32)
+        out = torch.empty(rows, **opt)
+        hidden = torch.empty(rows, 64, **opt) if need_grad else None
+        H = _lib.Head64()
+        H.x, H.rows = x2.data_ptr(), rows
+        H.w1, H.b1, H.w2, H.b2 = [t.data_ptr() for t in wb]
+        H.hidden, H.out = _ptr(hidden), out.data_ptr()
+        import ctypes
+        with torch.cuda.device(x2.device):
+            _lib.check(L.piml_head64_fwd(ctypes.byref(H), _stream()), 'piml_head64_fwd')
+        if need_grad:
+            ctx.save_for_backward(x2, hidden, out, *wb)
+        ctx.x_shape = tuple(x.shape)
+        ctx.set_materialize_grads(False)
+        return out.view(x.shape[:-1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 5
+        import ctypes
+        L = _lib.lib()
+        x2, hidden, out, w1, b1, w2, b2 = ctx.saved_tensors
+        rows = x2.shape[0]
+        opt = dict(device=x2.device, dtype=torch.float32)
+        g = _gpu_f32('g_out', g).reshape(rows)
+        gx = torch.empty(rows, 64, **opt) if ctx.needs_input_grad[0] else None
+        part = L.piml_head64_partial_floats()
+        partials = torch.empty(L.piml_head64_slots(rows), part, **opt)
+        grads = torch.empty(part, **opt)
+        H = _lib.Head64()
+        H.x, H.rows = x2.data_ptr(), rows
+        H.w1, H.b1, H.w2, H.b2 = [t.data_ptr() for t in (w1, b1, w2, b2)]
+        H.hidden, H.out, H.g_out = hidden.data_ptr(), out.data_ptr(), g.data_ptr()
+        H.g_x, H.partials, H.grads = _ptr(gx), partials.data_ptr(), grads.data_ptr()
+        with torch.cuda.device(x2.device):
+            _lib.check(L.piml_head64_bwd(ctypes.byref(H), _stream()), 'piml_head64_bwd')
+        need = ctx.needs_input_grad
+        return (gx.view(ctx.x_shape) if gx is not None else None,
+                grads[:4096].view(64, 64) if need[1] else None, grads[4096:4160] if need[2] else None,
+                grads[4160:4224].view(1, 64) if need[3] else None, grads[4224:4225] if need[4] else None)
+
+
+def collision_head64(x, w1, b1, w2, b2):
+    """sigmoid(Linear(64, 1)(relu(Linear(64, 64)(x)))) for x (..., 64) -> (...,): `pinnsf_bm`'s collision head on the decoder
+    output of every neighbour row (src/models/model.py:1183, 1214-1215), forward and backward on hand-written kernels."""
+    if not x.is_cuda:
+        raise _lib.PimlHipError('collision_head64: expected GPU tensors (piml_amd has no CPU path)')
+    if x.shape[-1] != 64 or tuple(w1.shape) != (64, 64) or tuple(w2.shape) != (1, 64) or tuple(b1.shape) != (64,) \
+            or tuple(b2.shape) != (1,) or x.numel() == 0:
+        raise ValueError('collision_head64: x (..., 64), Linear(64, 64), Linear(64, 1) expected')
+    return _CollisionHead64.apply(x, w1, b1, w2, b2)
+
+
 def collision_head(msgs, w1, b1, w2, b2):
     """sigmoid(Linear(64, 1)(relu(Linear(128, 64)(msgs)))) for msgs (..., 128) -> (...,)   (model.py:1296-1300)."""
     if not msgs.is_cuda:
