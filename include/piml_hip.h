@@ -511,6 +511,9 @@ int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* 
  * branch 1): the number of partial slots each branch's `partials` must hold. */
 int piml_encoder_workgroups(const piml_encoder_branch* branches, int nbranches, int* wg_branch0);
 int piml_encoder_fwd(const piml_encoder_branch* branches, int nbranches, void* stream);
+/* the forward alone: `packed` already holds the images of these weights (piml_encoder_pack / piml_pinnsf_pack), e.g. one
+ * pack per rollout or per back-propagated window instead of one per frame */
+int piml_encoder_fwd_packed(const piml_encoder_branch* branches, int nbranches, void* stream);
 int piml_encoder_bwd(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* pooled (agents, 128) = sum over k consecutive rows of msgs (agents * k, 128) */
 int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream);
@@ -568,6 +571,7 @@ int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const f
  */
 int piml_rowdecoder_slots(long long rows);
 int piml_rowdecoder_fwd(const piml_decoder_branch* branches, int nbranches, void* stream);
+int piml_rowdecoder_fwd_packed(const piml_decoder_branch* branches, int nbranches, void* stream); /* without the pack launch */
 int piml_rowdecoder_bwd(const piml_decoder_branch* branches, int nbranches, void* stream);
 
 typedef struct piml_collision_head {

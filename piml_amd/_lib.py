@@ -100,6 +100,7 @@ SIGNATURES = {
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],
+    'piml_encoder_fwd_packed': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_bwd': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_ksum': [_p, _ll, _i, _p, _p],
     'piml_decoder_pack_floats': [],
@@ -109,6 +110,7 @@ SIGNATURES = {
     'piml_decoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p, _p, _f, _p, _p],
     'piml_rowdecoder_slots': [_ll],
     'piml_rowdecoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p],
+    'piml_rowdecoder_fwd_packed': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_rowdecoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_collision_head_pack_floats': [],
     'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],

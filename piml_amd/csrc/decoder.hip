@@ -1192,11 +1192,17 @@ static int rowdec_fill(DecArgs& A, const piml_decoder_branch* br, int nbr, bool 
     return hipSuccess;
 }
 
-PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) {
+static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, void* stream);
+PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, true, stream); }
+// `packed` already holds the operand images of these weights (piml_pinnsf_pack / an earlier piml_rowdecoder_fwd)
+PIML_API int piml_rowdecoder_fwd_packed(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, false, stream); }
+
+static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, void* stream) {
     hipStream_t s = as_stream(stream);
     DecArgs A;
     if (int e = rowdec_fill(A, br, nbr, false)) return e;
-    if (int e = dec_stage_pack(br, nbr, s)) return e;
+    if (pack)
+        if (int e = dec_stage_pack(br, nbr, s)) return e;
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
     if (tiles0 + tiles1 > kRowdecBigTiles) {       // many rows: one wave per tile, fragments in LDS (rowdec_fwd_big_kernel)
         const int split = rowdec_wg_split(br, nbr, 256);

@@ -1018,6 +1018,11 @@ PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stre
     return enc_stage_fwd(br, nbr, as_stream(stream));
 }
 
+// `packed` already holds the operand images of these weights (piml_encoder_pack / piml_pinnsf_pack)
+PIML_API int piml_encoder_fwd_packed(const piml_encoder_branch* br, int nbr, void* stream) {
+    return enc_stage_fwd(br, nbr, as_stream(stream));
+}
+
 PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream) {
     if (agents == 0) return hipSuccess;
     if (!msgs || !pooled || agents < 0 || k < 0) return hipErrorInvalidValue;

@@ -291,9 +291,10 @@ class _PINNSFBase(nn.Module):
             return {}
         from .. import ops
         specs = self._launch_specs([(p, f) for _, f, _, p in use])
+        packs = self._active_packs() if [c[0] for c in use] == [c[0] for c in cand] else None     # pack order = branch order
         res = ops.fused_encoders([dict(x=f, scale=sp[0], keep_bits=sp[1], pooled=not self.bottleneck,
                                        weights=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)])
-                                  for (_, f, e, p), sp in zip(use, specs)])
+                                  for (_, f, e, p), sp in zip(use, specs)], packs=packs)
         return {c[0]: r for c, r in zip(use, res)}
 
     @staticmethod
@@ -328,7 +329,8 @@ class _PINNSFBase(nn.Module):
         if not brs:
             return {}
         from .. import ops
-        return dict(zip(names, ops.fused_row_decoder(brs)))
+        full = ['ped'] + (['obs'] if self.obs_feature_dim > 0 else [])
+        return dict(zip(names, ops.fused_row_decoder(brs, packs=self._active_packs() if names == full else None)))
 
     def _branch(self, feats, encoder, processor, decoder, predictor, pre=None, rowdec=None, want_sum=True):
         """`pre` = (processor(encoder(feats)), its neighbour-axis sum) when the fused encoder kernel produced them;
@@ -369,7 +371,7 @@ class _PINNSFBase(nn.Module):
         from .. import ops
         fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
         head = self._fusable_head()
-        packs = self._packs if (self._packs is not None and self._packs.active) else None
+        packs = self._active_packs()
         specs = self._launch_specs([(p, f) for f, _, p, _, _ in cand])
         res = ops.fused_pinnsf(
             [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
@@ -403,8 +405,16 @@ class _PINNSFBase(nn.Module):
         return None
 
     def _pack_spec(self):
-        """Weights of the fused network in ops.pinnsf_prepack order, or None when `_fused_network` would not run."""
-        if self.bottleneck or self.residual or not FUSED_NETWORK or not FUSED_ENCODER:
+        """Weights of the fused kernels in ops.pinnsf_prepack order (pedestrian branch first), or None when the forward
+        pass would not use them: the whole network (`_fused_network`), or -- bottleneck variants -- the fused encoders +
+        row decoders."""
+        if self.residual or not FUSED_ENCODER or not FUSED_GLUE:
+            return None
+        if self.bottleneck and not FUSED_ROW_DECODER:
+            return None
+        if not self.bottleneck and not FUSED_NETWORK:
+            return None
+        if type(self).forward is not _PINNSFBase.forward:            # the polar variants post-process per row
             return None
         cand = [(self.ped_encoder, self.ped_decoder, self.ped_predictor)]
         if self.obs_feature_dim > 0:
@@ -417,7 +427,10 @@ class _PINNSFBase(nn.Module):
                 return None
             enc_w.append([t for lin in el for t in (lin.weight, lin.bias)])
             dec_w.append([t for lin in dl for t in (lin.weight, lin.bias)] + [q.mlp[0].weight, q.mlp[0].bias])
-        return enc_w, dec_w, self._fusable_head()
+        return enc_w, dec_w, (None if self.bottleneck else self._fusable_head())
+
+    def _active_packs(self):
+        return self._packs if (self._packs is not None and self._packs.active) else None
 
     @contextlib.contextmanager
     def packed_weights(self):

@@ -1374,7 +1374,7 @@ class _FusedEncoders(torch.autograd.Function):
     outputs: per branch msgs (..., k, 128), pooled (..., 128) (a 0-element tensor when not wanted)."""
 
     @staticmethod
-    def forward(ctx, nbr, scales, want_pooled, need_grad, keeps, *tensors):
+    def forward(ctx, nbr, scales, want_pooled, need_grad, keeps, packs, *tensors):
         L = _lib.lib()
         xs = [tensors[7 * b] for b in range(nbr)]
         wbs = [[_gpu_f32('encoder weight', t.detach()) for t in tensors[7 * b + 1:7 * b + 7]] for b in range(nbr)]
@@ -1391,13 +1391,22 @@ class _FusedEncoders(torch.autograd.Function):
             h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
         keeps, draws = zip(*[_resolve_keep(keeps[b], x2s[b].shape[0], ENCODER_HIDDEN, dev) for b in range(nbr)])
-        packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
+        if packs is not None:               # images packed once for many forward passes (PinnsfPacks, branch order = pack order)
+            if packs.sig_enc is None or packs.sig_enc[:nbr] != tuple(_branch_sig(wb) for wb in wbs):
+                raise ValueError('fused_encoders: `packs` were filled from other weight tensors, or the weights were modified '
+                                 'in place since (pinnsf_prepack first)')
+            packed = packs.epack
+        else:
+            packed = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)      # weights as MFMA operand fragments
         arr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], msgs[b], h1s[b], h2s[b],
                                                               packed=packed[b], keep_bits=keeps[b], draw_p=draws[b])
                                            for b in range(nbr)])
         outs = []
         with torch.cuda.device(dev):
-            _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
+            if packs is not None:
+                _lib.check(L.piml_encoder_fwd_packed(arr, nbr, _stream()), 'piml_encoder_fwd_packed')
+            else:
+                _lib.check(L.piml_encoder_fwd(arr, nbr, _stream()), 'piml_encoder_fwd')
             for b in range(nbr):
                 lead = tuple(xs[b].shape[:-2])
                 if want_pooled[b]:
@@ -1420,7 +1429,7 @@ class _FusedEncoders(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gouts):
         nbr, scales, want_pooled, ks, xshapes, need_grad = ctx.meta
-        nin = 5 + 7 * nbr
+        nin = 6 + 7 * nbr
         if not need_grad or all(g is None for g in gouts):
             return (None,) * nin
         L = _lib.lib()
@@ -1444,7 +1453,7 @@ class _FusedEncoders(torch.autograd.Function):
             gp = _gpu_f32('g_pooled', gp).reshape(-1, ENCODER_HIDDEN) if gp is not None else None
             g2 = torch.empty(R, ENCODER_HIDDEN, **opt)
             g1 = torch.empty(R, ENCODER_HIDDEN, **opt)
-            gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[5 + 7 * b] else None
+            gx = torch.empty(R, in_dim, **opt) if ctx.needs_input_grad[6 + 7 * b] else None
             keep.append((gm, gp, g2, g1, gx))
             structs.append(_enc_branch_struct(x2s[b], ks[b], scales[b], wbs[b], None, h1s[b], h2s[b], gp, gm, g2, g1, gx,
                                               packed=packed[b], keep_bits=ctx.keeps[b]))
@@ -1463,8 +1472,8 @@ class _FusedEncoders(torch.autograd.Function):
         for i, b in enumerate(live):
             flat = flats[i]
             in_dim = x2s[b].shape[1]
-            need = ctx.needs_input_grad[5 + 7 * b:5 + 7 * b + 7]
-            o = 5 + 7 * b
+            need = ctx.needs_input_grad[6 + 7 * b:6 + 7 * b + 7]
+            o = 6 + 7 * b
             if need[0]:
                 grads[o] = keep[i][4].view(xshapes[b])
             dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
@@ -1476,13 +1485,14 @@ class _FusedEncoders(torch.autograd.Function):
         return tuple(grads)
 
 
-def fused_encoders(branches):
+def fused_encoders(branches, packs=None):
     """branches: list (1 or 2 entries) of dicts {x (..., k, in<=8), scale, weights: (w1, b1, w2, b2, w3, b3) with the
     nn.Linear layouts (128, in), (128,), (128, 128), ..., pooled: bool, keep_bits: optional, the processor's
     train-mode dropout: int32 bits (rows, 4) (dropout_keep_bits layout) or ('draw', p) = the forward launch draws the mask
     itself from the device's dropout state (fold 1 / (1 - p) into `scale`; the same kind for every branch)}.
     Returns [(msgs (..., k, 128), pooled (..., 128) | None), ...]: msgs = keep * scale * encoder(x),
-    pooled = msgs.sum(-2)  (src/models/model.py:1271-1283)."""
+    pooled = msgs.sum(-2)  (src/models/model.py:1271-1283).  packs: a PinnsfPacks that pinnsf_prepack filled from these
+    very encoder weights, in this branch order (skips the pack launch)."""
     if not 1 <= len(branches) <= 2:
         raise ValueError('fused_encoders: one or two branches')
     flat = []
@@ -1502,7 +1512,7 @@ def fused_encoders(branches):
     if len({(k is None, isinstance(k, tuple)) for k in keeps}) > 1:
         raise ValueError('fused_encoders: the same kind of keep_bits (none / given bits / drawn) for every branch')
     out = _FusedEncoders.apply(len(branches), tuple(float(b['scale']) for b in branches),
-                               tuple(bool(b.get('pooled', True)) for b in branches), need_grad, keeps, *flat)
+                               tuple(bool(b.get('pooled', True)) for b in branches), need_grad, keeps, packs, *flat)
     return [(out[2 * i], out[2 * i + 1] if branches[i].get('pooled', True) else None) for i in range(len(branches))]
 
 
@@ -1531,6 +1541,7 @@ class PinnsfPacks:
     def __init__(self):
         self.epack = self.dpack = self.hpack = None
         self.sig = None          # (data pointer, version) of the packed weights
+        self.sig_enc = self.sig_dec = None       # the same per encoder / decoder branch (fused_encoders / fused_row_decoder)
         self.active = False
 
     def __deepcopy__(self, memo):          # images are derived data: a copied model packs for itself
@@ -1566,6 +1577,10 @@ def _pack_structs(enc_w, dec_w, head_w, packs):
     return earr, darr, head
 
 
+def _branch_sig(wb):
+    return tuple((t.data_ptr(), t._version) for t in wb)
+
+
 def _weights_sig(enc_w, dec_w, head_w):
     """(storage address, in-place modification count) of every packed weight: an optimizer step or load_state_dict between the
     prepack and a forward pass that uses the images changes the count and is refused (stale operand images)."""
@@ -1587,6 +1602,8 @@ def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
         _lib.check(_lib.lib().piml_pinnsf_pack(earr, darr, len(enc_w), ctypes.byref(head) if head is not None else None,
                                                0, _stream()), 'piml_pinnsf_pack')
     packs.sig = _weights_sig(enc_w, dec_w, head_w)
+    packs.sig_enc = tuple(_branch_sig(wb) for wb in enc_w)
+    packs.sig_dec = tuple(_branch_sig(wb) for wb in dec_w)
 
 
 # side streams inside piml_pinnsf_fwd / bwd: off by default (cross-stream edges cost more than they hide in a HIP graph)
@@ -1828,7 +1845,7 @@ class _FusedRowDecoder(torch.autograd.Function):
     PER = 7
 
     @staticmethod
-    def forward(ctx, nbr, *tensors):
+    def forward(ctx, nbr, packs, *tensors):
         L = _lib.lib()
         PER = _FusedRowDecoder.PER
         embs = [_gpu_f32('embedding', tensors[PER * b]) for b in range(nbr)]
@@ -1838,7 +1855,13 @@ class _FusedRowDecoder(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         e2 = [e.reshape(-1, ENCODER_HIDDEN) for e in embs]
         rows = [e.shape[0] for e in e2]
-        dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+        if packs is not None:
+            if packs.sig_dec is None or packs.sig_dec[:nbr] != tuple(_branch_sig(wb) for wb in wbs):
+                raise ValueError('fused_row_decoder: `packs` were filled from other weight tensors, or the weights were '
+                                 'modified in place since (pinnsf_prepack first)')
+            dpack = packs.dpack
+        else:
+            dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
         preds = [torch.empty(r, 2, **opt) for r in rows]
         h1 = [torch.empty(r, 64, **opt) for r in rows]
         d2 = [torch.empty(r, 64, **opt) for r in rows]
@@ -1848,7 +1871,8 @@ class _FusedRowDecoder(torch.autograd.Function):
             B.pred = preds[b].data_ptr()
             structs.append(B)
         with torch.cuda.device(dev):
-            _lib.check(L.piml_rowdecoder_fwd((_lib.DecoderBranch * nbr)(*structs), nbr, _stream()), 'piml_rowdecoder_fwd')
+            fwd = L.piml_rowdecoder_fwd_packed if packs is not None else L.piml_rowdecoder_fwd
+            _lib.check(fwd((_lib.DecoderBranch * nbr)(*structs), nbr, _stream()), 'piml_rowdecoder_fwd')
         if need_grad:
             ctx.save_for_backward(*e2, *h1, *d2, *[w for wb in wbs for w in wb], dpack)
         ctx.meta = (nbr, rows, [tuple(e.shape) for e in embs], need_grad)
@@ -1864,7 +1888,7 @@ class _FusedRowDecoder(torch.autograd.Function):
     def backward(ctx, *gs):
         nbr, rows, eshapes, need_grad = ctx.meta
         PER = _FusedRowDecoder.PER
-        grads = [None] * (1 + PER * nbr)
+        grads = [None] * (2 + PER * nbr)
         live = [b for b in range(nbr) if gs[2 * b] is not None or gs[2 * b + 1] is not None]
         if not need_grad or not live:
             return tuple(grads)
@@ -1895,7 +1919,7 @@ class _FusedRowDecoder(torch.autograd.Function):
             _lib.check(L.piml_rowdecoder_bwd((_lib.DecoderBranch * len(live))(*structs), len(live), _stream()),
                        'piml_rowdecoder_bwd')
         for i, b in enumerate(live):
-            o = 1 + PER * b
+            o = 2 + PER * b
             if ctx.needs_input_grad[o]:
                 grads[o] = gembs[i].view(eshapes[b])
             flat = flats[i]
@@ -1908,7 +1932,7 @@ class _FusedRowDecoder(torch.autograd.Function):
         return tuple(grads)
 
 
-def fused_row_decoder(branches):
+def fused_row_decoder(branches, packs=None):
     """Decoder + predictor of the bottleneck PINNSF variants applied to every neighbour ROW on the fused MFMA kernels
     (src/models/model.py:1116-1122: `ped_msgs = self.ped_predictor(self.ped_decoder(ped_embeddings))`).
     branches: 1 or 2 dicts {emb (..., 128), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b)}.
@@ -1925,7 +1949,7 @@ def fused_row_decoder(branches):
                 [tuple(t.shape) for t in p] != [(2, 64), (2,)]:
             raise ValueError('fused_row_decoder: unsupported geometry (128 -> 64 -> 64, predictor 64 -> 2)')
         flat += [e, *d, *p]
-    out = _FusedRowDecoder.apply(len(branches), *flat)
+    out = _FusedRowDecoder.apply(len(branches), packs, *flat)
     return [(out[2 * b], out[2 * b + 1]) for b in range(len(branches))]
 
 

@@ -643,3 +643,47 @@ def test_collision_head64_matches_float64(rows):
         worst = max(worst, float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)))
     print(f'collision_head64 rows={rows}: max rel err vs float64 {worst:.1e}')
     assert worst <= 1e-5          # north-star bar; measured 2e-7 .. 2e-6 (the largest for a single row: nothing averages)
+
+
+@pytest.mark.parametrize('name', ['PINNSF_bottleneck_multitask', 'PINNSF_bottleneck'])
+def test_bottleneck_variants_with_prepacked_weights_are_bitwise_neutral(name):
+    """`packed_weights()` for the bottleneck variants: ONE pack launch for the encoders' and the row decoders' operand
+    images, skipped by every forward pass inside the block (a rollout, the frames of a training window).  Same kernels on
+    the same data: bitwise equal outputs and gradients; a stale image (weights changed inside the block) is refused."""
+    import types
+    import piml_amd.models.model as MODEL
+    from piml_amd import ops
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128, processor_hidden_size=128,
+        decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16, decoder_hidden_layers=2, dropout=0.5,
+        activation='relu', dataset_name='gc1560')
+    torch.manual_seed(0)
+    net = getattr(MODEL, name)(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn(700, 6, 6, generator=g).to(DEV), torch.randn(700, 10, 6, generator=g).to(DEV), torch.randn(700, 7, generator=g).to(DEV)]
+
+    def run():
+        ins = [t.clone().requires_grad_(True) for t in base]
+        net.zero_grad(set_to_none=True)
+        out = net(*ins)
+        sum((o * 0.5).sum() for o in out).backward()
+        return [o.detach().clone() for o in out] + [t.grad.clone() for t in ins] + [p.grad.clone() for p in net.parameters() if p.grad is not None]
+    ref = run()
+    calls = []
+    real = ops.pinnsf_prepack
+    ops.pinnsf_prepack = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with net.packed_weights():
+            packed, packed2 = run(), run()
+    finally:
+        ops.pinnsf_prepack = real
+    assert calls == [1] and net._packs is not None
+    for other in (packed, packed2):
+        assert len(other) == len(ref)
+        for a, b in zip(ref, other):
+            assert torch.equal(a, b)
+    with net.packed_weights():
+        with torch.no_grad():
+            net.ped_decoder.mlp[0].weight.mul_(1.5)
+        with pytest.raises(ValueError, match='modified'):
+            net(*base)
