@@ -720,14 +720,15 @@ def main():
     x3_products = bool(_lib.lib().piml_encoder_products(-1))      # split bf16 products (default) or PIML_ENC_PRODUCTS=f32
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # 5 samples whatever --steps is.  A sample is ONE extra eager launch of the relfeat forward kernel (same inputs,
+    # One sample per ten timed steps (1 .. 5).  A sample is ONE extra eager launch of the relfeat forward kernel (same inputs,
     # same output buffers) right behind a replayed step, bracketed by two HIP events: the kernel runs behind other
     # kernels, not behind an idle gap, and the cost of the two event records (measured by an empty pair) is subtracted.
     # The events are only READ after the timed region (reading one synchronises the stream): a sample costs the timed
     # region one ~22 us launch and nothing else.
     TIMED_LAUNCHES = 1
-    n_samples = max(1, min(5, args.steps))
+    n_samples = max(1, min(5, args.steps // 10))       # one per ten steps: a sample costs the timed region one ~22 us launch (1 %)
     sample_at = {round(i * args.steps / n_samples) for i in range(n_samples)}
+    timer_pool = [(_lib.StreamTimer(), _lib.StreamTimer()) for _ in range(n_samples)] if graph is not None else []   # events are made HERE, not in the timed region
 
     def run_step(i, timed):
         if graph is not None:
@@ -741,7 +742,7 @@ def main():
             if use_dist:
                 st.exchange_backward()
             if sample:
-                tk, tc = _lib.StreamTimer(), _lib.StreamTimer()
+                tk, tc = timer_pool[len(sample_timers)]
                 tk.start()
                 st.relaunch_relfeat()
                 tk.stop()
