@@ -614,23 +614,22 @@ int piml_head64_bwd(const piml_head64* head, void* stream);
 
 /*
  * The whole non-bottleneck PINNSF network (src/models/model.py:1271-1305: both encoders, the decoder tails, the
- * desired-force epilogue and, for `pinnsf_m`, the collision head) as ONE call that forks its independent stages over
- * HIP streams and joins them again on `stream` (event fork/join: legal under stream capture, where the forks become
- * parallel branches of the graph).  Side streams are created per device on first use, outside any capture
- * (piml_pinnsf_streams_init, idempotent; the first piml_pinnsf_* call does it too).
+ * desired-force epilogue and, for `pinnsf_m`, the collision head) as ONE call per direction.  Default: the stages run in
+ * program order on `stream` -- what a captured HIP graph wants:
  *
- *   piml_pinnsf_pack   the MFMA operand images of every weight (encoder, decoder, head) -> the `packed` fields,
- *                      three small launches in a row on `stream`.  Weights that did not change since the last pack
- *                      (rollouts, evaluation) need no repack: pass PIML_PACKED_VALID to fwd.  A training step hides
- *                      the packs behind the neighbour search by calling this on a stream of its own, forked before
- *                      the features are built and joined before piml_pinnsf_fwd.  flags: reserved (0).
- *   piml_pinnsf_fwd    [decoder + head packs on a side stream | encoder pack] -> encoders -> [collision head on a side
- *                      stream | pooling -> decoder tails] -> join.  head may be NULL.
- *   piml_pinnsf_bwd    decoder dX -> [decoder dW + reduction on a side stream | encoder dX -> dW] -> join -> encoder
- *                      reduction.  Same fields as piml_decoder_bwd / piml_encoder_bwd.
- * flags: PIML_PACKED_VALID (fwd: skip the packs); PIML_FORK (use the side streams; without it the stages run in program
- * order on `stream`, which is what a captured HIP graph wants: on ROCm 7.2 every cross-stream edge of a replayed graph
- * costs more than the ~5 us stage it hides -- measured 0.247 ms/step serial vs 0.295 forked at cfg3).
+ *   piml_pinnsf_pack   ONE launch for the MFMA operand images of every weight (encoder x 2, decoder x 2, head) -> the
+ *                      `packed` fields.  Weights that did not change since the last pack (rollouts, evaluation, the frames
+ *                      of one back-propagated window) need no repack: pass PIML_PACKED_VALID to fwd.  flags: reserved (0).
+ *   piml_pinnsf_fwd    [pack unless PIML_PACKED_VALID] -> encoders (both branches, one launch; draws the dropout masks
+ *                      itself when the branches carry drop_state) -> [neighbour-axis sums + decoder tails + desired force +
+ *                      collision head] (one launch).  head may be NULL.
+ *   piml_pinnsf_bwd    [decoder dX chain + decoder dW partials] -> encoder dX -> encoder dW -> ONE slot sum for all four
+ *                      partial sets.  Same fields as piml_decoder_bwd / piml_encoder_bwd.
+ * flags: PIML_PACKED_VALID (fwd: skip the pack); PIML_FORK (opt-in: the independent stages on library-owned side streams
+ * with event fork / join -- packs and collision head beside the encoders, decoder dW beside the encoder chain.  Measured
+ * SLOWER inside captured graphs on ROCm 7.2, where every cross-stream edge of a replayed graph costs more than the ~5 us
+ * stage it hides: 0.247 ms/step serial vs 0.295 forked at cfg3, DESIGN.md.  The side streams are created per device on
+ * first use, outside any capture: piml_pinnsf_streams_init, idempotent).
  */
 #define PIML_PACKED_VALID 1
 #define PIML_FORK 2

@@ -1,7 +1,8 @@
 # -*- coding: utf-8 -*-
 """Experiment driver with the reference's command line (src/main.py:26-173): pre-train PINNSF
 pointwise, optionally fine-tune it through differentiable rollouts (-f), then roll a clip out and
-count collisions -- every pairwise operator on the MI355X (HIP), the MLP in PyTorch-ROCm.
+count collisions -- the pairwise operators AND the PINNSF networks (incl. their train-mode dropout) on this
+package's hand-written gfx950 kernels; PyTorch-ROCm is the plumbing (memory, streams, autograd, Adam).
 
     python -m piml_amd.main [--flags as in the reference]
 
@@ -68,7 +69,7 @@ def get_args(argv=None):
     A('--collision_loss_version', type=str, default='v0')
     A('--save_dir', type=str, default='', help='checkpoint directory ("" = keep weights in memory only)')
     A('--tunableop', type=int, default=0, help='1: load the pre-tuned GEMM selections (piml_amd/tuning)')
-    A('--hip_graph', type=int, default=1, help='0: run the fine-tuning step eagerly instead of replaying a captured HIP graph')
+    A('--hip_graph', type=int, default=1, help='0: run the training steps (pointwise pre-training and fine-tuning) eagerly instead of replaying captured HIP graphs')
     A('--inplace_quirk', type=int, default=1,
       help='1 (default): carry the waypoint indices / first-frame velocity history of a rollout over to the next rollout of '
            'the same clip or batch, as the reference does through its in-place views (SURVEY quirk Q12); 0: every '

@@ -585,7 +585,7 @@ class BaseSimulator(Pedestrians):
         replayed from ONE captured HIP graph.  One graph per batch geometry; the batch is copied into
         the graph's static input buffers.  Weights / Adam state touched by the warm-up iterations are
         restored before capture, so training is step-for-step the eager sequence."""
-        key = tuple((k, tuple(getattr(batch, k).shape)) for k in self._BATCH_TENSORS) + (id(self.optimizer), self.model.training)
+        key = tuple((k, tuple(getattr(batch, k).shape)) for k in self._BATCH_TENSORS) + (id(self.optimizer), self.model.training) + self._path_flags()
         entry = self._graphed_steps.get(key)
         if entry is None:
             # train mode: the processors' dropout masks are drawn on the device from a (seed, call counter) state that
@@ -638,6 +638,85 @@ class BaseSimulator(Pedestrians):
         graph.replay()
         return out, aux
 
+    @staticmethod
+    def _path_flags():
+        """The kernel-path switches a captured step depends on (a graph captured under one setting is not replayed under another)."""
+        return (MODEL.FUSED_GLUE, MODEL.FUSED_ENCODER, MODEL.FUSED_NETWORK, MODEL.FUSED_ROW_DECODER, MODEL.FUSED_KSUM_TAIL)
+
+    def _pointwise_terms(self, batch):
+        """Loss terms of a pointwise batch (simulators.py:327-356): (loss, mse, reg | None, collision_pred | None)."""
+        args = self.args
+        ped_features, obs_features, self_features, labels = batch
+        predictions = self.model(ped_features, obs_features, self_features)
+        pred, p_msg = predictions[0], predictions[1]
+        if args.pinnsf_interaction == 'sim':
+            mse_loss = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+        elif args.pinnsf_interaction == 'loss':                                        # PINN-loss pretraining
+            version = 'v2' if args.iter_flag else 'v0'
+            target = ops.calc_acceleration(ped_features, version, args.dataset_name)
+            mse_loss = F.mse_loss(p_msg, target, reduction='sum') + \
+                args.true_label_weight * F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+        else:
+            raise NotImplementedError(args.pinnsf_interaction)
+        loss, reg, cp = mse_loss, None, None
+        if args.reg_weight > 0:
+            reg = self.l1_reg_loss(p_msg, args.reg_weight, 'sum')
+            loss = loss + reg
+        if args.collision_pred_weight > 0 and args.model == 'pinnsf_bm':
+            cp = F.binary_cross_entropy(predictions[-1], labels[:, 6:], reduction='sum')
+            loss = loss + cp
+        return loss, mse_loss, reg, cp
+
+    def _graphed_pointwise_step(self, batch):
+        """One pointwise pre-training step (HOT LOOP A: zero_grad, forward, losses, backward, Adam) replayed from ONE captured
+        HIP graph per batch geometry -- eagerly the step is ~60 launches behind ~0.9 ms of Python, ctypes and autograd
+        bookkeeping, whatever the batch size.  Same protocol as `_graphed_rollout_step`: the batch is copied into static
+        buffers, weights / Adam state / dropout draw counter touched by the warm-up iterations are put back before the
+        capture, so the sequence of updates is the eager one."""
+        key = ('pointwise',) + tuple(tuple(t.shape) for t in batch) + (id(self.optimizer), self.model.training) + self._path_flags()
+        entry = self._graphed_steps.get(key)
+        if entry is None:
+            static = [t.clone() for t in batch]
+            params = [p for g in self.optimizer.param_groups for p in g['params']]
+            saved_p = [p.detach().clone() for p in params]
+            saved_s = {id(p): {k: v.clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
+                       for p in params}
+            drop_state = ops.dropout_state(static[0].device)
+            drop_calls = drop_state[1].clone()
+
+            def one_step():
+                self.optimizer.zero_grad(set_to_none=True)
+                with self._packed_weights():
+                    terms = self._pointwise_terms(static)
+                    terms[0].backward()
+                self.optimizer.step()
+                return terms
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    one_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p, sp in zip(params, saved_p):
+                    p.copy_(sp)
+                    for k, v in self.optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            v.copy_(saved_s[id(p)][k]) if k in saved_s[id(p)] else v.zero_()
+                drop_state[1].copy_(drop_calls)
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                terms = one_step()
+            entry = (graph, static, terms)
+            self._graphed_steps[key] = entry
+        graph, static, terms = entry
+        for dst, src in zip(static, batch):
+            dst.copy_(src)
+        graph.replay()
+        return terms
+
     def train_batch(self, batch_data):
         """One optimiser step on either batch type (the body of simulators.py:314-360).
         Returns the dict of scalar logs of this batch."""
@@ -663,28 +742,19 @@ class BaseSimulator(Pedestrians):
             log.update({k: float(v.detach()) for k, v in zip(names, out)})
             log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
         else:                                                                              # pointwise rows
-            ped_features, obs_features, self_features, labels = batch_data
-            predictions = self.model(ped_features, obs_features, self_features)
-            pred, p_msg = predictions[0], predictions[1]
-            if args.pinnsf_interaction == 'sim':
-                mse_loss = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
-            elif args.pinnsf_interaction == 'loss':                                        # PINN-loss pretraining
-                version = 'v2' if args.iter_flag else 'v0'
-                target = ops.calc_acceleration(ped_features, version, args.dataset_name)
-                mse_loss = F.mse_loss(p_msg, target, reduction='sum') + \
-                    args.true_label_weight * F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+            graphed = (getattr(args, 'hip_graph', True) and getattr(args, 'hip_graph_pointwise', True)
+                       and batch_data[0].is_cuda and hip_graphs_safe() and self._capturable())
+            if graphed:
+                loss, mse_loss, reg, cp = self._graphed_pointwise_step(tuple(batch_data))
             else:
-                raise NotImplementedError(args.pinnsf_interaction)
-            loss = mse_loss
-            if args.reg_weight > 0:
-                reg = self.l1_reg_loss(p_msg, args.reg_weight, 'sum')
-                loss = loss + reg
+                loss, mse_loss, reg, cp = self._pointwise_terms(batch_data)
+            if reg is not None:
                 log['reg'] = float(reg.detach())
-            if args.collision_pred_weight > 0 and args.model == 'pinnsf_bm':
-                cp = F.binary_cross_entropy(predictions[-1], labels[:, 6:], reduction='sum')
-                loss = loss + cp
+            if cp is not None:
                 log['collision_pred'] = float(cp.detach())
-            log.update(loss=float(loss.detach()), mse=float(mse_loss.detach()), n=int(labels.shape[0]))
+            log.update(loss=float(loss.detach()), mse=float(mse_loss.detach()), n=int(batch_data[3].shape[0]))
+            if graphed:
+                return log
         loss.backward()
         self.optimizer.step()
         return log

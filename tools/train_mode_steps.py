@@ -72,7 +72,7 @@ def main():
                 batch = (torch.randn(rows, 6, 6, generator=gen).to(DEV), torch.randn(rows, 10, 6, generator=gen).to(DEV),
                          torch.randn(rows, 7, generator=gen).to(DEV), torch.rand(rows, 12, generator=gen).to(DEV))
                 ms = timeit(lambda: sim.train_batch(batch), reps)
-                print(f'{tag}: pointwise pre-training step, {rows} rows: {ms:.3f} ms/step (eager)', flush=True)
+                print(f'{tag}: pointwise pre-training step, {rows} rows: {ms:.3f} ms/step (one captured graph)', flush=True)
             # ---- HOT LOOP C: fine-tuning step, the golden GC batch (4 windows x 5 frames x 122 agents) and 8 x its agents ----
             data = load_data(g, 'train_' + ('pinnsf_m' if model == 'pinnsf_m' else 'pinnsf_bm'))
             for times in (1, 8):
