@@ -742,8 +742,10 @@ class BaseSimulator(Pedestrians):
             log.update({k: float(v.detach()) for k, v in zip(names, out)})
             log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
         else:                                                                              # pointwise rows
+            # (only with the hand-written kernels: capturing the library-GEMM path here segfaulted in hipStreamEndCapture
+            # when an earlier capture of the process had used other GEMM selections -- that path stays eager, as before)
             graphed = (getattr(args, 'hip_graph', True) and getattr(args, 'hip_graph_pointwise', True)
-                       and batch_data[0].is_cuda and hip_graphs_safe() and self._capturable())
+                       and batch_data[0].is_cuda and hip_graphs_safe() and self._capturable() and all(self._path_flags()))
             if graphed:
                 loss, mse_loss, reg, cp = self._graphed_pointwise_step(tuple(batch_data))
             else:
