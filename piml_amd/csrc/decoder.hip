@@ -9,6 +9,8 @@
 // accumulators chained as the next layer's B operand, weights pre-packed as A-fragments (here read straight from
 // the packed global image: a wave owns one 32-agent tile and uses every fragment once, so LDS staging buys nothing).
 // One workgroup = one 32-agent tile, wave 0 = pedestrian branch, wave 1 = obstacle branch, combined through LDS.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "pack.hpp"
 #include "stages.hpp"
@@ -300,14 +302,16 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<
 // the complete, masked g_pre1 (32 MFMAs).
 // ROWS: per-neighbour-row use (see dec_fwd_body): one 4-wave workgroup per (tile, branch), g_pred per row from
 // J.g_pred_rows, optional extra gradient J.g_d2 on the decoder output, no desired-force part.
-template <bool ROWS = false>
+// SPLIT (round 3): the agent-level chain with one 4-wave workgroup per (tile, branch) like the forward's SPLIT form --
+// the 8-wave form runs 128 workgroups at the 4096-agent scene, half the CUs.
+template <bool ROWS = false, bool SPLIT = false>
 __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile, int rows_branch = 0) {
-    constexpr int NB = ROWS ? 1 : 2;
+    constexpr int NB = (ROWS || SPLIT) ? 1 : 2;
     __shared__ float part[NB][2][2][16][64];       // [branch][ob][kh][register][lane]
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
     const int j = lane & 31, h = lane >> 5;
-    const int b = ROWS ? rows_branch : wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
-    const int bi = ROWS ? 0 : b;
+    const int b = (ROWS || SPLIT) ? rows_branch : wave >> 2, ob = (wave >> 1) & 1, kh = wave & 1, blk = wave & 3;
+    const int bi = (ROWS || SPLIT) ? 0 : b;
     const bool active = b < A.nbr;
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long agent = tile * 32 + j;
@@ -326,7 +330,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
 #pragma unroll
             for (int q = 0; q < 4; ++q) gd2[q] = *reinterpret_cast<const float4*>(J.g_d2 + (valid ? agent : 0) * DD + dfeat0(kh, q, h));
         }
-        if (!ROWS && wave == 0 && A.g_self && A.self_features) {        // wave-uniform: the desired-force gradient's inputs
+        if (!ROWS && wave == 0 && b == 0 && A.g_self && A.self_features) {        // wave-uniform: the desired-force gradient's inputs
             const float* sp = A.self_features + (valid ? agent : 0) * 7;
             sfv[0] = sp[0]; sfv[1] = sp[1]; sfv[4] = sp[6];
         }
@@ -420,7 +424,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
     }
     }
     // desired-force backward (pinnsf_epilogue_bwd_kernel's arithmetic), one lane per agent
-    if (!ROWS && wave == 0 && h == 0 && valid && A.g_self && A.self_features) {
+    if (!ROWS && wave == 0 && b == 0 && h == 0 && valid && A.g_self && A.self_features) {
         const float dx = sfv[0], dy = sfv[1], v0 = sfv[4], tau = A.tau;
         const float n = norm2(dx, dy);
         const float t = (n == 0.f) ? n + 0.1f : n;
@@ -503,6 +507,77 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
         if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;           // waves 0 and 2
         if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
     }
+}
+
+// The same partials by FOUR waves (the (tile, branch) workgroups of dec_bwd_split_kernel): wave w owns blocks (0, w) and
+// (1, w) of dW1 (they share the pooled-column operand), block (w >> 1, w & 1) of dW2, waves 0 / 1 column block w of dW3.
+__device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p, int w, int lane) {
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const long long R = J.agents;
+    const long long s0 = (long long)p * DEC_SLAB < R ? (long long)p * DEC_SLAB : R;
+    const long long s1e = s0 + DEC_SLAB < R ? s0 + DEC_SLAB : R;
+    const int i = lane & 31, h = lane >> 5;
+    const int mb2 = w >> 1, nb2 = w & 1;
+    const bool do3 = w < 2;
+    f32x16 c1a, c1b, c2, c3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c1a[r] = 0.f; c1b[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
+    float s1a = 0.f, s1b = 0.f, s2 = 0.f, s3 = 0.f;
+    constexpr int U = DEC_SLAB / 2;
+    float a1a[U], a1b[U], b1[U], a2[U], b2[U], a3[U], b3[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                 // every load of the slab is issued before its first MFMA
+        const long long row = s0 + 2 * u + h;
+        const bool ok = row < s1e;
+        const long long ro = ok ? row : (s0 < R ? s0 : 0);
+        a1a[u] = J.g_pre1[ro * DD + i];
+        a1b[u] = J.g_pre1[ro * DD + 32 + i];
+        b1[u] = J.pooled[ro * DH + 32 * w + i];
+        a2[u] = J.g_pre2[ro * DD + 32 * mb2 + i];
+        b2[u] = J.h1[ro * DD + 32 * nb2 + i];
+        a3[u] = (do3 && i < 2) ? A.g_pred[ro * 2 + i] : 0.f;
+        b3[u] = do3 ? J.d2[ro * DD + 32 * nb2 + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool ok = s0 + 2 * u + h < s1e;
+        const float xa = ok ? a1a[u] : 0.f, xb = ok ? a1b[u] : 0.f, x2 = ok ? a2[u] : 0.f, x3 = ok ? a3[u] : 0.f;
+        c1a = dmfma(xa, b1[u], c1a);
+        c1b = dmfma(xb, b1[u], c1b);
+        c2 = dmfma(x2, b2[u], c2);
+        if (do3) c3 = dmfma(x3, b3[u], c3);
+        s1a += xa; s1b += xb; s2 += x2; s3 += x3;
+    }
+    float* P = J.partials + (size_t)p * DEC_PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+        P[(size_t)ri * DH + 32 * w + i] = c1a[r];
+        P[(size_t)(32 + ri) * DH + 32 * w + i] = c1b[r];
+        P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = c2[r];
+        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = c3[r];
+    }
+    s1a += __shfl_xor(s1a, 32, 64);
+    s1b += __shfl_xor(s1b, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s3 += __shfl_xor(s3, 32, 64);
+    float* Pb = P + DD * DH + DD * DD + 2 * DD;
+    if (h == 0) {
+        if (w == 0) { Pb[i] = s1a; Pb[32 + i] = s1b; }
+        if (nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;                  // waves 0 and 2
+        if (w == 0 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
+    }
+}
+
+// dX chain + weight-gradient partials per (32-agent tile, branch): 2 x tiles workgroups of four waves
+__global__ __launch_bounds__(256) void dec_bwd_split_kernel(DecArgs A) {
+    const int bx = blockIdx.x;
+    const int b = A.nbr > 1 ? (bx & 1) : 0;
+    const long long tile = A.nbr > 1 ? (bx >> 1) : bx;
+    dec_bwd_dx_body<false, true>(A, tile, b);
+    __threadfence_block();
+    __syncthreads();
+    dec_bwd_dw_body4(A, b, (int)tile, uniform((int)(threadIdx.x >> 6)), threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
@@ -1102,7 +1177,9 @@ int piml::dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const floa
     A.g_self = g_self;
     static_assert(DEC_SLAB == 32, "the dW slab of a workgroup is its dX tile");
     const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
-    hipLaunchKernelGGL(dec_bwd_kernel, dim3(tiles), dim3(512), 0, s, A);
+    static const bool whole = getenv("PIML_DEC_BWD_SPLIT") && atoi(getenv("PIML_DEC_BWD_SPLIT")) == 0;     // A/B: the 8-wave form
+    if (whole) hipLaunchKernelGGL(dec_bwd_kernel, dim3(tiles), dim3(512), 0, s, A);
+    else hipLaunchKernelGGL(dec_bwd_split_kernel, dim3(tiles * (unsigned)nbr), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 
