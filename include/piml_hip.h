@@ -458,6 +458,10 @@ int piml_probe_arith(const float* rx, const float* ry, const float* hx, const fl
  *
  * fwd:  x (rows, in_dim <= 8) -> msgs (rows, 128); h1 / h2 (rows, 128): post-ReLU activations of layers 1 / 2,
  *       saved for the backward (NULL for inference).  pooled comes from piml_encoder_ksum.
+ *       h1 may be NULL in forward AND backward (every branch) when the backward does without it: relu_mask given, split
+ *       products, more than piml_encoder_split_tiles() tiles (the dX chain then masks with the sign bits), layer-split
+ *       weight gradients (piml_encoder_dw2, which recompute h1 from x on the matrix cores) and at least two workgroups per
+ *       branch (piml_encoder_workgroups) -- 33 MB less to write and 33 MB less to read at the 4096-agent scene.
  * bwd:  upstream g_pooled (rows / k, 128) and / or g_msgs (rows, 128) (one may be NULL)
  *       -> g2, g1 (rows, 128): caller-provided scratch, the gradients at the pre-activations of layers 2 and 1;
  *          g_x (rows, in_dim) or NULL when the inputs need no gradient;
@@ -505,6 +509,11 @@ long long piml_encoder_split_tiles(long long tiles);
  * rounding of the product); 0: the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32).  Environment at load time:
  * PIML_ENC_PRODUCTS=f32.  Returns the previous value; < 0 only queries. */
 int piml_encoder_products(int split_bf16);
+/* Weight gradients of the split-product backward above piml_encoder_split_tiles() tiles: 1 (default) = layer-split
+ * workgroups (piml_amd/csrc/encoder_dw2.hip: a workgroup takes ONE of the two 128 x 128 products over a longer slab --
+ * half the partial bytes -- and recomputes h1 from x when the branches carry none), 0 = one slab and both products per
+ * workgroup (enc_bwd_dw_x3_kernel).  Environment at load time: PIML_ENC_DW2=0.  Returns the previous value; < 0 queries. */
+int piml_encoder_dw2(int layer_split);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve

@@ -758,6 +758,19 @@ __global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes) {
     sum_slots_16x16(J.partials, J.grads, B, lanes);
 }
 
+// the same for layer-split slots (encoder_dw2.hip): blockIdx.y = 2 * branch + layer
+struct Reduce2Args { piml_encoder_branch br[2]; int n0[2], n1[2]; };
+__global__ __launch_bounds__(256) void enc_reduce2_kernel(Reduce2Args A) {
+    const int b = blockIdx.y >> 1, L = blockIdx.y & 1;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    if (L == 0) {
+        if ((int)blockIdx.x * 16 < DW2_L0_LANES) sum_slots_16x16(J.partials, J.grads, A.n0[b], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1);
+    } else {
+        if ((int)blockIdx.x * 16 < DW2_L1_LANES)
+            sum_slots_16x16(J.partials + (size_t)A.n0[b] * (DW2_L0_LANES * 4), J.grads, A.n1[b], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
+    }
+}
+
 static int split_workgroups(const piml_encoder_branch* br, int nbr, int total, long long unit) {
     // workgroups for branch 0, proportional to the rows (each branch gets at least one)
     if (nbr < 2) return total;
@@ -812,15 +825,8 @@ static int enc_check(const piml_encoder_branch* br, int nbr) {
     return hipSuccess;
 }
 
-static int enc_bwd_check(const piml_encoder_branch* br, int nbr) {
-    if (int e = enc_check(br, nbr)) return e;
-    for (int i = 0; i < nbr; ++i) {
-        const piml_encoder_branch& b = br[i];
-        if (!b.h1 || !b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 || (!b.g_pooled && !b.g_msgs))
-            return hipErrorInvalidValue;
-    }
-    return hipSuccess;
-}
+static int enc_bwd_check(const piml_encoder_branch* br, int nbr);
+
 
 // dynamic LDS above 64 KB has to be enabled per kernel once per process
 static int enc_set_lds(const void* f, int bytes) {
@@ -866,6 +872,24 @@ PIML_API int piml_encoder_products(int x3) {
 
 // PIML_ENC_DX_SPLIT=f32: the few-rows dX chain on the f32 matrix instruction even with split products elsewhere (A/B)
 static const bool g_dx_split_f32 = getenv("PIML_ENC_DX_SPLIT") && getenv("PIML_ENC_DX_SPLIT")[0] == 'f';
+
+// h1 may be absent (all branches) exactly when the backward runs without it: the dX chain on sign bits (relu_mask, more than
+// piml_encoder_split_tiles() tiles, split products) and the weight gradients on the layer-split kernel, which recomputes it
+static int enc_bwd_check(const piml_encoder_branch* br, int nbr) {
+    if (int e = enc_check(br, nbr)) return e;
+    bool no_h1 = false;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if (!b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 || (!b.g_pooled && !b.g_msgs)) return hipErrorInvalidValue;
+        no_h1 = no_h1 || !b.h1;
+    }
+    if (no_h1) {
+        for (int i = 0; i < nbr; ++i)
+            if (br[i].h1 || !br[i].relu_mask) return hipErrorInvalidValue;
+        if (!enc_dw2_used(br, nbr, nullptr, nullptr)) return hipErrorInvalidValue;
+    }
+    return hipSuccess;
+}
 
 static int x3_ready() {
     static int state = -1;
@@ -962,10 +986,62 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     return hipGetLastError();
 }
 
+// Layer-split weight gradients (encoder_dw2.hip): split products, the one-wave path (more than piml_encoder_split_tiles()
+// tiles), both branches with the same kinds of upstream gradients / keep bits / h1, at least two workgroups per branch.
+// PIML_ENC_DW2=0 keeps enc_bwd_dw_x3_kernel (A/B).
+// PIML_ENC_DW_WIDE=0: the slab weight-gradient kernel with per-feature dword staging loads (enc_bwd_dw_x3_kernel) instead
+// of the wide-load form (encoder_dww.hip); same sums, A/B switch
+static const bool g_dw_wide = !(getenv("PIML_ENC_DW_WIDE") && atoi(getenv("PIML_ENC_DW_WIDE")) == 0);
+static int g_dw2 = getenv("PIML_ENC_DW2") && atoi(getenv("PIML_ENC_DW2")) != 0;
+
+PIML_API int piml_encoder_dw2(int on) {
+    const int old = g_dw2;
+    if (on >= 0) g_dw2 = on ? 1 : 0;
+    return old;
+}
+
+bool piml::enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1) {
+    if (!g_dw2 || !g_x3 || !br || nbr < 1 || nbr > 2) return false;
+    long long tiles = 0;
+    for (int i = 0; i < nbr; ++i) {
+        tiles += (br[i].rows + 31) / 32;
+        if ((br[i].keep_bits != nullptr) != (br[0].keep_bits != nullptr) || (br[i].h1 != nullptr) != (br[0].h1 != nullptr)) return false;
+    }
+    if (tiles <= g_split_tiles) return false;
+    const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
+    const int w[2] = {w0, total - w0};
+    for (int i = 0; i < nbr; ++i) {
+        if (w[i] < 2) return false;
+        int a, c;
+        enc_dw2_split(w[i], &a, &c);
+        if (n0) n0[i] = a;
+        if (n1) n1[i] = c;
+    }
+    return true;
+}
+
 int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s) {
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     const int total = fill_args(A, br, nbr);
+    if (enc_dw2_used(br, nbr, nullptr, nullptr)) {
+        static int ready = -1;
+        if (ready < 0) ready = enc_dw2_set_attributes();
+        if (ready) return ready;
+        // the kernel variant (which upstream gradients exist) is per launch: branches that disagree are launched separately,
+        // each on its own workgroups and slots
+        if (nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) && (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr))) {
+            enc_dw2_launch(A, total, s);
+        } else {
+            for (int i = 0; i < 2; ++i) {
+                EncArgs B = A;
+                B.nbr = 1;
+                B.br[0] = B.br[1] = A.br[i];
+                enc_dw2_launch(B, i == 0 ? A.wg_split : total - A.wg_split, s);
+            }
+        }
+        return hipGetLastError();
+    }
     static bool attr_set = false;
     if (!attr_set) {
         const void* dw[3] = {reinterpret_cast<const void*>(enc_bwd_dw_kernel<true, true>),
@@ -977,7 +1053,13 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
     }
     if (g_x3)
         if (int e = x3_ready()) return e;
+    if (g_x3 && g_dw_wide) {
+        static int wide_ready = -1;
+        if (wide_ready < 0) wide_ready = enc_dww_set_attributes();
+        if (wide_ready) return wide_ready;
+    }
     auto launch_dw = [&](const EncArgs& B, int grid) {
+        if (g_x3 && g_dw_wide) return enc_dww_launch(B, grid, B.br[0].keep_bits != nullptr, s);
         if (g_x3) return enc_x3_launch_bwd_dw(B, grid, B.br[0].keep_bits != nullptr, s);
         const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
         if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
@@ -1005,6 +1087,12 @@ int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     fill_args(A, br, nbr);
+    Reduce2Args R2 = {};
+    if (enc_dw2_used(br, nbr, R2.n0, R2.n1)) {
+        for (int i = 0; i < nbr; ++i) R2.br[i] = br[i];
+        hipLaunchKernelGGL(enc_reduce2_kernel, dim3((DW2_L1_LANES + 15) / 16, 2 * nbr), dim3(256), 0, s, R2);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, ENC_PART / 4);
     return hipGetLastError();
 }

@@ -65,4 +65,11 @@ void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool d
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
 void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, bool drop, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
 
+// encoder_dw2.hip: the weight gradients as layer-split workgroups (half the partial bytes, h1 recomputed when absent)
+int enc_dww_set_attributes();                                                          // encoder_dww.hip: the same slabs, wide staging loads
+void enc_dww_launch(const EncArgs& A, int grid, bool drop, hipStream_t s);
+int enc_dw2_set_attributes();
+void enc_dw2_split(int w, int* n0, int* n1);          // a branch's w workgroups -> layer-0 / layer-1 workgroups
+void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s);
+
 }  // namespace piml

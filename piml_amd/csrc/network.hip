@@ -100,18 +100,21 @@ __global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) {
     }
 }
 
-// ---- one launch for every slot sum of the backward pass: blockIdx.y = encoder branches, then decoder branches ----
+// ---- one launch for every slot sum of the backward pass: blockIdx.y = a set of slots (encoder branches -- one set each, or
+// two with the layer-split slots of encoder_dw2.hip -- then the decoder branches) ----
+struct ReduceSet {
+    const float* parts;
+    float* grads;
+    int slots, lanes, split, off0, off1;       // float4 geometry: sum_slots_16x16 (pack.hpp)
+};
 struct ReduceAll {
-    const float* parts[4];
-    float* grads[4];
-    int slots[4];
-    int nbr;
+    ReduceSet set[6];
+    int nsets;
 };
 
 __global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) {
-    const int y = blockIdx.y;
-    const int lanes = y < A.nbr ? ENC_PART / 4 : DEC_PART / 4;
-    if ((int)blockIdx.x * 16 < lanes) sum_slots_16x16(A.parts[y], A.grads[y], A.slots[y], lanes);
+    const ReduceSet S = A.set[blockIdx.y];
+    if ((int)blockIdx.x * 16 < S.lanes) sum_slots_16x16(S.parts, S.grads, S.slots, S.lanes, S.split, S.off0, S.off1);
 }
 
 }  // namespace piml
@@ -156,20 +159,26 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
 static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s) {
     ReduceAll R = {};
-    R.nbr = nbr;
-    int w0 = 0;
+    int w0 = 0, n = 0, maxl = 0;
     const int total = piml_encoder_workgroups(enc, nbr, &w0);
     const int dslots = piml_decoder_workgroups(dec[0].agents);
+    int n0[2] = {0, 0}, n1[2] = {0, 0};
+    const bool dw2 = enc_dw2_used(enc, nbr, n0, n1);
+    auto add = [&](const float* parts, float* grads, int slots, int lanes, int split, int off0, int off1) {
+        R.set[n++] = ReduceSet{parts, grads, slots, lanes, split, off0, off1};
+        if (lanes > maxl) maxl = lanes;
+    };
     for (int i = 0; i < nbr; ++i) {
-        R.parts[i] = enc[i].partials;
-        R.grads[i] = enc[i].grads;
-        R.slots[i] = nbr == 1 ? total : (i == 0 ? w0 : total - w0);
-        R.parts[nbr + i] = dec[i].partials;
-        R.grads[nbr + i] = dec[i].grads;
-        R.slots[nbr + i] = dslots;
+        if (dw2) {
+            add(enc[i].partials, enc[i].grads, n0[i], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1);
+            add(enc[i].partials + (size_t)n0[i] * (DW2_L0_LANES * 4), enc[i].grads, n1[i], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
+        } else {
+            add(enc[i].partials, enc[i].grads, nbr == 1 ? total : (i == 0 ? w0 : total - w0), ENC_PART / 4, 0x7fffffff, 0, 0);
+        }
     }
-    constexpr int ge = (ENC_PART / 4 + 15) / 16, gd = (DEC_PART / 4 + 15) / 16;
-    hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3(ge > gd ? ge : gd, 2 * nbr), dim3(256), 0, s, R);
+    for (int i = 0; i < nbr; ++i) add(dec[i].partials, dec[i].grads, dslots, DEC_PART / 4, 0x7fffffff, 0, 0);
+    R.nsets = n;
+    hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3((maxl + 15) / 16, n), dim3(256), 0, s, R);
     return hipGetLastError();
 }
 

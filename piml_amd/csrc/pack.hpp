@@ -161,7 +161,10 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
 // ---- sums over per-workgroup partial slots (fixed order: deterministic), one block of 256 threads per column group ----
 // 16 float4 columns x 16 slot groups per block (wide grid); a thread's slots are fetched eight at a time, all loads
 // (clamped, unconditional) issued before the first add: the sums are latency-bound, not bandwidth-bound
-__device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes) {
+// Target of float4 column j: off0 + j for j < split, off1 + (j - split) behind it (a slot whose fields land in two places of
+// the gradient buffer: the layer-split slots of encoder_dw2.hip); the plain form is split = lanes, off0 = 0.
+__device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes,
+                                                int split = 0x7fffffff, int off0 = 0, int off1 = 0) {
     __shared__ float4 sh[256];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + col;
@@ -189,8 +192,13 @@ __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partia
             const float4 v = sh[q * 16 + col];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        reinterpret_cast<float4*>(grads)[j] = s;
+        reinterpret_cast<float4*>(grads)[j < split ? off0 + j : off1 + (j - split)] = s;
     }
 }
+
+// layer-split encoder slots (encoder_dw2.hip): float4 geometry of the two slot kinds inside a full ENC_PART gradient buffer
+constexpr int DW2_L0_LANES = (EH * EH + EH) / 4, DW2_L0_SPLIT = EH * EH / 4, DW2_L0_OFF1 = (2 * EH * EH + 1024) / 4;
+constexpr int DW2_L1_LANES = (EH * EH + 1024 + 2 * EH) / 4, DW2_L1_SPLIT = (EH * EH + 1024) / 4, DW2_L1_OFF0 = EH * EH / 4,
+              DW2_L1_OFF1 = (2 * EH * EH + 1024 + EH) / 4;
 
 }  // namespace piml

@@ -1364,6 +1364,29 @@ def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, 
     return B
 
 
+H1_RECOMPUTE = _os.environ.get('PIML_H1_RECOMPUTE', '1') != '0'      # do not store h1 where the backward can do without (below)
+
+
+def _h1_needed(rows_per_branch):
+    """False when the backward of these branches runs without h1 (include/piml_hip.h, piml_encoder_branch): sign bits for
+    the dX chain + layer-split weight gradients that recompute it from x.  The forward then does not store it."""
+    if not (H1_RECOMPUTE and RELU_MASK):
+        return True
+    import ctypes
+    L = _lib.lib()
+    # every branch on its own above the bound: the backward may run on a subset of them (branches without upstream gradient)
+    tiles = min((r + 31) // 32 for r in rows_per_branch)
+    if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1 and tiles > L.piml_encoder_split_tiles(-1)):
+        return True
+    arr = (_lib.EncoderBranch * len(rows_per_branch))()
+    for b, r in enumerate(rows_per_branch):
+        arr[b].rows = r
+    w0 = ctypes.c_int(0)
+    total = L.piml_encoder_workgroups(arr, len(rows_per_branch), ctypes.byref(w0))
+    w = [total] if len(rows_per_branch) == 1 else [w0.value, total - w0.value]
+    return min(w) < 2
+
+
 def _h2_buffer(R, opt):
     """h2 (R, 128) with room behind it for piml_encoder_branch.relu_mask (256 dwords per 32-row tile)."""
     return torch.empty(R + 2 * ((R + 31) // 32), ENCODER_HIDDEN, **opt)
@@ -1388,8 +1411,10 @@ class _FusedEncoders(torch.autograd.Function):
             x2s.append(x2)
             ks.append(x.shape[-2])
             msgs.append(torch.empty(R, ENCODER_HIDDEN, **opt))
-            h1s.append(torch.empty(R, ENCODER_HIDDEN, **opt) if need_grad else None)
+            h1s.append(None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
+        if need_grad and _h1_needed([x2.shape[0] for x2 in x2s]):
+            h1s = [torch.empty(x2.shape[0], ENCODER_HIDDEN, **opt) for x2 in x2s]
         keeps, draws = zip(*[_resolve_keep(keeps[b], x2s[b].shape[0], ENCODER_HIDDEN, dev) for b in range(nbr)])
         if packs is not None:               # images packed once for many forward passes (PinnsfPacks, branch order = pack order)
             if packs.sig_enc is None or packs.sig_enc[:nbr] != tuple(_branch_sig(wb) for wb in wbs):
@@ -1418,8 +1443,7 @@ class _FusedEncoders(torch.autograd.Function):
                 else:
                     pooled = torch.empty(0, **opt)
                 outs += [msgs[b].view(*lead, ks[b], ENCODER_HIDDEN), pooled]
-        ctx.save_for_backward(*x2s, *[t for t in h1s if t is not None], *[t for t in h2s if t is not None],
-                              *[w for wb in wbs for w in wb], packed)
+        ctx.save_for_backward(*x2s, *h1s, *h2s, *[w for wb in wbs for w in wb], packed)
         ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
         ctx.keeps = keeps
         ctx.set_materialize_grads(False)
@@ -1646,8 +1670,10 @@ class _FusedPinnsf(torch.autograd.Function):
             ks.append(x.shape[-2])
             R = x2s[b].shape[0]
             msgs.append(torch.empty(R, H, **opt))
-            h1s.append(torch.empty(R, H, **opt) if need_grad else None)
+            h1s.append(None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
+        if need_grad and _h1_needed([x2.shape[0] for x2 in x2s]):
+            h1s = [torch.empty(x2.shape[0], H, **opt) for x2 in x2s]
         flags = _lib.FORK if FORK_NETWORK else 0
         if packs is not None:
             if packs.sig != _weights_sig(ewb, dwb, hwb):
