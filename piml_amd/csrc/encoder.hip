@@ -992,7 +992,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
 // PIML_ENC_DW_WIDE=0: the slab weight-gradient kernel with per-feature dword staging loads (enc_bwd_dw_x3_kernel) instead
 // of the wide-load form (encoder_dww.hip); same sums, A/B switch
 static const bool g_dw_wide = !(getenv("PIML_ENC_DW_WIDE") && atoi(getenv("PIML_ENC_DW_WIDE")) == 0);
-static int g_dw2 = getenv("PIML_ENC_DW2") && atoi(getenv("PIML_ENC_DW2")) != 0;
+static int g_dw2 = !(getenv("PIML_ENC_DW2") && atoi(getenv("PIML_ENC_DW2")) == 0);
 
 PIML_API int piml_encoder_dw2(int on) {
     const int old = g_dw2;

@@ -1,23 +1,30 @@
-// Weight gradients of the PINNSF encoder on split bf16 products, LAYER-SPLIT decomposition (round 3).
+// Weight gradients of the PINNSF encoder on split bf16 products: LAYER-SPLIT workgroups, PRODUCER / CONSUMER waves (round 3).
 //
 // Reference arithmetic: the autograd of MLP(in, [128, 128, 128]) (src/models/model.py:40-65) under the processor
 // Dropout_p(2 x) and the neighbour-axis sum (:82-119, :1279-1283):
 //     dW3 = G3^T H2, db3 = colsum G3        G3 = keep * scale * (g_pooled[row / k] + g_msgs[row])
 //     dW2 = G2^T H1, db2 = colsum G2        H1 = relu(W1 x + b1)
 //     dW1 = G1^T X,  db1 = colsum G1
-// enc_bwd_dw_x3_kernel (encoder_x3.hip) gives every workgroup a row slab and BOTH 128 x 128 products: 128 accumulator
-// registers per wave, four operand arrays staged per batch, one partial slot of 34 k floats per workgroup (35 MB written and
-// read back at the 4096-agent scene), and h1 read from memory (33 MB that the forward only stores for this kernel: the
-// dX chain masks with sign bits).  Here a workgroup takes ONE layer of a longer slab:
-//     L = 0:  dW3, db3                  stages G3 (built from g_pooled / g_msgs / keep bits) and H2 (loaded)
-//     L = 1:  dW2, db2, dW1, db1        stages G2 (loaded) and H1 -- RECOMPUTED from x when the branch carries no h1
-// -> 64 accumulator registers per wave (wave w: output blocks (w >> 1, 2 (w & 1) + {0, 1})), two staged arrays, half the
-// partial bytes, no h1 traffic at all.  A batch is 32 rows = two k-blocks.  Fragment layout as in encoder_x3.hip (lane
-// (f & 31) + 32 hh of feature block f >> 5 holds 8 bf16 = 8 rows), but the rows of a k-block are taken in the order of a
-// 32 x 32 accumulator's registers -- element t of lane half hh = row 16 kb + 4 hh + (t & 3) + 8 (t >> 2) -- on BOTH operand
-// sides, because that is the layout in which the recomputed H1 arrives: the H-side wave of feature block blk runs
-// relu(W1 x + b1) for the batch's 32 rows as four f32 matrix instructions in the TRANSPOSED orientation (A = rows of x,
-// B = W1's fragments), result lane (n, h), register r = row (r & 3) + 8 (r >> 2) + 4 h of feature 32 blk + n.
+// The slab kernels (enc_bwd_dw_x3_kernel, enc_bwd_dw_x3w_kernel) give every workgroup BOTH 128 x 128 products and let every
+// wave do everything in turn -- load, split into bf16 pieces, write to LDS, barrier, products -- so the phases of a batch
+// add up (s_memtime: ~5 000 cycles per 16 rows, of which the matrix pipe works 1 500), whatever the instruction scheduling.
+// Here
+//   * a workgroup takes ONE layer of a longer slab (L = 0: dW3, db3 from G3 | H2;  L = 1: dW2, db2, dW1, db1 from G2 | H1):
+//     64 KB partial slots instead of 136 KB, two staged arrays, 16 output blocks;
+//   * waves 0-3 are CONSUMERS: wave (iq, jq) owns the output blocks {2 iq, 2 iq + 1} x {2 jq, 2 jq + 1} (128 accumulator
+//     registers), reads operand fragments from LDS and issues the 48 products of a 32-row batch -- and, on L = 1, the
+//     dW1 / db1 sums on the otherwise idle vector pipe;
+//   * waves 4-7 are PRODUCERS: wave (array, row half) loads four consecutive features of eight rows per lane with 16-byte
+//     loads (two batches ahead), builds G3 where that is its array, splits, and writes half fragment entries (ds_write_b64)
+//     into the other LDS buffer.  One barrier per batch; a SIMD hosts one wave of each kind, so the matrix pipe and the
+//     vector pipe of a SIMD work at the same time by construction, not by scheduling.
+//   * H1R (branches without h1): the H-side producers of an L = 1 workgroup compute h1 = relu(W1 x + b1) of the batch with
+//     the forward's f32 matrix instructions instead of loading it (33 MB less to write in the forward and to read here).
+// Operand features are dealt round-robin as in encoder_dww.hip: feature f <-> block f & 3, slot f >> 2, so that the four
+// features of a producer lane land in four blocks at one slot (conflict-free 8-byte writes); element t of lane half g of a
+// fragment entry = row 8 g + t of the k-block on both sides.  A recomputed H1 arrives as lane (n, h), register r = row
+// (r & 3) + 8 (r >> 2) + 4 h of the batch: registers 4 q .. 4 q + 3 are exactly half h of the entry of k-group q & 1 of
+// k-block q >> 1.
 #include "common.hpp"
 #include "encoder.hpp"
 #include "x3.hpp"
@@ -30,8 +37,13 @@ constexpr int DW2_BUF = 2 * DW2_ARR + 64;            // G | H | the batch's x ro
 constexpr int DW2_LDS_BYTES = 2 * DW2_BUF * 16;      // two buffers
 constexpr int DW2_PART0 = EH * EH + EH;              // dW3 | db3
 constexpr int DW2_PART1 = EH * EH + 1024 + 2 * EH;   // dW2 | dW1 (128 x in_dim in a 1024-float field) | db2 | db1
+constexpr int DW2_RED = 8 * 128 * 9;                 // floats of the final dW1 / db1 exchange (8 row groups), then 4 x 128 bias sums
 static_assert(DW2_PART0 + DW2_PART1 == ENC_PART, "the two slot kinds partition a full slot");
-static_assert(4 * 128 * 9 * 4 + 2 * 128 * 4 <= DW2_LDS_BYTES, "final exchange fits");
+static_assert((DW2_RED + 4 * 128) * 4 <= DW2_LDS_BYTES, "final exchange fits");
+
+#ifndef PIML_DW2_DEPTH
+#define PIML_DW2_DEPTH 2
+#endif
 
 struct Dw2Args {
     EncArgs A;
@@ -56,246 +68,300 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
     slab = (slab + 1) & ~1u;
     const unsigned r0 = __builtin_amdgcn_readfirstlane(p * slab < R ? p * slab : R);
     const unsigned r1 = __builtin_amdgcn_readfirstlane(r0 + slab < R ? r0 + slab : R);
-    const float scale = J.scale;
-    const int ia = wave >> 1, jb0 = 2 * (wave & 1);        // output blocks (ia, jb0), (ia, jb0 + 1)
-
-    f32x16 c[2], sm[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { c[u][r] = 0.f; sm[u][r] = 0.f; }
-    // staging role: feature sf, lane half sh of the fragment; waves 0-3 the G array, waves 4-7 the H array
-    const unsigned sf = tid & 127, sh = (wave >> 1) & 1;
-    const bool gside = wave < 4;
-    const unsigned slot = (sf >> 5) * 64 + (sf & 31) + 32 * sh;
-    const int hblk = (wave - 4) & 3;                       // H1R: feature block of this H-side wave
-    // dW1 / db1 role (L = 1): feature sf, rows 8 rg .. 8 rg + 7 of the batch
-    const unsigned rg = wave >> 1;
-    float sG = 0.f, s1 = 0.f;                              // column sums: of the staged G array (db3 / db2), of g1 (db1)
-    float w1[8];
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) w1[cc] = 0.f;
-
-    // Every load goes through a buffer resource over this workgroup's slab with the row as the SCALAR offset (rows are
-    // wave-uniform): no address arithmetic on the vector pipe, a row past the slab reads as 0 by the range check.
+    const unsigned nb = __builtin_amdgcn_readfirstlane((r1 - r0 + DW2_ROWS - 1) / DW2_ROWS);
+    // Buffer resources over this workgroup's slab: the (wave-uniform) row goes into the SCALAR offset, clamped to the range
+    // for rows past the slab -- the hardware's range check answers those with zeros --, the lane's place inside two rows into
+    // the vector offset.  A role without business with an array gets a resource of zero bytes.
     const unsigned srows = r1 - r0, sbytes = srows * EH * 4;
     auto rsrc = [&](const void* base, unsigned bytes) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
     };
-    const unsigned pbytes = (R / K) * EH * 4;
-    // array 0 of this role: L0 G side: g_pooled (whole array, row / k) or g_msgs; L0 H side: h2; L1 G side: g2; L1 H side: h1
-    const bool pooled0 = L == 0 && gside && POOL;
-    const float* a0 = L == 0 ? (gside ? (POOL ? J.g_pooled : J.g_msgs) : J.h2) : (gside ? J.g2 : J.h1);
-    const bool a0_live = !(H1R && L == 1 && !gside);       // H1R: nothing is loaded for H1
-    const __amdgpu_buffer_rsrc_t rs0 = pooled0 ? rsrc(a0, pbytes) : rsrc(a0_live ? a0 + (size_t)r0 * EH : nullptr, a0_live ? sbytes : 0u);
-    const __amdgpu_buffer_rsrc_t rsm = rsrc((POOL && MSGS) ? J.g_msgs + (size_t)r0 * EH : nullptr, (POOL && MSGS) ? sbytes : 0u);
-    const __amdgpu_buffer_rsrc_t rsg = rsrc(J.g1 + (size_t)r0 * EH, sbytes);
-    const __amdgpu_buffer_rsrc_t rsx = rsrc(J.x + (size_t)r0 * IN, srows * IN * 4);
-    const unsigned kbytes = srows * 16;
-    const __amdgpu_buffer_rsrc_t rsk = rsrc(DROP ? J.keep_bits + (size_t)r0 * 4 : nullptr, DROP ? kbytes : 0u);
-    const unsigned xvoff = (tid < 256 && (unsigned)(tid & 7) < IN) ? ((tid >> 3) * IN + (tid & 7)) * 4 : 0x7fff0000u;
     auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
     };
-    // H1R: W1 fragments + bias of this wave's feature block, the x operand's lane offsets
-    float w1b[4] = {0.f, 0.f, 0.f, 0.f}, b1n = 0.f;
-    unsigned xav[4] = {0x7fff0000u, 0x7fff0000u, 0x7fff0000u, 0x7fff0000u};
-    if (H1R && L == 1 && !gside) {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            w1b[s_] = J.packed[32768 + (hblk * 4 + s_) * 64 + lane];
-            const unsigned cx = 2u * s_ + (lane >> 5);
-            if (cx < IN) xav[s_] = ((lane & 31) * IN + cx) * 4;
-        }
-        b1n = J.packed[32768 + 1024 + 32 * hblk + (lane & 31)];
-    }
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+    };
+    const unsigned fi = lane & 31, rsub = lane >> 5;
+    const unsigned avoff = rsub * (4 * EH * 4) + fi * 16;        // features 4 fi .. 4 fi + 3 of the row 4 rsub behind the scalar one
+    // the partial slot: L0 [dW3 | db3] at slot p, L1 [dW2 | dW1 | db2 | db1] behind the branch's L0 slots
+    float* P = L ? J.partials + (size_t)D.n0[b] * DW2_PART0 + (size_t)p * DW2_PART1 : J.partials + (size_t)p * DW2_PART0;
 
-    // agent (row / k) of the unit's first row, kept incrementally (the batches are requested in row order, 32 rows apart)
-    unsigned pidx0 = __umulhi(r0 + 4 * sh, kmagic), prem0 = r0 + 4 * sh - pidx0 * K;
-    const unsigned q32 = __umulhi(32u, kmagic), m32 = 32u - q32 * K;
-    const unsigned q5 = __umulhi(5u, kmagic), m5 = 5u - q5 * K;
-    struct Stage { float a[16], m[16], g1[8], x, xa[4]; unsigned kw[16]; };
-    auto stage_load = [&](unsigned rb_) -> Stage {           // issue the loads of the batch starting at row rb
-        Stage S;
-        const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);
-        unsigned pidx = pidx0, prem = prem0;
-        if (POOL) {
-            pidx0 += q32; prem0 += m32;
-            if (prem0 >= K) { prem0 -= K; ++pidx0; }
+    if (wave < 4) {
+        // ================================================ consumers ================================================
+        const int iq = wave >> 1, jq = wave & 1;
+        f32x16 c[2][2], sm[2][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c[u >> 1][u & 1][r] = 0.f; sm[u >> 1][u & 1][r] = 0.f; }
+        // dW1 / db1 (L = 1): features 4 fi .. 4 fi + 3 of rows 8 wave + 4 rsub .. + 3 of the batch
+        float w1[4][8], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1[j] = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) w1[j][cc] = 0.f;
         }
+        const __amdgpu_buffer_rsrc_t rsg = rsrc(J.g1 + (size_t)r0 * EH, L == 1 ? sbytes : 0u);
+        struct G1 { float4 v[4]; };
+        auto g1_load = [&](unsigned rb_) -> G1 {
+            G1 g;
+            const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) S.xa[s_] = 0.f;
-        if (H1R)
-            if (L == 1 && !gside) {                            // the batch's x rows as the A operand of the h1 product
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) S.xa[s_] = ld(rsx, xav[s_], rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4);
+            for (int t = 0; t < 4; ++t) {
+                const unsigned row = rb + 8 * wave + t;
+                g.v[t] = ld4(rsg, avoff, row < r1 ? (row - r0) * (EH * 4) : sbytes);
             }
+            return g;
+        };
+        auto compute = [&](const float* buf, const G1& g) {
+            const u32x4* B = reinterpret_cast<const u32x4*>(buf);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {                         // e = 8 kb + t: row 16 kb + 4 sh + (t & 3) + 8 (t >> 2)
-            const unsigned row = rb + 16 * (e >> 3) + 4 * sh + (e & 3) + 8 * ((e >> 2) & 1);       // scalar
-            const unsigned rel = row < r1 ? (row - r0) * (EH * 4) : sbytes;
-            const unsigned pi = __builtin_amdgcn_readfirstlane(pidx);
-            const unsigned off0 = pooled0 ? (row < r1 ? pi * (EH * 4) : pbytes) : rel;
-            S.a[e] = 0.f;
-            if (a0_live) S.a[e] = ld(rs0, sf * 4, off0);
-            if (POOL) {                                         // to the unit's next row: + 1, or + 5 behind every fourth
-                if ((e & 3) == 3) {
-                    prem += m5; pidx += q5;
-                    if (prem >= K) { prem -= K; ++pidx; }
-                } else {
-                    ++prem;
-                    if (prem == K) { prem = 0; ++pidx; }
+            for (int kb = 0; kb < 2; ++kb) {
+                const u32x4* Ap = B + kb * 256 + (2 * iq) * 64 + lane;
+                const u32x4* Bp = B + DW2_ARR + kb * 256 + (2 * jq) * 64 + lane;
+                u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    ah[u] = Ap[u * 64]; am[u] = Ap[512 + u * 64]; al[u] = Ap[1024 + u * 64];
+                    bh[u] = Bp[u * 64]; bm[u] = Bp[512 + u * 64]; bl[u] = Bp[1024 + u * 64];
+                }
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {
+#ifdef EXP_NO_MFMA
+                        c[ia][jb][0] += __uint_as_float(ah[ia][0] ^ bh[jb][1] ^ am[ia][2] ^ bm[jb][3] ^ al[ia][0] ^ bl[jb][1]);
+#else
+                        kblock_x3(c[ia][jb], sm[ia][jb], ah[ia], am[ia], al[ia], bh[jb], bm[jb], bl[jb]);
+#endif
+                    }
+            }
+            if (L == 1) {
+                const float4* xr = reinterpret_cast<const float4*>(buf + 2 * DW2_ARR * 4 + (8 * wave + 4 * rsub) * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 xa = xr[2 * t], xb = xr[2 * t + 1];
+                    const float gv[4] = {g.v[t].x, g.v[t].y, g.v[t].z, g.v[t].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        w1[j][0] = __fmaf_rn(gv[j], xa.x, w1[j][0]); w1[j][1] = __fmaf_rn(gv[j], xa.y, w1[j][1]);
+                        w1[j][2] = __fmaf_rn(gv[j], xa.z, w1[j][2]); w1[j][3] = __fmaf_rn(gv[j], xa.w, w1[j][3]);
+                        w1[j][4] = __fmaf_rn(gv[j], xb.x, w1[j][4]); w1[j][5] = __fmaf_rn(gv[j], xb.y, w1[j][5]);
+                        w1[j][6] = __fmaf_rn(gv[j], xb.z, w1[j][6]); w1[j][7] = __fmaf_rn(gv[j], xb.w, w1[j][7]);
+                        s1[j] += gv[j];
+                    }
                 }
             }
-            S.m[e] = 0.f;
-            if (POOL && MSGS)
-                if (L == 0 && gside) S.m[e] = ld(rsm, sf * 4, rel);
-            S.kw[e] = 0u;
-            if (DROP)
-                if (L == 0 && gside) S.kw[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsk, (int)((sf >> 5) * 4), (int)(row < r1 ? (row - r0) * 16 : kbytes), 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            S.g1[t] = 0.f;
-            if (L == 1) {
-                const unsigned row = rb + 8 * rg + t;
-                S.g1[t] = ld(rsg, sf * 4, row < r1 ? (row - r0) * (EH * 4) : sbytes);
-            }
-        }
-        S.x = 0.f;
-        if (L == 1) S.x = ld(rsx, xvoff, rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4);
-        return S;
-    };
-    float gq[8];                                             // g1 values of the batch in the compute phase
-    auto write_pieces = [&](u32x4* dst, const float (&v)[16]) {     // dst: the array's entry of this lane; [piece][kb] 256 apart
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) split3(v[8 * kb + 2 * d], v[8 * kb + 2 * d + 1], hi[d], mid[d], lo[d]);
-            dst[(0 * 2 + kb) * 256] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-            dst[(1 * 2 + kb) * 256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
-            dst[(2 * 2 + kb) * 256] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
-        }
-    };
-    auto stage_write = [&](const Stage& S, float* buf) {     // registers -> split -> LDS
-        u32x4* B = reinterpret_cast<u32x4*>(buf);
-        float v[16];
-        if (H1R && L == 1 && !gside) {
-            // h1 of the batch's 32 rows x this wave's 32 features: lane (n, h), register r = row (r & 3) + 8 (r >> 2) + 4 h
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = b1n;
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) acc = mfma32(S.xa[s_], w1b[s_], acc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = relu1(acc[r]);
-            write_pieces(B + DW2_ARR + hblk * 64 + lane, v);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = (L == 0 && gside) ? (S.a[e] + S.m[e]) * scale : S.a[e];
-            if (DROP && L == 0 && gside) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = ((S.kw[e] >> (sf & 31)) & 1u) ? v[e] : 0.f;
-            }
-            if (gside) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sG += v[e];
-            }
-            write_pieces(B + (gside ? 0 : DW2_ARR) + slot, v);
-        }
-        if (L == 1 && tid < 256) buf[2 * DW2_ARR * 4 + tid] = S.x;
-    };
-    auto take_g1 = [&](const Stage& S) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) gq[t] = S.g1[t];
-    };
-    auto compute = [&](const float* buf) {
-        const u32x4* B = reinterpret_cast<const u32x4*>(buf);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const u32x4* Ap = B + kb * 256 + ia * 64 + lane;
-            const u32x4* Bp = B + DW2_ARR + kb * 256 + jb0 * 64 + lane;
-            const u32x4 ah = Ap[0], am = Ap[512], al = Ap[1024];
-            u32x4 bh[2], bm[2], bl[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { bh[u] = Bp[u * 64]; bm[u] = Bp[512 + u * 64]; bl[u] = Bp[1024 + u * 64]; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) kblock_x3(c[u], sm[u], ah, am, al, bh[u], bm[u], bl[u]);
-        }
-        if (L == 1) {                                          // dW1 / db1: rows 8 rg .. 8 rg + 7 of the batch
-            const float4* xr = reinterpret_cast<const float4*>(buf + 2 * DW2_ARR * 4 + rg * 64);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float4 xa = xr[2 * t], xb = xr[2 * t + 1];
-                const float g = gq[t];
-                w1[0] = __fmaf_rn(g, xa.x, w1[0]); w1[1] = __fmaf_rn(g, xa.y, w1[1]);
-                w1[2] = __fmaf_rn(g, xa.z, w1[2]); w1[3] = __fmaf_rn(g, xa.w, w1[3]);
-                w1[4] = __fmaf_rn(g, xb.x, w1[4]); w1[5] = __fmaf_rn(g, xb.y, w1[5]);
-                w1[6] = __fmaf_rn(g, xb.z, w1[6]); w1[7] = __fmaf_rn(g, xb.w, w1[7]);
-                s1 += g;
-            }
-        }
-    };
-    if (r0 < r1) {
-        const unsigned nb = (r1 - r0 + DW2_ROWS - 1) / DW2_ROWS;
-        {
-            const Stage S = stage_load(r0);
-            stage_write(S, lds);
-            take_g1(S);
-        }
-        __syncthreads();
+        };
+        G1 g = g1_load(r0);
+        __syncthreads();                                           // batch 0 is in buffer 0
         for (unsigned t = 0; t < nb; ++t) {
-            float* cur = lds + (t & 1) * DW2_BUF * 4;
-            float* nxt = lds + ((t + 1) & 1) * DW2_BUF * 4;
-            // the next batch's loads are issued BETWEEN this batch's products (see enc_bwd_dw_x3_kernel)
-            const Stage S2 = stage_load(r0 + (t + 1) * DW2_ROWS);
-            compute(cur);
-            __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);          // fragment + x reads
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one product
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);       // two loads
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            stage_write(S2, nxt);
-            take_g1(S2);
+            const G1 gn = g1_load(r0 + (t + 1) * DW2_ROWS);
+            compute(lds + (t & 1) * DW2_BUF * 4, g);
+            g = gn;
             __syncthreads();
         }
-    }
-    // ---- the partial slot: L0 [dW3 | db3] at slot p, L1 [dW2 | dW1 | db2 | db1] behind the branch's L0 slots ----
-    float* P = L ? J.partials + (size_t)D.n0[b] * DW2_PART0 + (size_t)p * DW2_PART1 : J.partials + (size_t)p * DW2_PART0;
-    const int n = lane & 31, h = lane >> 5;
-    // accumulator u, register r, lane (n, h): dW[32 ia + (r & 3) + 8 (r >> 2) + 4 h][32 (jb0 + u) + n]
+        const int n = lane & 31, h = lane >> 5;
+        // accumulator (ia, jb), register r, lane (n, h): operand blocks (2 iq + ia, 2 jq + jb), slots ((r & 3) + 8 (r >> 2) + 4 h, n)
+        // = dW[4 slot_a + 2 iq + ia][4 n + 2 jq + jb]: the two jb of a register are neighbours in memory
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = 32 * ia + (r & 3) + 8 * (r >> 2) + 4 * h;
-            P[(size_t)orow * EH + 32 * (jb0 + u) + n] = c[u][r] + sm[u][r];
-        }
-    // column sums (and dW1): the partial sums of the row groups / lane halves meet in LDS (the batch buffers are dead)
-    __syncthreads();
-    {
+            for (int r = 0; r < 16; ++r) {
+                const int orow = 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + 2 * iq + ia;
+                *reinterpret_cast<float2*>(P + (size_t)orow * EH + 4 * n + 2 * jq) =
+                    make_float2(c[ia][0][r] + sm[ia][0][r], c[ia][1][r] + sm[ia][1][r]);
+            }
+        __syncthreads();                                           // the batch buffers are dead
         if (L == 1) {
-            float* red = lds + (rg * 128 + sf) * 9;
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) red[cc] = w1[cc];
-            red[8] = s1;
+            for (int j = 0; j < 4; ++j) {
+                float* red = lds + ((size_t)(wave * 2 + rsub) * 128 + 4 * fi + j) * 9;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) red[cc] = w1[j][cc];
+                red[8] = s1[j];
+            }
         }
-        float* red2 = lds + 4 * 128 * 9 + sh * 128 + sf;
-        if (gside) red2[0] = sG;
+    } else {
+        // ================================================ producers ================================================
+        const unsigned pw = wave - 4, sa = pw >> 1, hh = pw & 1;         // array (0: G, 1: H), row half of a k-block
+        const bool g3 = L == 0 && sa == 0;                              // this wave builds G3
+        const bool pooled0 = POOL && g3;
+        const bool h1r = H1R && L == 1 && sa == 1;                      // this wave recomputes H1
+        const unsigned pbytes = (R / K) * EH * 4;
+        const float* slab_base = L == 0 ? (sa == 0 ? J.g_msgs : J.h2) : (sa == 0 ? J.g2 : J.h1);
+        const __amdgpu_buffer_rsrc_t rsa = pooled0 ? rsrc(J.g_pooled, pbytes) : rsrc(slab_base + (size_t)r0 * EH, h1r ? 0u : sbytes);
+        const __amdgpu_buffer_rsrc_t rsm = rsrc(J.g_msgs + (size_t)r0 * EH, (POOL && MSGS && g3) ? sbytes : 0u);
+        const unsigned kbytes = srows * 16;
+        const __amdgpu_buffer_rsrc_t rsk = rsrc(DROP ? J.keep_bits + (size_t)r0 * 4 : nullptr, (DROP && g3) ? kbytes : 0u);
+        const unsigned keep_all = (DROP && g3) ? 0u : 0xffffffffu;
+        const float sc = g3 ? J.scale : 1.f;
+        const unsigned kvoff = rsub * 64 + (fi >> 3) * 4;
+        // the batch's x rows: for the consumers' dW1 (L = 1; one float per producer thread) and as the A operand of H1R
+        const __amdgpu_buffer_rsrc_t rsx = rsrc(J.x + (size_t)r0 * IN, L == 1 ? srows * IN * 4 : 0u);
+        const unsigned ptid = tid - 256;
+        const unsigned xvoff = ((ptid & 7) < IN) ? ((ptid >> 3) * IN + (ptid & 7)) * 4 : 0x7fff0000u;
+        float w1b[2][4], b1n[2] = {0.f, 0.f};
+        unsigned xav[4] = {0x7fff0000u, 0x7fff0000u, 0x7fff0000u, 0x7fff0000u};
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) w1b[v][s_] = 0.f;
+        if (h1r) {       // virtual block vb = 2 hh + v: features 4 n + vb; B operand lane (n, g): W1[feature][2 s + g]
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const unsigned cx = 2u * s_ + rsub;
+                if (cx < IN) {
+                    xav[s_] = (fi * IN + cx) * 4;
+#pragma unroll
+                    for (int v = 0; v < 2; ++v) w1b[v][s_] = J.w1[(size_t)(4 * fi + 2 * hh + v) * IN + cx];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) b1n[v] = J.b1[4 * fi + 2 * hh + v];
+        }
+        float sb[4] = {0.f, 0.f, 0.f, 0.f};          // column sums of the G array's four features (db3 / db2)
+
+        struct Stage { float4 a[8], m[8]; float xa[4], x; unsigned kw[8]; };
+        auto stage_load = [&](unsigned rb_) -> Stage {
+            Stage S;
+            const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);
+            const unsigned xso = rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4;
+#ifdef EXP_NO_LOAD
+            for (int e = 0; e < 8; ++e) { S.a[e] = make_float4(rb * 1e-3f, 1.f, 2.f, 3.f); S.m[e] = S.a[e]; S.kw[e] = rb; }
+            for (int s_ = 0; s_ < 4; ++s_) S.xa[s_] = 1.f;
+            S.x = 1.f;
+            return S;
+#endif
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                S.xa[s_] = 0.f;
+                if (H1R) S.xa[s_] = ld(rsx, h1r ? xav[s_] : 0x7fff0000u, xso);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                                // e = 4 kb + t
+                const unsigned row = rb + 16 * (e >> 2) + 8 * hh + (e & 3);     // scalar: the row of lane half 0 (half 1: + 4)
+                const unsigned rel = row < r1 ? (row - r0) * (EH * 4) : sbytes;
+                unsigned vo = avoff, so = rel;
+                if (POOL) {
+                    const unsigned mine = row + 4 * rsub;
+                    const unsigned pv = mine < r1 ? __umulhi(mine, kmagic) * (EH * 4) + fi * 16 : pbytes;
+                    vo = pooled0 ? pv : avoff;
+                    so = pooled0 ? 0u : rel;
+                }
+                S.a[e] = ld4(rsa, vo, so);
+                S.m[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (POOL && MSGS) S.m[e] = ld4(rsm, avoff, rel);
+                S.kw[e] = 0u;
+                if (DROP) S.kw[e] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsk, (int)kvoff, (int)(row < r1 ? (row - r0) * 16 : kbytes), 0);
+            }
+            S.x = ld(rsx, xvoff, xso);
+            return S;
+        };
+        auto stage_write = [&](const Stage& S, float* buf) {
+            uint2* base = reinterpret_cast<uint2*>(buf);
+#ifdef EXP_NO_SPLIT
+            for (int e = 0; e < 8; ++e) sb[e & 3] += S.a[e].x + S.a[e].y + S.a[e].z + S.a[e].w + S.m[e].x + __uint_as_float(S.kw[e]);
+            sb[0] += S.x + S.xa[0] + S.xa[1] + S.xa[2] + S.xa[3];
+            return;
+#endif
+            if (h1r) {
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = b1n[v];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) acc = mfma32(S.xa[s_], w1b[v][s_], acc);
+                    // lane (n = fi, h = rsub): registers 4 q .. 4 q + 3 = half h of entry (block vb, slot n + 32 (q & 1)) of k-block q >> 1
+                    uint2* d0 = base + ((size_t)DW2_ARR + (2 * hh + v) * 64 + fi) * 2 + rsub;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split3(relu1(acc[4 * q]), relu1(acc[4 * q + 1]), h0, m0, l0);
+                        split3(relu1(acc[4 * q + 2]), relu1(acc[4 * q + 3]), h1, m1, l1);
+                        uint2* d = d0 + ((q >> 1) * 256 + 32 * (q & 1)) * 2;
+                        d[0] = make_uint2(h0, h1);
+                        d[2 * 512] = make_uint2(m0, m1);
+                        d[2 * 1024] = make_uint2(l0, l1);
+                    }
+                }
+            } else {
+                // entry (array sa, piece, k-block, block j, slot fi + 32 hh), half rsub (rows 4 rsub .. + 3 of the unit), as uint2
+                uint2* d0 = base + ((size_t)sa * DW2_ARR + fi + 32 * hh) * 2 + rsub;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    float u[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 a = S.a[4 * kb + t], m = S.m[4 * kb + t];
+                        u[t][0] = (a.x + m.x) * sc; u[t][1] = (a.y + m.y) * sc; u[t][2] = (a.z + m.z) * sc; u[t][3] = (a.w + m.w) * sc;
+                        if (DROP) {
+                            const unsigned kw = (S.kw[4 * kb + t] | keep_all) >> ((4 * fi) & 31);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) u[t][j] = keep_if(u[t][j], kw, j);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sb[j] += (u[0][j] + u[1][j]) + (u[2][j] + u[3][j]);
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split3(u[0][j], u[1][j], h0, m0, l0);
+                        split3(u[2][j], u[3][j], h1, m1, l1);
+                        uint2* d = d0 + (kb * 256 + j * 64) * 2;
+                        d[0] = make_uint2(h0, h1);
+                        d[2 * 512] = make_uint2(m0, m1);
+                        d[2 * 1024] = make_uint2(l0, l1);
+                    }
+                }
+            }
+            buf[2 * DW2_ARR * 4 + ptid] = S.x;
+        };
+        // DEPTH batches ahead.  Measured at the 4096-agent scene (us, same box): depth 2: 39.6, 3: 41.2, 4: 41.5, 5: 44.8 -- the
+        // bytes in flight are not what holds this kernel back (a deeper ring costs registers and moves instead).
+        constexpr int DEPTH = (POOL && MSGS) ? 2 : (DROP ? (PIML_DW2_DEPTH > 3 ? 3 : PIML_DW2_DEPTH) : PIML_DW2_DEPTH);      // (the g_msgs variant holds two arrays per batch)
+        constexpr int UNROLL = (DEPTH % 2) ? 2 * DEPTH : DEPTH;
+        Stage S[DEPTH];
+        S[0] = stage_load(r0);
+        stage_write(S[0], lds);
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i) S[i] = stage_load(r0 + (i + 1) * DW2_ROWS);      // S[i]: batch i + 1
+        __syncthreads();                                           // batch 0 is in buffer 0
+        for (unsigned t0 = 0; t0 < nb; t0 += UNROLL) {
+#pragma unroll
+            for (int i = 0; i < UNROLL; ++i) {
+                const unsigned t = t0 + i;                             // the consumers multiply batch t; t % DEPTH == i % DEPTH
+                if (t < nb) {
+                    S[(i + DEPTH - 1) % DEPTH] = stage_load(r0 + (t + DEPTH) * DW2_ROWS);
+                    stage_write(S[i % DEPTH], lds + ((i + 1) & 1) * DW2_BUF * 4);          // batch t + 1
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();                                           // the batch buffers are dead
+        if (sa == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[DW2_RED + (hh * 2 + rsub) * 128 + 4 * fi + j] = sb[j];
+        }
     }
+    // ---- column sums (and dW1): the partial sums of the row groups meet in LDS ----
     __syncthreads();
     if (tid < 128) {
-        const float dbG = lds[4 * 128 * 9 + tid] + lds[4 * 128 * 9 + 128 + tid];
+        const float* q = lds + DW2_RED + tid;
+        const float dbG = (q[0] + q[128]) + (q[256] + q[384]);
         if (L == 0) {
             P[EH * EH + tid] = dbG;
         } else {
             float acc[9];
 #pragma unroll
-            for (int cc = 0; cc < 9; ++cc)
-                acc[cc] = (lds[(0 * 128 + tid) * 9 + cc] + lds[(1 * 128 + tid) * 9 + cc]) + (lds[(2 * 128 + tid) * 9 + cc] + lds[(3 * 128 + tid) * 9 + cc]);
+            for (int cc = 0; cc < 9; ++cc) {
+                float v[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) v[g] = lds[((size_t)g * 128 + tid) * 9 + cc];
+                acc[cc] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
             float* o = P + EH * EH + tid * IN;                  // dW1 row-major (128, in_dim) at the head of its 1024 floats
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc)
@@ -311,9 +377,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
 }
 
 // slots of layer 0 among a branch's `w` workgroups: the layer-1 workgroups move about twice the bytes per row (g2 + g1
-// against h2), so they get two thirds of them (PIML_DW2_L0_SHARE: per mille, default 360)
+// against h2) but their H side is recomputed, not loaded, and building G3 is the dearest staging: measured best at an even
+// split (PIML_DW2_L0_SHARE, per mille: 300: 51.7 us, 420: 42.0, 500: 40.2, 550: 43.9, 600: 46.4)
 static int dw2_l0_share() {
-    static int v = getenv("PIML_DW2_L0_SHARE") ? atoi(getenv("PIML_DW2_L0_SHARE")) : 360;
+    static int v = getenv("PIML_DW2_L0_SHARE") ? atoi(getenv("PIML_DW2_L0_SHARE")) : 500;
     return v;
 }
 void enc_dw2_split(int w, int* n0, int* n1) {

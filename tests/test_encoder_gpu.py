@@ -38,6 +38,26 @@ def reference(br, g_msgs, g_pooled):
     return msgs.detach(), pooled.detach(), x.grad, [t.grad for t in w]
 
 
+def dodge_relu_kinks(br, rel=1e-5, rounds=12):
+    """Re-draw the input rows that put a ReLU pre-activation within `rel` of zero (relative to the layer's mean magnitude):
+    two correct float32 evaluations round such a value to different sides of zero, and a comparison at 1e-5 would then
+    measure one flipped ReLU -- a whole gradient row appearing or vanishing -- instead of the arithmetic (at 5 M
+    pre-activations a float32 ulp around zero is hit about every other draw)."""
+    g = torch.Generator().manual_seed(1234)
+    w = [t.detach().double() for t in br['weights']]
+    with torch.no_grad():
+        for _ in range(rounds):
+            x = br['x'].detach().double()
+            z1 = x @ w[0].t() + w[1]
+            z2 = torch.relu(z1) @ w[2].t() + w[3]
+            bad = ((z1.abs() < rel * z1.abs().mean()) | (z2.abs() < rel * z2.abs().mean())).any(-1)
+            n = int(bad.sum())
+            if n == 0:
+                return br
+            br['x'][bad] = (torch.randn(n, br['x'].shape[-1], generator=g) * 2).to(DEV)
+    raise AssertionError('dodge_relu_kinks: still near a kink after re-drawing')
+
+
 def relerr(got, want):
     want = want.to(got.device)
     return float((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
@@ -558,6 +578,7 @@ def test_split_tile_x3_backward_is_bitwise_the_one_wave_x3_backward(agents, drop
     leaves = [t for br in brs for t in (br['x'], *br['weights'])]
     res = {}
     old, old_products = L.piml_encoder_split_tiles(-1), L.piml_encoder_products(1)
+    old_dw2 = L.piml_encoder_dw2(0)      # the same weight-gradient kernel on both sides: this is about the two dX chains
     try:
         for split in (True, False):
             L.piml_encoder_split_tiles(1 << 30 if split else 0)
@@ -567,9 +588,71 @@ def test_split_tile_x3_backward_is_bitwise_the_one_wave_x3_backward(agents, drop
     finally:
         L.piml_encoder_split_tiles(old)
         L.piml_encoder_products(old_products)
+        L.piml_encoder_dw2(old_dw2)
     assert len(res[True]) == len(res[False]) == 4 + 14
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shapes,upstream,drop', [
+    ([(4096, 6, 6), (4096, 10, 6)], 'pooled', False), ([(4096, 6, 6), (4096, 10, 6)], 'both', True),
+    ([(5000, 7, 5), (3001, 5, 8)], 'msgs', False), ([(9000, 5, 6)], 'both', False), ([(4100, 9, 6), (4100, 9, 6)], 'mixed', True),
+])
+@pytest.mark.parametrize('recompute', [True, False])
+def test_layer_split_weight_gradients(shapes, upstream, drop, recompute, monkeypatch):
+    """piml_amd/csrc/encoder_dw2.hip (layer-split workgroups, producer / consumer waves; h1 recomputed from x when the forward
+    did not store it) against float64 and against the slab kernel (encoder_dww.hip) on the same inputs: same products, another
+    order of the row sums.  'mixed': the two branches carry different kinds of upstream gradient (two launches)."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    monkeypatch.setattr(ops, 'H1_RECOMPUTE', recompute)
+    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles(-1)
+    g = torch.Generator().manual_seed(77)
+    branches = [dodge_relu_kinks(make_branch(n, k, d, seed=3 * i + 1, scale=4.0 if drop else 2.0)) for i, (n, k, d) in enumerate(shapes)]
+    if drop:
+        for br, (n, k, d) in zip(branches, shapes):
+            br['keep_bits'] = ops.pack_keep_bits(torch.rand(n * k, H, generator=g) >= 0.5).to(DEV)
+    kinds = [upstream] * len(shapes) if upstream != 'mixed' else ['pooled', 'both']
+    ups = []
+    for (n, k, d), kind in zip(shapes, kinds):
+        gm = torch.randn(n, k, H, generator=g).to(DEV) if kind in ('both', 'msgs') else None
+        gp = torch.randn(n, H, generator=g).to(DEV) if kind in ('both', 'pooled') else None
+        ups.append((gm, gp))
+    leaves = [t for br in branches for t in (br['x'], *br['weights'])]
+    res = {}
+    old = L.piml_encoder_dw2(-1)
+    try:
+        for on in (1, 0):
+            L.piml_encoder_dw2(on)
+            outs = ops.fused_encoders(branches)
+            loss = 0
+            for (msgs, pooled), (gm, gp) in zip(outs, ups):
+                loss = loss + ((msgs * gm).sum() if gm is not None else 0) + ((pooled * gp).sum() if gp is not None else 0)
+            res[on] = torch.autograd.grad(loss, leaves)
+    finally:
+        L.piml_encoder_dw2(old)
+    worst = {}
+    it1, it0 = iter(res[1]), iter(res[0])
+    for br, (gm, gp) in zip(branches, ups):
+        ref = dict(br)
+        if drop:        # the processor with an injected mask: keep * scale * x (scale = 2 / (1 - p) = 4)
+            keep = ops.unpack_keep_bits(br['keep_bits'], H).to(DEV).double().view(*br['x'].shape[:-1], H)
+            x = br['x'].detach().double().requires_grad_(True)
+            w = [t.detach().double().requires_grad_(True) for t in br['weights']]
+            h = torch.relu(torch.relu(x @ w[0].t() + w[1]) @ w[2].t() + w[3])
+            msgs = keep * br['scale'] * (h @ w[4].t() + w[5])
+            l64 = ((msgs * gm.double()).sum() if gm is not None else 0) + ((msgs.sum(-2) * gp.double()).sum() if gp is not None else 0)
+            l64.backward()
+            rgx, rgw = x.grad, [t.grad for t in w]
+        else:
+            _, _, rgx, rgw = reference(ref, gm, gp)
+        for name, r in zip(('g_x', 'dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3'), [rgx, *rgw]):
+            a, b = next(it1), next(it0)
+            worst[name] = max(worst.get(name, 0), relerr(a, r))
+            worst[name + ' vs slab'] = max(worst.get(name + ' vs slab', 0), relerr(a, b.double()))
+    print(f'layer-split dW {shapes} upstream={upstream} drop={drop} recompute={recompute}: ' +
+          ', '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    assert max(worst.values()) <= 1e-5, worst
 
 
 @pytest.mark.parametrize('shapes', [[(4096, 6, 6), (4096, 10, 6)], [(5000, 7, 5), (33, 3, 8)]])
