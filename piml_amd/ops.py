@@ -1367,15 +1367,19 @@ def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, 
 H1_RECOMPUTE = _os.environ.get('PIML_H1_RECOMPUTE', '1') != '0'      # do not store h1 where the backward can do without (below)
 
 
-def _h1_needed(rows_per_branch):
+def _h1_needed(rows_per_branch, alone=True):
     """False when the backward of these branches runs without h1 (include/piml_hip.h, piml_encoder_branch): sign bits for
-    the dX chain + layer-split weight gradients that recompute it from x.  The forward then does not store it."""
+    the dX chain + layer-split weight gradients that recompute it from x.  The forward then does not store it.
+    alone: the backward may run on any subset of the branches (fused_encoders: a branch without upstream gradient is left
+    out), so every branch has to be above the bound on its own; the PINNSF network's backward always has the gradient of
+    the accelerations for all of them, and the launch as a whole counts."""
     if not (H1_RECOMPUTE and RELU_MASK):
         return True
     import ctypes
     L = _lib.lib()
     # every branch on its own above the bound: the backward may run on a subset of them (branches without upstream gradient)
-    tiles = min((r + 31) // 32 for r in rows_per_branch)
+    per_branch = [(r + 31) // 32 for r in rows_per_branch]
+    tiles = min(per_branch) if alone else sum(per_branch)
     if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1 and tiles > L.piml_encoder_split_tiles(-1)):
         return True
     arr = (_lib.EncoderBranch * len(rows_per_branch))()
@@ -1672,7 +1676,7 @@ class _FusedPinnsf(torch.autograd.Function):
             msgs.append(torch.empty(R, H, **opt))
             h1s.append(None)
             h2s.append(_h2_buffer(R, opt) if need_grad else None)
-        if need_grad and _h1_needed([x2.shape[0] for x2 in x2s]):
+        if need_grad and _h1_needed([x2.shape[0] for x2 in x2s], alone=False):
             h1s = [torch.empty(x2.shape[0], H, **opt) for x2 in x2s]
         flags = _lib.FORK if FORK_NETWORK else 0
         if packs is not None:
@@ -1805,6 +1809,10 @@ class _FusedPinnsf(torch.autograd.Function):
                         if need[jx]:
                             grads[o + jx] = t
             else:                            # only the messages carry a gradient: the encoders alone
+                if h1s[live[0]] is None and _h1_needed([x2s[b].shape[0] for b in live], alone=False):
+                    raise _lib.PimlHipError(
+                        'fused_pinnsf: a backward pass through the messages of a subset of the branches only needs the '
+                        'layer-1 activations, which the forward did not store; run it with PIML_H1_RECOMPUTE=0')
                 _lib.check(L.piml_encoder_bwd(earr, len(live), _stream()), 'piml_encoder_bwd')
             for i, b in enumerate(live):
                 flat = flats[i]

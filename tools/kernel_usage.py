@@ -1,5 +1,6 @@
 """Per-kernel register / scratch / occupancy table from `hipcc -Rpass-analysis=kernel-resource-usage` output.
 usage: python tools/kernel_usage.py [file.hip ...] [--grep enc_]   (default: every source of libpiml_hip.so)"""
+import os
 import re
 import subprocess
 import sys
@@ -10,7 +11,7 @@ from piml_amd import build as B  # noqa: E402
 
 def usage(srcs):
     cmd = ['/opt/rocm/bin/hipcc'] + [f for f in B.FLAGS if f not in ('-shared',)] + \
-        ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', '/dev/null']
+        os.environ.get('PIML_HIPCC_EXTRA', '').split() + ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', '/dev/null']
     rows = []
     for src in srcs:
         out = subprocess.run(cmd + [src], capture_output=True, text=True).stderr
