@@ -131,11 +131,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
                 for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb) {
-#ifdef EXP_NO_MFMA
-                        c[ia][jb][0] += __uint_as_float(ah[ia][0] ^ bh[jb][1] ^ am[ia][2] ^ bm[jb][3] ^ al[ia][0] ^ bl[jb][1]);
-#else
                         kblock_x3(c[ia][jb], sm[ia][jb], ah[ia], am[ia], al[ia], bh[jb], bm[jb], bl[jb]);
-#endif
                     }
             }
             if (L == 1) {
@@ -229,12 +225,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
             Stage S;
             const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);
             const unsigned xso = rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4;
-#ifdef EXP_NO_LOAD
-            for (int e = 0; e < 8; ++e) { S.a[e] = make_float4(rb * 1e-3f, 1.f, 2.f, 3.f); S.m[e] = S.a[e]; S.kw[e] = rb; }
-            for (int s_ = 0; s_ < 4; ++s_) S.xa[s_] = 1.f;
-            S.x = 1.f;
-            return S;
-#endif
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) {
                 S.xa[s_] = 0.f;
@@ -262,11 +252,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
         };
         auto stage_write = [&](const Stage& S, float* buf) {
             uint2* base = reinterpret_cast<uint2*>(buf);
-#ifdef EXP_NO_SPLIT
-            for (int e = 0; e < 8; ++e) sb[e & 3] += S.a[e].x + S.a[e].y + S.a[e].z + S.a[e].w + S.m[e].x + __uint_as_float(S.kw[e]);
-            sb[0] += S.x + S.xa[0] + S.xa[1] + S.xa[2] + S.xa[3];
-            return;
-#endif
             if (h1r) {
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {
