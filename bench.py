@@ -859,10 +859,17 @@ def main():
             print(f'[bench] stage trace unavailable ({type(ex).__name__}: {ex})', file=sys.stderr)
     _phase('stage trace done')
     x3 = '_x3' if x3_products else ''
+    dw = 'dw'
+    if x3_products and fused_mlp:      # the layer-split weight-gradient kernel (encoder_dw2.hip) above the few-rows bound
+        from piml_amd import _lib as _plib
+        if _plib.lib().piml_encoder_dw2(-1) == 1 and N * (6 + 10) // 32 > _plib.lib().piml_encoder_split_tiles(-1):
+            dw = 'dw2'
     stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
                     'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
-                    'enc_bwd_dw': f'enc_bwd_dw{x3}_kernel', 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
+                    'enc_bwd_dw': f'enc_bwd_{dw}{x3}_kernel', 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
     static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
+    if os.environ.get('PIML_DEC_BWD_SPLIT', '1') != '0':       # decoder backward as (tile, branch) workgroups (the default)
+        stage_kernel['dec_bwd'] = 'dec_bwd_split_kernel'
     live_src = ('live: HIP events between the stage launches of an eager step queued behind 24 replays of the captured '
                 f'step, median of 5, minus the cost of an empty event interval ({stage_us.get("event_pair_overhead", 0.0):.1f} us) '
                 '(piml_trace_*); includes the dispatch gap in front of the kernel, which rocprofv3\'s kernel duration does not')
