@@ -727,7 +727,9 @@ def main():
     # region one ~22 us launch and nothing else.
     TIMED_LAUNCHES = 1
     n_samples = max(1, min(5, args.steps // 10))       # one per ten steps: a sample costs the timed region one ~22 us launch (1 %)
-    sample_at = {round(i * args.steps / n_samples) for i in range(n_samples)}
+    # (in the MIDDLE of each tenth: the sample behind the region's first replay measured a whole step's length more than the
+    # others -- 0.13-0.21 ms against 0.024-0.027 -- in every run; the queue in front of it is empty at that point)
+    sample_at = {min(args.steps - 1, int((i + 0.5) * args.steps / n_samples)) for i in range(n_samples)}
     timer_pool = [(_lib.StreamTimer(), _lib.StreamTimer()) for _ in range(n_samples)] if graph is not None else []   # events are made HERE, not in the timed region
 
     def run_step(i, timed):
@@ -830,7 +832,8 @@ def main():
         overhead_ms_samples = [tc.elapsed_ms() for _, tc in sample_timers]
     # median over the sampled launches: robust against the occasional preempted / cold sample
     launches_per_sample = TIMED_LAUNCHES if graph is not None else 1
-    raw_ms = median(kernel_ms_samples)                 # interval around `launches_per_sample` launches
+    raw_ms = sorted(kernel_ms_samples)[(len(kernel_ms_samples) - 1) // 2]      # (lower) median of the intervals around `launches_per_sample` launches
+    _phase('relfeat samples (ms): ' + ', '.join(f'{v:.4f}' for v in kernel_ms_samples))
     overhead_ms = median(overhead_ms_samples)
     kernel_ms = max(raw_ms - overhead_ms, 1e-6) / launches_per_sample
     pairs_step = N_real * (N_real + M_eff)             # all ranks together (absent padding agents are not counted)
