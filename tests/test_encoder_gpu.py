@@ -597,6 +597,7 @@ def test_split_tile_x3_backward_is_bitwise_the_one_wave_x3_backward(agents, drop
 @pytest.mark.parametrize('shapes,upstream,drop', [
     ([(4096, 6, 6), (4096, 10, 6)], 'pooled', False), ([(4096, 6, 6), (4096, 10, 6)], 'both', True),
     ([(5000, 7, 5), (3001, 5, 8)], 'msgs', False), ([(9000, 5, 6)], 'both', False), ([(4100, 9, 6), (4100, 9, 6)], 'mixed', True),
+    ([(8192, 6, 6), (8192, 10, 6)], 'pooled', True),          # a rank's share of the 16384-agent scene on two GPUs: 2 tiles per wave
 ])
 @pytest.mark.parametrize('recompute', [True, False])
 def test_layer_split_weight_gradients(shapes, upstream, drop, recompute, monkeypatch):
