@@ -568,7 +568,9 @@ int piml_decoder_bwd(const piml_decoder_branch* branches, int nbranches, const f
 /*
  * Collision head of `pinnsf_m` (src/models/model.py:1246, 1296-1300): out[row] = sigmoid(w2 . relu(W1 msgs[row] + b1)
  * + b2), msgs (rows, 128), W1 (64, 128), w2 (1, 64); forward only.  `packed`: piml_collision_head_pack_floats()
- * floats of scratch.
+ * floats of scratch.  The 128 -> 64 layer runs as f32 arithmetic on split bf16 products like the encoder layers
+ * (piml_amd/csrc/decoder.hip: head_fwd_body_x3; environment PIML_HEAD_PRODUCTS=f32 at load time: the f32 matrix
+ * instruction); both stay within 1e-6 of float64 (tests/test_encoder_gpu.py).
  */
 /*
  * The bottleneck variants (`pinnsf_bottleneck`, `pinnsf_bm`, src/models/model.py:1062-1221) apply decoder + predictor to

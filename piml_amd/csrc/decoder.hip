@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "pack.hpp"
 #include "stages.hpp"
+#include "x3.hpp"
 #include "../../include/piml_hip.h"
 
 namespace piml {
@@ -1044,9 +1045,85 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, lo
     if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + bias[64])));
 }
 
+// Layer 1 (128 -> 64) as SPLIT bf16 PRODUCTS (x3.hpp: f32 = hi + mid + lo, six products per k-block, f32 accumulation with
+// the small terms apart -- the encoder layers' arithmetic): 96 matrix instructions of 32 cycles per wave instead of a chain
+// of 128 f32 ones of 64.  The head's waves share their SIMDs with the decoder chains of the same launch, and those chains
+// wait for the matrix pipe: the launch took 3.1 us less without the head's matrix instructions (variant build).  The row's
+// 128 values are split once (lane (row, g): features 16 kb + 8 g + t of k-block kb, the order of the packed W1 pieces);
+// W1's pieces stream from the packed image (L2), one k-block ahead.  PIML_HEAD_PRODUCTS=f32 keeps the f32 instruction.
+template <int WAVES = 4>
+__device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs, long long rows,
+                                                 const float* __restrict__ packed, float* __restrict__ out, long long bx) {
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    const long long row = (bx * WAVES + wave) * 32 + j;
+    if ((bx * WAVES + wave) * 32 >= rows) return;
+    const bool valid = row < rows;
+    const float* bias = packed + HP_B;
+    const u32x4* W = reinterpret_cast<const u32x4*>(packed + HP_X3) + lane;      // [ob][kb][piece] 64 apart
+    u32x4 wf[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wf[0][p] = W[p * 64];
+    u32x4 xh[8], xm[8], xl[8];
+    {
+        const float* base = msgs + (valid ? row : 0) * DH + 8 * h;
+        float4 v[8][2];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            v[kb][0] = *reinterpret_cast<const float4*>(base + 16 * kb);
+            v[kb][1] = *reinterpret_cast<const float4*>(base + 16 * kb + 4);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            unsigned hi[4], mid[4], lo[4];
+            split3(v[kb][0].x, v[kb][0].y, hi[0], mid[0], lo[0]);
+            split3(v[kb][0].z, v[kb][0].w, hi[1], mid[1], lo[1]);
+            split3(v[kb][1].x, v[kb][1].y, hi[2], mid[2], lo[2]);
+            split3(v[kb][1].z, v[kb][1].w, hi[3], mid[3], lo[3]);
+            xh[kb] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+            xm[kb] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+            xl[kb] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob) {
+        f32x16 acc, sm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const int g = ob * 8 + kb;
+            if (g + 1 < 16) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[(g + 1) & 1][p] = W[((g + 1) * 3 + p) * 64];
+            }
+            kblock_x3(acc, sm, wf[g & 1][0], wf[g & 1][1], wf[g & 1][2], xh[kb], xm[kb], xl[kb]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w2 = *reinterpret_cast<const float4*>(packed + HP_W2 + dfeat0(ob, q, h));
+            dot += w2.x * fmaxf(acc[4 * q] + sm[4 * q], 0.f) + w2.y * fmaxf(acc[4 * q + 1] + sm[4 * q + 1], 0.f) +
+                   w2.z * fmaxf(acc[4 * q + 2] + sm[4 * q + 2], 0.f) + w2.w * fmaxf(acc[4 * q + 3] + sm[4 * q + 3], 0.f);
+        }
+    }
+    dot += __shfl_xor(dot, 32, 64);
+    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + bias[64])));
+}
+
+// PIML_HEAD_PRODUCTS=f32: the collision head's 128 -> 64 layer on the f32 matrix instruction (A/B); default: split bf16 products
+static const bool g_head_x3 = !(getenv("PIML_HEAD_PRODUCTS") && getenv("PIML_HEAD_PRODUCTS")[0] == 'f');
+
+template <bool X3>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ msgs, long long rows,
                                                        const float* __restrict__ packed, float* __restrict__ out) {
-    head_fwd_body(msgs, rows, packed, out, blockIdx.x);
+    if (X3) head_fwd_body_x3(msgs, rows, packed, out, blockIdx.x);
+    else head_fwd_body(msgs, rows, packed, out, blockIdx.x);
 }
 
 
@@ -1113,13 +1190,17 @@ int piml::dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s) 
 // The decoder tails (incl. their neighbour-axis sums) and the collision head in ONE launch: both consume the encoders'
 // messages and nothing of each other.  Blocks [0, dec_blocks) are (32-agent tile, branch) units, the rest head blocks of
 // 4 x 32 message rows.  `acc` must be zero on entry when there are two branches (enc_stage_fwd clears it on the way).
-__global__ __launch_bounds__(256) void dec_fwd_head_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
+// (two waves per SIMD: decoder and head workgroups of one launch are all resident at once -- 448 x 4 waves at the 4096-agent
+// scene; left alone the compiler gives the split-product head 64 accumulation registers on top of the decoder body's 224)
+template <bool X3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_fwd_head_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
     const int bx = blockIdx.x;
     if (bx < dec_blocks) {
         if (A.nbr > 1) dec_fwd_body<true, true>(A, bx >> 1, bx & 1);
         else dec_fwd_body<true, true>(A, bx, 0);
     } else {
-        head_fwd_body<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+        if (X3) head_fwd_body_x3<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+        else head_fwd_body<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
     }
 }
 
@@ -1139,7 +1220,8 @@ int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml
     A.tau = tau;
     A.acc = acc;
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
-    hipLaunchKernelGGL(dec_fwd_head_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    if (g_head_x3) hipLaunchKernelGGL(dec_fwd_head_kernel<true>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    else hipLaunchKernelGGL(dec_fwd_head_kernel<false>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
 
@@ -1210,7 +1292,8 @@ int piml::head_stage_fwd(const piml_collision_head* h, hipStream_t s) {
     if (int e = head_check(h)) return e;
     if (h->rows == 0) return hipSuccess;
     const long long tiles = (h->rows + 31) / 32;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, h->msgs, h->rows, h->packed, h->out);
+    if (g_head_x3) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, h->msgs, h->rows, h->packed, h->out);
+    else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, h->msgs, h->rows, h->packed, h->out);
     return hipGetLastError();
 }
 

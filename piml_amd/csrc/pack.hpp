@@ -140,10 +140,14 @@ __device__ __forceinline__ float dec_pack_value(const piml_decoder_branch& J, in
     }
 }
 
-// collision head: A1 [ob 2][bp 4][q 4][lane 64] float4 (W1 fragments) | b1 64 | b2 1 + 3 pad | w2 64 (raw row)
+// collision head: A1 [ob 2][bp 4][q 4][lane 64] float4 (W1 fragments for the f32 matrix instruction) | b1 64 | b2 1 + 3 pad |
+// w2 64 (raw row) | W1 split into bf16 pieces for the split-product form: [ob 2][kb 8][piece 3][lane 64] u32x4 -- lane
+// (i, g) holds W1[32 ob + i][16 kb + 8 g + t], t = 0 .. 7, packed pairwise
 constexpr int HP_B = 2 * 4 * 4 * 256;
 constexpr int HP_W2 = HP_B + 68;
-constexpr int HEAD_PACK = HP_W2 + 64;
+constexpr int HP_X3 = HP_W2 + 64;
+constexpr int HEAD_PACK = HP_X3 + 2 * 8 * 3 * 256;
+static_assert(HP_X3 % 4 == 0, "16-byte aligned fragments");
 
 __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, const float* __restrict__ b1,
                                                  const float* __restrict__ w2, const float* __restrict__ b2, int e) {
@@ -152,6 +156,14 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
         const int bp = rest & 3, ob = rest >> 2;
         const int i = 32 * ob + (lane & 31), c = 32 * bp + 8 * q + 4 * (lane >> 5) + u;
         return w1[(size_t)i * DH + c];
+    }
+    if (e >= HP_X3) {
+        const int x = e - HP_X3, d = x & 3, lane = (x >> 2) & 63, rest = x >> 8;
+        const int piece = rest % 3, kb = (rest / 3) & 7, ob = rest / 24;
+        const int i = 32 * ob + (lane & 31), c = 16 * kb + 8 * (lane >> 5) + 2 * d;
+        unsigned hi, mid, lo;
+        split3(w1[(size_t)i * DH + c], w1[(size_t)i * DH + c + 1], hi, mid, lo);
+        return __uint_as_float(piece == 0 ? hi : (piece == 1 ? mid : lo));
     }
     if (e >= HP_W2) return w2[e - HP_W2];
     const int g = e - HP_B;
