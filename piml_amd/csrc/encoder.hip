@@ -988,10 +988,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
 
 // Layer-split weight gradients (encoder_dw2.hip): split products, the one-wave path (more than piml_encoder_split_tiles()
 // tiles), both branches with the same kinds of upstream gradients / keep bits / h1, at least two workgroups per branch.
-// PIML_ENC_DW2=0 keeps enc_bwd_dw_x3_kernel (A/B).
-// PIML_ENC_DW_WIDE=0: the slab weight-gradient kernel with per-feature dword staging loads (enc_bwd_dw_x3_kernel) instead
-// of the wide-load form (encoder_dww.hip); same sums, A/B switch
-static const bool g_dw_wide = !(getenv("PIML_ENC_DW_WIDE") && atoi(getenv("PIML_ENC_DW_WIDE")) == 0);
+// PIML_ENC_DW2=0 keeps the slab kernel of encoder_dww.hip at every size (A/B).
 static int g_dw2 = !(getenv("PIML_ENC_DW2") && atoi(getenv("PIML_ENC_DW2")) == 0);
 
 PIML_API int piml_encoder_dw2(int on) {
@@ -1053,14 +1050,13 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
     }
     if (g_x3)
         if (int e = x3_ready()) return e;
-    if (g_x3 && g_dw_wide) {
+    if (g_x3) {
         static int wide_ready = -1;
         if (wide_ready < 0) wide_ready = enc_dww_set_attributes();
         if (wide_ready) return wide_ready;
     }
     auto launch_dw = [&](const EncArgs& B, int grid) {
-        if (g_x3 && g_dw_wide) return enc_dww_launch(B, grid, B.br[0].keep_bits != nullptr, s);
-        if (g_x3) return enc_x3_launch_bwd_dw(B, grid, B.br[0].keep_bits != nullptr, s);
+        if (g_x3) return enc_dww_launch(B, grid, B.br[0].keep_bits != nullptr, s);
         const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
         if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, true>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);
         else if (pool) hipLaunchKernelGGL((enc_bwd_dw_kernel<true, false>), dim3(grid), dim3(ENC_THREADS), DW_LDS_FLOATS * 4, s, B);

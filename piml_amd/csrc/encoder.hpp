@@ -63,7 +63,6 @@ void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);  
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask
-void enc_x3_launch_bwd_dw(const EncArgs& A, int grid, bool drop, hipStream_t s);      // kernel variant from A.br[0]'s upstream pointers
 
 // encoder_dw2.hip: the weight gradients as layer-split workgroups (half the partial bytes, h1 recomputed when absent)
 int enc_dww_set_attributes();                                                          // encoder_dww.hip: the same slabs, wide staging loads

@@ -5,7 +5,7 @@
 //     dW3 = G3^T H2, db3 = colsum G3        G3 = keep * scale * (g_pooled[row / k] + g_msgs[row])
 //     dW2 = G2^T H1, db2 = colsum G2        H1 = relu(W1 x + b1)
 //     dW1 = G1^T X,  db1 = colsum G1
-// The slab kernels (enc_bwd_dw_x3_kernel, enc_bwd_dw_x3w_kernel) give every workgroup BOTH 128 x 128 products and let every
+// The slab kernel (enc_bwd_dw_x3w_kernel, encoder_dww.hip) gives every workgroup BOTH 128 x 128 products and lets every
 // wave do everything in turn -- load, split into bf16 pieces, write to LDS, barrier, products -- so the phases of a batch
 // add up (s_memtime: ~5 000 cycles per 16 rows, of which the matrix pipe works 1 500), whatever the instruction scheduling.
 // Here

@@ -1,17 +1,26 @@
-// Weight gradients of the PINNSF encoder on split bf16 products: the slab kernel with WIDE staging loads (round 3).
+// Weight gradients of the PINNSF encoder on split bf16 products: the SLAB kernel (few rows; wide staging loads, round 3).
 //
 // Reference arithmetic: the autograd of MLP(in, [128, 128, 128]) (src/models/model.py:40-65) under the processor
 // Dropout_p(2 x) and the neighbour-axis sum (:82-119, :1279-1283):
 //     dW3 = G3^T H2, db3 = colsum G3        G3 = keep * scale * (g_pooled[row / k] + g_msgs[row])
 //     dW2 = G2^T H1, db2 = colsum G2
 //     dW1 = G1^T X,  db1 = colsum G1
-// Same decomposition, products, accumulators and partial slots as enc_bwd_dw_x3_kernel (encoder_x3.hip): a workgroup owns
-// a row slab, a batch is 16 rows = one k-block, wave (L, iq, jq) owns the output blocks {2 iq, 2 iq + 1} x {2 jq, 2 jq + 1}
-// of layer L.  What differs is how a batch gets from memory into the operand fragments.  There a staging thread owns one
-// feature and loads eight rows of it with eight dword loads (a fragment entry = 8 rows of ONE feature): 21 load
-// instructions per wave and batch, 256 bytes each, and the CU's address unit -- not the matrix pipe -- set the pace.
+// A workgroup owns a row slab and both layers: split-K over slabs, one partial slot per workgroup in enc_bwd_dw_kernel's layout
+// (encoder.hip; the same slot sum afterwards).  Both operands of a product are data, so both are split into their three
+// bf16 pieces on the way into LDS, per buffer (u32x4): [array 4: G3 G2 H2 H1][piece 3][block 4][lane 64] = 48 KB + the
+// batch's x rows; two buffers; a batch is 16 rows = one k-block; wave (L, iq, jq) owns the output blocks {2 iq, 2 iq + 1} x
+// {2 jq, 2 jq + 1} of layer L (main + small accumulators: 128 registers), 24 matrix instructions a batch; dW1 / db1 on the
+// vector pipe by feature.  Every load goes through a buffer resource over the slab with the (wave-uniform) row in the
+// SCALAR offset: no address arithmetic on the vector pipe, rows past the slab answered with zeros by the range check.
+// History (round 2 form, removed in round 3): a staging thread owned one feature and loaded eight rows of it with eight
+// dword loads (a fragment entry = 8 rows of ONE feature) -- 21 load instructions per wave and batch, 256 bytes each, and
+// the CU's address unit, not the matrix pipe, set the pace (s_memtime, wave 0, per batch: load issue 1 950 cycles as a
+// burst, products 1 980, split + LDS writes 1 250, barrier 320; the loads were then issued BETWEEN the products, as they
+// still are here).  Measured on that form and dropped, all within +-3 us: loads two batches ahead in two register sets,
+// the two waves of a SIMD taking the phases of a barrier interval in opposite order, one scalar offset per 8-row unit.
 // Here a thread loads FOUR consecutive features of four rows with four 16-byte loads (a wave instruction = two whole
-// rows, 1 KB) and writes, per feature, the three pieces of its four rows as half a fragment entry (ds_write_b64).  For
+// rows, 1 KB) and writes, per feature, the three pieces of its four rows as half a fragment entry (ds_write_b64): 9 load
+// instructions per wave and batch, 46 -> 42 us at the 4096-agent scene.  For
 // those writes to be conflict-free the features of a thread must land in four DIFFERENT blocks at the SAME lane slot, so
 // the operand features are dealt round-robin:
 //     feature f  <->  block f & 3, slot f >> 2             (instead of block f >> 5, slot f & 31)
@@ -49,7 +58,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3w_kernel(EncArgs A) 
     // staging role: array sa (0: G3, 1: G2, 2: H2, 3: H1), row half hh of the batch; lane (fi, rsub): features 4 fi .. 4 fi + 3
     // of rows 8 hh + 4 rsub .. + 3.  (sa, hh: wave-uniform.)
     const unsigned sa = wave >> 1, hh = wave & 1, fi = lane & 31, rsub = lane >> 5;
-    // dW1 / db1 role (as in enc_bwd_dw_x3_kernel): feature sf, rows 4 rg .. 4 rg + 3 of the batch
+    // dW1 / db1 role: feature sf, rows 4 rg .. 4 rg + 3 of the batch
     const unsigned sf = tid & 127, rg = wave >> 1;
     float sb[4] = {0.f, 0.f, 0.f, 0.f};          // bias sums of this thread's four features (db3 on array 0, db2 on array 1)
     float s1 = 0.f;

@@ -789,252 +789,8 @@ __global__ __launch_bounds__(512) void enc_bwd_dx_split_x3_kernel(EncArgs A, int
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// backward, part 2: dW3 = G3^T H2, dW2 = G2^T H1 (split products), dW1 = G1^T X and the bias gradients (vector pipe),
-// split-K over row slabs, one partial slot per workgroup in enc_bwd_dw_kernel's layout (same slot sum afterwards).
-// ---------------------------------------------------------------------------------------------------------
-// A batch is 16 rows = ONE k-block.  Both operands of a product are data here, so both are split on the way into LDS: a
-// staging thread owns (feature f, row half hh) of a G-side and an H-side array -- eight rows of one column, loaded with
-// eight coalesced dword loads -- and writes their three pieces as the fragment entry of lane (f & 31) + 32 hh of feature
-// block f >> 5 (A operand: G^T, B operand: H; element t of both = row 8 hh + t of the batch).  LDS, per buffer (u32x4):
-// [array 4: G3 G2 H2 H1][piece 3][block 4][lane 64] = 48 KB + the batch's x rows (128 floats); two buffers.
-// Wave (L, iq, jq): layer L (0: dW3, 1: dW2), output blocks {2 iq, 2 iq + 1} x {2 jq, 2 jq + 1}: 24 instructions a batch.
-
-template <bool POOL, bool MSGS, bool DROP>
-__global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_x3_kernel(EncArgs A) {
-    extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
-    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
-    const int wg0 = b ? A.wg_split : 0;
-    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
-    const unsigned p = (unsigned)((int)blockIdx.x - wg0);
-    const unsigned R = (unsigned)J.rows;                   // rows < 2^24 (checked on the host): 32-bit indexing
-    const unsigned IN = __builtin_amdgcn_readfirstlane((unsigned)J.in_dim), K = __builtin_amdgcn_readfirstlane((unsigned)J.k);
-    const unsigned kmagic = __builtin_amdgcn_readfirstlane((unsigned)((0x100000000ull + K - 1) / K));      // row / K == umulhi(row, kmagic) for row * K < 2^32
-    unsigned slab = (R + nwg - 1) / nwg;
-    slab = (slab + 1) & ~1u;
-    // every quantity a scalar offset is built from is declared wave-uniform: what the compiler cannot prove uniform it
-    // wraps into a waterfall loop per load (and shuffles the accumulators around it)
-    const unsigned r0 = __builtin_amdgcn_readfirstlane(p * slab < R ? p * slab : R);
-    const unsigned r1 = __builtin_amdgcn_readfirstlane(r0 + slab < R ? r0 + slab : R);
-    const float scale = J.scale;
-    const int L = wave >> 2, iq = (wave >> 1) & 1, jq = wave & 1;
-
-    f32x16 c[2][2], sm[2][2];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { c[u >> 1][u & 1][r] = 0.f; sm[u >> 1][u & 1][r] = 0.f; }
-    // staging role: feature sf, row half sh; waves 0-3 own the G side (G3, G2) and the bias sums, waves 4-7 the H side
-    const unsigned sf = tid & 127, sh = (wave >> 1) & 1;          // sh, rg: wave-uniform (a wave = 64 consecutive features)
-    const bool gside = wave < 4;
-    const unsigned slot = (sf >> 5) * 64 + (sf & 31) + 32 * sh;
-    // dW1 / db1 role: feature sf, rows 4 rg .. 4 rg + 3 of the batch
-    const unsigned rg = wave >> 1;
-    float s3 = 0.f, s2 = 0.f, s1 = 0.f;
-    float w1[8];
-#pragma unroll
-    for (int cc = 0; cc < 8; ++cc) w1[cc] = 0.f;
-    // Every load goes through a buffer resource whose range is this workgroup's slab (base = first row of the slab,
-    // num_records = its bytes) with the row as the SCALAR offset: rows are wave-uniform here (a wave = 64 features of the
-    // same rows), so the addressing costs no vector instruction at all, and a row past the slab gets the offset
-    // num_records, which the hardware range check (offset >= num_records - scalar offset) answers with 0.  (The vector
-    // pipe, not the matrix pipe, was this kernel's first limit: 338 vector instructions per wave and batch with per-lane
-    // addressing, against 24 matrix instructions.)
-    const unsigned srows = r1 - r0, sbytes = srows * EH * 4;
-    auto rsrc = [&](const float* base, unsigned first, unsigned bytes) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + first), 0, (int)bytes, 0x00020000);
-    };
-    const bool pooled0 = gside && POOL;                         // G3 from the per-agent gradient: row / k into the whole array
-    const unsigned pbytes = (R / K) * EH * 4;
-    const float* a0 = gside ? (POOL ? J.g_pooled : J.g_msgs) : J.h2;
-    const __amdgpu_buffer_rsrc_t rs0 = pooled0 ? rsrc(a0, 0, pbytes) : rsrc(a0, r0 * EH, sbytes);
-    const __amdgpu_buffer_rsrc_t rsm = rsrc((POOL && MSGS) ? J.g_msgs : J.g2, r0 * EH, sbytes);
-    const __amdgpu_buffer_rsrc_t rs1 = rsrc(gside ? J.g2 : J.h1, r0 * EH, sbytes);
-    const __amdgpu_buffer_rsrc_t rsg = rsrc(J.g1, r0 * EH, sbytes);
-    const __amdgpu_buffer_rsrc_t rsx = rsrc(J.x, r0 * IN, srows * IN * 4);
-    // dropout: the keep word of (row, feature block sf >> 5), 16 bytes per row (G side only: g3 = keep * scale * (...))
-    const unsigned kbytes = srows * 16;
-    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned*>(DROP ? J.keep_bits + (size_t)r0 * 4 : nullptr), 0, (int)(DROP ? kbytes : 0u), 0x00020000);
-    const unsigned xvoff = (tid < 128 && (unsigned)(tid & 7) < IN) ? ((tid >> 3) * IN + (tid & 7)) * 4 : 0x7fff0000u;
-    auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
-    };
-
-    unsigned pidx0 = __umulhi(r0 + 8 * sh, kmagic), prem0 = r0 + 8 * sh - pidx0 * K;      // of row r0 + 8 sh
-    const unsigned q16 = __umulhi(16u, kmagic), m16 = 16u - q16 * K;                       // 16 / k, 16 % k
-    struct Stage { float a[8], m[8], v[8], g1[4], x; unsigned kw[8]; };
-    auto stage_load = [&](unsigned rb_) -> Stage {           // issue the loads of the batch starting at row rb
-        Stage S;
-        const unsigned rb = __builtin_amdgcn_readfirstlane(rb_);       // uniform; said so (else: a waterfall loop per scalar offset)
-        // agent (row / k) of the unit's first row, kept incrementally: the batches are requested in row order, 16 rows apart
-        // (a multiply-high per load here, scalar as it is, sent the register allocation into ~200 spills)
-        unsigned pidx = pidx0, prem = prem0;
-        if (POOL) {
-            pidx0 += q16; prem0 += m16;
-            if (prem0 >= K) { prem0 -= K; ++pidx0; }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const unsigned row = rb + 8 * sh + t;                       // scalar
-            const unsigned rel = row < r1 ? (row - r0) * (EH * 4) : sbytes;
-            const unsigned pi = __builtin_amdgcn_readfirstlane(pidx);     // (the compiler keeps the stepped index on the vector pipe)
-            const unsigned off0 = pooled0 ? (row < r1 ? pi * (EH * 4) : pbytes) : rel;
-            S.a[t] = ld(rs0, sf * 4, off0);
-            if (POOL) {                                                 // row + 1: the agent index steps when the remainder wraps
-                ++prem;
-                if (prem == K) { prem = 0; ++pidx; }
-            }
-            S.m[t] = 0.f;
-            if (POOL && MSGS)
-                if (gside) S.m[t] = ld(rsm, sf * 4, rel);
-            S.v[t] = ld(rs1, sf * 4, rel);
-            S.kw[t] = 0u;
-            if (DROP)
-                if (gside) S.kw[t] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsk, (int)((sf >> 5) * 4), (int)(row < r1 ? (row - r0) * 16 : kbytes), 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned row = rb + 4 * rg + t;
-            S.g1[t] = ld(rsg, sf * 4, row < r1 ? (row - r0) * (EH * 4) : sbytes);
-        }
-        S.x = ld(rsx, xvoff, rb < r1 ? (rb - r0) * IN * 4 : srows * IN * 4);
-        return S;
-    };
-    float gq[4];                                             // g1 values of the batch in the compute phase
-    auto stage_write = [&](const Stage& S, float* buf) {     // registers -> split -> LDS
-        u32x4* B = reinterpret_cast<u32x4*>(buf);
-        float u0[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) u0[t] = gside ? (S.a[t] + S.m[t]) * scale : S.a[t];
-        if (DROP && gside) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) u0[t] = ((S.kw[t] >> (sf & 31)) & 1u) ? u0[t] : 0.f;
-        }
-        if (gside) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { s3 += u0[t]; s2 += S.v[t]; }
-        }
-        unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) split3(u0[2 * d], u0[2 * d + 1], hi[d], mid[d], lo[d]);
-        u32x4* d0 = B + (gside ? 0 : 2) * DWX_ARR + slot;
-        d0[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-        d0[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
-        d0[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) split3(S.v[2 * d], S.v[2 * d + 1], hi[d], mid[d], lo[d]);
-        u32x4* d1 = d0 + DWX_ARR;
-        d1[0] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-        d1[256] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
-        d1[512] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
-        if (tid < 128) buf[4 * DWX_ARR * 4 + tid] = S.x;
-    };
-    auto take_g1 = [&](const Stage& S) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) gq[t] = S.g1[t];
-    };
-    auto compute = [&](const float* buf) {
-        const u32x4* B = reinterpret_cast<const u32x4*>(buf);
-        const u32x4* Ap = B + (L ? 1 : 0) * DWX_ARR + (2 * iq) * 64 + lane;
-        const u32x4* Bp = B + (L ? 3 : 2) * DWX_ARR + (2 * jq) * 64 + lane;
-        u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ah[u] = Ap[u * 64]; am[u] = Ap[256 + u * 64]; al[u] = Ap[512 + u * 64];
-            bh[u] = Bp[u * 64]; bm[u] = Bp[256 + u * 64]; bl[u] = Bp[512 + u * 64];
-        }
-#pragma unroll
-        for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) kblock_x3(c[ia][jb], sm[ia][jb], ah[ia], am[ia], al[ia], bh[jb], bm[jb], bl[jb]);
-        // dW1 / db1: rows 4 rg .. 4 rg + 3 of the batch
-        const float4* xr = reinterpret_cast<const float4*>(buf + 4 * DWX_ARR * 4 + rg * 32);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 xa = xr[2 * t], xb = xr[2 * t + 1];
-            const float g = gq[t];
-            w1[0] = __fmaf_rn(g, xa.x, w1[0]); w1[1] = __fmaf_rn(g, xa.y, w1[1]);
-            w1[2] = __fmaf_rn(g, xa.z, w1[2]); w1[3] = __fmaf_rn(g, xa.w, w1[3]);
-            w1[4] = __fmaf_rn(g, xb.x, w1[4]); w1[5] = __fmaf_rn(g, xb.y, w1[5]);
-            w1[6] = __fmaf_rn(g, xb.z, w1[6]); w1[7] = __fmaf_rn(g, xb.w, w1[7]);
-            s1 += g;
-        }
-    };
-    if (r0 < r1) {
-        const unsigned nb = (r1 - r0 + DW_X3_ROWS - 1) / DW_X3_ROWS;
-        // One batch of loads ahead, issued between the products (below).  Phases of a batch by s_memtime (wave 0, before that):
-        // load issue 1 950 cycles, products 1 980, split + LDS writes 1 250, barrier 320.  Measured and dropped, all within
-        // +-3 us of this form (42 us, 175 MB = 4.1 TB/s): loads two batches ahead in two register sets (loop unrolled by two,
-        // vmcnt(40) waits), with and without the next batch's split scheduled into this batch's products; the two waves of a
-        // SIMD taking the split / write and the product phase in opposite order; h1 recomputed from x instead of read
-        // (33 MB less, 64 FMAs per unit more: slower); one scalar offset per 8-row unit + immediates.
-        {
-            const Stage S = stage_load(r0);
-            stage_write(S, lds);
-            take_g1(S);
-        }
-        __syncthreads();
-        for (unsigned t = 0; t < nb; ++t) {
-            float* cur = lds + (t & 1) * DWX_BUF * 4;
-            float* nxt = lds + ((t + 1) & 1) * DWX_BUF * 4;
-            // The next batch's 21 loads are issued BETWEEN this batch's products: as a burst in front of them they took as long
-            // as the products themselves (s_memtime, wave 0: 1 950 cycles of issue, 8 waves' loads queueing at the CU's one
-            // address unit, then 1 980 cycles of products with that unit idle).  Nothing of the loaded values is touched
-            // before the fence below (their arithmetic would be awaited).
-            const Stage S2 = stage_load(r0 + (t + 1) * DW_X3_ROWS);
-            compute(cur);
-            __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);          // fragment + x reads
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one product
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one load
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            stage_write(S2, nxt);
-            take_g1(S2);
-            __syncthreads();
-        }
-    }
-    float* P = J.partials + (size_t)p * ENC_PART;
-    const int n = lane & 31, h = lane >> 5;
-    // accumulator (ia, jb), register r, lane (n, h): dW[32 (2 iq + ia) + (r & 3) + 8 (r >> 2) + 4 h][32 (2 jq + jb) + n]
-#pragma unroll
-    for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int orow = 32 * (2 * iq + ia) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                P[L * 16384 + (size_t)orow * EH + 32 * (2 * jq + jb) + n] = c[ia][jb][r] + sm[ia][jb][r];
-            }
-    // dW1 and the bias gradients: partial sums of the row groups / row halves meet in LDS (the batch buffers are dead)
-    __syncthreads();
-    {
-        float* red = lds + (rg * 128 + sf) * 9;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) red[cc] = w1[cc];
-        red[8] = s1;
-        float* red2 = lds + DWX_RED + (sh * 128 + sf) * 2;
-        if (gside) { red2[0] = s3; red2[1] = s2; }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        float acc[9];
-#pragma unroll
-        for (int cc = 0; cc < 9; ++cc)
-            acc[cc] = (lds[(0 * 128 + tid) * 9 + cc] + lds[(1 * 128 + tid) * 9 + cc]) + (lds[(2 * 128 + tid) * 9 + cc] + lds[(3 * 128 + tid) * 9 + cc]);
-        float* o = P + 32768 + tid * IN;                  // dW1 row-major (128, in_dim) at the head of its 1024 floats
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-            if ((unsigned)cc < IN) o[cc] = acc[cc];
-        P[32768 + 1024 + 256 + tid] = acc[8];
-        P[32768 + 1024 + tid] = lds[DWX_RED + tid * 2] + lds[DWX_RED + (128 + tid) * 2];
-        P[32768 + 1024 + 128 + tid] = lds[DWX_RED + tid * 2 + 1] + lds[DWX_RED + (128 + tid) * 2 + 1];
-    }
-}
+// (backward, part 2 -- the weight gradients dW = G^T H on split products -- lives in encoder_dww.hip (row slabs, both layers per
+// workgroup: few rows) and encoder_dw2.hip (layer-split workgroups of producer / consumer waves: above the few-rows bound).)
 
 int enc_x3_set_attributes() {
     auto set = [](const void* f, int bytes) { return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
@@ -1043,14 +799,6 @@ int enc_x3_set_attributes() {
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<0>), X3_SPLIT_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<1>), X3_SPLIT_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_split_x3_kernel<2>), X3_SPLIT_LDS_BYTES)) return e;
-    const void* dw[6] = {reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true, false>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false, false>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true, false>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, true, true>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<true, false, true>),
-                         reinterpret_cast<const void*>(enc_bwd_dw_x3_kernel<false, true, true>)};
-    for (const void* f : dw)
-        if (int e = set(f, DWX_LDS_BYTES)) return e;
     const void* dx[4] = {reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false, false>),
                          reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true, false>),
                          reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<false, true>),
@@ -1069,20 +817,6 @@ void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hip
     else if (mask) hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<true, false>), g, b, X3_DX_LDS_BYTES, s, A);
     else if (drop) hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<false, true>), g, b, X3_DX_LDS_BYTES, s, A);
     else hipLaunchKernelGGL((enc_bwd_dx_x3_kernel<false, false>), g, b, X3_DX_LDS_BYTES, s, A);
-}
-
-void enc_x3_launch_bwd_dw(const EncArgs& B, int grid, bool drop, hipStream_t s) {
-    const bool pool = B.br[0].g_pooled != nullptr, msgs = B.br[0].g_msgs != nullptr;
-    const dim3 g(grid), b(ENC_THREADS);
-    if (drop) {
-        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true, true>), g, b, DWX_LDS_BYTES, s, B);
-        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false, true>), g, b, DWX_LDS_BYTES, s, B);
-        else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true, true>), g, b, DWX_LDS_BYTES, s, B);
-    } else {
-        if (pool && msgs) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, true, false>), g, b, DWX_LDS_BYTES, s, B);
-        else if (pool) hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<true, false, false>), g, b, DWX_LDS_BYTES, s, B);
-        else hipLaunchKernelGGL((enc_bwd_dw_x3_kernel<false, true, false>), g, b, DWX_LDS_BYTES, s, B);
-    }
 }
 
 void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void kblock_x3(f32x16& acc, f32x16& small, u32x4 wh, 
     acc = mfma_bf(wh, xh, acc);
 }
 
-// batch geometry of the slab weight-gradient kernels (enc_bwd_dw_x3_kernel, enc_bwd_dw_x3w_kernel)
+// batch geometry of the slab weight-gradient kernel (enc_bwd_dw_x3w_kernel, encoder_dww.hip)
 constexpr int DW_X3_ROWS = 16;
 constexpr int DWX_ARR = 3 * 256;                       // u32x4 of one array's three pieces
 constexpr int DWX_BUF = 4 * DWX_ARR + 32;              // + x rows [16][8] floats
