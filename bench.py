@@ -869,7 +869,7 @@ def main():
             dw = 'dw2'
     stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
                     'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
-                    'enc_bwd_dw': f'enc_bwd_{dw}{x3}_kernel', 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
+                    'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
     static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
     if os.environ.get('PIML_DEC_BWD_SPLIT', '1') != '0':       # decoder backward as (tile, branch) workgroups (the default)
         stage_kernel['dec_bwd'] = 'dec_bwd_split_kernel'

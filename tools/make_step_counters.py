@@ -56,6 +56,7 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'enc_fwd_x3_kernel': 2 * ROWS * (6 * 128 + 2 * 128 * 128),
     'enc_bwd_dx_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'enc_bwd_dw_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
+    'enc_bwd_dw_x3w_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'enc_bwd_dw2_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),      # (+ the recomputed layer 1: f32 instructions, not counted)
     'dec_fwd_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dx_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
