@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 14
+#define PIML_HIP_ABI_VERSION 15
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -201,6 +201,28 @@ int piml_collision_friends(float* coll, const float* base, int C, int T, int S_b
  * counts (n_thresholds, S, N), overwritten.  Callers: src/models/simulators.py:708-724,
  * src/functions/metrics.py:16-26.
  */
+/*
+ * Rollout losses of the fine-tuning step (src/models/simulators.py:172-249 as assembled at :790-819), forward and the
+ * gradient fields in ONE launch:  p (C, T, N, 2) predicted positions; labels (C, T, N, labels_ld) with the label position in
+ * columns 0-1; mask_pred (C, T, N) int64 (!= 0: the agent is predicted in that frame); gates (T) bytes (!= 0: the frame has
+ * a predicted agent at all); collisions / hard_collisions (C, T, N) counts or NULL; abnormal_mask (N) or NULL.
+ *   p_res = where(mask & gate, p, 0), lab = where(mask, labels[..., :2], 0), decay_t = time_decay^(T - 1 - t)
+ *   out[0] = sum (p_res - lab)^2 decay_t                                       (multiple_rollout_mse_loss, reduction 'sum')
+ *   out[1] = sum [sum_t collisions > 0] abnormal ((p_res - (p_res.n) n) - (lab - (lab.n) n))^2 decay_t,
+ *            n = (lab[T-1] - lab[0]) / (|.| + 1e-6)                            (multiple_rollout_collision_loss, 'sum')
+ *   out[2] = the same with hard_collisions
+ * g_mse / g_coll / g_hard (C, T, N, 2) = d out[i] / d p.  piml_rollout_losses_bwd: g_p = sum_i g_out[i] * g_i.  The sums
+ * run in a fixed order.  partial: 3 * piml_rollout_losses_blocks(C, N) floats, ticket: one zeroed unsigned (left zero);
+ * both only used when piml_rollout_losses_blocks(C, N) > 1.
+ */
+int piml_rollout_losses_blocks(int C, int N);
+int piml_rollout_losses(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
+                        const unsigned char* gates, const float* collisions, const float* hard_collisions,
+                        const float* abnormal_mask, int C, int T, int N, float time_decay, float* out, float* g_mse,
+                        float* g_coll, float* g_hard, float* partial, unsigned* ticket, void* stream);
+int piml_rollout_losses_bwd(const float* g_out, const float* g_mse, const float* g_coll, const float* g_hard, long long n,
+                            float* g_p, void* stream);
+
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);
 

@@ -10,7 +10,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -96,6 +96,9 @@ SIGNATURES = {
     'piml_encoder_partial_floats': [],
     'piml_encoder_pack_floats': [],
     'piml_encoder_split_tiles': [_ll],
+    'piml_rollout_losses_blocks': [_i, _i],
+    'piml_rollout_losses': [_p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
+    'piml_rollout_losses_bwd': [_p, _p, _p, _p, _ll, _p, _p],
     'piml_encoder_products': [_i],
     'piml_encoder_dw2': [_i],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],

@@ -1,0 +1,175 @@
+// Rollout losses of the fine-tuning step (HOT LOOP C) in one launch + one for the gradient.
+//
+// Reference: src/models/simulators.py:172-249 (multiple_rollout_mse_loss, multiple_rollout_collision_avoidance_loss,
+// multiple_rollout_collision_loss) as test_multiple_rollouts_for_training assembles them (:790-819):
+//     p_res  = where(keep & gate_t, p, 0)          keep = mask_p_pred != 0,  gate_t = any agent of frame t is predicted
+//     lab    = where(keep, labels[..., :2], 0)
+//     mse    = sum (p_res - lab)^2 * decay^(T - 1 - t)
+//     n_i    = (lab[:, T-1] - lab[:, 0]) / (|.| + 1e-6)                       per (window, agent)
+//     avoid  = ((p_res - (p_res . n) n) - (lab - (lab . n) n))^2 * decay^(T - 1 - t)
+//     focus  = sum [sum_t collisions > 0] * avoid * abnormal_mask             once for `collisions`, once for `hard_collisions`
+// On torch operators this is ~45 forward and ~60 backward launches of a few microseconds each on 4 x 5 x 122 x 2 numbers
+// (rocprofv3: 258 kernels per fine-tuning step, 200 of them such glue).  Here one thread owns a (window, agent) pair and
+// walks its T frames; the three sums are reduced in a fixed order (deterministic) -- by the last workgroup out when the
+// launch has more than one -- and the three gradient fields d(sum)/d(p) are written on the way, so the backward is one
+// scaled sum of them.
+#include "common.hpp"
+#include "../../include/piml_hip.h"
+
+#include <cmath>
+
+namespace piml {
+
+constexpr int LOSS_THREADS = 256;
+
+struct LossArgs {
+    const float* p;              // (C, T, N, 2)
+    const float* lab;            // (C, T, N, ld): columns 0, 1 = label position
+    long long ld;
+    const long long* keep;       // (C, T, N) mask_p_pred (!= 0: predicted)
+    const unsigned char* gate;   // (T)
+    const float* coll;           // (C, T, N) or NULL
+    const float* hard;           // (C, T, N) or NULL
+    const float* abn;            // (N) or NULL
+    int C, T, N;
+    float time_decay;
+    float* out;                  // 3 sums
+    float* g_mse;                // (C, T, N, 2) each
+    float* g_coll;
+    float* g_hard;
+    float* partial;              // (blocks, 3)
+    unsigned* ticket;            // zero on entry, zero again on exit
+};
+
+__device__ __forceinline__ void block_sum3(float (&v)[3], float* red) {
+    // fixed-order tree over the workgroup's threads
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] = v[q];
+    __syncthreads();
+    for (int s = LOSS_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] += red[q * LOSS_THREADS + tid + s];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = red[q * LOSS_THREADS];
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A) {
+    __shared__ float red[3 * LOSS_THREADS];
+    __shared__ unsigned last;
+    const int T = A.T, N = A.N;
+    const long long pairs = (long long)A.C * N;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < pairs; e += (long long)gridDim.x * LOSS_THREADS) {
+        const long long c = e / N, n = e - c * N;
+        auto at = [&](int t) { return (c * T + t) * N + n; };
+        auto label = [&](int t, float& x, float& y) {
+            const long long i = at(t);
+            const bool k = A.keep[i] != 0;
+            x = k ? A.lab[i * A.ld] : 0.f;
+            y = k ? A.lab[i * A.ld + 1] : 0.f;
+        };
+        float l0x, l0y, l1x, l1y;
+        label(0, l0x, l0y);
+        label(T - 1, l1x, l1y);
+        float nx = l1x - l0x, ny = l1y - l0y;
+        const float nn = sqrtf(nx * nx + ny * ny) + 1e-6f;         // torch.norm(ni, p=2, dim=-1) + 1e-6
+        nx = nx / nn; ny = ny / nn;
+        float cs = 0.f, hs = 0.f;
+        for (int t = 0; t < T; ++t) {
+            if (A.coll) cs += A.coll[at(t)];
+            if (A.hard) hs += A.hard[at(t)];
+        }
+        const float ab = A.abn ? A.abn[n] : 1.f;
+        const float wc = (A.coll && cs > 0.f) ? ab : 0.f, wh = (A.hard && hs > 0.f) ? ab : 0.f;
+        for (int t = 0; t < T; ++t) {
+            const long long i = at(t);
+            const bool k = A.keep[i] != 0, live = k && A.gate[t] != 0;
+            float lx, ly;
+            label(t, lx, ly);
+            const float px = live ? A.p[i * 2] : 0.f, py = live ? A.p[i * 2 + 1] : 0.f;
+            const float decay = powf(A.time_decay, (float)(T - 1 - t));
+            const float dx = px - lx, dy = py - ly;
+            s[0] += dx * dx * decay + dy * dy * decay;
+            const float dp = px * nx + py * ny, dl = lx * nx + ly * ny;
+            const float ex = (px - dp * nx) - (lx - dl * nx), ey = (py - dp * ny) - (ly - dl * ny);
+            const float av = ex * ex * decay + ey * ey * decay;
+            s[1] += wc * av;
+            s[2] += wh * av;
+            // d/dp: the mask passes the gradient only where p_res is p; d|e|^2 / dp = 2 (e - (e . n) n)
+            const float m = live ? 2.f * decay : 0.f;
+            const float en = ex * nx + ey * ny;
+            const float ax = m * (ex - en * nx), ay = m * (ey - en * ny);
+            A.g_mse[i * 2] = m * dx; A.g_mse[i * 2 + 1] = m * dy;
+            A.g_coll[i * 2] = wc * ax; A.g_coll[i * 2 + 1] = wc * ay;
+            A.g_hard[i * 2] = wh * ax; A.g_hard[i * 2 + 1] = wh * ay;
+        }
+    }
+    block_sum3(s, red);
+    if (gridDim.x == 1) {
+        if (threadIdx.x < 3) A.out[threadIdx.x] = s[threadIdx.x];
+        return;
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A.partial[blockIdx.x * 3 + q] = s[q];
+        __threadfence();
+        last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float r[3] = {0.f, 0.f, 0.f};
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += LOSS_THREADS)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[q] += A.partial[b * 3 + q];
+    __syncthreads();
+    block_sum3(r, red);
+    if (threadIdx.x < 3) A.out[threadIdx.x] = r[threadIdx.x];
+    if (threadIdx.x == 0) *A.ticket = 0u;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ g_mse,
+                                                                         const float* __restrict__ g_coll, const float* __restrict__ g_hard,
+                                                                         long long n, float* __restrict__ g_p) {
+    const float a = g_out[0], b = g_out[1], c = g_out[2];
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * LOSS_THREADS)
+        g_p[e] = a * g_mse[e] + b * g_coll[e] + c * g_hard[e];
+}
+
+}  // namespace piml
+
+using namespace piml;
+
+PIML_API int piml_rollout_losses_blocks(int C, int N) {
+    const long long pairs = (long long)C * N;
+    long long b = (pairs + LOSS_THREADS - 1) / LOSS_THREADS;
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+PIML_API int piml_rollout_losses(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
+                                 const unsigned char* gates, const float* collisions, const float* hard_collisions,
+                                 const float* abnormal_mask, int C, int T, int N, float time_decay, float* out, float* g_mse,
+                                 float* g_coll, float* g_hard, float* partial, unsigned* ticket, void* stream) {
+    if (!p || !labels || !mask_pred || !gates || !out || !g_mse || !g_coll || !g_hard || C < 1 || T < 1 || N < 1 || labels_ld < 2)
+        return hipErrorInvalidValue;
+    const int blocks = piml_rollout_losses_blocks(C, N);
+    if (blocks > 1 && (!partial || !ticket)) return hipErrorInvalidValue;
+    LossArgs A = {p, labels, labels_ld, mask_pred, gates, collisions, hard_collisions, abnormal_mask, C, T, N, time_decay,
+                  out, g_mse, g_coll, g_hard, partial, ticket};
+    hipLaunchKernelGGL(rollout_losses_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_rollout_losses_bwd(const float* g_out, const float* g_mse, const float* g_coll, const float* g_hard,
+                                     long long n, float* g_p, void* stream) {
+    if (!g_out || !g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
+    long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
+    hipLaunchKernelGGL(rollout_losses_bwd_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(LOSS_THREADS), 0, as_stream(stream),
+                       g_out, g_mse, g_coll, g_hard, n, g_p);
+    return hipGetLastError();
+}

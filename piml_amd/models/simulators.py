@@ -59,6 +59,7 @@ class BaseSimulator(Pedestrians):
     # the per-frame integrator / waypoint / injection block of the fine-tuning rollout as one HIP launch each
     # way (ops.train_rollout_step); False keeps the torch-op expression of the same arithmetic
     fused_train_step = True
+    fused_rollout_losses = True      # ops.rollout_losses for the mse / collision-focus sums of the training rollout (else torch operators)
 
     def __init__(self, args):
         super().__init__()
@@ -535,16 +536,32 @@ class BaseSimulator(Pedestrians):
         pad = [torch.zeros_like(p_steps[0])] * t_start
         gate4 = gates.view(1, -1, 1, 1)
         p_res = torch.stack(pad + p_steps, dim=1)                             # c, t, n, 2
-        keep = (mask_pred != 0).unsqueeze(-1)
-        p_res = torch.where(keep & gate4, p_res, torch.zeros_like(p_res))     # :728 gate and :793 delete 'nan'
-        labels = torch.where(keep, labels, torch.zeros_like(labels))          # :794
-        lab_p = labels[:, :, :, :2]
-        mse_loss = self.multiple_rollout_mse_loss(p_res, lab_p, args.time_decay, reduction='sum')
-        loss = loss + mse_loss
-
         zero = torch.zeros((), device=dev)
         collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc = zero, zero, zero, zero
-        if args.collision_loss_weight > 0 and args.collision_loss_version in ('v0', 'v2'):   # :800-819
+        want_coll = args.collision_loss_weight > 0 and args.collision_loss_version in ('v0', 'v2')
+        fused_losses = self.fused_rollout_losses and p_res.is_cuda and p_res.dim() == 4 and p_res.dtype == torch.float32
+        if fused_losses:
+            # :790-819 as ONE launch forward and one backward (ops.rollout_losses: the masks, the time-decayed squared error
+            # and the two collision-focus sums; on torch operators ~100 launches of a few microseconds each)
+            am = data.abnormal_mask if args.collision_loss_version == 'v2' else None
+            sums = ops.rollout_losses(p_res, labels, mask_pred, gates, collisions if want_coll else None,
+                                      hard_collisions if want_coll else None, am, args.time_decay)
+            mse_loss = sums[0]
+            loss = loss + mse_loss
+            if want_coll:
+                collision_loss = sums[1] * args.collision_loss_weight
+                hard_collision_loss = sums[2] * (args.collision_loss_weight * args.hard_collision_penalty)
+                loss = loss + collision_loss + hard_collision_loss
+            if args.teacher_weight > 0:
+                labels = torch.where((mask_pred != 0).unsqueeze(-1), labels, torch.zeros_like(labels))   # :794
+        else:
+            keep = (mask_pred != 0).unsqueeze(-1)
+            p_res = torch.where(keep & gate4, p_res, torch.zeros_like(p_res))     # :728 gate and :793 delete 'nan'
+            labels = torch.where(keep, labels, torch.zeros_like(labels))          # :794
+            lab_p = labels[:, :, :, :2]
+            mse_loss = self.multiple_rollout_mse_loss(p_res, lab_p, args.time_decay, reduction='sum')
+            loss = loss + mse_loss
+        if not fused_losses and want_coll:                                    # :800-819
             am = data.abnormal_mask if args.collision_loss_version == 'v2' else None
             collision_loss = self.multiple_rollout_collision_loss(
                 p_res, lab_p, args.time_decay, args.collision_focus_weight, collisions, reduction='sum',

@@ -538,6 +538,69 @@ def collision_counts(position, thresholds):
     return counts
 
 
+_LOSS_TICKETS = {}
+
+
+class _RolloutLosses(torch.autograd.Function):
+    """piml_rollout_losses / piml_rollout_losses_bwd (include/piml_hip.h): the three loss sums of the fine-tuning rollout and
+    their gradient with respect to the predicted positions."""
+
+    @staticmethod
+    def forward(ctx, p, labels, mask_pred, gates, collisions, hard_collisions, abnormal_mask, time_decay):
+        L = _lib.lib()
+        pc = _gpu_f32('p', p.detach())
+        C, T, N = pc.shape[0], pc.shape[1], pc.shape[2]
+        lab = _gpu_f32('labels', labels.detach())
+        if tuple(lab.shape[:3]) != (C, T, N) or lab.shape[-1] < 2 or pc.shape[-1] != 2:
+            raise ValueError('p must be (C, T, N, 2), labels (C, T, N, >= 2)')
+        mp = mask_pred.detach().contiguous()
+        if mp.dtype != torch.int64 or tuple(mp.shape) != (C, T, N):
+            raise ValueError('mask_pred must be int64 (C, T, N)')
+        g8 = gates.detach().contiguous().view(torch.uint8)
+        dev = pc.device
+        opt = dict(device=dev, dtype=torch.float32)
+        co = None if collisions is None else _gpu_f32('collisions', collisions.detach())
+        hc = None if hard_collisions is None else _gpu_f32('hard_collisions', hard_collisions.detach())
+        ab = None if abnormal_mask is None else _gpu_f32('abnormal_mask', abnormal_mask.detach().reshape(-1))
+        out = torch.empty(3, **opt)
+        gm, gc, gh = torch.empty_like(pc), torch.empty_like(pc), torch.empty_like(pc)
+        blocks = L.piml_rollout_losses_blocks(C, N)
+        partial, ticket = None, None
+        if blocks > 1:
+            partial = torch.empty(blocks, 3, **opt)
+            ticket = _LOSS_TICKETS.get(dev)
+            if ticket is None:       # zeroed once; the launch leaves it zero
+                ticket = _LOSS_TICKETS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_rollout_losses(_ptr(pc), _ptr(lab), lab.shape[-1], _ptr(mp), _ptr(g8), _ptr(co), _ptr(hc), _ptr(ab),
+                                             C, T, N, float(time_decay), _ptr(out), _ptr(gm), _ptr(gc), _ptr(gh),
+                                             _ptr(partial), _ptr(ticket), _stream()), 'piml_rollout_losses')
+        ctx.save_for_backward(gm, gc, gh)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        if g_out is None or not ctx.needs_input_grad[0]:
+            return (None,) * 8
+        gm, gc, gh = ctx.saved_tensors
+        go = _gpu_f32('g_out', g_out)
+        gp = torch.empty_like(gm)
+        with torch.cuda.device(gm.device):
+            _lib.check(_lib.lib().piml_rollout_losses_bwd(_ptr(go), _ptr(gm), _ptr(gc), _ptr(gh), gm.numel(), _ptr(gp),
+                                                          _stream()), 'piml_rollout_losses_bwd')
+        return (gp,) + (None,) * 7
+
+
+def rollout_losses(p, labels, mask_pred, gates, collisions=None, hard_collisions=None, abnormal_mask=None, time_decay=1.0):
+    """(mse, collision-focus loss of `collisions`, of `hard_collisions`) of a training rollout -- BaseSimulator's
+    multiple_rollout_mse_loss and multiple_rollout_collision_loss (reduction 'sum') on the masked / gated positions, as
+    test_multiple_rollouts_for_training puts them together (src/models/simulators.py:172-249, 790-819) -- as one launch
+    forward and one backward.  p (C, T, N, 2) carries the gradient; labels (C, T, N, >= 2) unmasked; mask_pred (C, T, N) int64;
+    gates (T) bool.  Returns a (3,) tensor."""
+    return _RolloutLosses.apply(p, labels, mask_pred, gates, collisions, hard_collisions, abnormal_mask, float(time_decay))
+
+
 def collision_label(ped_features):
     """Pedestrians.calculate_collision_label (data.py:514-535): (..., k, >=4) -> (..., k)."""
     f = _gpu_f32('ped_features', ped_features.detach())

@@ -1,0 +1,71 @@
+"""GPU: ops.rollout_losses (piml_amd/csrc/losses.hip) against the torch-operator expression of the same losses --
+BaseSimulator.multiple_rollout_mse_loss / multiple_rollout_collision_loss on the masked, gated positions, exactly as
+_training_rollout_frames assembles them (reference src/models/simulators.py:172-249, 790-819) -- values and the gradient
+with respect to the predicted positions.  Tolerance 1e-5 relative to each tensor's largest magnitude; measured error printed."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def torch_losses(sim, p, labels, mask_pred, gates, coll, hard, abn, decay):
+    keep = (mask_pred != 0).unsqueeze(-1)
+    gate4 = gates.view(1, -1, 1, 1)
+    p_res = torch.where(keep & gate4, p, torch.zeros_like(p))
+    lab = torch.where(keep, labels, torch.zeros_like(labels))[..., :2]
+    out = [sim.multiple_rollout_mse_loss(p_res, lab, decay, reduction='sum')]
+    for c in (coll, hard):
+        out.append(sim.multiple_rollout_collision_loss(p_res, lab, decay, 10, c, reduction='sum', abnormal_mask=abn))
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize('C,T,N,decay,with_abn', [(4, 5, 122, 1.0, False), (4, 10, 37, 0.9, True), (1, 2, 1, 0.5, False),
+                                                 (16, 5, 976, 0.9, True), (3, 7, 30000, 1.0, False)])
+def test_rollout_losses_match_the_torch_expression(C, T, N, decay, with_abn):
+    from piml_amd import ops
+    from piml_amd.models.simulators import BaseSimulator
+    sim = BaseSimulator.__new__(BaseSimulator)          # the loss methods use no state
+    g = torch.Generator().manual_seed(C * 1000 + N)
+    p = (torch.randn(C, T, N, 2, generator=g) * 3).to(DEV)
+    labels = (torch.randn(C, T, N, 7, generator=g) * 3).to(DEV)
+    mask_pred = (torch.rand(C, T, N, generator=g) < 0.7).long().to(DEV) * 3
+    mask_pred[:, T - 1] = 0 if T > 2 else mask_pred[:, T - 1]           # a frame nobody is predicted in: gate closed
+    gates = mask_pred.sum(dim=(0, 2)) > 0
+    absent = (torch.rand(C, T, N, generator=g) < 0.1).to(DEV) & (mask_pred == 0)
+    p = torch.where(absent.unsqueeze(-1), torch.full_like(p, float('nan')), p)            # absent agents: NaN, masked out
+    labels = torch.where(absent.unsqueeze(-1), torch.full_like(labels, float('nan')), labels)
+    coll = (torch.rand(C, T, N, generator=g) < 0.05).float().to(DEV) * 2
+    hard = (torch.rand(C, T, N, generator=g) < 0.02).float().to(DEV)
+    abn = (torch.rand(N, generator=g) < 0.8).float().to(DEV) if with_abn else None
+    w = torch.tensor([1.0, 10.0, 100.0], device=DEV)
+
+    p1 = p.clone().requires_grad_(True)
+    got = ops.rollout_losses(p1, labels, mask_pred, gates, coll, hard, abn, decay)
+    (got * w).sum().backward()
+    p2 = p.clone().requires_grad_(True)
+    want = torch_losses(sim, p2, labels, mask_pred, gates, coll, hard, abn, decay)
+    (want * w).sum().backward()
+    err = float(((got.double() - want.double()).abs() / want.double().abs().clamp_min(1e-30)).max())
+    g2 = torch.nan_to_num(p2.grad)
+    gerr = float((p1.grad.double() - g2.double()).abs().max() / g2.double().abs().max().clamp_min(1e-30))
+    print(f'rollout losses C={C} T={T} N={N} decay={decay}: sums {err:.1e}, gradient {gerr:.1e}')
+    assert torch.isfinite(got).all() and torch.isfinite(p1.grad).all()
+    assert err <= 1e-5 and gerr <= 1e-5
+    # without collision records only the squared error is asked for
+    only = ops.rollout_losses(p, labels, mask_pred, gates, None, None, None, decay)
+    assert float((only[0] - got[0]).abs()) <= 1e-6 * float(got[0].abs()) and float(only[1]) == 0.0 and float(only[2]) == 0.0
+
+
+def test_rollout_losses_are_deterministic():
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C, T, N = 8, 5, 5000
+    p = torch.randn(C, T, N, 2, generator=g).to(DEV)
+    labels = torch.randn(C, T, N, 6, generator=g).to(DEV)
+    mask_pred = (torch.rand(C, T, N, generator=g) < 0.8).long().to(DEV)
+    gates = mask_pred.sum(dim=(0, 2)) > 0
+    coll = (torch.rand(C, T, N, generator=g) < 0.1).float().to(DEV)
+    first = ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9)
+    for _ in range(10):
+        assert torch.equal(first, ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9))
