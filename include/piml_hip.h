@@ -666,6 +666,8 @@ int piml_head64_bwd(const piml_head64* head, void* stream);
  */
 #define PIML_PACKED_VALID 1
 #define PIML_FORK 2
+#define PIML_ACCUMULATE 4 /* piml_pinnsf_bwd: every branch's `grads` += the slot sums instead of = (a further backward pass through
+                             the same weights inside one optimiser step: the frames of a training rollout); not with PIML_FORK */
 int piml_pinnsf_streams_init(void);
 int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,
                      const piml_collision_head* head, int flags, void* stream);

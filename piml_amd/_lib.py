@@ -46,7 +46,7 @@ class Head64(ctypes.Structure):
                 ('g_out', _p), ('g_x', _p), ('partials', _p), ('grads', _p)]
 
 
-PACKED_VALID, FORK = 1, 2          # piml_pinnsf_* flags
+PACKED_VALID, FORK, ACCUMULATE = 1, 2, 4          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {

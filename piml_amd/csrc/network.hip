@@ -110,11 +110,12 @@ struct ReduceSet {
 struct ReduceAll {
     ReduceSet set[6];
     int nsets;
+    int accumulate;       // PIML_ACCUMULATE: grads += the sums
 };
 
 __global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) {
     const ReduceSet S = A.set[blockIdx.y];
-    if ((int)blockIdx.x * 16 < S.lanes) sum_slots_16x16(S.parts, S.grads, S.slots, S.lanes, S.split, S.off0, S.off1);
+    if ((int)blockIdx.x * 16 < S.lanes) sum_slots_16x16(S.parts, S.grads, S.slots, S.lanes, S.split, S.off0, S.off1, A.accumulate != 0);
 }
 
 }  // namespace piml
@@ -157,8 +158,9 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
 }
 
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
-static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s) {
+static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate) {
     ReduceAll R = {};
+    R.accumulate = accumulate ? 1 : 0;
     int w0 = 0, n = 0, maxl = 0;
     const int total = piml_encoder_workgroups(enc, nbr, &w0);
     const int dslots = piml_decoder_workgroups(dec[0].agents);
@@ -230,10 +232,11 @@ PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_
         trace_mark("enc_bwd_dx", m);
         PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
         trace_mark("enc_bwd_dw", m);
-        PIML_TRY(reduce_all(enc, dec, nbr, m));
+        PIML_TRY(reduce_all(enc, dec, nbr, m, (flags & PIML_ACCUMULATE) != 0));
         trace_mark("pinnsf_reduce", m);
         return hipSuccess;
     }
+    if (flags & PIML_ACCUMULATE) return hipErrorInvalidValue;      // (the forked form sums its slots per stage: not offered there)
     PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
     Side* S;
     PIML_TRY(side_streams(&S));

@@ -175,8 +175,9 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
 // (clamped, unconditional) issued before the first add: the sums are latency-bound, not bandwidth-bound
 // Target of float4 column j: off0 + j for j < split, off1 + (j - split) behind it (a slot whose fields land in two places of
 // the gradient buffer: the layer-split slots of encoder_dw2.hip); the plain form is split = lanes, off0 = 0.
+// accumulate: grads += the sum (a second backward pass through the same weights inside one optimiser step).
 __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes,
-                                                int split = 0x7fffffff, int off0 = 0, int off1 = 0) {
+                                                int split = 0x7fffffff, int off0 = 0, int off1 = 0, bool accumulate = false) {
     __shared__ float4 sh[256];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + col;
@@ -204,7 +205,12 @@ __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partia
             const float4 v = sh[q * 16 + col];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        reinterpret_cast<float4*>(grads)[j < split ? off0 + j : off1 + (j - split)] = s;
+        float4* dst = reinterpret_cast<float4*>(grads) + (j < split ? off0 + j : off1 + (j - split));
+        if (accumulate) {
+            const float4 o = *dst;
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        *dst = s;
     }
 }
 

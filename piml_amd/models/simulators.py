@@ -64,6 +64,7 @@ class BaseSimulator(Pedestrians):
     def __init__(self, args):
         super().__init__()
         self.args = args
+        self._grad_sink = ops.ParamGradSink()      # the captured fine-tuning step sums its frames' weight gradients in here
         self.set_model(args)
         self.set_optimizer(args)
         self.set_scheduler(args)
@@ -620,8 +621,9 @@ class BaseSimulator(Pedestrians):
 
             def one_step():
                 self.optimizer.zero_grad(set_to_none=True)
-                out, aux = self._training_rollout(static)
-                out[0].backward()
+                with self._grad_sink.step():      # the frames' weight gradients summed inside the slot-sum launches
+                    out, aux = self._training_rollout(static)
+                    out[0].backward()
                 self.optimizer.step()
                 return out, aux
             # inside the graph the obstacle branch of the MLP runs on a side stream (parallel chains of

@@ -13,6 +13,7 @@ from . import _lib
 MAX_TOPK = 32
 # Opt-in: the relative-feature backward without float atomics (bit-reproducible gradients; the neighbour-list entries are
 # sorted by source with torch.sort(stable=True) and gathered in that fixed order).  Default: the atomic scatter.
+import contextlib
 import os as _os
 DETERMINISTIC_BWD = _os.environ.get('PIML_DETERMINISTIC_BWD', '0') == '1'
 
@@ -1701,6 +1702,53 @@ def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
 FORK_NETWORK = _os.environ.get('PIML_FORK_NETWORK', '0') == '1'
 
 
+class ParamGradSink:
+    """Weight gradients of the fused PINNSF network summed across the backward passes of ONE optimiser step inside the slot-sum
+    launch (PIML_ACCUMULATE) instead of by autograd's per-tensor accumulation: a training rollout runs the network once per
+    frame, and every backward pass after the first costs one `grad += new` launch per parameter tensor (~30 launches of 3 us
+    at the fine-tuning step).  Use:
+
+        sink = ops.ParamGradSink()                 # persistent: its buffers are what p.grad points into
+        with sink.step():                          # zero_grad(set_to_none=True) before, optimizer.step() after
+            loss = ...; loss.backward()
+
+    Inside the block `fused_pinnsf`'s backward returns no weight gradients to autograd; at the end every parameter that got
+    one has `p.grad` = a view of the sink's flat buffers (added to an existing p.grad, should autograd have produced one for
+    the same tensor on another path).  Capturable into a HIP graph (the buffers are static)."""
+    _active = None
+
+    def __init__(self):
+        self._bufs = {}          # key -> (encoder flats, decoder flats)
+        self._seen = None        # keys that have had their first backward pass of the running step
+        self._assign = None      # id(param) -> (param, view)
+
+    @contextlib.contextmanager
+    def step(self):
+        if ParamGradSink._active is not None:
+            raise RuntimeError('ParamGradSink.step() does not nest')
+        self._seen, self._assign = set(), {}
+        ParamGradSink._active = self
+        try:
+            yield self
+        finally:
+            ParamGradSink._active = None
+            for p, view in self._assign.values():
+                p.grad = view if p.grad is None else p.grad + view
+            self._seen, self._assign = None, None
+
+    def buffers(self, key, n_enc, part, n_dec, dpart, opt):
+        """-> (encoder flats, decoder flats, accumulate?) of the network `key` for this backward pass"""
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = ([torch.empty(part, **opt) for _ in range(n_enc)], [torch.empty(dpart, **opt) for _ in range(n_dec)])
+        acc = key in self._seen
+        self._seen.add(key)
+        return b[0], b[1], acc
+
+    def give(self, param, view):
+        self._assign.setdefault(id(param), (param, view))
+
+
 class _FusedPinnsf(torch.autograd.Function):
     """inputs: need_grad, nbr, scales, tau, fold_epilogue, packs (PinnsfPacks or None), nhead (0 / 1),
     self_features (..., N, 7), then per branch x (..., N, k, in), encoder w1 b1 w2 b2 w3 b3, decoder w1 b1 w2 b2,
@@ -1779,6 +1827,8 @@ class _FusedPinnsf(torch.autograd.Function):
         ctx.meta = (nbr, tuple(scales), float(tau), bool(fold_epilogue), tuple(ks), [tuple(x.shape) for x in xs],
                     tuple(self_features.shape), agents, need_grad, int(nhead))
         ctx.keeps = keeps
+        ctx.sink = ParamGradSink._active if need_grad else None
+        ctx.params = tensors if ctx.sink is not None else None       # (the Parameter objects themselves: p.grad is set on them)
         ctx.set_materialize_grads(False)
         out = (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
         if nhead:
@@ -1840,7 +1890,17 @@ class _FusedPinnsf(torch.autograd.Function):
             total = L.piml_encoder_workgroups(earr, len(live), ctypes.byref(w0))
             slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
             parts = [torch.empty(n, part, **opt) for n in slots]
-            flats = [torch.empty(part, **opt) for _ in slots]
+            # weight gradients: fresh buffers handed to autograd, or -- inside ParamGradSink.step(), whole network only -- the
+            # sink's persistent ones, summed across the backward passes of the step by the slot-sum launch itself
+            sink = ctx.sink if (g_acc is not None and ctx.sink is ParamGradSink._active and not FORK_NETWORK) else None
+            dflats = None
+            if sink is not None:
+                key = tuple(id(t) for i, t in enumerate(ctx.params[:PER * nbr]) if i % PER)       # the weight tensors (not the inputs x)
+                flats, dflats, accumulate = sink.buffers(key, len(live), part, nbr, L.piml_decoder_partial_floats(), opt)
+                if accumulate:
+                    flags |= _lib.ACCUMULATE
+            else:
+                flats = [torch.empty(part, **opt) for _ in slots]
             for i in range(len(live)):
                 earr[i].partials, earr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
             if g_acc is not None:           # decoder tails + encoders: one forked call
@@ -1849,7 +1909,8 @@ class _FusedPinnsf(torch.autograd.Function):
                 g_self = torch.empty(agents, 7, **opt) if want_self else None
                 nwg = L.piml_decoder_workgroups(agents)
                 dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
-                dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+                if dflats is None:
+                    dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
                 dstructs = []
                 for b in range(nbr):
                     gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
@@ -1870,7 +1931,10 @@ class _FusedPinnsf(torch.autograd.Function):
                     rest = flat[64 * H + 4096 + 128:]
                     for jx, t in enumerate((dW1, rest[:64], dW2, rest[64:128], dW3, rest[128:130])):
                         if need[jx]:
-                            grads[o + jx] = t
+                            if sink is not None:
+                                sink.give(ctx.params[o + jx - FIRST], t)
+                            else:
+                                grads[o + jx] = t
             else:                            # only the messages carry a gradient: the encoders alone
                 if h1s[live[0]] is None and _h1_needed([x2s[b].shape[0] for b in live], alone=False):
                     raise _lib.PimlHipError(
@@ -1889,7 +1953,10 @@ class _FusedPinnsf(torch.autograd.Function):
                 db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
                 for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
                     if need[jx]:
-                        grads[o + jx] = t
+                        if sink is not None:
+                            sink.give(ctx.params[o + jx - FIRST], t)
+                        else:
+                            grads[o + jx] = t
         return tuple(grads)
 
 
