@@ -430,13 +430,13 @@ class BaseSimulator(Pedestrians):
         dt = data.time_unit
         waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
         T = data.num_frames
-        mask_pred = data.mask_p_pred.clone().long()                           # c, t, n
-        labels = data.labels.clone()
+        mask_pred = data.mask_p_pred.long()                                   # c, t, n   (read only: no copies of it or of the labels)
+        labels = data.labels
         thr = args.collision_threshold
 
         state = [data.ped_features[..., t_start, :, :, :], data.obs_features[..., t_start, :, :, :],
                  data.self_features[..., t_start, :, :]]
-        desired_speed = state[2][..., -1:].clone()
+        desired_speed = state[2][..., -1:]
         a_cur = data.acceleration[..., t_start, :, :].clone()
         v_cur = data.velocity[..., t_start, :, :].clone()
         p_cur = data.position[..., t_start, :, :].clone()
@@ -446,12 +446,15 @@ class BaseSimulator(Pedestrians):
 
         dev = p_cur.device
         p_steps, a_steps, cnt_steps, lab_steps = [], [], [], []
-        pred_collisions = torch.zeros(data.ped_features[..., 0].shape, device=dev)
-        true_collision = torch.zeros(data.ped_features[..., 0].shape, device=dev)
-        loss = torch.zeros((), device=dev)
-        reg_loss = torch.zeros((), device=dev)
-        nan_seen = torch.zeros((), device=dev, dtype=torch.bool)
         bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
+        zero = torch.zeros((), device=dev)          # (one zero for every sum that starts at 0: each torch.zeros is a launch)
+        pred_collisions = true_collision = zero
+        if bm_head:
+            pred_collisions = torch.zeros(data.ped_features[..., 0].shape, device=dev)
+            true_collision = torch.zeros(data.ped_features[..., 0].shape, device=dev)
+        loss = zero
+        reg_loss = zero
+        nan_seen = None                             # (the fused frame step keeps its own flag on the device)
         # `if torch.sum(mask) > 0` of every frame (:707), evaluated once for all frames: the per-frame records
         # below are gated after the loop in one pass instead of frame by frame
         gates = mask_pred.sum(dim=(0, 2)) > 0                                 # (T,)
@@ -493,7 +496,7 @@ class BaseSimulator(Pedestrians):
                     p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt,
                     new_flag=new_flag_u8, series=series, t_next=t + 1, nan_flag=nan_flag, zero_nan=True)
             else:
-                nan_seen = nan_seen | a_next.isnan().any()
+                nan_seen = a_next.isnan().any() if nan_seen is None else (nan_seen | a_next.isnan().any())
                 v_next = v_cur + a_cur * dt                                   # :741-743
                 p_next = p_cur + v_cur * dt
 
@@ -521,7 +524,7 @@ class BaseSimulator(Pedestrians):
 
         def frames(steps):
             """per-frame (2, C, N) count records -> two gated (C, T, N) tensors"""
-            pad = [torch.zeros_like(steps[0])] * t_start
+            pad = [torch.zeros_like(steps[0])] * t_start if t_start else []
             allf = torch.stack(pad + steps, dim=2) * gates_f.view(1, 1, -1, 1)    # (2, C, T, N)
             return allf[0], allf[1]
         collisions, hard_collisions = frames(cnt_steps)
@@ -534,10 +537,9 @@ class BaseSimulator(Pedestrians):
         aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions),
                'dest_idx_final': dest_idx.detach().clone(), 't_start': t_start}
 
-        pad = [torch.zeros_like(p_steps[0])] * t_start
+        pad = [torch.zeros_like(p_steps[0])] * t_start if t_start else []
         gate4 = gates.view(1, -1, 1, 1)
         p_res = torch.stack(pad + p_steps, dim=1)                             # c, t, n, 2
-        zero = torch.zeros((), device=dev)
         collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc = zero, zero, zero, zero
         want_coll = args.collision_loss_weight > 0 and args.collision_loss_version in ('v0', 'v2')
         fused_losses = self.fused_rollout_losses and p_res.is_cuda and p_res.dim() == 4 and p_res.dtype == torch.float32
@@ -577,7 +579,11 @@ class BaseSimulator(Pedestrians):
             a_mse = self.multiple_rollout_mse_loss(a_res, labels[..., 4:6], args.time_decay, reduction='sum',
                                                    reverse=True)
             loss = loss + a_mse * args.teacher_weight
-        if args.collision_pred_weight > 0:                                    # :826-830
+        if args.collision_pred_weight > 0 and not bm_head:
+            # :826-830 with both tensors still all zeros (only `pinnsf_bm` fills them, :731-733): BCE(0, 0) = 0 and every
+            # rounded prediction equals its label -- the values the six launches below would compute
+            collision_pred_acc = zero + 1.0
+        elif args.collision_pred_weight > 0:                                  # :826-830
             collision_pred_loss = F.binary_cross_entropy(pred_collisions, true_collision,
                                                          reduction='sum') * args.collision_pred_weight
             collision_pred_acc = torch.sum(torch.round(pred_collisions) == true_collision) / true_collision.numel()

@@ -14,10 +14,12 @@ MAX_TOPK = 32
 # Opt-in: the relative-feature backward without float atomics (bit-reproducible gradients; the neighbour-list entries are
 # sorted by source with torch.sort(stable=True) and gathered in that fixed order).  Default: the atomic scatter.
 import contextlib
+import functools
 import os as _os
 DETERMINISTIC_BWD = _os.environ.get('PIML_DETERMINISTIC_BWD', '0') == '1'
 
 
+@functools.lru_cache(maxsize=None)
 def cos_threshold(angle_deg):
     """float32(cos(3.14 * angle / 180)): the reference's view-cone threshold, with its 3.14
     (src/data/data.py:442-443), rounded the way torch compares float32 with a scalar."""
