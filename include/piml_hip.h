@@ -546,6 +546,9 @@ int piml_encoder_fwd(const piml_encoder_branch* branches, int nbranches, void* s
  * pack per rollout or per back-propagated window instead of one per frame */
 int piml_encoder_fwd_packed(const piml_encoder_branch* branches, int nbranches, void* stream);
 int piml_encoder_bwd(const piml_encoder_branch* branches, int nbranches, void* stream);
+/* accumulate != 0: `grads` += the slot sums instead of = (a further backward pass through the same weights within one
+ * optimiser step -- the frames of a training rollout; cf. PIML_ACCUMULATE of piml_pinnsf_bwd). */
+int piml_encoder_bwd_acc(const piml_encoder_branch* branches, int nbranches, int accumulate, void* stream);
 /* pooled (agents, 128) = sum over k consecutive rows of msgs (agents * k, 128) */
 int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream);
 
@@ -606,6 +609,7 @@ int piml_rowdecoder_slots(long long rows);
 int piml_rowdecoder_fwd(const piml_decoder_branch* branches, int nbranches, void* stream);
 int piml_rowdecoder_fwd_packed(const piml_decoder_branch* branches, int nbranches, void* stream); /* without the pack launch */
 int piml_rowdecoder_bwd(const piml_decoder_branch* branches, int nbranches, void* stream);
+int piml_rowdecoder_bwd_acc(const piml_decoder_branch* branches, int nbranches, int accumulate, void* stream);   /* grads +=, see piml_encoder_bwd_acc */
 
 typedef struct piml_collision_head {
     const float* msgs; /* (rows, 128) */
@@ -644,6 +648,7 @@ int piml_head64_partial_floats(void);
 int piml_head64_slots(long long rows);
 int piml_head64_fwd(const piml_head64* head, void* stream);
 int piml_head64_bwd(const piml_head64* head, void* stream);
+int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream);   /* grads +=, see piml_encoder_bwd_acc */
 
 /*
  * The whole non-bottleneck PINNSF network (src/models/model.py:1271-1305: both encoders, the decoder tails, the

@@ -106,6 +106,7 @@ SIGNATURES = {
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_fwd_packed': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_bwd': [ctypes.POINTER(EncoderBranch), _i, _p],
+    'piml_encoder_bwd_acc': [ctypes.POINTER(EncoderBranch), _i, _i, _p],
     'piml_encoder_ksum': [_p, _ll, _i, _p, _p],
     'piml_decoder_pack_floats': [],
     'piml_decoder_partial_floats': [],
@@ -116,12 +117,14 @@ SIGNATURES = {
     'piml_rowdecoder_fwd': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_rowdecoder_fwd_packed': [ctypes.POINTER(DecoderBranch), _i, _p],
     'piml_rowdecoder_bwd': [ctypes.POINTER(DecoderBranch), _i, _p],
+    'piml_rowdecoder_bwd_acc': [ctypes.POINTER(DecoderBranch), _i, _i, _p],
     'piml_collision_head_pack_floats': [],
     'piml_collision_head_fwd': [_p, _ll, _p, _p, _p, _p, _p, _p, _p],
     'piml_head64_partial_floats': [],
     'piml_head64_slots': [_ll],
     'piml_head64_fwd': [ctypes.POINTER(Head64), _p],
     'piml_head64_bwd': [ctypes.POINTER(Head64), _p],
+    'piml_head64_bwd_acc': [ctypes.POINTER(Head64), _i, _p],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_pack': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),
                          _i, _p],

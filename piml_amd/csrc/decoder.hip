@@ -957,9 +957,9 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
     }
 }
 
-__global__ __launch_bounds__(256) void rowdec_reduce_kernel(DecArgs A, int B0, int B1, int lanes) {
+__global__ __launch_bounds__(256) void rowdec_reduce_kernel(DecArgs A, int B0, int B1, int lanes, int accumulate) {
     const piml_decoder_branch J = blockIdx.y ? A.br[1] : A.br[0];
-    sum_slots_16x16(J.partials, J.grads, blockIdx.y ? B1 : B0, lanes);
+    sum_slots_16x16(J.partials, J.grads, blockIdx.y ? B1 : B0, lanes, 0x7fffffff, 0, 0, accumulate != 0);
 }
 
 __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int lanes) {
@@ -1373,7 +1373,9 @@ static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, voi
     return hipGetLastError();
 }
 
-PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* stream) {
+PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* stream) { return piml_rowdecoder_bwd_acc(br, nbr, 0, stream); }
+
+PIML_API int piml_rowdecoder_bwd_acc(const piml_decoder_branch* br, int nbr, int accumulate, void* stream) {
     hipStream_t s = as_stream(stream);
     DecArgs A;
     if (int e = rowdec_fill(A, br, nbr, true)) return e;
@@ -1393,7 +1395,7 @@ PIML_API int piml_rowdecoder_bwd(const piml_decoder_branch* br, int nbr, void* s
     hipLaunchKernelGGL(rowdec_bwd_dw_lds_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 2 * RD_BUF * 4, s, A, slots0,
                        rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
     hipLaunchKernelGGL(rowdec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, slots0, slots1,
-                       DEC_PART / 4);
+                       DEC_PART / 4, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -751,23 +751,24 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw_kernel(EncArgs A) {
 }
 
 // grads = sum over the branch's partial slots (sum_slots_16x16, pack.hpp); blockIdx.y = branch
-__global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes) {
+__global__ __launch_bounds__(256) void enc_reduce_kernel(EncArgs A, int lanes, int accumulate) {
     const int b = blockIdx.y;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int B = b ? 256 - A.wg_split : (A.nbr > 1 ? A.wg_split : 256);
-    sum_slots_16x16(J.partials, J.grads, B, lanes);
+    sum_slots_16x16(J.partials, J.grads, B, lanes, 0x7fffffff, 0, 0, accumulate != 0);
 }
 
 // the same for layer-split slots (encoder_dw2.hip): blockIdx.y = 2 * branch + layer
-struct Reduce2Args { piml_encoder_branch br[2]; int n0[2], n1[2]; };
+struct Reduce2Args { piml_encoder_branch br[2]; int n0[2], n1[2]; int accumulate; };
 __global__ __launch_bounds__(256) void enc_reduce2_kernel(Reduce2Args A) {
     const int b = blockIdx.y >> 1, L = blockIdx.y & 1;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     if (L == 0) {
-        if ((int)blockIdx.x * 16 < DW2_L0_LANES) sum_slots_16x16(J.partials, J.grads, A.n0[b], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1);
+        if ((int)blockIdx.x * 16 < DW2_L0_LANES) sum_slots_16x16(J.partials, J.grads, A.n0[b], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1, A.accumulate != 0);
     } else {
         if ((int)blockIdx.x * 16 < DW2_L1_LANES)
-            sum_slots_16x16(J.partials + (size_t)A.n0[b] * (DW2_L0_LANES * 4), J.grads, A.n1[b], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
+            sum_slots_16x16(J.partials + (size_t)A.n0[b] * (DW2_L0_LANES * 4), J.grads, A.n1[b], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1,
+                            A.accumulate != 0);
     }
 }
 
@@ -1079,17 +1080,18 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
     return hipGetLastError();
 }
 
-int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate) {
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     fill_args(A, br, nbr);
     Reduce2Args R2 = {};
+    R2.accumulate = accumulate ? 1 : 0;
     if (enc_dw2_used(br, nbr, R2.n0, R2.n1)) {
         for (int i = 0; i < nbr; ++i) R2.br[i] = br[i];
         hipLaunchKernelGGL(enc_reduce2_kernel, dim3((DW2_L1_LANES + 15) / 16, 2 * nbr), dim3(256), 0, s, R2);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, ENC_PART / 4);
+    hipLaunchKernelGGL(enc_reduce_kernel, dim3((ENC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, ENC_PART / 4, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1116,8 +1118,10 @@ PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float
     return hipGetLastError();
 }
 
-PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) {
+PIML_API int piml_encoder_bwd_acc(const piml_encoder_branch* br, int nbr, int accumulate, void* stream) {
     if (int e = enc_stage_bwd_dx(br, nbr, as_stream(stream))) return e;
     if (int e = enc_stage_bwd_dw(br, nbr, as_stream(stream))) return e;
-    return enc_stage_reduce(br, nbr, as_stream(stream));
+    return enc_stage_reduce(br, nbr, as_stream(stream), accumulate != 0);
 }
+
+PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) { return piml_encoder_bwd_acc(br, nbr, 0, stream); }

@@ -217,8 +217,9 @@ __global__ __launch_bounds__(256) void head64_bwd_kernel(piml_head64 A) {
     for (int e = threadIdx.x; e < H64_PART; e += 256) out[e] = e < HD * HD + 2 * HD + 1 ? P[e] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void head64_reduce_kernel(const float* __restrict__ partials, float* __restrict__ grads, int slots) {
-    sum_slots_16x16(partials, grads, slots, H64_PART / 4);
+__global__ __launch_bounds__(256) void head64_reduce_kernel(const float* __restrict__ partials, float* __restrict__ grads, int slots,
+                                                            int accumulate) {
+    sum_slots_16x16(partials, grads, slots, H64_PART / 4, 0x7fffffff, 0, 0, accumulate != 0);
 }
 
 }  // namespace piml
@@ -244,12 +245,15 @@ PIML_API int piml_head64_fwd(const piml_head64* A, void* stream) {
     return hipGetLastError();
 }
 
-PIML_API int piml_head64_bwd(const piml_head64* A, void* stream) {
+PIML_API int piml_head64_bwd(const piml_head64* A, void* stream) { return piml_head64_bwd_acc(A, 0, stream); }
+
+PIML_API int piml_head64_bwd_acc(const piml_head64* A, int accumulate, void* stream) {
     if (int e = head64_check(A, true)) return e;
     if (A->rows == 0) return hipSuccess;
     const int slots = piml_head64_slots(A->rows);
     hipLaunchKernelGGL(head64_bwd_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), *A);
-    hipLaunchKernelGGL(head64_reduce_kernel, dim3((H64_PART / 4 + 15) / 16), dim3(256), 0, as_stream(stream), A->partials, A->grads, slots);
+    hipLaunchKernelGGL(head64_reduce_kernel, dim3((H64_PART / 4 + 15) / 16), dim3(256), 0, as_stream(stream), A->partials, A->grads, slots,
+                       accumulate ? 1 : 0);
     trace_mark("head64_bwd", as_stream(stream));
     return hipGetLastError();
 }

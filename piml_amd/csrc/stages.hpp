@@ -13,7 +13,7 @@ int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
 int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
-int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s);
+int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate = false);
 // true when enc_stage_bwd_dw writes these branches' partials as layer-split slots (encoder_dw2.hip); then
 // n0[i] / n1[i] = the layer-0 / layer-1 slots of branch i
 bool enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1);

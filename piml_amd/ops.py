@@ -1515,6 +1515,8 @@ class _FusedEncoders(torch.autograd.Function):
                 outs += [msgs[b].view(*lead, ks[b], ENCODER_HIDDEN), pooled]
         ctx.save_for_backward(*x2s, *h1s, *h2s, *[w for wb in wbs for w in wb], packed)
         ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
+        ctx.sink = ParamGradSink._active if need_grad else None
+        ctx.params = tensors if ctx.sink is not None else None
         ctx.keeps = keeps
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -1557,11 +1559,18 @@ class _FusedEncoders(torch.autograd.Function):
         total = L.piml_encoder_workgroups(arr, len(live), ctypes.byref(w0))
         slots = [w0.value, total - w0.value] if len(live) == 2 else [total]
         parts = [torch.empty(n, part, **opt) for n in slots]
-        flats = [torch.empty(part, **opt) for _ in slots]
+        sink = ParamGradSink.current(ctx.sink)
+        flats, accumulate = (None, False)
+        if sink is not None:
+            flats, accumulate = sink.take([tuple(id(t) for t in ctx.params[7 * b + 1:7 * b + 7]) for b in live], part, opt)
+            if flats is None:
+                sink = None
+        if sink is None:
+            flats = [torch.empty(part, **opt) for _ in slots]
         for i in range(len(live)):
             arr[i].partials, arr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
         with torch.cuda.device(dev):
-            _lib.check(L.piml_encoder_bwd(arr, len(live), _stream()), 'piml_encoder_bwd')
+            _lib.check(L.piml_encoder_bwd_acc(arr, len(live), int(accumulate), _stream()), 'piml_encoder_bwd')
         H = ENCODER_HIDDEN
         for i, b in enumerate(live):
             flat = flats[i]
@@ -1575,7 +1584,10 @@ class _FusedEncoders(torch.autograd.Function):
             db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
             for j, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
                 if need[j]:
-                    grads[o + j] = t
+                    if sink is not None:
+                        sink.give(ctx.params[7 * b + j], t)
+                    else:
+                        grads[o + j] = t
         return tuple(grads)
 
 
@@ -1738,14 +1750,29 @@ class ParamGradSink:
                 p.grad = view if p.grad is None else p.grad + view
             self._seen, self._assign = None, None
 
-    def buffers(self, key, n_enc, part, n_dec, dpart, opt):
-        """-> (encoder flats, decoder flats, accumulate?) of the network `key` for this backward pass"""
-        b = self._bufs.get(key)
-        if b is None:
-            b = self._bufs[key] = ([torch.empty(part, **opt) for _ in range(n_enc)], [torch.empty(dpart, **opt) for _ in range(n_dec)])
-        acc = key in self._seen
-        self._seen.add(key)
-        return b[0], b[1], acc
+    def take(self, keys, size, opt):
+        """Persistent flat buffers (`size` floats) for the weight sets `keys` (one per branch of the call) in this backward
+        pass -> (buffers, accumulate?).  accumulate: they hold the sums of the step's earlier passes.  One launch has one
+        flag: when only some of the branches have been through a pass before (the last frame of a rollout may feed the
+        loss through one branch only), the others' buffers are cleared here and the launch accumulates into all of them."""
+        if not keys:
+            return None, False
+        seen = [k in self._seen for k in keys]
+        bufs = []
+        for k, was in zip(keys, seen):
+            b = self._bufs.get((k, size))
+            if b is None:
+                b = self._bufs[(k, size)] = torch.empty(size, **opt)
+            if any(seen) and not was:
+                b.zero_()
+            bufs.append(b)
+            self._seen.add(k)
+        return bufs, any(seen)
+
+    @staticmethod
+    def current(ctx_sink):
+        """the sink a backward pass may use: the one its forward ran under, if its step() is still open"""
+        return ctx_sink if (ctx_sink is not None and ctx_sink is ParamGradSink._active) else None
 
     def give(self, param, view):
         self._assign.setdefault(id(param), (param, view))
@@ -1894,14 +1921,17 @@ class _FusedPinnsf(torch.autograd.Function):
             parts = [torch.empty(n, part, **opt) for n in slots]
             # weight gradients: fresh buffers handed to autograd, or -- inside ParamGradSink.step(), whole network only -- the
             # sink's persistent ones, summed across the backward passes of the step by the slot-sum launch itself
-            sink = ctx.sink if (g_acc is not None and ctx.sink is ParamGradSink._active and not FORK_NETWORK) else None
+            sink = ParamGradSink.current(ctx.sink) if (g_acc is not None and not FORK_NETWORK) else None
             dflats = None
             if sink is not None:
-                key = tuple(id(t) for i, t in enumerate(ctx.params[:PER * nbr]) if i % PER)       # the weight tensors (not the inputs x)
-                flats, dflats, accumulate = sink.buffers(key, len(live), part, nbr, L.piml_decoder_partial_floats(), opt)
-                if accumulate:
+                ids = lambda lo, hi: tuple(id(t) for t in ctx.params[lo:hi])
+                flats, acc_e = sink.take([ids(PER * b + 1, PER * b + 7) for b in live], part, opt)
+                dflats, acc_d = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], L.piml_decoder_partial_floats(), opt)
+                if flats is None or dflats is None or acc_e != acc_d:
+                    sink, dflats = None, None
+                elif acc_e:
                     flags |= _lib.ACCUMULATE
-            else:
+            if sink is None:
                 flats = [torch.empty(part, **opt) for _ in slots]
             for i in range(len(live)):
                 earr[i].partials, earr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
@@ -2042,6 +2072,8 @@ class _FusedRowDecoder(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(*e2, *h1, *d2, *[w for wb in wbs for w in wb], dpack)
         ctx.meta = (nbr, rows, [tuple(e.shape) for e in embs], need_grad)
+        ctx.sink = ParamGradSink._active if need_grad else None
+        ctx.params = tensors if ctx.sink is not None else None
         ctx.set_materialize_grads(False)
         out = []
         for b in range(nbr):
@@ -2068,13 +2100,20 @@ class _FusedRowDecoder(torch.autograd.Function):
         opt = dict(device=dev, dtype=torch.float32)
         H = ENCODER_HIDDEN
         structs, keep, flats, gembs = [], [], [], []
-        for b in live:
+        sink = ParamGradSink.current(ctx.sink)
+        sunk, accumulate = (None, False)
+        if sink is not None:
+            sunk, accumulate = sink.take([tuple(id(t) for t in ctx.params[PER * b + 1:PER * b + 7]) for b in live],
+                                         L.piml_decoder_partial_floats(), opt)
+            if sunk is None:
+                sink = None
+        for i, b in enumerate(live):
             R = rows[b]
             gp = _gpu_f32('g_pred', gs[2 * b]).reshape(R, 2) if gs[2 * b] is not None else torch.zeros(R, 2, **opt)
             gd = _gpu_f32('g_decoded', gs[2 * b + 1]).reshape(R, 64) if gs[2 * b + 1] is not None else None
             gp2, gp1, gemb = torch.empty(R, 64, **opt), torch.empty(R, 64, **opt), torch.empty(R, H, **opt)
             parts = torch.empty(L.piml_rowdecoder_slots(R), L.piml_decoder_partial_floats(), **opt)
-            flat = torch.empty(L.piml_decoder_partial_floats(), **opt)
+            flat = sunk[i] if sink is not None else torch.empty(L.piml_decoder_partial_floats(), **opt)
             B = _dec_branch_struct(e2[b], R, 1, wbs[b], dpack[b], None, h1[b], d2[b], gp2, gp1, gemb, parts, flat)
             B.g_pred_rows, B.g_d2 = gp.data_ptr(), _ptr(gd)
             structs.append(B)
@@ -2082,7 +2121,7 @@ class _FusedRowDecoder(torch.autograd.Function):
             flats.append(flat)
             gembs.append(gemb)
         with torch.cuda.device(dev):
-            _lib.check(L.piml_rowdecoder_bwd((_lib.DecoderBranch * len(live))(*structs), len(live), _stream()),
+            _lib.check(L.piml_rowdecoder_bwd_acc((_lib.DecoderBranch * len(live))(*structs), len(live), int(accumulate), _stream()),
                        'piml_rowdecoder_bwd')
         for i, b in enumerate(live):
             o = 2 + PER * b
@@ -2094,7 +2133,10 @@ class _FusedRowDecoder(torch.autograd.Function):
             rest = flat[64 * H + 4096 + 128:]
             for jx, t in enumerate((dW1, rest[:64], dW2, rest[64:128], dW3, rest[128:130])):
                 if ctx.needs_input_grad[o + 1 + jx]:
-                    grads[o + 1 + jx] = t
+                    if sink is not None:
+                        sink.give(ctx.params[PER * b + 1 + jx], t)
+                    else:
+                        grads[o + 1 + jx] = t
         return tuple(grads)
 
 
@@ -2174,6 +2216,8 @@ class _CollisionHead64(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x2, hidden, out, *wb)
         ctx.x_shape = tuple(x.shape)
+        ctx.sink = ParamGradSink._active if need_grad else None
+        ctx.params = (w1, b1, w2, b2) if ctx.sink is not None else None
         ctx.set_materialize_grads(False)
         return out.view(x.shape[:-1])
 
@@ -2191,18 +2235,28 @@ class _CollisionHead64(torch.autograd.Function):
         gx = torch.empty(rows, 64, **opt) if ctx.needs_input_grad[0] else None
         part = L.piml_head64_partial_floats()
         partials = torch.empty(L.piml_head64_slots(rows), part, **opt)
-        grads = torch.empty(part, **opt)
+        sink = ParamGradSink.current(ctx.sink)
+        sunk, accumulate = (None, False)
+        if sink is not None:
+            sunk, accumulate = sink.take([tuple(id(t) for t in ctx.params)], part, opt)
+            if sunk is None:
+                sink = None
+        grads = sunk[0] if sink is not None else torch.empty(part, **opt)
         H = _lib.Head64()
         H.x, H.rows = x2.data_ptr(), rows
         H.w1, H.b1, H.w2, H.b2 = [t.data_ptr() for t in (w1, b1, w2, b2)]
         H.hidden, H.out, H.g_out = hidden.data_ptr(), out.data_ptr(), g.data_ptr()
         H.g_x, H.partials, H.grads = _ptr(gx), partials.data_ptr(), grads.data_ptr()
         with torch.cuda.device(x2.device):
-            _lib.check(L.piml_head64_bwd(ctypes.byref(H), _stream()), 'piml_head64_bwd')
+            _lib.check(L.piml_head64_bwd_acc(ctypes.byref(H), int(accumulate), _stream()), 'piml_head64_bwd')
         need = ctx.needs_input_grad
-        return (gx.view(ctx.x_shape) if gx is not None else None,
-                grads[:4096].view(64, 64) if need[1] else None, grads[4096:4160] if need[2] else None,
-                grads[4160:4224].view(1, 64) if need[3] else None, grads[4224:4225] if need[4] else None)
+        views = (grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64), grads[4224:4225])
+        if sink is not None:
+            for j, v in enumerate(views):
+                if need[1 + j]:
+                    sink.give(ctx.params[j], v)
+            return (gx.view(ctx.x_shape) if gx is not None else None, None, None, None, None)
+        return (gx.view(ctx.x_shape) if gx is not None else None,) + tuple(v if need[1 + j] else None for j, v in enumerate(views))
 
 
 def collision_head64(x, w1, b1, w2, b2):

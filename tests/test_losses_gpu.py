@@ -69,3 +69,42 @@ def test_rollout_losses_are_deterministic():
     first = ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9)
     for _ in range(10):
         assert torch.equal(first, ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9))
+
+
+@pytest.mark.parametrize('model', ['pinnsf_m', 'pinnsf_bm'])
+def test_param_grad_sink_equals_autograd_accumulation(model):
+    """ops.ParamGradSink: the weight gradients of several backward passes through the same network inside one optimiser step,
+    summed by the slot-sum launches themselves (PIML_ACCUMULATE / piml_*_bwd_acc), are BITWISE what autograd's per-tensor
+    accumulation gives (same sums, same order), for the fused network (`pinnsf_m`) and the encoder / row decoder / head64
+    operators of `pinnsf_bm`."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_simulator_gpu import sim_args
+    from piml_amd import ops
+    from piml_amd.models.simulators import BaseSimulator
+    torch.manual_seed(5)
+    sim = BaseSimulator(sim_args(model=model, dropout=0.0, learning_rate=1e-3))
+    net = sim.model
+    net.train(False)
+    g = torch.Generator().manual_seed(11)
+    frames = [(torch.randn(4, 122, 6, 6, generator=g).to(DEV), torch.randn(4, 122, 10, 6, generator=g).to(DEV),
+               torch.randn(4, 122, 7, generator=g).to(DEV)) for _ in range(3)]
+
+    def run(use_sink):
+        for p in net.parameters():
+            p.grad = None
+        import contextlib
+        sink = ops.ParamGradSink()
+        with (sink.step() if use_sink else contextlib.nullcontext()):
+            loss = 0
+            for pf, of, sf in frames:
+                out = net(pf, of, sf)
+                loss = loss + out[0].square().sum() + (out[-1].sum() if model == 'pinnsf_bm' else 0)
+            loss.backward()
+        return [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+    want, got = run(False), run(True)
+    assert sum(w is not None for w in want) >= 24
+    for (name, _), w, gt in zip(net.named_parameters(), want, got):
+        assert (w is None) == (gt is None), name
+        if w is not None:
+            assert torch.equal(w, gt), name

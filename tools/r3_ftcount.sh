@@ -2,5 +2,5 @@
 # kernels per fine-tuning step (HOT LOOP C, 4 windows x 5 frames x 122 agents, pinnsf_m, train mode): rocprofv3 kernel stats
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ftcount; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -- python3 $R/tools/train_mode_steps.py --models pinnsf_m --reps 200 --finetune-only > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -- python3 $R/tools/train_mode_steps.py --models ${MODEL:-pinnsf_m} --reps 200 --finetune-only > $O/log.txt 2>&1
 cp $(ls $O/p/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv; rm -rf $O/p
