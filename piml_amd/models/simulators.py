@@ -449,9 +449,7 @@ class BaseSimulator(Pedestrians):
         bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
         zero = torch.zeros((), device=dev)          # (one zero for every sum that starts at 0: each torch.zeros is a launch)
         pred_collisions = true_collision = zero
-        if bm_head:
-            pred_collisions = torch.zeros(data.ped_features[..., 0].shape, device=dev)
-            true_collision = torch.zeros(data.ped_features[..., 0].shape, device=dev)
+        pred_steps, true_steps = [], []             # bm head: per-frame records, stacked and gated once after the loop
         loss = zero
         reg_loss = zero
         nan_seen = None                             # (the fused frame step keeps its own flag on the device)
@@ -483,8 +481,8 @@ class BaseSimulator(Pedestrians):
             p_steps.append(p_cur)                                             # :728-729
             a_steps.append(a_cur)
             if bm_head:                                                       # :731-733
-                pred_collisions[:, t] = predictions[-1] * gf
-                true_collision[:, t] = self.calculate_collision_label(state[0]) * gf
+                pred_steps.append(predictions[-1])
+                true_steps.append(self.calculate_collision_label(state[0]))
             if args.reg_weight > 0:                                           # :735-737 (cumulative, as shipped)
                 reg_loss = reg_loss + self.l1_reg_loss(p_msg, args.reg_weight, 'sum') * gf
                 loss = loss + reg_loss * gf
@@ -584,6 +582,12 @@ class BaseSimulator(Pedestrians):
             # rounded prediction equals its label -- the values the six launches below would compute
             collision_pred_acc = zero + 1.0
         elif args.collision_pred_weight > 0:                                  # :826-830
+            # (c, t, n, k) records of :731-733: zeros in the frames before t_start, every frame times its gate -- one stack and
+            # one product instead of two slice assignments per frame
+            gk = gates_f.view(1, -1, 1, 1)
+            padk = [torch.zeros_like(true_steps[0])] * t_start if t_start else []
+            pred_collisions = torch.stack(padk + pred_steps, dim=1) * gk
+            true_collision = torch.stack(padk + true_steps, dim=1) * gk
             collision_pred_loss = F.binary_cross_entropy(pred_collisions, true_collision,
                                                          reduction='sum') * args.collision_pred_weight
             collision_pred_acc = torch.sum(torch.round(pred_collisions) == true_collision) / true_collision.numel()
