@@ -1315,10 +1315,13 @@ PIML_API int piml_decoder_bwd(const piml_decoder_branch* br, int nbr, const floa
 // slab of the row-wise dW kernel: a multiple of DEC_SLAB rows, at least 256 (the workgroup holds ~100 KB of LDS, one per
 // CU: with the reference's 24 576 + 40 960 rows the two branches make 96 + 160 = 256 workgroups, each pipelining 8 chunks),
 // and at most 256 slots per branch
+// (few rows -- the training rollout on real clips, 3 000 - 5 000 rows per branch: slabs of 64, or a dozen workgroups walk
+// eight chunks each while 240 CUs idle: pinnsf_bm fine-tuning step 1.45 -> 1.38 ms)
 static long long rowdec_slab(long long rows) {
     long long slab = (rows + 255) / 256;
     slab = (slab + DEC_SLAB - 1) / DEC_SLAB * DEC_SLAB;
-    return slab < 256 ? 256 : slab;
+    const long long least = rows < 16384 ? 64 : 256;
+    return slab < least ? least : slab;
 }
 
 // 32-row tiles (both branches) above which the row decoder runs one wave per tile with LDS-staged fragments
