@@ -658,6 +658,12 @@ class BaseSimulator(Pedestrians):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out, aux = one_step()
+                # every scalar the host reads after the step in ONE vector (one device-to-host read instead of eleven
+                # synchronising ones): the 7 loss terms, the two collision totals, the NaN flag, the predicted-agent count
+                aux['log_vec'] = torch.stack([*[o.detach().float().reshape(()) for o in out], aux['collisions'].float(),
+                                              aux['hard_collisions'].float(),
+                                              aux['nan_seen'].float() if torch.is_tensor(aux['nan_seen']) else out[0].detach().float() * 0,
+                                              (static.mask_p_pred == 1).sum().float()])
             self.model.obs_stream = None
             entry = (graph, static, out, aux)
             self._graphed_steps[key] = entry
@@ -755,13 +761,14 @@ class BaseSimulator(Pedestrians):
         from .. import hip_graphs_safe
         if channelled and getattr(args, 'hip_graph', True) and batch_data.position.is_cuda and hip_graphs_safe():
             out, aux = self._graphed_rollout_step(batch_data)
-            assert not bool(aux['nan_seen']), f'find nan in epoch : {self.epoch} {self.batch_idx}'
+            vals = aux['log_vec'].tolist()            # the step's only host synchronisation
+            assert not vals[9], f'find nan in epoch : {self.epoch} {self.batch_idx}'
             self._carry_dest_idx(batch_data, aux)
-            self.collision_count += aux['collisions'].item()
-            self.hard_collision_count += aux['hard_collisions'].item()
+            self.collision_count += vals[7]
+            self.hard_collision_count += vals[8]
             names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')
-            log.update({k: float(v.detach()) for k, v in zip(names, out)})
-            log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
+            log.update(dict(zip(names, vals[:7])))
+            log['n'] = int(vals[10])
             return log
         self.optimizer.zero_grad()
         if channelled:                                                                     # channelled windows
