@@ -744,13 +744,16 @@ class BaseSimulator(Pedestrians):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 terms = one_step()
-            entry = (graph, static, terms)
+                # the scalars the host logs, in one vector: one synchronising read per step (absent terms: NaN placeholders)
+                log_vec = torch.stack([(t.detach().float().reshape(()) if t is not None else terms[0].detach().float() * float('nan'))
+                                       for t in terms])
+            entry = (graph, static, terms, log_vec)
             self._graphed_steps[key] = entry
-        graph, static, terms = entry
+        graph, static, terms, log_vec = entry
         for dst, src in zip(static, batch):
             dst.copy_(src)
         graph.replay()
-        return terms
+        return terms, log_vec
 
     def train_batch(self, batch_data):
         """One optimiser step on either batch type (the body of simulators.py:314-360).
@@ -783,16 +786,20 @@ class BaseSimulator(Pedestrians):
             graphed = (getattr(args, 'hip_graph', True) and getattr(args, 'hip_graph_pointwise', True)
                        and batch_data[0].is_cuda and hip_graphs_safe() and self._capturable() and all(self._path_flags()))
             if graphed:
-                loss, mse_loss, reg, cp = self._graphed_pointwise_step(tuple(batch_data))
-            else:
-                loss, mse_loss, reg, cp = self._pointwise_terms(batch_data)
+                (loss, mse_loss, reg, cp), log_vec = self._graphed_pointwise_step(tuple(batch_data))
+                vals = log_vec.tolist()                # the step's only host synchronisation
+                if reg is not None:
+                    log['reg'] = vals[2]
+                if cp is not None:
+                    log['collision_pred'] = vals[3]
+                log.update(loss=vals[0], mse=vals[1], n=int(batch_data[3].shape[0]))
+                return log
+            loss, mse_loss, reg, cp = self._pointwise_terms(batch_data)
             if reg is not None:
                 log['reg'] = float(reg.detach())
             if cp is not None:
                 log['collision_pred'] = float(cp.detach())
             log.update(loss=float(loss.detach()), mse=float(mse_loss.detach()), n=int(batch_data[3].shape[0]))
-            if graphed:
-                return log
         loss.backward()
         self.optimizer.step()
         return log
