@@ -668,8 +668,8 @@ class BaseSimulator(Pedestrians):
             entry = (graph, static, out, aux)
             self._graphed_steps[key] = entry
         graph, static, out, aux = entry
-        for k in self._BATCH_TENSORS:
-            getattr(static, k).copy_(getattr(batch, k))
+        # the batch into the graph's static inputs: multi-tensor copies (one launch per dtype instead of one per tensor)
+        torch._foreach_copy_([getattr(static, k) for k in self._BATCH_TENSORS], [getattr(batch, k) for k in self._BATCH_TENSORS])
         graph.replay()
         return out, aux
 
@@ -750,8 +750,7 @@ class BaseSimulator(Pedestrians):
             entry = (graph, static, terms, log_vec)
             self._graphed_steps[key] = entry
         graph, static, terms, log_vec = entry
-        for dst, src in zip(static, batch):
-            dst.copy_(src)
+        torch._foreach_copy_(list(static), list(batch))
         graph.replay()
         return terms, log_vec
 
