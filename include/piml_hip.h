@@ -211,7 +211,8 @@ int piml_collision_friends(float* coll, const float* base, int C, int T, int S_b
  *   out[1] = sum [sum_t collisions > 0] abnormal ((p_res - (p_res.n) n) - (lab - (lab.n) n))^2 decay_t,
  *            n = (lab[T-1] - lab[0]) / (|.| + 1e-6)                            (multiple_rollout_collision_loss, 'sum')
  *   out[2] = the same with hard_collisions
- * g_mse / g_coll / g_hard (C, T, N, 2) = d out[i] / d p.  piml_rollout_losses_bwd: g_p = sum_i g_out[i] * g_i.  The sums
+ * g_mse / g_coll / g_hard (C, T, N, 2) = d out[i] / d p.  piml_rollout_losses_bwd: g_p = sum_i *g_out_i * g_i, the three
+ * upstream gradients as device scalars (NULL = 0).  The sums
  * run in a fixed order.  partial: 3 * piml_rollout_losses_blocks(C, N) floats, ticket: one zeroed unsigned (left zero);
  * both only used when piml_rollout_losses_blocks(C, N) > 1.
  */
@@ -220,8 +221,8 @@ int piml_rollout_losses(const float* p, const float* labels, long long labels_ld
                         const unsigned char* gates, const float* collisions, const float* hard_collisions,
                         const float* abnormal_mask, int C, int T, int N, float time_decay, float* out, float* g_mse,
                         float* g_coll, float* g_hard, float* partial, unsigned* ticket, void* stream);
-int piml_rollout_losses_bwd(const float* g_out, const float* g_mse, const float* g_coll, const float* g_hard, long long n,
-                            float* g_p, void* stream);
+int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, const float* g_out2, const float* g_mse,
+                            const float* g_coll, const float* g_hard, long long n, float* g_p, void* stream);
 
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);

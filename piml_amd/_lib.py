@@ -98,7 +98,7 @@ SIGNATURES = {
     'piml_encoder_split_tiles': [_ll],
     'piml_rollout_losses_blocks': [_i, _i],
     'piml_rollout_losses': [_p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
-    'piml_rollout_losses_bwd': [_p, _p, _p, _p, _ll, _p, _p],
+    'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],
     'piml_encoder_products': [_i],
     'piml_encoder_dw2': [_i],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],

@@ -133,10 +133,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A
     if (threadIdx.x == 0) *A.ticket = 0u;
 }
 
-__global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ g_mse,
+__global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_bwd_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
+                                                                         const float* __restrict__ g2, const float* __restrict__ g_mse,
                                                                          const float* __restrict__ g_coll, const float* __restrict__ g_hard,
                                                                          long long n, float* __restrict__ g_p) {
-    const float a = g_out[0], b = g_out[1], c = g_out[2];
+    const float a = g0 ? *g0 : 0.f, b = g1 ? *g1 : 0.f, c = g2 ? *g2 : 0.f;
     for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * LOSS_THREADS)
         g_p[e] = a * g_mse[e] + b * g_coll[e] + c * g_hard[e];
 }
@@ -165,11 +166,11 @@ PIML_API int piml_rollout_losses(const float* p, const float* labels, long long 
     return hipGetLastError();
 }
 
-PIML_API int piml_rollout_losses_bwd(const float* g_out, const float* g_mse, const float* g_coll, const float* g_hard,
-                                     long long n, float* g_p, void* stream) {
-    if (!g_out || !g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
+PIML_API int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, const float* g_out2, const float* g_mse,
+                                     const float* g_coll, const float* g_hard, long long n, float* g_p, void* stream) {
+    if (!g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
     long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
     hipLaunchKernelGGL(rollout_losses_bwd_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(LOSS_THREADS), 0, as_stream(stream),
-                       g_out, g_mse, g_coll, g_hard, n, g_p);
+                       g_out0, g_out1, g_out2, g_mse, g_coll, g_hard, n, g_p);
     return hipGetLastError();
 }

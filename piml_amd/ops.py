@@ -579,19 +579,21 @@ class _RolloutLosses(torch.autograd.Function):
                                              C, T, N, float(time_decay), _ptr(out), _ptr(gm), _ptr(gc), _ptr(gh),
                                              _ptr(partial), _ptr(ticket), _stream()), 'piml_rollout_losses')
         ctx.save_for_backward(gm, gc, gh)
-        return out
+        ctx.set_materialize_grads(False)
+        # three scalars, not one (3,) tensor: indexing that one costs a zero fill, a copy and an accumulation per term backward
+        return out[0], out[1], out[2]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_out):
-        if g_out is None or not ctx.needs_input_grad[0]:
+    def backward(ctx, g0, g1, g2):
+        if (g0 is None and g1 is None and g2 is None) or not ctx.needs_input_grad[0]:
             return (None,) * 8
         gm, gc, gh = ctx.saved_tensors
-        go = _gpu_f32('g_out', g_out)
+        gs = [None if g is None else _gpu_f32('g_out', g) for g in (g0, g1, g2)]
         gp = torch.empty_like(gm)
         with torch.cuda.device(gm.device):
-            _lib.check(_lib.lib().piml_rollout_losses_bwd(_ptr(go), _ptr(gm), _ptr(gc), _ptr(gh), gm.numel(), _ptr(gp),
-                                                          _stream()), 'piml_rollout_losses_bwd')
+            _lib.check(_lib.lib().piml_rollout_losses_bwd(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gm), _ptr(gc), _ptr(gh),
+                                                          gm.numel(), _ptr(gp), _stream()), 'piml_rollout_losses_bwd')
         return (gp,) + (None,) * 7
 
 
@@ -600,7 +602,7 @@ def rollout_losses(p, labels, mask_pred, gates, collisions=None, hard_collisions
     multiple_rollout_mse_loss and multiple_rollout_collision_loss (reduction 'sum') on the masked / gated positions, as
     test_multiple_rollouts_for_training puts them together (src/models/simulators.py:172-249, 790-819) -- as one launch
     forward and one backward.  p (C, T, N, 2) carries the gradient; labels (C, T, N, >= 2) unmasked; mask_pred (C, T, N) int64;
-    gates (T) bool.  Returns a (3,) tensor."""
+    gates (T) bool.  Returns the three scalars."""
     return _RolloutLosses.apply(p, labels, mask_pred, gates, collisions, hard_collisions, abnormal_mask, float(time_decay))
 
 

@@ -41,7 +41,7 @@ def test_rollout_losses_match_the_torch_expression(C, T, N, decay, with_abn):
     w = torch.tensor([1.0, 10.0, 100.0], device=DEV)
 
     p1 = p.clone().requires_grad_(True)
-    got = ops.rollout_losses(p1, labels, mask_pred, gates, coll, hard, abn, decay)
+    got = torch.stack(ops.rollout_losses(p1, labels, mask_pred, gates, coll, hard, abn, decay))
     (got * w).sum().backward()
     p2 = p.clone().requires_grad_(True)
     want = torch_losses(sim, p2, labels, mask_pred, gates, coll, hard, abn, decay)
@@ -53,7 +53,7 @@ def test_rollout_losses_match_the_torch_expression(C, T, N, decay, with_abn):
     assert torch.isfinite(got).all() and torch.isfinite(p1.grad).all()
     assert err <= 1e-5 and gerr <= 1e-5
     # without collision records only the squared error is asked for
-    only = ops.rollout_losses(p, labels, mask_pred, gates, None, None, None, decay)
+    only = torch.stack(ops.rollout_losses(p, labels, mask_pred, gates, None, None, None, decay))
     assert float((only[0] - got[0]).abs()) <= 1e-6 * float(got[0].abs()) and float(only[1]) == 0.0 and float(only[2]) == 0.0
 
 
@@ -66,9 +66,9 @@ def test_rollout_losses_are_deterministic():
     mask_pred = (torch.rand(C, T, N, generator=g) < 0.8).long().to(DEV)
     gates = mask_pred.sum(dim=(0, 2)) > 0
     coll = (torch.rand(C, T, N, generator=g) < 0.1).float().to(DEV)
-    first = ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9)
+    first = torch.stack(ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9))
     for _ in range(10):
-        assert torch.equal(first, ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9))
+        assert torch.equal(first, torch.stack(ops.rollout_losses(p, labels, mask_pred, gates, coll, coll, None, 0.9)))
 
 
 @pytest.mark.parametrize('model', ['pinnsf_m', 'pinnsf_bm'])
