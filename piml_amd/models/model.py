@@ -345,8 +345,22 @@ class _PINNSFBase(nn.Module):
                 msgs = predictor(decoded)
             return (msgs.sum(dim=-2) if want_sum else None), msgs, decoded, emb
         emb, pooled = pre if pre is not None else self._encode_process_pool(feats, encoder, processor)
-        acc = predictor(decoder(pooled))
-        return acc, emb, None, emb
+        return self._decode_pooled(pooled, decoder, predictor), emb, None, emb
+
+    def _decode_pooled(self, pooled, decoder, predictor):
+        """predictor(decoder(pooled)) of a non-bottleneck branch outside the whole-network operator (`pinnsf_res`): the row
+        decoder kernels with the agents in the role of the rows (ops.fused_row_decoder) when the geometry is the reference's
+        128 -> 64 -> 64 -> 2, else the library layers."""
+        dl, da = decoder.mlp[0::2], decoder.mlp[1::2]
+        if (FUSED_ROW_DECODER and FUSED_GLUE and pooled.is_cuda and pooled.dtype == torch.float32 and pooled.shape[-1] == 128
+                and len(dl) == 2 and (dl[0].in_features, dl[0].out_features, dl[1].in_features, dl[1].out_features) == (128, 64, 64, 64)
+                and isinstance(da[0], nn.ReLU) and isinstance(da[1], nn.Identity) and len(predictor.mlp) == 2
+                and (predictor.mlp[0].in_features, predictor.mlp[0].out_features) == (64, 2)
+                and isinstance(predictor.mlp[1], nn.Identity) and pooled.numel() // 128 >= FUSED_ENCODER_MIN_ROWS):
+            from .. import ops
+            return ops.fused_row_decoder([dict(emb=pooled, decoder=[t for lin in dl for t in (lin.weight, lin.bias)],
+                                               predictor=[predictor.mlp[0].weight, predictor.mlp[0].bias])])[0][0]
+        return predictor(decoder(pooled))
 
     def _fused_network(self, ped_features, obs_features, self_features):
         """`pinnsf` / `pinnsf_m` with the reference's default geometry: the whole network -- both encoders, processor
@@ -496,7 +510,7 @@ class _PINNSFBase(nn.Module):
         if self.residual:
             emb, pooled = self._process_and_pool(self.ped_processor, encoded)
             ped_msgs = emb
-            acc = self.ped_predictor(self.ped_decoder(pooled))
+            acc = self._decode_pooled(pooled, self.ped_decoder, self.ped_predictor)
             decoded = None
         else:
             acc, ped_msgs, decoded, emb = self._branch(ped_features, self.ped_encoder, self.ped_processor,
