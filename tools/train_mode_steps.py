@@ -65,7 +65,7 @@ def main():
         for train in ((True, False) if '--with-eval' in sys.argv else (True,)):
             tag = f'{model} {"train() dropout " + str(p) if train else "eval()"}'
             # ---- HOT LOOP A: pointwise rows (batch_size 128 in piml-gcdata.yaml; 1024 and 4096 for scale) ----
-            for rows in (() if '--finetune-only' in sys.argv else (128, 1024, 4096)):
+            for rows in (() if '--finetune-only' in sys.argv else ((128,) if '--pointwise-only' in sys.argv else (128, 1024, 4096))):
                 torch.manual_seed(666)
                 sim = BaseSimulator(sim_args(model=model, dropout=p, learning_rate=2e-4, collision_pred_weight=5e-2))
                 sim.model.train(train)
@@ -75,7 +75,7 @@ def main():
                 print(f'{tag}: pointwise pre-training step, {rows} rows: {ms:.3f} ms/step (one captured graph)', flush=True)
             # ---- HOT LOOP C: fine-tuning step, the golden GC batch (4 windows x 5 frames x 122 agents) and 8 x its agents ----
             data = load_data(g, 'train_' + ('pinnsf_m' if model == 'pinnsf_m' else 'pinnsf_bm'))
-            for times in ((1,) if '--finetune-only' in sys.argv else (1, 8)):
+            for times in (() if '--pointwise-only' in sys.argv else ((1,) if '--finetune-only' in sys.argv else (1, 8))):
                 torch.manual_seed(666)
                 sim = BaseSimulator(sim_args(model=model, dropout=p, learning_rate=1e-3, hip_graph=True))
                 sim.model.train(train)
