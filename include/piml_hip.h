@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 15
+#define PIML_HIP_ABI_VERSION 16
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -537,6 +537,13 @@ int piml_encoder_products(int split_bf16);
  * half the partial bytes -- and recomputes h1 from x when the branches carry none), 0 = one slab and both products per
  * workgroup (enc_bwd_dw_x3_kernel).  Environment at load time: PIML_ENC_DW2=0.  Returns the previous value; < 0 queries. */
 int piml_encoder_dw2(int layer_split);
+/* One-pass backward above piml_encoder_split_tiles() tiles (piml_amd/csrc/encoder_bwd3.hip; reference: the autograd of
+ * src/models/model.py:40-65 under :82-119): 1 (default) = where the layer-split weight gradients run, the forward left
+ * `relu_mask` and the branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are ONE launch
+ * that keeps the pre-activation gradients on the CU -- `g2` / `g1` are neither written nor read and may be NULL -- and dW3 /
+ * db3 are the layer-0 workgroups of piml_encoder_dw2's kernel; 0 = the dX kernel writes g2 / g1 and the weight-gradient kernel
+ * reads them back.  Environment at load time: PIML_ENC_FUSED_BWD=0.  Returns the previous value; < 0 only queries. */
+int piml_encoder_fused_bwd(int on);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve

@@ -9,8 +9,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 15
+# PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
+LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
+ABI_VERSION = 16
 
 _lib = None
 
@@ -101,6 +102,7 @@ SIGNATURES = {
     'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],
     'piml_encoder_products': [_i],
     'piml_encoder_dw2': [_i],
+    'piml_encoder_fused_bwd': [_i],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],

@@ -827,6 +827,7 @@ static int enc_check(const piml_encoder_branch* br, int nbr) {
 }
 
 static int enc_bwd_check(const piml_encoder_branch* br, int nbr);
+static bool enc_bwd_is_fused(const piml_encoder_branch* br, int nbr);
 
 
 // dynamic LDS above 64 KB has to be enabled per kernel once per process
@@ -881,9 +882,12 @@ static int enc_bwd_check(const piml_encoder_branch* br, int nbr) {
     bool no_h1 = false;
     for (int i = 0; i < nbr; ++i) {
         const piml_encoder_branch& b = br[i];
-        if (!b.h2 || !b.g2 || !b.g1 || !b.partials || !b.grads || b.k < 1 || (!b.g_pooled && !b.g_msgs)) return hipErrorInvalidValue;
+        if (!b.h2 || !b.partials || !b.grads || b.k < 1 || (!b.g_pooled && !b.g_msgs)) return hipErrorInvalidValue;
         no_h1 = no_h1 || !b.h1;
     }
+    if (!enc_bwd_is_fused(br, nbr))           // g2 / g1 scratch: only the two-kernel form passes them through memory
+        for (int i = 0; i < nbr; ++i)
+            if (!br[i].g2 || !br[i].g1) return hipErrorInvalidValue;
     if (no_h1) {
         for (int i = 0; i < nbr; ++i)
             if (br[i].h1 || !br[i].relu_mask) return hipErrorInvalidValue;
@@ -956,6 +960,15 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     const int total = fill_args(A, br, nbr);
+    if (enc_bwd_is_fused(br, nbr)) {          // dX chain + dW2 / dW1 / db2 / db1, one workgroup (four waves, one per SIMD) per CU
+        if (int e = x3_ready()) return e;
+        static int ready = -1;
+        if (ready < 0) ready = enc_f3_set_attributes();
+        if (ready) return ready;
+        const int nA[2] = {nbr > 1 ? A.wg_split : total, nbr > 1 ? total - A.wg_split : 0};
+        enc_f3_launch(A, nA, nA, s);
+        return hipGetLastError();
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (int e = enc_set_lds(reinterpret_cast<const void*>(enc_bwd_dx_kernel), DX_LDS_FLOATS * 4)) return e;
@@ -998,6 +1011,27 @@ PIML_API int piml_encoder_dw2(int on) {
     return old;
 }
 
+// One-pass backward (encoder_bwd3.hip): where the layer-split weight gradients run AND the forward left the sign bits AND the
+// branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are one launch that keeps g2 / g1
+// on the CU; dW3 / db3 stay with the layer-0 workgroups of encoder_dw2.hip, now all of them.  PIML_ENC_FUSED_BWD=0 keeps the
+// two-kernel form (A/B).
+static int g_f3 = getenv("PIML_ENC_FUSED_BWD") ? atoi(getenv("PIML_ENC_FUSED_BWD")) != 0 : 0;      // (off until it beats the two kernels)
+
+PIML_API int piml_encoder_fused_bwd(int on) {
+    const int old = g_f3;
+    if (on >= 0) g_f3 = on ? 1 : 0;
+    return old;
+}
+
+static bool enc_f3_used(const piml_encoder_branch* br, int nbr) {
+    if (!g_f3) return false;
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].relu_mask || (br[i].g_pooled != nullptr) != (br[0].g_pooled != nullptr) ||
+            (br[i].g_msgs != nullptr) != (br[0].g_msgs != nullptr) || (!br[i].g_pooled && !br[i].g_msgs))
+            return false;
+    return true;
+}
+
 bool piml::enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1) {
     if (!g_dw2 || !g_x3 || !br || nbr < 1 || nbr > 2) return false;
     long long tiles = 0;
@@ -1008,14 +1042,21 @@ bool piml::enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1
     if (tiles <= g_split_tiles) return false;
     const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
     const int w[2] = {w0, total - w0};
+    const bool f3 = enc_f3_used(br, nbr);
     for (int i = 0; i < nbr; ++i) {
         if (w[i] < 2) return false;
         int a, c;
         enc_dw2_split(w[i], &a, &c);
+        if (f3) a = c = w[i];        // every workgroup of the branch writes a layer-0 slot in one launch and a layer-1 slot in the other
         if (n0) n0[i] = a;
         if (n1) n1[i] = c;
     }
     return true;
+}
+
+// true: the backward of these branches is enc_f3_launch + the layer-0 half of enc_dw2_launch
+static bool enc_bwd_is_fused(const piml_encoder_branch* br, int nbr) {
+    return enc_dw2_used(br, nbr, nullptr, nullptr) && enc_f3_used(br, nbr);
 }
 
 int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s) {
@@ -1028,7 +1069,9 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
         if (ready) return ready;
         // the kernel variant (which upstream gradients exist) is per launch: branches that disagree are launched separately,
         // each on its own workgroups and slots
-        if (nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) && (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr))) {
+        if (enc_f3_used(br, nbr)) {                 // the lower layers' gradients came with the dX chain (enc_stage_bwd_dx)
+            enc_dw2_launch(A, total, s, true);
+        } else if (nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) && (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr))) {
             enc_dw2_launch(A, total, s);
         } else {
             for (int i = 0; i < 2; ++i) {

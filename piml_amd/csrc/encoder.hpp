@@ -69,6 +69,12 @@ int enc_dww_set_attributes();                                                   
 void enc_dww_launch(const EncArgs& A, int grid, bool drop, hipStream_t s);
 int enc_dw2_set_attributes();
 void enc_dw2_split(int w, int* n0, int* n1);          // a branch's w workgroups -> layer-0 / layer-1 workgroups
-void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s);
+// l0_only: every workgroup takes layer 0 (dW3 / db3); the lower layers' gradients come from enc_f3_launch
+void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s, bool l0_only = false);
+
+// encoder_bwd3.hip: dX chain + dW2 / dW1 / db2 / db1 in one pass (g2 / g1 never leave the CU); nA[b] workgroups for branch b,
+// their slots behind slot0[b] layer-0 slots of the branch's `partials`
+int enc_f3_set_attributes();
+void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, hipStream_t s);
 
 }  // namespace piml

@@ -402,13 +402,17 @@ static void dw2_go(const Dw2Args& D, dim3 g, bool drop, bool h1r, hipStream_t s)
 
 // A: the launch's branches (A.wg_split = workgroups of branch 0 out of `total`); both branches have the same kinds of
 // upstream gradients, keep bits and h1 (checked by the caller)
-void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s) {
+void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s, bool l0_only) {
     Dw2Args D;
     D.A = A;
     const int w0 = A.nbr > 1 ? A.wg_split : total;
     enc_dw2_split(w0, &D.n0[0], &D.n1[0]);
     D.n0[1] = D.n1[1] = 0;
     if (A.nbr > 1) enc_dw2_split(total - w0, &D.n0[1], &D.n1[1]);
+    if (l0_only) {
+        D.n0[0] = w0; D.n1[0] = 0;
+        D.n0[1] = A.nbr > 1 ? total - w0 : 0; D.n1[1] = 0;
+    }
     const bool pool = A.br[0].g_pooled != nullptr, msgs = A.br[0].g_msgs != nullptr;
     const bool drop = A.br[0].keep_bits != nullptr, h1r = A.br[0].h1 == nullptr;
     const dim3 g(total);

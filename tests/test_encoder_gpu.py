@@ -656,12 +656,95 @@ def test_layer_split_weight_gradients(shapes, upstream, drop, recompute, monkeyp
     assert max(worst.values()) <= 1e-5, worst
 
 
+def _float64_grads(br, gm, gp, drop):
+    """float64 autograd of one branch, with the injected keep mask when `drop`."""
+    from piml_amd import ops
+    if not drop:
+        _, _, rgx, rgw = reference(br, gm, gp)
+        return [rgx, *rgw]
+    keep = ops.unpack_keep_bits(br['keep_bits'], H).to(DEV).double().view(*br['x'].shape[:-1], H)
+    x = br['x'].detach().double().requires_grad_(True)
+    w = [t.detach().double().requires_grad_(True) for t in br['weights']]
+    h = torch.relu(torch.relu(x @ w[0].t() + w[1]) @ w[2].t() + w[3])
+    msgs = keep * br['scale'] * (h @ w[4].t() + w[5])
+    l64 = ((msgs * gm.double()).sum() if gm is not None else 0) + ((msgs.sum(-2) * gp.double()).sum() if gp is not None else 0)
+    l64.backward()
+    return [x.grad, *[t.grad for t in w]]
+
+
+@pytest.mark.parametrize('shapes,upstream,drop', [
+    ([(4096, 6, 6), (4096, 10, 6)], 'pooled', False), ([(4096, 6, 6), (4096, 10, 6)], 'pooled', True),
+    ([(4096, 6, 6), (4096, 10, 6)], 'both', True), ([(5000, 7, 5), (3001, 5, 8)], 'msgs', False), ([(9000, 5, 6)], 'both', False),
+    ([(4099, 9, 3), (2050, 13, 1)], 'pooled', False),         # ragged last tiles, in_dim 3 and 1, k that does not divide 32
+    ([(8192, 6, 6), (8192, 10, 6)], 'pooled', True), ([(16384, 6, 6), (16384, 10, 6)], 'pooled', False),
+])
+def test_one_pass_backward(shapes, upstream, drop):
+    """piml_amd/csrc/encoder_bwd3.hip -- dX chain + dW2 / dW1 / db2 / db1 in one launch, g2 / g1 never stored -- against float64
+    and against the two-kernel form (enc_bwd_dx_x3_kernel + enc_bwd_dw2_x3_kernel) on the same inputs; twice, bitwise equal
+    (no atomics).  The no-input-gradient form (pointwise training) rides along: same weight gradients bit for bit."""
+    from piml_amd import ops, _lib
+    L = _lib.lib()
+    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles(-1)
+    g = torch.Generator().manual_seed(78)
+    branches = [dodge_relu_kinks(make_branch(n, k, d, seed=3 * i + 2, scale=4.0 if drop else 2.0)) for i, (n, k, d) in enumerate(shapes)]
+    if drop:
+        for br, (n, k, d) in zip(branches, shapes):
+            br['keep_bits'] = ops.pack_keep_bits(torch.rand(n * k, H, generator=g) >= 0.5).to(DEV)
+    ups = []
+    for (n, k, d) in shapes:
+        gm = torch.randn(n, k, H, generator=g).to(DEV) if upstream in ('both', 'msgs') else None
+        gp = torch.randn(n, H, generator=g).to(DEV) if upstream in ('both', 'pooled') else None
+        ups.append((gm, gp))
+    leaves = [t for br in branches for t in (br['x'], *br['weights'])]
+
+    def run():
+        outs = ops.fused_encoders(branches)
+        loss = 0
+        for (msgs, pooled), (gm, gp) in zip(outs, ups):
+            loss = loss + ((msgs * gm).sum() if gm is not None else 0) + ((pooled * gp).sum() if gp is not None else 0)
+        return torch.autograd.grad(loss, leaves)
+    res = {}
+    old = L.piml_encoder_fused_bwd(-1)
+    try:
+        for on in (1, 0):
+            L.piml_encoder_fused_bwd(on)
+            res[on] = run()
+        L.piml_encoder_fused_bwd(1)
+        again = run()
+        for br in branches:
+            br['x'].requires_grad_(False)
+        wleaves = [t for br in branches for t in br['weights']]
+        outs = ops.fused_encoders(branches)
+        loss = 0
+        for (msgs, pooled), (gm, gp) in zip(outs, ups):
+            loss = loss + ((msgs * gm).sum() if gm is not None else 0) + ((pooled * gp).sum() if gp is not None else 0)
+        no_gx = torch.autograd.grad(loss, wleaves)
+    finally:
+        L.piml_encoder_fused_bwd(old)
+        for br in branches:
+            br['x'].requires_grad_(True)
+    for a, b in zip(res[1], again):
+        assert torch.equal(a, b), 'one-pass backward is not reproducible'
+    for a, b in zip([t for i, t in enumerate(res[1]) if i % 7], no_gx):
+        assert torch.equal(a, b), 'weight gradients depend on whether g_x is wanted'
+    worst = {}
+    it1, it0 = iter(res[1]), iter(res[0])
+    for br, (gm, gp) in zip(branches, ups):
+        for name, r in zip(('g_x', 'dW1', 'db1', 'dW2', 'db2', 'dW3', 'db3'), _float64_grads(br, gm, gp, drop)):
+            a, b = next(it1), next(it0)
+            worst[name] = max(worst.get(name, 0), relerr(a, r))
+            worst[name + ' vs two kernels'] = max(worst.get(name + ' vs two kernels', 0), relerr(a, b.double()))
+    print(f'one-pass backward {shapes} upstream={upstream} drop={drop}: ' + ', '.join(f'{k} {v:.1e}' for k, v in worst.items()))
+    assert max(worst.values()) <= 1e-5, worst
+
+
 @pytest.mark.parametrize('shapes', [[(4096, 6, 6), (4096, 10, 6)], [(5000, 7, 5), (33, 3, 8)]])
 def test_sign_bit_masks_equal_the_saved_activations(shapes, monkeypatch):
     """The dX chain of the split-product kernels masks with the signs of h1 / h2 read as bits (piml_encoder_branch.relu_mask,
     written by the forward) or, without that buffer, with the saved activations themselves: the same predicate, so every
     output and gradient is bitwise identical."""
-    from piml_amd import ops
+    from piml_amd import ops, _lib
+    old = _lib.lib().piml_encoder_fused_bwd(0)         # (the one-pass backward needs the bits: test_one_pass_backward)
     res = {}
     for masks in (True, False):
         monkeypatch.setattr(ops, 'RELU_MASK', masks)
@@ -670,6 +753,7 @@ def test_sign_bit_masks_equal_the_saved_activations(shapes, monkeypatch):
         outs = ops.fused_encoders(brs)
         loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
         res[masks] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
+    _lib.lib().piml_encoder_fused_bwd(old)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
 
