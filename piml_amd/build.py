@@ -24,6 +24,10 @@ CFLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=
           '-fhip-fp32-correctly-rounded-divide-sqrt',
           '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 FLAGS = CFLAGS + ['-shared']      # (the one-command form; kept for readers of older notes)
+# per-file extras.  encoder_bwd3.hip: its vector work sits between matrix instructions issued by ONE wave per SIMD, where a
+# packed-f32 instruction (v_pk_fma_f32 / v_pk_add_f32, what the SLP vectoriser makes of two neighbouring scalar operations)
+# costs ~16 issue cycles against 2 x 4 (tools/probe_mfma_slots.hip).
+FILE_FLAGS = {'encoder_bwd3.hip': ['-fno-slp-vectorize']}
 
 
 def sources():
@@ -84,7 +88,7 @@ def build(force=False, verbose=False, extra=()):
         return LIB
     flags = CFLAGS + list(extra) + os.environ.get('PIML_HIPCC_EXTRA', '').split()
     with ThreadPoolExecutor(max_workers=int(os.environ.get('PIML_BUILD_JOBS', '4'))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, flags, verbose=verbose, force=bool(extra)), sources()))
+        objs = list(ex.map(lambda s: _compile(s, flags + FILE_FLAGS.get(os.path.basename(s), []), verbose=verbose, force=bool(extra)), sources()))
     return _link(objs, LIB, verbose)
 
 
@@ -95,7 +99,8 @@ def variant(name, defines, verbose=False):
     objs = []
     for s in sources():
         extra = defines.get(os.path.basename(s))
-        objs.append(_compile(s, flags + list(extra), tag='.' + name, verbose=verbose) if extra else _compile(s, flags, verbose=verbose))
+        ff = flags + FILE_FLAGS.get(os.path.basename(s), [])
+        objs.append(_compile(s, ff + list(extra), tag='.' + name, verbose=verbose) if extra else _compile(s, ff, verbose=verbose))
     return _link(objs, os.path.join(HERE, f'libpiml_hip_{name}.so'), verbose)
 
 

@@ -872,6 +872,9 @@ PIML_API int piml_encoder_products(int x3) {
     return old;
 }
 
+// PIML_ENC_FUSED_DW3=0: dW3 / db3 stay a launch of their own (the layer-0 workgroups of encoder_dw2.hip) behind the one-pass kernel
+static int g_f3_dw3 = !(getenv("PIML_ENC_FUSED_DW3") && atoi(getenv("PIML_ENC_FUSED_DW3")) == 0);
+
 // PIML_ENC_DX_SPLIT=f32: the few-rows dX chain on the f32 matrix instruction even with split products elsewhere (A/B)
 static const bool g_dx_split_f32 = getenv("PIML_ENC_DX_SPLIT") && getenv("PIML_ENC_DX_SPLIT")[0] == 'f';
 
@@ -966,7 +969,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
         if (ready < 0) ready = enc_f3_set_attributes();
         if (ready) return ready;
         const int nA[2] = {nbr > 1 ? A.wg_split : total, nbr > 1 ? total - A.wg_split : 0};
-        enc_f3_launch(A, nA, nA, s);
+        enc_f3_launch(A, nA, nA, g_f3_dw3 != 0, s);
         return hipGetLastError();
     }
     static bool attr_set = false;
@@ -1015,7 +1018,7 @@ PIML_API int piml_encoder_dw2(int on) {
 // branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are one launch that keeps g2 / g1
 // on the CU; dW3 / db3 stay with the layer-0 workgroups of encoder_dw2.hip, now all of them.  PIML_ENC_FUSED_BWD=0 keeps the
 // two-kernel form (A/B).
-static int g_f3 = getenv("PIML_ENC_FUSED_BWD") ? atoi(getenv("PIML_ENC_FUSED_BWD")) != 0 : 0;      // (off until it beats the two kernels)
+static int g_f3 = !(getenv("PIML_ENC_FUSED_BWD") && atoi(getenv("PIML_ENC_FUSED_BWD")) == 0);
 
 PIML_API int piml_encoder_fused_bwd(int on) {
     const int old = g_f3;
@@ -1027,7 +1030,8 @@ static bool enc_f3_used(const piml_encoder_branch* br, int nbr) {
     if (!g_f3) return false;
     for (int i = 0; i < nbr; ++i)
         if (!br[i].relu_mask || (br[i].g_pooled != nullptr) != (br[0].g_pooled != nullptr) ||
-            (br[i].g_msgs != nullptr) != (br[0].g_msgs != nullptr) || (!br[i].g_pooled && !br[i].g_msgs))
+            (br[i].g_msgs != nullptr) != (br[0].g_msgs != nullptr) || (!br[i].g_pooled && !br[i].g_msgs) ||
+            (br[i].g_x != nullptr) != (br[0].g_x != nullptr) || br[i].rows >= (1ll << 22))      // (32-bit byte offsets into (rows, 128) arrays)
             return false;
     return true;
 }
@@ -1070,7 +1074,7 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
         // the kernel variant (which upstream gradients exist) is per launch: branches that disagree are launched separately,
         // each on its own workgroups and slots
         if (enc_f3_used(br, nbr)) {                 // the lower layers' gradients came with the dX chain (enc_stage_bwd_dx)
-            enc_dw2_launch(A, total, s, true);
+            if (!g_f3_dw3) enc_dw2_launch(A, total, s, true);        // (and dW3 / db3 too, unless PIML_ENC_FUSED_DW3=0)
         } else if (nbr == 1 || ((br[0].g_pooled != nullptr) == (br[1].g_pooled != nullptr) && (br[0].g_msgs != nullptr) == (br[1].g_msgs != nullptr))) {
             enc_dw2_launch(A, total, s);
         } else {
