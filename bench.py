@@ -832,7 +832,7 @@ def main():
         overhead_ms_samples = [tc.elapsed_ms() for _, tc in sample_timers]
     # median over the sampled launches: robust against the occasional preempted / cold sample
     launches_per_sample = TIMED_LAUNCHES if graph is not None else 1
-    raw_ms = sorted(kernel_ms_samples)[(len(kernel_ms_samples) - 1) // 2]      # (lower) median of the intervals around `launches_per_sample` launches
+    raw_ms = median(kernel_ms_samples)      # median of the intervals around `launches_per_sample` launches
     _phase('relfeat samples (ms): ' + ', '.join(f'{v:.4f}' for v in kernel_ms_samples))
     overhead_ms = median(overhead_ms_samples)
     kernel_ms = max(raw_ms - overhead_ms, 1e-6) / launches_per_sample
@@ -845,12 +845,12 @@ def main():
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
     prof = None
-    ppath = os.path.join(ROOT, 'profiles', 'r03_step_counters.json')
-    if world == 1 and os.path.exists(ppath):
-        pj = json.load(open(ppath))
+    pname = next((f for f in ('r04_step_counters.json', 'r03_step_counters.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+    if world == 1 and pname:
+        pj = json.load(open(os.path.join(ROOT, 'profiles', pname)))
         if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
             prof = pj
-    prof_src = 'profiles/r03_step_counters.json (rocprofv3 --pmc passes of the same command, committed: STATIC, not measured in this run)'
+    prof_src = f'profiles/{pname} (rocprofv3 --pmc passes of the same command, committed: STATIC, not measured in this run)'
 
     # every launch stage of the step, timed LIVE (outside the timed region): HIP events between the stage launches of an
     # eager step queued behind replays of the captured one (Step.trace_stages)
@@ -863,13 +863,23 @@ def main():
     _phase('stage trace done')
     x3 = '_x3' if x3_products else ''
     dw = 'dw'
+    one_pass = False
     if x3_products and fused_mlp:      # the layer-split weight-gradient kernel (encoder_dw2.hip) above the few-rows bound
         from piml_amd import _lib as _plib
         if _plib.lib().piml_encoder_dw2(-1) == 1 and N * (6 + 10) // 32 > _plib.lib().piml_encoder_split_tiles(-1):
             dw = 'dw2'
+            # ... and on top of it the one-pass backward (encoder_bwd3.hip): dX chain + every weight gradient in the `enc_bwd_dx`
+            # stage, the `enc_bwd_dw` stage launches nothing (PIML_ENC_FUSED_BWD / PIML_ENC_FUSED_DW3 switch it back)
+            one_pass = _plib.lib().piml_encoder_fused_bwd(-1) == 1 and os.environ.get('PIML_RELU_MASK', '1') != '0'
     stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
                     'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
                     'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
+    if one_pass:
+        stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
+        if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':
+            stage_kernel['enc_bwd_dw'] = '(no launch: dW3 is phase 2 of enc_bwd_fused_x3_kernel)'
+    # kernels whose f32 products run as six bf16 products (priced against the bf16 matrix pipe AND the HBM ceiling)
+    split_kernels = {'enc_fwd_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw2_x3_kernel', 'enc_bwd_dw_x3w_kernel', 'enc_bwd_fused_x3_kernel'}
     static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
     if os.environ.get('PIML_DEC_BWD_SPLIT', '1') != '0':       # decoder backward as (tile, branch) workgroups (the default)
         stage_kernel['dec_bwd'] = 'dec_bwd_split_kernel'
@@ -892,12 +902,14 @@ def main():
             if stage in ('relfeat_fwd', 'event_pair_overhead'):
                 continue
             kname = stage_kernel.get(stage, stage)
+            if kname.startswith('(no launch') and us < 3.0:
+                continue
             e = {'name': kname, 'us': us, 'share_of_step': us / (ms_per_step * 1e3), 'us_source': live_src}
             sk = static.get(kname)
             if sk:       # counters are static; every fraction is recomputed from the LIVE duration
                 e['hbm_bytes'] = sk.get('hbm_bytes')
                 e['hbm_frac'] = sk['hbm_bytes'] / (us * 1e-6) / (HBM_PEAK_GBS * 1e9) if sk.get('hbm_bytes') else None
-                if '_x3_' in kname and sk.get('flops'):
+                if kname in split_kernels and sk.get('flops'):
                     bf16 = 6.0 * sk['flops'] * (2 * 128 * 128) / (2 * 128 * 128 + 6 * 128)      # executed: 6 x the two 128 x 128 layers
                     e['mfma_frac'] = bf16 / (us * 1e-6) / 2.5e15
                     e['bound'] = 'hbm' if (e['hbm_frac'] or 0) >= e['mfma_frac'] else 'mfma'
@@ -1061,8 +1073,9 @@ def main():
                 secondary['pinnsf_bm_step'] = {
                     'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': bm.mode,
                     'note': '`--model pinnsf_bm` (decoder + predictor per NEIGHBOUR row): the same forward + backward step; '
-                            'fused encoders + fused row decoder (piml_rowdecoder_*), its 64->64->1 collision head on library '
-                            'GEMMs; 1.145 ms/step with the decoders on library GEMMs (PIML_FUSED_ROW_DECODER=0)'}
+                            'fused encoders (one-pass backward, encoder_bwd3.hip) + fused row decoder (piml_rowdecoder_*) + its '
+                            '64->64->1 collision head on matrix cores (head64.hip): no library GEMM; 1.145 ms/step with the '
+                            'decoders on library GEMMs (PIML_FUSED_ROW_DECODER=0)'}
                 del bm
             except Exception as ex:   # noqa: BLE001 - informational
                 secondary['pinnsf_bm_step'] = {'error': f'{type(ex).__name__}: {ex}'}

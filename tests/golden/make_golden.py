@@ -795,7 +795,83 @@ def gen_mainflow_pointwise(cases=('gc', 'ucy'),
         os.chdir(cwd)
 
 
-GENS = dict(mainflow_pointwise=gen_mainflow_pointwise, mainflow=gen_mainflow, relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
+def gen_mainflow_spread(case='ucy'):
+    """The REFERENCE against ITSELF: the same train -> finetune -> test sequence as gen_mainflow (same seed, same weights, same
+    batches), run again under other -- equally valid -- float32 summation orders of the reference's own CPU kernels:
+      threads1    torch.set_num_threads(1)   (the GEMM / reduction blocking follows the thread count)
+      threads4    torch.set_num_threads(4)
+      nomkldnn    torch.backends.mkldnn disabled (nn.Linear through the native BLAS path)
+    and records what moves: the final test row [loss, mse, mae, ot, mmd], the collision counts, the per-epoch fine-tuning
+    losses and the best fine-tuned weights' L2 norm + the tensors mainflow_<case>.npz keeps.  The committed fixture of
+    gen_mainflow is the 8-thread run.  tests/test_main_gpu.py bounds this package's distance to the reference by the
+    reference's own spread (mainflow_<case>_spread.npz)."""
+    import contextlib
+    import io
+    import re
+    import yaml
+    import data.dataset as DATASET
+    import models.simulators as SIM
+    import utils.data_loader as LOADER
+    scratch = '/tmp/piml_ref_mainflow_spread'
+    os.makedirs(os.path.join(scratch, 'src'), exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(os.path.join(scratch, 'src'))
+    float_re = r'([-+0-9.eE]+|nan|inf)'
+    cfg = MAINFLOW_CASES[case]
+    out = {}
+    try:
+        for tag in ('threads8', 'threads1', 'threads4', 'nomkldnn'):
+            torch.set_num_threads({'threads1': 1, 'threads4': 4}.get(tag, 8))
+            mk = torch.backends.mkldnn.flags(enabled=tag != 'nomkldnn')
+            args = mainflow_args(case, exp_name=f'spread_{case}_{tag}')
+            yamls = {}
+            for stage in ('pretrain', 'finetune'):
+                path = os.path.join(scratch, f'{case}_{stage}.yaml')
+                yaml.safe_dump({k: [os.path.join(REF, f) for f in v] for k, v in cfg[stage].items()}, open(path, 'w'))
+                yamls[stage] = path
+            log = io.StringIO()
+            with mk, contextlib.redirect_stdout(log):
+                np.random.seed(args.seed)
+                torch.manual_seed(args.seed)
+                synthetic = DATASET.PointwisePedDataset()
+                synthetic.load_data(yamls['pretrain'])
+                synthetic.build_dataset(args)
+                np.random.seed(args.seed)
+                loaders = LOADER.data_loader(synthetic.train_data, args.batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
+                torch.manual_seed(args.seed)
+                sim = SIM.BaseSimulator(args)
+                sim.train(loaders, synthetic.valid_data)
+                real = DATASET.TimeIndexedPedDataset2()
+                real.load_data(yamls['finetune'])
+                real.build_dataset(args)
+                ft_loaders = LOADER.data_loader(real.train_data, args.ft_batch_size, args.seed, shuffle=args.shuffle, drop_last=True)
+                print('@@ stage finetune')
+                sim.finetune(ft_loaders, real.valid_data, real.test_data)
+                best_ft = torch.load(f'../saved_model/{args.exp_name}_{args.model_name_suffix}_finetuned')
+            text = log.getvalue()
+            pre, ft = text.split('@@ stage finetune')
+
+            def grab(txt, pattern):
+                return np.array([[float(x) for x in (m if isinstance(m, tuple) else (m,))] for m in re.findall(pattern, txt)], np.float64)
+            out[f'{tag}/pre_train'] = grab(pre, r'Training loss:' + float_re + r', mse:' + float_re)
+            out[f'{tag}/pre_val'] = grab(pre, r'Validation loss:' + float_re + r', val_mse:' + float_re)
+            out[f'{tag}/ft_train'] = grab(ft, r'Training loss:' + float_re + r', mse:' + float_re + r', coll_pred:' + float_re +
+                                          r', acc_pred:' + float_re + r', coll:' + float_re + r', hard_coll:' + float_re)
+            out[f'{tag}/ft_test'] = grab(ft, r'Test loss:' + float_re + r', test_mse:' + float_re + r', test_mae:' + float_re +
+                                         r', test ot:' + float_re + r', test mmd:' + float_re)
+            out[f'{tag}/collisions'] = grab(ft, r'test/val collision count hard/soft: ' + float_re + r' & ' + float_re)
+            out[f'{tag}/l2'] = np.float64(sum(float((v.double() ** 2).sum()) for v in best_ft.values()) ** 0.5)
+            for k, v in best_ft.items():
+                if k.startswith(('ped_encoder.mlp.0', 'ped_encoder.mlp.2', 'ped_encoder.mlp.4', 'obs_encoder.mlp.2', 'ped_predictor')):
+                    out[f'{tag}/w/{k}'] = v.clone()
+            print(tag, 'final test row', out[f'{tag}/ft_test'][-1], 'collisions', out[f'{tag}/collisions'][-1], flush=True)
+        save(f'mainflow_{case}_spread', **out)
+    finally:
+        torch.set_num_threads(8)
+        os.chdir(cwd)
+
+
+GENS = dict(mainflow_spread=gen_mainflow_spread, mainflow_pointwise=gen_mainflow_pointwise, mainflow=gen_mainflow, relfeat=gen_relfeat, collision=gen_collision, mlapm=gen_mlapm, calcacc=gen_calcacc, model=gen_model, rollout=gen_rollout, dataset=gen_dataset, metrics=gen_metrics, rollout_more=gen_rollout_more, rollout_flags=gen_rollout_flags, model_polar=gen_model_polar)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(GENS)
