@@ -870,7 +870,7 @@ def main():
             dw = 'dw2'
             # ... and on top of it the one-pass backward (encoder_bwd3.hip): dX chain + every weight gradient in the `enc_bwd_dx`
             # stage, the `enc_bwd_dw` stage launches nothing (PIML_ENC_FUSED_BWD / PIML_ENC_FUSED_DW3 switch it back)
-            one_pass = _plib.lib().piml_encoder_fused_bwd(-1) == 1 and os.environ.get('PIML_RELU_MASK', '1') != '0'
+            one_pass = _plib.lib().piml_encoder_fused_bwd(-1) >= 1 and os.environ.get('PIML_RELU_MASK', '1') != '0'
     stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
                     'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
                     'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}

@@ -542,7 +542,10 @@ int piml_encoder_dw2(int layer_split);
  * `relu_mask` and the branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are ONE launch
  * that keeps the pre-activation gradients on the CU -- `g2` / `g1` are neither written nor read and may be NULL -- and dW3 /
  * db3 are the layer-0 workgroups of piml_encoder_dw2's kernel; 0 = the dX kernel writes g2 / g1 and the weight-gradient kernel
- * reads them back.  Environment at load time: PIML_ENC_FUSED_BWD=0.  Returns the previous value; < 0 only queries. */
+ * reads them back; 2 = the one-pass kernel as eight waves of 16-feature blocks (encoder_bwd4.hip, two waves per SIMD; measured
+ * level with the four-wave form, kept for A/B).  In the one-pass forms dW3 / db3 are a second phase of the same launch
+ * (PIML_ENC_FUSED_DW3=0: the layer-0 workgroups of piml_encoder_dw2's kernel in a launch of their own).  Environment at load
+ * time: PIML_ENC_FUSED_BWD=0 / 1 / 2.  Returns the previous value; < 0 only queries. */
 int piml_encoder_fused_bwd(int on);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);

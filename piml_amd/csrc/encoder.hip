@@ -872,6 +872,18 @@ PIML_API int piml_encoder_products(int x3) {
     return old;
 }
 
+// One-pass backward (encoder_bwd3.hip): where the layer-split weight gradients run AND the forward left the sign bits AND the
+// branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are one launch that keeps g2 / g1
+// on the CU; dW3 / db3 stay with the layer-0 workgroups of encoder_dw2.hip, now all of them.  PIML_ENC_FUSED_BWD=0 keeps the
+// two-kernel form (A/B).
+static int g_f3 = getenv("PIML_ENC_FUSED_BWD") ? (atoi(getenv("PIML_ENC_FUSED_BWD")) == 2 ? 2 : atoi(getenv("PIML_ENC_FUSED_BWD")) != 0) : 1;
+
+PIML_API int piml_encoder_fused_bwd(int on) {
+    const int old = g_f3;
+    if (on >= 0) g_f3 = on == 2 ? 2 : (on ? 1 : 0);
+    return old;
+}
+
 // PIML_ENC_FUSED_DW3=0: dW3 / db3 stay a launch of their own (the layer-0 workgroups of encoder_dw2.hip) behind the one-pass kernel
 static int g_f3_dw3 = !(getenv("PIML_ENC_FUSED_DW3") && atoi(getenv("PIML_ENC_FUSED_DW3")) == 0);
 
@@ -966,10 +978,14 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (enc_bwd_is_fused(br, nbr)) {          // dX chain + dW2 / dW1 / db2 / db1, one workgroup (four waves, one per SIMD) per CU
         if (int e = x3_ready()) return e;
         static int ready = -1;
-        if (ready < 0) ready = enc_f3_set_attributes();
+        if (ready < 0) {
+            ready = enc_f3_set_attributes();
+            if (!ready) ready = enc_f4_set_attributes();
+        }
         if (ready) return ready;
         const int nA[2] = {nbr > 1 ? A.wg_split : total, nbr > 1 ? total - A.wg_split : 0};
-        enc_f3_launch(A, nA, nA, g_f3_dw3 != 0, s);
+        if (g_f3 == 2) enc_f4_launch(A, nA, nA, g_f3_dw3 != 0, s);      // eight waves of 16-feature blocks (encoder_bwd4.hip)
+        else enc_f3_launch(A, nA, nA, g_f3_dw3 != 0, s);                // four waves of 32-feature blocks (encoder_bwd3.hip): the default
         return hipGetLastError();
     }
     static bool attr_set = false;
@@ -1011,18 +1027,6 @@ static int g_dw2 = !(getenv("PIML_ENC_DW2") && atoi(getenv("PIML_ENC_DW2")) == 0
 PIML_API int piml_encoder_dw2(int on) {
     const int old = g_dw2;
     if (on >= 0) g_dw2 = on ? 1 : 0;
-    return old;
-}
-
-// One-pass backward (encoder_bwd3.hip): where the layer-split weight gradients run AND the forward left the sign bits AND the
-// branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are one launch that keeps g2 / g1
-// on the CU; dW3 / db3 stay with the layer-0 workgroups of encoder_dw2.hip, now all of them.  PIML_ENC_FUSED_BWD=0 keeps the
-// two-kernel form (A/B).
-static int g_f3 = !(getenv("PIML_ENC_FUSED_BWD") && atoi(getenv("PIML_ENC_FUSED_BWD")) == 0);
-
-PIML_API int piml_encoder_fused_bwd(int on) {
-    const int old = g_f3;
-    if (on >= 0) g_f3 = on ? 1 : 0;
     return old;
 }
 

@@ -74,6 +74,9 @@ void enc_dw2_launch(const EncArgs& A, int total, hipStream_t s, bool l0_only = f
 
 // encoder_bwd3.hip: dX chain + dW2 / dW1 / db2 / db1 in one pass (g2 / g1 never leave the CU); nA[b] workgroups for branch b,
 // their slots behind slot0[b] layer-0 slots of the branch's `partials`
+// encoder_bwd4.hip: the same in eight waves (two per SIMD, 16-feature blocks): the default; encoder_bwd3.hip with PIML_ENC_FUSED_V=3
+int enc_f4_set_attributes();
+void enc_f4_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s);
 int enc_f3_set_attributes();
 // with_dw3: the launch also does dW3 / db3 (layer-0 slots, slot = workgroup index within the branch; needs slot0[b] == nA[b])
 void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s);

@@ -678,7 +678,8 @@ def _float64_grads(br, gm, gp, drop):
     ([(4099, 9, 3), (2050, 13, 1)], 'pooled', False),         # ragged last tiles, in_dim 3 and 1, k that does not divide 32
     ([(8192, 6, 6), (8192, 10, 6)], 'pooled', True), ([(16384, 6, 6), (16384, 10, 6)], 'pooled', False),
 ])
-def test_one_pass_backward(shapes, upstream, drop):
+@pytest.mark.parametrize('form', [1, 2])
+def test_one_pass_backward(shapes, upstream, drop, form):
     """piml_amd/csrc/encoder_bwd3.hip -- dX chain + dW2 / dW1 / db2 / db1 in one launch, g2 / g1 never stored -- against float64
     and against the two-kernel form (enc_bwd_dx_x3_kernel + enc_bwd_dw2_x3_kernel) on the same inputs; twice, bitwise equal
     (no atomics).  The no-input-gradient form (pointwise training) rides along: same weight gradients bit for bit."""
@@ -706,10 +707,10 @@ def test_one_pass_backward(shapes, upstream, drop):
     res = {}
     old = L.piml_encoder_fused_bwd(-1)
     try:
-        for on in (1, 0):
+        for on in (form, 0):
             L.piml_encoder_fused_bwd(on)
-            res[on] = run()
-        L.piml_encoder_fused_bwd(1)
+            res[1 if on else 0] = run()
+        L.piml_encoder_fused_bwd(form)
         again = run()
         for br in branches:
             br['x'].requires_grad_(False)

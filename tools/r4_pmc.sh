@@ -15,7 +15,7 @@ for sub in ('sq1', 'sq2'):
     for f in glob.glob(f'{O}/{sub}/*/*_counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'enc_bwd' in k or 'enc_fwd' in k:
+            if 'enc_bwd' in k:
                 agg[k.split('(')[0][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in agg.items():
         print(k)
