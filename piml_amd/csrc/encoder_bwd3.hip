@@ -685,16 +685,6 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         auto mfma_aa = [&](f32x16& d, const u32x4& a_, const u32x4& b_) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a_), "v"(b_));
         };
-        // four values of a row -> three 8-byte chunks of pieces at [row][chunk n] of an image
-        auto lay = [&](unsigned char* im, int i, float x, float y, float z, float w_) {
-            unsigned hi0, mid0, lo0, hi1, mid1, lo1;
-            split3(x, y, hi0, mid0, lo0);
-            split3(z, w_, hi1, mid1, lo1);
-            unsigned char* d = im + (8 * w + 4 * h + i) * 256 + ((n ^ (8 * i)) * 8);        // (row & 3 = i)
-            *reinterpret_cast<uint2*>(d) = make_uint2(hi0, hi1);
-            *reinterpret_cast<uint2*>(d + 8192) = make_uint2(mid0, mid1);
-            *reinterpret_cast<uint2*>(d + 16384) = make_uint2(lo0, lo1);
-        };
         // reader: lane 4 q + p of 16-lane group g16 supplies row r0 + q, chunk 8 blk + 4 (g16 & 1) + p; r0 = 16 s + 8 half2 + 4 (g16 >> 1)
         int tr_off;
         {
@@ -711,23 +701,41 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         };
         // (two register sets addressed by a compile-time index: a run-time index would put them into scratch)
         P2Pre Q0, Q1;
-        auto p2_tile = [&](const P2Pre& C, int pb) {
-            unsigned char* imH = img(pb, 0);
-            unsigned char* imG = img(pb, 1);
+        // laying a tile's rows into the images, 24 steps (row i, array G / H, three steps each: values + first half of the first
+        // pair's split | its second half + first half of the second pair's | second half + the three stores): they ride between
+        // the products of the tile BEFORE (the other image pair), pinned like the steps of phase 1
+        float lv[4];
+        unsigned lh0, lm0, ll0, lh1, lm1, ll1;
+        auto lay_step = [&](const P2Pre& C, int pb, int st) {
+            const int i = st / 6, arr = (st / 3) & 1, sub = st % 3;         // arr 0: G3, 1: H2
+            if (sub == 0) {
+                if (arr == 0) {
+                    lv[0] = C.gp[i].x + C.gm[i].x; lv[1] = C.gp[i].y + C.gm[i].y; lv[2] = C.gp[i].z + C.gm[i].z; lv[3] = C.gp[i].w + C.gm[i].w;
+                    if (DROP) {
+                        const unsigned m = C.kw[i] >> ((4 * n) & 31);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float g[4] = {C.gp[i].x + C.gm[i].x, C.gp[i].y + C.gm[i].y, C.gp[i].z + C.gm[i].z, C.gp[i].w + C.gm[i].w};
-                if (DROP) {
-                    const unsigned m = C.kw[i] >> ((4 * n) & 31);
+                        for (int u = 0; u < 4; ++u) lv[u] = keep_if(lv[u], m, u);
+                    }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) g[u] = keep_if(g[u], m, u);
+                    for (int u = 0; u < 4; ++u) d3[u] += lv[u];
+                } else {
+                    lv[0] = C.hv[i].x; lv[1] = C.hv[i].y; lv[2] = C.hv[i].z; lv[3] = C.hv[i].w;
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d3[u] += g[u];
-                lay(imG, i, g[0], g[1], g[2], g[3]);
-                lay(imH, i, C.hv[i].x, C.hv[i].y, C.hv[i].z, C.hv[i].w);
+                split_a(lv[0], lv[1], lh0);
+            } else if (sub == 1) {
+                split_b(lm0, ll0);
+                split_a(lv[2], lv[3], lh1);
+            } else {
+                split_b(lm1, ll1);
+                unsigned char* d = img(pb, arr == 0 ? 1 : 0) + (8 * w + 4 * h + i) * 256 + ((n ^ (8 * i)) * 8);        // (row & 3 = i)
+                *reinterpret_cast<uint2*>(d) = make_uint2(lh0, lh1);
+                *reinterpret_cast<uint2*>(d + 8192) = make_uint2(lm0, lm1);
+                *reinterpret_cast<uint2*>(d + 16384) = make_uint2(ll0, ll1);
             }
-            __syncthreads();
+        };
+        auto mma_tile = [&](int pb, const P2Pre& Cn) {         // 48 products on image pair pb; the NEXT tile (Cn) is laid into the other pair
+            const unsigned char* imH = img(pb, 0);
+            const unsigned char* imG = img(pb, 1);
             u32x4 ga[2][3], ob[2][3];
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_)
@@ -735,34 +743,46 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
                 for (int p = 0; p < 3; ++p) ga[s_][p] = frag(imG, w, s_, p);
 #pragma unroll
             for (int p = 0; p < 3; ++p) ob[0][p] = frag(imH, 0, 0, p);
+            auto fill = [&](int sl) {
+                if (sl % 6 == 0) {                             // the next group's operands
+                    const int u_ = sl / 6 + 1;
+                    if (u_ < 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                      // u = 2 jb + s: the operands of the next group under this group's products
-                const int jb = u >> 1, s_ = u & 1;
-                if (u < 7) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) ob[(u + 1) & 1][p] = frag(imH, (u + 1) >> 1, (u + 1) & 1, p);
+                        for (int p = 0; p < 3; ++p) ob[u_ & 1][p] = frag(imH, u_ >> 1, u_ & 1, p);
+                    }
+                    return;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                const int f = sl - sl / 6 - 1;                 // 40 free steps
+                if (f < 24) lay_step(Cn, pb ^ 1, f);
+            };
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                      // u = 2 jb + s
+                const int jb = u >> 1, s_ = u & 1;
                 const u32x4 (&o)[3] = ob[u & 1];
-                mfma_aa(sm[jb], ga[s_][2], o[0]);
-                mfma_aa(sm[jb], ga[s_][1], o[1]);
-                mfma_aa(sm[jb], ga[s_][0], o[2]);
-                mfma_aa(sm[jb], ga[s_][1], o[0]);
-                mfma_aa(sm[jb], ga[s_][0], o[1]);
-                mfma_aa(c[jb], ga[s_][0], o[0]);
-                __builtin_amdgcn_sched_barrier(0);
+                F3_SLOT(mfma_aa(sm[jb], ga[s_][2], o[0]), fill(u * 6 + 0));
+                F3_SLOT(mfma_aa(sm[jb], ga[s_][1], o[1]), fill(u * 6 + 1));
+                F3_SLOT(mfma_aa(sm[jb], ga[s_][0], o[2]), fill(u * 6 + 2));
+                F3_SLOT(mfma_aa(sm[jb], ga[s_][1], o[0]), fill(u * 6 + 3));
+                F3_SLOT(mfma_aa(sm[jb], ga[s_][0], o[1]), fill(u * 6 + 4));
+                F3_SLOT(mfma_aa(c[jb], ga[s_][0], o[0]), fill(u * 6 + 5));
             }
         };
         int t2 = bx;
         p2_load(Q0, t2);
+        p2_load(Q1, t2 + nwg);
         __syncthreads();                                       // (phase 1's last reads of the buffers under the images are done)
+#pragma unroll
+        for (int st_ = 0; st_ < 24; ++st_) lay_step(Q0, 0, st_);
+        __syncthreads();
         for (; t2 < ntiles; t2 += 2 * nwg) {
-            p2_load(Q1, t2 + nwg);
-            p2_tile(Q0, 0);
-            if (t2 + nwg < ntiles) {
-                p2_load(Q0, t2 + 2 * nwg);
-                p2_tile(Q1, 1);
-            }
+            // image pair 0 holds tile t2, Q1 the requests of tile t2 + nwg, Q0 is free
+            p2_load(Q0, t2 + 2 * nwg);
+            mma_tile(0, Q1);
+            __syncthreads();
+            if (t2 + nwg >= ntiles) break;
+            p2_load(Q1, t2 + 3 * nwg);
+            mma_tile(1, Q0);
+            __syncthreads();
         }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c[jb]), "+a"(sm[jb]));
