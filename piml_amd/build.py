@@ -84,7 +84,7 @@ def needs_build():
 
 
 def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+    if not force and not extra and not needs_build():
         return LIB
     flags = CFLAGS + list(extra) + os.environ.get('PIML_HIPCC_EXTRA', '').split()
     with ThreadPoolExecutor(max_workers=int(os.environ.get('PIML_BUILD_JOBS', '4'))) as ex:

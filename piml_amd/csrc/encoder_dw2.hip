@@ -306,7 +306,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dw2_x3_kernel(Dw2Args D) 
         };
         // DEPTH batches ahead.  Measured at the 4096-agent scene (us, same box): depth 2: 39.6, 3: 41.2, 4: 41.5, 5: 44.8 -- the
         // bytes in flight are not what holds this kernel back (a deeper ring costs registers and moves instead).
-        constexpr int DEPTH = (POOL && MSGS) ? 2 : (DROP ? (PIML_DW2_DEPTH > 3 ? 3 : PIML_DW2_DEPTH) : PIML_DW2_DEPTH);      // (the g_msgs variant holds two arrays per batch)
+        constexpr int DEPTH = (POOL && MSGS) ? (DROP && H1R ? 1 : 2) : (DROP ? (PIML_DW2_DEPTH > 3 ? 3 : PIML_DW2_DEPTH) : PIML_DW2_DEPTH);      // (the g_msgs variant holds two arrays per batch; with keep bits and the recomputation on top, two batches in flight spilled 25 registers)
         constexpr int UNROLL = (DEPTH % 2) ? 2 * DEPTH : DEPTH;
         Stage S[DEPTH];
         S[0] = stage_load(r0);

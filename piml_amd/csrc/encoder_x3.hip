@@ -302,15 +302,15 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
         xb[s] = (valid && c < IN) ? J.x[(valid ? row : 0) * IN + c] : 0.f;
         w1[s] = W1g[(blk * 4 + s) * 64 + lane];
     }
-    float4 bq[3][4];
+    // the biases of one layer at a time, the next layer's requested under this layer's products (all three held at once were 48
+    // registers: with the dropout forms' mask words the kernel spilled 4)
+    float4 bq[4], bqn[4];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[l][q] = *reinterpret_cast<const float4*>(bias + 128 * l + feat0(blk, q, h));
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + feat0(blk, q, h));
     f32x16 acc, sm;
-    auto init = [&](int l) {
+    auto init = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[l][q].x; acc[4 * q + 1] = bq[l][q].y; acc[4 * q + 2] = bq[l][q].z; acc[4 * q + 3] = bq[l][q].w; }
+        for (int q = 0; q < 4; ++q) { acc[4 * q] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
     };
@@ -335,7 +335,9 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
         }
     };
     // ---- layer 1 (f32 instruction, as in enc_fwd_x3_kernel) ----
-    init(0);
+    init();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const float4*>(bias + 128 + feat0(blk, q, h));
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma32(w1[s], xb[s], acc);
 #pragma unroll
@@ -346,13 +348,15 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
     // ---- layers 2 and 3 ----
 #pragma unroll
     for (int l = 1; l < 3; ++l) {
-        init(l);
-        u32x4 wn[8][3];
+        init();
+        u32x4 wn[8][2];                                // (hi, mid) of the next layer; its lo pieces follow once wf's are dead (as in the dX form)
         if (l == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bqn[q] = *reinterpret_cast<const float4*>(bias + 256 + feat0(blk, q, h));
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {          // next layer's, under this layer's products
                 const int fb = blk * 8 + kb;
-                wn[kb][0] = W3hm[(fb * 2) * 64]; wn[kb][1] = W3hm[(fb * 2 + 1) * 64]; wn[kb][2] = W3lo[fb * 64];
+                wn[kb][0] = W3hm[(fb * 2) * 64]; wn[kb][1] = W3hm[(fb * 2 + 1) * 64];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -362,6 +366,10 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
             const u32x4* e = src + ((kb >> 1) * 3 * 2 + (kb & 1)) * 64;
             kblock_x3(acc, sm, wf[kb][0], wf[kb][1], wf[kb][2], e[0], e[2 * 64], e[4 * 64]);
         }
+        if (l == 1) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) wf[kb][2] = W3lo[(blk * 8 + kb) * 64];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += sm[r];
         if (l == 1) {
@@ -370,7 +378,9 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
             store(J.h2, 1.f);
             hand_over(1);
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; wf[kb][2] = wn[kb][2]; }
+            for (int kb = 0; kb < 8; ++kb) { wf[kb][0] = wn[kb][0]; wf[kb][1] = wn[kb][1]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = bqn[q];
             __syncthreads();
         } else {
             if (DROP == 1) keep_block(acc, valid ? J.keep_bits[row * 4 + blk] : 0u, h);
@@ -428,16 +438,19 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
     stage_linear<X3_IMG>(lds, x3 + 2 * X3_IMG, tid);
     stage_linear<1024>(lds + X3_DX_F32, J.packed + PACK_FWD + 32768, tid);
     __syncthreads();
-    u32x4 w2r[W2T_ROUNDS];       // W2^T's LDS part: in flight behind the first tile's first layer
+    // W2^T's LDS part.  (Rounds 2 - 3 kept it in flight in 32 registers behind the first tile's first layer: those registers
+    // were what the kernel spilled -- 9 / 13 VGPRs.  Since round 4 this kernel is the fallback of the one-pass backward and
+    // stages everything up front: ~1 us of prologue, no scratch.)
     {
+        u32x4 w2r[W2T_ROUNDS];
         const u32x4* src = reinterpret_cast<const u32x4*>(x3 + 3 * X3_IMG);
 #pragma unroll
         for (int r = 0; r < W2T_ROUNDS; ++r) {
             const int e = r * ENC_THREADS + tid;
             w2r[r] = src[e < W2T_N4 ? e : 0];
         }
+        land_w2t(w2r, lds, tid);
     }
-    bool w2_pending = true;
 
     const float scale = J.scale;
     for (long long tile = first; tile < ntiles; tile += stride) {
@@ -529,15 +542,15 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
                     store4_stream(o + feat0(blk, q, h), acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             }
         }
-        if (w2_pending) {
-            land_w2t(w2r, lds, tid);
-            w2_pending = false;
-        }
         // ---- g_h1 = W2^T g2, masked by h1 -> g1; g_x = W1^T g1 block by block on the vector pipe ----
-        u32x4 lw[2][8];              // LO pieces of W2^T, one output block ahead
+        // LO pieces of W2^T: HALF an output block ahead (k-blocks 4 .. 7 of this block and 0 .. 3 of the next are requested
+        // under the products of k-blocks 0 .. 3 / 4 .. 7).  A whole block ahead in two register sets was 64 registers, and
+        // the kernel spilled 9 - 13 of its 256; since round 4 this kernel is the fallback of the one-pass backward (no
+        // sign bits, PIML_ENC_FUSED_BWD=0, branches with different kinds of upstream gradient).
+        u32x4 lw[8];
         u32x4 tail[4];               // hi / mid of fragments 30, 31 (block 3, k-blocks 6, 7)
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) lw[0][kb] = W2lo_g[kb * 64];
+        for (int kb = 0; kb < 8; ++kb) lw[kb] = W2lo_g[kb * 64];
 #pragma unroll
         for (int u = 0; u < 4; ++u) tail[u] = W2hm_g[(X3_FB2T * 2 + u) * 64];
         split_tile(g, P);
@@ -553,10 +566,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp1 + feat0(blk, q, h));
             }
-            if (blk < 3) {
-#pragma unroll
-                for (int kb = 0; kb < 8; ++kb) lw[(blk + 1) & 1][kb] = W2lo_g[((blk + 1) * 8 + kb) * 64];
-            }
             f32x16 acc, sm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sm[r] = 0.f;
@@ -567,7 +576,15 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
                 const int fb = blk * 8 + kb;
                 const u32x4 wh = fb < X3_FB2T ? W2hm[(fb * 2) * 64] : tail[fb < X3_FB2T ? 0 : (fb - X3_FB2T) * 2];
                 const u32x4 wm = fb < X3_FB2T ? W2hm[(fb * 2 + 1) * 64] : tail[fb < X3_FB2T ? 0 : (fb - X3_FB2T) * 2 + 1];
-                kblock_x3(acc, sm, wh, wm, lw[blk & 1][kb], P.hi[kb], P.mid[kb], P.lo[kb]);
+                kblock_x3(acc, sm, wh, wm, lw[kb], P.hi[kb], P.mid[kb], P.lo[kb]);
+                if (kb == 3 && blk < 3) {          // k-blocks 0 .. 3 of the next output block: their registers are free now
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) lw[k2] = W2lo_g[((blk + 1) * 8 + k2) * 64];
+                }
+            }
+            if (blk < 3) {
+#pragma unroll
+                for (int k2 = 4; k2 < 8; ++k2) lw[k2] = W2lo_g[((blk + 1) * 8 + k2) * 64];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += sm[r];
@@ -624,7 +641,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_bwd_dx_x3_kernel(EncArgs A) {
             }
         }
     }
-    if (w2_pending) land_w2t(w2r, lds, tid);       // a wave without a tile: the barrier still counts it
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -280,6 +280,26 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                     const float cs = cos_sim_prenorm(rx, ry, d, h0, h1);   // :439-440
                     const bool ok = act && cs >= cos_thr && d <= dthr;     // :441-443, :461
                     unsigned cd = ok ? __float_as_uint(d) : kEmptyDist;
+                    // PIML_RELFEAT_LANE_DRAIN (round 4, measured and NOT the default): candidates that precede the current k-th
+                    // entry enter the list in LANE order -- the list is the k smallest by (distance, index) of everything
+                    // offered to it whatever the order of the offers, so the result is bit-identical (62 tests) -- for two
+                    // readlanes + a scalar comparison + the insertion per round instead of a wave-wide minimum + tie walk +
+                    // insertion.  But a chunk offered in lane order inserts entries that a later, nearer one pushes out again
+                    // (k ln(64 / k) insertions for the first chunk instead of k): 25.4 vs 22.5 us at the 4096-agent scene,
+                    // 39.6 vs 35.6 for a rank's 2048 x 16384 share of the 16384-agent scene.
+#ifdef PIML_RELFEAT_LANE_DRAIN
+                    for (u64 q = __builtin_amdgcn_ballot_w64(cd <= kth_d && cd != kEmptyDist); q; q &= q - 1) {
+                        PIML_STAT(++st_rounds;)
+                        const int s = __builtin_ctzll(q);
+                        const unsigned nd = (unsigned)__builtin_amdgcn_readlane((int)cd, s);
+                        const unsigned ni = (unsigned)(base + __builtin_amdgcn_readlane(jl, s));
+                        if (nd > kth_d || (nd == kth_d && ni > kth_i)) continue;       // the k-th entry has moved on
+                        PIML_STAT(++st_ins;)
+                        list_insert(list_d, list_i, nd, ni);
+                        kth_d = (unsigned)__builtin_amdgcn_readlane((int)list_d, k - 1);
+                        kth_i = (unsigned)__builtin_amdgcn_readlane((int)list_i, k - 1);
+                    }
+#else
                     // drain the chunk in (distance, index) order: at most k entries can enter
 #pragma unroll 1
                     for (;;) {
@@ -302,6 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                         kth_i = (unsigned)__builtin_amdgcn_readlane((int)list_i, k - 1);
                         if (lane == s) cd = kEmptyDist;
                     }
+#endif
                     if (kth_d != kEmptyDist) {
                         // any source that can still enter the list has dist <= d_k, hence
                         // d2 <= d_k^2 (1 + 2^-20) whatever the rounding of sqrt and the product

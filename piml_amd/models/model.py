@@ -495,7 +495,10 @@ class _PINNSFBase(nn.Module):
                            f'(encoder {[lin.out_features for lin in self.ped_encoder.mlp[0::2]]}, '
                            f'{len(self.ped_processor.hidden_units)} processor layers, {ped_features.dtype})')
         # the side stream only pays for the library-GEMM chain; the fused encoder launch already fills the chip
-        side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre) else None
+        # (and never while a processor DRAWS a dropout mask: the draw counter is one per device -- offset + ticket,
+        # philox.hpp -- and assumes one drawing launch in flight; two branches drawing on two streams would race on it)
+        drawing = any(p.dropout_active() and p.keep_bits is None for p in (self.ped_processor, self.obs_processor))
+        side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre and not drawing) else None
         # bottleneck variants with a per-row |dest|: neighbour-axis sums + desired force in one launch (ops.pinnsf_epilogue_ksum)
         ksum_tail = (self.bottleneck and FUSED_GLUE and FUSED_KSUM_TAIL and not self.residual and side is None and self_features.is_cuda
                      and self_features.dtype == torch.float32 and (self_features.dim() == 2 or self.fix_dest_norm))

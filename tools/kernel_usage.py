@@ -1,47 +1,43 @@
-"""Per-kernel register / scratch / occupancy table from `hipcc -Rpass-analysis=kernel-resource-usage` output.
-usage: python tools/kernel_usage.py [file.hip ...] [--grep enc_]   (default: every source of libpiml_hip.so)"""
-import os
+"""Per-kernel register / scratch / occupancy table of libpiml_hip.so from `hipcc -Rpass-analysis=kernel-resource-usage`
+(the per-file flags of piml_amd/build.py apply).
+usage: python -m piml_amd.build --usage 2> usage.log; python tools/kernel_usage.py usage.log [--md] [--spills]"""
 import re
 import subprocess
 import sys
 
-sys.path.insert(0, __file__.rsplit('/', 2)[0])
-from piml_amd import build as B  # noqa: E402
 
-
-def usage(srcs):
-    cmd = ['/opt/rocm/bin/hipcc'] + [f for f in B.FLAGS if f not in ('-shared',)] + \
-        os.environ.get('PIML_HIPCC_EXTRA', '').split() + ['-Rpass-analysis=kernel-resource-usage', '-c', '-o', '/dev/null']
-    rows = []
-    for src in srcs:
-        out = subprocess.run(cmd + [src], capture_output=True, text=True).stderr
-        cur = None
-        for line in out.splitlines():
-            m = re.search(r'Function Name: (\S+)', line)
-            if m:
-                cur = {'name': subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()}
-                rows.append(cur)
-                continue
-            for key, pat in (('vgpr', r' VGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'),
-                             ('occ', r'Occupancy \[waves/SIMD\]: (\d+)'), ('spill', r'VGPRs Spill: (\d+)'),
-                             ('lds', r'LDS Size \[bytes/block\]: (\d+)'), ('sgpr', r' SGPRs: (\d+)')):
-                m = re.search(pat, line)
-                if m and cur is not None:
-                    cur[key] = int(m.group(1))
-    return rows
+def parse(path):
+    rows, cur = [], None
+    for line in open(path):
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = {'mangled': m.group(1)}
+            rows.append(cur)
+            continue
+        for key, pat in (('vgpr', r' VGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'),
+                         ('occ', r'Occupancy \[waves/SIMD\]: (\d+)'), ('spill', r'VGPRs Spill: (\d+)')):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    names = subprocess.run(['c++filt'] + [r['mangled'] for r in rows], capture_output=True, text=True).stdout.splitlines()
+    seen, out = set(), []
+    for r, n in zip(rows, names):
+        r['name'] = re.sub(r'\(.*', '', n).replace('void ', '').replace('piml::', '')
+        if r['name'] not in seen:
+            seen.add(r['name'])
+            out.append(r)
+    return out
 
 
 if __name__ == '__main__':
-    args = sys.argv[1:]
-    pat = None
-    if '--grep' in args:
-        i = args.index('--grep')
-        pat = args[i + 1]
-        del args[i:i + 2]
-    rows = usage(args or B.sources())
-    print(f'{"kernel":90s} vgpr agpr spill scratch occ')
-    for r in rows:
-        if pat and pat not in r['name']:
-            continue
-        name = re.sub(r'\(.*', '', r['name'])[:90]
-        print(f'{name:90s} {r.get("vgpr", -1):4d} {r.get("agpr", -1):4d} {r.get("spill", -1):5d} {r.get("scratch", -1):7d} {r.get("occ", -1):3d}')
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    rows = parse(args[0])
+    if '--spills' in sys.argv:
+        rows = [r for r in rows if r.get('spill', 0) > 0]
+    if '--md' in sys.argv:
+        print('| kernel | VGPRs | AGPRs | VGPRs spilled | scratch B/lane | waves/SIMD |\n|---|---|---|---|---|---|')
+        for r in rows:
+            print(f"| `{r['name']}` | {r.get('vgpr')} | {r.get('agpr')} | {r.get('spill')} | {r.get('scratch')} | {r.get('occ')} |")
+    else:
+        for r in rows:
+            print(f"{r['name'][:100]:100s} vgpr {r.get('vgpr'):4d} agpr {r.get('agpr'):4d} spill {r.get('spill'):4d} scratch {r.get('scratch'):5d} occ {r.get('occ')}")
