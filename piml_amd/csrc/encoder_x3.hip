@@ -401,9 +401,11 @@ __global__ __launch_bounds__(512) void enc_fwd_split_x3_kernel(EncArgs A, int pa
 // (Round 4, measured and removed: the four-waves-per-tile cut made PERSISTENT for many rows -- two crews of four waves per
 // workgroup, each wave's (hi, mid) weight fragments of both layers in 128 AGPRs as asm operands, the lo pieces in LDS, no weight
 // traffic per tile at all; bitwise equal to enc_fwd_x3_kernel, 112 tests green.  36.4 us against 27.2 at the 4096-agent scene:
-// a tile is three phases separated by workgroup barriers, the two crews of a SIMD march through them in lockstep -- the barrier
-// is per workgroup, not per crew -- and nothing overlaps the hand-overs.  One wave per tile keeps its activations in registers
-// between the layers and pays for that with the weights' trip through LDS, which is the cheaper of the two.)
+// a tile is three phases separated by workgroup barriers and the two crews of a SIMD march through them in lockstep.  As
+// INDEPENDENT workgroups of one crew each (48 KB of LDS, the lo pieces from L2; two per CU, their barriers unrelated) 41.9 us,
+// one per CU 46.9.  One wave per tile keeps its activations in registers between the layers and pays for that with the
+// weights' trip through LDS, which is the cheaper of the two: the hand-over of a tile's activations through LDS and a barrier
+// per layer is what the cut costs, whatever happens to the weights.)
 
 // ---------------------------------------------------------------------------------------------------------
 // backward, part 1: the dX chain (see enc_bwd_dx_kernel in encoder.hip for the arithmetic)

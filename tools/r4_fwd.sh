@@ -2,8 +2,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4fwd; rm -rf $O; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_encoder_gpu.py tests/test_dropout_gpu.py -m gpu -x -q 2>&1 | tail -8
-for v in 1 0; do
+PIML_ENC_FWD_PERS=2 timeout 1500 python -m pytest tests/test_encoder_gpu.py tests/test_dropout_gpu.py -m gpu -x -q 2>&1 | tail -3
+for v in 2 1 0; do
   PIML_ENC_FWD_PERS=$v timeout 300 python bench.py --cpu-seconds 0 --secondary 0 > $O/bench_$v.json 2> $O/bench_$v.err
   python - $v <<'PY'
 import json,os,sys
