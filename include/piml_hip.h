@@ -713,6 +713,30 @@ int piml_allgather_state(void* comm, const float* own, size_t floats_per_rank, f
 int piml_reducescatter_grad(void* comm, const float* full, float* own, size_t floats_per_rank, void* stream);
 int piml_allreduce_sum(void* comm, float* buf, size_t count, void* stream);
 
+/*
+ * P2P-store all-gather of the state records ("fall back to / compare with a P2P-store epilogue ... into peers'
+ * double-buffered state arrays"; piml_amd/csrc/p2p.hip; the reference has no counterpart, src/models/simulators.py:64-67 is
+ * nn.DataParallel).  No collective library in the data path: every rank stores its block into every peer's receive buffer
+ * (xGMI stores between GPUs of a node, plain stores when ranks share a GPU) and raises a flag word per (receiver, sender).
+ *   Per rank: recv = piml_p2p_alloc(2 * world * floats_per_rank * 4) and flags = piml_p2p_alloc(2 * world * 4) (zeroed);
+ *   both exported (piml_p2p_export -> 64 opaque bytes, carried to the peers by the host: a pipe, the torch.distributed store)
+ *   and opened there (piml_p2p_open); a rank's own buffers enter the tables as they are.
+ *   piml_allgather_state_p2p(own, floats_per_rank (multiple of 4), rank, world, peer_recv[world], peer_flags[world], seq, ...):
+ *   step seq = 1, 2, 3, ... (the same on every rank); on return of the launch's completion recv[seq & 1][s] holds rank s's
+ *   block for every s, i.e. recv + (seq & 1) * world * floats_per_rank is the gathered (N, 6) array.  spin_limit: rounds of
+ *   ~4 us the wait for the peers' flags may take (0: ~0.5 s); when it runs out status[0] (a device int the caller zeroed) is
+ *   set to 1 and the launch ends -- a lost peer is an error to read back, never a hang.
+ */
+typedef struct piml_ipc_handle { char internal[64]; } piml_ipc_handle;
+int piml_p2p_alloc(size_t bytes, void** devptr);
+int piml_p2p_free(void* devptr);
+int piml_p2p_export(void* devptr, piml_ipc_handle* out);
+int piml_p2p_open(const piml_ipc_handle* in, void** devptr);
+int piml_p2p_close(void* devptr);
+int piml_p2p_copy(void* dst, const void* src, size_t bytes, void* stream);
+int piml_allgather_state_p2p(const float* own, size_t floats_per_rank, int rank, int world, float* const* peer_recv,
+                             unsigned* const* peer_flags, unsigned seq, unsigned spin_limit, int* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,13 @@ SIGNATURES = {
     'piml_rollout_losses_blocks': [_i, _i],
     'piml_rollout_losses': [_p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],
+    'piml_p2p_alloc': [_z, ctypes.POINTER(_p)],
+    'piml_p2p_free': [_p],
+    'piml_p2p_export': [_p, _p],
+    'piml_p2p_open': [_p, ctypes.POINTER(_p)],
+    'piml_p2p_close': [_p],
+    'piml_p2p_copy': [_p, _p, _z, _p],
+    'piml_allgather_state_p2p': [_p, _z, _i, _i, ctypes.POINTER(_p), ctypes.POINTER(_p), ctypes.c_uint, ctypes.c_uint, _p, _p],
     'piml_encoder_products': [_i],
     'piml_encoder_dw2': [_i],
     'piml_encoder_fused_bwd': [_i],

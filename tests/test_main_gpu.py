@@ -76,8 +76,10 @@ TOL = {
     'gc': dict(pre_train=1e-6, pre_val=5e-6, ft_train=1e-4, ft_counts=0.0, weights=2e-4, val=2e-2, metrics=3e-4,
                collisions=0.0, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                ref_collisions=0.0),
-    'ucy': dict(pre_train=1e-3, pre_val=1e-2, ft_train=6e-2, ft_counts=3e-2, weights=1.2e-2, val=2e-2, metrics=3e-2,
-                collisions=6e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
+    # round 4: <= 3x this build's measured values (metrics 5.4e-4, weights 2.6e-3, ft_train 1.4e-3 .. 1.6e-2 over the builds,
+    # collisions 6.7e-3 = 2 of 296), AND the distance is bounded by the reference's own spread below (<= 2x).
+    'ucy': dict(pre_train=2e-4, pre_val=2e-3, ft_train=5e-2, ft_counts=3e-2, weights=7e-3, val=2e-3, metrics=4e-3,
+                collisions=2e-2, ref_first10_m=1e-4, ref_first40_m=1e-4, ref_metrics=1e-4, ref_mae_per_frame_m=1e-4,
                 ref_collisions=0.0),
 }
 
@@ -195,6 +197,28 @@ def test_main_flow_matches_reference_end_to_end(case):
         report['spread_pre_val'] = rel(first['pre_val'], [h['val_loss'] for h in MAIN.LAST_RUN['pretrain_history']])
         report['library_path_vs_reference_metrics'] = max(rel(ev2[1], last[1]), rel(ev2[2], last[2]), rel(ev2[3], last[3]),
                                                           rel(ev2[4], last[4]))
+    if case == 'ucy':
+        # The REFERENCE against ITSELF (tests/golden/make_golden.py::gen_mainflow_spread -> mainflow_ucy_spread.npz): the same flow,
+        # same seed, same batches, under other float32 summation orders of its own CPU kernels (1 / 4 / 8 torch threads, oneDNN
+        # off).  1 thread and oneDNN-off reproduce the 8-thread fixture to 1e-9; FOUR threads move the final metrics by 4.4e-4,
+        # the second epoch's fine-tuning loss by 1.6e-2, the best weights by 1.6e-3 and the soft collision count from 296 to 298:
+        # the configuration is chaotic in the reference itself, by the amounts this package's fused path differs from it.
+        sp = golden('mainflow_ucy_spread')
+        tags = [t for t in ('threads1', 'threads4', 'nomkldnn')]
+        base = sp['threads8/ft_test'][-1]
+        assert np.allclose(base, last, rtol=1e-12), 'the spread fixture was generated from another reference run'
+        ref_metrics = max(rel(sp[f'{t}/ft_test'][-1][1:5], base[1:5]) for t in tags)
+        ref_ft_train = max(rel(sp[f'{t}/ft_train'][:, :4], sp['threads8/ft_train'][:, :4]) for t in tags)
+        ref_coll = max(rel(sp[f'{t}/collisions'][-1] + 1.0, sp['threads8/collisions'][-1] + 1.0) for t in tags)
+        ref_w = 0.0
+        for k in sp.files:
+            if k.startswith('threads8/w/'):
+                w = sp[k]
+                ref_w = max(ref_w, max(float(np.abs(sp[k.replace('threads8', t)] - w).max() / max(np.abs(w).max(), 1e-12)) for t in tags))
+        report['reference_self_spread(metrics, ft_train, weights, collisions)'] = (ref_metrics, ref_ft_train, ref_w, ref_coll)
+        own_metrics = max(report['test_mse'], report['mae'], report['ot'], report['mmd'])
+        report['distance / reference self-spread (metrics, ft_train, weights, collisions)'] = (
+            own_metrics / ref_metrics, report['ft_train'] / ref_ft_train, report['weights_best_ft'] / ref_w, report['collisions'] / ref_coll)
     print(f'\n[cfg5 {case}] measured deviations from the reference (relative unless noted):')
     for k, v in report.items():
         print(f'    {k:32s} {v}')
@@ -221,6 +245,10 @@ def test_main_flow_matches_reference_end_to_end(case):
     assert report['collisions'] <= tol['collisions']
     if case == 'ucy':       # this package's library-GEMM path follows the reference's trajectory itself (see TOL)
         assert report['library_path_vs_reference_metrics'] <= 1e-4
+        # ... and the fused path is no further from the reference than twice the reference is from itself
+        assert ref_metrics >= 1e-4, 'the reference reproduces itself: the divergence would be this package\'s'
+        for d in report['distance / reference self-spread (metrics, ft_train, weights, collisions)']:
+            assert d <= 2.0, report
 
 
 @pytest.mark.parametrize('case', ['gc', 'ucy'])
