@@ -58,6 +58,8 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'enc_bwd_dw_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'enc_bwd_dw_x3w_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'enc_bwd_dw2_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128),      # (+ the recomputed layer 1: f32 instructions, not counted)
+    # round 4, one-pass backward: the dX chain (2 layers) + dW3 / dW2 / dW1 (+ the recomputed layers 1 and 2, not counted)
+    'enc_bwd_fused_x3_kernel': 2 * ROWS * (2 * 128 * 128 + 6 * 128) + 2 * ROWS * (2 * 128 * 128 + 6 * 128),
     'dec_fwd_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dx_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
     'dec_bwd_dw_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2),
@@ -91,7 +93,7 @@ for r in rows:
     if key in FLOPS and '_x3_' in key:
         # f32 arithmetic carried by six bf16 matrix instructions per k-block: priced against BOTH ceilings, the larger
         # fraction names the bound.  Executed bf16 FLOPs = 6 x the two 128 x 128 layers' (the K <= 8 layer stays f32 / VALU).
-        bf16_flops = 6 * 2 * ROWS * 2 * 128 * 128
+        bf16_flops = 6 * 2 * ROWS * 2 * 128 * 128 * (2 if 'fused' in key else 1)
         mfma_frac = bf16_flops / (us * 1e-6) / BF16_MFMA_PEAK
         hbm_frac = hbm / (us * 1e-6) / HBM_PEAK
         e.update(bound='hbm' if hbm_frac >= mfma_frac else 'mfma', frac=round(max(hbm_frac, mfma_frac), 3),
