@@ -310,10 +310,15 @@ class Step:
         """PINNSF forward, backward through the MLP and relfeat backward (+ collectives)."""
         from piml_amd.sharded import allreduce_gradients
         acc = self.model(pf, of, self_features)[0]
-        acc.backward(self.ones)
+        with self._deferred():     # the weight-gradient slot sums ride in the relfeat backward's launch
+            acc.backward(self.ones)
         if self.sh is not None:
             allreduce_gradients(self.params, self.group)
         return acc
+
+    def _deferred(self):
+        import contextlib
+        return getattr(self.ops, 'deferred_slot_sums', contextlib.nullcontext)()
 
     def features_local(self):
         return self.ops.relative_features_packed_self(self.state_all, self.dest_own, self.obstacles, self.v0_own,
@@ -330,7 +335,8 @@ class Step:
 
     def rest_local(self, pf, of, self_features, *_idx):
         acc = self.model(pf, of, self_features)[0]
-        acc.backward(self.ones)
+        with self._deferred():
+            acc.backward(self.ones)
         # captured: ONE concatenation of the (N, 6) state gradient and all weight gradients into a static
         # bucket, so that the backward exchange is a single latency-bound all-reduce (0.9 MB at 16384 agents)
         grads = [p.grad for p in self.params if p.grad is not None]
@@ -874,6 +880,8 @@ def main():
     stage_kernel = {'pinnsf_pack': 'pinnsf_pack_kernel', 'relfeat_fwd': 'relfeat_fwd_kernel', 'enc_fwd': f'enc_fwd{x3}_kernel',
                     'dec_fwd_head': 'dec_fwd_head_kernel', 'dec_bwd': 'dec_bwd_kernel', 'enc_bwd_dx': f'enc_bwd_dx{x3}_kernel',
                     'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
+    if 'pinnsf_reduce' not in stage_us and stage_us:      # the slot sums rode in the relfeat backward's launch (ops.deferred_slot_sums)
+        stage_kernel['relfeat_bwd'] = 'relfeat_bwd_reduce_kernel'
     if one_pass:
         stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
         if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':

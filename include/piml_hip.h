@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 16
+#define PIML_HIP_ABI_VERSION 17
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -684,6 +684,13 @@ int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream); 
 #define PIML_FORK 2
 #define PIML_ACCUMULATE 4 /* piml_pinnsf_bwd: every branch's `grads` += the slot sums instead of = (a further backward pass through
                              the same weights inside one optimiser step: the frames of a training rollout); not with PIML_FORK */
+#define PIML_DEFER_SLOT_SUMS 8 /* piml_pinnsf_bwd: do NOT launch the slot sums; leave them with the library, which runs them as the
+                                  leading workgroups of the next piml_relfeat_self_bwd on the same stream (the two kernels are
+                                  independent and small: one launch boundary, ~5 us, less per step), or -- whichever comes first
+                                  -- at piml_pinnsf_slot_sums_flush / at the next deferring piml_pinnsf_bwd.  Until then the
+                                  branches' `grads` are NOT valid: for callers that know a relfeat backward follows (the step of
+                                  src/models/simulators.py:699-779: network backward, then the features' backward); not with PIML_FORK */
+int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */
 int piml_pinnsf_streams_init(void);
 int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,
                      const piml_collision_head* head, int flags, void* stream);

@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 
@@ -47,7 +47,7 @@ class Head64(ctypes.Structure):
                 ('g_out', _p), ('g_x', _p), ('partials', _p), ('grads', _p)]
 
 
-PACKED_VALID, FORK, ACCUMULATE = 1, 2, 4          # piml_pinnsf_* flags
+PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS = 1, 2, 4, 8          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -135,6 +135,7 @@ SIGNATURES = {
     'piml_head64_bwd': [ctypes.POINTER(Head64), _p],
     'piml_head64_bwd_acc': [ctypes.POINTER(Head64), _i, _p],
     'piml_pinnsf_streams_init': [],
+    'piml_pinnsf_slot_sums_flush': [],
     'piml_pinnsf_pack': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),
                          _i, _p],
     'piml_pinnsf_fwd': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "pack.hpp"
+#include "reduce.hpp"
 #include "stages.hpp"
 #include "trace.hpp"
 
@@ -100,22 +101,63 @@ __global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) {
     }
 }
 
-// ---- one launch for every slot sum of the backward pass: blockIdx.y = a set of slots (encoder branches -- one set each, or
-// two with the layer-split slots of encoder_dw2.hip -- then the decoder branches) ----
-struct ReduceSet {
-    const float* parts;
-    float* grads;
-    int slots, lanes, split, off0, off1;       // float4 geometry: sum_slots_16x16 (pack.hpp)
-};
-struct ReduceAll {
-    ReduceSet set[6];
-    int nsets;
-    int accumulate;       // PIML_ACCUMULATE: grads += the sums
-};
+// ---- one launch for every slot sum of the backward pass (reduce.hpp): a set of slots per gx workgroups (encoder branches --
+// one set each, or two with the layer-split slots of encoder_dw2.hip -- then the decoder branches) ----
+__global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) { reduce_block(A, (int)blockIdx.x); }
 
-__global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) {
-    const ReduceSet S = A.set[blockIdx.y];
-    if ((int)blockIdx.x * 16 < S.lanes) sum_slots_16x16(S.parts, S.grads, S.slots, S.lanes, S.split, S.off0, S.off1, A.accumulate != 0);
+int launch_slot_sums(const ReduceAll& R, hipStream_t s) {
+    hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3((unsigned)(R.gx * R.nsets)), dim3(256), 0, s, R);
+    return hipGetLastError();
+}
+
+// ---- deferred slot sums (PIML_DEFER_SLOT_SUMS): one waiting entry per device ----
+namespace {
+struct PendingSums {
+    ReduceAll R;
+    hipStream_t stream = nullptr;
+    bool valid = false;
+};
+PendingSums g_pending[kMaxDevices];
+
+PendingSums* pending_entry() {
+    int dev = 0;
+    if (hipGetDevice(&dev) || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_pending[dev];
+}
+}  // namespace
+
+int pending_slot_sums_flush() {
+    PendingSums* P = pending_entry();
+    if (!P) return hipErrorInvalidDevice;
+    ReduceAll R;
+    hipStream_t s;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!P->valid) return hipSuccess;
+        R = P->R; s = P->stream; P->valid = false;
+    }
+    const int e = launch_slot_sums(R, s);
+    trace_mark("pinnsf_reduce", s);
+    return e;
+}
+
+int pending_slot_sums_leave(const ReduceAll& R, hipStream_t s) {
+    if (int e = pending_slot_sums_flush()) return e;          // sums already waiting: they run now, on the stream they were left on
+    PendingSums* P = pending_entry();
+    if (!P) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_mu);
+    P->R = R; P->stream = s; P->valid = true;
+    return hipSuccess;
+}
+
+bool pending_slot_sums_take(hipStream_t s, ReduceAll* out) {
+    PendingSums* P = pending_entry();
+    if (!P) return false;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!P->valid || P->stream != s) return false;
+    *out = P->R;
+    P->valid = false;
+    return true;
 }
 
 }  // namespace piml
@@ -158,7 +200,7 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
 }
 
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
-static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate) {
+static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate, bool defer = false) {
     ReduceAll R = {};
     R.accumulate = accumulate ? 1 : 0;
     int w0 = 0, n = 0, maxl = 0;
@@ -180,9 +222,14 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
     }
     for (int i = 0; i < nbr; ++i) add(dec[i].partials, dec[i].grads, dslots, DEC_PART / 4, 0x7fffffff, 0, 0);
     R.nsets = n;
-    hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3((maxl + 15) / 16, n), dim3(256), 0, s, R);
-    return hipGetLastError();
+    R.gx = (maxl + 15) / 16;
+    if (defer) return pending_slot_sums_leave(R, s);          // the next piml_relfeat_self_bwd on `s` (or a flush) runs them
+    const int e = launch_slot_sums(R, s);
+    trace_mark("pinnsf_reduce", s);
+    return e;
 }
+
+PIML_API int piml_pinnsf_slot_sums_flush(void) { return pending_slot_sums_flush(); }
 
 PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
                              const piml_collision_head* head, const float* self_features, float tau, float* acc,
@@ -232,11 +279,10 @@ PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_
         trace_mark("enc_bwd_dx", m);
         PIML_TRY(enc_stage_bwd_dw(enc, nbr, m));
         trace_mark("enc_bwd_dw", m);
-        PIML_TRY(reduce_all(enc, dec, nbr, m, (flags & PIML_ACCUMULATE) != 0));
-        trace_mark("pinnsf_reduce", m);
+        PIML_TRY(reduce_all(enc, dec, nbr, m, (flags & PIML_ACCUMULATE) != 0, (flags & PIML_DEFER_SLOT_SUMS) != 0));
         return hipSuccess;
     }
-    if (flags & PIML_ACCUMULATE) return hipErrorInvalidValue;      // (the forked form sums its slots per stage: not offered there)
+    if (flags & (PIML_ACCUMULATE | PIML_DEFER_SLOT_SUMS)) return hipErrorInvalidValue;      // (the forked form sums its slots per stage: not offered there)
     PIML_TRY(dec_stage_bwd_dx(dec, nbr, g_pred, self_features, tau, g_self, m));
     Side* S;
     PIML_TRY(side_streams(&S));

@@ -176,11 +176,12 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
 // Target of float4 column j: off0 + j for j < split, off1 + (j - split) behind it (a slot whose fields land in two places of
 // the gradient buffer: the layer-split slots of encoder_dw2.hip); the plain form is split = lanes, off0 = 0.
 // accumulate: grads += the sum (a second backward pass through the same weights inside one optimiser step).
-__device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes,
-                                                int split = 0x7fffffff, int off0 = 0, int off1 = 0, bool accumulate = false) {
+// (bx: the column block, blockIdx.x of a launch of its own)
+__device__ __forceinline__ void sum_slots_16x16_at(int bx, const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes,
+                                                   int split = 0x7fffffff, int off0 = 0, int off1 = 0, bool accumulate = false) {
     __shared__ float4 sh[256];
     const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + col;
+    const int j = bx * 16 + col;
     const float4* parts = reinterpret_cast<const float4*>(partials);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j < lanes)
@@ -212,6 +213,11 @@ __device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partia
         }
         *dst = s;
     }
+}
+
+__device__ __forceinline__ void sum_slots_16x16(const float* __restrict__ partials, float* __restrict__ grads, int B, int lanes,
+                                                int split = 0x7fffffff, int off0 = 0, int off1 = 0, bool accumulate = false) {
+    sum_slots_16x16_at((int)blockIdx.x, partials, grads, B, lanes, split, off0, off1, accumulate);
 }
 
 // layer-split encoder slots (encoder_dw2.hip): float4 geometry of the two slot kinds inside a full ENC_PART gradient buffer

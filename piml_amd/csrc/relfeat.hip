@@ -16,6 +16,7 @@
 // No N x N intermediate exists; v / a are touched only for the k selected neighbours.
 #include "common.hpp"
 #include "trace.hpp"
+#include "reduce.hpp"
 #include "../../include/piml_hip.h"
 
 #include <cmath>
@@ -399,15 +400,15 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
 // row's gradient block is read nearly coalesced and the sum over slots is three xor-shuffles.
 // The scatter into the selected sources uses float atomics (a few hundred KB in total); the
 // row's own term is added atomically too because other rows scatter into it concurrently.
-__global__ __launch_bounds__(256) void relfeat_bwd_kernel(
-        const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
+__device__ __forceinline__ void relfeat_bwd_rows(
+        int bid, const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
         const int* __restrict__ ped_idx, const int* __restrict__ obs_idx, const float* __restrict__ p, int ld,
         const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
         float2* g_dest, int gld, float* __restrict__ g_speed) {
     // gld = 2: g_destf rows are d/d(dest_feat).  gld = 7: they are d/d(self_features) rows; their v / a columns join
     // the row's own term and column 6 is d/d(desired speed) (g_speed, may be NULL)
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row = (long)bid * 4 + (threadIdx.x >> 6);
     if (row >= (long)C * fcnt) return;
     const int c = (int)(row / fcnt), fl = (int)(row - (long)c * fcnt);
     const size_t ci = (size_t)c * N + f0 + fl;
@@ -439,6 +440,30 @@ __global__ __launch_bounds__(256) void relfeat_bwd_kernel(
         atomicAdd(g_state + ci * 6 + q, own);
     }
     if (gld == 7 && g_speed && lane == 6) g_speed[row] = reinterpret_cast<const float*>(g_destf)[row * 7 + 6];
+}
+
+__global__ __launch_bounds__(256) void relfeat_bwd_kernel(
+        const float* __restrict__ g_ped, const float* __restrict__ g_obs, const float2* __restrict__ g_destf,
+        const int* __restrict__ ped_idx, const int* __restrict__ obs_idx, const float* __restrict__ p, int ld,
+        const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
+        float2* g_dest, int gld, float* __restrict__ g_speed) {
+    relfeat_bwd_rows((int)blockIdx.x, g_ped, g_obs, g_destf, ped_idx, obs_idx, p, ld, dest, C, N, f0, fcnt, kpe, koe, g_state, g_dest,
+                     gld, g_speed);
+}
+
+// The same rows behind the DEFERRED slot sums of the network's backward pass (reduce.hpp): workgroups [0, nred) sum weight-
+// gradient slots (bandwidth: they go first), the rest are the relfeat backward's -- two independent small kernels in one launch.
+__global__ __launch_bounds__(256) void relfeat_bwd_reduce_kernel(
+        const ReduceAll R, int nred, const float* __restrict__ g_ped, const float* __restrict__ g_obs,
+        const float2* __restrict__ g_destf, const int* __restrict__ ped_idx, const int* __restrict__ obs_idx,
+        const float* __restrict__ p, const float2* __restrict__ dest, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
+        float2* g_dest, float* __restrict__ g_speed) {
+    if ((int)blockIdx.x < nred) {
+        reduce_block(R, (int)blockIdx.x);
+        return;
+    }
+    relfeat_bwd_rows((int)blockIdx.x - nred, g_ped, g_obs, g_destf, ped_idx, obs_idx, p, 6, dest, 1, N, f0, fcnt, kpe, koe, g_state,
+                     g_dest, 7, g_speed);
 }
 
 // Deterministic variant of relfeat_bwd (no atomics, bit-reproducible): one thread per (source agent, component).
@@ -674,9 +699,18 @@ PIML_API int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_f
     if (!g_self || !state || !destination_rows || !g_state || !g_destination || (kp_eff > 0 && (!g_ped_feat || !ped_idx)) ||
         (ko_eff > 0 && (!g_obs_feat || !obs_idx)))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
-                       g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,
-                       focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+    ReduceAll R;
+    if (pending_slot_sums_take(as_stream(stream), &R)) {       // slot sums left by piml_pinnsf_bwd(PIML_DEFER_SLOT_SUMS) on this stream
+        const int nred = R.gx * R.nsets;
+        hipLaunchKernelGGL(relfeat_bwd_reduce_kernel, dim3((unsigned)(nred + (focal_count + 3) / 4)), dim3(256), 0, as_stream(stream),
+                           R, nred, g_ped_feat, g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state,
+                           (const float2*)destination_rows, N, focal_begin, focal_count, kp_eff, ko_eff, g_state,
+                           (float2*)g_destination, g_speed);
+    } else {
+        hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
+                           g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,
+                           focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+    }
     trace_mark("relfeat_bwd", as_stream(stream));
     return hipGetLastError();
 }

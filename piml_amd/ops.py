@@ -1780,6 +1780,39 @@ class ParamGradSink:
         self._assign.setdefault(id(param), (param, view))
 
 
+_DEFER_DEPTH = 0
+_DEFER_KEEP = []        # the slot buffers deferred sums will read: alive until those sums have been launched
+
+
+class deferred_slot_sums:
+    """`with ops.deferred_slot_sums(): loss.backward()` -- inside, the backward of a fused network (fused_pinnsf) does not launch
+    the sums of its weight-gradient slots; the backward of the relative features that follows it in the same pass
+    (relative_features_packed_self) runs them as the leading workgroups of its own launch (PIML_DEFER_SLOT_SUMS: the two kernels
+    are independent and small, a launch boundary costs ~5 us), and whatever is still waiting at exit is launched there.  The
+    weight gradients are complete when the block exits, not before: the network's backward defers only when no parameter of
+    it holds a .grad yet (autograd then keeps the buffers it is handed instead of reading them) or a ParamGradSink owns them.
+    PIML_DEFER_SLOT_SUMS=0 in the environment turns the block into a no-op."""
+
+    def __enter__(self):
+        global _DEFER_DEPTH
+        _DEFER_DEPTH += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_DEPTH
+        _DEFER_DEPTH -= 1
+        if _DEFER_DEPTH == 0:
+            _lib.check(_lib.lib().piml_pinnsf_slot_sums_flush(), 'piml_pinnsf_slot_sums_flush')
+            _DEFER_KEEP.clear()
+        return False
+
+
+def _defer_slot_sums(params, sink):
+    if _DEFER_DEPTH <= 0 or FORK_NETWORK or _os.environ.get('PIML_DEFER_SLOT_SUMS', '1') == '0':
+        return False
+    return sink is not None or all(getattr(p, 'grad', None) is None for p in params)
+
+
 class _FusedPinnsf(torch.autograd.Function):
     """inputs: need_grad, nbr, scales, tau, fold_epilogue, packs (PinnsfPacks or None), nhead (0 / 1),
     self_features (..., N, 7), then per branch x (..., N, k, in), encoder w1 b1 w2 b2 w3 b3, decoder w1 b1 w2 b2,
@@ -1859,7 +1892,7 @@ class _FusedPinnsf(torch.autograd.Function):
                     tuple(self_features.shape), agents, need_grad, int(nhead))
         ctx.keeps = keeps
         ctx.sink = ParamGradSink._active if need_grad else None
-        ctx.params = tensors if ctx.sink is not None else None       # (the Parameter objects themselves: p.grad is set on them)
+        ctx.params = tensors if need_grad else None       # (the Parameter objects themselves: p.grad is set on them / looked at)
         ctx.set_materialize_grads(False)
         out = (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
         if nhead:
@@ -1952,6 +1985,9 @@ class _FusedPinnsf(torch.autograd.Function):
                     dstructs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
                                                        gp2, gp1, g_pooled[b], dparts[b], dflats[b]))
                 darr = (_lib.DecoderBranch * nbr)(*dstructs)
+                if len(live) == nbr and _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink):
+                    flags |= _lib.DEFER_SLOT_SUMS
+                    _DEFER_KEEP[:] = [parts, dparts]       # (a second deferral launches the sums waiting so far: their buffers may go)
                 _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags,
                                              _stream()), 'piml_pinnsf_bwd')
                 if want_self:
