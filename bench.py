@@ -1091,7 +1091,13 @@ def main():
     if leg_timer is not None:
         leg_timer.cancel()
     if use_dist:
-        out['exchange'] = {'backward': args.exchange, 'overlap': bool(st.pre is not None),
+        # proof that the collective library saw `world` ranks: every rank contributes (rank, device index) to one all-gather on
+        # the GPU (backend "nccl" = RCCL over xGMI) and the line carries what came back
+        seen = torch.empty(world, 2, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(seen, torch.tensor([[rank, torch.cuda.current_device()]], dtype=torch.int32, device=dev))
+        seen = seen.cpu().tolist()
+        out['exchange'] = {'ranks_seen': len({r for r, _ in seen}), 'ranks': seen, 'backend': dist.get_backend(),
+                           'backward': args.exchange, 'overlap': bool(st.pre is not None),
                            'model_cost_us': exchange_why, 'padded_agents': N - N_real,
                            'other_variants': exchange_other,
                            'note': 'bucket = one all-reduce of [d/d(state) (N,6) | weight gradients]; rs = '

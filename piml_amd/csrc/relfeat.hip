@@ -44,6 +44,8 @@ struct RelfeatArgs {
     // are bit-identical to one launch over [0, N).
     int a_lo[2], a_hi[2];   // agent-pass source ranges (the second may be empty)
     int flags;              // kRfPedFeat | kRfObs | kRfDest | kRfPedList | kRfInit
+    int split;              // 1: the launch has twice the workgroups -- the first half runs the pedestrian pass (+ dest / self features) of its rows,
+                            // the second half the obstacle pass of the same rows (relfeat_fwd_kernel<W, false> only)
     const float* speed;   // non-NULL: dest_feat rows are the model's self_features rows [dest - p, v, a, v0] (dest_ld >= 7)
     float* zero; long zero_n;   // optional: buffer this launch clears (the state gradient its backward accumulates into)
     long long* tick;            // optional: device-side frame counter this launch advances by one (it does not read it)
@@ -89,6 +91,57 @@ __device__ __forceinline__ void list_insert(unsigned& ld, unsigned& li, unsigned
     li = moves ? (below_moves ? up_i : ni) : li;
 }
 
+// ---- epilogue of a focal row: gather the k selected sources, write features / indices (lane s = slot s) ----
+__device__ __forceinline__ void relfeat_epilogue(const RelfeatArgs& A, int flags, int c, int fl, int lane, const u64 (&lists)[2], float pix,
+                                                 float piy, float vix, float viy, float aix, float aiy, float2 vi2, float2 ai2) {
+    const int ld = A.ld;
+    const int kpe = min(A.kp, A.N), koe = min(A.ko, A.M);
+    const size_t row = (size_t)c * A.fcnt + fl;
+    if (lane < kpe && (flags & kRfPedList)) {
+        const u64 key = lists[0];
+        A.ped_idx[row * kpe + lane] = key == kEmptyKey ? -1 : (int)(unsigned)key;
+    }
+    if (lane < kpe && (flags & kRfPedFeat)) {
+        const u64 key = lists[0];
+        const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
+        if (j >= 0) {
+            const size_t cj = ((size_t)c * A.N + j) * ld;
+            const float2 pj = *reinterpret_cast<const float2*>(A.p + cj);
+            const float2 vj = *reinterpret_cast<const float2*>(A.v + cj);
+            const float2 aj = *reinterpret_cast<const float2*>(A.a + cj);
+            f0 = pj.x - pix; f1 = pj.y - piy;                           // data.py:491-492
+            f2 = nan_to_zero(vj.x) - vix; f3 = nan_to_zero(vj.y) - viy;
+            f4 = nan_to_zero(aj.x) - aix; f5 = nan_to_zero(aj.y) - aiy;
+        }
+        float2* out = reinterpret_cast<float2*>(A.ped_feat + (row * kpe + lane) * 6);
+        out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
+        A.ped_idx[row * kpe + lane] = j;
+    }
+    if (lane < koe && (flags & kRfObs)) {
+        const u64 key = lists[1];
+        const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
+        if (j >= 0) {
+            const float2 oj = A.obs[j];
+            f0 = oj.x - pix; f1 = oj.y - piy;                           // data.py:506-508
+            f2 = 0.f - vix; f3 = 0.f - viy; f4 = 0.f - aix; f5 = 0.f - aiy;
+        }
+        float2* out = reinterpret_cast<float2*>(A.obs_feat + (row * koe + lane) * 6);
+        out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
+        A.obs_idx[row * koe + lane] = j;
+    }
+    if (lane == 0 && (flags & kRfDest)) {
+        const float2 d = A.dest[row];
+        float* df = A.dest_feat + row * A.dest_ld;          // row stride: 2, or the width of a self_features row
+        df[0] = nan_to_zero(d.x - pix); df[1] = nan_to_zero(d.y - piy);                    // :496-497
+        if (A.speed) {                                      // self_features = [dest - p, v, a, v0], raw v and a
+            df[2] = vi2.x; df[3] = vi2.y; df[4] = ai2.x; df[5] = ai2.y;
+            df[6] = A.speed[row];
+        }
+    }
+}
+
 constexpr int kObsTile = 2048;     // RES: obstacle points resident next to the agent tile (16 KiB)
 
 // LDS (dynamic): agent tile x | y (kTile floats each), the waves' candidate rings, and -- RES -- the obstacle tile x | y.
@@ -121,8 +174,15 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
             A.zero[e] = 0.f;
 
     const int bpc = (A.fcnt + WAVES - 1) / WAVES;          // blocks per slice
-    const int c = blockIdx.x / bpc;
-    const int fl = (blockIdx.x - c * bpc) * WAVES + wave;   // focal row of this wave
+    // split launch: workgroups [0, C * bpc) run the pedestrian pass of their rows, [C * bpc, 2 C * bpc) the obstacle pass of the
+    // same rows -- a row's two passes are independent, and a launch of a few thousand rows is bound by the LATENCY of a row (a
+    // chain of dependent drains), not by issue slots: side by side the chain is one pass long instead of two
+    const int nb = A.C * bpc;
+    const int kind = (!RES && A.split) ? ((int)blockIdx.x >= nb ? 2 : 1) : 0;
+    const int bid = (int)blockIdx.x - (kind == 2 ? nb : 0);
+    const int flags = kind == 1 ? (A.flags & ~kRfObs) : (kind == 2 ? kRfObs : A.flags);
+    const int c = bid / bpc;
+    const int fl = (bid - c * bpc) * WAVES + wave;          // focal row of this wave
     const bool has = fl < A.fcnt;
     const int i = A.f0 + (has ? fl : 0);
     const size_t ci = (size_t)c * A.N + i;
@@ -185,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     // in the binary, so it stays resident in the instruction cache (inlining it at every
     // append site made each execution an instruction-fetch miss chain).
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = kind == 2 ? 1 : 0; pass < (kind == 1 ? 1 : 2); ++pass) {
         const float* __restrict__ src = pass == 0 ? A.p + (size_t)c * A.N * ld : (const float*)A.obs;
         const int sld = pass == 0 ? ld : 2;
         const int cnt = pass == 0 ? A.N : A.M;
@@ -194,14 +254,14 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
         const float dthr = pass == 0 ? A.dthr_p : A.dthr_o;
         float cut2 = pass == 0 ? A.cut2_p : A.cut2_o;      // wave-uniform
 
-        if (pass == 1 && !(A.flags & kRfObs)) break;       // (uniform over the launch: no barrier is skipped unevenly)
+        if (pass == 1 && !(flags & kRfObs)) break;         // (uniform over the workgroup: no barrier is skipped unevenly)
         float* const tile_x = pass == 0 ? agent_x : obs_x;
         float* const tile_y = pass == 0 ? agent_y : obs_y;
 
         unsigned list_d = kEmptyDist, list_i = 0;          // lane s: s-th nearest in-view source so far
         unsigned kth_d = kEmptyDist, kth_i = 0;            // wave-uniform copy of lane k-1's entry
         unsigned head = 0, tail = 0;                       // wave-uniform ring cursors
-        if (pass == 0 && (A.flags & kRfInit) && alive && k > 0) {
+        if (pass == 0 && (flags & kRfInit) && alive && k > 0) {
             // the list the LOCAL part left in ped_idx (sorted, -1 = empty slot); distances by the arithmetic of phase 2
             const int j = lane < k ? A.ped_idx[((size_t)c * A.fcnt + fl) * k + lane] : -1;
             if (j >= 0) {
@@ -240,6 +300,9 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                 if (!flush) {
                     // phase 1: lane owns points j0 + 4*lane + {0..3} and j0 + 256 + 4*lane + {0..3}
                     // packed fp32 (v_pk_add/mul/fma): two points per instruction
+                    // (round 4, measured and dropped: the next group's points fetched one trip ahead -- 16 more registers,
+                    // 23.0 vs 21.8 us at the 4096-agent scene, 130 vs 115 at 16384: the SIMDs are short of issue slots, not
+                    // waiting for the LDS)
                     float d2[8];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -342,58 +405,13 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
     if (!has) return;
 #ifdef PIML_RELFEAT_STATS
     if (A.stats && lane == 0) {
-        int* o = A.stats + ((size_t)c * A.fcnt + fl) * 12;
+        int* o = A.stats + ((size_t)c * A.fcnt + fl + (kind == 2 ? (size_t)A.C * A.fcnt : 0)) * 12;   // (split: the obstacle workgroups' rows behind the others)
         o[0] = st_evals; o[1] = st_rounds; o[2] = st_ins; o[3] = st_cand;
         for (int q = 0; q < 7; ++q) o[4 + q] = (int)(st_t[q] - st_t[0]);   // cycles since kernel entry of this wave
     }
 #endif
 
-    // ---- epilogue: gather the k selected sources, write features / indices ----
-    const int kpe = min(A.kp, A.N), koe = min(A.ko, A.M);
-    const size_t row = (size_t)c * A.fcnt + fl;
-    if (lane < kpe && (A.flags & kRfPedList)) {
-        const u64 key = lists[0];
-        A.ped_idx[row * kpe + lane] = key == kEmptyKey ? -1 : (int)(unsigned)key;
-    }
-    if (lane < kpe && (A.flags & kRfPedFeat)) {
-        const u64 key = lists[0];
-        const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
-        if (j >= 0) {
-            const size_t cj = ((size_t)c * A.N + j) * ld;
-            const float2 pj = *reinterpret_cast<const float2*>(A.p + cj);
-            const float2 vj = *reinterpret_cast<const float2*>(A.v + cj);
-            const float2 aj = *reinterpret_cast<const float2*>(A.a + cj);
-            f0 = pj.x - pix; f1 = pj.y - piy;                           // data.py:491-492
-            f2 = nan_to_zero(vj.x) - vix; f3 = nan_to_zero(vj.y) - viy;
-            f4 = nan_to_zero(aj.x) - aix; f5 = nan_to_zero(aj.y) - aiy;
-        }
-        float2* out = reinterpret_cast<float2*>(A.ped_feat + (row * kpe + lane) * 6);
-        out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
-        A.ped_idx[row * kpe + lane] = j;
-    }
-    if (lane < koe && (A.flags & kRfObs)) {
-        const u64 key = lists[1];
-        const int j = key == kEmptyKey ? -1 : (int)(unsigned)key;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f, f5 = 0.f;
-        if (j >= 0) {
-            const float2 oj = A.obs[j];
-            f0 = oj.x - pix; f1 = oj.y - piy;                           // data.py:506-508
-            f2 = 0.f - vix; f3 = 0.f - viy; f4 = 0.f - aix; f5 = 0.f - aiy;
-        }
-        float2* out = reinterpret_cast<float2*>(A.obs_feat + (row * koe + lane) * 6);
-        out[0] = make_float2(f0, f1); out[1] = make_float2(f2, f3); out[2] = make_float2(f4, f5);
-        A.obs_idx[row * koe + lane] = j;
-    }
-    if (lane == 0 && (A.flags & kRfDest)) {
-        const float2 d = A.dest[row];
-        float* df = A.dest_feat + row * A.dest_ld;          // row stride: 2, or the width of a self_features row
-        df[0] = nan_to_zero(d.x - pix); df[1] = nan_to_zero(d.y - piy);                    // :496-497
-        if (A.speed) {                                      // self_features = [dest - p, v, a, v0], raw v and a
-            df[2] = vi2.x; df[3] = vi2.y; df[4] = ai2.x; df[5] = ai2.y;
-            df[6] = A.speed[row];
-        }
-    }
+    relfeat_epilogue(A, flags, c, fl, lane, lists, pix, piy, vix, viy, aix, aiy, vi2, ai2);
 }
 
 // One wavefront per focal row; lane = slot * 8 + component (components 6, 7 idle), so a
@@ -573,6 +591,7 @@ static int relfeat_launch(const float* position, const float* heading, const flo
     RelfeatArgs A;
     A.a_lo[0] = 0; A.a_hi[0] = N; A.a_lo[1] = 0; A.a_hi[1] = 0;
     A.flags = kRfPedFeat | kRfObs | kRfDest;
+    A.split = 0;
     if (part == 1) {            // LOCAL: the focal block's own agents as sources + everything that needs no remote record
         A.a_lo[0] = focal_begin; A.a_hi[0] = focal_begin + focal_count;
         A.flags = kRfObs | kRfDest | kRfPedList;
@@ -614,6 +633,22 @@ static int relfeat_launch(const float* position, const float* heading, const flo
             if (!attr) attr = relfeat_attr<4>();
         }
         if (attr) return attr;
+    }
+    // split launch (pedestrian and obstacle passes of a row in different workgroups): whenever the obstacle pass exists
+    static const bool split_off = getenv("PIML_RELFEAT_SPLIT") && atoi(getenv("PIML_RELFEAT_SPLIT")) == 0;
+    // (measured, tools/time_relfeat.py: 8.4 -> 6.2 us at 122 agents, 10.6 -> 7.7 at 1024, 22.3 -> 21.8 at 4096 + 2000 points,
+    // 34.6 -> 29.3 for a rank's 2048 x 16384 share, 120 -> 115 at 16384; 64 slices of 128 agents -- 8192 short rows, bound by
+    // issue slots -- 17.9 -> 22.5: not split)
+    if (!split_off && (A.flags & kRfObs) && M > 0 && A.ko > 0 && A.kp > 0 && (C == 1 || rows <= 4096)) {
+        A.split = 1;
+        const dim3 grid2(grid.x * 2);
+        switch (waves) {
+            case 16: relfeat_go<16, false>(grid2, block, stream, A); break;
+            case 8: relfeat_go<8, false>(grid2, block, stream, A); break;
+            case 4: relfeat_go<4, false>(grid2, block, stream, A); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
     }
     switch (waves * 2 + (res ? 1 : 0)) {
         case 33: relfeat_go<16, true>(grid, block, stream, A); break;
