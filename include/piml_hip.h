@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 17
+#define PIML_HIP_ABI_VERSION 18
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -660,6 +660,38 @@ int piml_head64_slots(long long rows);
 int piml_head64_fwd(const piml_head64* head, void* stream);
 int piml_head64_bwd(const piml_head64* head, void* stream);
 int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream);   /* grads +=, see piml_encoder_bwd_acc */
+
+/*
+ * The corrector of `pinnsf_res` (src/models/model.py:1016-1020, :1050-1052; attn_pooling :950-970; ResDNN :82-119) on
+ * hand-written kernels (piml_amd/csrc/corrector.hip), forward and backward:
+ *     r = keep * scale * enc,  hid = relu(Wa r + ba),  s = wb . hid + bb,  attn = softmax_k(exp(s)),
+ *     pooled = sum_k attn r,   out = Wd relu(Wc pooled + bc) + bd
+ * enc (agents * k, 128): the pedestrian encoder's raw output, an agent's k neighbour rows consecutive; scale / keep_bits:
+ * what corrector[0] (a ResDNN of >= 2 "layers" = Dropout(2 x)) does to it -- scale 2 in eval mode, 2 / (1 - p) and the
+ * keep-mask bits (rows, 4) int32 of piml_dropout_keep_bits in train mode (NULL: keep everything); weights in nn.Linear
+ * layouts: wa (128, 128), ba (128), wb (1, 128), bb (1), wc (64, 128), bc (64), wd (2, 64), bd (2).
+ * fwd writes hid (rows, 128; NULL for inference), score / attn (rows), pooled (agents, 128), chid (agents, 64), out (agents, 2).
+ * bwd reads them and g_out (agents, 2); writes g_enc (rows, 128; NULL = not wanted); scratch g_pooled (agents, 128),
+ *     g_score (rows), partials_a = piml_corrector_slots(0, ..) x piml_corrector_partial_floats(0) floats, partials_b likewise
+ *     with 1; grads = [dWa 128x128 | dba 128 | dwb 128 | dbb 1 | 3 pad | dWc 64x128 | dbc 64 | dWd 2x64 | dbd 2 | 2 pad];
+ *     accumulate != 0: grads += (see piml_encoder_bwd_acc).  No atomics: bit-reproducible.
+ */
+typedef struct piml_corrector {
+    long long agents;
+    int k;
+    float scale;
+    const float* enc;
+    const unsigned* keep_bits;
+    const float *wa, *ba, *wb, *bb, *wc, *bc, *wd, *bd;
+    float *hid, *score, *attn, *pooled, *chid, *out;
+    const float* g_out;
+    float *g_pooled, *g_score, *g_enc;
+    float *partials_a, *partials_b, *grads;
+} piml_corrector;
+int piml_corrector_partial_floats(int which);
+int piml_corrector_slots(int which, long long agents, int k);
+int piml_corrector_fwd(const piml_corrector* c, void* stream);
+int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
 
 /*
  * The whole non-bottleneck PINNSF network (src/models/model.py:1271-1305: both encoders, the decoder tails, the

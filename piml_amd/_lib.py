@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 
@@ -45,6 +45,15 @@ class Head64(ctypes.Structure):
     """piml_head64 (include/piml_hip.h)."""
     _fields_ = [('x', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('hidden', _p), ('out', _p),
                 ('g_out', _p), ('g_x', _p), ('partials', _p), ('grads', _p)]
+
+
+class Corrector(ctypes.Structure):
+    """piml_corrector (include/piml_hip.h)."""
+    _fields_ = [('agents', _ll), ('k', _i), ('scale', _f), ('enc', _p), ('keep_bits', _p),
+                ('wa', _p), ('ba', _p), ('wb', _p), ('bb', _p), ('wc', _p), ('bc', _p), ('wd', _p), ('bd', _p),
+                ('hid', _p), ('score', _p), ('attn', _p), ('pooled', _p), ('chid', _p), ('out', _p),
+                ('g_out', _p), ('g_pooled', _p), ('g_score', _p), ('g_enc', _p),
+                ('partials_a', _p), ('partials_b', _p), ('grads', _p)]
 
 
 PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS = 1, 2, 4, 8          # piml_pinnsf_* flags
@@ -134,6 +143,10 @@ SIGNATURES = {
     'piml_head64_fwd': [ctypes.POINTER(Head64), _p],
     'piml_head64_bwd': [ctypes.POINTER(Head64), _p],
     'piml_head64_bwd_acc': [ctypes.POINTER(Head64), _i, _p],
+    'piml_corrector_partial_floats': [_i],
+    'piml_corrector_slots': [_i, _ll, _i],
+    'piml_corrector_fwd': [ctypes.POINTER(Corrector), _p],
+    'piml_corrector_bwd': [ctypes.POINTER(Corrector), _i, _p],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_slot_sums_flush': [],
     'piml_pinnsf_pack': [ctypes.POINTER(EncoderBranch), ctypes.POINTER(DecoderBranch), _i, ctypes.POINTER(CollisionHead),

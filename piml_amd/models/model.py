@@ -56,6 +56,8 @@ FUSED_NETWORK = os.environ.get('PIML_FUSED_NETWORK', '1') != '0'
 FUSED_ROW_DECODER = os.environ.get('PIML_FUSED_ROW_DECODER', '1') != '0'
 # ... and their neighbour-axis sums + desired-force term in one launch (PIML_FUSED_KSUM_TAIL=0: torch .sum + the plain epilogue)
 FUSED_KSUM_TAIL = os.environ.get('PIML_FUSED_KSUM_TAIL', '1') != '0'
+# pinnsf_res's corrector (attention pooling + 128 -> 64 -> 2 tail) on ops.fused_corrector (csrc/corrector.hip)
+FUSED_CORRECTOR = os.environ.get('PIML_FUSED_CORRECTOR', '1') != '0'
 PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
 
 
@@ -408,6 +410,25 @@ class _PINNSFBase(nn.Module):
                 out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
         return out
 
+    def _correct(self, encoded):
+        """corrector[2](corrector[1](corrector[0](encoded)))  (model.py:1050-1052) -- on the hand-written kernels
+        (ops.fused_corrector) when the three modules have the reference geometry, else module by module."""
+        res, pool, tail = self.corrector[0], self.corrector[1], self.corrector[2]
+        gw, tl = pool.get_weights.mlp, tail.mlp
+        if FUSED_GLUE and FUSED_CORRECTOR and encoded.is_cuda and encoded.dtype == torch.float32 and encoded.dim() >= 3 \
+                and encoded.shape[-1] == 128 and encoded.shape[-2] <= 64 and encoded.numel() > 0 and res.scales_input() \
+                and len(gw) == 4 and len(tl) == 4 and isinstance(gw[1], nn.ReLU) and isinstance(gw[3], nn.Identity) \
+                and isinstance(tl[1], nn.ReLU) and isinstance(tl[3], nn.Identity) \
+                and (gw[0].in_features, gw[0].out_features, gw[2].out_features) == (128, 128, 1) \
+                and (tl[0].in_features, tl[0].out_features, tl[2].out_features) == (128, 64, 2) \
+                and (not res.dropout_active() or res.dropout.p < 1):
+            from .. import ops
+            scale, keep = res.fused_spec(encoded.numel() // 128, encoded.device)
+            out = ops.fused_corrector(encoded, scale, keep, (gw[0].weight, gw[0].bias, gw[2].weight, gw[2].bias),
+                                      (tl[0].weight, tl[0].bias, tl[2].weight, tl[2].bias))
+            return out
+        return tail(pool(res(encoded)))
+
     def _fusable_head(self):
         """(w1, b1, w2, b2) of the `pinnsf_m` collision head when it has the reference geometry MLP(128, [64, 1])."""
         if self.collision_head != 'msgs':
@@ -541,8 +562,7 @@ class _PINNSFBase(nn.Module):
                 acc = acc + acc_o
             predictions = acc + self.desired_force(self_features)
         if self.residual:
-            r = self.corrector[0](encoded)
-            predictions = predictions + self.corrector[2](self.corrector[1](r))
+            predictions = predictions + self._correct(encoded)
         out = [predictions, ped_msgs]
         if out_obs is not None:
             out.append(out_obs)

@@ -2297,6 +2297,106 @@ class _CollisionHead64(torch.autograd.Function):
         return (gx.view(ctx.x_shape) if gx is not None else None,) + tuple(v if need[1 + j] else None for j, v in enumerate(views))
 
 
+class _Corrector(torch.autograd.Function):
+    """The corrector of `pinnsf_res` (piml_corrector_fwd / bwd, piml_amd/csrc/corrector.hip; src/models/model.py:1016-1020,
+    :1050-1052): enc (..., N, k, 128), scale, keep_bits, then wa ba wb bb (attn_pooling.get_weights) and wc bc wd bd
+    (the 128 -> 64 -> 2 tail) -> (..., N, 2)."""
+
+    @staticmethod
+    def forward(ctx, enc, scale, keep_bits, *weights):
+        import ctypes
+        L = _lib.lib()
+        e2 = _gpu_f32('enc', enc)
+        k = e2.shape[-2]
+        rows = e2.numel() // 128
+        agents = rows // k
+        e2 = e2.reshape(rows, 128)
+        wb = [_gpu_f32('corrector weight', t.detach()) for t in weights]
+        need_grad = any(ctx.needs_input_grad)
+        opt = dict(device=e2.device, dtype=torch.float32)
+        hid = torch.empty(rows, 128, **opt) if need_grad else None
+        score, attn = torch.empty(rows, **opt), torch.empty(rows, **opt)
+        pooled, chid, out = torch.empty(agents, 128, **opt), torch.empty(agents, 64, **opt), torch.empty(agents, 2, **opt)
+        if keep_bits is not None and (keep_bits.dtype != torch.int32 or tuple(keep_bits.shape) != (rows, 4) or not keep_bits.is_contiguous()):
+            raise ValueError('fused_corrector: keep_bits must be contiguous int32 (rows, 4) (ops.dropout_keep_bits / pack_keep_bits)')
+        C = _lib.Corrector()
+        C.agents, C.k, C.scale = agents, k, float(scale)
+        C.enc, C.keep_bits = e2.data_ptr(), _ptr(keep_bits)
+        C.wa, C.ba, C.wb, C.bb, C.wc, C.bc, C.wd, C.bd = [t.data_ptr() for t in wb]
+        C.hid, C.score, C.attn, C.pooled, C.chid, C.out = _ptr(hid), score.data_ptr(), attn.data_ptr(), pooled.data_ptr(), chid.data_ptr(), out.data_ptr()
+        with torch.cuda.device(e2.device):
+            _lib.check(L.piml_corrector_fwd(ctypes.byref(C), _stream()), 'piml_corrector_fwd')
+        if need_grad:
+            ctx.save_for_backward(e2, hid, score, attn, pooled, chid, *wb)
+        ctx.meta = (tuple(enc.shape), agents, k, float(scale))
+        ctx.keep = keep_bits
+        ctx.sink = ParamGradSink._active if need_grad else None
+        ctx.params = weights if ctx.sink is not None else None
+        ctx.set_materialize_grads(False)
+        return out.view(*enc.shape[:-2], 2)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 11
+        import ctypes
+        L = _lib.lib()
+        e2, hid, score, attn, pooled, chid, *wb = ctx.saved_tensors
+        enc_shape, agents, k, scale = ctx.meta
+        rows = agents * k
+        opt = dict(device=e2.device, dtype=torch.float32)
+        g = _gpu_f32('g_out', g).reshape(agents, 2)
+        g_enc = torch.empty(rows, 128, **opt) if ctx.needs_input_grad[0] else None
+        g_pooled, g_score = torch.empty(agents, 128, **opt), torch.empty(rows, **opt)
+        pa, pb = L.piml_corrector_partial_floats(0), L.piml_corrector_partial_floats(1)
+        parts_a = torch.empty(L.piml_corrector_slots(0, agents, k), pa, **opt)
+        parts_b = torch.empty(L.piml_corrector_slots(1, agents, k), pb, **opt)
+        sink = ParamGradSink.current(ctx.sink)
+        sunk, accumulate = (None, False)
+        if sink is not None:
+            sunk, accumulate = sink.take([tuple(id(t) for t in ctx.params)], pa + pb, opt)
+            if sunk is None:
+                sink = None
+        grads = sunk[0] if sink is not None else torch.empty(pa + pb, **opt)
+        C = _lib.Corrector()
+        C.agents, C.k, C.scale = agents, k, scale
+        C.enc, C.keep_bits = e2.data_ptr(), _ptr(ctx.keep)
+        C.wa, C.ba, C.wb, C.bb, C.wc, C.bc, C.wd, C.bd = [t.data_ptr() for t in wb]
+        C.hid, C.score, C.attn, C.pooled, C.chid, C.out = hid.data_ptr(), score.data_ptr(), attn.data_ptr(), pooled.data_ptr(), chid.data_ptr(), None
+        C.g_out, C.g_pooled, C.g_score, C.g_enc = g.data_ptr(), g_pooled.data_ptr(), g_score.data_ptr(), _ptr(g_enc)
+        C.partials_a, C.partials_b, C.grads = parts_a.data_ptr(), parts_b.data_ptr(), grads.data_ptr()
+        out_dummy = torch.empty(1, **opt)
+        C.out = out_dummy.data_ptr()
+        with torch.cuda.device(e2.device):
+            _lib.check(L.piml_corrector_bwd(ctypes.byref(C), int(accumulate), _stream()), 'piml_corrector_bwd')
+        A, B = grads[:pa], grads[pa:]
+        views = (A[:16384].view(128, 128), A[16384:16512], A[16512:16640].view(1, 128), A[16640:16641],
+                 B[:8192].view(64, 128), B[8192:8256], B[8256:8384].view(2, 64), B[8384:8386])
+        need = ctx.needs_input_grad
+        ge = g_enc.view(enc_shape) if g_enc is not None else None
+        if sink is not None:
+            for j, v in enumerate(views):
+                if need[3 + j]:
+                    sink.give(ctx.params[j], v)
+            return (ge, None, None) + (None,) * 8
+        return (ge, None, None) + tuple(v if need[3 + j] else None for j, v in enumerate(views))
+
+
+def fused_corrector(enc, scale, keep_bits, get_weights, tail):
+    """`pinnsf_res`'s corrector on the hand-written kernels: enc (..., N, k, 128) float32 = the pedestrian encoder's raw
+    output; (scale, keep_bits) = what corrector[0] does to it (ResDNN.fused_spec: keep * scale * enc, keep_bits None in
+    eval mode); get_weights = (wa (128,128), ba, wb (1,128), bb) of attn_pooling.get_weights; tail = (wc (64,128), bc,
+    wd (2,64), bd) of corrector[2].  Returns the residual acceleration (..., N, 2)."""
+    if not enc.is_cuda:
+        raise _lib.PimlHipError('fused_corrector: expected GPU tensors (piml_amd has no CPU path)')
+    shapes = [tuple(t.shape) for t in (*get_weights, *tail)]
+    if enc.dim() < 3 or enc.shape[-1] != 128 or not 1 <= enc.shape[-2] <= 64 or enc.numel() == 0 or \
+            shapes != [(128, 128), (128,), (1, 128), (1,), (64, 128), (64,), (2, 64), (2,)]:
+        raise ValueError('fused_corrector: unsupported geometry (enc (..., N, k <= 64, 128); MLP(128, [128, 1]); MLP(128, [64, 2]))')
+    return _Corrector.apply(enc, float(scale), keep_bits, *get_weights, *tail)
+
+
 def collision_head64(x, w1, b1, w2, b2):
     """sigmoid(Linear(64, 1)(relu(Linear(64, 64)(x)))) for x (..., 64) -> (...,): `pinnsf_bm`'s collision head on the decoder
     output of every neighbour row (src/models/model.py:1183, 1214-1215), forward and backward on hand-written kernels."""
