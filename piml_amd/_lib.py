@@ -52,7 +52,7 @@ class Corrector(ctypes.Structure):
     _fields_ = [('agents', _ll), ('k', _i), ('scale', _f), ('enc', _p), ('keep_bits', _p),
                 ('wa', _p), ('ba', _p), ('wb', _p), ('bb', _p), ('wc', _p), ('bc', _p), ('wd', _p), ('bd', _p),
                 ('hid', _p), ('score', _p), ('attn', _p), ('pooled', _p), ('chid', _p), ('out', _p),
-                ('g_out', _p), ('g_pooled', _p), ('g_score', _p), ('g_enc', _p),
+                ('g_out', _p), ('g_pooled', _p), ('g_score', _p), ('g_chid', _p), ('g_enc', _p),
                 ('partials_a', _p), ('partials_b', _p), ('grads', _p)]
 
 

@@ -2348,7 +2348,7 @@ class _Corrector(torch.autograd.Function):
         opt = dict(device=e2.device, dtype=torch.float32)
         g = _gpu_f32('g_out', g).reshape(agents, 2)
         g_enc = torch.empty(rows, 128, **opt) if ctx.needs_input_grad[0] else None
-        g_pooled, g_score = torch.empty(agents, 128, **opt), torch.empty(rows, **opt)
+        g_pooled, g_score, g_chid = torch.empty(agents, 128, **opt), torch.empty(rows, **opt), torch.empty(agents, 64, **opt)
         pa, pb = L.piml_corrector_partial_floats(0), L.piml_corrector_partial_floats(1)
         parts_a = torch.empty(L.piml_corrector_slots(0, agents, k), pa, **opt)
         parts_b = torch.empty(L.piml_corrector_slots(1, agents, k), pb, **opt)
@@ -2364,7 +2364,7 @@ class _Corrector(torch.autograd.Function):
         C.enc, C.keep_bits = e2.data_ptr(), _ptr(ctx.keep)
         C.wa, C.ba, C.wb, C.bb, C.wc, C.bc, C.wd, C.bd = [t.data_ptr() for t in wb]
         C.hid, C.score, C.attn, C.pooled, C.chid, C.out = hid.data_ptr(), score.data_ptr(), attn.data_ptr(), pooled.data_ptr(), chid.data_ptr(), None
-        C.g_out, C.g_pooled, C.g_score, C.g_enc = g.data_ptr(), g_pooled.data_ptr(), g_score.data_ptr(), _ptr(g_enc)
+        C.g_out, C.g_pooled, C.g_score, C.g_chid, C.g_enc = g.data_ptr(), g_pooled.data_ptr(), g_score.data_ptr(), g_chid.data_ptr(), _ptr(g_enc)
         C.partials_a, C.partials_b, C.grads = parts_a.data_ptr(), parts_b.data_ptr(), grads.data_ptr()
         out_dummy = torch.empty(1, **opt)
         C.out = out_dummy.data_ptr()
