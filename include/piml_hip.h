@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 18
+#define PIML_HIP_ABI_VERSION 20
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -91,6 +91,20 @@ int piml_relfeat_fwd_tick(const float* position, const float* heading, const flo
                           float cos_thr_obs, float dist_thr_ped, float dist_thr_obs, float* ped_feat, float* obs_feat,
                           float* dest_feat, int dest_feat_ld, int32_t* ped_idx, int32_t* obs_idx, long long* tick,
                           void* stream);
+/* piml_relfeat_fwd / piml_relfeat_bwd with the model's self_features rows [dest - p, v, a, v0] (C, n, 7) in place of the
+ * destination features: the per-frame torch.cat of the training rollout (src/models/simulators.py:778-779) inside the launch.
+ * desired_speed (C, n).  bwd: g_self (C, n, 7); ACCUMULATES into g_state (C, N, 6) = d/d(p, v, a) (cleared by the caller);
+ * writes g_destination (C, n, 2) and g_speed (C, n; may be NULL). */
+int piml_relfeat_fwd_self(const float* position, const float* heading, const float* velocity, const float* acceleration,
+                          int state_ld, const float* destination, const float* obstacles, const float* desired_speed, int C,
+                          int N, int M, int focal_begin, int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
+                          float cos_thr_obs, float dist_thr_ped, float dist_thr_obs, float* ped_feat, float* obs_feat,
+                          float* self_features, int32_t* ped_idx, int32_t* obs_idx, void* stream);
+int piml_relfeat_bwd_self(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int32_t* ped_idx,
+                          const int32_t* obs_idx, const float* position, int state_ld, const float* destination, int C, int N,
+                          int focal_begin, int focal_count, int kp_eff, int ko_eff, float* g_state, float* g_destination,
+                          float* g_speed, void* stream);
+
 
 /*
  * piml_relfeat_fwd for ONE scene of packed (N, 6) = (p, v, a) records that also writes the model's self_features rows
@@ -216,6 +230,9 @@ int piml_collision_friends(float* coll, const float* base, int C, int T, int S_b
  * run in a fixed order.  partial: 3 * piml_rollout_losses_blocks(C, N) floats, ticket: one zeroed unsigned (left zero);
  * both only used when piml_rollout_losses_blocks(C, N) > 1.
  */
+/* n device-to-device copies (dst[i] <- src[i], bytes[i] bytes; the ranges of one pair do not overlap) in one launch per 24
+ * pairs: the tensors of a training batch into the static inputs of the captured step (src/models/simulators.py:699-779). */
+int piml_multi_copy(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream);
 int piml_rollout_losses_blocks(int C, int N);
 int piml_rollout_losses(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
                         const unsigned char* gates, const float* collisions, const float* hard_collisions,

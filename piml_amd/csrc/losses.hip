@@ -174,3 +174,50 @@ PIML_API int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, c
                        g_out0, g_out1, g_out2, g_mse, g_coll, g_hard, n, g_p);
     return hipGetLastError();
 }
+
+// ---- one launch for a list of device-to-device copies (the batch of a training step into the static inputs of its captured
+// graph: fifteen tensors of a few KB each were fifteen copy launches of ~2.6 us, src/models/simulators.py:699-779's
+// `data` fields) ----
+namespace piml {
+constexpr int kMultiCopyMax = 24;
+struct MultiCopy {
+    void* dst[kMultiCopyMax];
+    const void* src[kMultiCopyMax];
+    unsigned long long bytes[kMultiCopyMax];
+    int n;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopy M) {
+    const int e = blockIdx.y;
+    const unsigned long long nb = M.bytes[e];
+    char* d = static_cast<char*>(M.dst[e]);
+    const char* s = static_cast<const char*>(M.src[e]);
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * 256 + threadIdx.x, stride = (unsigned long long)gridDim.x * 256;
+    if (((reinterpret_cast<unsigned long long>(d) | reinterpret_cast<unsigned long long>(s)) & 15ull) == 0) {
+        const unsigned long long n16 = nb >> 4;
+        for (unsigned long long i = t0; i < n16; i += stride) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (unsigned long long i = (n16 << 4) + t0; i < nb; i += stride) d[i] = s[i];
+    } else {
+        for (unsigned long long i = t0; i < nb; i += stride) d[i] = s[i];
+    }
+}
+}  // namespace piml
+
+PIML_API int piml_multi_copy(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream) {
+    if (n < 0 || (n > 0 && (!dst || !src || !bytes))) return hipErrorInvalidValue;
+    for (int base = 0; base < n; base += piml::kMultiCopyMax) {
+        piml::MultiCopy M = {};
+        size_t most = 0;
+        M.n = n - base < piml::kMultiCopyMax ? n - base : piml::kMultiCopyMax;
+        for (int i = 0; i < M.n; ++i) {
+            if (bytes[base + i] && (!dst[base + i] || !src[base + i])) return hipErrorInvalidValue;
+            M.dst[i] = dst[base + i]; M.src[i] = src[base + i]; M.bytes[i] = bytes[base + i];
+            if (bytes[base + i] > most) most = bytes[base + i];
+        }
+        if (most == 0) continue;
+        size_t gx = (most / 16 + 255) / 256;
+        gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+        hipLaunchKernelGGL(piml::multi_copy_kernel, dim3((unsigned)gx, (unsigned)M.n), dim3(256), 0, piml::as_stream(stream), M);
+    }
+    return hipGetLastError();
+}
+

@@ -674,6 +674,42 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
                           obs_feat, dest_feat, dest_feat_ld, ped_idx, obs_idx, nullptr, nullptr, 0, stream);
 }
 
+// piml_relfeat_fwd whose third output is the model's self_features rows [dest - p, v, a, v0] (C, n, 7) instead of the
+// destination features (C, n, 2): the per-frame torch.cat of the training rollout (src/models/simulators.py:778-779) inside
+// the launch.  desired_speed (C, n): v0 of the focal rows.
+PIML_API int piml_relfeat_fwd_self(const float* position, const float* heading, const float* velocity,
+                                   const float* acceleration, int state_ld, const float* destination, const float* obstacles,
+                                   const float* desired_speed, int C, int N, int M, int focal_begin, int focal_count,
+                                   int topk_ped, int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped,
+                                   float dist_thr_obs, float* ped_feat, float* obs_feat, float* self_features, int32_t* ped_idx,
+                                   int32_t* obs_idx, void* stream) {
+    if (C > 0 && focal_count > 0 && (!desired_speed || !self_features)) return hipErrorInvalidValue;
+    return relfeat_launch(position, heading, velocity, acceleration, state_ld, destination, obstacles, C, N, M, focal_begin,
+                          focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
+                          obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, nullptr, 0, stream);
+}
+
+// Backward of piml_relfeat_fwd_self: g_self (C, n, 7) carries d/d(dest_feat) in columns 0-1, d/d(v, a) of the focal rows in
+// 2-5 and d/d(desired speed) in 6.  ACCUMULATES into g_state (C, N, 6) = d/d(p, v, a), which the caller has cleared;
+// g_destination (C, n, 2) and g_speed (C, n; may be NULL) are written.
+PIML_API int piml_relfeat_bwd_self(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int32_t* ped_idx,
+                                   const int32_t* obs_idx, const float* position, int state_ld, const float* destination, int C,
+                                   int N, int focal_begin, int focal_count, int kp_eff, int ko_eff, float* g_state,
+                                   float* g_destination, float* g_speed, void* stream) {
+    if (C < 0 || N < 0 || focal_begin < 0 || focal_count < 0 || focal_begin + focal_count > N || kp_eff < 0 || ko_eff < 0 ||
+        state_ld < 2 || (state_ld & 1))
+        return hipErrorInvalidValue;
+    if (C == 0 || focal_count == 0) return hipSuccess;
+    if (!g_self || !position || !destination || !g_state || !g_destination || (kp_eff > 0 && (!g_ped_feat || !ped_idx)) ||
+        (ko_eff > 0 && (!g_obs_feat || !obs_idx)))
+        return hipErrorInvalidValue;
+    const long rows = (long)C * focal_count;
+    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat, g_obs_feat,
+                       (const float2*)g_self, ped_idx, obs_idx, position, state_ld, (const float2*)destination, C, N, focal_begin,
+                       focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+    return hipGetLastError();
+}
+
 // piml_relfeat_fwd that also advances a device-side frame counter by one (the captured inference-rollout frame ends with
 // this launch: the increment was a 4 us launch of its own).  The kernel never reads the counter.
 PIML_API int piml_relfeat_fwd_tick(const float* position, const float* heading, const float* velocity,

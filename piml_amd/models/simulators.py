@@ -469,6 +469,7 @@ class BaseSimulator(Pedestrians):
             dest_num_i64 = dest_num.long().to(dev).contiguous()
             dest_idx = dest_idx.long()
             nan_flag = torch.zeros((), device=dev, dtype=torch.int32)
+            speed_rows = desired_speed.contiguous()
 
         for t in range(t_start, T):
             predictions = self.model(*state)                                  # :701
@@ -512,13 +513,14 @@ class BaseSimulator(Pedestrians):
                     dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
                     dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
 
-            if fused_step:    # v, a are already NaN-free (zero_nan): the operator itself, without the in-place fills
-                pf, of, df = ops.relative_features(
-                    p_cur, v_cur, a_cur, dest_cur, obstacles, args.topk_ped, args.sight_angle_ped,
-                    args.dist_threshold_ped, args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs)
+            if fused_step:    # v, a are already NaN-free (zero_nan): the operator itself, without the in-place fills,
+                # and the self_features rows of :778-779 written by the same launch (no torch.cat per frame)
+                state = list(ops.relative_features_self(
+                    p_cur, v_cur, a_cur, dest_cur, obstacles, speed_rows, args.topk_ped, args.sight_angle_ped,
+                    args.dist_threshold_ped, args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs))
             else:
                 pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)   # :772-776, differentiable
-            state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]      # :778-779
+                state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]  # :778-779
 
         def frames(steps):
             """per-frame (2, C, N) count records -> two gated (C, T, N) tensors"""
@@ -668,8 +670,8 @@ class BaseSimulator(Pedestrians):
             entry = (graph, static, out, aux)
             self._graphed_steps[key] = entry
         graph, static, out, aux = entry
-        # the batch into the graph's static inputs: multi-tensor copies (one launch per dtype instead of one per tensor)
-        torch._foreach_copy_([getattr(static, k) for k in self._BATCH_TENSORS], [getattr(batch, k) for k in self._BATCH_TENSORS])
+        # the batch into the graph's static inputs: ONE launch (ops.multi_copy; torch._foreach_copy_ issued a copy per tensor)
+        ops.multi_copy([getattr(static, k) for k in self._BATCH_TENSORS], [getattr(batch, k) for k in self._BATCH_TENSORS])
         graph.replay()
         return out, aux
 
@@ -750,7 +752,7 @@ class BaseSimulator(Pedestrians):
             entry = (graph, static, terms, log_vec)
             self._graphed_steps[key] = entry
         graph, static, terms, log_vec = entry
-        torch._foreach_copy_(list(static), list(batch))
+        ops.multi_copy(list(static), list(batch))
         graph.replay()
         return terms, log_vec
 

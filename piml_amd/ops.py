@@ -169,6 +169,63 @@ class _RelativeFeatures(torch.autograd.Function):
         return (g_state[..., 0:2], g_state[..., 2:4], g_state[..., 4:6], g_destination) + (None,) * 10
 
 
+class _RelativeFeaturesSelf(torch.autograd.Function):
+    """_RelativeFeatures whose third output is the model's self_features rows [dest - p, v, a, v0] (..., N, 7)
+    (piml_relfeat_fwd_self / piml_relfeat_bwd_self): the training rollout's per-frame torch.cat inside the launch."""
+
+    @staticmethod
+    def forward(ctx, position, velocity, acceleration, destination, obstacles, desired_speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o):
+        p = _gpu_f32('position', position)
+        v = _gpu_f32('velocity', velocity)
+        a = _gpu_f32('acceleration', acceleration)
+        d = _gpu_f32('destination', destination)
+        o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
+        if not (p.shape == v.shape == a.shape == d.shape) or p.shape[-1] != 2 or p.dim() < 2:
+            raise ValueError('position/velocity/acceleration/destination must share a (..., N, 2) shape')
+        N = p.shape[-2]
+        lead = tuple(p.shape[:-2])
+        C = p.numel() // max(N * 2, 1)
+        v0 = _gpu_f32('desired_speed', desired_speed)
+        if v0.numel() != C * N:
+            raise ValueError(f'desired_speed must hold one value per agent, got {tuple(v0.shape)}')
+        M = o.shape[0]
+        kpe, koe = min(kp, N), min(ko, M)
+        opt = dict(device=p.device, dtype=torch.float32)
+        pf, of = torch.empty(*lead, N, kpe, 6, **opt), torch.empty(*lead, N, koe, 6, **opt)
+        sf = torch.empty(*lead, N, 7, **opt)
+        pi = torch.empty(*lead, N, kpe, device=p.device, dtype=torch.int32)
+        oi = torch.empty(*lead, N, koe, device=p.device, dtype=torch.int32)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().piml_relfeat_fwd_self(
+                _ptr(p), None, _ptr(v), _ptr(a), 2, _ptr(d), _ptr(o), _ptr(v0), C, N, M, 0, N, kp, ko, cos_p, cos_o, dthr_p, dthr_o,
+                _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), _stream()), 'piml_relfeat_fwd_self')
+        ctx.save_for_backward(pi, oi, p, d)
+        ctx.geom = (C, N, kpe, koe, lead, tuple(desired_speed.shape))
+        ctx.mark_non_differentiable(pi, oi)
+        ctx.set_materialize_grads(False)
+        return pf, of, sf, pi, oi
+
+    @staticmethod
+    def backward(ctx, g_ped, g_obs, g_self, _gi, _go):
+        if g_ped is None and g_obs is None and g_self is None:
+            return (None,) * 12
+        pi, oi, p, d = ctx.saved_tensors
+        C, N, kpe, koe, lead, speed_shape = ctx.geom
+        opt = dict(device=p.device, dtype=torch.float32)
+
+        def dense(g, shape):
+            return torch.zeros(shape, **opt) if g is None else _gpu_f32('grad', g)
+        g_ped, g_obs, g_self = dense(g_ped, (*lead, N, kpe, 6)), dense(g_obs, (*lead, N, koe, 6)), dense(g_self, (*lead, N, 7))
+        g_state = torch.zeros(*lead, N, 6, **opt)
+        g_dest = torch.empty(*lead, N, 2, **opt)
+        g_speed = torch.empty(speed_shape, **opt) if ctx.needs_input_grad[5] else None
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().piml_relfeat_bwd_self(
+                _ptr(g_ped), _ptr(g_obs), _ptr(g_self), _ptr(pi), _ptr(oi), _ptr(p), 2, _ptr(d), C, N, 0, N, kpe, koe,
+                _ptr(g_state), _ptr(g_dest), _ptr(g_speed), _stream()), 'piml_relfeat_bwd_self')
+        return (g_state[..., 0:2], g_state[..., 2:4], g_state[..., 4:6], g_dest, None, g_speed) + (None,) * 6
+
+
 class _RelativeFeaturesPacked(torch.autograd.Function):
     """Interleaved (..., N, 6) = (p, v, a) state records (the all-gathered buffer of
     agent-block sharding) + destinations of the focal rows only."""
@@ -416,6 +473,26 @@ def relative_features(position, velocity, acceleration, destination, obstacles,
     return out if return_index else out[:3]
 
 
+def relative_features_self(position, velocity, acceleration, destination, obstacles, desired_speed,
+                           topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                           topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, return_index=False):
+    """relative_features whose third result is the model's self_features (..., N, 7) = [dest - p, v, a, v0] -- what the
+    training rollout concatenates per frame (src/models/simulators.py:778-779) -- written by the same launch.
+    desired_speed (..., N, 1) or (..., N).  Differentiable w.r.t. position, velocity, acceleration, destination, speed."""
+    if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
+        raise ValueError(f'topk must be <= {MAX_TOPK}')
+    if DETERMINISTIC_BWD:       # the atomics-free backward exists for the plain operator: features + cat, as before
+        out = relative_features(position, velocity, acceleration, destination, obstacles, topk_ped, sight_angle_ped,
+                                dist_threshold_ped, topk_obs, sight_angle_obs, dist_threshold_obs, return_index=True)
+        v0 = desired_speed if desired_speed.dim() == position.dim() else desired_speed.unsqueeze(-1)
+        out = (out[0], out[1], torch.cat((out[2], velocity, acceleration, v0), dim=-1), out[3], out[4])
+        return out if return_index else out[:3]
+    out = _RelativeFeaturesSelf.apply(position, velocity, acceleration, destination, obstacles, desired_speed,
+                                      int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
+                                      float(dist_threshold_ped), float(dist_threshold_obs))
+    return out if return_index else out[:3]
+
+
 # ------------------------------------------------------------------------------------------
 # closed-form social force (MLAPM.step)
 # ------------------------------------------------------------------------------------------
@@ -542,6 +619,25 @@ def collision_counts(position, thresholds):
 
 
 _LOSS_TICKETS = {}
+
+
+def multi_copy(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of GPU tensors in ONE launch (piml_multi_copy) when every pair is contiguous, of one
+    dtype and shape and on the current stream's device; anything else goes through torch._foreach_copy_."""
+    import ctypes
+    dsts, srcs = list(dsts), list(srcs)
+    ok = len(dsts) == len(srcs) and len(dsts) > 0 and all(
+        d.is_cuda and s.is_cuda and d.device == s.device == dsts[0].device and d.dtype == s.dtype and d.shape == s.shape
+        and d.is_contiguous() and s.is_contiguous() and not d.requires_grad for d, s in zip(dsts, srcs))
+    if not ok:
+        torch._foreach_copy_(dsts, srcs)
+        return
+    n = len(dsts)
+    da = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    sa = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    ba = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d in dsts])
+    with torch.cuda.device(dsts[0].device):
+        _lib.check(_lib.lib().piml_multi_copy(da, sa, ba, n, _stream()), 'piml_multi_copy')
 
 
 class _RolloutLosses(torch.autograd.Function):

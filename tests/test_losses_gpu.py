@@ -108,3 +108,25 @@ def test_param_grad_sink_equals_autograd_accumulation(model):
         assert (w is None) == (gt is None), name
         if w is not None:
             assert torch.equal(w, gt), name
+
+
+def test_multi_copy_one_launch_for_a_batch_of_tensors():
+    """ops.multi_copy (piml_multi_copy): the training batch into the captured step's static inputs -- mixed dtypes, odd byte
+    counts, an empty tensor, more pairs than one launch holds; anything non-contiguous falls back to torch._foreach_copy_."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4, 5, 122, 6, 6), (4, 5, 122, 7), (4, 5, 122), (3,), (0, 2), (1,), (17, 13)] * 5       # 35 pairs
+    dtypes = [torch.float32, torch.float32, torch.int64, torch.uint8, torch.float32, torch.bool, torch.int32] * 5
+    srcs = [(torch.rand(*s, generator=g) * 100).to(dt).cuda() for s, dt in zip(shapes, dtypes)]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    ops.multi_copy(dsts, srcs)
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    # unaligned views (odd byte offsets) and a non-contiguous pair
+    base_s, base_d = torch.arange(1000, dtype=torch.uint8).cuda(), torch.zeros(1000, dtype=torch.uint8).cuda()
+    ops.multi_copy([base_d[3:500]], [base_s[5:502]])
+    assert torch.equal(base_d[3:500], base_s[5:502]) and int(base_d[:3].sum()) == 0 and int(base_d[500:].sum()) == 0
+    a, b = torch.rand(8, 8).cuda(), torch.zeros(8, 8).cuda()
+    ops.multi_copy([b.t()], [a.t()])
+    assert torch.equal(a, b)

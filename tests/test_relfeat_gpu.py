@@ -317,3 +317,35 @@ def test_relfeat_backward_deterministic_variant(oracle, N, M, C, packed):
                                   out[4].cpu().numpy(), sc['position'], sc['destination'])
         for got, x in zip(g1, want):
             assert np.abs(np.nan_to_num(got.cpu().numpy()) - x).max() <= 1e-5 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize('lead', [(), (4,)])
+def test_relative_features_self_equals_features_plus_cat(lead):
+    """ops.relative_features_self (piml_relfeat_fwd_self / bwd_self): the per-frame torch.cat((dest_features, v, a, v0)) of the
+    training rollout (src/models/simulators.py:778-779) inside the launch -- features bit-equal, gradients equal to the float
+    atomics' order."""
+    import numpy as np
+    import torch
+    from piml_amd import ops
+    from piml_amd.scenes import synthetic_gc_scene
+    N, M = 122, 100
+    sc = synthetic_gc_scene(N, M, seed=5, channels=lead[0] if lead else None)
+    p, v, a, d = [torch.tensor(sc[k], device='cuda').requires_grad_(True) for k in ('position', 'velocity', 'acceleration', 'destination')]
+    v0 = torch.tensor(sc['desired_speed'], device='cuda').requires_grad_(True)
+    o = torch.tensor(sc['obstacles'], device='cuda')
+    pf, of, df = ops.relative_features(p, v, a, d, o)
+    sf_want = torch.cat((df, v, a, v0), dim=-1)
+    pf2, of2, sf = ops.relative_features_self(p, v, a, d, o, v0)
+    assert torch.equal(pf, pf2) and torch.equal(of, of2)
+    assert torch.equal(torch.nan_to_num(sf), torch.nan_to_num(sf_want)) and torch.equal(sf.isnan(), sf_want.isnan())
+    g = torch.Generator().manual_seed(1)
+    w1, w2, w3 = [torch.randn(t.shape, generator=g).cuda() for t in (pf, of, sf)]
+    finite = ~sf_want.isnan()
+
+    def grads(outs):
+        loss = (outs[0] * w1).sum() + (outs[1] * w2).sum() + torch.where(finite, outs[2] * w3, torch.zeros_like(w3)).sum()
+        return torch.autograd.grad(loss, [p, v, a, d, v0], allow_unused=True)
+    want = grads((pf, of, sf_want))
+    got = grads((pf2, of2, sf))
+    for x, y in zip(want, got):
+        assert torch.allclose(torch.nan_to_num(x), torch.nan_to_num(y), rtol=1e-5, atol=1e-6)
