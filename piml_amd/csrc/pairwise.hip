@@ -470,61 +470,141 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_kernel(const floa
 constexpr int kCollMaxThr = 4;
 
 // General path, parallel form (more than 25 slices with a scratch buffer): two sweeps over the S x N x N pairs.
-//   K1  totals[h][i][j] += number of slices in which the pair collides (integer atomics: exact in any order);
-//       grid = (j tiles of 64, i tiles of 4, slice chunks of CC_CHUNK), one wavefront per (i, slice chunk), lanes = j
-//   K2  counts[h][s][i] = sum_j collide(s, i, j) and 0 < totals[h][i][j] <= 25 (friends rule, data.py:587-591);
-//       one wavefront per (s, i), lanes stride over j, wave reduction, plain store.
+//   K1  totals[h][i][j] += number of slices in which the pair collides (integer atomics: exact in any order).  A wavefront
+//       takes 8 agents i x 64 partners j x a chunk of 32 slices: a slice's 64 partner positions are fetched once for 8 x 64
+//       pairs, and "norm2(...) < thr" is tested on the SQUARED distance against the smallest float whose correctly rounded
+//       square root reaches thr (lt_cut2: the same predicate, no square root per pair);
+//   K2  counts[h][s][i] = sum_j collide(s, i, j) and 0 < totals[h][i][j] <= 25 (friends rule, data.py:587-591), tiled the same way.
+// Round 3's form evaluated one agent per wavefront with a square root per pair: 1.60 ms at S = 750, N = 1024.
 constexpr int CC_CHUNK = 32;
+constexpr int CC_IB = 8;
 
-__global__ __launch_bounds__(256) void collision_totals_kernel(const float2* __restrict__ p, int S, int N,
-                                                               const float* __restrict__ thr, int nthr,
-                                                               int* __restrict__ totals) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane, i = blockIdx.y * 4 + wave;
-    const int s0 = blockIdx.z * CC_CHUNK, s1 = min(S, s0 + CC_CHUNK);
-    if (i >= N || j >= N || i == j) return;
-    int cnt[kCollMaxThr] = {0, 0, 0, 0};
-    for (int s = s0; s < s1; ++s) {
-        const float2 pi = p[(size_t)s * N + i], pj = p[(size_t)s * N + j];
-        const float d = norm2(pj.x - pi.x, pj.y - pi.y);          // NaN compares false
-#pragma unroll
-        for (int h = 0; h < kCollMaxThr; ++h)
-            if (h < nthr) cnt[h] += d < thr[h] ? 1 : 0;
+// smallest non-negative float x with sqrtf(x) >= th, i.e. "sqrtf(d2) < th"  <=>  "d2 < x" for the correctly rounded,
+// monotone sqrtf both sides use; ok = false when th is outside the range where the short search below is exact (the caller
+// then keeps the square root)
+__device__ __noinline__ float lt_cut2(float th, bool& ok) {
+    ok = th > 1e-18f && th < 1e18f;
+    if (!ok) return 0.f;
+    float x = th * th;
+#pragma unroll 1
+    for (int it = 0; it < 8 && sqrtf(x) >= th; ++it) x = __uint_as_float(__float_as_uint(x) - 1u);       // now sqrtf(x) < th
+    ok = sqrtf(x) < th;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const float nx = __uint_as_float(__float_as_uint(x) + 1u);
+        if (sqrtf(nx) >= th) return nx;
+        x = nx;
     }
-#pragma unroll
-    for (int h = 0; h < kCollMaxThr; ++h)
-        if (h < nthr && cnt[h]) atomicAdd(totals + ((size_t)h * N + i) * N + j, cnt[h]);
+    ok = false;
+    return 0.f;
 }
 
+// limits of the pair test for T thresholds: lim[h] is compared with d2 (use_sqrt false) or with sqrtf(d2) (true)
+template <int T>
+__device__ __forceinline__ bool cc_limits(const float* __restrict__ thr, float (&lim)[T]) {
+    bool all = true;
+    float c2[T];
+#pragma unroll
+    for (int h = 0; h < T; ++h) {
+        bool ok;
+        c2[h] = lt_cut2(thr[h], ok);
+        all = all && ok;
+    }
+#pragma unroll
+    for (int h = 0; h < T; ++h) lim[h] = all ? c2[h] : thr[h];
+    return !all;
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void collision_totals_kernel(const float2* __restrict__ p, int S, int N,
+                                                               const float* __restrict__ thr, int* __restrict__ totals) {
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+    const int j = blockIdx.x * 64 + lane, i0 = (blockIdx.y * 4 + wave) * CC_IB;
+    const int s0 = blockIdx.z * CC_CHUNK, s1 = min(S, s0 + CC_CHUNK);
+    if (i0 >= N) return;
+    float lim[T];
+    const bool use_sqrt = cc_limits<T>(thr, lim);
+    int cnt[CC_IB][T];
+#pragma unroll
+    for (int u = 0; u < CC_IB; ++u)
+#pragma unroll
+        for (int h = 0; h < T; ++h) cnt[u][h] = 0;
+    const int jj = j < N ? j : 0;
+#pragma unroll 1
+    for (int s = s0; s < s1; ++s) {
+        const float2* row = p + (size_t)s * N;
+        const float2 pj = row[jj];
+#pragma unroll
+        for (int u = 0; u < CC_IB; ++u) {
+            const float2 pi = row[min(i0 + u, N - 1)];                       // wave-uniform address
+            float x = sq2(pj.x - pi.x, pj.y - pi.y);                         // NaN compares false
+            if (use_sqrt) x = sqrtf(x);
+#pragma unroll
+            for (int h = 0; h < T; ++h) cnt[u][h] += x < lim[h] ? 1 : 0;
+        }
+    }
+    if (j >= N) return;
+#pragma unroll
+    for (int u = 0; u < CC_IB; ++u) {
+        const int i = i0 + u;
+        if (i >= N || i == j) continue;
+#pragma unroll
+        for (int h = 0; h < T; ++h)
+            if (cnt[u][h]) atomicAdd(totals + ((size_t)h * N + i) * N + j, cnt[u][h]);
+    }
+}
+
+// K2: one wavefront per (slice s, 8 agents i), lanes stride over the partners j: the pairs of the slice once more (squared-
+// distance test, a partner's position fetched once for the 8 agents); only a pair that collides reads its total.
+// (A per-agent list of the colliding non-friend partners instead of this second sweep was built and measured: with
+// temporally coherent rollouts the lists are a handful of entries, but uncorrelated frames make them the whole row --
+// 5.1 ms at S = 750, N = 1024 -- so the sweep stays.)
+template <int T>
 __global__ __launch_bounds__(256) void collision_counts_from_totals_kernel(const float2* __restrict__ p, int S, int N,
-                                                                           const float* __restrict__ thr, int nthr,
+                                                                           const float* __restrict__ thr,
                                                                            const int* __restrict__ totals,
                                                                            float* __restrict__ counts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long w = (long long)blockIdx.x * 4 + wave;           // (s, i)
-    if (w >= (long long)S * N) return;
-    const int s = (int)(w / N), i = (int)(w - (long long)s * N);
-    const float2 pi = p[(size_t)s * N + i];
-    int cnt[kCollMaxThr] = {0, 0, 0, 0};
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+    const int ib = (N + CC_IB - 1) / CC_IB;
+    const long long w = (long long)blockIdx.x * 4 + wave;           // (s, i block)
+    if (w >= (long long)S * ib) return;
+    const int s = (int)(w / ib), i0 = (int)(w - (long long)s * ib) * CC_IB;
+    float lim[T];
+    const bool use_sqrt = cc_limits<T>(thr, lim);
+    const float2* row = p + (size_t)s * N;
+    float2 pi[CC_IB];
+#pragma unroll
+    for (int u = 0; u < CC_IB; ++u) pi[u] = row[min(i0 + u, N - 1)];
+    int cnt[CC_IB][T];
+#pragma unroll
+    for (int u = 0; u < CC_IB; ++u)
+#pragma unroll
+        for (int h = 0; h < T; ++h) cnt[u][h] = 0;
+#pragma unroll 1
     for (int j = lane; j < N; j += 64) {
-        if (j == i) continue;
-        const float2 pj = p[(size_t)s * N + j];
-        const float d = norm2(pj.x - pi.x, pj.y - pi.y);
+        const float2 pj = row[j];
 #pragma unroll
-        for (int h = 0; h < kCollMaxThr; ++h)
-            if (h < nthr && d < thr[h]) {
-                const int t = totals[((size_t)h * N + i) * N + j];
-                cnt[h] += (t > 0 && t <= 25) ? 1 : 0;
-            }
+        for (int u = 0; u < CC_IB; ++u) {
+            const int i = i0 + u;
+            float x = sq2(pj.x - pi[u].x, pj.y - pi[u].y);
+            if (use_sqrt) x = sqrtf(x);
+#pragma unroll
+            for (int h = 0; h < T; ++h)
+                if (x < lim[h] && i < N && i != j) {
+                    const int t = totals[((size_t)h * N + i) * N + j];
+                    cnt[u][h] += (t > 0 && t <= 25) ? 1 : 0;
+                }
+        }
     }
 #pragma unroll
-    for (int h = 0; h < kCollMaxThr; ++h) {
-        if (h >= nthr) break;
-        int c = cnt[h];
+    for (int u = 0; u < CC_IB; ++u)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0) counts[((size_t)h * S + s) * N + i] = (float)c;
-    }
+        for (int h = 0; h < T; ++h) {
+            int c = cnt[u][h];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == 0 && i0 + u < N) counts[((size_t)h * S + s) * N + i0 + u] = (float)c;
+        }
 }
 
 // Fast path of collision_counts for stacks of at most 25 slices (the training rollouts: S = number
@@ -766,11 +846,21 @@ PIML_API int piml_collision_counts_scratch(const float* position, int S, int N, 
     if (S < 0 || N < 0 || n_thresholds < 0 || n_thresholds > kCollMaxThr) return hipErrorInvalidValue;
     if ((long)S * N * n_thresholds == 0) return hipSuccess;
     if (!position || !thresholds || !counts || !totals_zeroed) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(collision_totals_kernel, dim3((N + 63) / 64, (N + 3) / 4, (S + CC_CHUNK - 1) / CC_CHUNK), dim3(256),
-                       0, as_stream(stream), (const float2*)position, S, N, thresholds, n_thresholds, totals_zeroed);
-    const long long waves = (long long)S * N;
-    hipLaunchKernelGGL(collision_counts_from_totals_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       as_stream(stream), (const float2*)position, S, N, thresholds, n_thresholds, totals_zeroed, counts);
+    const dim3 g1((N + 63) / 64, (N + 4 * CC_IB - 1) / (4 * CC_IB), (S + CC_CHUNK - 1) / CC_CHUNK);
+    const long long waves = (long long)S * ((N + CC_IB - 1) / CC_IB);
+    const dim3 g2((unsigned)((waves + 3) / 4));
+    const float2* pp = (const float2*)position;
+#define PIML_CC2(T)                                                                                                              \
+    hipLaunchKernelGGL(collision_totals_kernel<T>, g1, dim3(256), 0, as_stream(stream), pp, S, N, thresholds, totals_zeroed);   \
+    hipLaunchKernelGGL(collision_counts_from_totals_kernel<T>, g2, dim3(256), 0, as_stream(stream), pp, S, N, thresholds,       \
+                       totals_zeroed, counts)
+    switch (n_thresholds) {
+        case 1: PIML_CC2(1); break;
+        case 2: PIML_CC2(2); break;
+        case 3: PIML_CC2(3); break;
+        default: PIML_CC2(4); break;
+    }
+#undef PIML_CC2
     return hipGetLastError();
 }
 
