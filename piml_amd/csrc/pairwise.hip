@@ -9,6 +9,7 @@
 #include "../../include/piml_hip.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace piml {
 
@@ -19,6 +20,7 @@ struct MlapmParams {
     float tau, A, B, Cc, D, cth, sth, r2;   // cos/sin of theta, 2*radius
     float B2, C2, D2;            // B, C, D pre-multiplied by log2(e): exp(x) = exp2(x * log2 e)
     int skip_absent;             // 1: sources with a NaN position contribute nothing (absent agents)
+    int ucy_two_phase;           // backward, UCY: the two-phase form (PIML_MLAPM_UCY_TWO_PHASE=0 keeps the scalar loop)
 };
 
 // MLAPM is a smooth force law checked to 1e-5 relative (not a discrete selection like relfeat), so
@@ -125,12 +127,65 @@ __device__ __forceinline__ void mlapm_pair2(const MlapmParams& P, v2f rx, v2f ry
     fy = sc * dy;
 }
 
+// UCY (variant 2) in two phases (round 4).  g = exp(B r + C) only for pairs the collision predicate flags, 1 otherwise
+// (mlapm.py:43-53), and the predicate -- three square roots and two divisions in the reference's exact float32 operations --
+// cost more than the rest of the pair.  Phase 1 gives every pair its g = 1 term on packed arithmetic and a CONSERVATIVE
+// distance test: every clause of the predicate implies that the relative position comes within 2R of the origin for some
+// t in [0, 1] of r + t w, hence |r| - |w| < 2R; a pair with (|r| - |w|)^2 - (2R)^2 > 1e-6 (|r|^2 + 1) (the slack covers the
+// roundings of both sides, 1e-7 relative, with a factor of ten) cannot be flagged.  The others -- ~4 % of the pairs of a
+// 4096-agent hall -- are compacted into a per-wave ring and get the exact predicate 64 at a time; a flagged pair adds the
+// difference (g - 1) x its g = 1 term.  Same sums up to the order of the additions.
+__device__ __forceinline__ void mlapm_pair2_ucy(const MlapmParams& P, v2f rx, v2f ry, v2f wx, v2f wy, float vix, float viy,
+                                                float ex, float ey, v2f& fx, v2f& fy, bool& near0, bool& near1) {
+    const v2f zero = {0.f, 0.f}, one = {1.f, 1.f};
+    const v2f d2 = pk_fma(ry, ry, rx * rx);
+    const bool p0 = d2.x > 0.f, p1 = d2.y > 0.f;                                  // NaN -> false
+    const v2f rinv = {fast_rsq(d2.x), fast_rsq(d2.y)};
+    const v2f r = pk_sel(p0, p1, d2 * rinv, d2);
+    const v2f dot = pk_fma(v2f{viy, viy}, ry, v2f{vix, vix} * rx);
+    const v2f view = pk_sel(dot.x > 0.f, dot.y > 0.f, one, zero);                 // :27
+    const v2f ninv = pk_sel(p0, p1, rinv, zero);
+    const v2f nx = rx * ninv, ny = ry * ninv;
+    const v2f cr = pk_fma(rx, v2f{ey, ey}, -(ry * v2f{ex, ex}));                  // :48
+    const v2f st = {cr.x > 0.f ? -P.sth : (cr.x <= 0.f ? P.sth : cr.x),
+                    cr.y > 0.f ? -P.sth : (cr.y <= 0.f ? P.sth : cr.y)};
+    const v2f cth = {P.cth, P.cth};
+    const v2f sc = view * v2f{P.A, P.A};                                          // g = 1
+    fx = sc * pk_fma(cth, nx, -(st * ny));
+    fy = sc * pk_fma(st, nx, cth * ny);
+    // conservative test: far = certainly not flagged
+    const v2f w2 = pk_fma(wy, wy, wx * wx);
+    const v2f wn = w2 * v2f{fast_rsq(fmaxf(w2.x, 1e-30f)), fast_rsq(fmaxf(w2.y, 1e-30f))};
+    const v2f a = r - wn;
+    const v2f slack = pk_fma(v2f{1e-6f, 1e-6f}, d2, v2f{1e-6f + P.r2 * P.r2, 1e-6f + P.r2 * P.r2});
+    near0 = !(a.x > 0.f && a.x * a.x > slack.x);                                  // (NaN: near)
+    near1 = !(a.y > 0.f && a.y * a.y > slack.y);
+}
+
+// exact second phase of one candidate: the difference between its flagged term and the g = 1 term phase 1 added
+__device__ __forceinline__ float2 mlapm_ucy_correction(const MlapmParams& P, float rx, float ry, float wx, float wy,
+                                                       float vix, float viy, float ex, float ey) {
+    if (!ucy_collision(rx, ry, wx, wy, P.r2)) return make_float2(0.f, 0.f);       // :43-47, exact
+    const float d2 = rx * rx + ry * ry;
+    const bool pos = d2 > 0.f;
+    const float rinv = fast_rsq(d2);
+    const float r = pos ? d2 * rinv : d2;
+    const float view = (vix * rx + viy * ry > 0.f) ? 1.f : 0.f;
+    const float ninv = pos ? rinv : 0.f;
+    const float nx = rx * ninv, ny = ry * ninv;
+    const float cr = rx * ey - ry * ex;
+    const float st = cr > 0.f ? -P.sth : (cr <= 0.f ? P.sth : cr);
+    const float s = view * P.A * (fast_exp2(P.B2 * r + P.C2) - 1.f);              // :53 minus the g = 1 term
+    return make_float2(s * (P.cth * nx - st * ny), s * (st * nx + P.cth * ny));
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
         const float2* __restrict__ dest, int N, MlapmParams P, float dt, float2* __restrict__ action,
         float2* __restrict__ force) {
     __shared__ float4 tile[kMlTile];                        // (px, py, vx, vy)
+    __shared__ unsigned short ucy_ring[WAVES][256];        // UCY: tile-local indices of the pairs that need the exact predicate
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * WAVES + wave;
     const bool has = i < N;
@@ -165,6 +220,52 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
                 acc2x += fx; acc2y += fy;
             }
         }
+        if (P.variant == 2) {
+            // phase 1 on two sources per lane (j, j + 64; the second clamped and masked at the tile's end), candidates into
+            // the ring; phase 2 whenever 64 are waiting, and for what is left at the end of the tile
+            const v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, vix2 = {vi.x, vi.x}, viy2 = {vi.y, vi.y};
+            unsigned short* ring = ucy_ring[uniform(wave)];
+            unsigned head = 0, tail = 0;
+            for (int j0 = 0;; j0 += 128) {
+                const bool more = j0 < tn;
+                if (more) {
+                    const int ja = j0 + lane, jb = j0 + 64 + lane;
+                    const bool va = ja < tn, vb = jb < tn;
+                    const float4 a = tile[va ? ja : 0], b = tile[vb ? jb : 0];
+                    v2f fx, fy;
+                    bool na, nb;
+                    mlapm_pair2_ucy(P, v2f{a.x, b.x} - pix, v2f{a.y, b.y} - piy, v2f{a.z, b.z} - vix2, v2f{a.w, b.w} - viy2,
+                                    vi.x, vi.y, ex, ey, fx, fy, na, nb);
+                    const bool absent_a = P.skip_absent && (a.x != a.x || a.y != a.y);
+                    const bool absent_b = P.skip_absent && (b.x != b.x || b.y != b.y);
+                    if (!va || absent_a) { fx.x = 0.f; fy.x = 0.f; na = false; }
+                    if (!vb || absent_b) { fx.y = 0.f; fy.y = 0.f; nb = false; }
+                    acc2x += fx; acc2y += fy;
+                    const u64 ma = __builtin_amdgcn_ballot_w64(na);
+                    if (ma) {
+                        if (na) ring[(tail + mbcnt(ma)) & 255] = (unsigned short)ja;
+                        tail += (unsigned)__builtin_popcountll(ma);
+                    }
+                    const u64 mb = __builtin_amdgcn_ballot_w64(nb);
+                    if (mb) {
+                        if (nb) ring[(tail + mbcnt(mb)) & 255] = (unsigned short)jb;
+                        tail += (unsigned)__builtin_popcountll(mb);
+                    }
+                }
+                while (tail - head >= (more ? 64u : 1u)) {
+                    const unsigned n = min(64u, tail - head);
+                    __builtin_amdgcn_wave_barrier();
+                    if ((unsigned)lane < n) {
+                        const float4 c = tile[ring[(head + lane) & 255]];
+                        const float2 t = mlapm_ucy_correction(P, c.x - pi.x, c.y - pi.y, c.z - vi.x, c.w - vi.y, vi.x, vi.y, ex, ey);
+                        sx += t.x; sy += t.y;
+                    }
+                    head += n;
+                }
+                if (!more) break;
+            }
+            continue;
+        }
         for (; j < tn; j += 64) {
             const float4 s = tile[j];
             if (P.skip_absent && (s.x != s.x || s.y != s.y)) continue;      // absent source
@@ -188,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
 // UCY collision flag are piecewise constant and carry no gradient (as in autograd).
 __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, float ry, float wx, float wy,
                                                 float vix, float viy, float ex, float ey, float Gx, float Gy,
-                                                float& ax, float& ay, float& bx, float& by) {
+                                                float& ax, float& ay, float& bx, float& by, int ucy_flag = -1) {
     ax = ay = bx = by = 0.f;
     const float d2 = rx * rx + ry * ry;
     if (!(d2 > 0.f) || !(vix * rx + viy * ry > 0.f)) return;
@@ -219,7 +320,7 @@ __device__ __forceinline__ void mlapm_pair_grad(const MlapmParams& P, float rx, 
         hx = k1 * (q_ok ? n8x - cs * mx : n8x) * qi8;              // d(cs)/d(vv)
         hy = k1 * (q_ok ? n8y - cs * my : n8y) * qi8;
     } else {
-        const float cf = ucy_collision(rx, ry, wx, wy, P.r2) ? 1.f : 0.f;      // the forward's exact flag
+        const float cf = (ucy_flag >= 0 ? ucy_flag != 0 : ucy_collision(rx, ry, wx, wy, P.r2)) ? 1.f : 0.f;      // the forward's exact flag
         phi2 = (P.B2 * r + P.C2) * cf; fx = P.B * cf * nx; fy = P.B * cf * ny;
     }
     const float AE = -P.A * fast_exp2(phi2);
@@ -255,6 +356,8 @@ __device__ __forceinline__ void mlapm_pair_grad2(const MlapmParams& P, v2f rx, v
     if (P.variant == 0) {
         phi2 = v2f{P.B2, P.B2} * r;
         fx = Bv * nx; fy = Bv * ny;
+    } else if (P.variant == 2) {      // UCY with the collision flag off (the flagged pairs get their difference afterwards)
+        phi2 = zero; fx = zero; fy = zero;
     } else {
         const v2f w2 = pk_fma(wy, wy, wx * wx);
         const v2f ri8 = {fminf(rinv.x, 1e8f), fminf(rinv.y, 1e8f)};
@@ -292,6 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_kernel(
         float2* __restrict__ g_dest) {
     __shared__ float4 tile_pv[kMlTile];                     // (px, py, vx, vy)
     __shared__ float4 tile_eg[kMlTile];                     // (ex, ey, Gx, Gy), G = dt * g_action
+    __shared__ unsigned short ucy_ring[WAVES][128];        // UCY: tile-local indices of the pairs that need the exact predicate
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * WAVES + wave;
     const bool has = x < N;
@@ -322,6 +426,56 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_kernel(
                 mlapm_pair_grad2(P, v2f{rx, -rx}, v2f{ry, -ry}, v2f{wx, -wx}, v2f{wy, -wy}, v2f{vx.x, s.z},
                                  v2f{vx.y, s.w}, v2f{ex, t.x}, v2f{ey, t.y}, v2f{Gx, t.z}, v2f{Gy, t.w}, ax, ay, bx, by);
                 spx += ax.y - ax.x; spy += ay.y - ay.x; svx += bx.y - bx.x; svy += by.y - by.x;
+            }
+            continue;
+        }
+        if (P.ucy_two_phase) {
+            // UCY in two phases (see mlapm_pair2_ucy): every pair with the flag off on packed arithmetic, both roles at once;
+            // the pairs the conservative distance test cannot rule out -- the predicate is the same for both roles -- go
+            // through a ring, get the exact flag once, and a flagged pair adds [flag on] - [flag off] for both roles
+            unsigned short* ring = ucy_ring[uniform(wave)];
+            unsigned head = 0, tail = 0;
+            const float lim = 1e-6f + P.r2 * P.r2;
+            for (int j0 = 0;; j0 += 64) {
+                const bool more = j0 < tn;
+                if (more) {
+                    const int j = j0 + lane;
+                    const bool in = j < tn;
+                    const float4 s = tile_pv[in ? j : 0], t = tile_eg[in ? j : 0];
+                    const float rx = s.x - px.x, ry = s.y - px.y, wx = s.z - vx.x, wy = s.w - vx.y;
+                    v2f ax, ay, bx, by;
+                    mlapm_pair_grad2(P, v2f{rx, -rx}, v2f{ry, -ry}, v2f{wx, -wx}, v2f{wy, -wy}, v2f{vx.x, s.z},
+                                     v2f{vx.y, s.w}, v2f{ex, t.x}, v2f{ey, t.y}, v2f{Gx, t.z}, v2f{Gy, t.w}, ax, ay, bx, by);
+                    if (in) { spx += ax.y - ax.x; spy += ay.y - ay.x; svx += bx.y - bx.x; svy += by.y - by.x; }
+                    const float d2 = rx * rx + ry * ry, w2 = wx * wx + wy * wy;
+                    const float a = d2 * fast_rsq(d2) - w2 * fast_rsq(fmaxf(w2, 1e-30f));
+                    const bool near = in && !(a > 0.f && a * a > 1e-6f * d2 + lim);
+                    const u64 m = __builtin_amdgcn_ballot_w64(near);
+                    if (m) {
+                        if (near) ring[(tail + mbcnt(m)) & 127] = (unsigned short)j;
+                        tail += (unsigned)__builtin_popcountll(m);
+                    }
+                }
+                while (tail - head >= (more ? 64u : 1u)) {
+                    const unsigned n = min(64u, tail - head);
+                    __builtin_amdgcn_wave_barrier();
+                    if ((unsigned)lane < n) {
+                        const int j = ring[(head + lane) & 127];
+                        const float4 s = tile_pv[j], t = tile_eg[j];
+                        const float rx = s.x - px.x, ry = s.y - px.y, wx = s.z - vx.x, wy = s.w - vx.y;
+                        if (ucy_collision(rx, ry, wx, wy, P.r2)) {
+                            float a1x, a1y, b1x, b1y, a0x, a0y, b0x, b0y;
+                            mlapm_pair_grad(P, rx, ry, wx, wy, vx.x, vx.y, ex, ey, Gx, Gy, a1x, a1y, b1x, b1y, 1);      // x focal
+                            mlapm_pair_grad(P, rx, ry, wx, wy, vx.x, vx.y, ex, ey, Gx, Gy, a0x, a0y, b0x, b0y, 0);
+                            spx -= a1x - a0x; spy -= a1y - a0y; svx -= b1x - b0x; svy -= b1y - b0y;
+                            mlapm_pair_grad(P, -rx, -ry, -wx, -wy, s.z, s.w, t.x, t.y, t.z, t.w, a1x, a1y, b1x, b1y, 1);  // o focal
+                            mlapm_pair_grad(P, -rx, -ry, -wx, -wy, s.z, s.w, t.x, t.y, t.z, t.w, a0x, a0y, b0x, b0y, 0);
+                            spx += a1x - a0x; spy += a1y - a0y; svx += b1x - b0x; svy += b1y - b0y;
+                        }
+                    }
+                    head += n;
+                }
+                if (!more) break;
             }
             continue;
         }
@@ -713,6 +867,8 @@ static MlapmParams make_params(int variant, float tau, float A, float B, float C
                                float radius, int skip_absent = 0) {
     MlapmParams P;
     P.skip_absent = skip_absent;
+    static const bool two_phase_off = getenv("PIML_MLAPM_UCY_TWO_PHASE") && atoi(getenv("PIML_MLAPM_UCY_TWO_PHASE")) == 0;
+    P.ucy_two_phase = two_phase_off ? 0 : 1;
     P.variant = variant; P.tau = tau; P.A = A; P.B = B; P.Cc = Cc; P.D = D;
     // the reference forms theta = sign * theta / 180 * pi in float32 (mlapm.py:34)
     const float th = theta_deg / 180.f * 3.14159265358979323846f;
