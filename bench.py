@@ -274,8 +274,8 @@ class Step:
         # with the reference's --dropout 0.5 (src/main.py:45, src/models/simulators.py:311): every step draws fresh
         # keep-masks on the device (ops.dropout_keep_bits inside the captured graph) and the fused kernels apply them
         self.model = getattr(MODEL, model_name)(model_args()).to(dev).train(bool(train_mode))
-        if train_mode:
-            self.ops.dropout_state(dev)     # the device-side (seed, call counter) must exist before a capture
+        if train_mode:      # the device-side (seed, call counter) must exist before a capture; the rank is folded into the seed
+            getattr(self.ops, 'dropout_seed', lambda s, d: self.ops.dropout_state(d))(666, dev)
         if two_streams:
             self.model.obs_stream = torch.cuda.Stream()
         self.params = [p for p in self.model.parameters()]

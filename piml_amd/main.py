@@ -13,6 +13,8 @@ undefined `args.f_batch_size`) on channelled windows, and does not need a checkp
 """
 import argparse
 import os
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')      # before torch brings the HIP runtime up (piml_amd.hip_graphs_safe)
 import random
 import string
 import time
@@ -93,6 +95,8 @@ def set_exp_configs(args):
     torch.manual_seed(args.seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(args.seed)
+        from . import ops
+        ops.dropout_seed(args.seed)      # the fused kernels' own draw counter back to 0 (a repeated seed does not rewind it by itself)
 
 
 LAST_RUN = {}      # the objects of the most recent main() call (tests / notebooks): simulator, histories, args

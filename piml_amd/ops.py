@@ -1286,7 +1286,8 @@ def dropout_state(device, seed=None):
     Inside a stream capture nothing is written from the host."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    torch_seed = int(torch.cuda.initial_seed())
+    with torch.cuda.device(idx):          # the seed of THIS device's generator (not of whichever device is current)
+        torch_seed = int(torch.cuda.initial_seed())
     ent = _DROPOUT_STATE.get(idx)
     capturing = torch.cuda.is_current_stream_capturing()
     if ent is None and capturing:
@@ -1301,6 +1302,20 @@ def dropout_state(device, seed=None):
             ent[0].copy_(st)
             ent[1] = torch_seed
     return _DROPOUT_STATE[idx][0]
+
+
+def dropout_seed(seed, device=None, rank=None):
+    """Reset the device's dropout draws: (seed, call counter 0, ticket 0) -- what torch.manual_seed does to torch's own
+    generator, explicitly.  `torch.manual_seed(s)` with the SAME s as before does not rewind the counter by itself (the state
+    only notices a seed that changed): loops that re-seed per run (BaseSimulator, the tools) call this.  rank (default: the
+    torch.distributed rank when a process group is up) is folded into the seed, so that the ranks of a sharded run do not
+    draw identical masks for equal local row indices."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    mixed = (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & ((1 << 64) - 1)
+    return dropout_state(device, seed=mixed)
 
 
 def dropout_keep_bits(rows, cols, p, device, stream_id=0):

@@ -80,3 +80,23 @@ def test_collision_counts_both_general_forms_agree():
     torch.cuda.synchronize()
     assert torch.equal(out, want)
     assert float(want[0, :, 0].sum()) == float(want[0, :, 1].sum())      # the friends pair is filtered symmetrically
+
+
+def test_graph_replay_self_test_passes_where_the_variable_is_in_effect():
+    """piml_amd.hip_graphs_safe()'s last resort (the launcher did not export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 and nobody can
+    tell whether the import set it in time): the hazard's own reproduction, once per process.  In this process the variable
+    is in effect (conftest / the import), so the self-test has to come back clean -- and a process that initialised HIP
+    before importing the package gets an answer from it instead of blind trust."""
+    import subprocess
+    import sys
+    import piml_amd
+    assert piml_amd._probe_graph_replay() is True
+    code = ('import torch; torch.cuda.is_available(); torch.zeros(1, device="cuda"); import piml_amd; '
+            'print("SAFE", piml_amd.hip_graphs_safe(), piml_amd._PROBED, piml_amd._GRAPHS_SAFE)')
+    env = {k: v for k, v in os.environ.items() if k not in ('DEBUG_CLR_GRAPH_PACKET_CAPTURE', 'PIML_TRUST_HIP_GRAPHS')}
+    env['PYTHONPATH'] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-W', 'ignore', '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('SAFE')][0].split()
+    # torch initialised first: the import-time rule already says "not safe" (is_initialized() saw it) -- no probe needed
+    assert line[1] == 'False' and line[3] == 'False'
