@@ -498,13 +498,24 @@ class _PINNSFBase(nn.Module):
             # on the fused kernels with scale 1 and no mask (its own launch) and the processor is the glue pass
             # (ops.scale_ksum, mask-aware); the obstacle branch takes the standard fused path
             pre = {}
-            if self._encoder_fusable(ped_features, self.ped_encoder, self.ped_processor):
+            ped_ok = self._encoder_fusable(ped_features, self.ped_encoder, self.ped_processor)
+            obs_ok = self.obs_feature_dim > 0 and self._encoder_fusable(obs_features, self.obs_encoder, self.obs_processor)
+            ped_branch = dict(x=ped_features, scale=1.0, pooled=False,
+                              weights=[t for lin in self.ped_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])
+            spec = self._launch_specs([(self.obs_processor, obs_features)])[0] if obs_ok else None
+            if ped_ok and obs_ok and spec[1] is None and tuple(ped_features.shape[:-2]) == tuple(obs_features.shape[:-2]):
+                # no mask on either branch (eval mode / p = 0): BOTH encoders in one launch per direction -- the row count
+                # of the many-rows kernels and of the one-pass backward instead of two few-rows launches
                 from .. import ops
-                encoded = ops.fused_encoders([dict(x=ped_features, scale=1.0, pooled=False,
-                                                   weights=[t for lin in self.ped_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])[0][0]
-            if self.obs_feature_dim > 0 and self._encoder_fusable(obs_features, self.obs_encoder, self.obs_processor):
+                both = ops.fused_encoders([ped_branch, dict(x=obs_features, scale=spec[0], keep_bits=None, pooled=True,
+                                                            weights=[t for lin in self.obs_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])
+                encoded, pre['obs'] = both[0][0], both[1]
+                ped_ok = obs_ok = False
+            if ped_ok:
                 from .. import ops
-                spec = self._launch_specs([(self.obs_processor, obs_features)])[0]
+                encoded = ops.fused_encoders([ped_branch])[0][0]
+            if obs_ok:
+                from .. import ops
                 pre['obs'] = ops.fused_encoders([dict(x=obs_features, scale=spec[0], keep_bits=spec[1], pooled=True,
                                                       weights=[t for lin in self.obs_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])[0]
         else:
