@@ -199,6 +199,7 @@ class _PINNSFBase(nn.Module):
         ucy = getattr(args, 'dataset_name', None) in {'ucy'}
         self.tau = self.taus[1] if ucy else self.taus[0]
         self.fix_dest_norm = False
+        self._ones_bits = None      # pinnsf_res: cached all-ones keep-mask of the pedestrian branch (see forward)
         # optional: a side stream on which the obstacle branch runs concurrently with the pedestrian
         # branch (the two are independent until their accelerations are added; inside a captured
         # HIP graph this becomes two parallel chains of GEMMs that fill the 256 CUs better)
@@ -502,15 +503,27 @@ class _PINNSFBase(nn.Module):
             obs_ok = self.obs_feature_dim > 0 and self._encoder_fusable(obs_features, self.obs_encoder, self.obs_processor)
             ped_branch = dict(x=ped_features, scale=1.0, pooled=False,
                               weights=[t for lin in self.ped_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])
-            spec = self._launch_specs([(self.obs_processor, obs_features)])[0] if obs_ok else None
-            if ped_ok and obs_ok and spec[1] is None and tuple(ped_features.shape[:-2]) == tuple(obs_features.shape[:-2]):
-                # no mask on either branch (eval mode / p = 0): BOTH encoders in one launch per direction -- the row count
-                # of the many-rows kernels and of the one-pass backward instead of two few-rows launches
+            spec = None
+            if ped_ok and obs_ok and tuple(ped_features.shape[:-2]) == tuple(obs_features.shape[:-2]):
+                # BOTH encoders in one launch per direction -- the row count of the many-rows kernels and of the one-pass
+                # backward instead of two few-rows launches.  A launch applies one KIND of mask to all its
+                # branches: in train mode the obstacle branch's bits are drawn up front (ops.dropout_keep_bits, one small
+                # launch) and the pedestrian branch, whose raw output the corrector reads, gets an all-ones mask
                 from .. import ops
-                both = ops.fused_encoders([ped_branch, dict(x=obs_features, scale=spec[0], keep_bits=None, pooled=True,
+                rows_o = obs_features.numel() // obs_features.shape[-1]
+                scale_o, keep_o = self.obs_processor.fused_spec(rows_o, obs_features.device)
+                if keep_o is not None:
+                    rows_p = ped_features.numel() // ped_features.shape[-1]
+                    key = (rows_p, ped_features.device)
+                    if self._ones_bits is None or self._ones_bits[0] != key:
+                        self._ones_bits = (key, torch.full((rows_p, 4), -1, dtype=torch.int32, device=ped_features.device))
+                    ped_branch['keep_bits'] = self._ones_bits[1]
+                both = ops.fused_encoders([ped_branch, dict(x=obs_features, scale=scale_o, keep_bits=keep_o, pooled=True,
                                                             weights=[t for lin in self.obs_encoder.mlp[0::2] for t in (lin.weight, lin.bias)])])
                 encoded, pre['obs'] = both[0][0], both[1]
                 ped_ok = obs_ok = False
+            elif obs_ok:
+                spec = self._launch_specs([(self.obs_processor, obs_features)])[0]
             if ped_ok:
                 from .. import ops
                 encoded = ops.fused_encoders([ped_branch])[0][0]
