@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 20
+#define PIML_HIP_ABI_VERSION 21
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -233,6 +233,15 @@ int piml_collision_friends(float* coll, const float* base, int C, int T, int S_b
 /* n device-to-device copies (dst[i] <- src[i], bytes[i] bytes; the ranges of one pair do not overlap) in one launch per 24
  * pairs: the tensors of a training batch into the static inputs of the captured step (src/models/simulators.py:699-779). */
 int piml_multi_copy(void* const* dst, const void* const* src, const size_t* bytes, int n, void* stream);
+/* The prologue of the differentiable training rollout in one launch (src/models/simulators.py:672-697, :707): frame t_start of
+ * position / velocity / acceleration / destination (C, T, N, 2) and dest_idx (C, T, N) int64 copied out, new_flag =
+ * (long(mask_p - mask_p_pred) == 1) as bytes, mask_pred = long(mask_p_pred), gates[t] = (sum over (c, n) of mask_pred > 0) as
+ * bytes and as floats, speed = self_features[..., t_start, :, 6], *nan_flag = 0. */
+int piml_rollout_prologue(const float* position, const float* velocity, const float* acceleration, const float* destination,
+                          const long long* dest_idx, const float* mask_p, const float* mask_p_pred, const float* self_features,
+                          int C, int T, int N, int t_start, float* p0, float* v0, float* a0, float* d0, long long* di0,
+                          unsigned char* new_flag, long long* mask_pred, unsigned char* gates, float* gates_f, float* speed,
+                          int* nan_flag, void* stream);
 int piml_rollout_losses_blocks(int C, int N);
 int piml_rollout_losses(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
                         const unsigned char* gates, const float* collisions, const float* hard_collisions,

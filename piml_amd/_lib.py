@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 
@@ -107,6 +107,7 @@ SIGNATURES = {
     'piml_encoder_pack_floats': [],
     'piml_encoder_split_tiles': [_ll],
     'piml_multi_copy': [ctypes.POINTER(_p), ctypes.POINTER(_p), ctypes.POINTER(_z), _i, _p],
+    'piml_rollout_prologue': [_p] * 8 + [_i] * 4 + [_p] * 11 + [_p],
     'piml_rollout_losses_blocks': [_i, _i],
     'piml_rollout_losses': [_p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],

@@ -221,3 +221,85 @@ PIML_API int piml_multi_copy(void* const* dst, const void* const* src, const siz
     return hipGetLastError();
 }
 
+// ---- the prologue of the differentiable training rollout in ONE launch (src/models/simulators.py:672-697 of
+// test_multiple_rollouts_for_training: the clones of frame t_start, `new_peds_flag = (mask_p - mask_p_pred).long() == 1`,
+// `mask_p_pred.long()`, the per-frame gates `torch.sum(mask_p_pred[:, t]) > 0` of :707, the desired speeds) -- on torch
+// operators fourteen launches of a few KB each in front of every fine-tuning step.  One workgroup: the arrays are (C, T, N)
+// with C T N of a few thousand. ----
+namespace piml {
+struct PrologueArgs {
+    const float *position, *velocity, *acceleration, *destination;      // (C, T, N, 2)
+    const long long* dest_idx;                                            // (C, T, N)
+    const float *mask_p, *mask_p_pred;                                    // (C, T, N)
+    const float* self_features;                                           // (C, T, N, 7)
+    int C, T, N, t_start;
+    float *p0, *v0, *a0, *d0;                                             // (C, N, 2)
+    long long* di0;                                                       // (C, N)
+    unsigned char* new_flag;                                              // (C, T, N)
+    long long* mask_pred;                                                 // (C, T, N)
+    unsigned char* gates;                                                 // (T)
+    float* gates_f;                                                       // (T)
+    float* speed;                                                         // (C, N)
+    int* nan_flag;
+};
+__global__ __launch_bounds__(1024) void rollout_prologue_kernel(PrologueArgs A) {
+    __shared__ long long red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long CN = (long)A.C * A.N, CTN = CN * A.T;
+    for (long e = tid; e < CTN; e += 1024) {
+        const float mp = A.mask_p[e], mq = A.mask_p_pred[e];
+        A.new_flag[e] = (long long)(mp - mq) == 1 ? 1 : 0;
+        A.mask_pred[e] = (long long)mq;
+    }
+    for (long e = tid; e < CN; e += 1024) {
+        const long c = e / A.N, n = e - c * A.N;
+        const long src = (c * A.T + A.t_start) * A.N + n;
+        reinterpret_cast<float2*>(A.p0)[e] = reinterpret_cast<const float2*>(A.position)[src];
+        reinterpret_cast<float2*>(A.v0)[e] = reinterpret_cast<const float2*>(A.velocity)[src];
+        reinterpret_cast<float2*>(A.a0)[e] = reinterpret_cast<const float2*>(A.acceleration)[src];
+        reinterpret_cast<float2*>(A.d0)[e] = reinterpret_cast<const float2*>(A.destination)[src];
+        A.di0[e] = A.dest_idx[src];
+        A.speed[e] = A.self_features[src * 7 + 6];
+    }
+    if (tid == 0) *A.nan_flag = 0;
+    for (int t = 0; t < A.T; ++t) {                       // gate of frame t: sum over (c, n) of long(mask_p_pred) > 0
+        long long sum = 0;
+        for (long e = tid; e < CN; e += 1024) {
+            const long c = e / A.N, n = e - c * A.N;
+            sum += (long long)A.mask_p_pred[(c * A.T + t) * A.N + n];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)sum, o, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)sum >> 32), o, 64);
+            sum += (long long)(((unsigned long long)hi << 32) | lo);
+        }
+        __syncthreads();
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+            for (int w = 0; w < 16; ++w) tot += red[w];
+            A.gates[t] = tot > 0 ? 1 : 0;
+            A.gates_f[t] = tot > 0 ? 1.f : 0.f;
+        }
+    }
+}
+}  // namespace piml
+
+PIML_API int piml_rollout_prologue(const float* position, const float* velocity, const float* acceleration, const float* destination,
+                                   const long long* dest_idx, const float* mask_p, const float* mask_p_pred,
+                                   const float* self_features, int C, int T, int N, int t_start, float* p0, float* v0, float* a0,
+                                   float* d0, long long* di0, unsigned char* new_flag, long long* mask_pred, unsigned char* gates,
+                                   float* gates_f, float* speed, int* nan_flag, void* stream) {
+    if (C < 0 || T < 1 || N < 0 || t_start < 0 || t_start >= T) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    if (!position || !velocity || !acceleration || !destination || !dest_idx || !mask_p || !mask_p_pred || !self_features || !p0 ||
+        !v0 || !a0 || !d0 || !di0 || !new_flag || !mask_pred || !gates || !gates_f || !speed || !nan_flag)
+        return hipErrorInvalidValue;
+    piml::PrologueArgs A = {position, velocity, acceleration, destination, dest_idx, mask_p, mask_p_pred, self_features, C, T, N, t_start,
+                            p0, v0, a0, d0, di0, new_flag, mask_pred, gates, gates_f, speed, nan_flag};
+    hipLaunchKernelGGL(piml::rollout_prologue_kernel, dim3(1), dim3(1024), 0, piml::as_stream(stream), A);
+    return hipGetLastError();
+}
+

@@ -430,19 +430,30 @@ class BaseSimulator(Pedestrians):
         dt = data.time_unit
         waypoints, obstacles, dest_num = data.waypoints, data.obstacles, data.dest_num
         T = data.num_frames
-        mask_pred = data.mask_p_pred.long()                                   # c, t, n   (read only: no copies of it or of the labels)
         labels = data.labels
         thr = args.collision_threshold
 
         state = [data.ped_features[..., t_start, :, :, :], data.obs_features[..., t_start, :, :, :],
                  data.self_features[..., t_start, :, :]]
-        desired_speed = state[2][..., -1:]
-        a_cur = data.acceleration[..., t_start, :, :].clone()
-        v_cur = data.velocity[..., t_start, :, :].clone()
-        p_cur = data.position[..., t_start, :, :].clone()
-        dest_cur = data.destination[..., t_start, :, :].clone()
-        dest_idx = data.dest_idx[..., t_start, :].clone()
-        new_flag = (data.mask_p - data.mask_p_pred).long() == 1
+        # channelled (C, T, N, .) batches on the fused frame step: the clones of frame t_start, the new-pedestrian flags, the
+        # integer mask, the per-frame gates and the desired speeds in ONE launch (ops.rollout_prologue; fourteen otherwise)
+        pro = None
+        if self.fused_train_step and data.position.dim() == 4 and data.position.is_cuda and T == data.position.shape[1]:
+            pro = ops.rollout_prologue(data, t_start)
+        if pro is not None:
+            mask_pred = pro['mask_pred']
+            desired_speed = pro['speed']
+            a_cur, v_cur, p_cur, dest_cur, dest_idx = pro['a'], pro['v'], pro['p'], pro['dest'], pro['dest_idx']
+            new_flag = None
+        else:
+            mask_pred = data.mask_p_pred.long()                               # c, t, n   (read only: no copies of it or of the labels)
+            desired_speed = state[2][..., -1:]
+            a_cur = data.acceleration[..., t_start, :, :].clone()
+            v_cur = data.velocity[..., t_start, :, :].clone()
+            p_cur = data.position[..., t_start, :, :].clone()
+            dest_cur = data.destination[..., t_start, :, :].clone()
+            dest_idx = data.dest_idx[..., t_start, :].clone()
+            new_flag = (data.mask_p - data.mask_p_pred).long() == 1
 
         dev = p_cur.device
         p_steps, a_steps, cnt_steps, lab_steps = [], [], [], []
@@ -455,8 +466,11 @@ class BaseSimulator(Pedestrians):
         nan_seen = None                             # (the fused frame step keeps its own flag on the device)
         # `if torch.sum(mask) > 0` of every frame (:707), evaluated once for all frames: the per-frame records
         # below are gated after the loop in one pass instead of frame by frame
-        gates = mask_pred.sum(dim=(0, 2)) > 0                                 # (T,)
-        gates_f = gates.to(p_cur.dtype)
+        if pro is not None:
+            gates, gates_f = pro['gates'], pro['gates_f']
+        else:
+            gates = mask_pred.sum(dim=(0, 2)) > 0                             # (T,)
+            gates_f = gates.to(p_cur.dtype)
         need_label_counts = bool(args.new_collision_loss_flag)                # label collisions are only read there
         if need_label_counts:
             lab_frames = labels[..., :2].transpose(0, 1).contiguous()         # (T, C, N, 2): frame t is contiguous
@@ -465,11 +479,14 @@ class BaseSimulator(Pedestrians):
         if fused_step:
             series = tuple(x.contiguous() for x in (data.position, data.velocity, data.acceleration,
                                                     data.destination, data.dest_idx.long()))
-            new_flag_u8 = new_flag.contiguous().view(torch.uint8)
             dest_num_i64 = dest_num.long().to(dev).contiguous()
-            dest_idx = dest_idx.long()
-            nan_flag = torch.zeros((), device=dev, dtype=torch.int32)
-            speed_rows = desired_speed.contiguous()
+            if pro is not None:
+                new_flag_u8, nan_flag, speed_rows = pro['new_flag_u8'], pro['nan_flag'], pro['speed']
+            else:
+                new_flag_u8 = new_flag.contiguous().view(torch.uint8)
+                dest_idx = dest_idx.long()
+                nan_flag = torch.zeros((), device=dev, dtype=torch.int32)
+                speed_rows = desired_speed.contiguous()
 
         for t in range(t_start, T):
             predictions = self.model(*state)                                  # :701

@@ -640,6 +640,35 @@ def multi_copy(dsts, srcs):
         _lib.check(_lib.lib().piml_multi_copy(da, sa, ba, n, _stream()), 'piml_multi_copy')
 
 
+def rollout_prologue(data, t_start):
+    """The prologue of the differentiable training rollout in one launch (piml_rollout_prologue; src/models/simulators.py:672-697,
+    :707) or None when the batch is not the expected (C, T, N, .) float32 / int64 layout on the GPU (the caller then uses the
+    torch operators).  Returns dict(p, v, a, dest (C, N, 2), dest_idx (C, N) int64, new_flag_u8 (C, T, N) uint8, mask_pred
+    (C, T, N) int64, gates (T) bool, gates_f (T) float32, speed (C, N, 1), nan_flag () int32)."""
+    f32 = [data.position, data.velocity, data.acceleration, data.destination, data.mask_p, data.mask_p_pred, data.self_features]
+    if data.position.dim() != 4 or not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in f32) or \
+            data.dest_idx.dtype != torch.int64 or not data.dest_idx.is_contiguous() or not data.dest_idx.is_cuda or \
+            data.self_features.shape[-1] != 7 or tuple(data.mask_p.shape) != tuple(data.position.shape[:3]) or \
+            tuple(data.mask_p_pred.shape) != tuple(data.position.shape[:3]) or tuple(data.dest_idx.shape) != tuple(data.position.shape[:3]):
+        return None
+    C, T, N = data.position.shape[:3]
+    dev = data.position.device
+    opt = dict(device=dev, dtype=torch.float32)
+    out = dict(p=torch.empty(C, N, 2, **opt), v=torch.empty(C, N, 2, **opt), a=torch.empty(C, N, 2, **opt),
+               dest=torch.empty(C, N, 2, **opt), dest_idx=torch.empty(C, N, device=dev, dtype=torch.int64),
+               new_flag_u8=torch.empty(C, T, N, device=dev, dtype=torch.uint8),
+               mask_pred=torch.empty(C, T, N, device=dev, dtype=torch.int64), gates=torch.empty(T, device=dev, dtype=torch.bool),
+               gates_f=torch.empty(T, **opt), speed=torch.empty(C, N, 1, **opt), nan_flag=torch.empty((), device=dev, dtype=torch.int32))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().piml_rollout_prologue(
+            _ptr(data.position), _ptr(data.velocity), _ptr(data.acceleration), _ptr(data.destination), _ptr(data.dest_idx),
+            _ptr(data.mask_p), _ptr(data.mask_p_pred), _ptr(data.self_features), C, T, N, int(t_start),
+            _ptr(out['p']), _ptr(out['v']), _ptr(out['a']), _ptr(out['dest']), _ptr(out['dest_idx']), _ptr(out['new_flag_u8']),
+            _ptr(out['mask_pred']), _ptr(out['gates']), _ptr(out['gates_f']), _ptr(out['speed']), _ptr(out['nan_flag']), _stream()),
+            'piml_rollout_prologue')
+    return out
+
+
 class _RolloutLosses(torch.autograd.Function):
     """piml_rollout_losses / piml_rollout_losses_bwd (include/piml_hip.h): the three loss sums of the fine-tuning rollout and
     their gradient with respect to the predicted positions."""
