@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 21
+#define PIML_HIP_ABI_VERSION 22
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -93,13 +93,14 @@ int piml_relfeat_fwd_tick(const float* position, const float* heading, const flo
                           void* stream);
 /* piml_relfeat_fwd / piml_relfeat_bwd with the model's self_features rows [dest - p, v, a, v0] (C, n, 7) in place of the
  * destination features: the per-frame torch.cat of the training rollout (src/models/simulators.py:778-779) inside the launch.
- * desired_speed (C, n).  bwd: g_self (C, n, 7); ACCUMULATES into g_state (C, N, 6) = d/d(p, v, a) (cleared by the caller);
+ * desired_speed (C, n); g_state_zero (C, N, 6; may be NULL): cleared by the forward launch for the backward to accumulate into.
+ * bwd: g_self (C, n, 7); ACCUMULATES into g_state (C, N, 6) = d/d(p, v, a) (cleared by the caller / by the forward);
  * writes g_destination (C, n, 2) and g_speed (C, n; may be NULL). */
 int piml_relfeat_fwd_self(const float* position, const float* heading, const float* velocity, const float* acceleration,
                           int state_ld, const float* destination, const float* obstacles, const float* desired_speed, int C,
                           int N, int M, int focal_begin, int focal_count, int topk_ped, int topk_obs, float cos_thr_ped,
                           float cos_thr_obs, float dist_thr_ped, float dist_thr_obs, float* ped_feat, float* obs_feat,
-                          float* self_features, int32_t* ped_idx, int32_t* obs_idx, void* stream);
+                          float* self_features, int32_t* ped_idx, int32_t* obs_idx, float* g_state_zero, void* stream);
 int piml_relfeat_bwd_self(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int32_t* ped_idx,
                           const int32_t* obs_idx, const float* position, int state_ld, const float* destination, int C, int N,
                           int focal_begin, int focal_count, int kp_eff, int ko_eff, float* g_state, float* g_destination,
@@ -346,6 +347,14 @@ int piml_train_step_fwd(const float* position, const float* velocity, const floa
 int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
                         const uint8_t* new_flag, const uint8_t* zero_mask, int C, int T, int N, int t_next, float dt,
                         float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
+/* piml_train_step_bwd with a second source of d/d(outputs): g_state6 (C, N, 6; may be NULL) = d/d(p', v', a') interleaved, as
+ * piml_relfeat_bwd_self leaves it, is ADDED to the three separate gradients (each may be NULL) before the frame's backward --
+ * the two consumers of a frame's state (the next frame's step and its features) without a gradient accumulation in between. */
+int piml_train_step_bwd6(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
+                         const float* g_state6, const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T, int N,
+                         int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred,
+                         void* stream);
+
 
 /*
  * Glue of the PINNSF network around its (PyTorch-ROCm / rocBLAS) GEMMs -- SURVEY.md row a8:

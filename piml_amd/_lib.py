@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     'piml_collision_correction_bwd': [_p, _p, _p, _p, _z, _i, _i, _f, _f, _p, _p, _p, _p],
     'piml_train_step_fwd': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     'piml_train_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
+    'piml_train_step_bwd6': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_bwd': [_p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_ksum_fwd': [_p, _i, _p, _i, _p, _z, _f, _p, _p],
@@ -163,7 +164,7 @@ SIGNATURES = {
     'piml_allgather_state': [_p, _p, _z, _p, _p],
     'piml_reducescatter_grad': [_p, _p, _p, _z, _p],
     'piml_allreduce_sum': [_p, _p, _z, _p],
-    'piml_relfeat_fwd_self': [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p],
+    'piml_relfeat_fwd_self': [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_relfeat_bwd_self': [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     'piml_relfeat_fwd_tick': [_p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f,
                               _p, _p, _p, _i, _p, _p, _p, _p],

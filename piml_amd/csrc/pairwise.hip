@@ -1172,7 +1172,8 @@ __global__ void train_step_fwd_kernel(const TrainStepArgs A) {
 // keep = agent not re-initialised at t_next:  g_p = keep g_p',  g_v = keep (g_v' + dt g_p'),
 // g_a = keep dt g_v',  g_a_pred = keep g_a'.
 __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
-                                      const float2* __restrict__ ga_o, const unsigned char* __restrict__ new_flag,
+                                      const float2* __restrict__ ga_o, const float2* __restrict__ g6,
+                                      const unsigned char* __restrict__ new_flag,
                                       const unsigned char* __restrict__ zero_mask, int C, int T, int N, int t_next,
                                       float dt, float2* __restrict__ gp,
                                       float2* __restrict__ gv, float2* __restrict__ ga,
@@ -1183,8 +1184,12 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
     bool keep = true;
     if (new_flag && t_next < T) keep = new_flag[((size_t)c * T + t_next) * N + i] == 0;
     const float2 z = make_float2(0.f, 0.f);
-    const float2 a = (keep && gp_o) ? gp_o[g] : z;
+    float2 a = (keep && gp_o) ? gp_o[g] : z;
     float2 b = (keep && gv_o) ? gv_o[g] : z, e = (keep && ga_o) ? ga_o[g] : z;
+    if (keep && g6) {        // the features' share of d/d(p', v', a'), interleaved (C, N, 6)
+        const float2 q0 = g6[3 * g], q1 = g6[3 * g + 1], q2 = g6[3 * g + 2];
+        a.x += q0.x; a.y += q0.y; b.x += q1.x; b.y += q1.y; e.x += q2.x; e.y += q2.y;
+    }
     if (zero_mask) {         // components that were NaN and zeroed in the forward pass pass no gradient
         const unsigned m = zero_mask[g];
         if (m & 1u) b.x = 0.f;
@@ -1435,8 +1440,22 @@ PIML_API int piml_train_step_bwd(const float* g_position_out, const float* g_vel
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::train_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
-                       (const float2*)g_acceleration_out, new_flag, zero_mask, C, T, N, t_next, dt, (float2*)g_position,
-                       (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
+                       (const float2*)g_acceleration_out, (const float2*)nullptr, new_flag, zero_mask, C, T, N, t_next, dt,
+                       (float2*)g_position, (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
+    return hipGetLastError();
+}
+
+PIML_API int piml_train_step_bwd6(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
+                                  const float* g_state6, const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T,
+                                  int N, int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration,
+                                  float* g_a_pred, void* stream) {
+    if (C < 0 || N < 0 || T < 0) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::train_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
+                       (const float2*)g_acceleration_out, (const float2*)g_state6, new_flag, zero_mask, C, T, N, t_next, dt,
+                       (float2*)g_position, (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
     return hipGetLastError();
 }
 

@@ -676,17 +676,18 @@ PIML_API int piml_relfeat_fwd(const float* position, const float* heading, const
 
 // piml_relfeat_fwd whose third output is the model's self_features rows [dest - p, v, a, v0] (C, n, 7) instead of the
 // destination features (C, n, 2): the per-frame torch.cat of the training rollout (src/models/simulators.py:778-779) inside
-// the launch.  desired_speed (C, n): v0 of the focal rows.
+// the launch.  desired_speed (C, n): v0 of the focal rows.  g_state_zero (C * N * 6 floats, may be NULL) is cleared on the way
+// for piml_relfeat_bwd_self to accumulate into.
 PIML_API int piml_relfeat_fwd_self(const float* position, const float* heading, const float* velocity,
                                    const float* acceleration, int state_ld, const float* destination, const float* obstacles,
                                    const float* desired_speed, int C, int N, int M, int focal_begin, int focal_count,
                                    int topk_ped, int topk_obs, float cos_thr_ped, float cos_thr_obs, float dist_thr_ped,
                                    float dist_thr_obs, float* ped_feat, float* obs_feat, float* self_features, int32_t* ped_idx,
-                                   int32_t* obs_idx, void* stream) {
+                                   int32_t* obs_idx, float* g_state_zero, void* stream) {
     if (C > 0 && focal_count > 0 && (!desired_speed || !self_features)) return hipErrorInvalidValue;
     return relfeat_launch(position, heading, velocity, acceleration, state_ld, destination, obstacles, C, N, M, focal_begin,
                           focal_count, topk_ped, topk_obs, cos_thr_ped, cos_thr_obs, dist_thr_ped, dist_thr_obs, ped_feat,
-                          obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, nullptr, 0, stream);
+                          obs_feat, self_features, 7, ped_idx, obs_idx, desired_speed, g_state_zero, (long)C * N * 6, stream);
 }
 
 // Backward of piml_relfeat_fwd_self: g_self (C, n, 7) carries d/d(dest_feat) in columns 0-1, d/d(v, a) of the focal rows in

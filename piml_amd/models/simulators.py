@@ -507,10 +507,12 @@ class BaseSimulator(Pedestrians):
 
             a_next = predictions[0]
             if fused_step:
-                # :741-769 as one differentiable launch (integrator, waypoint switch, injection, NaN flag)
-                p_cur, v_cur, a_cur, dest_cur, dest_idx = ops.train_rollout_step(
-                    p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt,
-                    new_flag=new_flag_u8, series=series, t_next=t + 1, nan_flag=nan_flag, zero_nan=True)
+                # :741-769 as one differentiable launch (integrator, waypoint switch, injection, NaN flag) and :772-779 (the
+                # features of the new state incl. the self_features rows) as a second, both inside ONE autograd node
+                p_cur, v_cur, a_cur, dest_cur, dest_idx, *state = ops.rollout_frame(
+                    p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt, new_flag_u8, series, t + 1,
+                    nan_flag, obstacles, speed_rows, args.topk_ped, args.sight_angle_ped, args.dist_threshold_ped,
+                    args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs)
             else:
                 nan_seen = a_next.isnan().any() if nan_seen is None else (nan_seen | a_next.isnan().any())
                 v_next = v_cur + a_cur * dt                                   # :741-743
@@ -530,12 +532,7 @@ class BaseSimulator(Pedestrians):
                     dest_cur = self._inject(new, dest_cur, data.destination[..., t + 1, :, :])
                     dest_idx = self._inject(new, dest_idx, data.dest_idx[..., t + 1, :])
 
-            if fused_step:    # v, a are already NaN-free (zero_nan): the operator itself, without the in-place fills,
-                # and the self_features rows of :778-779 written by the same launch (no torch.cat per frame)
-                state = list(ops.relative_features_self(
-                    p_cur, v_cur, a_cur, dest_cur, obstacles, speed_rows, args.topk_ped, args.sight_angle_ped,
-                    args.dist_threshold_ped, args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs))
-            else:
+            if not fused_step:
                 pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)   # :772-776, differentiable
                 state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]  # :778-779
 

@@ -198,7 +198,7 @@ class _RelativeFeaturesSelf(torch.autograd.Function):
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().piml_relfeat_fwd_self(
                 _ptr(p), None, _ptr(v), _ptr(a), 2, _ptr(d), _ptr(o), _ptr(v0), C, N, M, 0, N, kp, ko, cos_p, cos_o, dthr_p, dthr_o,
-                _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), _stream()), 'piml_relfeat_fwd_self')
+                _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), None, _stream()), 'piml_relfeat_fwd_self')
         ctx.save_for_backward(pi, oi, p, d)
         ctx.geom = (C, N, kpe, koe, lead, tuple(desired_speed.shape))
         ctx.mark_non_differentiable(pi, oi)
@@ -1495,6 +1495,127 @@ def train_rollout_step(position, velocity, acceleration, a_pred, destination, de
     return _TrainRolloutStep.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(),
                                    waypoints.contiguous(), dest_num.contiguous(), new_flag, series, int(t_next),
                                    float(dt), nan_flag, bool(zero_nan))
+
+
+class _RolloutFrame(torch.autograd.Function):
+    """One frame of the fine-tuning rollout between two model calls as ONE autograd node: _TrainRolloutStep (integrator,
+    waypoint switch, injection, NaN -> 0; src/models/simulators.py:741-769) followed by _RelativeFeaturesSelf on its outputs
+    (:772-779).  The new state feeds both the next frame's step and this frame's features; as two nodes autograd sums the two
+    gradients per tensor (three strided additions per frame) -- here the features' backward accumulates into a (C, N, 6)
+    buffer its forward launch cleared and the step's backward adds that buffer to the gradients it is handed
+    (piml_train_step_bwd6): two launches per frame and direction, nothing else."""
+
+    @staticmethod
+    def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag,
+                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o):
+        L = _lib.lib()
+        p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
+                                 (('position', p), ('velocity', v), ('acceleration', a), ('a_pred', a_pred), ('destination', dest))]
+        o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
+        v0 = _gpu_f32('desired_speed', speed)
+        C, N = p.shape[0], p.shape[1]
+        D = waypoints.shape[-3]
+        per_slice = int(waypoints.dim() == 4)
+        T = series[0].shape[1] if series is not None else max(int(t_next), 1)
+        dev = p.device
+        opt = dict(device=dev, dtype=torch.float32)
+        outs = [torch.empty(C, N, 2, **opt) for _ in range(4)]
+        idx_out = torch.empty(C, N, device=dev, dtype=torch.int64)
+        sp = [None] * 5 if series is None else [_ptr(x) for x in series]
+        zero_mask = torch.empty(C, N, device=dev, dtype=torch.uint8)
+        M = o.shape[0]
+        kpe, koe = min(kp, N), min(ko, M)
+        pf, of, sf = torch.empty(C, N, kpe, 6, **opt), torch.empty(C, N, koe, 6, **opt), torch.empty(C, N, 7, **opt)
+        pi = torch.empty(C, N, kpe, device=dev, dtype=torch.int32)
+        oi = torch.empty(C, N, koe, device=dev, dtype=torch.int32)
+        need = any(ctx.needs_input_grad[:4])
+        g6 = torch.empty(C, N, 6, **opt) if need else None
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_train_step_fwd(
+                _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
+                _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
+                float(dt), *[_ptr(x) for x in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
+                _ptr(zero_mask), _stream()), 'piml_train_step_fwd')
+            _lib.check(L.piml_relfeat_fwd_self(
+                _ptr(outs[0]), None, _ptr(outs[1]), _ptr(outs[2]), 2, _ptr(outs[3]), _ptr(o), _ptr(v0), C, N, M, 0, N, kp, ko,
+                cos_p, cos_o, dthr_p, dthr_o, _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), _ptr(g6), _stream()),
+                'piml_relfeat_fwd_self')
+        ctx.save_for_backward(pi, oi, outs[0], outs[3])
+        ctx.new_flag, ctx.zero_mask, ctx.geom, ctx.g6 = new_flag, zero_mask, (C, T, N, int(t_next), float(dt), kpe, koe), g6
+        ctx.mark_non_differentiable(outs[3], idx_out)
+        ctx.set_materialize_grads(False)
+        return (*outs, idx_out, pf, of, sf)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gp_o, gv_o, ga_o, _gd, _gi, g_pf, g_of, g_sf):
+        C, T, N, t_next, dt, kpe, koe = ctx.geom
+        feats = any(g is not None for g in (g_pf, g_of, g_sf))
+        if not feats and all(g is None for g in (gp_o, gv_o, ga_o)):
+            return (None,) * 21
+        pi, oi, p_out, dest_out = ctx.saved_tensors
+        dev = p_out.device
+        opt = dict(device=dev, dtype=torch.float32)
+        L = _lib.lib()
+        g6 = None
+        with torch.cuda.device(dev):
+            if feats:
+                g6, ctx.g6 = ctx.g6, None                      # the forward's cleared buffer, once; a second pass clears a fresh one
+                if g6 is None:
+                    g6 = torch.zeros(C, N, 6, **opt)
+
+                def dense(g, shape):
+                    return torch.zeros(shape, **opt) if g is None else _gpu_f32('grad', g)
+                g_pf, g_of, g_sf = dense(g_pf, (C, N, kpe, 6)), dense(g_of, (C, N, koe, 6)), dense(g_sf, (C, N, 7))
+                g_dest = torch.empty(C, N, 2, **opt)           # (the step's destination output carries no gradient)
+                _lib.check(L.piml_relfeat_bwd_self(
+                    _ptr(g_pf), _ptr(g_of), _ptr(g_sf), _ptr(pi), _ptr(oi), _ptr(p_out), 2, _ptr(dest_out), C, N, 0, N, kpe, koe,
+                    _ptr(g6), _ptr(g_dest), None, _stream()), 'piml_relfeat_bwd_self')
+            need = ctx.needs_input_grad
+            # an input whose gradient is identically zero gets None (not zeros): autograd then does not walk into the model
+            # call that produced a_pred just to propagate nothing (g_p = g_p', g_v = g_v' + dt g_p', g_a = dt g_v', g_a_pred = g_a')
+            hp, hv, ha = (gp_o is not None or feats), (gv_o is not None or feats), (ga_o is not None or feats)
+            live = (hp, hp or hv, hv, ha)
+            gs = [torch.empty(C, N, 2, **opt) if (need[k] and live[k]) else None for k in range(4)]
+            cont = [None if g is None else _gpu_f32('grad', g) for g in (gp_o, gv_o, ga_o)]
+            _lib.check(L.piml_train_step_bwd6(
+                *[_ptr(g) for g in cont], _ptr(g6), _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
+                _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd6')
+        return (*gs,) + (None,) * 17
+
+
+def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt, new_flag, series,
+                  t_next, nan_flag, obstacles, desired_speed, topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
+                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4):
+    """train_rollout_step(..., zero_nan=True) + relative_features_self on its result as one autograd node (_RolloutFrame).
+    Returns (position', velocity', acceleration', destination', dest_idx', ped_features, obs_features, self_features)."""
+    if position.dim() != 3 or position.shape[-1] != 2 or not position.is_cuda:
+        raise ValueError('rollout_frame: (C, N, 2) GPU state expected')
+    if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
+        raise ValueError(f'topk must be <= {MAX_TOPK}')
+    if DETERMINISTIC_BWD:        # the atomics-free feature backward exists for the plain operator only
+        st = train_rollout_step(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt,
+                                new_flag=new_flag, series=series, t_next=t_next, nan_flag=nan_flag, zero_nan=True)
+        return (*st, *relative_features_self(st[0], st[1], st[2], st[3], obstacles, desired_speed, topk_ped, sight_angle_ped,
+                                             dist_threshold_ped, topk_obs, sight_angle_obs, dist_threshold_obs))
+    C, N = position.shape[0], position.shape[1]
+    if dest_idx.dtype != torch.int64 or dest_num.dtype != torch.int64 or tuple(dest_idx.shape) != (C, N) or dest_num.numel() != N:
+        raise ValueError('rollout_frame: dest_idx (C, N) int64 and dest_num (N) int64 expected')
+    if new_flag is not None:
+        if new_flag.dtype == torch.bool:
+            new_flag = new_flag.view(torch.uint8)
+        T = series[0].shape[1]
+        if new_flag.dtype != torch.uint8 or tuple(new_flag.shape) != (C, T, N) or not new_flag.is_contiguous():
+            raise ValueError('rollout_frame: new_flag must be contiguous (C, T, N) bool / uint8')
+        for x, w, dt_ in zip(series, (2, 2, 2, 2, None), (torch.float32,) * 4 + (torch.int64,)):
+            if tuple(x.shape) != (C, T, N) + ((w,) if w else ()) or x.dtype != dt_ or not x.is_contiguous():
+                raise ValueError('rollout_frame: series tensors must be contiguous (C, T, N[, 2]) float32 / int64')
+    else:
+        series = None
+    return _RolloutFrame.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(), waypoints.contiguous(),
+                               dest_num.contiguous(), new_flag, series, int(t_next), float(dt), nan_flag, obstacles, desired_speed,
+                               int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
+                               float(dist_threshold_ped), float(dist_threshold_obs))
 
 
 class _CollisionCorrection(torch.autograd.Function):
