@@ -652,6 +652,8 @@ def rollout_prologue(data, t_start):
             tuple(data.mask_p_pred.shape) != tuple(data.position.shape[:3]) or tuple(data.dest_idx.shape) != tuple(data.position.shape[:3]):
         return None
     C, T, N = data.position.shape[:3]
+    if C * T * N > (1 << 20) or not 0 <= int(t_start) < T:      # one workgroup walks the arrays: training windows, not clips
+        return None
     dev = data.position.device
     opt = dict(device=dev, dtype=torch.float32)
     out = dict(p=torch.empty(C, N, 2, **opt), v=torch.empty(C, N, 2, **opt), a=torch.empty(C, N, 2, **opt),

@@ -130,3 +130,59 @@ def test_multi_copy_one_launch_for_a_batch_of_tensors():
     a, b = torch.rand(8, 8).cuda(), torch.zeros(8, 8).cuda()
     ops.multi_copy([b.t()], [a.t()])
     assert torch.equal(a, b)
+
+
+def test_rollout_prologue_and_frame_node_equal_the_torch_expressions():
+    """ops.rollout_prologue (piml_rollout_prologue) against the statements it replaces (src/models/simulators.py:672-697, :707),
+    and ops.rollout_frame (one autograd node: frame step + features of its result) against the two-operator composition:
+    outputs bit-equal, gradients equal up to the order of the float atomics."""
+    import types
+    from piml_amd import ops
+    from piml_amd.scenes import synthetic_gc_scene
+    g = torch.Generator().manual_seed(9)
+    C, T, N, M = 3, 5, 97, 60
+    sc = synthetic_gc_scene(N, M, seed=2, channels=C * T)
+    f = lambda k: torch.tensor(sc[k], device='cuda').view(C, T, N, -1).contiguous()
+    data = types.SimpleNamespace(position=f('position'), velocity=f('velocity'), acceleration=f('acceleration'), destination=f('destination'))
+    data.dest_idx = torch.randint(0, 3, (C, T, N), generator=g).cuda()
+    data.mask_p = (torch.rand(C, T, N, generator=g) > 0.3).float().cuda()
+    data.mask_p_pred = (data.mask_p * (torch.rand(C, T, N, generator=g) > 0.4).float().cuda()).contiguous()
+    data.mask_p_pred[:, 3] = 0                      # a frame nobody is predicted in: its gate is closed
+    data.self_features = torch.randn(C, T, N, 7, generator=g).cuda()
+    for t0 in (0, 2):
+        pro = ops.rollout_prologue(data, t0)
+        assert pro is not None
+        assert torch.equal(pro['mask_pred'], data.mask_p_pred.long())
+        assert torch.equal(pro['new_flag_u8'].bool(), (data.mask_p - data.mask_p_pred).long() == 1)
+        gates = data.mask_p_pred.long().sum(dim=(0, 2)) > 0
+        assert torch.equal(pro['gates'], gates) and torch.equal(pro['gates_f'], gates.float()) and int(pro['nan_flag']) == 0
+        for k, src in (('p', data.position), ('v', data.velocity), ('a', data.acceleration), ('dest', data.destination)):
+            a, b = pro[k], src[:, t0]
+            assert torch.equal(a.isnan(), b.isnan()) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        assert torch.equal(pro['dest_idx'], data.dest_idx[:, t0]) and torch.equal(pro['speed'], data.self_features[:, t0, :, 6:])
+    # the frame node
+    pro = ops.rollout_prologue(data, 0)
+    obstacles = torch.tensor(sc['obstacles'], device='cuda')
+    waypoints = torch.rand(4, N, 2, generator=g).cuda() * 30
+    dest_num = torch.full((N,), 4, dtype=torch.int64, device='cuda')
+    series = (data.position, data.velocity, data.acceleration, data.destination, data.dest_idx)
+    res = []
+    for fused in (True, False):
+        leaves = [torch.nan_to_num(pro[k]).clone().requires_grad_(True) for k in ('p', 'v', 'a')]
+        a_pred = torch.randn(C, N, 2, generator=torch.Generator().manual_seed(4)).cuda().requires_grad_(True)
+        nan_flag = torch.zeros((), dtype=torch.int32, device='cuda')
+        if fused:
+            out = ops.rollout_frame(*leaves, a_pred, pro['dest'], pro['dest_idx'], waypoints, dest_num, 0.08, pro['new_flag_u8'], series, 1,
+                                    nan_flag, obstacles, pro['speed'])
+        else:
+            st = ops.train_rollout_step(*leaves, a_pred, pro['dest'], pro['dest_idx'], waypoints, dest_num, 0.08, new_flag=pro['new_flag_u8'],
+                                        series=series, t_next=1, nan_flag=nan_flag, zero_nan=True)
+            out = (*st, *ops.relative_features_self(st[0], st[1], st[2], st[3], obstacles, pro['speed']))
+        ws = [torch.randn(o.shape, generator=torch.Generator().manual_seed(20 + i)).cuda() for i, o in enumerate(out)]
+        loss = sum((torch.nan_to_num(o) * w).sum() for o, w in zip(out, ws) if o.dtype == torch.float32 and o.requires_grad)
+        grads = torch.autograd.grad(loss, leaves + [a_pred])
+        res.append((out, grads))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
