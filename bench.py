@@ -726,21 +726,25 @@ def main():
     x3_products = bool(_lib.lib().piml_encoder_products(-1))      # split bf16 products (default) or PIML_ENC_PRODUCTS=f32
     cal_timer = _lib.StreamTimer()
     ev_pairs, sample_timers = [], []
-    # One sample per ten timed steps (1 .. 5).  A sample is ONE extra eager launch of the relfeat forward kernel (same inputs,
-    # same output buffers) right behind a replayed step, bracketed by two HIP events: the kernel runs behind other
-    # kernels, not behind an idle gap, and the cost of the two event records (measured by an empty pair) is subtracted.
-    # The events are only READ after the timed region (reading one synchronises the stream): a sample costs the timed
-    # region one ~22 us launch and nothing else.
+    # The TIMED region holds exactly --steps replays of the step and nothing else (round 4: until then it also held one sample
+    # per ten steps -- four event records and an extra relfeat launch each, 2.5 - 4 % of a 20-step region, measured by leaving
+    # them out: 0.159 / 0.162 / 0.157 ms/step with, 0.1545 / 0.1558 / 0.1534 without on one box).  The live time of the relfeat
+    # forward kernel is sampled right BEHIND the region, in the same stream of replays: five further replays, each followed by
+    # ONE extra eager launch of the kernel (same inputs, same output buffers) bracketed by two HIP events -- it runs behind
+    # other kernels, not behind an idle gap -- and the cost of the two event records (an empty pair) is subtracted.  The region
+    # itself is also bracketed by two HIP events on the stream (`roofline.timed_region_event_ms`).
     TIMED_LAUNCHES = 1
-    n_samples = max(1, min(5, args.steps // 10))       # one per ten steps: a sample costs the timed region one ~22 us launch (1 %)
-    # (in the MIDDLE of each tenth: the sample behind the region's first replay measured a whole step's length more than the
-    # others -- 0.13-0.21 ms against 0.024-0.027 -- in every run; the queue in front of it is empty at that point)
-    sample_at = {min(args.steps - 1, int((i + 0.5) * args.steps / n_samples)) for i in range(n_samples)}
+    n_samples = 5
+    # (not behind the first replay of a burst: that sample measured a whole step's length more than the others -- 0.13-0.21 ms
+    # against 0.024-0.027 -- in every run; the queue in front of it is empty at that point)
+    sample_at = set(range(n_samples)) if graph is not None else \
+        {min(args.steps - 1, int((i + 0.5) * args.steps / max(1, min(5, args.steps // 10)))) for i in range(max(1, min(5, args.steps // 10)))}
     timer_pool = [(_lib.StreamTimer(), _lib.StreamTimer()) for _ in range(n_samples)] if graph is not None else []   # events are made HERE, not in the timed region
+    region_timer = _lib.StreamTimer()
 
     def run_step(i, timed):
         if graph is not None:
-            sample = timed and i in sample_at
+            sample = timed == 'sample' and i in sample_at
             if use_dist:
                 st.exchange_forward()
             if st.pre is not None:
@@ -788,11 +792,18 @@ def main():
     st.barrier()
     _phase('warmup done')
     t0 = time.perf_counter()
+    region_timer.start()
     for i in range(args.steps):
         run_step(i, True)
+    region_timer.stop()
     st.barrier()
     elapsed = time.perf_counter() - t0
     _phase('timed region done')
+    region_event_ms = region_timer.elapsed_ms()
+    if graph is not None:           # the relfeat samples, behind the region (see above); two unsampled replays lead the burst
+        for i in range(-2, n_samples):
+            run_step(i, 'sample')
+        st.barrier()
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -897,8 +908,9 @@ def main():
 
     if True:      # (every rank assembles the line; rank 0 writes it)
         kernels = [{'name': 'relfeat_fwd_kernel', 'us': kernel_ms * 1e3, 'share_of_step': kernel_ms / ms_per_step,
-                    'us_source': f'live: HIP events inside the timed region, {len(kernel_ms_samples)} samples x '
-                                 f'{launches_per_sample} launches, median, event-pair overhead subtracted',
+                    'us_source': f'live: HIP events around {len(kernel_ms_samples)} x {launches_per_sample} eager re-launches, each behind a '
+                                 'replay of the step, queued right behind the timed region (which holds the --steps replays and '
+                                 'nothing else); median, event-pair overhead subtracted',
                     'us_stage_trace': stage_us.get('relfeat_fwd'),
                     'bound': 'valu', 'frac': (prof or {}).get('relfeat_fwd_kernel', {}).get('valu_busy_frac'),
                     'frac_source': ('SQ_ACTIVE_INST_VALU share of the SIMD cycles, ' + prof_src) if prof else None,
@@ -955,6 +967,9 @@ def main():
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
+                         'timed_region_event_ms': region_event_ms,
+                         'timed_region_event_note': 'HIP events on the launch stream around the --steps replays of the timed region '
+                                                    '(max over ranks of the wall clock between the barriers is what `value` uses)',
                          'traffic': (prof or {}).get('step_hbm_bytes'),
                          'algorithmic_bytes': bytes_step,
                          'definition': 'SURVEY.md 8d step-level contract: operand-stream bytes of one step (24 B/ped pair + '
