@@ -367,7 +367,7 @@ class Step:
 
     def step_body(self, timer=None):
         """One forward + backward pass of the hot path over the scene, eagerly."""
-        with self.model.packed_weights():     # weight packs on a side stream, hidden behind the neighbour search
+        with self.model.packed_weights():     # the weight pack rides as trailing workgroups of the relfeat forward launch (PIML_DEFER_PACK)
             if timer is not None:
                 timer.start()
             feats = self.features()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 22
+#define PIML_HIP_ABI_VERSION 23
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -757,6 +757,12 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
                                   -- at piml_pinnsf_slot_sums_flush / at the next deferring piml_pinnsf_bwd.  Until then the
                                   branches' `grads` are NOT valid: for callers that know a relfeat backward follows (the step of
                                   src/models/simulators.py:699-779: network backward, then the features' backward); not with PIML_FORK */
+#define PIML_DEFER_PACK 16 /* piml_pinnsf_pack: do NOT launch; the next relfeat FORWARD launch on the same stream (piml_relfeat_self_fwd,
+                              piml_relfeat_self_fwd_part, piml_relfeat_fwd_self) runs the pack as its trailing workgroups -- the
+                              pack depends on the weights only and is a ~4 us launch in front of the step's chain by itself.
+                              Whichever comes first: every consumer of packed images (piml_pinnsf_fwd, piml_encoder_fwd_packed,
+                              piml_rowdecoder_fwd_packed) and piml_pinnsf_pack_flush launch a pack that is still waiting */
+int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */
 int piml_pinnsf_streams_init(void);
 int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,

@@ -13,6 +13,7 @@
 
 #include "common.hpp"
 #include "pack.hpp"
+#include "reduce.hpp"
 #include "stages.hpp"
 #include "x3.hpp"
 #include "../../include/piml_hip.h"
@@ -1358,7 +1359,10 @@ static int rowdec_fill(DecArgs& A, const piml_decoder_branch* br, int nbr, bool 
 static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, void* stream);
 PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, true, stream); }
 // `packed` already holds the operand images of these weights (piml_pinnsf_pack / an earlier piml_rowdecoder_fwd)
-PIML_API int piml_rowdecoder_fwd_packed(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, false, stream); }
+PIML_API int piml_rowdecoder_fwd_packed(const piml_decoder_branch* br, int nbr, void* stream) {
+    if (int e = pending_pack_flush()) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
+    return rowdecoder_fwd(br, nbr, false, stream);
+}
 
 static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, void* stream) {
     hipStream_t s = as_stream(stream);

@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "encoder.hpp"
 #include "pack.hpp"
+#include "reduce.hpp"
 #include "philox.hpp"
 #include "stages.hpp"
 #include "../../include/piml_hip.h"
@@ -1157,6 +1158,7 @@ PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stre
 
 // `packed` already holds the operand images of these weights (piml_encoder_pack / piml_pinnsf_pack)
 PIML_API int piml_encoder_fwd_packed(const piml_encoder_branch* br, int nbr, void* stream) {
+    if (int e = pending_pack_flush()) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
     return enc_stage_fwd(br, nbr, as_stream(stream));
 }
 

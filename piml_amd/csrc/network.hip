@@ -79,26 +79,13 @@ int edge(hipStream_t from, hipStream_t to, hipEvent_t ev) {
 
 }  // namespace
 
-// ---- one launch for every weight image of the network: blockIdx.y = encoder branches, decoder branches, head ----
-struct PackAll {
-    piml_encoder_branch enc[2];
-    piml_decoder_branch dec[2];
-    piml_collision_head head;
-    int nbr, has_head;
-};
+// ---- one launch for every weight image of the network: blockIdx.y = encoder branches, decoder branches, head (reduce.hpp) ----
+__global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) { pack_element(A, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x)); }
 
-__global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (y < A.nbr) {
-        const piml_encoder_branch& J = A.enc[y];
-        if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
-    } else if (y < 2 * A.nbr) {
-        const piml_decoder_branch& J = A.dec[y - A.nbr];
-        if (e < DEC_PACK) J.packed[e] = dec_pack_value(J, e);
-    } else if (e < HEAD_PACK) {
-        A.head.packed[e] = head_pack_value(A.head.w1, A.head.b1, A.head.w2, A.head.b2, e);
-    }
+int launch_pack(const PackAll& A, hipStream_t s) {
+    hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((kPackMax + 255) / 256, 2 * A.nbr + (A.has_head ? 1 : 0)), dim3(256), 0, s, A);
+    trace_mark("pinnsf_pack", s);
+    return hipGetLastError();
 }
 
 // ---- one launch for every slot sum of the backward pass (reduce.hpp): a set of slots per gx workgroups (encoder branches --
@@ -125,6 +112,52 @@ PendingSums* pending_entry() {
     return &g_pending[dev];
 }
 }  // namespace
+
+namespace {
+struct PendingPack {
+    PackAll A;
+    hipStream_t stream = nullptr;
+    bool valid = false;
+};
+PendingPack g_pending_pack[kMaxDevices];
+PendingPack* pending_pack_entry() {
+    int dev = 0;
+    if (hipGetDevice(&dev) || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_pending_pack[dev];
+}
+}  // namespace
+
+int pending_pack_flush() {
+    PendingPack* P = pending_pack_entry();
+    if (!P) return hipErrorInvalidDevice;
+    PackAll A;
+    hipStream_t s;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!P->valid) return hipSuccess;
+        A = P->A; s = P->stream; P->valid = false;
+    }
+    return launch_pack(A, s);
+}
+
+int pending_pack_leave(const PackAll& A, hipStream_t s) {
+    if (int e = pending_pack_flush()) return e;
+    PendingPack* P = pending_pack_entry();
+    if (!P) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_mu);
+    P->A = A; P->stream = s; P->valid = true;
+    return hipSuccess;
+}
+
+bool pending_pack_take(hipStream_t s, PackAll* out) {
+    PendingPack* P = pending_pack_entry();
+    if (!P) return false;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!P->valid || P->stream != s) return false;
+    *out = P->A;
+    P->valid = false;
+    return true;
+}
 
 int pending_slot_sums_flush() {
     PendingSums* P = pending_entry();
@@ -173,7 +206,6 @@ PIML_API int piml_pinnsf_streams_init(void) {
 // hipStreamEndCapture on ROCm 7.2, tools/probe_capture_fork.py.)
 PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
                               const piml_collision_head* head, int flags, void* stream) {
-    (void)flags;
     if (!enc || !dec || nbr < 1 || nbr > 2) return hipErrorInvalidValue;
     PackAll A = {};
     A.nbr = nbr;
@@ -191,13 +223,11 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
         if (!head->w1 || !head->b1 || !head->w2 || !head->b2 || !head->packed) return hipErrorInvalidValue;
         A.head = *head;
     }
-    constexpr int kMax = PACK_FLOATS > DEC_PACK ? PACK_FLOATS : DEC_PACK;
-    static_assert(HEAD_PACK <= kMax, "grid covers the largest image");
-    hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((kMax + 255) / 256, 2 * nbr + (head ? 1 : 0)), dim3(256), 0,
-                       as_stream(stream), A);
-    trace_mark("pinnsf_pack", as_stream(stream));
-    return hipGetLastError();
+    if (flags & PIML_DEFER_PACK) return pending_pack_leave(A, as_stream(stream));      // the next relfeat forward on `stream` runs it
+    return launch_pack(A, as_stream(stream));
 }
+
+PIML_API int piml_pinnsf_pack_flush(void) { return pending_pack_flush(); }
 
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
 static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate, bool defer = false) {
@@ -236,6 +266,7 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
                              int flags, void* stream) {
     hipStream_t m = as_stream(stream);
     const bool pack = !(flags & PIML_PACKED_VALID);
+    PIML_TRY(pending_pack_flush());          // a deferred pack nobody took: now (no-op otherwise)
     if (!(flags & PIML_FORK)) {
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
         // the split decoder tiles accumulate their two branches into `acc`: cleared by the encoder launch

@@ -154,7 +154,13 @@ constexpr int relfeat_lds_bytes() { return (2 * kTile + WAVES * kRing / 2 + (RES
 // measured at the 4096-agent scene (in-kernel stamps, tools/relfeat_stats.py) a median wave spent 7.5 k of its 32.6 k cycles
 // in that wait (per-row work is data dependent: 18 k median, 26 k max for the pedestrian pass).
 template <int WAVES, bool RES>
-__global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatArgs A) {
+__global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatArgs A, const PackWork PK) {
+    // a deferred weight pack (PIML_DEFER_PACK, reduce.hpp) rides as the launch's trailing workgroups: they reach a CU when
+    // the short obstacle workgroups have left, under the tail of the pedestrian passes
+    if (PK.first_block >= 0 && (int)blockIdx.x >= PK.first_block) {
+        pack_block(PK.A, (int)blockIdx.x - PK.first_block, WAVES * 64);
+        return;
+    }
     // source tiles, structure-of-arrays so that a lane fetches 4 consecutive points per
     // ds_read_b128 (x) + ds_read_b128 (y)
     extern __shared__ __attribute__((aligned(16))) float rf_lds[];
@@ -170,7 +176,8 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
 
     if (A.tick && blockIdx.x == 0 && threadIdx.x == 0) *A.tick += 1;
     if (A.zero)                                             // a few 100 KB, spread over the whole grid
-        for (long e = (long)blockIdx.x * (WAVES * 64) + threadIdx.x; e < A.zero_n; e += (long)gridDim.x * (WAVES * 64))
+        for (long e = (long)blockIdx.x * (WAVES * 64) + threadIdx.x; e < A.zero_n;
+             e += (long)(PK.first_block >= 0 ? PK.first_block : (int)gridDim.x) * (WAVES * 64))
             A.zero[e] = 0.f;
 
     const int bpc = (A.fcnt + WAVES - 1) / WAVES;          // blocks per slice
@@ -560,9 +567,15 @@ static float dist2_cutoff(float thr) {
 using namespace piml;
 
 template <int W, bool R>
-static void relfeat_go(dim3 grid, dim3 block, void* stream, const RelfeatArgs& A) {
+static void relfeat_go(dim3 grid, dim3 block, void* stream, const RelfeatArgs& A, bool forward_of_a_step = false) {
     constexpr int bytes = relfeat_lds_bytes<W, R>();
-    relfeat_fwd_kernel<W, R><<<grid, block, bytes, as_stream(stream)>>>(A);
+    PackWork PK;
+    PK.first_block = -1;
+    if (forward_of_a_step && pending_pack_take(as_stream(stream), &PK.A)) {     // a pack left by piml_pinnsf_pack(PIML_DEFER_PACK)
+        PK.first_block = (int)grid.x;
+        grid.x += (unsigned)(pack_blocks_per_set(W * 64) * (2 * PK.A.nbr + (PK.A.has_head ? 1 : 0)));
+    }
+    relfeat_fwd_kernel<W, R><<<grid, block, bytes, as_stream(stream)>>>(A, PK);
 }
 template <int W>
 static int relfeat_attr() {
@@ -643,20 +656,20 @@ static int relfeat_launch(const float* position, const float* heading, const flo
         A.split = 1;
         const dim3 grid2(grid.x * 2);
         switch (waves) {
-            case 16: relfeat_go<16, false>(grid2, block, stream, A); break;
-            case 8: relfeat_go<8, false>(grid2, block, stream, A); break;
-            case 4: relfeat_go<4, false>(grid2, block, stream, A); break;
+            case 16: relfeat_go<16, false>(grid2, block, stream, A, true); break;
+            case 8: relfeat_go<8, false>(grid2, block, stream, A, true); break;
+            case 4: relfeat_go<4, false>(grid2, block, stream, A, true); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     switch (waves * 2 + (res ? 1 : 0)) {
-        case 33: relfeat_go<16, true>(grid, block, stream, A); break;
-        case 32: relfeat_go<16, false>(grid, block, stream, A); break;
-        case 17: relfeat_go<8, true>(grid, block, stream, A); break;
-        case 16: relfeat_go<8, false>(grid, block, stream, A); break;
-        case 9: relfeat_go<4, true>(grid, block, stream, A); break;
-        case 8: relfeat_go<4, false>(grid, block, stream, A); break;
+        case 33: relfeat_go<16, true>(grid, block, stream, A, true); break;
+        case 32: relfeat_go<16, false>(grid, block, stream, A, true); break;
+        case 17: relfeat_go<8, true>(grid, block, stream, A, true); break;
+        case 16: relfeat_go<8, false>(grid, block, stream, A, true); break;
+        case 9: relfeat_go<4, true>(grid, block, stream, A, true); break;
+        case 8: relfeat_go<4, false>(grid, block, stream, A, true); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1958,10 +1958,15 @@ def _weights_sig(enc_w, dec_w, head_w):
     return tuple((t.data_ptr(), t._version) for wb in (*enc_w, *dec_w, *([head_w] if head_w is not None else [])) for t in wb)
 
 
-def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
+DEFER_PACK = _os.environ.get('PIML_DEFER_PACK', '1') != '0'
+
+
+def pinnsf_prepack(packs, enc_w, dec_w, head_w=None, defer=None):
     """Pack the weights of a fused PINNSF network into `packs` (one launch on the current stream).
     enc_w / dec_w: per branch (w1, b1, w2, b2, w3, b3) encoder and (w1, b1, w2, b2, wp, bp) decoder + predictor tensors;
-    head_w: (w1, b1, w2, b2) of the collision head or None."""
+    head_w: (w1, b1, w2, b2) of the collision head or None.  defer (default: PIML_DEFER_PACK != 0): the launch is left to
+    the next relfeat forward on the stream, which runs the pack as its trailing workgroups (PIML_DEFER_PACK of the C ABI);
+    every consumer of the packs launches it itself if no relfeat forward came in between."""
     import ctypes
     enc_w = [[_gpu_f32('encoder weight', t.detach()) for t in wb] for wb in enc_w]
     dec_w = [[_gpu_f32('decoder weight', t.detach()) for t in wb] for wb in dec_w]
@@ -1970,8 +1975,10 @@ def pinnsf_prepack(packs, enc_w, dec_w, head_w=None):
     packs.ensure(dev)
     earr, darr, head = _pack_structs(enc_w, dec_w, head_w, packs)
     with torch.cuda.device(dev):
+        flags = _lib.DEFER_PACK if (DEFER_PACK if defer is None else defer) else 0
         _lib.check(_lib.lib().piml_pinnsf_pack(earr, darr, len(enc_w), ctypes.byref(head) if head is not None else None,
-                                               0, _stream()), 'piml_pinnsf_pack')
+                                               flags, _stream()), 'piml_pinnsf_pack')
+        packs.pending_structs = (earr, darr, head, enc_w, dec_w, head_w) if flags else None      # (alive until the pack has run)
     packs.sig = _weights_sig(enc_w, dec_w, head_w)
     packs.sig_enc = tuple(_branch_sig(wb) for wb in enc_w)
     packs.sig_dec = tuple(_branch_sig(wb) for wb in dec_w)
