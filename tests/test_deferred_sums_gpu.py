@@ -97,3 +97,38 @@ def test_deferred_slot_sums_inside_a_captured_graph():
     assert len(have) == len(want) - 1
     for a, b in zip(want, have):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('relfeat_between', [True, False])
+def test_deferred_weight_pack_is_bitwise_the_standalone_launch(relfeat_between, monkeypatch):
+    """PIML_DEFER_PACK (model.packed_weights() by default): the pack rides as trailing workgroups of the next relfeat forward
+    launch, or -- when no such launch comes before the network -- is launched by the network's forward itself; either way the
+    outputs and gradients are bitwise those of the pack as a launch of its own, also when the weights changed since the
+    previous pack (a stale image would show)."""
+    from piml_amd import ops
+    model, scene = _model(), _scene()
+    state, dest, obs, v0 = scene
+    N = state.shape[0]
+    base = [p.detach().clone() for p in model.parameters()]
+    feats0 = ops.relative_features_packed_self(state, dest, obs, v0, 0, N)
+
+    def one_pass(factor, mode):
+        with torch.no_grad():
+            for p, b in zip(model.parameters(), base):
+                p.copy_(b * factor)
+                p.grad = None
+        import contextlib
+        monkeypatch.setattr(ops, 'DEFER_PACK', mode == 'deferred')
+        with (model.packed_weights() if mode != 'self' else contextlib.nullcontext()):
+            feats = ops.relative_features_packed_self(state, dest, obs, v0, 0, N) if relfeat_between else feats0
+            acc = model(*feats)[0]
+            acc.backward(torch.ones_like(acc))
+        torch.cuda.synchronize()
+        return [acc.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    for factor in (1.0, 1.25, 0.5):
+        want = one_pass(factor, 'self')              # no packed_weights block: the forward packs for itself
+        for mode in ('standalone', 'deferred'):
+            got = one_pass(factor, mode)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (factor, mode)
