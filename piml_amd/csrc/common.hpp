@@ -36,6 +36,10 @@ __device__ __forceinline__ int lane_id() {
 __device__ __forceinline__ unsigned mbcnt(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// `base` + the number of set bits of `m` strictly below this lane (the addend rides in the mbcnt instruction)
+__device__ __forceinline__ unsigned mbcnt_add(u64 m, unsigned base) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, base));
+}
 // value is identical in every lane: move it to an SGPR
 __device__ __forceinline__ float uniform(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));

@@ -67,26 +67,40 @@ template <int CTRL>
 __device__ __forceinline__ unsigned dpp_mov(unsigned x) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
 }
-// minimum over the 64 lanes, returned wave-uniform (4 DPP row steps + 4 readlanes)
+// minimum over the 64 lanes, returned wave-uniform.  Round 4: six DPP minima (quad_perm x 2, row_half_mirror, row_mirror, then
+// row_bcast:15 / row_bcast:31 carry the row minima into lane 63) and ONE readlane, written as asm -- from the builtins hipcc
+// made v_mov + s_nop + v_mov_dpp + v_min per step and four readlanes + a v_min3 behind them (19 vector instructions; a
+// drain round was 45 of them, fifteen rounds per focal row 41 % of the kernel's vector work).  Two wait states between a
+// vector write and a DPP read of the same register (s_nop 1).
 __device__ __forceinline__ unsigned wave_min_u32(unsigned x) {
-    x = min(x, dpp_mov<0xB1>(x));     // quad_perm [1,0,3,2]
-    x = min(x, dpp_mov<0x4E>(x));     // quad_perm [2,3,0,1]
-    x = min(x, dpp_mov<0x141>(x));    // row_half_mirror
-    x = min(x, dpp_mov<0x140>(x));    // row_mirror: every lane of a row holds the row minimum
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0);
-    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32);
-    const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);
-    return min(min(a, b), min(c, d));
+    unsigned r;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(r)
+        : "v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)r, 63);
 }
 // Insert the wave-uniform entry (nd, ni), which precedes the current k-th entry.  The lower
 // neighbour's entry arrives by a DPP wave_shr:1 move (lane 0 reads (0, 0), which never
-// follows the new entry, so lane 0 can only be the receiving slot).
+// follows the new entry, so lane 0 can only be the receiving slot).  (distance, index) compared as ONE 64-bit key.
 __device__ __forceinline__ void list_insert(unsigned& ld, unsigned& li, unsigned nd, unsigned ni) {
-    const unsigned up_d = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ld, 0x138, 0xf, 0xf, false);
-    const unsigned up_i = (unsigned)__builtin_amdgcn_update_dpp(0, (int)li, 0x138, 0xf, 0xf, false);
-    const bool moves = ld > nd || (ld == nd && li > ni);
-    const bool below_moves = up_d > nd || (up_d == nd && up_i > ni);
+    const unsigned up_d = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ld, 0x138, 0xf, 0xf, true);
+    const unsigned up_i = (unsigned)__builtin_amdgcn_update_dpp(0, (int)li, 0x138, 0xf, 0xf, true);
+    const u64 nk = ((u64)nd << 32) | ni;
+    const bool moves = (((u64)ld << 32) | li) > nk;
+    const bool below_moves = (((u64)up_d << 32) | up_i) > nk;
     ld = moves ? (below_moves ? up_d : nd) : ld;
     li = moves ? (below_moves ? up_i : ni) : li;
 }
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
                         const u64 m = __builtin_amdgcn_ballot_w64(d2[u] <= cut2);
                         if (m == 0) continue;                  // the common case once the cut-off is tight
                         if (d2[u] <= cut2)
-                            ring[(tail + mbcnt(m)) & (kRing - 1)] =
+                            ring[mbcnt_add(m, tail) & (kRing - 1)] =
                                 (unsigned short)(j0 + (u >> 2) * 256 + 4 * lane + (u & 3));
                         tail += (unsigned)__builtin_popcountll(m);
                     }
