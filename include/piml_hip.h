@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 23
+#define PIML_HIP_ABI_VERSION 24
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -228,7 +228,7 @@ int piml_collision_friends(float* coll, const float* base, int C, int T, int S_b
  *   out[2] = the same with hard_collisions
  * g_mse / g_coll / g_hard (C, T, N, 2) = d out[i] / d p.  piml_rollout_losses_bwd: g_p = sum_i *g_out_i * g_i, the three
  * upstream gradients as device scalars (NULL = 0).  The sums
- * run in a fixed order.  partial: 3 * piml_rollout_losses_blocks(C, N) floats, ticket: one zeroed unsigned (left zero);
+ * run in a fixed order.  partial: 6 * piml_rollout_losses_blocks(C, N) floats, ticket: one zeroed unsigned (left zero);
  * both only used when piml_rollout_losses_blocks(C, N) > 1.
  */
 /* n device-to-device copies (dst[i] <- src[i], bytes[i] bytes; the ranges of one pair do not overlap) in one launch per 24
@@ -250,6 +250,22 @@ int piml_rollout_losses(const float* p, const float* labels, long long labels_ld
                         float* g_coll, float* g_hard, float* partial, unsigned* ticket, void* stream);
 int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, const float* g_out2, const float* g_mse,
                             const float* g_coll, const float* g_hard, long long n, float* g_p, void* stream);
+/* piml_rollout_losses on the collision count records of the frames AS PRODUCED, with the statistics the step logs and the
+ * weighted total: count_frames = HOST array of T device pointers, frame t's (2, C, N) floats [collisions | hard collisions]
+ * (piml_collision_counts of its positions; NULL = zeros), gated here by gates[t] (src/models/simulators.py:708-715, :728);
+ * focus != 0: they also weight the two collision-focus sums (:800-819).  out (12 floats): [0] mse, [1] focus sum of the
+ * collisions, [2] of the hard collisions, [3] sum of the gated collisions, [4] of the hard ones, [5] number of entries with
+ * mask_pred == 1, [6] total = mse + w_coll [1] + w_hard [2], [7] w_coll [1], [8] w_hard [2].  T <= 32.
+ * bwd: upstream gradients of [0], [7], [8] and [6] (device scalars; the first three may be NULL, the last not). */
+int piml_rollout_losses_frames(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
+                               const unsigned char* gates, const float* const* count_frames, int focus,
+                               const float* abnormal_mask, int C, int T, int N, float time_decay, float w_coll, float w_hard,
+                               float* out, float* g_mse, float* g_coll, float* g_hard, float* partial, unsigned* ticket,
+                               void* stream);
+int piml_rollout_losses_frames_bwd(const float* g_mse_out, const float* g_collw_out, const float* g_hardw_out,
+                                   const float* g_total_out, float w_coll, float w_hard, const float* g_mse, const float* g_coll,
+                                   const float* g_hard, long long n, float* g_p, void* stream);
+
 
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);

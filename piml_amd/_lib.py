@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 
@@ -112,6 +112,8 @@ SIGNATURES = {
     'piml_rollout_losses_blocks': [_i, _i],
     'piml_rollout_losses': [_p, _p, _ll, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],
+    'piml_rollout_losses_frames': [_p, _p, _ll, _p, _p, ctypes.POINTER(_p), _i, _p, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
+    'piml_rollout_losses_frames_bwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _ll, _p, _p],
     'piml_p2p_alloc': [_z, ctypes.POINTER(_p)],
     'piml_p2p_free': [_p],
     'piml_p2p_export': [_p, _p],

@@ -37,33 +37,53 @@ struct LossArgs {
     float* g_mse;                // (C, T, N, 2) each
     float* g_coll;
     float* g_hard;
-    float* partial;              // (blocks, 3)
+    float* partial;              // (blocks, 6)
     unsigned* ticket;            // zero on entry, zero again on exit
+    // round 4 (piml_rollout_losses_frames): the collision count records of the frames as they were produced -- frames[t] =
+    // (2, C, N) floats [collisions | hard collisions] of frame t, NULL = zeros -- gated here (x gate[t]) instead of stacked and
+    // multiplied by torch operators; focus = 0: the counts only feed the statistics; the weighted total in out[6..8]
+    const float* frames[32];
+    int use_frames, focus, stats;
+    float w_coll, w_hard;
 };
 
-__device__ __forceinline__ void block_sum3(float (&v)[3], float* red) {
+constexpr int LOSS_SUMS = 6;       // mse, collision focus, hard focus, sum of collisions, of hard collisions, predicted entries
+
+__device__ __forceinline__ void block_sum6(float (&v)[LOSS_SUMS], float* red) {
     // fixed-order tree over the workgroup's threads
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] = v[q];
+    for (int q = 0; q < LOSS_SUMS; ++q) red[q * LOSS_THREADS + tid] = v[q];
     __syncthreads();
     for (int s = LOSS_THREADS / 2; s > 0; s >>= 1) {
         if (tid < s) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] += red[q * LOSS_THREADS + tid + s];
+            for (int q = 0; q < LOSS_SUMS; ++q) red[q * LOSS_THREADS + tid] += red[q * LOSS_THREADS + tid + s];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) v[q] = red[q * LOSS_THREADS];
+    for (int q = 0; q < LOSS_SUMS; ++q) v[q] = red[q * LOSS_THREADS];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void loss_write_out(const LossArgs& A, const float (&s)[LOSS_SUMS]) {
+    const int t = threadIdx.x;
+    if (t < 3) A.out[t] = s[t];
+    if (A.stats) {
+        if (t >= 3 && t < LOSS_SUMS) A.out[t] = s[t];
+        if (t == 6) A.out[6] = s[0] + A.w_coll * s[1] + A.w_hard * s[2];
+        if (t == 7) A.out[7] = A.w_coll * s[1];
+        if (t == 8) A.out[8] = A.w_hard * s[2];
+    }
 }
 
 __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A) {
-    __shared__ float red[3 * LOSS_THREADS];
+    __shared__ float red[LOSS_SUMS * LOSS_THREADS];
     __shared__ unsigned last;
     const int T = A.T, N = A.N;
     const long long pairs = (long long)A.C * N;
-    float s[3] = {0.f, 0.f, 0.f};
+    float s[LOSS_SUMS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < pairs; e += (long long)gridDim.x * LOSS_THREADS) {
         const long long c = e / N, n = e - c * N;
         auto at = [&](int t) { return (c * T + t) * N + n; };
@@ -73,6 +93,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A
             x = k ? A.lab[i * A.ld] : 0.f;
             y = k ? A.lab[i * A.ld + 1] : 0.f;
         };
+        auto counts = [&](int t, float& co, float& ha) {      // the frame's collision counts of this (window, agent), gated
+            co = 0.f; ha = 0.f;
+            if (A.use_frames) {
+                const float* f = A.frames[t];
+                if (f && A.gate[t] != 0) { co = f[e]; ha = f[pairs + e]; }
+            } else {
+                if (A.coll) co = A.coll[at(t)];
+                if (A.hard) ha = A.hard[at(t)];
+            }
+        };
         float l0x, l0y, l1x, l1y;
         label(0, l0x, l0y);
         label(T - 1, l1x, l1y);
@@ -81,11 +111,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A
         nx = nx / nn; ny = ny / nn;
         float cs = 0.f, hs = 0.f;
         for (int t = 0; t < T; ++t) {
-            if (A.coll) cs += A.coll[at(t)];
-            if (A.hard) hs += A.hard[at(t)];
+            float co, ha;
+            counts(t, co, ha);
+            cs += co; hs += ha;
+            if (A.keep[at(t)] == 1) s[5] += 1.f;
         }
+        s[3] += cs; s[4] += hs;
         const float ab = A.abn ? A.abn[n] : 1.f;
-        const float wc = (A.coll && cs > 0.f) ? ab : 0.f, wh = (A.hard && hs > 0.f) ? ab : 0.f;
+        const bool foc = A.use_frames ? A.focus != 0 : true;
+        const float wc = (foc && (A.use_frames || A.coll) && cs > 0.f) ? ab : 0.f;
+        const float wh = (foc && (A.use_frames || A.hard) && hs > 0.f) ? ab : 0.f;
         for (int t = 0; t < T; ++t) {
             const long long i = at(t);
             const bool k = A.keep[i] != 0, live = k && A.gate[t] != 0;
@@ -109,35 +144,39 @@ __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_kernel(LossArgs A
             A.g_hard[i * 2] = wh * ax; A.g_hard[i * 2 + 1] = wh * ay;
         }
     }
-    block_sum3(s, red);
+    block_sum6(s, red);
     if (gridDim.x == 1) {
-        if (threadIdx.x < 3) A.out[threadIdx.x] = s[threadIdx.x];
+        loss_write_out(A, s);
         return;
     }
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) A.partial[blockIdx.x * 3 + q] = s[q];
+        for (int q = 0; q < LOSS_SUMS; ++q) A.partial[blockIdx.x * LOSS_SUMS + q] = s[q];
         __threadfence();
         last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!last) return;
     __threadfence();
-    float r[3] = {0.f, 0.f, 0.f};
+    float r[LOSS_SUMS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (unsigned b = threadIdx.x; b < gridDim.x; b += LOSS_THREADS)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) r[q] += A.partial[b * 3 + q];
+        for (int q = 0; q < LOSS_SUMS; ++q) r[q] += A.partial[b * LOSS_SUMS + q];
     __syncthreads();
-    block_sum3(r, red);
-    if (threadIdx.x < 3) A.out[threadIdx.x] = r[threadIdx.x];
+    block_sum6(r, red);
+    loss_write_out(A, r);
     if (threadIdx.x == 0) *A.ticket = 0u;
 }
 
 __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_bwd_kernel(const float* __restrict__ g0, const float* __restrict__ g1,
                                                                          const float* __restrict__ g2, const float* __restrict__ g_mse,
                                                                          const float* __restrict__ g_coll, const float* __restrict__ g_hard,
-                                                                         long long n, float* __restrict__ g_p) {
-    const float a = g0 ? *g0 : 0.f, b = g1 ? *g1 : 0.f, c = g2 ? *g2 : 0.f;
+                                                                         long long n, float* __restrict__ g_p, const float* __restrict__ g3,
+                                                                         float w_coll, float w_hard) {
+    // g0..g2: upstream of the three raw sums (frames form: of mse, of w_coll * coll, of w_hard * hard); g3: of the weighted total
+    const float gt = g3 ? *g3 : 0.f;
+    const float a = (g0 ? *g0 : 0.f) + gt, b = (g1 ? *g1 : 0.f) * (g3 ? w_coll : 1.f) + gt * w_coll,
+                c = (g2 ? *g2 : 0.f) * (g3 ? w_hard : 1.f) + gt * w_hard;
     for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * LOSS_THREADS)
         g_p[e] = a * g_mse[e] + b * g_coll[e] + c * g_hard[e];
 }
@@ -160,8 +199,30 @@ PIML_API int piml_rollout_losses(const float* p, const float* labels, long long 
         return hipErrorInvalidValue;
     const int blocks = piml_rollout_losses_blocks(C, N);
     if (blocks > 1 && (!partial || !ticket)) return hipErrorInvalidValue;
-    LossArgs A = {p, labels, labels_ld, mask_pred, gates, collisions, hard_collisions, abnormal_mask, C, T, N, time_decay,
-                  out, g_mse, g_coll, g_hard, partial, ticket};
+    LossArgs A = {};
+    A.p = p; A.lab = labels; A.ld = labels_ld; A.keep = mask_pred; A.gate = gates; A.coll = collisions; A.hard = hard_collisions;
+    A.abn = abnormal_mask; A.C = C; A.T = T; A.N = N; A.time_decay = time_decay; A.out = out; A.g_mse = g_mse; A.g_coll = g_coll;
+    A.g_hard = g_hard; A.partial = partial; A.ticket = ticket;
+    hipLaunchKernelGGL(rollout_losses_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_rollout_losses_frames(const float* p, const float* labels, long long labels_ld, const long long* mask_pred,
+                                        const unsigned char* gates, const float* const* count_frames, int focus,
+                                        const float* abnormal_mask, int C, int T, int N, float time_decay, float w_coll,
+                                        float w_hard, float* out, float* g_mse, float* g_coll, float* g_hard, float* partial,
+                                        unsigned* ticket, void* stream) {
+    if (!p || !labels || !mask_pred || !gates || !count_frames || !out || !g_mse || !g_coll || !g_hard || C < 1 || T < 1 || T > 32 ||
+        N < 1 || labels_ld < 2)
+        return hipErrorInvalidValue;
+    const int blocks = piml_rollout_losses_blocks(C, N);
+    if (blocks > 1 && (!partial || !ticket)) return hipErrorInvalidValue;
+    LossArgs A = {};
+    A.p = p; A.lab = labels; A.ld = labels_ld; A.keep = mask_pred; A.gate = gates; A.abn = abnormal_mask; A.C = C; A.T = T; A.N = N;
+    A.time_decay = time_decay; A.out = out; A.g_mse = g_mse; A.g_coll = g_coll; A.g_hard = g_hard; A.partial = partial;
+    A.ticket = ticket;
+    for (int t = 0; t < T; ++t) A.frames[t] = count_frames[t];
+    A.use_frames = 1; A.focus = focus; A.stats = 1; A.w_coll = w_coll; A.w_hard = w_hard;
     hipLaunchKernelGGL(rollout_losses_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, as_stream(stream), A);
     return hipGetLastError();
 }
@@ -171,7 +232,21 @@ PIML_API int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, c
     if (!g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
     long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
     hipLaunchKernelGGL(rollout_losses_bwd_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(LOSS_THREADS), 0, as_stream(stream),
-                       g_out0, g_out1, g_out2, g_mse, g_coll, g_hard, n, g_p);
+                       g_out0, g_out1, g_out2, g_mse, g_coll, g_hard, n, g_p, (const float*)nullptr, 1.f, 1.f);
+    return hipGetLastError();
+}
+
+PIML_API int piml_rollout_losses_frames_bwd(const float* g_mse_out, const float* g_collw_out, const float* g_hardw_out,
+                                            const float* g_total_out, float w_coll, float w_hard, const float* g_mse,
+                                            const float* g_coll, const float* g_hard, long long n, float* g_p, void* stream) {
+    if (!g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
+    static const float zero_host = 0.f;
+    (void)zero_host;
+    long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
+    // g3 must be non-NULL for the weighted form: a missing total gradient is a device zero the caller passes
+    if (!g_total_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rollout_losses_bwd_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(LOSS_THREADS), 0, as_stream(stream),
+                       g_mse_out, g_collw_out, g_hardw_out, g_mse, g_coll, g_hard, n, g_p, g_total_out, w_coll, w_hard);
     return hipGetLastError();
 }
 

@@ -541,15 +541,23 @@ class BaseSimulator(Pedestrians):
             pad = [torch.zeros_like(steps[0])] * t_start if t_start else []
             allf = torch.stack(pad + steps, dim=2) * gates_f.view(1, 1, -1, 1)    # (2, C, T, N)
             return allf[0], allf[1]
-        collisions, hard_collisions = frames(cnt_steps)
+        # the frames' count records straight into the loss launch (ops.rollout_losses_frames: gated there, the collision totals
+        # and the predicted-entry count the step logs come back with the sums, the loss weights are applied inside): no stack,
+        # no products, no separate reductions
+        use_frames = (self.fused_rollout_losses and not need_label_counts and T <= 32 and p_steps[0].is_cuda
+                      and p_steps[0].dim() == 3 and p_steps[0].dtype == torch.float32)
+        collisions = hard_collisions = None
+        if not use_frames:
+            collisions, hard_collisions = frames(cnt_steps)
         if need_label_counts:                                                 # :782-788
             label_collisions, label_hard = frames(lab_steps)
             collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
         if fused_step:
             nan_seen = nan_flag != 0
-        aux = {'nan_seen': nan_seen, 'collisions': torch.sum(collisions), 'hard_collisions': torch.sum(hard_collisions),
-               'dest_idx_final': dest_idx.detach().clone(), 't_start': t_start}
+        aux = {'nan_seen': nan_seen, 'dest_idx_final': dest_idx.detach().clone(), 't_start': t_start}
+        if not use_frames:
+            aux['collisions'], aux['hard_collisions'] = torch.sum(collisions), torch.sum(hard_collisions)
 
         pad = [torch.zeros_like(p_steps[0])] * t_start if t_start else []
         gate4 = gates.view(1, -1, 1, 1)
@@ -557,7 +565,19 @@ class BaseSimulator(Pedestrians):
         collision_loss, hard_collision_loss, collision_pred_loss, collision_pred_acc = zero, zero, zero, zero
         want_coll = args.collision_loss_weight > 0 and args.collision_loss_version in ('v0', 'v2')
         fused_losses = self.fused_rollout_losses and p_res.is_cuda and p_res.dim() == 4 and p_res.dtype == torch.float32
-        if fused_losses:
+        if fused_losses and use_frames:
+            am = data.abnormal_mask if args.collision_loss_version == 'v2' else None
+            w_c = args.collision_loss_weight if want_coll else 0.0
+            total, mse_loss, coll_w, hard_w, stats = ops.rollout_losses_frames(
+                p_res, labels, mask_pred, gates, [None] * t_start + cnt_steps, want_coll, am, args.time_decay, w_c,
+                w_c * args.hard_collision_penalty)
+            loss = total if loss is zero else loss + total
+            if want_coll:
+                collision_loss, hard_collision_loss = coll_w, hard_w
+            aux['collisions'], aux['hard_collisions'], aux['n_pred'] = stats[0], stats[1], stats[2]
+            if args.teacher_weight > 0:
+                labels = torch.where((mask_pred != 0).unsqueeze(-1), labels, torch.zeros_like(labels))   # :794
+        elif fused_losses:
             # :790-819 as ONE launch forward and one backward (ops.rollout_losses: the masks, the time-decayed squared error
             # and the two collision-focus sums; on torch operators ~100 launches of a few microseconds each)
             am = data.abnormal_mask if args.collision_loss_version == 'v2' else None
@@ -679,7 +699,7 @@ class BaseSimulator(Pedestrians):
                 aux['log_vec'] = torch.stack([*[o.detach().float().reshape(()) for o in out], aux['collisions'].float(),
                                               aux['hard_collisions'].float(),
                                               aux['nan_seen'].float() if torch.is_tensor(aux['nan_seen']) else out[0].detach().float() * 0,
-                                              (static.mask_p_pred == 1).sum().float()])
+                                              aux['n_pred'] if 'n_pred' in aux else (static.mask_p_pred == 1).sum().float()])
             self.model.obs_stream = None
             entry = (graph, static, out, aux)
             self._graphed_steps[key] = entry

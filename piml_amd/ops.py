@@ -697,7 +697,7 @@ class _RolloutLosses(torch.autograd.Function):
         blocks = L.piml_rollout_losses_blocks(C, N)
         partial, ticket = None, None
         if blocks > 1:
-            partial = torch.empty(blocks, 3, **opt)
+            partial = torch.empty(blocks, 6, **opt)
             ticket = _LOSS_TICKETS.get(dev)
             if ticket is None:       # zeroed once; the launch leaves it zero
                 ticket = _LOSS_TICKETS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -722,6 +722,83 @@ class _RolloutLosses(torch.autograd.Function):
             _lib.check(_lib.lib().piml_rollout_losses_bwd(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gm), _ptr(gc), _ptr(gh),
                                                           gm.numel(), _ptr(gp), _stream()), 'piml_rollout_losses_bwd')
         return (gp,) + (None,) * 7
+
+
+class _RolloutLossesFrames(torch.autograd.Function):
+    """piml_rollout_losses_frames / _bwd: the rollout losses on the frames' collision count records as produced (gated inside),
+    with the weighted total and the statistics the step logs.  Outputs: total, mse, w_coll * focus(collisions),
+    w_hard * focus(hard collisions) (differentiable w.r.t. p) and stats (3,) = [sum of the gated collisions, of the hard ones,
+    number of entries with mask_pred == 1] (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, p, labels, mask_pred, gates, focus, abnormal_mask, time_decay, w_coll, w_hard, *frames):
+        import ctypes
+        L = _lib.lib()
+        pc = _gpu_f32('p', p.detach())
+        C, T, N = pc.shape[0], pc.shape[1], pc.shape[2]
+        lab = _gpu_f32('labels', labels.detach())
+        if tuple(lab.shape[:3]) != (C, T, N) or lab.shape[-1] < 2 or pc.shape[-1] != 2 or len(frames) != T or T > 32:
+            raise ValueError('p must be (C, T <= 32, N, 2), labels (C, T, N, >= 2), one count record (or None) per frame')
+        mp = mask_pred.detach().contiguous()
+        if mp.dtype != torch.int64 or tuple(mp.shape) != (C, T, N):
+            raise ValueError('mask_pred must be int64 (C, T, N)')
+        g8 = gates.detach().contiguous().view(torch.uint8)
+        dev = pc.device
+        opt = dict(device=dev, dtype=torch.float32)
+        fr = [None if f is None else _gpu_f32('count record', f.detach()) for f in frames]
+        for f in fr:
+            if f is not None and tuple(f.shape) != (2, C, N):
+                raise ValueError('count records must be (2, C, N)')
+        table = (ctypes.c_void_p * T)(*[None if f is None else f.data_ptr() for f in fr])
+        ab = None if abnormal_mask is None else _gpu_f32('abnormal_mask', abnormal_mask.detach().reshape(-1))
+        out = torch.empty(12, **opt)
+        gm, gc, gh = torch.empty_like(pc), torch.empty_like(pc), torch.empty_like(pc)
+        blocks = L.piml_rollout_losses_blocks(C, N)
+        partial, ticket = None, None
+        if blocks > 1:
+            partial = torch.empty(blocks, 6, **opt)
+            ticket = _LOSS_TICKETS.get(dev)
+            if ticket is None:       # zeroed once; the launch leaves it zero
+                ticket = _LOSS_TICKETS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_rollout_losses_frames(_ptr(pc), _ptr(lab), lab.shape[-1], _ptr(mp), _ptr(g8), table, int(bool(focus)),
+                                                    _ptr(ab), C, T, N, float(time_decay), float(w_coll), float(w_hard), _ptr(out),
+                                                    _ptr(gm), _ptr(gc), _ptr(gh), _ptr(partial), _ptr(ticket), _stream()),
+                       'piml_rollout_losses_frames')
+        ctx.save_for_backward(gm, gc, gh)
+        ctx.weights = (float(w_coll), float(w_hard))
+        ctx.nin = 9 + len(frames)
+        ctx.set_materialize_grads(False)
+        stats = out[3:6]
+        ctx.mark_non_differentiable(stats)
+        return out[6], out[0], out[7], out[8], stats
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_total, g_mse, g_collw, g_hardw, _gs):
+        if all(g is None for g in (g_total, g_mse, g_collw, g_hardw)) or not ctx.needs_input_grad[0]:
+            return (None,) * ctx.nin
+        gm, gc, gh = ctx.saved_tensors
+        w_coll, w_hard = ctx.weights
+        gs = [None if g is None else _gpu_f32('g_out', g) for g in (g_mse, g_collw, g_hardw)]
+        gt = _gpu_f32('g_out', g_total) if g_total is not None else torch.zeros((), device=gm.device, dtype=torch.float32)
+        gp = torch.empty_like(gm)
+        with torch.cuda.device(gm.device):
+            _lib.check(_lib.lib().piml_rollout_losses_frames_bwd(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gt), w_coll, w_hard,
+                                                                 _ptr(gm), _ptr(gc), _ptr(gh), gm.numel(), _ptr(gp), _stream()),
+                       'piml_rollout_losses_frames_bwd')
+        return (gp,) + (None,) * (ctx.nin - 1)
+
+
+def rollout_losses_frames(p, labels, mask_pred, gates, count_frames, focus, abnormal_mask=None, time_decay=1.0, w_coll=1.0,
+                          w_hard=1.0):
+    """rollout_losses on the frames' collision count records as ops.collision_counts left them (one (2, C, N) tensor or None
+    per frame; gated by `gates` inside), returning (total = mse + w_coll * focus_c + w_hard * focus_h, mse, w_coll * focus_c,
+    w_hard * focus_h, stats) -- stats (3,) = [sum of the gated collisions, sum of the gated hard collisions, number of
+    mask_pred == 1 entries], the scalars the training step logs (src/models/simulators.py:708-728, 790-819).  focus False: the
+    counts only feed the statistics (collision loss switched off)."""
+    return _RolloutLossesFrames.apply(p, labels, mask_pred, gates, bool(focus), abnormal_mask, float(time_decay), float(w_coll),
+                                      float(w_hard), *count_frames)
 
 
 def rollout_losses(p, labels, mask_pred, gates, collisions=None, hard_collisions=None, abnormal_mask=None, time_decay=1.0):

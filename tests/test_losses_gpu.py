@@ -186,3 +186,35 @@ def test_rollout_prologue_and_frame_node_equal_the_torch_expressions():
         assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('focus', [True, False])
+@pytest.mark.parametrize('C,T,N,t_start', [(4, 5, 122, 0), (2, 7, 1500, 2)])
+def test_rollout_losses_frames_equals_the_stacked_form(C, T, N, t_start, focus):
+    """ops.rollout_losses_frames (count records per frame, gated inside, weights and statistics inside) against
+    ops.rollout_losses on the stacked / gated tensors + the torch expressions around it (src/models/simulators.py:708-728,
+    790-819): every output, the statistics and the gradient."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(C * 100 + T)
+    p = torch.randn(C, T, N, 2, generator=g).cuda().requires_grad_(True)
+    labels = torch.randn(C, T, N, 12, generator=g).cuda()
+    mask = (torch.rand(C, T, N, generator=g) > 0.3).long().cuda()
+    mask[:, T - 2] = 0                                        # a closed gate
+    gates = mask.sum(dim=(0, 2)) > 0
+    recs = [None] * t_start + [(torch.rand(2, C, N, generator=g) > 0.9).float().cuda() for _ in range(T - t_start)]
+    abn = (torch.rand(N, generator=g) > 0.1).float().cuda()
+    w_c, w_h = 0.7, 0.7 * 3.0
+    total, mse, cw, hw, stats = ops.rollout_losses_frames(p, labels, mask, gates, recs, focus, abn, 0.9, w_c if focus else 0.0,
+                                                          w_h if focus else 0.0)
+    gp, = torch.autograd.grad(total, p)
+    stack = torch.stack([torch.zeros(2, C, N, device='cuda') if r is None else r for r in recs], dim=2) * gates.float().view(1, 1, -1, 1)
+    coll, hard = stack[0], stack[1]
+    sums = ops.rollout_losses(p, labels, mask, gates, coll if focus else None, hard if focus else None, abn, 0.9)
+    want_total = sums[0] + (sums[1] * w_c + sums[2] * w_h if focus else 0.0)
+    gw, = torch.autograd.grad(want_total, p)
+    close = lambda a, b: torch.allclose(a, b, rtol=2e-6, atol=1e-6)
+    assert close(total, want_total) and close(mse, sums[0])
+    if focus:
+        assert close(cw, sums[1] * w_c) and close(hw, sums[2] * w_h)
+    assert float(stats[0]) == float(coll.sum()) and float(stats[1]) == float(hard.sum()) and float(stats[2]) == float((mask == 1).sum())
+    assert torch.allclose(gp, gw, rtol=2e-6, atol=1e-7)
