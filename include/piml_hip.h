@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 24
+#define PIML_HIP_ABI_VERSION 25
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -405,6 +405,11 @@ int piml_pinnsf_epilogue_ksum_bwd(const float* g_out, const float* self_features
  */
 int piml_pinnsf_epilogue_agentnorm_fwd(const float* acc_ped, const float* acc_obs, const float* self_features,
                                        int C, int N, float tau, float* out, void* stream);
+/* piml_pinnsf_epilogue_ksum_fwd with the agent-axis norm of piml_pinnsf_epilogue_agentnorm_fwd (quirk Q2): the bottleneck
+ * variants' tail on the channelled (C, N, .) frames of the training rollout -- neighbour-axis sums + desired force in one launch.
+ * Backward: piml_pinnsf_epilogue_ksum_bwd with g_self = NULL (the broadcasts) + piml_pinnsf_epilogue_agentnorm_bwd. */
+int piml_pinnsf_epilogue_ksum_agentnorm_fwd(const float* pred_ped, int kp, const float* pred_obs, int ko, const float* self_features,
+                                            int C, int N, float tau, float* out, void* stream);
 int piml_pinnsf_epilogue_agentnorm_bwd(const float* g_out, const float* self_features, int C, int N, float tau,
                                        float* g_self, void* stream);
 

@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lib = None
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     'piml_pinnsf_epilogue_ksum_fwd': [_p, _i, _p, _i, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_ksum_bwd': [_p, _p, _z, _f, _i, _i, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_agentnorm_fwd': [_p, _p, _p, _i, _i, _f, _p, _p],
+    'piml_pinnsf_epilogue_ksum_agentnorm_fwd': [_p, _i, _p, _i, _p, _i, _i, _f, _p, _p],
     'piml_pinnsf_epilogue_agentnorm_bwd': [_p, _p, _i, _i, _f, _p, _p],
     'piml_self_features_fwd': [_p, _i, _p, _p, _z, _p, _p],
     'piml_self_features_bwd': [_p, _z, _p, _p, _p, _p],

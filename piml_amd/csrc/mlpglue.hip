@@ -111,10 +111,13 @@ __device__ __forceinline__ float2 block_sum2(float2 v, float2* sh) {
     return s;
 }
 
+// kp / ko >= 1: acc_ped / acc_obs hold kp / ko rows of 2 per agent (the bottleneck variants' per-neighbour predictions) and are
+// summed over them here (round 4: the training rollout's channelled frames took two torch reductions in front of this launch)
 __global__ __launch_bounds__(256) void pinnsf_epilogue_agentnorm_fwd_kernel(const float2* __restrict__ acc_ped,
                                                                              const float2* __restrict__ acc_obs,
                                                                              const float* __restrict__ sf, int N,
-                                                                             float tau, float2* __restrict__ out) {
+                                                                             float tau, float2* __restrict__ out, int kp = 1,
+                                                                             int ko = 1) {
     __shared__ float2 sh[4];
     const size_t base = (size_t)blockIdx.x * N;
     float2 sq = make_float2(0.f, 0.f);
@@ -129,9 +132,17 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_agentnorm_fwd_kernel(cons
     ty = (ty == 0.f) ? ty + 0.1f : ty;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const float* s = sf + (base + n) * 7;
-        float2 a = acc_ped[base + n];
+        float2 a = make_float2(0.f, 0.f);
+        for (int i = 0; i < kp; ++i) {
+            const float2 q = acc_ped[(base + n) * kp + i];
+            a.x += q.x; a.y += q.y;
+        }
         if (acc_obs) {
-            const float2 o = acc_obs[base + n];
+            float2 o = make_float2(0.f, 0.f);
+            for (int i = 0; i < ko; ++i) {
+                const float2 q = acc_obs[(base + n) * ko + i];
+                o.x += q.x; o.y += q.y;
+            }
             a.x += o.x;
             a.y += o.y;
         }
@@ -529,6 +540,18 @@ PIML_API int piml_pinnsf_epilogue_agentnorm_fwd(const float* acc_ped, const floa
     hipLaunchKernelGGL(pinnsf_epilogue_agentnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(acc_ped), reinterpret_cast<const float2*>(acc_obs),
                        self_features, N, tau, reinterpret_cast<float2*>(out));
+    return hipGetLastError();
+}
+
+PIML_API int piml_pinnsf_epilogue_ksum_agentnorm_fwd(const float* pred_ped, int kp, const float* pred_obs, int ko,
+                                                     const float* self_features, int C, int N, float tau, float* out,
+                                                     void* stream) {
+    if (C < 0 || N < 0 || kp < 1 || (pred_obs && ko < 1)) return hipErrorInvalidValue;
+    if (C == 0 || N == 0) return hipSuccess;
+    if (!pred_ped || !self_features || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pinnsf_epilogue_agentnorm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(pred_ped), reinterpret_cast<const float2*>(pred_obs), self_features, N, tau,
+                       reinterpret_cast<float2*>(out), kp, pred_obs ? ko : 1);
     return hipGetLastError();
 }
 

@@ -545,8 +545,9 @@ class _PINNSFBase(nn.Module):
         drawing = any(p.dropout_active() and p.keep_bits is None for p in (self.ped_processor, self.obs_processor))
         side = self.obs_stream if (self.obs_feature_dim > 0 and obs_features.is_cuda and not pre and not drawing) else None
         # bottleneck variants with a per-row |dest|: neighbour-axis sums + desired force in one launch (ops.pinnsf_epilogue_ksum)
+        # (round 4: also for channelled (C, N, 7) input with the reference's dim=1 norm, quirk Q2 -- the frames of the training rollout)
         ksum_tail = (self.bottleneck and FUSED_GLUE and FUSED_KSUM_TAIL and not self.residual and side is None and self_features.is_cuda
-                     and self_features.dtype == torch.float32 and (self_features.dim() == 2 or self.fix_dest_norm))
+                     and self_features.dtype == torch.float32 and (self_features.dim() in (2, 3) or self.fix_dest_norm))
         acc_o = None
         if self.obs_feature_dim > 0 and side is not None:      # fork: obstacle branch on the side stream
             side.wait_stream(torch.cuda.current_stream())
@@ -575,7 +576,8 @@ class _PINNSFBase(nn.Module):
                                                     rowdec=rowdec.get('obs'), want_sum=not ksum_tail)
         if ksum_tail:
             from .. import ops
-            predictions = ops.pinnsf_epilogue_ksum(ped_msgs, out_obs, self_features, self.tau)
+            predictions = ops.pinnsf_epilogue_ksum(ped_msgs, out_obs, self_features, self.tau,
+                                                   agent_norm=self_features.dim() == 3 and not self.fix_dest_norm)
         elif FUSED_GLUE and self_features.is_cuda and self_features.dtype == torch.float32 \
                 and (self_features.dim() in (2, 3) or self.fix_dest_norm):
             from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)

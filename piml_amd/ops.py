@@ -934,7 +934,7 @@ class _PinnsfEpilogue(torch.autograd.Function):
 
 class _PinnsfEpilogueKsum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred_ped, pred_obs, self_features, tau):
+    def forward(ctx, pred_ped, pred_obs, self_features, tau, agent_norm=False):
         sf = _gpu_f32('self_features', self_features)
         pp = _gpu_f32('pred_ped', pred_ped)
         po = _gpu_f32('pred_obs', pred_obs) if pred_obs is not None else None
@@ -942,9 +942,15 @@ class _PinnsfEpilogueKsum(torch.autograd.Function):
         kp, ko = pp.shape[-2], (po.shape[-2] if po is not None else 0)
         out = torch.empty(*sf.shape[:-1], 2, device=sf.device, dtype=torch.float32)
         with torch.cuda.device(sf.device):
-            _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_fwd(_ptr(pp), kp, _ptr(po), ko, _ptr(sf), rows, float(tau),
-                                                                _ptr(out), _stream()), 'piml_pinnsf_epilogue_ksum_fwd')
+            if agent_norm:      # (C, N, 7) input with the reference's dim=1 norm (quirk Q2)
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_agentnorm_fwd(_ptr(pp), kp, _ptr(po), ko, _ptr(sf), sf.shape[0], sf.shape[1],
+                                                                              float(tau), _ptr(out), _stream()),
+                           'piml_pinnsf_epilogue_ksum_agentnorm_fwd')
+            else:
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_fwd(_ptr(pp), kp, _ptr(po), ko, _ptr(sf), rows, float(tau),
+                                                                    _ptr(out), _stream()), 'piml_pinnsf_epilogue_ksum_fwd')
         ctx.save_for_backward(sf)
+        ctx.agent_norm = bool(agent_norm)
         ctx.meta = (float(tau), kp, ko, tuple(pp.shape), tuple(po.shape) if po is not None else None)
         ctx.set_materialize_grads(False)
         return out
@@ -962,21 +968,28 @@ class _PinnsfEpilogueKsum(torch.autograd.Function):
         g_pp = torch.empty(shp_p, **opt) if ctx.needs_input_grad[0] else None
         g_po = torch.empty(shp_o, **opt) if (shp_o is not None and ctx.needs_input_grad[1]) else None
         with torch.cuda.device(sf.device):
-            _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, tau, kp, ko, _ptr(g_self),
+            _lib.check(_lib.lib().piml_pinnsf_epilogue_ksum_bwd(_ptr(g), _ptr(sf), sf.numel() // 7, tau, kp, ko,
+                                                                None if ctx.agent_norm else _ptr(g_self),
                                                                 _ptr(g_pp), _ptr(g_po), _stream()),
                        'piml_pinnsf_epilogue_ksum_bwd')
-        return g_pp, g_po, g_self, None
+            if ctx.agent_norm and g_self is not None:
+                _lib.check(_lib.lib().piml_pinnsf_epilogue_agentnorm_bwd(_ptr(g), _ptr(sf), sf.shape[0], sf.shape[1], tau, _ptr(g_self),
+                                                                         _stream()), 'piml_pinnsf_epilogue_agentnorm_bwd')
+        return g_pp, g_po, g_self, None, None
 
 
-def pinnsf_epilogue_ksum(pred_ped, pred_obs, self_features, tau):
+def pinnsf_epilogue_ksum(pred_ped, pred_obs, self_features, tau, agent_norm=False):
     """Bottleneck variants: sum over the neighbour axis of pred_ped (..., kp, 2) [+ pred_obs (..., ko, 2) or None] + the
     desired-force term of self_features (..., 7), per-row |dest| (src/models/model.py:1116-1134) -- one launch per direction
-    instead of two reductions, two broadcasts and the epilogue."""
+    instead of two reductions, two broadcasts and the epilogue.  agent_norm=True ((C, N, 7) input only): the reference's
+    literal dim=1 norm over the agents of each slice (quirk Q2), as pinnsf_epilogue(agent_norm=True)."""
+    if agent_norm and self_features.dim() != 3:
+        raise ValueError('pinnsf_epilogue_ksum: agent_norm needs (C, N, 7) input')
     if self_features.shape[-1] != 7 or tuple(pred_ped.shape[:-2]) != tuple(self_features.shape[:-1]) or pred_ped.shape[-1] != 2:
         raise ValueError('pinnsf_epilogue_ksum: pred (..., k, 2) and self_features (..., 7) expected')
     if pred_obs is not None and (tuple(pred_obs.shape[:-2]) != tuple(self_features.shape[:-1]) or pred_obs.shape[-1] != 2):
         raise ValueError('pinnsf_epilogue_ksum: pred_obs (..., k, 2) must match self_features')
-    return _PinnsfEpilogueKsum.apply(pred_ped, pred_obs, self_features, tau)
+    return _PinnsfEpilogueKsum.apply(pred_ped, pred_obs, self_features, tau, bool(agent_norm))
 
 
 def pinnsf_epilogue(acc_ped, acc_obs, self_features, tau, agent_norm=False):
