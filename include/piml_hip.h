@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 25
+#define PIML_HIP_ABI_VERSION 26
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -278,6 +278,12 @@ int piml_collision_counts(const float* position, int S, int N, const float* thre
  */
 int piml_collision_counts_scratch(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                                   int* totals_zeroed, float* counts, void* stream);
+/* The same result from a per-frame cell grid (N <= 8192): one workgroup per slice bins its positions into cells of 1.02 x the
+ * largest threshold and tests the 3 x 3 block around every agent -- O(N x occupancy) pair tests per slice instead of N^2;
+ * two launches (totals, then counts), totals_zeroed as above. */
+int piml_collision_counts_grid(const float* position, int S, int N, const float* thresholds, int n_thresholds,
+                               int* totals_zeroed, float* counts, void* stream);
+
 
 /*
  * Pedestrians.calculate_collision_label (src/data/data.py:514-535): rows of >= 4 floats

@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
     'piml_collision_counts_scratch': [_p, _i, _i, _p, _i, _p, _p, _p],
+    'piml_collision_counts_grid': [_p, _i, _i, _p, _i, _p, _p, _p],
     'piml_collision_label': [_p, _z, _i, _p, _p],
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,

@@ -761,6 +761,123 @@ __global__ __launch_bounds__(256) void collision_counts_from_totals_kernel(const
         }
 }
 
+// Grid form of the many-slice path (round 4): a pair collides only within the largest threshold, so every frame is binned
+// once -- one workgroup per frame counting-sorts its N positions into a 32 x 32 torus of c x c cells (c = 1.02 x the largest
+// threshold; LDS atomics, one scan, one scatter) -- and an agent tests the 3 x 3 block around its cell: O(N x occupancy) pair
+// tests per frame instead of N^2.  PASS 0 adds every colliding ordered pair to totals[h][i][j] (integer atomics: exact in any
+// order); PASS 1 (a second launch) finds the same pairs again and counts those with 0 < total <= 25 (friends rule,
+// data.py:587-591).  Coordinates beyond 1e5 cells (or a non-finite cell size) make the frame's workgroup walk all pairs.
+// 750 x 1024: 0.97 ms (tiled two-sweep form above) -> see DESIGN.md 4.7.
+constexpr int CG_DIM = 32, CG_CELLS = CG_DIM * CG_DIM;
+
+template <int T, int PASS>
+__global__ __launch_bounds__(256) void collision_grid_kernel(const float2* __restrict__ p, int S, int N,
+                                                             const float* __restrict__ thr, int* __restrict__ totals,
+                                                             float* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned cg_lds[];
+    unsigned* const cnt = cg_lds;                                   // [CG_CELLS] counters -> start offsets
+    unsigned* const cur = cg_lds + CG_CELLS;                        // [CG_CELLS] scatter cursors
+    unsigned* const wsum = cur + CG_CELLS;                          // [4] wave totals + [1] overflow flag
+    float2* const sp = reinterpret_cast<float2*>(wsum + 8);         // [N] sorted positions
+    unsigned short* const si = reinterpret_cast<unsigned short*>(sp + N);   // [N] their agent indices
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2* row = p + (size_t)s * N;
+    float lim[T];
+    const bool use_sqrt = cc_limits<T>(thr, lim);
+    float tmax = 0.f;
+#pragma unroll
+    for (int h = 0; h < T; ++h) tmax = fmaxf(tmax, thr[h]);
+    const float c = tmax * 1.02f, inv_c = 1.f / c;
+    const bool grid_ok = c > 1e-18f && c < 1e18f;
+    for (int e = tid; e < CG_CELLS; e += 256) cnt[e] = 0;
+    if (tid == 0) wsum[4] = grid_ok ? 0u : 1u;
+    __syncthreads();
+    auto cell_of = [&](float2 q, bool& far) -> int {
+        const float fx = floorf(q.x * inv_c), fy = floorf(q.y * inv_c);
+        far = !(fabsf(fx) < 1e5f && fabsf(fy) < 1e5f);
+        return (((int)fy & (CG_DIM - 1)) << 5) | ((int)fx & (CG_DIM - 1));
+    };
+    bool any_far = false;
+    for (int n = tid; n < N; n += 256) {
+        const float2 q = row[n];
+        if (q.x != q.x || q.y != q.y) continue;                     // absent agents collide with nobody
+        bool far;
+        const int ce = cell_of(q, far);
+        any_far |= far;
+        atomicAdd(&cnt[ce], 1u);
+    }
+    if (any_far) wsum[4] = 1u;
+    __syncthreads();
+    // exclusive scan of the 1024 counters: thread t owns cells 4 t .. 4 t + 3
+    unsigned c4[4], tot = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { c4[u] = cnt[4 * tid + u]; tot += c4[u]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = (unsigned)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned run = inc - tot;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { cnt[4 * tid + u] = run; cur[4 * tid + u] = run; run += c4[u]; }
+    const bool overflow = wsum[4] != 0;
+    const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    if (!overflow)
+        for (int n = tid; n < N; n += 256) {
+            const float2 q = row[n];
+            if (q.x != q.x || q.y != q.y) continue;
+            bool far;
+            const unsigned pos = atomicAdd(&cur[cell_of(q, far)], 1u);
+            sp[pos] = q; si[pos] = (unsigned short)n;
+        }
+    __syncthreads();
+    // start(cell) = cnt[cell], end(cell) = cnt[cell + 1] (total for the last)
+    auto test = [&](int i, int j, float2 pi, float2 pj, int (&acc)[T]) {
+        if (i == j) return;
+        float x = sq2(pj.x - pi.x, pj.y - pi.y);                    // NaN compares false
+        if (use_sqrt) x = sqrtf(x);
+#pragma unroll
+        for (int h = 0; h < T; ++h)
+            if (x < lim[h]) {
+                if (PASS == 0) atomicAdd(totals + ((size_t)h * N + i) * N + j, 1);
+                else {
+                    const int t = totals[((size_t)h * N + i) * N + j];
+                    acc[h] += (t > 0 && t <= 25) ? 1 : 0;
+                }
+            }
+    };
+    for (int i = tid; i < N; i += 256) {
+        const float2 pi = row[i];
+        int acc[T];
+#pragma unroll
+        for (int h = 0; h < T; ++h) acc[h] = 0;
+        if (pi.x == pi.x && pi.y == pi.y) {
+            if (overflow) {
+                for (int j = 0; j < N; ++j) test(i, j, pi, row[j], acc);
+            } else {
+                const int fx = (int)floorf(pi.x * inv_c), fy = (int)floorf(pi.y * inv_c);
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int rowb = ((fy + dy) & (CG_DIM - 1)) << 5;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ce = rowb | ((fx + dx) & (CG_DIM - 1));
+                        const unsigned b0 = cnt[ce], b1 = ce + 1 < CG_CELLS ? cnt[ce + 1] : total;
+                        for (unsigned q = b0; q < b1; ++q) test(i, (int)si[q], pi, sp[q], acc);
+                    }
+                }
+            }
+        }
+        if (PASS == 1) {
+#pragma unroll
+            for (int h = 0; h < T; ++h) counts[((size_t)h * S + s) * N + i] = (float)acc[h];
+        }
+    }
+}
+
 // Fast path of collision_counts for stacks of at most 25 slices (the training rollouts: S = number
 // of windows in the batch): a pair can then collide in at most 25 slices, so the friends rule
 // (sum over slices <= 25, data.py:587-591) never removes anything and every slice is independent.
@@ -1017,6 +1134,39 @@ PIML_API int piml_collision_counts_scratch(const float* position, int S, int N, 
         default: PIML_CC2(4); break;
     }
 #undef PIML_CC2
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_counts_grid(const float* position, int S, int N, const float* thresholds, int n_thresholds,
+                                        int* totals_zeroed, float* counts, void* stream) {
+    if (S < 0 || N < 0 || n_thresholds < 0 || n_thresholds > kCollMaxThr || N > 8192) return hipErrorInvalidValue;
+    if ((long)S * N * n_thresholds == 0) return hipSuccess;
+    if (!position || !thresholds || !counts || !totals_zeroed) return hipErrorInvalidValue;
+    const size_t lds = (2 * piml::CG_CELLS + 8) * 4 + (size_t)N * 10 + 16;
+    const float2* pp = (const float2*)position;
+#define PIML_CG(T)                                                                                                                \
+    {                                                                                                                             \
+        static int attr = -1;                                                                                                     \
+        if (attr < 0) {                                                                                                           \
+            attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(piml::collision_grid_kernel<T, 0>),                     \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (2 * piml::CG_CELLS + 8) * 4 + 8192 * 10 + 16); \
+            if (!attr)                                                                                                            \
+                attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(piml::collision_grid_kernel<T, 1>),                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (2 * piml::CG_CELLS + 8) * 4 + 8192 * 10 + 16); \
+        }                                                                                                                         \
+        if (attr) return attr;                                                                                                    \
+        hipLaunchKernelGGL((piml::collision_grid_kernel<T, 0>), dim3(S), dim3(256), lds, as_stream(stream), pp, S, N, thresholds, \
+                           totals_zeroed, counts);                                                                                \
+        hipLaunchKernelGGL((piml::collision_grid_kernel<T, 1>), dim3(S), dim3(256), lds, as_stream(stream), pp, S, N, thresholds, \
+                           totals_zeroed, counts);                                                                                \
+    }
+    switch (n_thresholds) {
+        case 1: PIML_CG(1) break;
+        case 2: PIML_CG(2) break;
+        case 3: PIML_CG(3) break;
+        default: PIML_CG(4) break;
+    }
+#undef PIML_CG
     return hipGetLastError();
 }
 

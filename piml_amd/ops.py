@@ -594,6 +594,9 @@ def collision_detection(position, threshold, real_position=None):
 _THRESHOLDS = {}
 
 
+COLLISION_GRID = _os.environ.get('PIML_COLLISION_GRID', '1') != '0'
+
+
 def collision_counts(position, thresholds):
     """collision_detection(position (S,N,2), thr).sum(-1) for several thresholds in one sweep,
     without the (S,N,N) matrices.  Returns (len(thresholds), S, N)."""
@@ -610,8 +613,12 @@ def collision_counts(position, thresholds):
         if S > 25 and len(thresholds) <= 4 and len(thresholds) * N * N <= (1 << 28):
             # many slices (evaluation rollouts): the two-sweep parallel form with an (nthr, N, N) int32 scratch
             totals = torch.zeros(len(thresholds), N, N, device=p.device, dtype=torch.int32)
-            _lib.check(_lib.lib().piml_collision_counts_scratch(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(totals),
-                                                                _ptr(counts), _stream()), 'piml_collision_counts_scratch')
+            if N <= 8192 and COLLISION_GRID:       # per-frame cell grid: O(N x occupancy) pair tests per slice
+                _lib.check(_lib.lib().piml_collision_counts_grid(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(totals),
+                                                                 _ptr(counts), _stream()), 'piml_collision_counts_grid')
+            else:
+                _lib.check(_lib.lib().piml_collision_counts_scratch(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(totals),
+                                                                    _ptr(counts), _stream()), 'piml_collision_counts_scratch')
         else:
             _lib.check(_lib.lib().piml_collision_counts(_ptr(p), S, N, _ptr(thr), len(thresholds), _ptr(counts),
                                                         _stream()), 'piml_collision_counts')

@@ -195,3 +195,28 @@ def test_mlapm_rollout_matches_host_compaction_loop(oracle):
     m.rollout(*args, dt, radius, 300)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     print(f'MLAPM GC rollout N=4096: {300 / el:.0f} steps/s')
+
+
+def test_collision_counts_grid_form_equals_sweeps_and_oracle(oracle, monkeypatch):
+    """The per-frame cell-grid form of the many-slice path (piml_collision_counts_grid) against the two-sweep form and the
+    oracle: pairs that stay together for more than 25 frames (friends rule), distances exactly on a threshold, absent
+    agents, coordinates that alias on the 32 x 32 torus (a 60 m hall at 0.5 m cells), negative coordinates, and a frame
+    with a coordinate beyond the grid's trusted range (that workgroup walks all pairs)."""
+    from piml_amd import ops
+    rng = np.random.default_rng(11)
+    S, N = 60, 300
+    base = (rng.integers(-120, 120, size=(1, N, 2)) * 0.25).astype(np.float32)           # lattice over 60 m, negative too
+    p = base + (rng.integers(-1, 2, size=(S, N, 2)) * 0.25).astype(np.float32)            # jitter by lattice steps per frame
+    p[:, 10] = p[:, 11] + np.float32(0.25)                                                # a pair together in all 60 frames
+    p[:30, 20] = p[:30, 21]                                                               # ... in exactly 30
+    p[:20, 30] = p[:20, 31] + np.float32(0.5)                                             # exactly on the 0.5 threshold, 20 frames
+    p[rng.random((S, N)) < 0.05] = np.nan
+    p[7, 5] = (3.0e7, -2.0e7)                                                             # beyond 1e5 cells
+    thr = (0.5, 0.25)
+    want = [oracle.collision_detection(p, t).sum(-1) for t in thr]
+    for grid in (True, False):
+        monkeypatch.setattr(ops, 'COLLISION_GRID', grid)
+        got = ops.collision_counts(dev(p), thr).cpu().numpy()
+        for h in range(len(thr)):
+            assert np.array_equal(got[h], want[h]), (grid, thr[h], np.abs(got[h] - want[h]).max())
+    assert want[0].sum() > 0
