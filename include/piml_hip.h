@@ -733,7 +733,7 @@ int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream); 
  * keep-mask bits (rows, 4) int32 of piml_dropout_keep_bits in train mode (NULL: keep everything); weights in nn.Linear
  * layouts: wa (128, 128), ba (128), wb (1, 128), bb (1), wc (64, 128), bc (64), wd (2, 64), bd (2).
  * fwd writes hid (rows, 128; NULL for inference), score / attn (rows), pooled (agents, 128), chid (agents, 64), out (agents, 2).
- * bwd reads them and g_out (agents, 2); writes g_enc (rows, 128; NULL = not wanted); scratch g_pooled (agents, 128),
+ * bwd reads them (not `out`, which may be NULL there) and g_out (agents, 2); writes g_enc (rows, 128; NULL = not wanted); scratch g_pooled (agents, 128),
  *     g_score (rows), g_chid (agents, 64), partials_a = piml_corrector_slots(0, ..) x piml_corrector_partial_floats(0) floats, partials_b likewise
  *     with 1; grads = [dWa 128x128 | dba 128 | dwb 128 | dbb 1 | 3 pad | dWc 64x128 | dbc 64 | dWd 2x64 | dbd 2 | 2 pad];
  *     accumulate != 0: grads += (see piml_encoder_bwd_acc).  No atomics: bit-reproducible.

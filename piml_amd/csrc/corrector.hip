@@ -419,7 +419,7 @@ static int corrector_check(const piml_corrector* A, bool bwd) {
     if (!A || A->agents < 0 || A->k < 1 || A->k > 64 || A->agents * A->k >= (1ll << 31)) return hipErrorInvalidValue;
     if (A->agents == 0) return hipSuccess;
     if (!A->enc || !A->wa || !A->ba || !A->wb || !A->bb || !A->wc || !A->bc || !A->wd || !A->bd || !A->score || !A->attn ||
-        !A->pooled || !A->chid || !A->out)
+        !A->pooled || !A->chid || (!bwd && !A->out))
         return hipErrorInvalidValue;
     if (bwd && (!A->hid || !A->g_out || !A->g_pooled || !A->g_score || !A->g_chid || !A->partials_a || !A->partials_b || !A->grads))
         return hipErrorInvalidValue;

@@ -239,12 +239,9 @@ PIML_API int piml_rollout_losses_bwd(const float* g_out0, const float* g_out1, c
 PIML_API int piml_rollout_losses_frames_bwd(const float* g_mse_out, const float* g_collw_out, const float* g_hardw_out,
                                             const float* g_total_out, float w_coll, float w_hard, const float* g_mse,
                                             const float* g_coll, const float* g_hard, long long n, float* g_p, void* stream) {
-    if (!g_mse || !g_coll || !g_hard || !g_p || n < 1) return hipErrorInvalidValue;
-    static const float zero_host = 0.f;
-    (void)zero_host;
+    // (the weighted form is selected by a non-NULL total gradient: a caller without one passes a device zero)
+    if (!g_mse || !g_coll || !g_hard || !g_p || !g_total_out || n < 1) return hipErrorInvalidValue;
     long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
-    // g3 must be non-NULL for the weighted form: a missing total gradient is a device zero the caller passes
-    if (!g_total_out) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rollout_losses_bwd_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(LOSS_THREADS), 0, as_stream(stream),
                        g_mse_out, g_collw_out, g_hardw_out, g_mse, g_coll, g_hard, n, g_p, g_total_out, w_coll, w_hard);
     return hipGetLastError();

@@ -2733,8 +2733,6 @@ class _Corrector(torch.autograd.Function):
         C.hid, C.score, C.attn, C.pooled, C.chid, C.out = hid.data_ptr(), score.data_ptr(), attn.data_ptr(), pooled.data_ptr(), chid.data_ptr(), None
         C.g_out, C.g_pooled, C.g_score, C.g_chid, C.g_enc = g.data_ptr(), g_pooled.data_ptr(), g_score.data_ptr(), g_chid.data_ptr(), _ptr(g_enc)
         C.partials_a, C.partials_b, C.grads = parts_a.data_ptr(), parts_b.data_ptr(), grads.data_ptr()
-        out_dummy = torch.empty(1, **opt)
-        C.out = out_dummy.data_ptr()
         with torch.cuda.device(e2.device):
             _lib.check(L.piml_corrector_bwd(ctypes.byref(C), int(accumulate), _stream()), 'piml_corrector_bwd')
         A, B = grads[:pa], grads[pa:]
