@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 26
+#define PIML_HIP_ABI_VERSION 27
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -192,6 +192,20 @@ int piml_mlapm_step_bwd(const float* g_action, const float* position, const floa
                         float tau, float A, float B, float C, float D, float theta_deg, float radius,
                         float dt, float* g_position, float* g_velocity, float* g_desired_speed,
                         float* g_destination, void* stream);
+
+/*
+ * The same gradient with every ordered pair evaluated ONCE (raw and GC laws, N >= 512): a wavefront keeps 128 source
+ * agents in its lanes and rotates 64 focal agents -- with their focal-side sums -- through them, the two sides leave as
+ * partial rows in `workspace` (piml_mlapm_bwd_workspace_floats(N, variant) floats, 0 = this form does not apply) and a
+ * second launch adds an agent's rows in row order.  No atomics, fixed order.  With workspace == NULL, UCY or a small scene
+ * this IS piml_mlapm_step_bwd; a non-NULL workspace that is too small is hipErrorInvalidValue.
+ */
+long long piml_mlapm_bwd_workspace_floats(int N, int variant);
+int piml_mlapm_step_bwd_ws(const float* g_action, const float* position, const float* velocity,
+                           const float* desired_speed, const float* destination, int N, int variant,
+                           float tau, float A, float B, float C, float D, float theta_deg, float radius,
+                           float dt, float* g_position, float* g_velocity, float* g_desired_speed,
+                           float* g_destination, float* workspace, long long workspace_floats, void* stream);
 
 /*
  * Collision matrix, pair part of Pedestrians.collision_detection (src/data/data.py:549-564):

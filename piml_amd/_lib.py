@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 
@@ -66,6 +66,8 @@ SIGNATURES = {
                          _p, _p, _p, _i, _p, _p, _p],
     'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p, _p],
     'piml_mlapm_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p],
+    'piml_mlapm_bwd_workspace_floats': [_i, _i],
+    'piml_mlapm_step_bwd_ws': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _ll, _p],
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
     'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
@@ -198,6 +200,7 @@ def lib():
             fn.argtypes = args
             fn.restype = _i
         L.piml_encoder_split_tiles.restype = _ll
+        L.piml_mlapm_bwd_workspace_floats.restype = _ll
         L.piml_error_string.argtypes = [_i]
         L.piml_error_string.restype = ctypes.c_char_p
         if L.piml_abi_version() != ABI_VERSION:

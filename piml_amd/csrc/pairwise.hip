@@ -511,6 +511,144 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_kernel(
     }
 }
 
+// ---- backward, every ordered pair evaluated ONCE (round 4) ----
+// mlapm_bwd_kernel evaluates the ordered pair (f focal, s source) twice: in the wavefront that owns f and in the one that
+// owns s (2 N^2 evaluations for N^2 pairs), because each wavefront wants both of its agent's sums in its own registers.
+// Here a wavefront takes a 64-agent block X as focal agents and a 128-agent block O as sources: lane l keeps sources
+// o_l, o_(l+64) (position, velocity: 8 registers) and the focal records (p, v, e, G: 8 registers) travel through the lanes
+// by a one-lane wave rotation per step TOGETHER with their four focal-side sums, so after `steps` rotations every focal
+// agent has met every source of the block: the source-side sums stay where the source is (packed adds), the focal-side
+// sums ride with the focal agent (sum of the two packed elements), no atomics, no LDS, a fixed order.  The focal side of
+// (X, O) and the source side of (X-group, O) leave as partial rows; mlapm_bwd_sys_reduce_kernel adds an agent's rows in
+// row order and finishes with the desired-force terms.  `split` wavefronts share one (X, O) and do 64 / split steps each
+// (the focal records start rotated by h * 64 / split lanes) -- more wavefronts for small scenes.
+struct MlapmSysGeom {
+    int nxb, nob, gx, nxg, split, npad, focal_rows, rows;   // 64-blocks, 128-blocks, X blocks per wavefront, X groups
+};
+
+// (old == src: every lane is written, and the compiler may keep the value in place -- with old = 0 it spends a zero fill
+// and a copy around every rotation)
+__device__ __forceinline__ int wave_rot1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C, 0xF, 0xF, false); }
+__device__ __forceinline__ float wave_rot1(float v) { return __builtin_bit_cast(float, wave_rot1(__builtin_bit_cast(int, v))); }
+
+template <int VARIANT>
+__global__ __launch_bounds__(256) void mlapm_bwd_sys_kernel(
+        const float2* __restrict__ g_action, const float2* __restrict__ p, const float2* __restrict__ v,
+        const float2* __restrict__ dest, int N, MlapmParams P, float dt, MlapmSysGeom G, float4* __restrict__ part) {
+    MlapmParams Q = P;
+    Q.variant = VARIANT;                                    // the law's branches fold at compile time
+    const int lane = threadIdx.x & 63;
+    const int unit = uniform((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int h = unit % G.split, u = unit / G.split;
+    const int ob = u % G.nob, xg = u / G.nob;
+    if (xg >= G.nxg) return;
+    const float nan = __builtin_nanf("");
+    // sources: an agent past N is a NaN position -- d2 > 0 is false, the pair contributes exact zeros
+    const int o0 = ob * 128 + lane, o1 = o0 + 64;
+    const float2 p0 = o0 < N ? p[o0] : make_float2(nan, nan), p1 = o1 < N ? p[o1] : make_float2(nan, nan);
+    const float2 v0 = o0 < N ? v[o0] : make_float2(0.f, 0.f), v1 = o1 < N ? v[o1] : make_float2(0.f, 0.f);
+    const v2f opx = {p0.x, p1.x}, opy = {p0.y, p1.y}, ovx = {v0.x, v1.x}, ovy = {v0.y, v1.y};
+    v2f sax = {0.f, 0.f}, say = sax, sbx = sax, sby = sax;
+    const int steps = 64 / G.split;
+    for (int xb = xg * G.gx; xb < min(G.nxb, (xg + 1) * G.gx); ++xb) {
+        int xi = xb * 64 + ((lane + h * steps) & 63);
+        const bool in = xi < N;
+        const float2 px = in ? p[xi] : make_float2(nan, nan), vx = in ? v[xi] : make_float2(0.f, 0.f);
+        const float2 dx = in ? dest[xi] : make_float2(0.f, 0.f), ga = in ? g_action[xi] : make_float2(0.f, 0.f);
+        float ex = dx.x - px.x, ey = dx.y - px.y;
+        const float en = fmaxf(norm2(ex, ey), 1e-12f);
+        ex /= en; ey /= en;
+        float xpx = px.x, xpy = px.y, xvx = vx.x, xvy = vx.y, Gx = ga.x * dt, Gy = ga.y * dt;
+        float fax = 0.f, fay = 0.f, fbx = 0.f, fby = 0.f;
+        // a step: the focal records move on by one lane, meet the two sources of their new lane, and the focal-side sums
+        // follow them inside the addition itself (sum' = rotated sum + this pair's terms: one DPP add per sum)
+        for (int s = 0; s < steps; ++s) {
+            xpx = wave_rot1(xpx); xpy = wave_rot1(xpy); xvx = wave_rot1(xvx); xvy = wave_rot1(xvy);
+            ex = wave_rot1(ex); ey = wave_rot1(ey); Gx = wave_rot1(Gx); Gy = wave_rot1(Gy);
+            xi = wave_rot1(xi);
+            v2f ax, ay, bx, by;
+            mlapm_pair_grad2(Q, opx - v2f{xpx, xpx}, opy - v2f{xpy, xpy}, ovx - v2f{xvx, xvx}, ovy - v2f{xvy, xvy},
+                             v2f{xvx, xvx}, v2f{xvy, xvy}, v2f{ex, ex}, v2f{ey, ey}, v2f{Gx, Gx}, v2f{Gy, Gy}, ax, ay, bx, by);
+            sax += ax; say += ay; sbx += bx; sby += by;
+            fax = wave_rot1(fax) + (ax.x + ax.y); fay = wave_rot1(fay) + (ay.x + ay.y);
+            fbx = wave_rot1(fbx) + (bx.x + bx.y); fby = wave_rot1(fby) + (by.x + by.y);
+        }
+        // the focal agent loses what its sources gain
+        part[(size_t)(ob * G.split + h) * G.npad + xi] = make_float4(-fax, -fay, -fbx, -fby);
+    }
+    float4* row = part + (size_t)(G.focal_rows + xg * G.split + h) * G.npad;
+    row[o0] = make_float4(sax.x, say.x, sbx.x, sby.x);
+    row[o1] = make_float4(sax.y, say.y, sbx.y, sby.y);
+}
+
+// g_position / g_velocity = the partial rows of an agent in row order + the desired-force terms (the epilogue of
+// mlapm_bwd_kernel); 64 agents x 4 row slices per workgroup, the slices added in slice order.
+__global__ __launch_bounds__(256) void mlapm_bwd_sys_reduce_kernel(
+        const float4* __restrict__ part, int rows, int npad, const float2* __restrict__ g_action,
+        const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
+        const float2* __restrict__ dest, int N, MlapmParams P, float dt, float2* __restrict__ g_p,
+        float2* __restrict__ g_v, float* __restrict__ g_v0, float2* __restrict__ g_dest) {
+    __shared__ float4 red[4][64];
+    const int a = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + a;                      // < npad
+    const int per = (rows + 3) / 4, r0 = sl * per, r1 = min(rows, r0 + per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* q = part + (size_t)r0 * npad + x;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r, q += npad) {
+        const float4 t = *q;
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    red[sl][a] = s;
+    __syncthreads();
+    if (sl != 0 || x >= N) return;
+    for (int k = 1; k < 4; ++k) {
+        const float4 t = red[k][a];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const float2 px = p[x], dx = dest[x], ga = g_action[x];
+    float ex = dx.x - px.x, ey = dx.y - px.y;
+    const float dn = norm2(ex, ey), en = fmaxf(dn, 1e-12f);
+    ex /= en; ey /= en;
+    const float Gx = ga.x * dt, Gy = ga.y * dt;
+    // desired force (v0 e - v)/tau, e = d/|d| (mlapm.py:21-22), and action = v + F dt (:57)
+    const float v0x = v0[x];
+    const float ge = Gx * ex + Gy * ey;
+    g_v0[x] = ge / P.tau;
+    float tdx, tdy;
+    if (dn > 1e-12f) {
+        tdx = v0x / P.tau * (Gx - ge * ex) / dn;
+        tdy = v0x / P.tau * (Gy - ge * ey) / dn;
+    } else {
+        tdx = v0x / P.tau * Gx / 1e-12f; tdy = v0x / P.tau * Gy / 1e-12f;
+    }
+    g_dest[x] = make_float2(tdx, tdy);
+    g_p[x] = make_float2(s.x - tdx, s.y - tdy);
+    g_v[x] = make_float2(s.z + ga.x - Gx / P.tau, s.w + ga.y - Gy / P.tau);
+}
+
+// Geometry of the once-per-pair backward for N agents, or rows == 0 when mlapm_bwd_kernel is the launch (scenes below 512
+// agents: two launches cost what the pairs do -- 10.7 against 14.9 us at 512; UCY keeps its two-phase kernel).
+static MlapmSysGeom mlapm_sys_geom(int N, int variant) {
+    MlapmSysGeom G = {};
+    static const int off = getenv("PIML_MLAPM_BWD_SYS") ? atoi(getenv("PIML_MLAPM_BWD_SYS")) == 0 : 0;
+    static const int split_env = getenv("PIML_MLAPM_BWD_SPLIT") ? atoi(getenv("PIML_MLAPM_BWD_SPLIT")) : 0;
+    static const int min_n = getenv("PIML_MLAPM_BWD_SYS_MIN") ? atoi(getenv("PIML_MLAPM_BWD_SYS_MIN")) : 512;
+    if (off || variant == 2 || N < min_n) return G;
+    G.nxb = (N + 63) / 64; G.nob = (N + 127) / 128; G.npad = G.nob * 128;
+    // wavefronts per block pair (measured, GC law): 1 from 2048 pairs on (N = 4096: 41.8 us against 45.5 / 50.7 with 2 / 4),
+    // 2 from 256 pairs (N = 2048: 17.0 against 23.8 / 18.9 with 1 / 4), 4 below (N = 1024: 11.2 against 15.0 with 2)
+    const int pairs = G.nxb * G.nob;
+    G.split = (split_env == 1 || split_env == 2 || split_env == 4) ? split_env : (pairs >= 2048 ? 1 : pairs >= 256 ? 2 : 4);
+    // at most 8192 wavefronts: one X block per wavefront up to 8192 agents, more beyond (fewer partial rows)
+    G.gx = 1;
+    while ((long long)G.nob * ((G.nxb + G.gx - 1) / G.gx) * G.split > 8192 && G.gx < G.nxb) G.gx *= 2;
+    G.nxg = (G.nxb + G.gx - 1) / G.gx;
+    G.focal_rows = G.nob * G.split;
+    G.rows = G.focal_rows + G.nxg * G.split;
+    return G;
+}
+
 // ---- collision matrices (data.py:537-601) ----
 // coll[s,i,j] = [|p_j - p_i| < thr] (- 1 on the diagonal when `minus_identity`), NaN -> 0.
 __global__ void collision_pairs_kernel(const float2* __restrict__ p, int S, int N, float thr,
@@ -1041,6 +1179,45 @@ PIML_API int piml_mlapm_step_bwd(const float* g_action, const float* position, c
                            (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
                            (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
                            g_desired_speed, (float2*)g_destination);
+    return hipGetLastError();
+}
+
+PIML_API long long piml_mlapm_bwd_workspace_floats(int N, int variant) {
+    if (N <= 0 || variant < 0 || variant > 2) return 0;
+    const MlapmSysGeom G = mlapm_sys_geom(N, variant);
+    return (long long)G.rows * G.npad * 4;
+}
+
+PIML_API int piml_mlapm_step_bwd_ws(const float* g_action, const float* position, const float* velocity,
+                                    const float* desired_speed, const float* destination, int N, int variant,
+                                    float tau, float A, float B, float C, float D, float theta_deg, float radius,
+                                    float dt, float* g_position, float* g_velocity, float* g_desired_speed,
+                                    float* g_destination, float* workspace, long long workspace_floats, void* stream) {
+    if (N < 0 || variant < 0 || variant > 2 || workspace_floats < 0) return hipErrorInvalidValue;
+    const MlapmSysGeom G = N > 0 ? mlapm_sys_geom(N, variant) : MlapmSysGeom{};
+    const long long need = (long long)G.rows * G.npad * 4;
+    if (need == 0 || !workspace || workspace_floats < need)     // small scenes, UCY, or no room: the two-role kernel
+        return need && workspace ? hipErrorInvalidValue
+                                 : piml_mlapm_step_bwd(g_action, position, velocity, desired_speed, destination, N, variant, tau, A,
+                                                       B, C, D, theta_deg, radius, dt, g_position, g_velocity, g_desired_speed,
+                                                       g_destination, stream);
+    if (!g_action || !position || !velocity || !desired_speed || !destination || !g_position || !g_velocity ||
+        !g_desired_speed || !g_destination)
+        return hipErrorInvalidValue;
+    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
+    const int units = G.nob * G.nxg * G.split;
+    if (variant == 0)
+        hipLaunchKernelGGL(mlapm_bwd_sys_kernel<0>, dim3((units + 3) / 4), dim3(256), 0, as_stream(stream), (const float2*)g_action,
+                           (const float2*)position, (const float2*)velocity, (const float2*)destination, N, P, dt, G,
+                           (float4*)workspace);
+    else
+        hipLaunchKernelGGL(mlapm_bwd_sys_kernel<1>, dim3((units + 3) / 4), dim3(256), 0, as_stream(stream), (const float2*)g_action,
+                           (const float2*)position, (const float2*)velocity, (const float2*)destination, N, P, dt, G,
+                           (float4*)workspace);
+    hipLaunchKernelGGL(mlapm_bwd_sys_reduce_kernel, dim3(G.npad / 64), dim3(256), 0, as_stream(stream), (const float4*)workspace,
+                       G.rows, G.npad, (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
+                       (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity, g_desired_speed,
+                       (float2*)g_destination);
     return hipGetLastError();
 }
 

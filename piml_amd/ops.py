@@ -532,9 +532,12 @@ class _MlapmStep(torch.autograd.Function):
         gv0 = torch.empty(N, device=p.device, dtype=torch.float32)
         variant, tau, A, B, C, D, theta, radius, dt = ctx.params
         with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().piml_mlapm_step_bwd(_ptr(g), _ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau,
-                                                      A, B, C, D, theta, radius, dt, _ptr(gp), _ptr(gv), _ptr(gv0),
-                                                      _ptr(gd), _stream()), 'piml_mlapm_step_bwd')
+            L = _lib.lib()
+            need = int(L.piml_mlapm_bwd_workspace_floats(N, variant))    # 0: the two-role kernel (small scenes, UCY)
+            ws = torch.empty(need, device=p.device, dtype=torch.float32) if need else None
+            _lib.check(L.piml_mlapm_step_bwd_ws(_ptr(g), _ptr(p), _ptr(v), _ptr(v0), _ptr(d), N, variant, tau,
+                                                A, B, C, D, theta, radius, dt, _ptr(gp), _ptr(gv), _ptr(gv0),
+                                                _ptr(gd), _ptr(ws) if need else None, need, _stream()), 'piml_mlapm_step_bwd_ws')
         return (gp, gv, gv0.reshape(ctx.v0_shape), gd) + (None,) * 10
 
 

@@ -92,6 +92,101 @@ def test_mlapm_nan_poisons_like_reference():
     assert torch.isnan(act).all()
 
 
+_LAWS = dict(raw=dict(tau=0.5, A=7.55, B=-3.0), GC=dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56))
+
+
+def _mlapm_bwd_direct(entry, sc, w, ver, workspace=None):
+    """piml_mlapm_step_bwd / piml_mlapm_step_bwd_ws through the C ABI on the same inputs"""
+    from piml_amd import _lib, ops
+    pr = dict(C=0.0, D=0.0, theta=0.0)
+    pr.update(_LAWS[ver])
+    p, v, v0, d = [dev(sc[k]) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    N = p.shape[0]
+    out = [torch.full((N, 2), float('nan'), device=DEV), torch.full((N, 2), float('nan'), device=DEV),
+           torch.full((N,), float('nan'), device=DEV), torch.full((N, 2), float('nan'), device=DEV)]
+    ptr = lambda t: t.data_ptr()
+    args = [ptr(w), ptr(p), ptr(v), ptr(v0), ptr(d), N, ops.MLAPM_VARIANTS[ver], pr['tau'], pr['A'], pr['B'], pr['C'], pr['D'],
+            pr['theta'], 0.3, 0.08, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3])]
+    L = _lib.lib()
+    if entry == 'ws':
+        need = int(L.piml_mlapm_bwd_workspace_floats(N, ops.MLAPM_VARIANTS[ver]))
+        assert need > 0
+        ws = torch.full((need,), float('nan'), device=DEV) if workspace is None else workspace
+        rc = L.piml_mlapm_step_bwd_ws(*args, ptr(ws), ws.numel(), None)
+    else:
+        rc = L.piml_mlapm_step_bwd(*args, None)
+    torch.cuda.synchronize()
+    return rc, [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC'])
+@pytest.mark.parametrize('N', [512, 1000, 2048, 2111, 4096, 9000])
+def test_mlapm_backward_once_per_pair_matches_two_role_kernel(ver, N):
+    """The rotating-focal-agent backward (every ordered pair once, partial rows, fixed order) against the kernel that
+    evaluates both roles in the owning wavefront: the same pair terms, sums in a different order."""
+    sc = synthetic_gc_scene(N, 0, seed=11, nan_frac=0.0)
+    w = torch.randn(N, 2, device=DEV, generator=torch.Generator(DEV).manual_seed(N))
+    rc0, ref = _mlapm_bwd_direct('two_role', sc, w, ver)
+    rc1, got = _mlapm_bwd_direct('ws', sc, w, ver)
+    assert rc0 == 0 and rc1 == 0
+    for g, r, name in zip(got, ref, ('gp', 'gv', 'gv0', 'gdest')):
+        assert np.isfinite(g).all(), name
+        assert np.abs(g - r).max() <= 5e-6 * max(np.abs(r).max(), 1e-3), (name, np.abs(g - r).max(), np.abs(r).max())
+    rc2, again = _mlapm_bwd_direct('ws', sc, w, ver)
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))       # fixed order: bitwise repeatable
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC'])
+def test_mlapm_backward_float64_large(ver):
+    """ops.mlapm_step's gradient at a size the once-per-pair backward serves (N >= 512; ragged blocks) against autograd
+    through a float64 statement of mlapm.py:10-41.  (The reference's own autograd pins the same path at N = 1024:
+    test_mlapm_backward_matches_reference_autograd.)"""
+    from piml_amd import ops
+    N = 2111
+    pr = dict(C=0.0, D=0.0, theta=0.0)
+    pr.update(_LAWS[ver])
+    sc = synthetic_gc_scene(N, 0, seed=5, nan_frac=0.0)
+    w = torch.randn(N, 2, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    leaves = [dev(sc[k]).requires_grad_(True) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    act = ops.mlapm_step(*leaves, 0.08, 0.3, version=ver, **_LAWS[ver])
+    got = torch.autograd.grad(act, leaves, w)
+    p, v, v0, d = [dev(sc[k]).double().requires_grad_(True) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    e = torch.nn.functional.normalize(d - p, dim=-1)
+    force = (v0.reshape(-1, 1) * e - v) / pr['tau']
+    vr = p[None, :, :] - p[:, None, :]                      # [focal, source]
+    r = vr.norm(dim=-1, keepdim=True)
+    n = torch.nn.functional.normalize(vr, dim=-1)
+    view = ((v[:, None, :] * vr).sum(-1, keepdim=True) > 0).double()
+    if ver == 'raw':
+        term = view * pr['A'] * (pr['B'] * r).exp() * n
+    else:
+        vv = v[None, :, :] - v[:, None, :]
+        cs = torch.nn.functional.cosine_similarity(vr, vv, dim=-1).unsqueeze(-1)
+        cr = vr[..., 0] * e[:, None, 1] - vr[..., 1] * e[:, None, 0]
+        th = torch.where(cr > 0, -1.0, 1.0) * (pr['theta'] / 180 * np.pi)       # -sign(cr) theta, 0 -> +theta
+        c, s_ = th.cos(), th.sin()
+        direc = torch.stack([c * n[..., 0] - s_ * n[..., 1], s_ * n[..., 0] + c * n[..., 1]], dim=-1)
+        term = view * pr['A'] * (pr['B'] * r + pr['C'] * cs + pr['D'] * r * cs).exp() * direc
+    act64 = v + (force - term.sum(dim=1)) * 0.08
+    assert rel_err(act.detach().cpu().numpy(), act64.detach().cpu().numpy(), 1e-3) < REL
+    ref = torch.autograd.grad(act64, [p, v, v0, d], w.double())
+    for g, r_, name in zip(got, ref, ('gp', 'gv', 'gv0', 'gdest')):
+        g, r_ = g.cpu().numpy().reshape(-1), r_.cpu().numpy().reshape(-1)
+        assert np.abs(g - r_).max() <= 2e-5 * max(np.abs(r_).max(), 1e-3), (name, np.abs(g - r_).max(), np.abs(r_).max())
+
+
+def test_mlapm_backward_workspace_contract():
+    from piml_amd import _lib
+    L = _lib.lib()
+    assert L.piml_mlapm_bwd_workspace_floats(256, 1) == 0           # small scenes keep the two-role kernel
+    assert L.piml_mlapm_bwd_workspace_floats(4096, 2) == 0          # UCY keeps its two-phase kernel
+    assert L.piml_mlapm_bwd_workspace_floats(4096, 1) > 0
+    sc = synthetic_gc_scene(2048, 0, seed=2, nan_frac=0.0)
+    w = torch.ones(2048, 2, device=DEV)
+    rc, _ = _mlapm_bwd_direct('ws', sc, w, 'GC', workspace=torch.empty(1024, device=DEV))
+    assert rc != 0                                                  # a workspace that is too small is an error, not a fallback
+
+
 def test_collision_detection_matches_reference():
     from piml_amd.pedestrians import Pedestrians as P
     g = golden('collision_gc')
