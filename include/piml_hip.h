@@ -194,11 +194,12 @@ int piml_mlapm_step_bwd(const float* g_action, const float* position, const floa
                         float* g_destination, void* stream);
 
 /*
- * The same gradient with every ordered pair evaluated ONCE (raw and GC laws, N >= 512): a wavefront keeps 128 source
- * agents in its lanes and rotates 64 focal agents -- with their focal-side sums -- through them, the two sides leave as
- * partial rows in `workspace` (piml_mlapm_bwd_workspace_floats(N, variant) floats, 0 = this form does not apply) and a
- * second launch adds an agent's rows in row order.  No atomics, fixed order.  With workspace == NULL, UCY or a small scene
- * this IS piml_mlapm_step_bwd; a non-NULL workspace that is too small is hipErrorInvalidValue.
+ * The same gradient with every ordered pair evaluated ONCE (N >= 512): a wavefront keeps 128 source agents in its lanes and
+ * rotates 64 focal agents -- with their focal-side sums -- through them, the two sides leave as partial rows in `workspace`
+ * (piml_mlapm_bwd_workspace_floats(N, variant) floats, 0 = this form does not apply) and a second launch adds an agent's
+ * rows in a fixed order (UCY: the rotating pass gives every pair its flag-off term, the second launch -- a wavefront per
+ * agent -- adds [flag on] - [flag off] for the pairs the exact predicate flags).  No atomics.  With workspace == NULL or a
+ * small scene this IS piml_mlapm_step_bwd; a non-NULL workspace that is too small is hipErrorInvalidValue.
  */
 long long piml_mlapm_bwd_workspace_floats(int N, int variant);
 int piml_mlapm_step_bwd_ws(const float* g_action, const float* position, const float* velocity,

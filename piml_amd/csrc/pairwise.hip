@@ -627,6 +627,104 @@ __global__ __launch_bounds__(256) void mlapm_bwd_sys_reduce_kernel(
     g_v[x] = make_float2(s.z + ga.x - Gx / P.tau, s.w + ga.y - Gy / P.tau);
 }
 
+// UCY on the once-per-pair backward: mlapm_bwd_sys_kernel<2> gives every ordered pair its flag-off term (g = 1); this
+// kernel -- one wavefront per agent like mlapm_bwd_kernel -- finds the pairs the conservative distance test cannot rule out
+// (see mlapm_pair2_ucy), gives them the exact predicate once and adds [flag on] - [flag off] for both roles of a flagged
+// pair, then adds the agent's partial rows (lane = row, wave sum) and finishes like mlapm_bwd_sys_reduce_kernel.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mlapm_bwd_ucy_fix_kernel(
+        const float4* __restrict__ part, int rows, int npad, const float2* __restrict__ g_action,
+        const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
+        const float2* __restrict__ dest, int N, MlapmParams P, float dt, float2* __restrict__ g_p,
+        float2* __restrict__ g_v, float* __restrict__ g_v0, float2* __restrict__ g_dest) {
+    __shared__ float4 tile_pv[kMlTile];                     // (px, py, vx, vy)
+    __shared__ float4 tile_eg[kMlTile];                     // (ex, ey, Gx, Gy), G = dt * g_action
+    __shared__ unsigned short ring_all[WAVES][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * WAVES + wave;
+    const bool has = x < N;
+    const float2 px = p[has ? x : 0], vx = v[has ? x : 0], dx = dest[has ? x : 0], ga = g_action[has ? x : 0];
+    float ex = dx.x - px.x, ey = dx.y - px.y;
+    const float dn = norm2(ex, ey), en = fmaxf(dn, 1e-12f);
+    ex /= en; ey /= en;
+    const float Gx = ga.x * dt, Gy = ga.y * dt;
+    float spx = 0.f, spy = 0.f, svx = 0.f, svy = 0.f;
+    unsigned short* ring = ring_all[uniform(wave)];
+    const float lim = 1e-6f + P.r2 * P.r2;
+    for (int base = 0; base < N; base += kMlTile) {
+        const int tn = min(kMlTile, N - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn; t += WAVES * 64) {
+            const float2 a = p[base + t], b = v[base + t], d = dest[base + t], g = g_action[base + t];
+            float qx = d.x - a.x, qy = d.y - a.y;
+            const float qn = fmaxf(norm2(qx, qy), 1e-12f);
+            tile_pv[t] = make_float4(a.x, a.y, b.x, b.y);
+            tile_eg[t] = make_float4(qx / qn, qy / qn, g.x * dt, g.y * dt);
+        }
+        __syncthreads();
+        if (!has) continue;
+        unsigned head = 0, tail = 0;
+        for (int j0 = 0;; j0 += 64) {
+            const bool more = j0 < tn;
+            if (more) {
+                const int j = j0 + lane;
+                const bool in = j < tn;
+                const float4 s = tile_pv[in ? j : 0];
+                const float rx = s.x - px.x, ry = s.y - px.y, wx = s.z - vx.x, wy = s.w - vx.y;
+                const float d2 = rx * rx + ry * ry, w2 = wx * wx + wy * wy;
+                const float a = d2 * fast_rsq(d2) - w2 * fast_rsq(fmaxf(w2, 1e-30f));
+                const bool near = in && !(a > 0.f && a * a > 1e-6f * d2 + lim);
+                const u64 m = __builtin_amdgcn_ballot_w64(near);
+                if (m) {
+                    if (near) ring[(tail + mbcnt(m)) & 127] = (unsigned short)j;
+                    tail += (unsigned)__builtin_popcountll(m);
+                }
+            }
+            while (tail - head >= (more ? 64u : 1u)) {
+                const unsigned n = min(64u, tail - head);
+                __builtin_amdgcn_wave_barrier();
+                if ((unsigned)lane < n) {
+                    const int j = ring[(head + lane) & 127];
+                    const float4 s = tile_pv[j], t = tile_eg[j];
+                    const float rx = s.x - px.x, ry = s.y - px.y, wx = s.z - vx.x, wy = s.w - vx.y;
+                    if (ucy_collision(rx, ry, wx, wy, P.r2)) {
+                        float a1x, a1y, b1x, b1y, a0x, a0y, b0x, b0y;
+                        mlapm_pair_grad(P, rx, ry, wx, wy, vx.x, vx.y, ex, ey, Gx, Gy, a1x, a1y, b1x, b1y, 1);      // x focal
+                        mlapm_pair_grad(P, rx, ry, wx, wy, vx.x, vx.y, ex, ey, Gx, Gy, a0x, a0y, b0x, b0y, 0);
+                        spx -= a1x - a0x; spy -= a1y - a0y; svx -= b1x - b0x; svy -= b1y - b0y;
+                        mlapm_pair_grad(P, -rx, -ry, -wx, -wy, s.z, s.w, t.x, t.y, t.z, t.w, a1x, a1y, b1x, b1y, 1);  // o focal
+                        mlapm_pair_grad(P, -rx, -ry, -wx, -wy, s.z, s.w, t.x, t.y, t.z, t.w, a0x, a0y, b0x, b0y, 0);
+                        spx += a1x - a0x; spy += a1y - a0y; svx += b1x - b0x; svy += b1y - b0y;
+                    }
+                }
+                head += n;
+            }
+            if (!more) break;
+        }
+    }
+    if (!has) return;
+    for (int r = lane; r < rows; r += 64) {
+        const float4 t = part[(size_t)r * npad + x];
+        spx += t.x; spy += t.y; svx += t.z; svy += t.w;
+    }
+    spx = wave_sum(spx); spy = wave_sum(spy); svx = wave_sum(svx); svy = wave_sum(svy);
+    if (lane == 0) {
+        const float v0x = v0[x];
+        const float ge = Gx * ex + Gy * ey;
+        g_v0[x] = ge / P.tau;
+        float tdx, tdy;
+        if (dn > 1e-12f) {
+            tdx = v0x / P.tau * (Gx - ge * ex) / dn;
+            tdy = v0x / P.tau * (Gy - ge * ey) / dn;
+        } else {
+            tdx = v0x / P.tau * Gx / 1e-12f; tdy = v0x / P.tau * Gy / 1e-12f;
+        }
+        g_dest[x] = make_float2(tdx, tdy);
+        g_p[x] = make_float2(spx - tdx, spy - tdy);
+        g_v[x] = make_float2(svx + ga.x - Gx / P.tau, svy + ga.y - Gy / P.tau);
+    }
+}
+
 // Geometry of the once-per-pair backward for N agents, or rows == 0 when mlapm_bwd_kernel is the launch (scenes below 512
 // agents: two launches cost what the pairs do -- 10.7 against 14.9 us at 512; UCY keeps its two-phase kernel).
 static MlapmSysGeom mlapm_sys_geom(int N, int variant) {
@@ -634,7 +732,8 @@ static MlapmSysGeom mlapm_sys_geom(int N, int variant) {
     static const int off = getenv("PIML_MLAPM_BWD_SYS") ? atoi(getenv("PIML_MLAPM_BWD_SYS")) == 0 : 0;
     static const int split_env = getenv("PIML_MLAPM_BWD_SPLIT") ? atoi(getenv("PIML_MLAPM_BWD_SPLIT")) : 0;
     static const int min_n = getenv("PIML_MLAPM_BWD_SYS_MIN") ? atoi(getenv("PIML_MLAPM_BWD_SYS_MIN")) : 512;
-    if (off || variant == 2 || N < min_n) return G;
+    static const bool two_phase_off = getenv("PIML_MLAPM_UCY_TWO_PHASE") && atoi(getenv("PIML_MLAPM_UCY_TWO_PHASE")) == 0;
+    if (off || (variant == 2 && two_phase_off) || N < min_n) return G;
     G.nxb = (N + 63) / 64; G.nob = (N + 127) / 128; G.npad = G.nob * 128;
     // wavefronts per block pair (measured, GC law): 1 from 2048 pairs on (N = 4096: 41.8 us against 45.5 / 50.7 with 2 / 4),
     // 2 from 256 pairs (N = 2048: 17.0 against 23.8 / 18.9 with 1 / 4), 4 below (N = 1024: 11.2 against 15.0 with 2)
@@ -1196,7 +1295,7 @@ PIML_API int piml_mlapm_step_bwd_ws(const float* g_action, const float* position
     if (N < 0 || variant < 0 || variant > 2 || workspace_floats < 0) return hipErrorInvalidValue;
     const MlapmSysGeom G = N > 0 ? mlapm_sys_geom(N, variant) : MlapmSysGeom{};
     const long long need = (long long)G.rows * G.npad * 4;
-    if (need == 0 || !workspace || workspace_floats < need)     // small scenes, UCY, or no room: the two-role kernel
+    if (need == 0 || !workspace || workspace_floats < need)     // small scenes or no workspace: the two-role kernel
         return need && workspace ? hipErrorInvalidValue
                                  : piml_mlapm_step_bwd(g_action, position, velocity, desired_speed, destination, N, variant, tau, A,
                                                        B, C, D, theta_deg, radius, dt, g_position, g_velocity, g_desired_speed,
@@ -1206,18 +1305,23 @@ PIML_API int piml_mlapm_step_bwd_ws(const float* g_action, const float* position
         return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
     const int units = G.nob * G.nxg * G.split;
-    if (variant == 0)
-        hipLaunchKernelGGL(mlapm_bwd_sys_kernel<0>, dim3((units + 3) / 4), dim3(256), 0, as_stream(stream), (const float2*)g_action,
-                           (const float2*)position, (const float2*)velocity, (const float2*)destination, N, P, dt, G,
-                           (float4*)workspace);
-    else
-        hipLaunchKernelGGL(mlapm_bwd_sys_kernel<1>, dim3((units + 3) / 4), dim3(256), 0, as_stream(stream), (const float2*)g_action,
-                           (const float2*)position, (const float2*)velocity, (const float2*)destination, N, P, dt, G,
-                           (float4*)workspace);
-    hipLaunchKernelGGL(mlapm_bwd_sys_reduce_kernel, dim3(G.npad / 64), dim3(256), 0, as_stream(stream), (const float4*)workspace,
-                       G.rows, G.npad, (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
-                       (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity, g_desired_speed,
-                       (float2*)g_destination);
+#define PIML_SYS_LAUNCH(V)                                                                                                      \
+    hipLaunchKernelGGL(mlapm_bwd_sys_kernel<V>, dim3((units + 3) / 4), dim3(256), 0, as_stream(stream), (const float2*)g_action, \
+                       (const float2*)position, (const float2*)velocity, (const float2*)destination, N, P, dt, G,               \
+                       (float4*)workspace)
+#define PIML_SYS_FINISH(KERNEL, GRID, BLOCK)                                                                                    \
+    hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, as_stream(stream), (const float4*)workspace, G.rows, G.npad,         \
+                       (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,                \
+                       (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity, g_desired_speed,         \
+                       (float2*)g_destination)
+    if (variant == 0) PIML_SYS_LAUNCH(0);
+    else if (variant == 1) PIML_SYS_LAUNCH(1);
+    else PIML_SYS_LAUNCH(2);
+    if (variant != 2) PIML_SYS_FINISH(mlapm_bwd_sys_reduce_kernel, G.npad / 64, 256);
+    else if (N >= 4096) PIML_SYS_FINISH(mlapm_bwd_ucy_fix_kernel<16>, (N + 15) / 16, 1024);
+    else PIML_SYS_FINISH(mlapm_bwd_ucy_fix_kernel<4>, (N + 3) / 4, 256);
+#undef PIML_SYS_LAUNCH
+#undef PIML_SYS_FINISH
     return hipGetLastError();
 }
 

@@ -92,7 +92,8 @@ def test_mlapm_nan_poisons_like_reference():
     assert torch.isnan(act).all()
 
 
-_LAWS = dict(raw=dict(tau=0.5, A=7.55, B=-3.0), GC=dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56))
+_LAWS = dict(raw=dict(tau=0.5, A=7.55, B=-3.0), GC=dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56),
+             UCY=dict(tau=5 / 6, A=10.67, B=-3.33, C=0.5, theta=20))
 
 
 def _mlapm_bwd_direct(entry, sc, w, ver, workspace=None):
@@ -119,11 +120,12 @@ def _mlapm_bwd_direct(entry, sc, w, ver, workspace=None):
     return rc, [o.cpu().numpy() for o in out]
 
 
-@pytest.mark.parametrize('ver', ['raw', 'GC'])
+@pytest.mark.parametrize('ver', ['raw', 'GC', 'UCY'])
 @pytest.mark.parametrize('N', [512, 1000, 2048, 2111, 4096, 9000])
 def test_mlapm_backward_once_per_pair_matches_two_role_kernel(ver, N):
     """The rotating-focal-agent backward (every ordered pair once, partial rows, fixed order) against the kernel that
-    evaluates both roles in the owning wavefront: the same pair terms, sums in a different order."""
+    evaluates both roles in the owning wavefront: the same pair terms, sums in a different order.  (UCY: the flag-off terms
+    once per pair, the flagged pairs' differences from a wavefront per agent -- the exact predicate decides in both.)"""
     sc = synthetic_gc_scene(N, 0, seed=11, nan_frac=0.0)
     w = torch.randn(N, 2, device=DEV, generator=torch.Generator(DEV).manual_seed(N))
     rc0, ref = _mlapm_bwd_direct('two_role', sc, w, ver)
@@ -179,7 +181,7 @@ def test_mlapm_backward_workspace_contract():
     from piml_amd import _lib
     L = _lib.lib()
     assert L.piml_mlapm_bwd_workspace_floats(256, 1) == 0           # small scenes keep the two-role kernel
-    assert L.piml_mlapm_bwd_workspace_floats(4096, 2) == 0          # UCY keeps its two-phase kernel
+    assert L.piml_mlapm_bwd_workspace_floats(4096, 2) > 0
     assert L.piml_mlapm_bwd_workspace_floats(4096, 1) > 0
     sc = synthetic_gc_scene(2048, 0, seed=2, nan_frac=0.0)
     w = torch.ones(2048, 2, device=DEV)

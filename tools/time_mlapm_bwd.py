@@ -8,7 +8,8 @@ from piml_amd import _lib, ops
 from piml_amd.scenes import synthetic_gc_scene
 
 dev = 'cuda:0'
-LAWS = (('raw', dict(tau=0.5, A=7.55, B=-3.0, C=0.0, D=0.0, theta=0.0)), ('GC', dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56.0)))
+LAWS = (('raw', dict(tau=0.5, A=7.55, B=-3.0, C=0.0, D=0.0, theta=0.0)), ('GC', dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56.0)),
+        ('UCY', dict(tau=5 / 6, A=10.67, B=-3.33, C=0.5, D=0.0, theta=20.0)))
 L = _lib.lib()
 for N in [int(a) for a in sys.argv[1:]] or (2048, 4096, 8192, 16384):
     sc = synthetic_gc_scene(N, 0, seed=0, nan_frac=0.0)
