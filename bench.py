@@ -232,16 +232,32 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
     bwd_us = max(fb_us - fwd_us, 0.0)
     del keep
     bytes_fwd = 16 * m * m + 36 * m
-    return {'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
+    # the neighbour search in the shape every rank of the 8-GPU run launches (cfg4: 2048 focal rows against 16384 sources)
+    try:
+        from piml_amd.scenes import synthetic_gc_scene
+        big = synthetic_gc_scene(16384, int(np.asarray(scene['obstacles']).reshape(-1, 2).shape[0]), seed=0)
+        state = torch.tensor(np.concatenate([big['position'], big['velocity'], big['acceleration']], axis=-1), device=dev)
+        obs = torch.tensor(big['obstacles'], device=dev)
+        d_rows = torch.tensor(big['destination'][:2048], device=dev)
+        outs = ops.relative_features_packed(state, d_rows, obs, 0, 2048, return_index=True)
+        shard_us = timed(lambda: ops.relative_features_packed_into(outs, state, d_rows, obs, 0, 2048), reps=100)
+        shard = {'focal_rows': 2048, 'sources': 16384, 'obstacle_points': int(obs.shape[0]), 'fwd_us': shard_us,
+                 'note': 'relfeat_fwd_kernel for one rank\'s agent block of the cfg4 scene (back-to-back launches, HIP events)'}
+        del state, obs, d_rows, outs
+    except Exception as ex:   # noqa: BLE001 - informational
+        shard = {'error': f'{type(ex).__name__}: {ex}'}
+    return {'relfeat_shard_shape': shard,
+            'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
                               'pairs_per_s_fwd': m * m / fwd_us * 1e6,
                               'operand_stream_gbs_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9,
                               'bound': 'valu',
                               'valu_busy_frac_fwd': ((prof or {}).get('mlapm') or {}).get('fwd_valu_busy_frac'),
                               'valu_busy_frac_bwd': ((prof or {}).get('mlapm') or {}).get('bwd_valu_busy_frac'),
-                              'valu_busy_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles, profiles/r03_step_counters.json '
-                                                  '(rocprofv3 --pmc, committed: static)' if (prof or {}).get('mlapm') else None,
+                              'valu_busy_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles of the two-role backward / the forward, '
+                                                  'committed rocprofv3 --pmc pass (static)' if (prof or {}).get('mlapm') else None,
                               'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
-                                      'present agents of the same scene; forward: back-to-back eager launches; backward: (forward + backward '
+                                      'present agents of the same scene; forward: back-to-back eager launches; backward (every ordered pair '
+                                      'evaluated once: mlapm_bwd_sys_kernel + its partial-row launch): (forward + backward '
                                       'replayed from one captured HIP graph) - forward, HIP events'}}
 
 
@@ -940,6 +956,18 @@ def main():
                     e['bound'], e['valu_busy_frac'] = sk.get('bound'), sk.get('frac')
                 e['counters_source'] = prof_src
             kernels.append(e)
+        # registers / spills of the kernels named above, read from the code objects inside the library this process loaded
+        try:
+            usage = _lib.kernel_resource_usage()
+        except Exception as ex:   # noqa: BLE001 - informational
+            usage = {}
+        for e in kernels:
+            vs = {k: v for k, v in usage.items() if k.split('<')[0] == e['name']}
+            if vs:
+                e['registers'] = {'variants_in_library': len(vs), 'vgprs_max': max(v['vgprs'] for v in vs.values()),
+                                  'agprs_max': max(v['agprs'] or 0 for v in vs.values()),
+                                  'vgpr_spill_max': max(v['vgpr_spill'] for v in vs.values()),
+                                  'scratch_bytes_max': max(v['scratch_bytes'] for v in vs.values())}
         if not stage_us:      # no live trace (sharded / eager / library MLP): the committed profile's entries, marked as such
             for k in (prof or {}).get('other_kernels', []):
                 kernels.append(dict(k, us_source=prof_src))
@@ -976,7 +1004,12 @@ def main():
                                        '8 B/obstacle pair + 488 B/focal agent) / ms_per_step / (n_gpus x HBM peak); the sources '
                                        'are LDS/L2 resident, so real HBM traffic (`traffic`, PMC) is far below this model and '
                                        'the step is bound by the MLP kernels (HBM traffic of the saved activations / matrix pipe) and VALU issue, see `kernels`',
-                         'kernels': kernels},
+                         'kernels': kernels,
+                         'kernels_with_vgpr_spills': sorted(k for k, v in usage.items() if v['vgpr_spill']),
+                         'kernels_with_vgpr_spills_note': 'every kernel of libpiml_hip.so with a non-zero .vgpr_spill_count in its code '
+                                                          'object (kernels[].registers: the same source; vgprs = .vgpr_count, which counts '
+                                                          'architectural + accumulation registers together); both are A/B forms the default dispatch does not launch '
+                                                          '(PIML_DEC_BWD_SPLIT=0, PIML_ENC_FUSED_BWD=2; profiles/r04_kernel_usage.md)'},
         }
     import threading
     written = threading.Lock()
@@ -1124,6 +1157,9 @@ def main():
         out['single_gpu_same_scene'] = same_scene_1gpu
     if secondary is not None:
         out['secondary'] = secondary
+        shard = (secondary.get('relfeat_shard_shape') or {}).get('fwd_us')
+        if shard is not None and out['roofline']['kernels'] and out['roofline']['kernels'][0]['name'] == 'relfeat_fwd_kernel':
+            out['roofline']['kernels'][0]['shard_shape_us'] = shard      # 2048 focal rows x 16384 sources (secondary.relfeat_shard_shape)
     if rank == 0 and args.cpu_seconds > 0 and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline(scene, N, M_eff, args.cpu_seconds)

@@ -209,6 +209,82 @@ def lib():
     return _lib
 
 
+def _demangle_lite(sym):
+    """`_ZN4piml23enc_fwd_x3_kernelILi0EEEvNS_7EncArgsE` -> `enc_fwd_x3_kernel<0>`: the nested name's last component and
+    its literal template arguments (bool / int), which is all this library's kernels use."""
+    import re
+    i = 2
+    if sym[i:i + 1] == 'N':
+        i += 1
+    name = None
+    while i < len(sym) and sym[i].isdigit():
+        m = re.match(r'\d+', sym[i:])
+        n = int(m.group())
+        name = sym[i + m.end():i + m.end() + n]
+        i += m.end() + n
+    if name is None:
+        return sym
+    if sym[i:i + 1] == 'I':
+        args, i = [], i + 1
+        while sym[i:i + 1] == 'L':
+            m = re.match(r'L([bi])(n?\d+)E', sym[i:])
+            if not m:
+                break
+            v = int(m.group(2).replace('n', '-'))
+            args.append(('true' if v else 'false') if m.group(1) == 'b' else str(v))
+            i += m.end()
+        if args:
+            name += '<' + ', '.join(args) + '>'
+    return name
+
+
+def kernel_resource_usage(path=None):
+    """{kernel name: {vgprs, agprs, vgpr_spill, sgpr_spill, scratch_bytes, lds_bytes, symbol}} of every kernel IN the library
+    file (default: the one this process loads), read from the code objects' own metadata -- the NT_AMDGPU_METADATA notes of
+    the gfx950 ELFs in the file's offload bundles -- not from a build log.  bench.py prints the entries of the step's kernels;
+    tests/test_abi.py holds every kernel the default dispatch reaches to vgpr_spill == 0."""
+    import struct
+    import msgpack
+    blob = open(path or LIB_PATH, 'rb').read()
+    magic, out, at = b'__CLANG_OFFLOAD_BUNDLE__', {}, 0
+    while True:
+        at = blob.find(magic, at)
+        if at < 0:
+            break
+        n, = struct.unpack_from('<Q', blob, at + 24)
+        off = at + 32
+        for _ in range(n):
+            o, size, tl = struct.unpack_from('<QQQ', blob, off)
+            triple = blob[off + 24:off + 24 + tl]
+            off += 24 + tl
+            elf = blob[at + o:at + o + size]
+            if b'gfx950' not in triple or elf[:4] != b'\x7fELF':
+                continue
+            shoff, = struct.unpack_from('<Q', elf, 0x28)
+            shentsize, shnum = struct.unpack_from('<HH', elf, 0x3A)
+            for k in range(shnum):
+                sh_type, = struct.unpack_from('<I', elf, shoff + k * shentsize + 4)
+                if sh_type != 7:      # SHT_NOTE
+                    continue
+                q, sz = struct.unpack_from('<QQ', elf, shoff + k * shentsize + 0x18)
+                end = q + sz
+                while q + 12 <= end:
+                    namesz, descsz, typ = struct.unpack_from('<III', elf, q)
+                    q += 12 + ((namesz + 3) & ~3)
+                    desc = elf[q:q + descsz]
+                    q += (descsz + 3) & ~3
+                    if typ != 32:     # NT_AMDGPU_METADATA
+                        continue
+                    for kd in msgpack.unpackb(desc, raw=False).get('amdhsa.kernels', []):
+                        out[_demangle_lite(kd['.name'])] = {
+                            'vgprs': kd.get('.vgpr_count'), 'agprs': kd.get('.agpr_count'),
+                            'vgpr_spill': kd.get('.vgpr_spill_count'), 'sgpr_spill': kd.get('.sgpr_spill_count'),
+                            'scratch_bytes': kd.get('.private_segment_fixed_size'),
+                            'lds_bytes': kd.get('.group_segment_fixed_size'), 'symbol': kd['.name']}
+        at += len(magic)
+    return out
+
+
 def check(err, what):
     if err != 0:
         raise PimlHipError(f'{what} failed: hipError {err} ({lib().piml_error_string(err).decode()})')

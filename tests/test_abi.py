@@ -111,3 +111,19 @@ def test_tuning_file_is_consistent():
     keys = [(f[0], f[1]) for f in ops_]
     assert len(keys) == len(set(keys))
     assert tuning.LOADED is False                               # nothing is loaded on import
+
+
+def test_no_kernel_of_the_default_dispatch_spills():
+    """Register / scratch figures straight from the code objects inside libpiml_hip.so (`_lib.kernel_resource_usage`): the only
+    kernels with a non-zero spill count are the two A/B forms the default dispatch never launches (profiles/r04_kernel_usage.md:
+    `PIML_DEC_BWD_SPLIT=0`, `PIML_ENC_FUSED_BWD=2`)."""
+    from piml_amd import _lib
+    usage = _lib.kernel_resource_usage()
+    assert len(usage) > 150 and not [k for k in usage if k.startswith('_Z')]
+    for name in ('relfeat_fwd_kernel<16, false>', 'enc_fwd_x3_kernel<0>', 'enc_bwd_fused_x3_kernel<true, false, false, true>',
+                 'dec_fwd_head_kernel<true>', 'dec_bwd_split_kernel', 'relfeat_bwd_reduce_kernel', 'mlapm_bwd_sys_kernel<1>'):
+        assert name in usage, name
+    not_reached = {'dec_bwd_kernel', 'enc_bwd_fused8_x3_kernel<true, true, true, false>'}
+    # (scalar registers parked in lanes of a vector register -- `sgpr_spill`, no memory traffic -- are not counted)
+    spilling = {k: v['vgpr_spill'] for k, v in usage.items() if v['vgpr_spill']}
+    assert set(spilling) <= not_reached, spilling
