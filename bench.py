@@ -253,7 +253,7 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
                               'bound': 'valu',
                               'valu_busy_frac_fwd': ((prof or {}).get('mlapm') or {}).get('fwd_valu_busy_frac'),
                               'valu_busy_frac_bwd': ((prof or {}).get('mlapm') or {}).get('bwd_valu_busy_frac'),
-                              'valu_busy_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles of the two-role backward / the forward, '
+                              'valu_busy_source': 'SQ_ACTIVE_INST_VALU share of the SIMD cycles of mlapm_fwd_kernel / mlapm_bwd_sys_kernel, '
                                                   'committed rocprofv3 --pmc pass (static)' if (prof or {}).get('mlapm') else None,
                               'note': 'closed-form social force (MLAPM.step, GC variant) forward / analytic backward, '
                                       'present agents of the same scene; forward: back-to-back eager launches; backward (every ordered pair '

@@ -121,7 +121,8 @@ try:
     mlapm = {}
     for kname, c in mp.items():
         for tagk in ('fwd', 'bwd'):
-            if f'mlapm_{tagk}_kernel' in kname and c.get('SQ_BUSY_CU_CYCLES'):
+            # backward: the once-per-pair kernel (round 4: mlapm_bwd_sys_kernel), or the two-role kernel it replaced
+            if (f'mlapm_{tagk}_kernel' in kname or (tagk == 'bwd' and 'mlapm_bwd_sys_kernel' in kname)) and c.get('SQ_BUSY_CU_CYCLES'):
                 mlapm[f'{tagk}_valu_busy_frac'] = round(4 * c['SQ_ACTIVE_INST_VALU'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
                 mlapm[f'{tagk}_valu_insts_per_wave'] = round(c.get('SQ_INSTS_VALU', 0.0) / max(c.get('SQ_WAVES', 1.0), 1.0), 1)
 except (IndexError, FileNotFoundError):
