@@ -26,10 +26,19 @@ for N in (1024, 4096, 16384):
     for ver, pr in (('raw', dict(tau=0.5, A=7.55, B=-3.0)), ('GC', dict(tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56)),
                     ('UCY', dict(tau=5 / 6, A=10.67, B=-3.33, C=0.5, theta=20))):
         us = timeit(lambda: ops.mlapm_step(p, v, v0, d, 0.08, 0.3, version=ver, **pr))
-        pg = [x.clone().requires_grad_(True) for x in (p, v, v0, d)]
-        act = ops.mlapm_step(*pg, 0.08, 0.3, version=ver, **pr)
-        w = torch.randn_like(act)
-        usb = timeit(lambda: torch.autograd.grad(act, pg, w, retain_graph=True), reps=50)
+        # backward through the C entry the operator calls (an eager autograd.grad costs ~95 us of host time per call, more
+        # than the kernels below 8192 agents)
+        from piml_amd import _lib
+        L = _lib.lib()
+        q = dict(C=0.0, D=0.0, theta=0.0); q.update(pr)
+        w = torch.randn(N, 2, device=dev)
+        outs = [torch.empty(N, 2, device=dev), torch.empty(N, 2, device=dev), torch.empty(N, device=dev), torch.empty(N, 2, device=dev)]
+        var = ops.MLAPM_VARIANTS[ver]
+        need = int(L.piml_mlapm_bwd_workspace_floats(N, var))
+        ws = torch.empty(max(need, 1), device=dev)
+        args = [w.data_ptr(), p.data_ptr(), v.data_ptr(), v0.data_ptr(), d.data_ptr(), N, var, q['tau'], q['A'], q['B'], q['C'], q['D'],
+                float(q['theta']), 0.3, 0.08] + [o.data_ptr() for o in outs] + [ws.data_ptr() if need else None, need, None]
+        usb = timeit(lambda: L.piml_mlapm_step_bwd_ws(*args), reps=50)
         print(f'MLAPM {ver:3s} N={N}: fwd {us:8.1f} us ({N * N / us * 1e6:.3e} pairs/s, alg {16 * N * N / us / 1e3:.0f} GB/s)   bwd {usb:8.1f} us')
     if N <= 4096:
         pc = torch.tensor(synthetic_gc_scene(N, 0, seed=1, channels=4)['position'], device=dev)
