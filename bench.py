@@ -246,7 +246,51 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
         del state, obs, d_rows, outs
     except Exception as ex:   # noqa: BLE001 - informational
         shard = {'error': f'{type(ex).__name__}: {ex}'}
-    return {'relfeat_shard_shape': shard,
+    # the metric's second half: simulated steps per second of the same 4096-agent scene (inference, no gradients)
+    sim = {}
+    try:
+        import time as _time
+        from piml_amd.models.mlapm import MLAPM
+        mm = MLAPM(**gc)
+        mm.rollout(p, v, v0, d, 0.08, 0.3, 60)
+        torch.cuda.synchronize()
+        t0 = _time.perf_counter()
+        mm.rollout(p, v, v0, d, 0.08, 0.3, 2000)
+        torch.cuda.synchronize()
+        el = _time.perf_counter() - t0
+        sim['mlapm_gc'] = {'agents': m, 'steps_per_s': 2000 / el, 'us_per_step': el / 2000 * 1e6,
+                           'note': 'MLAPM.rollout (src/main_mlapm.py:18-36): a frame = ONE launch (piml_mlapm_rollout_step: state read '
+                                   'from the trajectory, arrivals leave, device-side frame counter), 8 frames per captured HIP graph; '
+                                   'wall clock over 2000 frames incl. the capture and the allocation of the trajectories'}
+    except Exception as ex:   # noqa: BLE001 - informational
+        sim['mlapm_gc'] = {'error': f'{type(ex).__name__}: {ex}'}
+    try:
+        import time as _time
+        from piml_amd.scenes import synthetic_rollout_data
+        from piml_amd.models.simulators import BaseSimulator
+        from piml_amd.main import get_args
+        a = get_args(['--dataset_name', 'gc1560', '--model', 'pinnsf_m'])
+        a.ped_feature_dim, a.obs_feature_dim, a.self_feature_dim, a.device = 6, 6, 7, str(dev)
+        a.exp_name, a.model_name_suffix = 'bench', 'bench'
+        T = 200
+        data = synthetic_rollout_data(n, int(np.asarray(scene['obstacles']).reshape(-1, 2).shape[0]), T, dev)
+        simulator = BaseSimulator(a)
+        simulator.model.eval()
+        with torch.no_grad():
+            simulator.get_multiple_rollouts(data, 0, load_model=False)
+            torch.cuda.synchronize()
+            t0 = _time.perf_counter()
+            simulator.get_multiple_rollouts(data, 0, load_model=False)
+            torch.cuda.synchronize()
+            el = _time.perf_counter() - t0
+        sim['pinnsf_m'] = {'agents': n, 'steps_per_s': T / el, 'us_per_step': el / T * 1e6,
+                           'note': 'BaseSimulator.get_multiple_rollouts (src/models/simulators.py:552-657), PINNSF_multitask eval(), '
+                                   'random-init weights: relfeat forward + fused network forward + integrator epilogue per frame, one '
+                                   'captured frame replayed; wall clock over 200 frames'}
+        del data, simulator
+    except Exception as ex:   # noqa: BLE001 - informational
+        sim['pinnsf_m'] = {'error': f'{type(ex).__name__}: {ex}'}
+    return {'relfeat_shard_shape': shard, 'simulated_steps': sim,
             'mlapm_gc_step': {'agents': m, 'pairs': m * m, 'fwd_us': fwd_us, 'bwd_us': bwd_us,
                               'pairs_per_s_fwd': m * m / fwd_us * 1e6,
                               'operand_stream_gbs_fwd': bytes_fwd / (fwd_us * 1e-6) / 1e9,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 27
+#define PIML_HIP_ABI_VERSION 28
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -180,6 +180,18 @@ int piml_mlapm_step_fwd(const float* position, const float* velocity, const floa
                         const float* destination, int N, int variant, float tau, float A, float B,
                         float C, float D, float theta_deg, float radius, float dt, int skip_absent,
                         float* action, float* force, void* stream);
+
+/*
+ * One frame of the simulation loop of src/main_mlapm.py:18-36 in ONE launch: the state of frame t - 1 = *frame_counter - 1 is
+ * read from the trajectories (frames, N, 2) themselves -- an agent within `radius` of its destination in a frame >= 1 is absent
+ * (NaN) from the next frame on, absent agents contribute nothing (skip_absent) -- MLAPM.step's velocity and p + v dt are
+ * written to frame t, and the last workgroup to finish sets *frame_counter = t + 1 (done_counter: a zeroed device word).
+ * Frame 0 is the caller's initial state.  A launch with *frame_counter outside [1, frames) does nothing.
+ */
+int piml_mlapm_rollout_step(float* traj_position, float* traj_velocity, const float* desired_speed,
+                            const float* destination, long long frames, int N, int variant, float tau, float A,
+                            float B, float C, float D, float theta_deg, float radius, float dt,
+                            long long* frame_counter, unsigned* done_counter, void* stream);
 
 /*
  * Analytic gradient of piml_mlapm_step_fwd (what autograd gives through mlapm.py:10-58):

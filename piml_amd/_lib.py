@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 
@@ -66,6 +66,7 @@ SIGNATURES = {
                          _p, _p, _p, _i, _p, _p, _p],
     'piml_mlapm_step_fwd': [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p, _p],
     'piml_mlapm_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p],
+    'piml_mlapm_rollout_step': [_p, _p, _p, _p, _ll, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p],
     'piml_mlapm_bwd_workspace_floats': [_i, _i],
     'piml_mlapm_step_bwd_ws': [_p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _ll, _p],
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],

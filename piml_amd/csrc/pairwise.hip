@@ -179,17 +179,54 @@ __device__ __forceinline__ float2 mlapm_ucy_correction(const MlapmParams& P, flo
     return make_float2(s * (P.cth * nx - st * ny), s * (st * nx + P.cth * ny));
 }
 
-template <int WAVES>
+// ROLL: one frame of the simulation loop of src/main_mlapm.py:18-36 in this launch.  The state of frame t - 1 is read from
+// the trajectory itself -- an agent that came within `radius` of its destination in frame t - 1 >= 1 is absent (NaN) from
+// frame t on (:34; frame 0 is the caller's initial state, not tested) -- the new velocity and p + v dt go to frame t, and the
+// last workgroup to finish moves the device-side frame counter on: a frame is ONE launch, K frames one captured graph.
+struct MlapmRoll {
+    float2* traj_p;              // (frames, N, 2)
+    float2* traj_v;
+    long long* t;                // frame to produce (device side)
+    unsigned* done;              // workgroups that finished this launch
+    long long frames;
+    float radius;
+};
+
+template <bool ROLL>
+__device__ __forceinline__ void mlapm_state(const float2* __restrict__ p, const float2* __restrict__ v, const float2* __restrict__ dest,
+                                            int j, bool test_arrival, float radius, float2& a, float2& b) {
+    a = p[j]; b = v[j];
+    if (ROLL && test_arrival) {
+        const float2 d = dest[j];
+        if (norm2(a.x - d.x, a.y - d.y) < radius) {                 // NaN compares false: absent stays absent
+            const float nan = __builtin_nanf("");
+            a = make_float2(nan, nan); b = a;
+        }
+    }
+}
+
+template <int WAVES, bool ROLL = false>
 __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         const float2* __restrict__ p, const float2* __restrict__ v, const float* __restrict__ v0,
         const float2* __restrict__ dest, int N, MlapmParams P, float dt, float2* __restrict__ action,
-        float2* __restrict__ force) {
+        float2* __restrict__ force, MlapmRoll Rr) {
     __shared__ float4 tile[kMlTile];                        // (px, py, vx, vy)
     __shared__ unsigned short ucy_ring[WAVES][256];        // UCY: tile-local indices of the pairs that need the exact predicate
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * WAVES + wave;
     const bool has = i < N;
-    const float2 pi = p[has ? i : 0], vi = v[has ? i : 0], di = dest[has ? i : 0];
+    bool test_arrival = false;
+    long long tf = 0;
+    if (ROLL) {
+        tf = *Rr.t;
+        if (tf < 1 || tf >= Rr.frames) return;              // past the trajectory: nothing to do (the counter stays)
+        p = Rr.traj_p + (tf - 1) * N; v = Rr.traj_v + (tf - 1) * N;
+        action = Rr.traj_v + tf * N;
+        test_arrival = tf - 1 >= 1;
+    }
+    float2 pi, vi;
+    mlapm_state<ROLL>(p, v, dest, has ? i : 0, test_arrival, Rr.radius, pi, vi);
+    const float2 di = dest[has ? i : 0];
     float ex = di.x - pi.x, ey = di.y - pi.y;
     const float en = fmaxf(norm2(ex, ey), 1e-12f);          // :21
     ex /= en; ey /= en;
@@ -199,7 +236,8 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         const int tn = min(kMlTile, N - base);
         __syncthreads();
         for (int t = threadIdx.x; t < tn; t += WAVES * 64) {
-            const float2 a = p[base + t], b = v[base + t];
+            float2 a, b;
+            mlapm_state<ROLL>(p, v, dest, base + t, test_arrival, Rr.radius, a, b);
             tile[t] = make_float4(a.x, a.y, b.x, b.y);
         }
         __syncthreads();
@@ -280,7 +318,19 @@ __global__ __launch_bounds__(WAVES * 64) void mlapm_fwd_kernel(
         const float fx = (v0i * ex - vi.x) / P.tau - sx;    // :22, :29/:40/:53
         const float fy = (v0i * ey - vi.y) / P.tau - sy;
         if (force) force[i] = make_float2(fx, fy);
-        action[i] = make_float2(vi.x + fx * dt, vi.y + fy * dt);   // :57
+        const float2 vn = make_float2(vi.x + fx * dt, vi.y + fy * dt);   // :57
+        action[i] = vn;
+        if (ROLL) Rr.traj_p[tf * N + i] = make_float2(pi.x + vn.x * dt, pi.y + vn.y * dt);   // main_mlapm.py:25 (explicit Euler)
+    }
+    if (ROLL) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(Rr.done, 1u) == gridDim.x - 1) {       // every workgroup has read the counter and written its rows
+                *Rr.done = 0u;
+                *Rr.t = tf + 1;
+            }
+        }
     }
 }
 
@@ -1249,11 +1299,30 @@ PIML_API int piml_mlapm_step_fwd(const float* position, const float* velocity, c
     if (N >= 4096)
         hipLaunchKernelGGL(mlapm_fwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),
                            (const float2*)position, (const float2*)velocity, desired_speed,
-                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force);
+                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force, MlapmRoll{});
     else
         hipLaunchKernelGGL(mlapm_fwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream),
                            (const float2*)position, (const float2*)velocity, desired_speed,
-                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force);
+                           (const float2*)destination, N, P, dt, (float2*)action, (float2*)force, MlapmRoll{});
+    return hipGetLastError();
+}
+
+PIML_API int piml_mlapm_rollout_step(float* traj_position, float* traj_velocity, const float* desired_speed,
+                                     const float* destination, long long frames, int N, int variant, float tau, float A,
+                                     float B, float C, float D, float theta_deg, float radius, float dt,
+                                     long long* frame_counter, unsigned* done_counter, void* stream) {
+    if (N < 0 || frames < 0 || variant < 0 || variant > 2) return hipErrorInvalidValue;
+    if (N == 0 || frames < 2) return hipSuccess;
+    if (!traj_position || !traj_velocity || !desired_speed || !destination || !frame_counter || !done_counter)
+        return hipErrorInvalidValue;
+    const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius, 1);
+    const MlapmRoll Rr = {(float2*)traj_position, (float2*)traj_velocity, frame_counter, done_counter, frames, radius};
+    if (N >= 4096)
+        hipLaunchKernelGGL((mlapm_fwd_kernel<16, true>), dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream), nullptr, nullptr,
+                           desired_speed, (const float2*)destination, N, P, dt, nullptr, nullptr, Rr);
+    else
+        hipLaunchKernelGGL((mlapm_fwd_kernel<4, true>), dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), nullptr, nullptr,
+                           desired_speed, (const float2*)destination, N, P, dt, nullptr, nullptr, Rr);
     return hipGetLastError();
 }
 

@@ -552,6 +552,30 @@ def mlapm_step(position, velocity, desired_speed, destination, dt, radius=0.3, v
                             float(dt), bool(skip_absent))
 
 
+def mlapm_rollout_step(traj_position, traj_velocity, desired_speed, destination, frame_counter, done_counter, dt, radius=0.3,
+                       version='GC', tau=0.5, A=0.0, B=0.0, C=0.0, D=0.0, theta=0.0):
+    """One frame of the simulation loop of src/main_mlapm.py:18-36 in one launch (piml_mlapm_rollout_step): reads frame
+    `frame_counter - 1` of the (frames, N, 2) trajectories (agents that arrived in it are absent from now on), writes frame
+    `frame_counter` and advances the counter on the device.  frame_counter: int64 (1,), done_counter: zeroed int32 (1,).
+    No autograd (inference)."""
+    if version not in MLAPM_VARIANTS:
+        raise NotImplementedError(version)
+    tp, tv = _gpu_f32('traj_position', traj_position), _gpu_f32('traj_velocity', traj_velocity)
+    v0, d = _gpu_f32('desired_speed', desired_speed), _gpu_f32('destination', destination)
+    if tp.dim() != 3 or tp.shape != tv.shape or tp.shape[-1] != 2 or not (tp.is_contiguous() and tv.is_contiguous()):
+        raise ValueError('trajectories must be contiguous (frames, N, 2)')
+    frames, N = int(tp.shape[0]), int(tp.shape[1])
+    if v0.numel() != N or tuple(d.shape) != (N, 2):
+        raise ValueError('desired_speed (N, 1) and destination (N, 2) expected')
+    if frame_counter.dtype != torch.int64 or done_counter.dtype != torch.int32 or not (frame_counter.is_cuda and done_counter.is_cuda):
+        raise ValueError('frame_counter: int64 (1,), done_counter: int32 (1,), both on the GPU')
+    with torch.cuda.device(tp.device):
+        _lib.check(_lib.lib().piml_mlapm_rollout_step(_ptr(tp), _ptr(tv), _ptr(v0.contiguous()), _ptr(d.contiguous()), frames, N,
+                                                      MLAPM_VARIANTS[version], float(tau), float(A), float(B), float(C), float(D),
+                                                      float(theta), float(radius), float(dt), _ptr(frame_counter),
+                                                      _ptr(done_counter), _stream()), 'piml_mlapm_rollout_step')
+
+
 # ------------------------------------------------------------------------------------------
 # collisions (Pedestrians.collision_detection / calculate_collision_label)
 # ------------------------------------------------------------------------------------------

@@ -123,3 +123,31 @@ def algorithmic_bytes(N, M, kind='pinsf'):
     if kind == 'pinsf':
         return N * (24 * N + 8 * M) + 488 * N
     return 16 * N * N + 36 * N
+
+
+def synthetic_rollout_data(N, M, T, dev, seed=0):
+    """A RawData-shaped clip of T frames of the synthetic scene for `BaseSimulator.get_multiple_rollouts` (frame 0 is the
+    scene, the rest is what the rollout overwrites): the container fields of src/data/data.py's RawData that the rollout of
+    src/models/simulators.py:552-657 reads.  Used by bench.py (`secondary.simulated_steps`) and tools/time_rollout.py."""
+    import types
+    import torch
+    from .pedestrians import Pedestrians
+    sc = synthetic_gc_scene(N, M, seed=seed)
+    t = lambda x: torch.tensor(x, device=dev)
+    rep = lambda x: t(x).unsqueeze(0).repeat(T, *([1] * x.ndim)).contiguous()
+    d = types.SimpleNamespace()
+    d.position, d.velocity, d.acceleration, d.destination = [rep(sc[k]) for k in ('position', 'velocity', 'acceleration', 'destination')]
+    d.velocity = torch.nan_to_num(d.velocity)
+    d.obstacles = t(sc['obstacles'])
+    far = sc['destination'] + (sc['destination'] - np.nan_to_num(sc['position'])) * 100
+    d.waypoints = torch.stack((t(sc['destination']), t(far.astype(np.float32))))
+    d.dest_num = torch.full((N,), 2, device=dev, dtype=torch.long)
+    d.dest_idx = torch.zeros(T, N, device=dev, dtype=torch.long)
+    present = (~torch.isnan(d.position[..., 0])).float()
+    d.mask_p, d.mask_p_pred = present, present.clone()
+    d.num_frames, d.time_unit, d.meta_data = T, 0.08, None
+    pf, of, df = Pedestrians().get_relative_features(d.position[:1].clone(), d.velocity[:1].clone(), d.acceleration[:1].clone(),
+                                                     d.destination[:1].clone(), d.obstacles, 6, 90, 4, 10, 90, 4)
+    d.ped_features, d.obs_features = pf.repeat(T, 1, 1, 1), of.repeat(T, 1, 1, 1)
+    d.self_features = torch.cat((df, d.velocity[:1], d.acceleration[:1], t(sc['desired_speed']).unsqueeze(0)), -1).repeat(T, 1, 1)
+    return d

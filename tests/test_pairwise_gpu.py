@@ -261,9 +261,12 @@ def test_mlapm_rollout_matches_host_compaction_loop(oracle):
     tau, A, B, C, D, theta = g['GC_params']
     p0, v0_, spd, dst = g['GC_N7_p'], g['GC_N7_v'], g['GC_N7_v0'], g['GC_N7_dest']
     steps, dt, radius = 200, 0.08, 0.3
-    traj_p, traj_v = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps)
-    eager_p, _ = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps, use_graph=False)
-    assert torch.equal(torch.nan_to_num(traj_p), torch.nan_to_num(eager_p))
+    traj_p, traj_v = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps)      # one launch per frame, 8 frames per graph
+    eager_p, eager_v = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps, use_graph=False)
+    assert torch.equal(torch.nan_to_num(traj_p), torch.nan_to_num(eager_p)) and torch.equal(torch.nan_to_num(traj_v), torch.nan_to_num(eager_v))
+    seq_p, seq_v = m.rollout(dev(p0), dev(v0_), dev(spd), dev(dst), dt, radius, steps, fused=False)   # MLAPM.step + torch glue per frame
+    assert torch.equal(torch.isnan(traj_p), torch.isnan(seq_p))
+    assert torch.equal(torch.nan_to_num(traj_p), torch.nan_to_num(seq_p)) and torch.equal(torch.nan_to_num(traj_v), torch.nan_to_num(seq_v))
     # host loop with compaction, as the reference does it
     N = p0.shape[0]
     p, v = p0.copy(), v0_.copy()
@@ -292,6 +295,26 @@ def test_mlapm_rollout_matches_host_compaction_loop(oracle):
     m.rollout(*args, dt, radius, 300)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     print(f'MLAPM GC rollout N=4096: {300 / el:.0f} steps/s')
+
+
+@pytest.mark.parametrize('ver', ['raw', 'GC', 'UCY'])
+@pytest.mark.parametrize('N', [200, 4100])
+def test_mlapm_fused_rollout_equals_operator_sequence(ver, N):
+    """A frame as ONE launch (state read from the trajectory, arrival test on the way in, device-side frame counter,
+    eight frames per captured graph) against MLAPM.step + torch glue per frame: same arrival frames, same numbers."""
+    from piml_amd.models.mlapm import MLAPM
+    sc = synthetic_gc_scene(N, 0, seed=4, nan_frac=0.03)
+    args = [dev(sc[k]) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+    args[3] = args[0] + (args[3] - args[0]) * 0.02          # destinations close by: agents arrive within the rollout
+    args[3] = torch.where(torch.isnan(args[3]), dev(sc['destination']), args[3])
+    m = MLAPM(version=ver, **_LAWS[ver])
+    steps = 37                                               # 1 + 4 graphs of 8 + 4 single frames
+    fp, fv = m.rollout(*args, 0.08, 0.3, steps)
+    sp, sv = m.rollout(*args, 0.08, 0.3, steps, fused=False)
+    assert torch.equal(torch.isnan(fp), torch.isnan(sp)) and torch.equal(torch.isnan(fv), torch.isnan(sv))
+    gone = torch.isnan(fp[-1, :, 0]) & ~torch.isnan(fp[0, :, 0])
+    assert int(gone.sum()) > 0                               # somebody did arrive
+    assert torch.equal(torch.nan_to_num(fp), torch.nan_to_num(sp)) and torch.equal(torch.nan_to_num(fv), torch.nan_to_num(sv))
 
 
 def test_collision_counts_grid_form_equals_sweeps_and_oracle(oracle, monkeypatch):

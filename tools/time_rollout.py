@@ -6,27 +6,7 @@ from piml_amd.scenes import synthetic_gc_scene
 from piml_amd.models.simulators import BaseSimulator
 
 
-def synthetic_rollout_data(N, M, T, dev, seed=0):
-    sc = synthetic_gc_scene(N, M, seed=seed)
-    t = lambda x: torch.tensor(x, device=dev)
-    rep = lambda x: t(x).unsqueeze(0).repeat(T, *([1] * x.ndim)).contiguous()
-    d = types.SimpleNamespace()
-    d.position, d.velocity, d.acceleration, d.destination = [rep(sc[k]) for k in ('position', 'velocity', 'acceleration', 'destination')]
-    d.velocity = torch.nan_to_num(d.velocity)
-    d.obstacles = t(sc['obstacles'])
-    far = sc['destination'] + (sc['destination'] - np.nan_to_num(sc['position'])) * 100
-    d.waypoints = torch.stack((t(sc['destination']), t(far.astype(np.float32))))
-    d.dest_num = torch.full((N,), 2, device=dev, dtype=torch.long)
-    d.dest_idx = torch.zeros(T, N, device=dev, dtype=torch.long)
-    present = (~torch.isnan(d.position[..., 0])).float()
-    d.mask_p, d.mask_p_pred = present, present.clone()
-    d.num_frames, d.time_unit, d.meta_data = T, 0.08, None
-    from piml_amd.pedestrians import Pedestrians
-    pf, of, df = Pedestrians().get_relative_features(d.position[:1].clone(), d.velocity[:1].clone(), d.acceleration[:1].clone(),
-                                                     d.destination[:1].clone(), d.obstacles, 6, 90, 4, 10, 90, 4)
-    d.ped_features, d.obs_features = pf.repeat(T, 1, 1, 1), of.repeat(T, 1, 1, 1)
-    d.self_features = torch.cat((df, d.velocity[:1], d.acceleration[:1], t(sc['desired_speed']).unsqueeze(0)), -1).repeat(T, 1, 1)
-    return d
+from piml_amd.scenes import synthetic_rollout_data      # noqa: E402 (the clip builder lives with the scenes)
 
 
 if __name__ == '__main__':
@@ -54,3 +34,19 @@ if __name__ == '__main__':
                 sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
                 print(f'N={N} M={M} graph={graph}: {T / dt:8.0f} steps/s ({dt / T * 1e6:.0f} us/step)')
+
+    # the closed-form simulator (MLAPM.rollout, src/main_mlapm.py:18-36): a frame as one launch against the operator sequence
+    from piml_amd.models.mlapm import MLAPM
+    m = MLAPM(version='GC', tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56)
+    for N in (122, 1024, 4096):
+        sc = synthetic_gc_scene(N, 0, seed=0, nan_frac=0.02)
+        a = [torch.tensor(sc[k], device=dev) for k in ('position', 'velocity', 'desired_speed', 'destination')]
+        T = 600
+        for name, kw in (('operator sequence, 1 frame per graph', dict(fused=False)), ('one launch per frame, 1 frame per graph', dict(frames_per_graph=1)),
+                         ('one launch per frame, 8 frames per graph', dict(frames_per_graph=8)),
+                         ('one launch per frame, 32 frames per graph', dict(frames_per_graph=32))):
+            m.rollout(*a, 0.08, 0.3, 80, **kw)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m.rollout(*a, 0.08, 0.3, T, **kw)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            print(f'MLAPM GC rollout N={N} ({name}): {T / dt:8.0f} steps/s ({dt / T * 1e6:.1f} us/step)')
