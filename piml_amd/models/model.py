@@ -190,6 +190,8 @@ class _PINNSFBase(nn.Module):
     """Shared body of the PINNSF variants; subclasses set the class attributes below."""
     bottleneck = False          # decoder + predictor applied per neighbour, then summed over k
     collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
+    predictions_only = False    # set by the inference rollouts (BaseSimulator): the fused network skips the 'msgs' collision head,
+                                # whose output those loops never read (simulators.py:602 takes [0]); forward then returns None in its place
     residual = False            # pinnsf_res corrector branch
     obs_encoder_in = 6          # PINNSF_residual uses args.obs_feature_dim instead
     taus = (2, 2)               # (non-ucy tau, ucy tau)
@@ -387,7 +389,7 @@ class _PINNSFBase(nn.Module):
             return None
         from .. import ops
         fold = self_features.dim() == 2 or self.fix_dest_norm          # per-row |dest|; else quirk Q2 below
-        head = self._fusable_head()
+        head = None if self.predictions_only else self._fusable_head()
         packs = self._active_packs()
         specs = self._launch_specs([(p, f) for f, _, p, _, _ in cand])
         res = ops.fused_pinnsf(
@@ -405,7 +407,9 @@ class _PINNSFBase(nn.Module):
         if len(msgs) > 1:
             out.append(msgs[1])
         if self.collision_head is not None:        # 'msgs' (pinnsf_m): head on the pedestrian messages
-            if head is not None:
+            if self.predictions_only:              # inference rollouts read the accelerations only: no head workgroups
+                out.append(None)
+            elif head is not None:
                 out.append(res[2].squeeze())
             else:
                 out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
@@ -463,7 +467,7 @@ class _PINNSFBase(nn.Module):
                 return None
             enc_w.append([t for lin in el for t in (lin.weight, lin.bias)])
             dec_w.append([t for lin in dl for t in (lin.weight, lin.bias)] + [q.mlp[0].weight, q.mlp[0].bias])
-        return enc_w, dec_w, (None if self.bottleneck else self._fusable_head())
+        return enc_w, dec_w, (None if (self.bottleneck or self.predictions_only) else self._fusable_head())
 
     def _active_packs(self):
         return self._packs if (self._packs is not None and self._packs.active) else None

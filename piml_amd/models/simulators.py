@@ -341,8 +341,18 @@ class BaseSimulator(Pedestrians):
         args = self.args
         if load_model:
             self.load_model(args, set_model=False, finetune_flag=self.finetune_flag)
-        with self._packed_weights():          # the weights do not change during a rollout: packed once, not per frame
-            return self._multiple_rollouts(data, t_start, use_graph, fused)
+        # inference frames read the predicted accelerations only: PINNSF_multitask's auxiliary collision head is not launched
+        # (set before the weights are packed: the pack then holds no head either)
+        only = not torch.is_grad_enabled() and hasattr(self.model, 'predictions_only')
+        before = getattr(self.model, 'predictions_only', False)
+        if only:
+            self.model.predictions_only = True
+        try:
+            with self._packed_weights():      # the weights do not change during a rollout: packed once, not per frame
+                return self._multiple_rollouts(data, t_start, use_graph, fused)
+        finally:
+            if only:
+                self.model.predictions_only = before
 
     def _multiple_rollouts(self, data, t_start, use_graph, fused):
         args = self.args

@@ -35,6 +35,8 @@ if __name__ == '__main__':
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
                 print(f'N={N} M={M} graph={graph}: {T / dt:8.0f} steps/s ({dt / T * 1e6:.0f} us/step)')
 
+    if '--no-mlapm' in sys.argv:
+        sys.exit(0)
     # the closed-form simulator (MLAPM.rollout, src/main_mlapm.py:18-36): a frame as one launch against the operator sequence
     from piml_amd.models.mlapm import MLAPM
     m = MLAPM(version='GC', tau=0.5, A=7.55, B=-3.0, C=0.2, D=-0.3, theta=56)
