@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 28
+#define PIML_HIP_ABI_VERSION 29
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -816,6 +816,17 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
                               pack depends on the weights only and is a ~4 us launch in front of the step's chain by itself.
                               Whichever comes first: every consumer of packed images (piml_pinnsf_fwd, piml_encoder_fwd_packed,
                               piml_rowdecoder_fwd_packed) and piml_pinnsf_pack_flush launch a pack that is still waiting */
+#define PIML_POOL_H2 32 /* piml_pinnsf_fwd, INFERENCE only (no head, no dropout, no backward): msgs = scale (W3 h2 + b3) is linear in
+                           h2, so the neighbour-axis sum is taken BEFORE the last encoder layer.  The encoder launch stops after layer 2
+                           and writes the agents' sums of h2: enc[i].msgs (agents, 128) = the part from the 32-row tile the agent's
+                           first row lies in, enc[i].h2 (agents, 128) = the part from the next tile (agents whose k rows straddle two
+                           tiles: (a k) >> 5 != (a k + k - 1) >> 5; undefined for the others).  dec[i].pooled = the same buffer as
+                           enc[i].msgs, dec[i].msgs = the same as enc[i].h2; the decoder tails run on their sum.  The CALLER folds
+                           the skipped layer into the decoder's first layer -- dec[i].w1 = scale * W_d1 * W3 (64 x 128),
+                           dec[i].b1 = b_d1 + scale * k * W_d1 * b3 -- when it packs; enc[i].w3 / b3 / scale are not read.
+                           Served when piml_pinnsf_pool_h2_ok(enc, nbranches): k = 6 or 10, split products, more tiles than
+                           piml_encoder_split_tiles(); hipErrorInvalidValue otherwise */
+int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */
 int piml_pinnsf_streams_init(void);

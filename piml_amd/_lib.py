@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _lib = None
 
@@ -56,7 +56,7 @@ class Corrector(ctypes.Structure):
                 ('partials_a', _p), ('partials_b', _p), ('grads', _p)]
 
 
-PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK = 1, 2, 4, 8, 16          # piml_pinnsf_* flags
+PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK, POOL_H2 = 1, 2, 4, 8, 16, 32          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -157,6 +157,7 @@ SIGNATURES = {
     'piml_corrector_slots': [_i, _ll, _i],
     'piml_corrector_fwd': [ctypes.POINTER(Corrector), _p],
     'piml_corrector_bwd': [ctypes.POINTER(Corrector), _i, _p],
+    'piml_pinnsf_pool_h2_ok': [ctypes.POINTER(EncoderBranch), _i],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_pack_flush': [],
     'piml_pinnsf_slot_sums_flush': [],

@@ -33,6 +33,8 @@ struct DecArgs {
     const float* g_pred;          // bwd in (agents, 2)
     float* g_self;                // bwd out (agents, 7) or NULL
     int wg_split;                 // dW kernel: workgroups [0, wg_split) serve branch 0
+    int pool_h2;                  // forward, PIML_POOL_H2: `pooled` holds the agents' first parts, `msgs` (agents, 128) the second
+                                  // parts of the agents whose k rows straddle two 32-row tiles (enc_fwd_pool_x3_kernel)
 };
 
 __device__ __forceinline__ f32x16 dmfma(float a, float b, f32x16 c) {
@@ -183,6 +185,19 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
             for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
+            if (!ROWS && A.pool_h2) {
+                const long long g0 = (valid ? agent : 0) * J.k;
+                if (valid && (g0 >> 5) != ((g0 + J.k - 1) >> 5)) {          // the agent's rows straddle two tiles: + its second part
+                    const float* more = J.msgs + agent * DH;
+#pragma unroll
+                    for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 c = *reinterpret_cast<const float4*>(more + dfeat0(2 * kh + bl, q, h));
+                            pv[bl][q].x += c.x; pv[bl][q].y += c.y; pv[bl][q].z += c.z; pv[bl][q].w += c.w;
+                        }
+                }
+            }
         }
         if (!POOL) late_loads();
         f32x16 a1;
@@ -1223,6 +1238,30 @@ int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
     if (g_head_x3) hipLaunchKernelGGL(dec_fwd_head_kernel<true>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
     else hipLaunchKernelGGL(dec_fwd_head_kernel<false>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    return hipGetLastError();
+}
+
+// PIML_POOL_H2: the decoder tails on the sums the inference forward left (no neighbour-axis sum, no head); (tile, branch)
+// workgroups like dec_fwd_head_kernel, `acc` cleared by the encoder launch when there are two branches
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_fwd_ph2_kernel(DecArgs A) {
+    const int bx = blockIdx.x;
+    if (A.nbr > 1) dec_fwd_body<false, true>(A, bx >> 1, bx & 1);
+    else dec_fwd_body<false, true>(A, bx, 0);
+}
+
+int piml::dec_stage_fwd_ph2(const piml_decoder_branch* br, int nbr, const float* self_features, float tau, float* acc,
+                            hipStream_t s) {
+    DecArgs A;
+    if (!acc) return hipErrorInvalidValue;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].msgs) return hipErrorInvalidValue;
+    A.self_features = self_features;
+    A.tau = tau;
+    A.acc = acc;
+    A.pool_h2 = 1;
+    const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
+    hipLaunchKernelGGL(dec_fwd_ph2_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A);
     return hipGetLastError();
 }
 

@@ -972,6 +972,37 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
     return hipGetLastError();
 }
 
+// The inference forward on pooled h2 serves: split products, no dropout, k = 6 or 10 neighbours per agent, whole agents, and
+// more tiles than the few-rows bound (below it enc_fwd_split_x3_kernel's four waves per tile win).
+bool piml::enc_pool_h2_ok(const piml_encoder_branch* br, int nbr) {
+    static const bool off = getenv("PIML_POOL_H2") && atoi(getenv("PIML_POOL_H2")) == 0;
+    if (off || !g_x3 || !br || nbr < 1 || nbr > 2) return false;
+    long long tiles = 0;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if ((b.k != 6 && b.k != 10) || b.rows <= 0 || b.rows % b.k || b.keep_bits || b.drop_state || b.in_dim > 8) return false;
+        tiles += (b.rows + 31) / 32;
+    }
+    return tiles > g_split_tiles;
+}
+
+int piml::enc_stage_fwd_pool(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
+    if (int e = enc_check(br, nbr)) return e;
+    if (!enc_pool_h2_ok(br, nbr)) return hipErrorInvalidValue;
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].msgs || !br[i].h2) return hipErrorInvalidValue;
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    if (zero && zero_n > 0) {
+        if (zero_n >= (1ll << 31)) return hipErrorInvalidValue;
+        A.zero = zero;
+        A.zero_n = (int)zero_n;
+    }
+    if (int e = x3_ready()) return e;
+    enc_x3_launch_fwd_pool(A, total, s);
+    return hipGetLastError();
+}
+
 int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s) {
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;

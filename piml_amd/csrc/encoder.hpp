@@ -59,6 +59,7 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 // encoder_x3.hip: the same stages on split bf16 products (launch only; arguments checked by the callers in encoder.hip)
 int enc_x3_set_attributes();
 // drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
+void enc_x3_launch_fwd_pool(const EncArgs& A, int total, hipStream_t s);      // inference: layers 1-2 + the agents' sums of h2
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);   // A.gen_state: draw the masks in the kernel
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile

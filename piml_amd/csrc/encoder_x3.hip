@@ -258,6 +258,135 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward for INFERENCE (no gradient, no dropout, nobody reads the per-row messages): the neighbour-axis sum taken BEFORE the
+// last layer.  msgs = scale (W3 h2 + b3) is linear in h2, so sum_r msgs[r] = scale (W3 sum_r h2[r] + k b3): this kernel stops
+// after layer 2 and leaves the agents' sums of h2; the caller folds scale W3 into the decoder's first layer
+// (W_d1' = scale W_d1 W3, b_d1' = b_d1 + scale k W_d1 b3: once per weight pack), so layer 3 -- half of the kernel's matrix
+// work -- and the 33 MB of messages are gone (rollout frame at 4096 agents 77 -> 6x us).
+// Layer 2 runs with its operands exchanged (kblock_x3_t): the output block is D'[row][feature] -- lane = feature, registers
+// = rows rho(r) + 4 h of the tile -- so an agent's sum is additions between REGISTERS (no transposition through LDS, the cost
+// that sank the round-3 attempt at summing inside the forward), one exchange between the lane halves per agent and block,
+// and 128-byte stores.  Which registers belong to which agent depends on (first row of the tile) mod k: three cases for
+// k = 6, five for k = 10, each compiled with the register -> agent map as constants (pool_rows<K, PH>; other k: the caller
+// keeps the message path).  An agent whose rows straddle two tiles gets its two parts into two buffers (`msgs` = the part
+// from the tile its first row lies in, `h2` = the rest; both (agents, 128)): no atomics, no cleared buffer, and the decoder adds
+// them ((a k) >> 5 != (a k + k - 1) >> 5 says which agents have a second part).
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int PH>
+__device__ __forceinline__ void pool_rows(const f32x16 (&a)[4], long long tile, long long agents, int lane, float* __restrict__ part_a,
+                                          float* __restrict__ part_b) {
+    constexpr int o = (PH * 32) % K;                 // rows of the tile's first agent that lie in earlier tiles
+    constexpr int S = (o + 31) / K + 1;              // agents with rows in this tile
+    const int i = lane & 31;
+    const bool h = lane >= 32;
+    const long long a0 = (tile * 32) / K;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        float sum[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) sum[s] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m0 = (r & 3) + 8 * (r >> 2), s0 = (o + m0) / K, s1 = (o + m0 + 4) / K;     // the register's row in half 0 / half 1
+            if (s0 == s1) sum[s0] += a[blk][r];
+            else {
+                sum[s0] += h ? 0.f : a[blk][r];
+                sum[s1] += h ? a[blk][r] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float tot = sum[s] + __shfl_xor(sum[s], 32);
+            const long long agent = a0 + s;
+            float* dst = (s == 0 && o != 0) ? part_b : part_a;
+            if (!h && agent < agents) dst[agent * EH + 32 * blk + i] = tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if (A.zero)
+        for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+    const float* x3 = J.packed + PACK_F32;
+    float xb[4];
+    load_x(xb, J.x, first, ntiles, R, IN, lane);
+    stage_linear<X3_IMG>(lds, x3, tid);                                         // W2's image; W3 is not needed
+    stage_linear<1024 + 384>(lds + X3_FWD_F32, J.packed + 32768, tid);
+    __syncthreads();
+    const int k = J.k;
+    const long long agents = R / k;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const u32x4* W2hm = reinterpret_cast<const u32x4*>(lds) + lane_t;
+        const u32x4* W2lo = W2hm + X3_HM / 4;
+        const float* W1f = lds + X3_FWD_F32;
+        const float* bias = W1f + 1024;
+        const int h = lane_t >> 5;
+        f32x16 a[4];
+        Pieces P;
+        // ---- layer 1 as in enc_fwd_x3_kernel ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + feat0(blk, q, h));
+                a[blk][4 * q + 0] = bq.x; a[blk][4 * q + 1] = bq.y; a[blk][4 * q + 2] = bq.z; a[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[blk] = mfma32(W1f[(blk * 4 + s) * 64 + lane_t], xb[s], a[blk]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[blk][r] = relu1(a[blk][r]);
+        }
+        split_tile(a, P);
+        load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
+        // ---- layer 2, transposed: a[blk] = relu(h2)[row rho(r) + 4 h][feature 32 blk + (lane & 31)] ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x16 acc, sm;
+            const float bv = bias[128 + 32 * blk + (lane_t & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; acc[r] = bv; }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                kblock_x3_t(acc, sm, W2hm[(fb * 2) * 64], W2hm[(fb * 2 + 1) * 64], W2lo[fb * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[blk][r] = relu1(acc[r] + sm[r]);
+        }
+        // ---- the agents' sums (wave-uniform choice of the register -> agent map) ----
+        if (k == 6) {
+            switch ((int)(tile % 3)) {
+                case 0: pool_rows<6, 0>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                case 1: pool_rows<6, 1>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                default: pool_rows<6, 2>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+            }
+        } else {
+            switch ((int)(tile % 5)) {
+                case 0: pool_rows<10, 0>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                case 1: pool_rows<10, 1>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                case 2: pool_rows<10, 2>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                case 3: pool_rows<10, 3>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+                default: pool_rows<10, 4>(a, tile, agents, lane_t, J.msgs, J.h2); break;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // forward for FEW rows (rollouts of real clips: 100 .. 1000 agents): four waves per tile like enc_fwd_split_kernel
 // (encoder.hip; a lone wave per SIMD is bound by the latency of its chain of dependent matrix instructions, here
 // 16 + 48 + 48 of them instead of 400).  Wave (t, blk) computes output block blk of every layer of tile t, two tiles per
@@ -832,6 +961,7 @@ int enc_x3_set_attributes() {
                          reinterpret_cast<const void*>(enc_bwd_dx_x3_kernel<true, true>)};
     for (const void* f : dx)
         if (int e = set(f, X3_DX_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_pool_x3_kernel), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<2>), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<1>), X3_FWD_LDS_BYTES)) return e;
     return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<0>), X3_FWD_LDS_BYTES);
@@ -857,6 +987,10 @@ void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop
     if (drop && A.gen_state) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<2>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
     else if (drop) hipLaunchKernelGGL(enc_fwd_split_x3_kernel<1>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
     else hipLaunchKernelGGL(enc_fwd_split_x3_kernel<0>, g, dim3(512), X3_SPLIT_LDS_BYTES, s, A, pairs0);
+}
+
+void enc_x3_launch_fwd_pool(const EncArgs& A, int total, hipStream_t s) {
+    hipLaunchKernelGGL(enc_fwd_pool_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
 }
 
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {

@@ -261,12 +261,23 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
 
 PIML_API int piml_pinnsf_slot_sums_flush(void) { return pending_slot_sums_flush(); }
 
+PIML_API int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_h2_ok(enc, nbr) ? 1 : 0; }
+
 PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
                              const piml_collision_head* head, const float* self_features, float tau, float* acc,
                              int flags, void* stream) {
     hipStream_t m = as_stream(stream);
     const bool pack = !(flags & PIML_PACKED_VALID);
     PIML_TRY(pending_pack_flush());          // a deferred pack nobody took: now (no-op otherwise)
+    if (flags & PIML_POOL_H2) {               // inference: the agents' sums of h2 instead of the messages (see the header)
+        if ((flags & PIML_FORK) || head || !enc_pool_h2_ok(enc, nbr)) return hipErrorInvalidValue;
+        if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, nullptr, 0, stream));
+        PIML_TRY(enc_stage_fwd_pool(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
+        trace_mark("enc_fwd", m);
+        PIML_TRY(dec_stage_fwd_ph2(dec, nbr, self_features, tau, acc, m));
+        trace_mark("dec_fwd_head", m);
+        return hipSuccess;
+    }
     if (!(flags & PIML_FORK)) {
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
         // the split decoder tiles accumulate their two branches into `acc`: cleared by the encoder launch

@@ -11,6 +11,10 @@ namespace piml {
 int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
 // packed image must be current; `zero` (optional): zero_n floats cleared by the launch
 int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
+// PIML_POOL_H2 (inference): the forward up to layer 2 and the agents' sums of h2 into `msgs` / `h2`, both (agents, 128)
+// (enc_fwd_pool_x3_kernel); enc_pool_h2_ok: the configuration it serves
+bool enc_pool_h2_ok(const piml_encoder_branch* br, int nbr);
+int enc_stage_fwd_pool(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
 int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
 int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate = false);
@@ -23,6 +27,8 @@ int dec_stage_pool(const piml_decoder_branch* br, int nbr, hipStream_t s);
 // pooling + decoder tails + (head may be NULL) the collision head in one launch; after the packs
 int dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
                         float tau, float* acc, hipStream_t s);
+int dec_stage_fwd_ph2(const piml_decoder_branch* br, int nbr, const float* self_features, float tau, float* acc,
+                      hipStream_t s);      // PIML_POOL_H2: decoder tails on the agents' sums (`pooled` + second parts in `msgs`)
 int dec_stage_fwd(const piml_decoder_branch* br, int nbr, const float* self_features, float tau, float* acc,
                   hipStream_t s);                                                     // after pack + pool
 int dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features, float tau,

@@ -46,6 +46,18 @@ __device__ __forceinline__ void kblock_x3(f32x16& acc, f32x16& small, u32x4 wh, 
     acc = mfma_bf(wh, xh, acc);
 }
 
+// The same six products with the operands exchanged: the activations' pieces as the A operand, the weight fragment as B --
+// the transposed output block (D'[row][feature]: lane = feature, registers = the tile's rows), every accumulator seeing the
+// same products in the same order.
+__device__ __forceinline__ void kblock_x3_t(f32x16& acc, f32x16& small, u32x4 wh, u32x4 wm, u32x4 wl, u32x4 xh, u32x4 xm, u32x4 xl) {
+    small = mfma_bf(xh, wl, small);
+    small = mfma_bf(xm, wm, small);
+    small = mfma_bf(xl, wh, small);
+    small = mfma_bf(xh, wm, small);
+    small = mfma_bf(xm, wh, small);
+    acc = mfma_bf(xh, wh, acc);
+}
+
 // batch geometry of the slab weight-gradient kernel (enc_bwd_dw_x3w_kernel, encoder_dww.hip)
 constexpr int DW_X3_ROWS = 16;
 constexpr int DWX_ARR = 3 * 256;                       // u32x4 of one array's three pieces

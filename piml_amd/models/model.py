@@ -22,6 +22,7 @@ surviving block is evaluated, and on the fused GPU path the keep-mask is drawn b
 import contextlib
 import logging
 import os
+import types
 
 _LOG = logging.getLogger('piml_amd')
 _NOTED = set()
@@ -59,6 +60,8 @@ FUSED_KSUM_TAIL = os.environ.get('PIML_FUSED_KSUM_TAIL', '1') != '0'
 # pinnsf_res's corrector (attention pooling + 128 -> 64 -> 2 tail) on ops.fused_corrector (csrc/corrector.hip)
 FUSED_CORRECTOR = os.environ.get('PIML_FUSED_CORRECTOR', '1') != '0'
 PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
+# inference frames (predictions only, eval): neighbour-axis sum before the encoders' last layer (ops.fused_pinnsf_pooled)
+POOLED_INFERENCE = os.environ.get('PIML_POOLED_INFERENCE', '1') != '0'
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -190,6 +193,7 @@ class _PINNSFBase(nn.Module):
     """Shared body of the PINNSF variants; subclasses set the class attributes below."""
     bottleneck = False          # decoder + predictor applied per neighbour, then summed over k
     collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
+    _ph2 = None                 # folded weights + operand images of the pooled inference path (see _pooled_inference)
     predictions_only = False    # set by the inference rollouts (BaseSimulator): the fused network skips the 'msgs' collision head,
                                 # whose output those loops never read (simulators.py:602 takes [0]); forward then returns None in its place
     residual = False            # pinnsf_res corrector branch
@@ -392,6 +396,16 @@ class _PINNSFBase(nn.Module):
         head = None if self.predictions_only else self._fusable_head()
         packs = self._active_packs()
         specs = self._launch_specs([(p, f) for f, _, p, _, _ in cand])
+        if self.predictions_only and POOLED_INFERENCE and packs is not None and not torch.is_grad_enabled() \
+                and all(sp[1] is None for sp in specs):
+            acc = self._pooled_inference(cand, specs, self_features, fold)
+            if acc is not None:
+                if not fold:
+                    if self_features.dim() == 3:
+                        acc = ops.pinnsf_epilogue(acc, None, self_features, self.tau, agent_norm=True)
+                    else:
+                        acc = acc + self.desired_force(self_features)
+                return [acc] + [None] * (len(cand) + (1 if self.collision_head is not None else 0))
         res = ops.fused_pinnsf(
             [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
@@ -414,6 +428,29 @@ class _PINNSFBase(nn.Module):
             else:
                 out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
         return out
+
+    def _pooled_inference(self, cand, specs, self_features, fold):
+        """Inference frames (predictions only, eval mode, inside packed_weights()): the neighbour-axis sum BEFORE the
+        encoders' last layer, that layer folded into the decoders' first (ops.fused_pinnsf_pooled / PIML_POOL_H2).  The
+        folded weights and their operand images are made at the first such frame of a packed_weights() block (outside any
+        graph capture) and dropped when the block ends.  None: not served (the message path runs)."""
+        from .. import ops
+        key = (tuple(f.shape[-2] for f, *_ in cand), tuple(float(sp[0]) for sp in specs))
+        st = self._ph2
+        if st is None or st.key != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            st = types.SimpleNamespace(key=key, packs=ops.PinnsfPacks(), enc_w=[], dec_w=[])
+            for (f, e, p, d, q), sp in zip(cand, specs):
+                ew = [t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)]
+                dw = [t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)] + [q.mlp[0].weight, q.mlp[0].bias]
+                st.enc_w.append(ew)
+                st.dec_w.append(ops.pooled_h2_decoder_weights(ew, dw, sp[0], f.shape[-2]))
+            ops.pinnsf_prepack(st.packs, st.enc_w, st.dec_w, None, defer=False)
+            self._ph2 = st
+        return ops.fused_pinnsf_pooled(
+            [dict(x=f, encoder=ew, decoder=dw) for (f, *_), ew, dw in zip(cand, st.enc_w, st.dec_w)],
+            self_features, self.tau, fold_epilogue=fold, packs=st.packs)
 
     def _correct(self, encoded):
         """corrector[2](corrector[1](corrector[0](encoded)))  (model.py:1050-1052) -- on the hand-written kernels
@@ -491,6 +528,7 @@ class _PINNSFBase(nn.Module):
             yield
         finally:
             self._packs.active = False
+            self._ph2 = None            # the folded inference weights belong to this block's weights
 
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'

@@ -2467,6 +2467,66 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
     return out[0], list(out[1:])
 
 
+def pooled_h2_decoder_weights(enc_w, dec_w, scale, k):
+    """The decoder's first layer with the encoder's last layer folded in (PIML_POOL_H2): sum_r scale (W3 h2_r + b3) fed to
+    W_d1 x + b_d1 is (scale W_d1 W3) sum_r h2_r + (b_d1 + scale k W_d1 b3).  enc_w = (w1, b1, w2, b2, w3, b3), dec_w = (w1, b1,
+    w2, b2, wp, bp); returns dec_w with the first two replaced (float64 products, rounded once)."""
+    w3, b3, wd1, bd1 = enc_w[4].detach().double(), enc_w[5].detach().double(), dec_w[0].detach().double(), dec_w[1].detach().double()
+    w1c = (float(scale) * (wd1 @ w3)).float().contiguous()
+    b1c = (bd1 + float(scale) * int(k) * (wd1 @ b3)).float().contiguous()
+    return [w1c, b1c, *dec_w[2:]]
+
+
+def fused_pinnsf_pooled(branches, self_features, tau, fold_epilogue=True, packs=None):
+    """INFERENCE form of fused_pinnsf (no autograd, no dropout, no head, nobody reads the per-row messages): the encoder launch
+    stops after layer 2 and leaves the agents' sums of h2, the decoder tails run on them (PIML_POOL_H2 of piml_pinnsf_fwd).
+    branches as for fused_pinnsf, but `decoder` is what pooled_h2_decoder_weights made of the decoder + predictor weights
+    (w1', b1', w2, b2, wp, bp) and `scale` is not applied again.  packs: a PinnsfPacks prepacked from these very tensors.
+    Returns acc (..., N, 2), or None when the library does not serve the configuration (k other than 6 / 10, few rows, f32
+    matrix instruction): the caller then takes fused_pinnsf."""
+    import ctypes
+    if torch.is_grad_enabled() and any(t.requires_grad for b in branches for t in (b['x'], *b['encoder'], *b['decoder'])):
+        raise ValueError('fused_pinnsf_pooled is an inference path: call it under torch.no_grad()')
+    L = _lib.lib()
+    nbr = len(branches)
+    H = ENCODER_HIDDEN
+    xs = [_gpu_f32('encoder input', b['x']) for b in branches]
+    lead = tuple(xs[0].shape[:-2])
+    if any(tuple(x.shape[:-2]) != lead for x in xs) or tuple(self_features.shape[:-1]) != lead or self_features.shape[-1] != 7:
+        raise ValueError('fused_pinnsf_pooled: the branches and self_features must share the leading (..., N) shape')
+    dev = xs[0].device
+    opt = dict(device=dev, dtype=torch.float32)
+    agents = 1
+    for d in lead:
+        agents *= d
+    ewb = [[_gpu_f32('encoder weight', t.detach()) for t in b['encoder']] for b in branches]
+    dwb = [[_gpu_f32('decoder weight', t.detach()) for t in b['decoder']] for b in branches]
+    x2s = [x.reshape(-1, x.shape[-1]) for x in xs]
+    ks = [x.shape[-2] for x in xs]
+    flags = _lib.POOL_H2
+    if packs is not None:
+        if packs.sig != _weights_sig(ewb, dwb, None):
+            raise ValueError('fused_pinnsf_pooled: `packs` were filled from other weight tensors: pinnsf_prepack first')
+        epack, dpack = packs.epack, packs.dpack
+        flags |= _lib.PACKED_VALID
+    else:
+        epack = torch.empty(nbr, L.piml_encoder_pack_floats(), **opt)
+        dpack = torch.empty(nbr, L.piml_decoder_pack_floats(), **opt)
+    part_a = [torch.empty(agents, H, **opt) for _ in range(nbr)]        # sums from the tile an agent's first row lies in
+    part_b = [torch.empty(agents, H, **opt) for _ in range(nbr)]        # ... from the next tile (straddling agents)
+    earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], 1.0, ewb[b], part_a[b], None, part_b[b], packed=epack[b])
+                                        for b in range(nbr)])
+    if not L.piml_pinnsf_pool_h2_ok(earr, nbr):
+        return None
+    darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(part_b[b], agents, ks[b], dwb[b], dpack[b], part_a[b], None, None)
+                                        for b in range(nbr)])
+    sf = _gpu_f32('self_features', self_features).reshape(agents, 7) if fold_epilogue else None
+    acc = torch.empty(agents, 2, **opt)
+    with torch.cuda.device(dev):
+        _lib.check(L.piml_pinnsf_fwd(earr, darr, nbr, None, _ptr(sf), float(tau), _ptr(acc), flags, _stream()), 'piml_pinnsf_fwd')
+    return acc.view(*lead, 2)
+
+
 class _FusedRowDecoder(torch.autograd.Function):
     """inputs: nbr, then per branch emb (..., 128), decoder w1 (64,128) b1 w2 (64,64) b2, predictor w (2,64) b  (7 tensors).
     outputs per branch: pred (..., 2), decoded (..., 64)."""

@@ -342,3 +342,44 @@ def test_train_rollout_step_zero_nan():
     g_out = torch.autograd.grad(sum((torch.nan_to_num(x) * y).sum() for x, y in zip(out[:3], w)), lb)
     for x, y in zip(g_out, g_ref):
         assert torch.allclose(torch.nan_to_num(x), torch.nan_to_num(y), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,M', [(4096, 2000), (2500, 700)])
+def test_pooled_inference_forward_matches_message_path(N, M):
+    """Inference frames sum the neighbour axis BEFORE the encoders' last layer (PIML_POOL_H2: layer 2 with exchanged operands,
+    the agents' sums as additions between registers, the last layer folded into the decoder's first).  Same accelerations as
+    the message path to float32 rounding, for tiles whose agents start at every offset (k = 6: three, k = 10: five) and a
+    row count that is not a multiple of 32; and the rollout that uses it equals the rollout that does not."""
+    from piml_amd.scenes import synthetic_rollout_data
+    from piml_amd.models.simulators import BaseSimulator
+    import piml_amd.models.model as MODEL
+    data = synthetic_rollout_data(N, M, 12, DEV)
+    torch.manual_seed(666)
+    sim = BaseSimulator(sim_args())
+    sim.model.eval()
+    pf, of, sf = data.ped_features[0], data.obs_features[0], data.self_features[0]
+    with torch.no_grad():
+        ref = sim.model(pf, of, sf)[0]
+        sim.model.predictions_only = True
+        try:
+            with sim.model.packed_weights():
+                got = sim.model(pf, of, sf)
+                assert sim.model._ph2 is not None                      # the pooled path did serve the call
+                again = sim.model(pf, of, sf)[0]
+            assert got[1] is None and got[-1] is None
+        finally:
+            sim.model.predictions_only = False
+        assert sim.model._ph2 is None
+        scale = ref.abs().max()
+        assert (got[0] - ref).abs().max() <= 1e-5 * scale, ((got[0] - ref).abs().max(), scale)
+        assert torch.equal(got[0], again)
+        # the whole rollout: pooled inference frames against message frames
+        a = sim.get_multiple_rollouts(data, 0, load_model=False)
+        keep = MODEL.POOLED_INFERENCE
+        MODEL.POOLED_INFERENCE = False
+        try:
+            b = sim.get_multiple_rollouts(data, 0, load_model=False)
+        finally:
+            MODEL.POOLED_INFERENCE = keep
+        pa, pb = torch.nan_to_num(a.position), torch.nan_to_num(b.position)
+        assert (pa - pb).abs().max() <= 1e-4, (pa - pb).abs().max()
