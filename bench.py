@@ -285,8 +285,9 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
             el = _time.perf_counter() - t0
         sim['pinnsf_m'] = {'agents': n, 'steps_per_s': T / el, 'us_per_step': el / T * 1e6,
                            'note': 'BaseSimulator.get_multiple_rollouts (src/models/simulators.py:552-657), PINNSF_multitask eval(), '
-                                   'random-init weights: relfeat forward + fused network forward + integrator epilogue per frame, one '
-                                   'captured frame replayed; wall clock over 200 frames'}
+                                   'random-init weights: relfeat forward + the inference forward of the network (neighbour-axis sum before the encoders\' '
+                                   'last layer, PIML_POOL_H2; no collision head) + integrator epilogue per frame, one captured frame replayed; '
+                                   'wall clock over 200 frames'}
         del data, simulator
     except Exception as ex:   # noqa: BLE001 - informational
         sim['pinnsf_m'] = {'error': f'{type(ex).__name__}: {ex}'}

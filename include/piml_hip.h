@@ -824,8 +824,8 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
                            enc[i].msgs, dec[i].msgs = the same as enc[i].h2; the decoder tails run on their sum.  The CALLER folds
                            the skipped layer into the decoder's first layer -- dec[i].w1 = scale * W_d1 * W3 (64 x 128),
                            dec[i].b1 = b_d1 + scale * k * W_d1 * b3 -- when it packs; enc[i].w3 / b3 / scale are not read.
-                           Served when piml_pinnsf_pool_h2_ok(enc, nbranches): k = 6 or 10, split products, more tiles than
-                           piml_encoder_split_tiles(); hipErrorInvalidValue otherwise */
+                           Served when piml_pinnsf_pool_h2_ok(enc, nbranches): k = 6 or 10, split products, more than 32 tiles of
+                           32 rows (environment PIML_POOL_H2_MIN_TILES); hipErrorInvalidValue otherwise */
 int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */

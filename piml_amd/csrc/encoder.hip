@@ -973,9 +973,12 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
 }
 
 // The inference forward on pooled h2 serves: split products, no dropout, k = 6 or 10 neighbours per agent, whole agents, and
-// more tiles than the few-rows bound (below it enc_fwd_split_x3_kernel's four waves per tile win).
+// more than 32 tiles (PIML_POOL_H2_MIN_TILES).  It also replaces the few-rows forward (four waves per tile): half the matrix
+// work and no message rows weigh more than the shorter chains -- rollout frame 44 -> 40 us at 512 agents, 48 -> 42 at 1024,
+// 65 -> 50 at 2048, 77 -> 58 at 4096; level at 122 (42 / 42, 46 / 38).
 bool piml::enc_pool_h2_ok(const piml_encoder_branch* br, int nbr) {
     static const bool off = getenv("PIML_POOL_H2") && atoi(getenv("PIML_POOL_H2")) == 0;
+    static const long long min_tiles = getenv("PIML_POOL_H2_MIN_TILES") ? atoll(getenv("PIML_POOL_H2_MIN_TILES")) : -1;
     if (off || !g_x3 || !br || nbr < 1 || nbr > 2) return false;
     long long tiles = 0;
     for (int i = 0; i < nbr; ++i) {
@@ -983,7 +986,7 @@ bool piml::enc_pool_h2_ok(const piml_encoder_branch* br, int nbr) {
         if ((b.k != 6 && b.k != 10) || b.rows <= 0 || b.rows % b.k || b.keep_bits || b.drop_state || b.in_dim > 8) return false;
         tiles += (b.rows + 31) / 32;
     }
-    return tiles > g_split_tiles;
+    return tiles > (min_tiles >= 0 ? min_tiles : 32);
 }
 
 int piml::enc_stage_fwd_pool(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
