@@ -1267,6 +1267,14 @@ __global__ void calc_acceleration_kernel(const float* __restrict__ rel, size_t R
     acc[q] = make_float2(-g * bx, -g * by);
 }
 
+// agents from which the 16-wave workgroups take over from the 4-wave ones (forward, rollout frame, two-role backward).  A
+// rollout frame -- a launch that waits for the one before it -- GC law, 4 / 16 waves: 1024 agents 13.7 / 12.5 us, 2048
+// 23.8 / 19.9, 4005 46.7 / 34.1 (512: 9.0 / 9.1); back-to-back forwards are level (tools/time_mlapm_wg.py).  Was 4096.
+static int mlapm_wg16_min() {
+    static const int v = getenv("PIML_MLAPM_WG16_MIN") ? atoi(getenv("PIML_MLAPM_WG16_MIN")) : 1024;
+    return v;
+}
+
 static MlapmParams make_params(int variant, float tau, float A, float B, float Cc, float D, float theta_deg,
                                float radius, int skip_absent = 0) {
     MlapmParams P;
@@ -1296,7 +1304,7 @@ PIML_API int piml_mlapm_step_fwd(const float* position, const float* velocity, c
     if (!position || !velocity || !desired_speed || !destination || !action) return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius, skip_absent);
     // big scenes: 16-wave workgroups (the whole (p,v) array is staged once per workgroup)
-    if (N >= 4096)
+    if (N >= mlapm_wg16_min())
         hipLaunchKernelGGL(mlapm_fwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),
                            (const float2*)position, (const float2*)velocity, desired_speed,
                            (const float2*)destination, N, P, dt, (float2*)action, (float2*)force, MlapmRoll{});
@@ -1317,7 +1325,7 @@ PIML_API int piml_mlapm_rollout_step(float* traj_position, float* traj_velocity,
         return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius, 1);
     const MlapmRoll Rr = {(float2*)traj_position, (float2*)traj_velocity, frame_counter, done_counter, frames, radius};
-    if (N >= 4096)
+    if (N >= mlapm_wg16_min())
         hipLaunchKernelGGL((mlapm_fwd_kernel<16, true>), dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream), nullptr, nullptr,
                            desired_speed, (const float2*)destination, N, P, dt, nullptr, nullptr, Rr);
     else
@@ -1337,7 +1345,7 @@ PIML_API int piml_mlapm_step_bwd(const float* g_action, const float* position, c
         !g_desired_speed || !g_destination)
         return hipErrorInvalidValue;
     const MlapmParams P = make_params(variant, tau, A, B, C, D, theta_deg, radius);
-    if (N >= 4096)
+    if (N >= mlapm_wg16_min())
         hipLaunchKernelGGL(mlapm_bwd_kernel<16>, dim3((N + 15) / 16), dim3(1024), 0, as_stream(stream),
                            (const float2*)g_action, (const float2*)position, (const float2*)velocity, desired_speed,
                            (const float2*)destination, N, P, dt, (float2*)g_position, (float2*)g_velocity,
@@ -1387,7 +1395,7 @@ PIML_API int piml_mlapm_step_bwd_ws(const float* g_action, const float* position
     else if (variant == 1) PIML_SYS_LAUNCH(1);
     else PIML_SYS_LAUNCH(2);
     if (variant != 2) PIML_SYS_FINISH(mlapm_bwd_sys_reduce_kernel, G.npad / 64, 256);
-    else if (N >= 4096) PIML_SYS_FINISH(mlapm_bwd_ucy_fix_kernel<16>, (N + 15) / 16, 1024);
+    else if (N >= mlapm_wg16_min()) PIML_SYS_FINISH(mlapm_bwd_ucy_fix_kernel<16>, (N + 15) / 16, 1024);
     else PIML_SYS_FINISH(mlapm_bwd_ucy_fix_kernel<4>, (N + 3) / 4, 256);
 #undef PIML_SYS_LAUNCH
 #undef PIML_SYS_FINISH
