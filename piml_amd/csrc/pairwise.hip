@@ -86,7 +86,7 @@ __device__ __forceinline__ float2 mlapm_pair(const MlapmParams& P, float rx, flo
 // (variants 0, 1).  Same expressions as mlapm_pair, element-wise on 2-vectors; products feeding sums are fused
 // (fma), which the 1e-5 relative bar of this smooth force law allows (the selections are unaffected).
 // (The variant stays a run-time value on purpose: a kernel specialised per variant at compile time measured
-// slower -- GC forward 38.7 us against 26.1 us at N = 4096.)
+// slower -- GC forward 38.7 us against 26.1 us at N = 4096; round 4, again, on the rollout frame: 47.5 against 34.1 us.)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
