@@ -188,7 +188,7 @@ def encoder_products_check(dev, _lib):
     return out
 
 
-def secondary_measurements(scene, n, dev, _lib, prof=None):
+def secondary_measurements(scene, n, dev, _lib, prof=None, light=False):
     """Back-to-back launches of the other HIP kernels of the path on the first `n` agents of the scene,
     timed with HIP events (informational; not part of `value`).  MLAPM operand-stream model: 16 B per pair + 36 B
     per agent -- a rate of LDS-resident operands, not HBM traffic and not a fraction of anything; the
@@ -233,7 +233,10 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
     del keep
     bytes_fwd = 16 * m * m + 36 * m
     # the neighbour search in the shape every rank of the 8-GPU run launches (cfg4: 2048 focal rows against 16384 sources)
+    # (light: a sharded run -- rank 0 keeps the other ranks waiting while it measures: only the short figures there)
     try:
+        if light:
+            raise RuntimeError('skipped in sharded runs (see the 1-GPU line)')
         from piml_amd.scenes import synthetic_gc_scene
         big = synthetic_gc_scene(16384, int(np.asarray(scene['obstacles']).reshape(-1, 2).shape[0]), seed=0)
         state = torch.tensor(np.concatenate([big['position'], big['velocity'], big['acceleration']], axis=-1), device=dev)
@@ -249,6 +252,8 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
     # the metric's second half: simulated steps per second of the same 4096-agent scene (inference, no gradients)
     sim = {}
     try:
+        if light:
+            raise RuntimeError('skipped in sharded runs (see the 1-GPU line)')
         import time as _time
         from piml_amd.models.mlapm import MLAPM
         mm = MLAPM(**gc)
@@ -265,6 +270,8 @@ def secondary_measurements(scene, n, dev, _lib, prof=None):
     except Exception as ex:   # noqa: BLE001 - informational
         sim['mlapm_gc'] = {'error': f'{type(ex).__name__}: {ex}'}
     try:
+        if light:
+            raise RuntimeError('skipped in sharded runs (see the 1-GPU line)')
         import time as _time
         from piml_amd.scenes import synthetic_rollout_data
         from piml_amd.models.simulators import BaseSimulator
@@ -1123,7 +1130,7 @@ def main():
     secondary = None
     if rank == 0 and args.secondary:
         try:
-            secondary = secondary_measurements(scene, n_own, dev, _lib, prof)
+            secondary = secondary_measurements(scene, n_own, dev, _lib, prof, light=world > 1)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1 and fused_mlp:      # live evidence that the split products ARE f32 arithmetic: both forms against float64
