@@ -73,3 +73,28 @@ def test_polar_bottleneck_matches_reference(tag):
     for q, o in enumerate(outs):
         ref = g[f'pinnsf_pb/out_{tag}{q}']
         assert np.abs(o.numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('k,scale', [(6, 2.0), (10, 1.0)])
+def test_pooled_inference_fold_is_the_reference_algebra(k, scale):
+    """The inference forward sums the neighbour axis BEFORE the encoder's last layer and folds that layer into the decoder's first
+    (ops.pooled_h2_decoder_weights, PIML_POOL_H2).  On the reference's own modules (model.py:1271-1283: encoder -> processor
+    scale -> sum over k -> decoder): decoder_1(sum_r scale (W3 h2_r + b3)) == W' sum_r h2_r + b', in float64 to 1e-12."""
+    import piml_amd.models.model as M
+    from piml_amd import ops
+    torch.manual_seed(3)
+    net = getattr(M, 'PINNSF_multitask')(model_args()).double()
+    enc = [t for lin in net.obs_encoder.mlp[0::2] for t in (lin.weight, lin.bias)]
+    dec = [t for lin in net.obs_decoder.mlp[0::2] for t in (lin.weight, lin.bias)] + [net.obs_predictor.mlp[0].weight,
+                                                                                       net.obs_predictor.mlp[0].bias]
+    h2 = torch.randn(37, k, 128, dtype=torch.float64).relu()
+    msgs = scale * (h2 @ enc[4].T + enc[5])                         # processor output per row (eval mode: no dropout)
+    want = msgs.sum(dim=-2) @ dec[0].T + dec[1]                     # the decoder's first layer on the pooled messages
+    w1c, b1c, *rest = ops.pooled_h2_decoder_weights(enc, dec, scale, k)
+    assert w1c.dtype == torch.float32 and tuple(w1c.shape) == (64, 128) and tuple(b1c.shape) == (64,)
+    assert all(a is b for a, b in zip(rest, dec[2:]))               # everything behind the first layer is untouched
+    w64 = scale * (dec[0] @ enc[4])
+    b64 = dec[1] + scale * k * (dec[0] @ enc[5])
+    got = h2.sum(dim=-2) @ w64.T + b64
+    assert (got - want).abs().max() <= 1e-12 * want.abs().max()
+    assert (w1c.double() - w64).abs().max() <= 6e-8 * w64.abs().max() and (b1c.double() - b64).abs().max() <= 6e-8 * b64.abs().max()
