@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 29
+#define PIML_HIP_ABI_VERSION 30
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -296,6 +296,11 @@ int piml_rollout_losses_frames_bwd(const float* g_mse_out, const float* g_collw_
 
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);
+/* The same for up to 32 frames of a training rollout in ONE launch (src/models/simulators.py:708-715 counts every frame on its
+ * own): frames[f] = a HOST array of device pointers to (S, N, 2) tensors, S <= 25 slices each (independent slices, as in
+ * piml_collision_counts below 26); counts (nframes, n_thresholds, S, N): record f is what a call on frame f alone writes. */
+int piml_collision_counts_frames(const float* const* frames, int nframes, int S, int N, const float* thresholds,
+                                 int n_thresholds, float* counts, void* stream);
 
 /*
  * The same counts for stacks of MORE than 25 slices (the evaluation's (t, N, 2) rollouts) in parallel form: needs

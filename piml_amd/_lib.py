@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _lib = None
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     'piml_collision_matrix': [_p, _i, _i, _f, _i, _p, _p],
     'piml_collision_friends': [_p, _p, _i, _i, _i, _i, _p],
     'piml_collision_counts': [_p, _i, _i, _p, _i, _p, _p],
+    'piml_collision_counts_frames': [_p, _i, _i, _i, _p, _i, _p, _p],
     'piml_collision_counts_scratch': [_p, _i, _i, _p, _i, _p, _p, _p],
     'piml_collision_counts_grid': [_p, _i, _i, _p, _i, _p, _p, _p],
     'piml_collision_label': [_p, _z, _i, _p, _p],

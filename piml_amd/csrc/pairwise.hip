@@ -1181,17 +1181,14 @@ __device__ __forceinline__ float sq_below(float thr) {       // max { y : sqrtf(
     return sqrtf(y) < thr ? y : -1.f;
 }
 
+// counts of ONE slice: agent i = this wave's, `ps` its slice's N points; out[h * hstride] = count for threshold h
 template <int WAVES, int NTHR>
-__global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
-        const float2* __restrict__ p, int S, int N, const float* __restrict__ thr, int nthr,
-        float* __restrict__ counts) {
+__device__ __forceinline__ void cc_fast_slice(const float2* __restrict__ ps, int N, int i, const float* __restrict__ thr,
+                                              float* __restrict__ out, size_t hstride) {
     __shared__ __attribute__((aligned(16))) float tx[kCollTile], ty[kCollTile];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bps = (N + WAVES - 1) / WAVES;
-    const int s = blockIdx.x / bps;
-    const int i = (blockIdx.x - s * bps) * WAVES + wave;
+    const int lane = threadIdx.x & 63;
     const bool has = i < N;
-    const float2 pi = p[(size_t)s * N + (has ? i : 0)];
+    const float2 pi = ps[has ? i : 0];
     float cut[NTHR];
     int cnt[NTHR];
 #pragma unroll
@@ -1202,7 +1199,7 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
         __syncthreads();
         for (int t = threadIdx.x; t < tn_pad; t += WAVES * 64) {
             float2 q = make_float2(qnan, qnan);
-            if (t < tn) q = p[(size_t)s * N + base + t];
+            if (t < tn) q = ps[base + t];
             tx[t] = q.x; ty[t] = q.y;
         }
         __syncthreads();
@@ -1226,8 +1223,38 @@ __global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
         int c = cnt[h];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0) counts[((size_t)h * S + s) * N + i] = (float)c;
+        if (lane == 0) out[(size_t)h * hstride] = (float)c;
     }
+}
+
+template <int WAVES, int NTHR>
+__global__ __launch_bounds__(WAVES * 64) void collision_counts_fast_kernel(
+        const float2* __restrict__ p, int S, int N, const float* __restrict__ thr, int nthr,
+        float* __restrict__ counts) {
+    const int wave = threadIdx.x >> 6;
+    const int bps = (N + WAVES - 1) / WAVES;
+    const int s = blockIdx.x / bps;
+    const int i = (blockIdx.x - s * bps) * WAVES + wave;
+    cc_fast_slice<WAVES, NTHR>(p + (size_t)s * N, N, i, thr, counts + (size_t)s * N + (i < N ? i : 0), (size_t)S * N);
+}
+
+// The same for the frames of a training rollout in ONE launch (src/models/simulators.py:708-715, once per frame there): frame f
+// is its own (S, N, 2) tensor, record f = counts[f] (nthr, S, N) is exactly what a launch on that frame alone writes.
+struct CcFrames {
+    const float2* p[32];
+    int nframes;
+};
+template <int WAVES, int NTHR>
+__global__ __launch_bounds__(WAVES * 64) void collision_counts_frames_kernel(CcFrames F, int S, int N, const float* __restrict__ thr,
+                                                                             float* __restrict__ counts) {
+    const int wave = threadIdx.x >> 6;
+    const int bps = (N + WAVES - 1) / WAVES;
+    const int fs = blockIdx.x / bps, f = fs / S, s = fs - f * S;
+    const int i = (blockIdx.x - fs * bps) * WAVES + wave;
+    const float2* ps = F.p[0];
+#pragma unroll 1
+    for (int q = 1; q < 32; ++q) ps = (q == f) ? F.p[q] : ps;            // (a by-value pointer table indexed at run time lands in scratch)
+    cc_fast_slice<WAVES, NTHR>(ps + (size_t)s * N, N, i, thr, counts + ((size_t)f * NTHR * S + s) * N + (i < N ? i : 0), (size_t)S * N);
 }
 
 // calculate_collision_label (data.py:514-535): any tau in {0,.1,...,.9} with 0 != |dp + dv tau| < 0.5
@@ -1469,6 +1496,31 @@ PIML_API int piml_collision_counts(const float* position, int S, int N, const fl
     } else {
         return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_counts_frames(const float* const* frames, int nframes, int S, int N, const float* thresholds,
+                                         int n_thresholds, float* counts, void* stream) {
+    if (nframes < 0 || nframes > 32 || S < 0 || S > 25 || N < 0 || n_thresholds < 1 || n_thresholds > kCollMaxThr) return hipErrorInvalidValue;
+    if ((long)nframes * S * N == 0) return hipSuccess;
+    if (!frames || !thresholds || !counts) return hipErrorInvalidValue;
+    CcFrames F = {};
+    F.nframes = nframes;
+    for (int f = 0; f < nframes; ++f) {
+        if (!frames[f]) return hipErrorInvalidValue;
+        F.p[f] = (const float2*)frames[f];
+    }
+    const int waves = (long)nframes * S * N >= 4096 ? 16 : 4;
+    const unsigned grid = (unsigned)(nframes * S * ((N + waves - 1) / waves));
+#define PIML_CCF_LAUNCH(W, T)                                                                                        \
+    hipLaunchKernelGGL((collision_counts_frames_kernel<W, T>), dim3(grid), dim3(W * 64), 0, as_stream(stream), F, S, N, \
+                       thresholds, counts)
+#define PIML_CCF_BY_T(W)                                                                                             \
+    switch (n_thresholds) { case 1: PIML_CCF_LAUNCH(W, 1); break; case 2: PIML_CCF_LAUNCH(W, 2); break;              \
+                            case 3: PIML_CCF_LAUNCH(W, 3); break; default: PIML_CCF_LAUNCH(W, 4); break; }
+    if (waves == 16) { PIML_CCF_BY_T(16) } else { PIML_CCF_BY_T(4) }
+#undef PIML_CCF_BY_T
+#undef PIML_CCF_LAUNCH
     return hipGetLastError();
 }
 

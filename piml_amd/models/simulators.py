@@ -37,6 +37,9 @@ from .. import ops
 from ..pedestrians import Pedestrians
 from . import model as MODEL
 
+# the frames' collision counts of a training window in one launch at its end (ops.collision_counts_frames) instead of one per frame
+BATCH_COUNTS = os.environ.get('PIML_BATCH_COUNTS', '1') != '0'
+
 
 class RolloutResult(types.SimpleNamespace):
     """What the reference returns as a `RawData` from get_multiple_rollouts (simulators.py:655-657)."""
@@ -498,12 +501,14 @@ class BaseSimulator(Pedestrians):
                 nan_flag = torch.zeros((), device=dev, dtype=torch.int32)
                 speed_rows = desired_speed.contiguous()
 
+        batch_counts = BATCH_COUNTS and p_cur.is_cuda and p_cur.dim() == 3 and p_cur.shape[0] <= 25 and T - t_start <= 32
         for t in range(t_start, T):
             predictions = self.model(*state)                                  # :701
             p_msg = predictions[1]
             gf = gates_f[t]
 
-            cnt_steps.append(ops.collision_counts(p_cur, (thr, thr / 2)))     # :708-715, fused, quirk Q7
+            if not batch_counts:
+                cnt_steps.append(ops.collision_counts(p_cur, (thr, thr / 2)))     # :708-715, fused, quirk Q7
             if need_label_counts:
                 lab_steps.append(ops.collision_counts(lab_frames[t], (thr, thr / 2)))   # :717-724
             p_steps.append(p_cur)                                             # :728-729
@@ -545,6 +550,9 @@ class BaseSimulator(Pedestrians):
             if not fused_step:
                 pf, of, df = self._features(p_cur, v_cur, a_cur, dest_cur, obstacles)   # :772-776, differentiable
                 state = [pf, of, torch.cat((df, v_cur, a_cur, desired_speed), dim=-1)]  # :778-779
+
+        if batch_counts:        # :708-715 for every frame of the window in one launch (the positions are not differentiated here)
+            cnt_steps = ops.collision_counts_frames(p_steps, (thr, thr / 2))
 
         def frames(steps):
             """per-frame (2, C, N) count records -> two gated (C, T, N) tensors"""

@@ -652,6 +652,32 @@ def collision_counts(position, thresholds):
     return counts
 
 
+def collision_counts_frames(frames, thresholds):
+    """[collision_counts(f, thresholds) for f in frames] in ONE launch (piml_collision_counts_frames): `frames` = up to 32
+    (S, N, 2) tensors of one shape with S <= 25 (the frames of a training rollout, each counted on its own by
+    src/models/simulators.py:708-715).  Returns a list of (len(thresholds), S, N) views of one buffer."""
+    import ctypes
+    ps = [_gpu_f32('position', f.detach()) for f in frames]
+    if not ps:
+        return []
+    S, N = ps[0].shape[0], ps[0].shape[1]
+    if any(p.dim() != 3 or tuple(p.shape) != (S, N, 2) for p in ps):
+        raise ValueError('collision_counts_frames: (S, N, 2) frames of one shape expected')
+    if len(ps) > 32 or S > 25 or not 1 <= len(thresholds) <= 4:
+        return [collision_counts(p, thresholds) for p in ps]
+    dev = ps[0].device
+    key = (dev, tuple(float(t) for t in thresholds))
+    thr = _THRESHOLDS.get(key)
+    if thr is None:
+        thr = _THRESHOLDS[key] = torch.tensor(key[1], device=dev, dtype=torch.float32)
+    counts = torch.empty(len(ps), len(thresholds), S, N, device=dev, dtype=torch.float32)
+    arr = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().piml_collision_counts_frames(arr, len(ps), S, N, _ptr(thr), len(thresholds), _ptr(counts), _stream()),
+                   'piml_collision_counts_frames')
+    return list(counts.unbind(0))
+
+
 _LOSS_TICKETS = {}
 
 

@@ -340,3 +340,19 @@ def test_collision_counts_grid_form_equals_sweeps_and_oracle(oracle, monkeypatch
         for h in range(len(thr)):
             assert np.array_equal(got[h], want[h]), (grid, thr[h], np.abs(got[h] - want[h]).max())
     assert want[0].sum() > 0
+
+
+@pytest.mark.parametrize('T,S,N', [(5, 4, 122), (1, 1, 7), (32, 3, 300), (6, 25, 1100)])
+def test_collision_counts_frames_equal_per_frame_calls(T, S, N):
+    """The frames of a training window counted in ONE launch: record f is bitwise what a launch on frame f alone writes."""
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    frames = []
+    for _ in range(T):
+        p = (torch.rand(S, N, 2, generator=g) * 8.0).to(DEV)
+        p[:, ::9] = float('nan')
+        frames.append(p)
+    got = ops.collision_counts_frames(frames, (0.5, 0.25))
+    assert len(got) == T
+    for f, rec in zip(frames, got):
+        assert torch.equal(rec, ops.collision_counts(f, (0.5, 0.25)))
