@@ -194,8 +194,9 @@ class _PINNSFBase(nn.Module):
     bottleneck = False          # decoder + predictor applied per neighbour, then summed over k
     collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
     _ph2 = None                 # folded weights + operand images of the pooled inference path (see _pooled_inference)
-    predictions_only = False    # set by the inference rollouts (BaseSimulator): the fused network skips the 'msgs' collision head,
-                                # whose output those loops never read (simulators.py:602 takes [0]); forward then returns None in its place
+    predictions_only = False    # set by the inference rollouts (BaseSimulator): the auxiliary collision head (`pinnsf_m`: on the messages,
+                                # `pinnsf_bm`: on the decoded rows) is not launched -- those loops read out[0] only (simulators.py:602) --
+                                # and forward returns None in its place
     residual = False            # pinnsf_res corrector branch
     obs_encoder_in = 6          # PINNSF_residual uses args.obs_feature_dim instead
     taus = (2, 2)               # (non-ucy tau, ucy tau)
@@ -634,7 +635,9 @@ class _PINNSFBase(nn.Module):
         out = [predictions, ped_msgs]
         if out_obs is not None:
             out.append(out_obs)
-        if self.collision_head is not None:
+        if self.collision_head is not None and self.predictions_only:
+            out.append(None)                    # inference rollouts read out[0] only: the auxiliary head is not launched
+        elif self.collision_head is not None:
             src = ped_msgs if self.collision_head == 'msgs' else decoded
             head = self.ped_collision_predictor.mlp
             if self.collision_head == 'decoded' and FUSED_GLUE and FUSED_ROW_DECODER and src.is_cuda \

@@ -25,7 +25,8 @@ if __name__ == '__main__':
         T = 200
         data = synthetic_rollout_data(N, M, T, dev)
         torch.manual_seed(666)
-        sim = BaseSimulator(sim_args(**(dict(mlp_side_stream_rows=1024) if tuned else {})))
+        extra = dict(model=sys.argv[sys.argv.index('--model') + 1]) if '--model' in sys.argv else {}
+        sim = BaseSimulator(sim_args(**extra, **(dict(mlp_side_stream_rows=1024) if tuned else {})))
         sim.model.eval()
         with torch.no_grad():
             for graph in (False, True):
