@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 30
+#define PIML_HIP_ABI_VERSION 31
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -354,6 +354,21 @@ int piml_rollout_step(float* position, float* velocity, float* acceleration, flo
                       float* acceleration_out, float* mask_out, float* self_features_next,
                       const float* desired_speed, const int64_t* frame_counter, int C, int T, int N,
                       float dt, int remove_arrived, void* stream);
+
+/* piml_rollout_step with the bottleneck variants' network epilogue in front of it (piml_pinnsf_epilogue_ksum_fwd's arithmetic: the sum
+ * of the agent's kp / ko per-neighbour predictions pred_ped (C N kp, 2) [+ pred_obs (C N ko, 2) or NULL] + the desired-force
+ * term of its self_features row, per-row norm): an inference frame of `pinnsf_bm` / `pinnsf_bottleneck` needs one launch for
+ * both.  The self_features read are the rows of `self_features_next` BEFORE this launch rewrites them (F must be 7); a_next is
+ * ignored (may be NULL). */
+int piml_rollout_step_ksum(const float* pred_ped, int kp, const float* pred_obs, int ko, float tau, float* position,
+                           float* velocity, float* acceleration, float* destination, int64_t* dest_idx, float* hist_velocity,
+                           int hist_width, const float* a_next, const float* waypoints, int D, int waypoints_per_slice,
+                           const int64_t* dest_num, const float* position_series, const float* velocity_series,
+                           const float* acceleration_series, const float* destination_series,
+                           const int64_t* dest_idx_series, const float* self_features_series, int F, const uint8_t* new_flag,
+                           float* position_out, float* velocity_out, float* acceleration_out, float* mask_out,
+                           float* self_features_next, const float* desired_speed, const int64_t* frame_counter, int C, int T,
+                           int N, float dt, int remove_arrived, void* stream);
 
 /*
  * The hand-written collision handling that closes PINNSF_polar_bottleneck_collision.forward

@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _lib = None
 
@@ -79,6 +79,8 @@ SIGNATURES = {
     'piml_calc_acceleration': [_p, _z, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p],
     'piml_rollout_step': [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                           _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    'piml_rollout_step_ksum': [_p, _i, _p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p,
+                               _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     'piml_collision_correction_fwd': [_p, _p, _p, _z, _i, _i, _f, _f, _p, _p],
     'piml_collision_correction_bwd': [_p, _p, _p, _p, _z, _i, _i, _f, _f, _p, _p, _p, _p],
     'piml_train_step_fwd': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -1646,9 +1646,7 @@ struct RolloutArgs {
 // One thread per (slice, agent): record frame t, lagged explicit Euler (quirk Q6), waypoint switch
 // at 0.5 m, leave-scene NaN, injection of agents entering at frame t+1 from the ground truth,
 // history shift, and the (hist, a, v0) columns of the next self_features row.
-__global__ void rollout_step_kernel(const RolloutArgs A) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)A.C * A.N) return;
+__device__ __forceinline__ void rollout_step_agent(const RolloutArgs& A, long long g, float2 an) {
     const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
     const long long t = *A.t_dev;
     const long long tn = t + 1, tc = tn < A.T ? tn : A.T - 1;
@@ -1660,7 +1658,6 @@ __global__ void rollout_step_kernel(const RolloutArgs A) {
 
     float2 vn = make_float2(__fadd_rn(v.x, __fmul_rn(a.x, A.dt)), __fadd_rn(v.y, __fmul_rn(a.y, A.dt)));   // :603
     float2 pn = make_float2(__fadd_rn(p.x, __fmul_rn(v.x, A.dt)), __fadd_rn(p.y, __fmul_rn(v.y, A.dt)));   // :604
-    float2 an = A.a_next[g];
     long long idx = A.dest_idx[g];
     if (norm2(p.x - d.x, p.y - d.y) < 0.5f) idx += 1;            // :608-609
     const bool gone = idx > A.dest_num[i] - 1;
@@ -1685,6 +1682,34 @@ __global__ void rollout_step_kernel(const RolloutArgs A) {
     }
     so[2 + hw] = an.x; so[3 + hw] = an.y; so[4 + hw] = A.desired_speed[g];             // :651
     A.p[g] = pn; A.v[g] = vn; A.a[g] = an; A.dest[g] = dn; A.dest_idx[g] = idx;
+}
+
+__global__ void rollout_step_kernel(const RolloutArgs A) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)A.C * A.N) return;
+    rollout_step_agent(A, g, A.a_next[g]);
+}
+
+// The same step with the bottleneck variants' network epilogue in front of it (the arithmetic of pinnsf_epilogue_ksum_fwd_kernel,
+// mlpglue.hip: sum of the agent's kp / ko per-neighbour predictions + the desired-force term of its self_features row): an
+// inference frame of `pinnsf_bm` / `pinnsf_bottleneck` has one launch for both.  `sf` IS the buffer the step rewrites
+// (A.selff_out): a thread reads its own row before it writes it.
+__global__ __launch_bounds__(256) void rollout_step_ksum_kernel(const RolloutArgs A, const float2* __restrict__ pred_ped, int kp,
+                                                                const float2* __restrict__ pred_obs, int ko, const float* sf, float tau) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)A.C * A.N) return;
+    const float* s = sf + g * 7;
+    const float dx = s[0], dy = s[1], vx = s[2], vy = s[3], v0 = s[6];
+    float t = norm2(dx, dy);
+    t = (t == 0.f) ? t + 0.1f : t;
+    float2 a = make_float2(0.f, 0.f), o = make_float2(0.f, 0.f);
+    for (int i = 0; i < kp; ++i) { const float2 v = pred_ped[g * kp + i]; a.x += v.x; a.y += v.y; }
+    if (pred_obs) {
+        for (int i = 0; i < ko; ++i) { const float2 v = pred_obs[g * ko + i]; o.x += v.x; o.y += v.y; }
+        a.x += o.x;
+        a.y += o.y;
+    }
+    rollout_step_agent(A, g, make_float2(a.x + (v0 * (dx / t) - vx) / tau, a.y + (v0 * (dy / t) - vy) / tau));
 }
 
 // ---- differentiable frame step of the fine-tuning rollout (src/models/simulators.py:741-769) ----
@@ -1953,6 +1978,37 @@ PIML_API int piml_rollout_step(float* position, float* velocity, float* accelera
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::rollout_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        piml::as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_rollout_step_ksum(const float* pred_ped, int kp, const float* pred_obs, int ko, float tau, float* position, float* velocity, float* acceleration, float* destination,
+                               int64_t* dest_idx, float* hist_velocity, int hist_width, const float* a_next,
+                               const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                               const float* position_series, const float* velocity_series,
+                               const float* acceleration_series, const float* destination_series,
+                               const int64_t* dest_idx_series, const float* self_features_series, int F,
+                               const uint8_t* new_flag, float* position_out, float* velocity_out,
+                               float* acceleration_out, float* mask_out, float* self_features_next,
+                               const float* desired_speed, const int64_t* frame_counter, int C, int T, int N,
+                               float dt, int remove_arrived, void* stream) {
+    if (C < 0 || T <= 0 || N < 0 || hist_width < 2 || F != hist_width + 5 || D <= 0) return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    piml::RolloutArgs A;
+    A.p = (float2*)position; A.v = (float2*)velocity; A.a = (float2*)acceleration; A.dest = (float2*)destination;
+    A.dest_idx = (long long*)dest_idx; A.hist = hist_velocity; A.hist_w = hist_width;
+    A.a_next = (const float2*)a_next; A.waypoints = (const float2*)waypoints; A.D = D;
+    A.wp_per_slice = waypoints_per_slice; A.dest_num = (const long long*)dest_num;
+    A.pos_s = (const float2*)position_series; A.vel_s = (const float2*)velocity_series;
+    A.acc_s = (const float2*)acceleration_series; A.dest_s = (const float2*)destination_series;
+    A.dest_idx_s = (const long long*)dest_idx_series; A.selff_s = self_features_series; A.F = F;
+    A.new_flag = new_flag; A.p_res = (float2*)position_out; A.v_res = (float2*)velocity_out;
+    A.a_res = (float2*)acceleration_out; A.mask_new = mask_out; A.selff_out = self_features_next;
+    A.desired_speed = desired_speed; A.t_dev = (const long long*)frame_counter;
+    A.C = C; A.T = T; A.N = N; A.dt = dt; A.remove_arrived = remove_arrived;
+    if (!pred_ped || kp < 1 || (pred_obs && ko < 1) || !(tau > 0.f) || F != 7 || !self_features_next) return hipErrorInvalidValue;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::rollout_step_ksum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, piml::as_stream(stream), A,
+                       (const float2*)pred_ped, kp, (const float2*)pred_obs, ko, (const float*)self_features_next, tau);
     return hipGetLastError();
 }
 

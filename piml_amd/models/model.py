@@ -193,6 +193,8 @@ class _PINNSFBase(nn.Module):
     """Shared body of the PINNSF variants; subclasses set the class attributes below."""
     bottleneck = False          # decoder + predictor applied per neighbour, then summed over k
     collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
+    defer_ksum_epilogue = False # set around an inference frame's forward by BaseSimulator: the bottleneck variants leave their epilogue
+    pending_ksum = None         # (neighbour-axis sums + desired force) to the integrator launch and park its operands here
     _ph2 = None                 # folded weights + operand images of the pooled inference path (see _pooled_inference)
     predictions_only = False    # set by the inference rollouts (BaseSimulator): the auxiliary collision head (`pinnsf_m`: on the messages,
                                 # `pinnsf_bm`: on the decoded rows) is not launched -- those loops read out[0] only (simulators.py:602) --
@@ -617,7 +619,12 @@ class _PINNSFBase(nn.Module):
                 acc_o, out_obs, _, _ = self._branch(obs_features, self.obs_encoder, self.obs_processor,
                                                     self.obs_decoder, self.obs_predictor, pre=pre.get('obs'),
                                                     rowdec=rowdec.get('obs'), want_sum=not ksum_tail)
-        if ksum_tail:
+        if ksum_tail and self.defer_ksum_epilogue and self_features.dim() == 2 and not torch.is_grad_enabled():
+            # inference frames: the caller's integrator launch sums the per-neighbour predictions and adds the desired-force term
+            # itself (ops.rollout_step ksum=); out[0] is None
+            self.pending_ksum = (ped_msgs, out_obs, self.tau)
+            predictions = None
+        elif ksum_tail:
             from .. import ops
             predictions = ops.pinnsf_epilogue_ksum(ped_msgs, out_obs, self_features, self.tau,
                                                    agent_norm=self_features.dim() == 3 and not self.fix_dest_norm)
@@ -630,7 +637,7 @@ class _PINNSFBase(nn.Module):
             if acc_o is not None:
                 acc = acc + acc_o
             predictions = acc + self.desired_force(self_features)
-        if self.residual:
+        if self.residual and predictions is not None:
             predictions = predictions + self._correct(encoded)
         out = [predictions, ped_msgs]
         if out_obs is not None:

@@ -39,6 +39,8 @@ from . import model as MODEL
 
 # the frames' collision counts of a training window in one launch at its end (ops.collision_counts_frames) instead of one per frame
 BATCH_COUNTS = os.environ.get('PIML_BATCH_COUNTS', '1') != '0'
+# inference frames of the bottleneck variants: the network's epilogue inside the integrator's launch (ops.rollout_step ksum=)
+STEP_WITH_KSUM = os.environ.get('PIML_STEP_WITH_KSUM', '1') != '0'
 
 
 class RolloutResult(types.SimpleNamespace):
@@ -286,8 +288,20 @@ class BaseSimulator(Pedestrians):
         epilogue (piml_rollout_step), the relative-feature kernel writing straight into the state
         buffers (which also advances the frame counter)."""
         a = self.args
-        a_next = self.model(st.pf, st.of, st.selff)[0]
-        ops.rollout_step(st, data, a_next.contiguous(), remove_arrived=True)
+        # the bottleneck variants leave their epilogue (neighbour-axis sums + desired force) to the integrator's launch
+        defer = STEP_WITH_KSUM and st.selff.dim() == 2 and hasattr(self.model, 'defer_ksum_epilogue')
+        if defer:
+            self.model.defer_ksum_epilogue, self.model.pending_ksum = True, None
+        try:
+            a_next = self.model(st.pf, st.of, st.selff)[0]
+            ksum = getattr(self.model, 'pending_ksum', None) if defer else None
+        finally:
+            if defer:
+                self.model.defer_ksum_epilogue, self.model.pending_ksum = False, None
+        if a_next is None:
+            ops.rollout_step(st, data, None, remove_arrived=True, ksum=ksum)
+        else:
+            ops.rollout_step(st, data, a_next.contiguous(), remove_arrived=True)
         ops.relative_features_into((st.pf, st.of, st.selff, st.ped_idx, st.obs_idx), st.p, st.v, st.a, st.dest,
                                    data.obstacles, a.topk_ped, a.sight_angle_ped, a.dist_threshold_ped,
                                    a.topk_obs, a.sight_angle_obs, a.dist_threshold_obs, tick=st.t)   # + st.t += 1

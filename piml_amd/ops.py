@@ -926,21 +926,32 @@ def relative_features_into(outs, position, velocity, acceleration, destination, 
     return outs
 
 
-def rollout_step(st, data, a_next, remove_arrived=True):
+def rollout_step(st, data, a_next, remove_arrived=True, ksum=None):
     """One launch of the fused integrator epilogue (piml_rollout_step) on the rollout state `st`
-    built by BaseSimulator._rollout_state (buffers updated in place)."""
+    built by BaseSimulator._rollout_state (buffers updated in place).
+    ksum = (pred_ped (..., kp, 2), pred_obs (..., ko, 2) or None, tau) with a_next = None: the bottleneck variants' network
+    epilogue (pinnsf_epilogue_ksum's arithmetic on the rows of st.selff) runs inside the same launch (piml_rollout_step_ksum)."""
     C = st.p.numel() // max(st.p.shape[-2] * 2, 1)
     N, T = st.p.shape[-2], st.T
     wp = data.waypoints
-    with torch.cuda.device(st.p.device):
-        _lib.check(_lib.lib().piml_rollout_step(
-            _ptr(st.p), _ptr(st.v), _ptr(st.a), _ptr(st.dest), _ptr(st.dest_idx), _ptr(st.hist), st.hist.shape[-1],
+    args = (_ptr(st.p), _ptr(st.v), _ptr(st.a), _ptr(st.dest), _ptr(st.dest_idx), _ptr(st.hist), st.hist.shape[-1],
             _ptr(a_next), _ptr(st.waypoints), wp.shape[-3], int(wp.dim() > 3), _ptr(st.dest_num),
             _ptr(st.series['position']), _ptr(st.series['velocity']), _ptr(st.series['acceleration']),
             _ptr(st.series['destination']), _ptr(st.series['dest_idx']), _ptr(st.series['self_features']),
             st.selff.shape[-1], _ptr(st.new_flag_u8), _ptr(st.p_res), _ptr(st.v_res), _ptr(st.a_res),
             _ptr(st.mask_new), _ptr(st.selff), _ptr(st.desired_speed), _ptr(st.t), C, T, N,
-            float(data.time_unit), int(remove_arrived), _stream()), 'piml_rollout_step')
+            float(data.time_unit), int(remove_arrived), _stream())
+    with torch.cuda.device(st.p.device):
+        if ksum is not None:
+            pp, po, tau = ksum
+            pp = _gpu_f32('pred_ped', pp)
+            po = _gpu_f32('pred_obs', po) if po is not None else None
+            if pp.numel() != C * N * pp.shape[-2] * 2 or (po is not None and po.numel() != C * N * po.shape[-2] * 2):
+                raise ValueError('rollout_step: per-neighbour predictions (..., k, 2) of the rollout\'s agents expected')
+            _lib.check(_lib.lib().piml_rollout_step_ksum(_ptr(pp), pp.shape[-2], _ptr(po), po.shape[-2] if po is not None else 1,
+                                                         float(tau), *args), 'piml_rollout_step_ksum')
+        else:
+            _lib.check(_lib.lib().piml_rollout_step(*args), 'piml_rollout_step')
 
 
 # ------------------------------------------------------------------------------------------------

@@ -383,3 +383,32 @@ def test_pooled_inference_forward_matches_message_path(N, M):
             MODEL.POOLED_INFERENCE = keep
         pa, pb = torch.nan_to_num(a.position), torch.nan_to_num(b.position)
         assert (pa - pb).abs().max() <= 1e-4, (pa - pb).abs().max()
+
+
+@pytest.mark.parametrize('model_name', ['pinnsf_bm', 'pinnsf_bottleneck'])
+def test_bottleneck_inference_frames_equal_operator_sequence(model_name):
+    """Inference frames of the bottleneck variants: no auxiliary collision head, and the network's epilogue (neighbour-axis sums +
+    desired force) inside the integrator's launch (piml_rollout_step_ksum) -- bitwise the trajectory of the operator sequence
+    (ops.pinnsf_epilogue_ksum, then ops.rollout_step), eager and replayed."""
+    from piml_amd.scenes import synthetic_rollout_data
+    from piml_amd.models.simulators import BaseSimulator
+    import piml_amd.models.simulators as SIM
+    data = synthetic_rollout_data(300, 120, 14, DEV)
+    torch.manual_seed(666)
+    sim = BaseSimulator(sim_args(model=model_name))
+    sim.model.eval()
+    res = {}
+    with torch.no_grad():
+        for merged in (True, False):
+            keep = SIM.STEP_WITH_KSUM
+            SIM.STEP_WITH_KSUM = merged
+            try:
+                for graph in (False, True):
+                    out = sim.get_multiple_rollouts(data, 0, load_model=False, use_graph=graph)
+                    res[(merged, graph)] = (torch.nan_to_num(out.position).clone(), torch.nan_to_num(out.acceleration).clone())
+            finally:
+                SIM.STEP_WITH_KSUM = keep
+    ref = res[(False, False)]
+    assert float(ref[1].abs().max()) > 0
+    for key, got in res.items():
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), key
