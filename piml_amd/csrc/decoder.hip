@@ -10,6 +10,7 @@
 // the packed global image: a wave owns one 32-agent tile and uses every fragment once, so LDS staging buys nothing).
 // One workgroup = one 32-agent tile, wave 0 = pedestrian branch, wave 1 = obstacle branch, combined through LDS.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "pack.hpp"
@@ -874,6 +875,37 @@ constexpr int RD_CHUNK = 32;
 constexpr int RD_G1 = 0, RD_G2 = RD_CHUNK * DD, RD_H1 = 2 * RD_CHUNK * DD, RD_D2 = 3 * RD_CHUNK * DD, RD_E = 4 * RD_CHUNK * DD,
               RD_GP = RD_E + RD_CHUNK * DH, RD_BUF = RD_GP + RD_CHUNK * 2;
 
+// the products of one 32-row chunk for a wave's role (1: c1 alone, 2: c1 + c2, 3: c1 + c3; cx / sx = the second accumulator and
+// its column sum): a wave's role is fixed, so one branch per chunk and straight-line code behind it, the operands of four k-steps
+// read ahead of their products -- with the role tested inside the k loop every product sat behind its own two LDS reads and
+// their full latency.  (Eight k-steps ahead, or the sums captured by a nested lambda: scratch traffic inside the products, whose
+// reloads wait for every global load in flight.)
+template <int ROLE>
+__device__ __forceinline__ float2 rd_products(const float* buf, int h, int i, int mb1, int nb1, int mb2, int nb2, f32x16& c1, f32x16& cx,
+                                              float s1, float sx) {
+    constexpr int AHEAD = 4;                // (s1, sx: the running column sums of the two A operands, in and out BY VALUE -- as
+                                            // reference parameters they ended up in scratch; one running sum: the order of the
+                                            // additions is the k order, as before)
+#pragma unroll
+    for (int k0 = 0; k0 < RD_CHUNK / 2; k0 += AHEAD) {
+        float a1[AHEAD], b1[AHEAD], a2[AHEAD], b2[AHEAD];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int row = 2 * (k0 + u) + h;
+            a1[u] = buf[RD_G1 + row * DD + 32 * mb1 + i]; b1[u] = buf[RD_E + row * DH + 32 * nb1 + i];
+            if (ROLE == 2) { a2[u] = buf[RD_G2 + row * DD + 32 * mb2 + i]; b2[u] = buf[RD_H1 + row * DD + 32 * nb2 + i]; }
+            if (ROLE == 3) { a2[u] = i < 2 ? buf[RD_GP + row * 2 + i] : 0.f; b2[u] = buf[RD_D2 + row * DD + 32 * nb2 + i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            c1 = dmfma(a1[u], b1[u], c1);
+            s1 += a1[u];
+            if (ROLE != 1) { cx = dmfma(a2[u], b2[u], cx); sx += a2[u]; }
+        }
+    }
+    return make_float2(s1, sx);
+}
+
 __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int slots0, long long slab0, long long slab1) {
     extern __shared__ __align__(16) float rd_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = uniform((int)(tid >> 6));
@@ -886,10 +918,10 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
     const int i = lane & 31, h = lane >> 5;
     const int mb1 = w >> 2, nb1 = w & 3, mb2 = (w >> 1) & 1, nb2 = w & 1;
     const bool do2 = w < 4, do3 = w == 4 || w == 5;
-    f32x16 c1, c2, c3;
+    f32x16 c1, cx;           // cx: the wave's second product (do2: dW2 block, do3: the predictor's dW), sx its column sum
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int r = 0; r < 16; ++r) { c1[r] = 0.f; cx[r] = 0.f; }
+    float s1 = 0.f, sx = 0.f;
     // staging role: row srow of the chunk, float4 column sc4 of the 64-wide arrays (and sc4, sc4 + 64 of the embeddings)
     const int srow = tid >> 4, sc4 = (tid & 15) * 4;
     struct Stage { float4 g1, g2, h1, d2, e0, e1; float gp; bool ok; };
@@ -904,12 +936,14 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
         S.d2 = *reinterpret_cast<const float4*>(J.d2 + ro * DD + sc4);
         S.e0 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + sc4);
         S.e1 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + 64 + sc4);
-        const long long gr = rb + (tid >> 1);                      // threads 0..63: the chunk's (row, component) of g_pred
-        S.gp = J.g_pred_rows[(gr < s1e && tid < 2 * RD_CHUNK ? gr : (s0 < R ? s0 : 0)) * 2 + (tid & 1)];
-        if (!(gr < s1e && tid < 2 * RD_CHUNK)) S.gp = 0.f;
+        // (every thread loads -- clamped -- and the value is looked at only when it is written to LDS: as a conditional load
+        // with its select right behind it the compiler put s_waitcnt vmcnt(0) in FRONT of the chunk's products in wave 0, and
+        // the whole workgroup waited for that wave at the barrier: loads and products took turns)
+        const long long gr = rb + ((tid & 63) >> 1);               // threads 0..63 matter: the chunk's (row, component) of g_pred
+        S.gp = J.g_pred_rows[(gr < s1e ? gr : (s0 < R ? s0 : 0)) * 2 + (tid & 1)];
         return S;
     };
-    auto stage_write = [&](const Stage S, float* buf) {
+    auto stage_write = [&](const Stage S, float* buf, long long rb) {
         auto sel = [&](const float4 v) { return make_float4(S.ok ? v.x : 0.f, S.ok ? v.y : 0.f, S.ok ? v.z : 0.f, S.ok ? v.w : 0.f); };
         *reinterpret_cast<float4*>(buf + RD_G1 + srow * DD + sc4) = sel(S.g1);
         *reinterpret_cast<float4*>(buf + RD_G2 + srow * DD + sc4) = sel(S.g2);
@@ -917,31 +951,19 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
         *reinterpret_cast<float4*>(buf + RD_D2 + srow * DD + sc4) = sel(S.d2);
         *reinterpret_cast<float4*>(buf + RD_E + srow * DH + sc4) = sel(S.e0);
         *reinterpret_cast<float4*>(buf + RD_E + srow * DH + 64 + sc4) = sel(S.e1);
-        if (tid < 2 * RD_CHUNK) buf[RD_GP + tid] = S.gp;
+        if (tid < 2 * RD_CHUNK) buf[RD_GP + tid] = rb + (tid >> 1) < s1e ? S.gp : 0.f;
     };
     auto compute = [&](const float* buf) {
-#pragma unroll
-        for (int ks = 0; ks < RD_CHUNK / 2; ++ks) {
-            const int row = 2 * ks + h;
-            const float a1 = buf[RD_G1 + row * DD + 32 * mb1 + i], b1 = buf[RD_E + row * DH + 32 * nb1 + i];
-            c1 = dmfma(a1, b1, c1);
-            s1 += a1;
-            if (do2) {
-                const float a2 = buf[RD_G2 + row * DD + 32 * mb2 + i], b2 = buf[RD_H1 + row * DD + 32 * nb2 + i];
-                c2 = dmfma(a2, b2, c2);
-                s2 += a2;
-            }
-            if (do3) {
-                const float a3 = i < 2 ? buf[RD_GP + row * 2 + i] : 0.f, b3 = buf[RD_D2 + row * DD + 32 * nb2 + i];
-                c3 = dmfma(a3, b3, c3);
-                s3 += a3;
-            }
-        }
+        float2 ds;
+        if (do2) ds = rd_products<2>(buf, h, i, mb1, nb1, mb2, nb2, c1, cx, s1, sx);
+        else if (do3) ds = rd_products<3>(buf, h, i, mb1, nb1, mb2, nb2, c1, cx, s1, sx);
+        else ds = rd_products<1>(buf, h, i, mb1, nb1, mb2, nb2, c1, cx, s1, sx);
+        s1 = ds.x; sx = ds.y;
     };
     if (s0 < s1e) {
         const int nb = (int)((s1e - s0 + RD_CHUNK - 1) / RD_CHUNK);
         Stage S = stage_load(s0);
-        stage_write(S, rd_lds);
+        stage_write(S, rd_lds, s0);
         __syncthreads();
         for (int t = 0; t < nb; ++t) {
             float* cur = rd_lds + (t & 1) * RD_BUF;
@@ -950,7 +972,7 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             __builtin_amdgcn_sched_barrier(0);
-            stage_write(S, nxt);
+            stage_write(S, nxt, s0 + (long long)(t + 1) * RD_CHUNK);
             __syncthreads();
         }
     }
@@ -959,17 +981,16 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
     for (int r = 0; r < 16; ++r) {
         const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
         P[(size_t)(32 * mb1 + ri) * DH + 32 * nb1 + i] = c1[r];
-        if (do2) P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = c2[r];
-        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = c3[r];
+        if (do2) P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = cx[r];
+        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = cx[r];
     }
     s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    s3 += __shfl_xor(s3, 32, 64);
+    sx += __shfl_xor(sx, 32, 64);
     float* Pb = P + DD * DH + DD * DD + 2 * DD;
     if (h == 0) {
         if (nb1 == 0) Pb[32 * mb1 + i] = s1;                       // waves 0 and 4
-        if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;           // waves 0 and 2
-        if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
+        if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = sx;           // waves 0 and 2
+        if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? sx : 0.f;    // db3 + padding
     }
 }
 

@@ -12,7 +12,10 @@ scene = synthetic_gc_scene(N, M, seed=0)
 import types
 _margs = bench.model_args
 bench.model_args = lambda: types.SimpleNamespace(**dict(_margs().__dict__, res_hidden_layers=3))
-for name in ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNSF_bottleneck', 'PINNSF_residual'):
+NAMES = ('PINNSF_multitask', 'PINNSF', 'PINNSF_bottleneck_multitask', 'PINNSF_bottleneck', 'PINNSF_residual')
+if '--models' in sys.argv:          # e.g. --models PINNSF_bottleneck_multitask (the program to put under rocprofv3 for one model's kernel mix)
+    NAMES = tuple(sys.argv[sys.argv.index('--models') + 1].split(','))
+for name in NAMES:
   for train in (False, True):
     try:
         st = bench.Step(scene, N, N, 0, M, dev, None, False, False, True, model_name=name, train_mode=train)
