@@ -323,7 +323,8 @@ __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<
 // SPLIT (round 3): the agent-level chain with one 4-wave workgroup per (tile, branch) like the forward's SPLIT form --
 // the 8-wave form runs 128 workgroups at the 4096-agent scene, half the CUs.
 template <bool ROWS = false, bool SPLIT = false>
-__device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile, int rows_branch = 0) {
+__device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile, int rows_branch = 0, float* keep_g2 = nullptr,
+                                                float* keep_g1 = nullptr) {
     constexpr int NB = (ROWS || SPLIT) ? 1 : 2;
     __shared__ float part[NB][2][2][16][64];       // [branch][ob][kh][register][lane]
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));   // in an SGPR: per-wave selects stay scalar
@@ -376,7 +377,14 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
                 g2[4 * q + 2] += valid ? gd2[q].z : 0.f; g2[4 * q + 3] += valid ? gd2[q].w : 0.f;
             }
         }
-        if (ob == 0 && valid) {
+        if (SPLIT && keep_g2) {            // the tile's g_pre2 stays in the workgroup (LDS [agent][64]): its only reader is the dW body
+            if (ob == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(keep_g2 + j * DD + dfeat0(kh, q, h)) =
+                        valid ? make_float4(g2[4 * q], g2[4 * q + 1], g2[4 * q + 2], g2[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if (ob == 0 && valid) {
             float* o = J.g_pre2 + agent * DD;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -408,7 +416,17 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
                 g1c[o2][4 * q + u] = (valid && m[u] > 0.f) ? v : 0.f;
             }
         }
-    if (blk < 2 && valid) {          // (compile-time register indices: a runtime g1c[blk] becomes a select chain)
+    if (SPLIT && keep_g1) {          // (g1c is already zero for agents past the end)
+        if (blk < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v0 = make_float4(g1c[0][4 * q], g1c[0][4 * q + 1], g1c[0][4 * q + 2], g1c[0][4 * q + 3]);
+                const float4 v1 = make_float4(g1c[1][4 * q], g1c[1][4 * q + 1], g1c[1][4 * q + 2], g1c[1][4 * q + 3]);
+                if (blk == 0) *reinterpret_cast<float4*>(keep_g1 + j * DD + dfeat0(0, q, h)) = v0;
+                else *reinterpret_cast<float4*>(keep_g1 + j * DD + dfeat0(1, q, h)) = v1;
+            }
+        }
+    } else if (blk < 2 && valid) {          // (compile-time register indices: a runtime g1c[blk] becomes a select chain)
         float* o = J.g_pre1 + agent * DD;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -529,7 +547,8 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
 
 // The same partials by FOUR waves (the (tile, branch) workgroups of dec_bwd_split_kernel): wave w owns blocks (0, w) and
 // (1, w) of dW1 (they share the pooled-column operand), block (w >> 1, w & 1) of dW2, waves 0 / 1 column block w of dW3.
-__device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p, int w, int lane) {
+__device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p, int w, int lane, const float* keep_g2 = nullptr,
+                                                 const float* keep_g1 = nullptr) {
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long R = J.agents;
     const long long s0 = (long long)p * DEC_SLAB < R ? (long long)p * DEC_SLAB : R;
@@ -548,10 +567,16 @@ __device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p,
         const long long row = s0 + 2 * u + h;
         const bool ok = row < s1e;
         const long long ro = ok ? row : (s0 < R ? s0 : 0);
-        a1a[u] = J.g_pre1[ro * DD + i];
-        a1b[u] = J.g_pre1[ro * DD + 32 + i];
+        if (keep_g1) {                 // the tile's gradients from the dX chain of the same workgroup (LDS, zero past the end)
+            a1a[u] = keep_g1[(2 * u + h) * DD + i];
+            a1b[u] = keep_g1[(2 * u + h) * DD + 32 + i];
+            a2[u] = keep_g2[(2 * u + h) * DD + 32 * mb2 + i];
+        } else {
+            a1a[u] = J.g_pre1[ro * DD + i];
+            a1b[u] = J.g_pre1[ro * DD + 32 + i];
+            a2[u] = J.g_pre2[ro * DD + 32 * mb2 + i];
+        }
         b1[u] = J.pooled[ro * DH + 32 * w + i];
-        a2[u] = J.g_pre2[ro * DD + 32 * mb2 + i];
         b2[u] = J.h1[ro * DD + 32 * nb2 + i];
         a3[u] = (do3 && i < 2) ? A.g_pred[ro * 2 + i] : 0.f;
         b3[u] = do3 ? J.d2[ro * DD + 32 * nb2 + i] : 0.f;
@@ -592,10 +617,12 @@ __global__ __launch_bounds__(256) void dec_bwd_split_kernel(DecArgs A) {
     const int bx = blockIdx.x;
     const int b = A.nbr > 1 ? (bx & 1) : 0;
     const long long tile = A.nbr > 1 ? (bx >> 1) : bx;
-    dec_bwd_dx_body<false, true>(A, tile, b);
-    __threadfence_block();
+    // g_pre2 / g_pre1 of the tile never leave the workgroup: the dX chain leaves them in LDS ([agent][64]) and the weight-gradient
+    // products read them there -- no stores to drain in front of the barrier, no round trip through L2 behind it (round 4)
+    __shared__ __align__(16) float keep[2][32 * DD];
+    dec_bwd_dx_body<false, true>(A, tile, b, keep[0], keep[1]);
     __syncthreads();
-    dec_bwd_dw_body4(A, b, (int)tile, uniform((int)(threadIdx.x >> 6)), threadIdx.x & 63);
+    dec_bwd_dw_body4(A, b, (int)tile, uniform((int)(threadIdx.x >> 6)), threadIdx.x & 63, keep[0], keep[1]);
 }
 
 __global__ __launch_bounds__(512) void dec_bwd_dw_kernel(DecArgs A) {
