@@ -456,28 +456,54 @@ __device__ __forceinline__ void relfeat_bwd_rows(
     const size_t ci = (size_t)c * N + f0 + fl;
     const int q = lane & 7, s0 = lane >> 3;
     float own = 0.f;
-    if (q < 6) {
-        for (int s = s0; s < kpe; s += 8) {
-            const int j = ped_idx[row * kpe + s];
-            if (j < 0) continue;
-            const float g = g_ped[(row * kpe + s) * 6 + q];
-            atomicAdd(g_state + ((size_t)c * N + j) * 6 + q, g);
-            own -= g;
+    // the row's own terms: requested up front too (they were three more round trips behind the neighbour sums)
+    const bool head = s0 == 0 && q < 6;
+    float d_q = 0.f, p_q = 0.f, gdf = 0.f;
+    if (head) {
+        if (q < 2) {
+            d_q = reinterpret_cast<const float*>(dest)[row * 2 + q];
+            p_q = p[ci * ld + q];
+            gdf = reinterpret_cast<const float*>(g_destf)[row * gld + q];
+        } else if (gld == 7) {
+            gdf = reinterpret_cast<const float*>(g_destf)[row * 7 + q];
         }
-        for (int s = s0; s < koe; s += 8)
-            if (obs_idx[row * koe + s] >= 0) own -= g_obs[(row * koe + s) * 6 + q];
+    }
+    if (q < 6) {
+        // every index and gradient of the lane requested at once (k <= PIML_MAX_TOPK: TR trips of 8 slots at most) -- as loops
+        // that looked at an index before they asked for its gradient a row was four dependent round trips to L2
+        constexpr int TR = (PIML_MAX_TOPK + 7) / 8;
+        int jp[TR], jo[TR];
+        float gp[TR], go[TR];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int s = s0 + 8 * t;
+            const bool inp = s < kpe, ino = s < koe;
+            jp[t] = inp ? ped_idx[row * kpe + s] : -1;
+            gp[t] = inp ? g_ped[(row * kpe + s) * 6 + q] : 0.f;
+            jo[t] = ino ? obs_idx[row * koe + s] : -1;
+            go[t] = ino ? g_obs[(row * koe + s) * 6 + q] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TR; ++t)
+            if (jp[t] >= 0) {
+                atomicAdd(g_state + ((size_t)c * N + jp[t]) * 6 + q, gp[t]);
+                own -= gp[t];
+            }
+#pragma unroll
+        for (int t = 0; t < TR; ++t)
+            if (jo[t] >= 0) own -= go[t];
     }
     own += __shfl_xor(own, 8, 64);
     own += __shfl_xor(own, 16, 64);
     own += __shfl_xor(own, 32, 64);
-    if (s0 == 0 && q < 6) {
+    if (head) {
         if (q < 2) {
-            const float dq = reinterpret_cast<const float*>(dest)[row * 2 + q] - p[ci * ld + q];
-            const float gd = dq != dq ? 0.f : reinterpret_cast<const float*>(g_destf)[row * gld + q];
+            const float dq = d_q - p_q;
+            const float gd = dq != dq ? 0.f : gdf;
             reinterpret_cast<float*>(g_dest)[row * 2 + q] = gd;
             own -= gd;
         } else if (gld == 7) {
-            own += reinterpret_cast<const float*>(g_destf)[row * 7 + q];
+            own += gdf;
         }
         atomicAdd(g_state + ci * 6 + q, own);
     }
