@@ -321,7 +321,7 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None):
+                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None, messages=False):
         from piml_amd import ops, _lib
         import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
@@ -342,6 +342,7 @@ class Step:
         # with the reference's --dropout 0.5 (src/main.py:45, src/models/simulators.py:311): every step draws fresh
         # keep-masks on the device (ops.dropout_keep_bits inside the captured graph) and the fused kernels apply them
         self.model = getattr(MODEL, model_name)(model_args()).to(dev).train(bool(train_mode))
+        self.model.messages_wanted = bool(messages)
         if train_mode:      # the device-side (seed, call counter) must exist before a capture; the rank is folded into the seed
             getattr(self.ops, 'dropout_seed', lambda s, d: self.ops.dropout_state(d))(666, dev)
         if two_streams:
@@ -683,6 +684,11 @@ def main():
                     help='1: the model of the timed step in train() mode with the reference\'s --dropout 0.5 (fresh keep-masks '
                          'drawn on the device every step); the replayed step is then not compared with an eager one '
                          '(different masks).  Default 0: eval(); the train-mode step is reported under secondary.train_mode_step')
+    ap.add_argument('--messages', type=int, default=0,
+                    help='1: the model also materialises the per-row messages predictions[1:3] (the drop-in default of a bare model call); '
+                         '0 (default): model.messages_wanted = False, what the reference\'s training loops need -- they read predictions[0] '
+                         'only unless reg_weight > 0 (src/models/simulators.py:331-347, :702-737) -- which lets the eval-mode / p = 0 '
+                         'network run on the agents\' sums of h2 (PIML_POOL_TRAIN)')
     ap.add_argument('--mlp', choices=('fused', 'library'), default='fused',
                     help='fused: the PINNSF network on the hand-written matrix-core kernels (encoder_x3.hip / encoder.hip / decoder.hip); '
                          'library: round 1\'s path, rocBLAS / hipBLASLt GEMMs + HIP glue kernels (A/B comparison)')
@@ -775,7 +781,7 @@ def main():
         args.verify = 0
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
               two_streams, bool(args.graph), exchange=args.exchange, overlap=bool(args.overlap),
-              train_mode=bool(args.train_mode))
+              train_mode=bool(args.train_mode), messages=bool(args.messages))
     M_eff = st.M_eff
 
     if autotune:
@@ -961,12 +967,15 @@ def main():
                     'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
     if 'pinnsf_reduce' not in stage_us and stage_us:      # the slot sums rode in the relfeat backward's launch (ops.deferred_slot_sums)
         stage_kernel['relfeat_bwd'] = 'relfeat_bwd_reduce_kernel'
+    sums_path = 'pinnsf_unfold' in stage_us       # PIML_POOL_TRAIN: the network ran on the agents' sums of h2 (--messages 0, eval mode)
+    if sums_path:
+        stage_kernel.update({'enc_fwd': 'enc_fwd_sum_x3_kernel', 'dec_fwd_head': 'dec_fwd_head_sum_kernel', 'pinnsf_unfold': 'pinnsf_unfold_kernel'})
     if one_pass:
         stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
         if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':
             stage_kernel['enc_bwd_dw'] = '(no launch: dW3 is phase 2 of enc_bwd_fused_x3_kernel)'
     # kernels whose f32 products run as six bf16 products (priced against the bf16 matrix pipe AND the HBM ceiling)
-    split_kernels = {'enc_fwd_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw2_x3_kernel', 'enc_bwd_dw_x3w_kernel', 'enc_bwd_fused_x3_kernel'}
+    split_kernels = {'enc_fwd_x3_kernel', 'enc_fwd_sum_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw2_x3_kernel', 'enc_bwd_dw_x3w_kernel', 'enc_bwd_fused_x3_kernel'}
     static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
     if os.environ.get('PIML_DEC_BWD_SPLIT', '1') != '0':       # decoder backward as (tile, branch) workgroups (the default)
         stage_kernel['dec_bwd'] = 'dec_bwd_split_kernel'
@@ -1098,7 +1107,7 @@ def main():
             tag = {'exchange': exch, 'overlap': ovl}
             try:
                 alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
-                           exchange=exch, overlap=ovl)
+                           exchange=exch, overlap=ovl, messages=bool(args.messages))
                 alt.capture()
                 k = max(10, min(args.steps, 50))
                 el = alt.time_steps(k, 5)
@@ -1114,7 +1123,7 @@ def main():
     if world > 1 and scaling == 'strong' and args.strong_baseline:
         if rank == 0:
             try:
-                one = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph))
+                one = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), messages=bool(args.messages))
                 one.capture()
                 k = max(10, min(args.steps, 50))
                 el1 = one.time_steps(k, 5)

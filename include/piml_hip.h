@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PIML_HIP_ABI_VERSION 31
+#define PIML_HIP_ABI_VERSION 32
 #define PIML_MAX_TOPK 32 /* topk_ped / topk_obs upper bound (reference defaults 6 / 10) */
 
 /* ABI version of the loaded library (== PIML_HIP_ABI_VERSION). */
@@ -628,6 +628,15 @@ typedef struct piml_encoder_branch {
                       Philox call per row, no extra launch), otherwise by one generator launch for all branches in front of it.
                       The draw counter advances once per launch.  Same state for every branch.  NULL: keep_bits is given */
     float drop_p;
+    /* PIML_POOL_TRAIN (piml_pinnsf_fwd / bwd): the branch on the agents' SUMS of h2 instead of on message rows.
+     * fwd out: sum_a / sum_b (agents, 128) = the agents' sums of h2 over their k rows, in two parts: sum_a from the 32-row tile
+     * the agent's first row lies in, sum_b from the next tile (only for agents whose rows straddle two tiles:
+     * (a k) >> 5 != (a k + k - 1) >> 5; undefined for the others).  `relu_mask` is required and holds the signs of h2 in the
+     * layout of the exchanged layer (dwords 128 .. 255 of a tile: lane l = (feature j, half h) owns dwords 128 + 2 l, + 1;
+     * bit 16 (blk & 1) + r of dword blk >> 1 = h2[row rho(r) + 4 h][32 blk + j] > 0).  `h2` (rows, 128) is written when
+     * non-NULL (the collision head reads the rows), `msgs` is not written.  bwd in: g_pooled = d/d(sums) (agents, 128);
+     * dW3 / db3 are not produced here (they follow from the decoder's folded first layer: piml_pinnsf_bwd). */
+    float *sum_a, *sum_b;
 } piml_encoder_branch;
 
 /* floats of one partial slot / of one `packed` buffer */
@@ -700,6 +709,16 @@ typedef struct piml_decoder_branch {
     float* pred;              /* fwd out (rows, 2): predictor output of every row */
     const float* g_pred_rows; /* bwd in (rows, 2) */
     const float* g_d2;        /* bwd in (rows, 64) or NULL: extra gradient on the decoder output (the `decoded` collision head) */
+    /* PIML_POOL_TRAIN: the encoder's last layer folded into this decoder's first (msgs = scale (W3 h2 + b3) is linear in h2, so
+     * W_d1 sum_r msgs_r + b_d1 = (scale W_d1 W3) sum_r h2_r + (b_d1 + k scale W_d1 b3)).  Non-NULL fold_w3 (128, 128) / fold_b3
+     * (128) = that encoder's w3 / b3, fold_scale = its processor scale: the pack ALSO writes the folded images (float64
+     * products, rounded once) behind the plain ones in `packed`; forward and backward use them under PIML_POOL_TRAIN.
+     * `w1` / `b1` stay the raw decoder weights.  Then pooled = the agents' sums of h2 (first parts in, completed sums out),
+     * msgs = their second parts (agents, 128), g_pooled = d/d(sums); in `grads` the dW1 / db1 fields hold the gradient of the
+     * FOLDED layer until the slot sums' epilogue has unfolded them (dw1_out below). */
+    const float *fold_w3, *fold_b3;
+    float fold_scale;
+    float* dw1_out; /* PIML_POOL_TRAIN bwd out (64, 128): d/d(w1) of the raw first layer (`grads`' dW1 field keeps d/d(W1')) */
 } piml_decoder_branch;
 
 int piml_decoder_pack_floats(void);
@@ -737,6 +756,10 @@ typedef struct piml_collision_head {
     const float *w1, *b1, *w2, *b2;
     float* packed; /* piml_collision_head_pack_floats() floats */
     float* out;    /* (rows) */
+    /* PIML_POOL_TRAIN: the head on h2 rows (msgs = that array) with the encoder's last layer folded into W1:
+     * W1' = fold_scale W1 fold_w3, b1' = b1 + fold_scale W1 fold_b3 (packed behind the plain images when fold_w3 is given) */
+    const float *fold_w3, *fold_b3;
+    float fold_scale;
 } piml_collision_head;
 
 int piml_collision_head_pack_floats(void);
@@ -846,6 +869,22 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
                            dec[i].b1 = b_d1 + scale * k * W_d1 * b3 -- when it packs; enc[i].w3 / b3 / scale are not read.
                            Served when piml_pinnsf_pool_h2_ok(enc, nbranches): k = 6 or 10, split products, more than 32 tiles of
                            32 rows (environment PIML_POOL_H2_MIN_TILES); hipErrorInvalidValue otherwise */
+#define PIML_POOL_TRAIN 64 /* piml_pinnsf_fwd AND piml_pinnsf_bwd (the same call pair): TRAINING on the agents' sums of h2 -- for
+                           processors without an active dropout mask (eval mode, or p = 0) and callers that read neither branch's
+                           per-row messages (the reference's training loops read predictions[0] only unless reg_weight > 0:
+                           src/models/simulators.py:331-347, :702-737).  The messages are linear in h2, so the neighbour-axis sum moves
+                           in front of the encoders' last layer (layer 2 runs with exchanged operands: a tile's rows sit on registers
+                           and an agent's sum is register additions), that layer is folded into the decoders' first layer and into
+                           the collision head's (fold_w3 / fold_b3 / fold_scale of piml_decoder_branch / piml_collision_head, packed
+                           by piml_pinnsf_pack), and its gradient is recovered from the folded layers' gradients after the slot sums:
+                               dW_d1 = s (G W3^T + k g_b b3^T),  dW3 = s W_d1^T G,  db3 = s k W_d1^T g_b     (G = d/d(W_d1'), g_b = d/d(b_d1')).
+                           Backward: every row of an agent sees the same upstream gradient g = d/d(sum), so G2 = g[agent] * [h2 > 0]
+                           directly -- the W3^T chain layer and the dW3 = G3^T H2 product over all rows (half of the backward's
+                           matrix work, and the 33 MB of saved h2) are gone.  enc[i].sum_a / sum_b / relu_mask, dec[i].pooled =
+                           enc[i].sum_a, dec[i].msgs = enc[i].sum_b, dec[i].fold_*, head->msgs = enc[0].h2, head->fold_*.
+                           Served when piml_pinnsf_pool_train_ok(enc, nbranches): k in {2, 6, 10}, whole agents, split products,
+                           more than piml_encoder_split_tiles() tiles, no keep_bits / drop_state; hipErrorInvalidValue otherwise */
+int piml_pinnsf_pool_train_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */

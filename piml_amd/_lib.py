@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PIML_LIB=<path>: an experimental build of the same ABI beside the shipped library (piml_amd.build.variant; tools/ A/B timings)
 LIB_PATH = os.environ.get('PIML_LIB') or os.path.join(_HERE, 'libpiml_hip.so')
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _lib = None
 
@@ -25,7 +25,7 @@ class EncoderBranch(ctypes.Structure):
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('scale', _f), ('h1', _p), ('h2', _p), ('msgs', _p), ('g_pooled', _p), ('g_msgs', _p),
                 ('g2', _p), ('g1', _p), ('g_x', _p), ('partials', _p), ('grads', _p), ('packed', _p), ('relu_mask', _p),
-                ('keep_bits', _p), ('drop_state', _p), ('drop_p', _f)]
+                ('keep_bits', _p), ('drop_state', _p), ('drop_p', _f), ('sum_a', _p), ('sum_b', _p)]
 
 
 class DecoderBranch(ctypes.Structure):
@@ -33,12 +33,14 @@ class DecoderBranch(ctypes.Structure):
     _fields_ = [('msgs', _p), ('agents', _ll), ('k', _i),
                 ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('w3', _p), ('b3', _p),
                 ('pooled', _p), ('h1', _p), ('d2', _p), ('g_pre2', _p), ('g_pre1', _p), ('g_pooled', _p),
-                ('partials', _p), ('grads', _p), ('packed', _p), ('pred', _p), ('g_pred_rows', _p), ('g_d2', _p)]
+                ('partials', _p), ('grads', _p), ('packed', _p), ('pred', _p), ('g_pred_rows', _p), ('g_d2', _p),
+                ('fold_w3', _p), ('fold_b3', _p), ('fold_scale', _f), ('dw1_out', _p)]
 
 
 class CollisionHead(ctypes.Structure):
     """piml_collision_head (include/piml_hip.h)."""
-    _fields_ = [('msgs', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('packed', _p), ('out', _p)]
+    _fields_ = [('msgs', _p), ('rows', _ll), ('w1', _p), ('b1', _p), ('w2', _p), ('b2', _p), ('packed', _p), ('out', _p),
+                ('fold_w3', _p), ('fold_b3', _p), ('fold_scale', _f)]
 
 
 class Head64(ctypes.Structure):
@@ -56,7 +58,7 @@ class Corrector(ctypes.Structure):
                 ('partials_a', _p), ('partials_b', _p), ('grads', _p)]
 
 
-PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK, POOL_H2 = 1, 2, 4, 8, 16, 32          # piml_pinnsf_* flags
+PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK, POOL_H2, POOL_TRAIN = 1, 2, 4, 8, 16, 32, 64          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -161,6 +163,7 @@ SIGNATURES = {
     'piml_corrector_fwd': [ctypes.POINTER(Corrector), _p],
     'piml_corrector_bwd': [ctypes.POINTER(Corrector), _i, _p],
     'piml_pinnsf_pool_h2_ok': [ctypes.POINTER(EncoderBranch), _i],
+    'piml_pinnsf_pool_train_ok': [ctypes.POINTER(EncoderBranch), _i],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_pack_flush': [],
     'piml_pinnsf_slot_sums_flush': [],

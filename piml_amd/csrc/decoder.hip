@@ -36,6 +36,9 @@ struct DecArgs {
     int wg_split;                 // dW kernel: workgroups [0, wg_split) serve branch 0
     int pool_h2;                  // forward, PIML_POOL_H2: `pooled` holds the agents' first parts, `msgs` (agents, 128) the second
                                   // parts of the agents whose k rows straddle two 32-row tiles (enc_fwd_pool_x3_kernel)
+                                  // 2 = PIML_POOL_TRAIN (forward and backward): the same, with the FOLDED first-layer images of
+                                  // `packed` (DP_A1F / DP_T1F / DP_CF, pack.hpp), bias b1 + k c, and the completed sums written
+                                  // back to `pooled` for the backward's dW1
 };
 
 __device__ __forceinline__ f32x16 dmfma(float a, float b, f32x16 c) {
@@ -113,7 +116,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
 #pragma unroll
         for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w1f[bl][q] = PK[DP_A1 / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
+            for (int q = 0; q < 4; ++q) w1f[bl][q] = PK[(A.pool_h2 == 2 ? DP_A1F : DP_A1) / 4 + ((ob * 4 + 2 * kh + bl) * 4 + q) * 64 + lane];
     }
     float4 b1v[4];
     float sfv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -123,6 +126,11 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             b1v[q] = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            if (!POOL && !ROWS && A.pool_h2 == 2) {          // folded first layer: b1 + k c (pack.hpp: DP_CF)
+                const float4 cv = *reinterpret_cast<const float4*>(J.packed + DP_CF + dfeat0(ob, q, h));
+                const float kf = (float)J.k;
+                b1v[q].x += kf * cv.x; b1v[q].y += kf * cv.y; b1v[q].z += kf * cv.z; b1v[q].w += kf * cv.w;
+            }
             w2f[q] = PK[DP_A2 / 4 + ((ob * 2 + kh) * 4 + q) * 64 + lane];
             w3f[q] = PK[DP_A3 / 4 + (kh * 4 + q) * 64 + lane];
             b2v[q] = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
@@ -170,9 +178,9 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
         }
         __syncthreads();
     }
+    float4 pv[2][4];
     if (active) {
         // ---- layer 1 partial: features of block ob, contraction over input blocks 2 kh, 2 kh + 1 ----
-        float4 pv[2][4];
         if (POOL) {
 #pragma unroll
             for (int bl = 0; bl < 2; ++bl)
@@ -224,6 +232,17 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
     }
     __syncthreads();
     if (active) {
+        // training on the sums (pool_h2 == 2): the completed sum is the backward's layer-1 input (dW1 = g_pre1^T pooled); written
+        // behind the barrier, when every wave of the workgroup has finished reading the first parts
+        if (!POOL && !ROWS && A.pool_h2 == 2 && ob == 0) {
+            const long long g0 = (valid ? agent : 0) * J.k;
+            if (valid && (g0 >> 5) != ((g0 + J.k - 1) >> 5)) {
+#pragma unroll
+                for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(J.pooled + agent * DH + dfeat0(2 * kh + bl, q, h)) = pv[bl][q];
+            }
+        }
         // ---- layer 2 partial: output block ob, contraction over hidden block kh (= relu of the summed layer-1 block kh) ----
         float x[16];
 #pragma unroll
@@ -364,7 +383,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
 #pragma unroll
         for (int q = 0; q < 4; ++q) t2f[q] = PK[DP_T2 / 4 + (ob * 8 + kh * 4 + q) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) t1f[t] = PK[DP_T1 / 4 + (blk * 8 + t) * 64 + lane];
+        for (int t = 0; t < 8; ++t) t1f[t] = PK[((!ROWS && A.pool_h2 == 2) ? DP_T1F : DP_T1) / 4 + (blk * 8 + t) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
         f32x16 g2, g1;
 #pragma unroll
@@ -1037,11 +1056,9 @@ __global__ __launch_bounds__(256) void dec_reduce_kernel(DecArgs A, int B, int l
 // head for `pinnsf_bm` only; a backward through it falls back to torch ops, ops.collision_head).
 // packed: pack.hpp (W1 fragments | b1 | b2 | raw w2 row)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        float* __restrict__ packed) {
+__global__ __launch_bounds__(256) void head_pack_kernel(piml_collision_head H) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < HEAD_PACK) packed[e] = head_pack_value(w1, b1, w2, b2, e);
+    if (e < HEAD_PACK) H.packed[e] = head_pack_value(H, e);
 }
 
 // One wave per 32-row tile.  Layer 1 (128 -> 64) on the matrix pipe; its fragments stream from the packed image (L2)
@@ -1115,7 +1132,8 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, lo
 // wait for the matrix pipe: the launch took 3.1 us less without the head's matrix instructions (variant build).  The row's
 // 128 values are split once (lane (row, g): features 16 kb + 8 g + t of k-block kb, the order of the packed W1 pieces);
 // W1's pieces stream from the packed image (L2), one k-block ahead.  PIML_HEAD_PRODUCTS=f32 keeps the f32 instruction.
-template <int WAVES = 4>
+// FOLD (PIML_POOL_TRAIN): the rows are h2 rows and W1 / b1 the images with the encoder's last layer folded in (pack.hpp: HP_X3F / HP_BF)
+template <int WAVES = 4, bool FOLD = false>
 __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs, long long rows,
                                                  const float* __restrict__ packed, float* __restrict__ out, long long bx) {
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
@@ -1123,8 +1141,8 @@ __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs,
     const long long row = (bx * WAVES + wave) * 32 + j;
     if ((bx * WAVES + wave) * 32 >= rows) return;
     const bool valid = row < rows;
-    const float* bias = packed + HP_B;
-    const u32x4* W = reinterpret_cast<const u32x4*>(packed + HP_X3) + lane;      // [ob][kb][piece] 64 apart
+    const float* bias = packed + (FOLD ? HP_BF : HP_B);
+    const u32x4* W = reinterpret_cast<const u32x4*>(packed + (FOLD ? HP_X3F : HP_X3)) + lane;      // [ob][kb][piece] 64 apart
     u32x4 wf[2][3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) wf[0][p] = W[p * 64];
@@ -1177,7 +1195,7 @@ __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs,
         }
     }
     dot += __shfl_xor(dot, 32, 64);
-    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + bias[64])));
+    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + packed[HP_B + 64])));
 }
 
 // PIML_HEAD_PRODUCTS=f32: the collision head's 128 -> 64 layer on the f32 matrix instruction (A/B); default: split bf16 products
@@ -1268,6 +1286,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     }
 }
 
+// PIML_POOL_TRAIN: the decoder tails on the agents' sums of h2 (no neighbour-axis sum here: dec_fwd_ph2_kernel's body with the
+// folded first layer, A.pool_h2 = 2) and the collision head on the h2 rows with the folded W1, in one launch as above
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_fwd_head_sum_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
+    const int bx = blockIdx.x;
+    if (bx < dec_blocks) {
+        if (A.nbr > 1) dec_fwd_body<false, true>(A, bx >> 1, bx & 1);
+        else dec_fwd_body<false, true>(A, bx, 0);
+    } else {
+        head_fwd_body_x3<4, true>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+    }
+}
+
+int piml::dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
+                            float tau, float* acc, hipStream_t s) {
+    DecArgs A;
+    if (!acc) return hipErrorInvalidValue;
+    if (int e = dec_fill(A, br, nbr)) return e;
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].msgs || !br[i].fold_w3 || !br[i].fold_b3) return hipErrorInvalidValue;
+    piml_collision_head Hd = {};
+    int head_blocks = 0;
+    if (h && h->rows > 0) {
+        if (int e = head_check(h)) return e;
+        if (!h->fold_w3 || !h->fold_b3) return hipErrorInvalidValue;
+        Hd = *h;
+        head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
+    }
+    A.self_features = self_features;
+    A.tau = tau;
+    A.acc = acc;
+    A.pool_h2 = 2;
+    const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
+    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    return hipGetLastError();
+}
+
 int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
                               float tau, float* acc, hipStream_t s) {
     DecArgs A;
@@ -1339,16 +1393,21 @@ int piml::dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* 
 }
 
 int piml::dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features,
-                              float tau, float* g_self, hipStream_t s) {
+                              float tau, float* g_self, hipStream_t s, bool sums) {
     DecArgs A;
     if (int e = dec_fill_bwd(A, br, nbr, g_pred)) return e;
     A.self_features = self_features;
     A.tau = tau;
     A.g_self = g_self;
+    if (sums) {          // PIML_POOL_TRAIN: W1'^T fragments (DP_T1F) in the dX chain; `pooled` = the completed sums of h2
+        for (int i = 0; i < nbr; ++i)
+            if (!br[i].fold_w3) return hipErrorInvalidValue;
+        A.pool_h2 = 2;
+    }
     static_assert(DEC_SLAB == 32, "the dW slab of a workgroup is its dX tile");
     const unsigned tiles = (unsigned)((br[0].agents + 31) / 32);
     static const bool whole = getenv("PIML_DEC_BWD_SPLIT") && atoi(getenv("PIML_DEC_BWD_SPLIT")) == 0;     // A/B: the 8-wave form
-    if (whole) hipLaunchKernelGGL(dec_bwd_kernel, dim3(tiles), dim3(512), 0, s, A);
+    if (whole && !sums) hipLaunchKernelGGL(dec_bwd_kernel, dim3(tiles), dim3(512), 0, s, A);
     else hipLaunchKernelGGL(dec_bwd_split_kernel, dim3(tiles * (unsigned)nbr), dim3(256), 0, s, A);
     return hipGetLastError();
 }
@@ -1372,7 +1431,7 @@ static int head_check(const piml_collision_head* h) {
 
 int piml::head_stage_pack(const piml_collision_head* h, hipStream_t s) {
     if (!h || !h->w1 || !h->b1 || !h->w2 || !h->b2 || !h->packed) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_pack_kernel, dim3((HEAD_PACK + 255) / 256), dim3(256), 0, s, h->w1, h->b1, h->w2, h->b2, h->packed);
+    hipLaunchKernelGGL(head_pack_kernel, dim3((HEAD_PACK + 255) / 256), dim3(256), 0, s, *h);
     return hipGetLastError();
 }
 
@@ -1497,7 +1556,7 @@ PIML_API int piml_collision_head_pack_floats(void) { return HEAD_PACK; }
 
 PIML_API int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, const float* b1, const float* w2,
                                      const float* b2, float* packed, float* out, void* stream) {
-    const piml_collision_head h = {msgs, rows, w1, b1, w2, b2, packed, out};
+    const piml_collision_head h = {msgs, rows, w1, b1, w2, b2, packed, out, nullptr, nullptr, 0.f};
     if (int e = head_stage_pack(&h, as_stream(stream))) return e;
     return head_stage_fwd(&h, as_stream(stream));
 }

@@ -1181,6 +1181,62 @@ int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s
     return hipGetLastError();
 }
 
+// Training on the agents' sums of h2 (PIML_POOL_TRAIN) serves: split products, the one-wave forward and the four-wave one-pass
+// backward (more than piml_encoder_split_tiles() tiles, layer-split slots, at least two workgroups per branch), k = 2, 6 or 10
+// neighbours per agent, whole agents, no dropout mask.  PIML_POOL_TRAIN=0 in the environment turns it off (A/B).
+bool piml::enc_pool_train_ok(const piml_encoder_branch* br, int nbr) {
+    static const bool off = getenv("PIML_POOL_TRAIN") && atoi(getenv("PIML_POOL_TRAIN")) == 0;
+    if (off || !g_x3 || !g_dw2 || g_f3 != 1 || !br || nbr < 1 || nbr > 2) return false;
+    long long tiles = 0;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if ((b.k != 2 && b.k != 6 && b.k != 10) || b.rows <= 0 || b.rows % b.k || b.keep_bits || b.drop_state || b.in_dim < 1 || b.in_dim > 8 ||
+            b.rows >= (1ll << 22))
+            return false;
+        tiles += (b.rows + 31) / 32;
+    }
+    if (tiles <= g_split_tiles) return false;
+    const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
+    return nbr == 1 || (w0 >= 2 && total - w0 >= 2);
+}
+
+int piml::enc_stage_fwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
+    if (int e = enc_check(br, nbr)) return e;
+    if (!enc_pool_train_ok(br, nbr)) return hipErrorInvalidValue;
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].sum_a || !br[i].sum_b || !br[i].relu_mask) return hipErrorInvalidValue;
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    if (zero && zero_n > 0) {
+        if (zero_n >= (1ll << 31)) return hipErrorInvalidValue;
+        A.zero = zero;
+        A.zero_n = (int)zero_n;
+    }
+    if (int e = x3_ready()) return e;
+    enc_x3_launch_fwd_sum(A, total, s);
+    return hipGetLastError();
+}
+
+// backward of enc_stage_fwd_sum: the one-pass kernel without its W3^T layer and without dW3 (encoder_bwd3.hip, SUMS = true)
+int piml::enc_stage_bwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s) {
+    if (int e = enc_check(br, nbr)) return e;
+    if (!enc_pool_train_ok(br, nbr)) return hipErrorInvalidValue;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if (!b.g_pooled || b.g_msgs || !b.relu_mask || !b.partials || !b.grads || (b.g_x != nullptr) != (br[0].g_x != nullptr)) return hipErrorInvalidValue;
+    }
+    EncArgs A;
+    const int total = fill_args(A, br, nbr);
+    if (int e = x3_ready()) return e;
+    static int ready = -1;
+    if (ready < 0) ready = enc_f3_set_attributes();
+    if (ready) return ready;
+    const int nA[2] = {nbr > 1 ? A.wg_split : total, nbr > 1 ? total - A.wg_split : 0};
+    const int zero[2] = {0, 0};
+    enc_f3_launch(A, nA, zero, false, s, true);
+    return hipGetLastError();
+}
+
 PIML_API int piml_encoder_pack(const piml_encoder_branch* br, int nbr, void* stream) {
     return enc_stage_pack(br, nbr, as_stream(stream));
 }

@@ -60,6 +60,7 @@ __device__ __forceinline__ int feat0(int blk, int q, int h) { return 32 * blk + 
 int enc_x3_set_attributes();
 // drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
 void enc_x3_launch_fwd_pool(const EncArgs& A, int total, hipStream_t s);      // inference: layers 1-2 + the agents' sums of h2
+void enc_x3_launch_fwd_sum(const EncArgs& A, int total, hipStream_t s);       // training on the agents' sums of h2 (PIML_POOL_TRAIN)
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);   // A.gen_state: draw the masks in the kernel
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
@@ -80,6 +81,7 @@ int enc_f4_set_attributes();
 void enc_f4_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s);
 int enc_f3_set_attributes();
 // with_dw3: the launch also does dW3 / db3 (layer-0 slots, slot = workgroup index within the branch; needs slot0[b] == nA[b])
-void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s);
+// sums: the PIML_POOL_TRAIN form (G2 = g_pooled[agent] * [h2 > 0]: no W3^T layer, no dW3; sign words of h2 in the exchanged layout)
+void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s, bool sums = false);
 
 }  // namespace piml

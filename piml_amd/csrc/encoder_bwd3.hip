@@ -145,9 +145,16 @@ struct F3Pre {
     float xa[4];                   // x[row][2 s + h]: A operand of the H1 recomputation
     float xs;                      // staging: x[tile row tid >> 3][tid & 7]
     unsigned mk;                   // staging: dword tid of the tile's 256 sign dwords
+    float g2[16];                  // SUMS: d/d(sum)[agent of row rho(r) + 4 h][feature 32 w + n] -- G2 before its mask
+    unsigned m2;                   // SUMS: the lane's sign word of h2 (blocks 2 (w >> 1), + 1: 16 rows each)
 };
 
-template <bool POOL, bool MSGS, bool DROP, bool GX>
+// SUMS (PIML_POOL_TRAIN, include/piml_hip.h): the branch was trained on the agents' sums of h2 -- every row of an agent sees the
+// same upstream gradient g = d/d(sum), so G2 = g[agent] * [h2 > 0] is loaded (one dword per row and lane: the lane's feature of
+// the row's agent, 128 contiguous bytes per lane half) instead of computed: no W3^T fragments, no G3 staging, no layer A, and no
+// phase 2 (dW3 / db3 follow from the decoder's folded first layer, network.hip: unfold).  The signs of h2 come in the layout of
+// the exchanged forward layer (enc_fwd_sum_x3_kernel), which is this kernel's accumulator layout: one dword per lane and tile.
+template <bool POOL, bool MSGS, bool DROP, bool GX, bool SUMS = false>
 __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -191,13 +198,13 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
             const int fb = w * 8 + kb;
-            wfA[kb][0] = imgA[(fb * 2) * 64]; wfA[kb][1] = imgA[(fb * 2 + 1) * 64];
+            if (!SUMS) { wfA[kb][0] = imgA[(fb * 2) * 64]; wfA[kb][1] = imgA[(fb * 2 + 1) * 64]; }
             wfB[kb][0] = imgB[(fb * 2) * 64]; wfB[kb][1] = imgB[(fb * 2 + 1) * 64];
         }
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
             const int fb = w * 8 + kb;
-            wlo[kb * 64] = imgA[X3_HM / 4 + fb * 64];
+            if (!SUMS) wlo[kb * 64] = imgA[X3_HM / 4 + fb * 64];
             wlo[(8 + kb) * 64] = imgB[X3_HM / 4 + fb * 64];
         }
     }
@@ -259,7 +266,15 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         const unsigned row = (unsigned)tile * 32 + n;
         const bool live = tile < ntiles;                     // (bitwise combinations: a short-circuit would branch)
         const bool valid = live & (row < R);
-        if (i < 4) {
+        if (SUMS && i < 4) {                               // registers 4 i .. 4 i + 3: rows rho(r) + 4 h of the tile, this lane's feature
+#pragma unroll
+            for (int r = 4 * i; r < 4 * i + 4; ++r) {
+                const unsigned rr = (unsigned)tile * 32 + rho(r) + 4 * h;
+                S.g2[r] = __uint_as_float(ld1(rs_gp, (live & (rr < R)) ? (__umulhi(rr, kmagic) * EH + 32 * w + n) * 4 : kOut));
+            }
+        } else if (SUMS && i == 4) {
+            S.m2 = ld1(rs_mk, live ? ((unsigned)tile * 256 + 128 + 2 * lane + (w >> 1)) * 4 : kOut);
+        } else if (i < 4) {
             const int s = i >> 1, half2 = i & 1;
             const unsigned f = 32 * w + 16 * s + 8 * half2 + 4 * h;
             S.gp[s][half2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -395,8 +410,10 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
 #pragma unroll
         for (int i = 0; i < 7; ++i) pf_step(i, tile);
         stage(0);
+        if (!SUMS) {
 #pragma unroll
-        for (int i = 0; i < 22; ++i) g3_step(i);
+            for (int i = 0; i < 22; ++i) g3_step(i);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) xa[s] = S.xa[s];
     }
@@ -413,9 +430,16 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         for (int s = 0; s < 4; ++s) f3_mfma32(hacc, xa[s], w1v[s]);
         f32x16 acc;
         u32x4 opa[2][4], ahi[8];                               // operands of a k-block: pieces hi, mid, lo of the activations + LO of the weights
+        unsigned m2w = 0;
+        if (SUMS) {                                            // G2 before its mask: loaded a tile ahead; then the next tile's requests
 #pragma unroll
-        for (int p = 0; p < 3; ++p) opa[0][p] = bufA[p * 64];
-        opa[0][3] = wlo[0];
+            for (int r = 0; r < 16; ++r) acc[r] = S.g2[r];
+            m2w = S.m2 >> (16 * (w & 1));
+        } else {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) opa[0][p] = bufA[p * 64];
+            opa[0][3] = wlo[0];
+        }
         const unsigned* mk2 = reinterpret_cast<const unsigned*>(smem + mk_off + par * 1024 + 512);       // layer 1 of the pair: h2
         auto fill_x = [&](int sl) {
             if (sl < 40 && sl % 5 == 0) {                      // the next k-block's operands
@@ -435,20 +459,29 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             else if (f >= 10 && f < 28) h1_step(f - 10);
             else if (f >= 30 && f < 38) mk_step(f - 30, mk2);
         };
+        if (SUMS) {                                            // no layer A: the steps that rode between its products, in order
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            ahi[kb] = opa[kb & 1][0];
-            if (kb == 0) F3_KSMALL(true, acc, opa[0], wfA[0][0], wfA[0][1], fill_x, 0);
-            else F3_KSMALL(false, acc, opa[kb & 1], wfA[kb][0], wfA[kb][1], fill_x, kb * 5);
+            for (int f = 0; f < 7; ++f) pf_step(f, ntile);
+            if (GX) gx_store(prev_tile);
+            f3_settle(hacc);
+#pragma unroll
+            for (int st_ = 0; st_ < 18; ++st_) h1_step(st_);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                ahi[kb] = opa[kb & 1][0];
+                if (kb == 0) F3_KSMALL(true, acc, opa[0], wfA[0][0], wfA[0][1], fill_x, 0);
+                else F3_KSMALL(false, acc, opa[kb & 1], wfA[kb][0], wfA[kb][1], fill_x, kb * 5);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) F3_SLOT(f3_mfma(acc, ahi[kb], wfA[kb][0]), fill_x(40 + kb));
         }
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) F3_SLOT(f3_mfma(acc, ahi[kb], wfA[kb][0]), fill_x(40 + kb));
         F3_STAMP(1);
-        f3_settle(acc);
+        if (!SUMS) f3_settle(acc);
         if (!(PIML_F3_SKIP & 8)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int t = __builtin_amdgcn_sbfe(mkw[r], bp, 1);
+                const int t = SUMS ? __builtin_amdgcn_sbfe(m2w, r, 1) : __builtin_amdgcn_sbfe(mkw[r], bp, 1);
                 acc[r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)t);
                 db2 += acc[r];
             }
@@ -492,7 +525,7 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             const int f = sl < 40 ? sl - sl / 5 - 1 : sl - 8;
             if ((PIML_F3_SKIP & 2) && f >= 1) return;
             if (f == 0) stage(par ^ 1);
-            else if (f >= 1 && f < 23) g3_step(f - 1);
+            else if (f >= 1 && f < 23) { if (!SUMS) g3_step(f - 1); }
             else if (f >= 30 && f < 38) mk_step(f - 30, mk1);
         };
 #pragma unroll
@@ -645,7 +678,7 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
     // the tile; rows past the end are agents past the end and read as zeros by the buffer range check.  Two image pairs: one
     // barrier per tile.  scale is applied once, to the sums.
     // =====================================================================================================================
-    if (F.with_dw3) {
+    if (!SUMS && F.with_dw3) {
         float* P0 = J.partials + (size_t)bx * F3_PART0;
         // accumulators pinned to AGPRs through asm operands (left to itself hipcc moves all 128 registers to VGPRs and back in
         // every iteration of this loop)
@@ -828,6 +861,10 @@ static int f3_set(int bytes) {
 int enc_f3_set_attributes() {
     if (int e = f3_set<true, true>(F3_LDS_BYTES)) return e;
     if (int e = f3_set<true, false>(F3_LDS_BYTES)) return e;
+    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_fused_x3_kernel<true, false, false, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES)) return e;
+    if (int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_bwd_fused_x3_kernel<true, false, false, true, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS_BYTES)) return e;
     return f3_set<false, true>(F3_LDS_BYTES);
 }
 
@@ -842,7 +879,7 @@ static void f3_go(const F3Args& F, dim3 g, bool drop, bool gx, hipStream_t s) {
 
 // A: the launch's branches (both with the same kinds of upstream gradients, keep bits and g_x: checked by the caller);
 // nA[b] workgroups and slot0[b] layer-0 slots in front for branch b
-void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s) {
+void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s, bool sums) {
     F3Args F;
     F.A = A;
     F.with_dw3 = with_dw3 ? 1 : 0;
@@ -851,6 +888,11 @@ void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_
     const bool pool = A.br[0].g_pooled != nullptr, msgs = A.br[0].g_msgs != nullptr, drop = A.br[0].keep_bits != nullptr;
     const bool gx = A.br[0].g_x != nullptr;
     const dim3 g((unsigned)(F.nA[0] + F.nA[1]));
+    if (sums) {          // (checked by the caller: g_pooled only, no keep bits)
+        if (gx) hipLaunchKernelGGL((enc_bwd_fused_x3_kernel<true, false, false, true, true>), g, dim3(F3_THREADS), F3_LDS_BYTES, s, F);
+        else hipLaunchKernelGGL((enc_bwd_fused_x3_kernel<true, false, false, false, true>), g, dim3(F3_THREADS), F3_LDS_BYTES, s, F);
+        return;
+    }
     if (pool && msgs) f3_go<true, true>(F, g, drop, gx, s);
     else if (pool) f3_go<true, false>(F, g, drop, gx, s);
     else f3_go<false, true>(F, g, drop, gx, s);

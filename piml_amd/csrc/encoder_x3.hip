@@ -387,6 +387,114 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward for TRAINING on the agents' sums of h2 (PIML_POOL_TRAIN, include/piml_hip.h): enc_fwd_pool_x3_kernel's two layers and
+// register sums, plus what a backward pass needs -- the signs of h1 (the row-per-lane words of enc_fwd_x3_kernel) and of h2 in
+// the layout of the exchanged layer, which is the layout the one-pass backward masks in (lane = feature, registers = the tile's
+// rows: no transposition on either side) -- and, where the branch carries `h2`, the h2 rows themselves for the collision head
+// (from the exchanged layout a (row, block) segment is 32 lanes x 4 B = 128 contiguous bytes).
+// Reference arithmetic: src/models/model.py:40-65 (layers 1 - 2), :1279-1283 (the sum; layer 3 and the processor scale are folded
+// into the decoder's first layer, pack.hpp: fold_w).
+// ---------------------------------------------------------------------------------------------------------
+template <bool ROWS>
+__device__ __forceinline__ void store_h2_rows(const f32x16 (&a)[4], float* __restrict__ h2, long long tile, long long R, int lane) {
+    if (!ROWS) return;
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < R) h2[row * EH + 32 * blk + j] = a[blk][r];
+        }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
+    const piml_encoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? A.wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - A.wg_split : (A.nbr > 1 ? A.wg_split : (int)gridDim.x);
+    const long long R = J.rows;
+    const int IN = J.in_dim;
+    const long long ntiles = (R + 31) >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    const long long stride = (long long)nwg * ENC_WAVES;
+    if (A.zero)
+        for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
+    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+    const float* x3 = J.packed + PACK_F32;
+    float xb[4];
+    load_x(xb, J.x, first, ntiles, R, IN, lane);
+    stage_linear<X3_IMG>(lds, x3, tid);                                         // W2's image; W3 is not needed
+    stage_linear<1024 + 384>(lds + X3_FWD_F32, J.packed + 32768, tid);
+    __syncthreads();
+    const int k = J.k;
+    const long long agents = R / k;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const u32x4* W2hm = reinterpret_cast<const u32x4*>(lds) + lane_t;
+        const u32x4* W2lo = W2hm + X3_HM / 4;
+        const float* W1f = lds + X3_FWD_F32;
+        const float* bias = W1f + 1024;
+        const int h = lane_t >> 5;
+        f32x16 a[4];
+        Pieces P;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + feat0(blk, q, h));
+                a[blk][4 * q + 0] = bq.x; a[blk][4 * q + 1] = bq.y; a[blk][4 * q + 2] = bq.z; a[blk][4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[blk] = mfma32(W1f[(blk * 4 + s) * 64 + lane_t], xb[s], a[blk]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[blk][r] = relu1(a[blk][r]);
+        }
+        uint2* mrow = reinterpret_cast<uint2*>(J.relu_mask) + (tile * 2) * 64 + lane_t;
+        mrow[0] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));       // h1: lane = row, bits = features (enc_fwd_x3_kernel's)
+        split_tile(a, P);
+        load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
+        // ---- layer 2, exchanged operands: a[blk] = relu(h2)[row rho(r) + 4 h][feature 32 blk + (lane & 31)] ----
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x16 acc, sm;
+            const float bv = bias[128 + 32 * blk + (lane_t & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; acc[r] = bv; }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = blk * 8 + kb;
+                kblock_x3_t(acc, sm, W2hm[(fb * 2) * 64], W2hm[(fb * 2 + 1) * 64], W2lo[fb * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[blk][r] = relu1(acc[r] + sm[r]);
+        }
+        mrow[64] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));      // h2: lane = feature, bits = the tile's rows
+        if (J.h2) store_h2_rows<true>(a, J.h2, tile, R, lane_t);
+        if (k == 6) {
+            switch ((int)(tile % 3)) {
+                case 0: pool_rows<6, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                case 1: pool_rows<6, 1>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                default: pool_rows<6, 2>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+            }
+        } else if (k == 10) {
+            switch ((int)(tile % 5)) {
+                case 0: pool_rows<10, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                case 1: pool_rows<10, 1>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                case 2: pool_rows<10, 2>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                case 3: pool_rows<10, 3>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+                default: pool_rows<10, 4>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
+            }
+        } else {
+            pool_rows<2, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // forward for FEW rows (rollouts of real clips: 100 .. 1000 agents): four waves per tile like enc_fwd_split_kernel
 // (encoder.hip; a lone wave per SIMD is bound by the latency of its chain of dependent matrix instructions, here
 // 16 + 48 + 48 of them instead of 400).  Wave (t, blk) computes output block blk of every layer of tile t, two tiles per
@@ -962,6 +1070,7 @@ int enc_x3_set_attributes() {
     for (const void* f : dx)
         if (int e = set(f, X3_DX_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_pool_x3_kernel), X3_FWD_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_sum_x3_kernel), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<2>), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<1>), X3_FWD_LDS_BYTES)) return e;
     return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<0>), X3_FWD_LDS_BYTES);
@@ -991,6 +1100,10 @@ void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop
 
 void enc_x3_launch_fwd_pool(const EncArgs& A, int total, hipStream_t s) {
     hipLaunchKernelGGL(enc_fwd_pool_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
+}
+
+void enc_x3_launch_fwd_sum(const EncArgs& A, int total, hipStream_t s) {
+    hipLaunchKernelGGL(enc_fwd_sum_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
 }
 
 void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {

@@ -80,10 +80,13 @@ int edge(hipStream_t from, hipStream_t to, hipEvent_t ev) {
 }  // namespace
 
 // ---- one launch for every weight image of the network: blockIdx.y = encoder branches, decoder branches, head (reduce.hpp) ----
-__global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) { pack_element(A, (int)blockIdx.y, (int)(blockIdx.x * 256 + threadIdx.x)); }
+__global__ __launch_bounds__(256) void pinnsf_pack_kernel(PackAll A) {
+    __shared__ double red[256];
+    pack_block(A, (int)blockIdx.x, 256, red);
+}
 
 int launch_pack(const PackAll& A, hipStream_t s) {
-    hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((kPackMax + 255) / 256, 2 * A.nbr + (A.has_head ? 1 : 0)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(pinnsf_pack_kernel, dim3((unsigned)pack_blocks_total(A, 256)), dim3(256), 0, s, A);
     trace_mark("pinnsf_pack", s);
     return hipGetLastError();
 }
@@ -94,6 +97,52 @@ __global__ __launch_bounds__(256) void pinnsf_reduce_kernel(ReduceAll A) { reduc
 
 int launch_slot_sums(const ReduceAll& R, hipStream_t s) {
     hipLaunchKernelGGL(pinnsf_reduce_kernel, dim3((unsigned)(R.gx * R.nsets)), dim3(256), 0, s, R);
+    return hipGetLastError();
+}
+
+// ---- PIML_POOL_TRAIN: the folded first layers' gradients -> the gradients of their factors (reduce.hpp: UnfoldSet) ----
+// float64 accumulation (the kernel is 4 M multiply-adds: its time is the launch); one thread per output element.
+__global__ __launch_bounds__(256) void pinnsf_unfold_kernel(ReduceAll R) {
+    const UnfoldSet U = R.unf[blockIdx.y];
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const float* __restrict__ G = U.dgrads;
+    const float* __restrict__ gb = U.dgrads + DD * DH + DD * DD + 2 * DD;
+    const double sc = (double)U.scale;
+    if (x < 64) {                     // row x of dW1: s (G[x][:] W3^T + k g_b[x] b3)
+        __shared__ float g[DH];
+        __shared__ double part[256];
+        if (tid < DH) g[tid] = G[(size_t)x * DH + tid];
+        __syncthreads();
+        const int m = tid & 127, half = tid >> 7;
+        const float4* wr = reinterpret_cast<const float4*>(U.w3 + (size_t)m * EH + 64 * half);
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 wv = wr[q];
+            const float* gq = g + 64 * half + 4 * q;
+            a += (double)gq[0] * wv.x + (double)gq[1] * wv.y + (double)gq[2] * wv.z + (double)gq[3] * wv.w;
+        }
+        part[tid] = a;
+        __syncthreads();
+        if (tid < DH)
+            U.dw1_out[(size_t)x * DH + tid] = (float)(sc * ((part[tid] + part[tid + 128]) + (double)U.k * (double)gb[x] * (double)U.b3[tid]));
+    } else if (x < 128) {             // rows 2 (x - 64), + 1 of dW3 = s W1^T G
+        const int m = 2 * (x - 64) + (tid >> 7), j = tid & 127;
+        double a = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < DD; ++i) a += (double)U.w1[(size_t)i * DH + m] * (double)G[(size_t)i * DH + j];
+        U.egrads[(size_t)m * EH + j] = (float)(sc * a);
+    } else if (tid < EH) {            // db3 = s k W1^T g_b
+        double a = 0.0;
+        for (int i = 0; i < DD; ++i) a += (double)U.w1[(size_t)i * DH + tid] * (double)gb[i];
+        U.egrads[2 * EH * EH + 8 * EH + tid] = (float)(sc * (double)U.k * a);
+    }
+}
+
+int launch_unfold(const ReduceAll& R, hipStream_t s) {
+    if (R.nunf <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pinnsf_unfold_kernel, dim3(kUnfoldBlocks, (unsigned)R.nunf), dim3(256), 0, s, R);
+    trace_mark("pinnsf_unfold", s);
     return hipGetLastError();
 }
 
@@ -169,9 +218,9 @@ int pending_slot_sums_flush() {
         if (!P->valid) return hipSuccess;
         R = P->R; s = P->stream; P->valid = false;
     }
-    const int e = launch_slot_sums(R, s);
+    if (int e = launch_slot_sums(R, s)) return e;
     trace_mark("pinnsf_reduce", s);
-    return e;
+    return launch_unfold(R, s);
 }
 
 int pending_slot_sums_leave(const ReduceAll& R, hipStream_t s) {
@@ -222,7 +271,16 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
     if (head) {
         if (!head->w1 || !head->b1 || !head->w2 || !head->b2 || !head->packed) return hipErrorInvalidValue;
         A.head = *head;
+        if (head->fold_w3) {
+            if (!head->fold_b3) return hipErrorInvalidValue;
+            A.has_fold = 1;
+        }
     }
+    for (int i = 0; i < nbr; ++i)
+        if (dec[i].fold_w3) {
+            if (!dec[i].fold_b3) return hipErrorInvalidValue;
+            A.has_fold = 1;
+        }
     if (flags & PIML_DEFER_PACK) return pending_pack_leave(A, as_stream(stream));      // the next relfeat forward on `stream` runs it
     return launch_pack(A, as_stream(stream));
 }
@@ -230,20 +288,25 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
 PIML_API int piml_pinnsf_pack_flush(void) { return pending_pack_flush(); }
 
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
-static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate, bool defer = false) {
+static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate, bool defer = false,
+                      bool sums = false) {
     ReduceAll R = {};
     R.accumulate = accumulate ? 1 : 0;
     int w0 = 0, n = 0, maxl = 0;
     const int total = piml_encoder_workgroups(enc, nbr, &w0);
     const int dslots = piml_decoder_workgroups(dec[0].agents);
     int n0[2] = {0, 0}, n1[2] = {0, 0};
-    const bool dw2 = enc_dw2_used(enc, nbr, n0, n1);
+    const bool dw2 = !sums && enc_dw2_used(enc, nbr, n0, n1);
     auto add = [&](const float* parts, float* grads, int slots, int lanes, int split, int off0, int off1) {
         R.set[n++] = ReduceSet{parts, grads, slots, lanes, split, off0, off1};
         if (lanes > maxl) maxl = lanes;
     };
     for (int i = 0; i < nbr; ++i) {
-        if (dw2) {
+        if (sums) {          // PIML_POOL_TRAIN: one layer-1 slot (dW2 | dW1 | db2 | db1) per workgroup; dW3 / db3 come from the unfold
+            add(enc[i].partials, enc[i].grads, nbr == 1 ? total : (i == 0 ? w0 : total - w0), DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
+            R.unf[i] = UnfoldSet{dec[i].grads, dec[i].w1, enc[i].w3, enc[i].b3, dec[i].fold_scale, enc[i].k, dec[i].dw1_out, enc[i].grads};
+            R.nunf = nbr;
+        } else if (dw2) {
             add(enc[i].partials, enc[i].grads, n0[i], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1);
             add(enc[i].partials + (size_t)n0[i] * (DW2_L0_LANES * 4), enc[i].grads, n1[i], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
         } else {
@@ -254,14 +317,15 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
     R.nsets = n;
     R.gx = (maxl + 15) / 16;
     if (defer) return pending_slot_sums_leave(R, s);          // the next piml_relfeat_self_bwd on `s` (or a flush) runs them
-    const int e = launch_slot_sums(R, s);
+    if (int e = launch_slot_sums(R, s)) return e;
     trace_mark("pinnsf_reduce", s);
-    return e;
+    return launch_unfold(R, s);
 }
 
 PIML_API int piml_pinnsf_slot_sums_flush(void) { return pending_slot_sums_flush(); }
 
 PIML_API int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_h2_ok(enc, nbr) ? 1 : 0; }
+PIML_API int piml_pinnsf_pool_train_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_train_ok(enc, nbr) ? 1 : 0; }
 
 PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
                              const piml_collision_head* head, const float* self_features, float tau, float* acc,
@@ -269,6 +333,17 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
     hipStream_t m = as_stream(stream);
     const bool pack = !(flags & PIML_PACKED_VALID);
     PIML_TRY(pending_pack_flush());          // a deferred pack nobody took: now (no-op otherwise)
+    if (flags & PIML_POOL_TRAIN) {            // training on the agents' sums of h2 (see the header)
+        if ((flags & (PIML_FORK | PIML_POOL_H2)) || !enc_pool_train_ok(enc, nbr)) return hipErrorInvalidValue;
+        for (int i = 0; i < nbr; ++i)
+            if (dec[i].pooled != enc[i].sum_a || dec[i].msgs != enc[i].sum_b) return hipErrorInvalidValue;
+        if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
+        PIML_TRY(enc_stage_fwd_sum(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
+        trace_mark("enc_fwd", m);
+        PIML_TRY(dec_stage_fwd_sum(dec, nbr, head, self_features, tau, acc, m));
+        trace_mark("dec_fwd_head", m);
+        return hipSuccess;
+    }
     if (flags & PIML_POOL_H2) {               // inference: the agents' sums of h2 instead of the messages (see the header)
         if ((flags & PIML_FORK) || head || !enc_pool_h2_ok(enc, nbr)) return hipErrorInvalidValue;
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, nullptr, 0, stream));
@@ -314,6 +389,16 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
 PIML_API int piml_pinnsf_bwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, const float* g_pred,
                              const float* self_features, float tau, float* g_self, int flags, void* stream) {
     hipStream_t m = as_stream(stream);
+    if (flags & PIML_POOL_TRAIN) {            // backward of a PIML_POOL_TRAIN forward
+        if (flags & PIML_FORK) return hipErrorInvalidValue;
+        for (int i = 0; i < nbr; ++i)
+            if (!dec[i].dw1_out || !dec[i].fold_w3 || dec[i].g_pooled != enc[i].g_pooled) return hipErrorInvalidValue;
+        PIML_TRY(dec_stage_bwd_fused(dec, nbr, g_pred, self_features, tau, g_self, m, true));
+        trace_mark("dec_bwd", m);
+        PIML_TRY(enc_stage_bwd_sum(enc, nbr, m));
+        trace_mark("enc_bwd_dx", m);
+        return reduce_all(enc, dec, nbr, m, (flags & PIML_ACCUMULATE) != 0, (flags & PIML_DEFER_SLOT_SUMS) != 0, true);
+    }
     if (!(flags & PIML_FORK)) {
         PIML_TRY(dec_stage_bwd_fused(dec, nbr, g_pred, self_features, tau, g_self, m));
         trace_mark("dec_bwd", m);

@@ -104,9 +104,17 @@ constexpr int DP_B = DP_A3 + 2 * 4 * 256;        // b1 64 | b2 64 | b3 2 | pad 2
 constexpr int DP_T3 = DP_B + 132;                // [ob 2][lane 64]                     W3^T: lane (i, h) = W3[h][32 ob + i]
 constexpr int DP_T2 = DP_T3 + 128;               // [ob 2][bp 2][q 4][lane 64] float4   W2^T
 constexpr int DP_T1 = DP_T2 + 2 * 2 * 4 * 256;   // [blk 4][bp 2][q 4][lane 64] float4  W1^T
-constexpr int DEC_PACK = DP_T1 + 4 * 2 * 4 * 256;
+// FOLDED first layer (piml_decoder_branch.fold_w3, training on the agents' sums of h2: PIML_POOL_TRAIN): the same two images of
+// W1' = fold_scale * W1 * fold_w3 (64 x 128; float64 products, rounded once) and the vector c = fold_scale * W1 * fold_b3
+// (the first layer's bias on the sums of an agent's k rows is b1 + k c); garbage when the branch carries no fold_w3
+constexpr int DP_A1F = DP_T1 + 4 * 2 * 4 * 256;
+constexpr int DP_T1F = DP_A1F + 2 * 4 * 4 * 256;
+constexpr int DP_CF = DP_T1F + 4 * 2 * 4 * 256;  // c 64
+constexpr int DEC_PACK = DP_CF + 64;
+constexpr int DEC_PACK_PLAIN = DP_A1F;           // what dec_pack_value fills; the folded part: dec_fold_item
 
 __device__ __forceinline__ float dec_pack_value(const piml_decoder_branch& J, int e) {
+    if (e >= DEC_PACK_PLAIN) return 0.f;          // (the folded images: dec_fold_item)
     if (e < DP_B) {                 // forward fragments
         int f = e, rows_in;         // rows_in: input width of the layer
         const float* W;
@@ -143,14 +151,20 @@ __device__ __forceinline__ float dec_pack_value(const piml_decoder_branch& J, in
 // collision head: A1 [ob 2][bp 4][q 4][lane 64] float4 (W1 fragments for the f32 matrix instruction) | b1 64 | b2 1 + 3 pad |
 // w2 64 (raw row) | W1 split into bf16 pieces for the split-product form: [ob 2][kb 8][piece 3][lane 64] u32x4 -- lane
 // (i, g) holds W1[32 ob + i][16 kb + 8 g + t], t = 0 .. 7, packed pairwise
+// | FOLDED (piml_collision_head.fold_w3: the head on h2 rows instead of message rows, PIML_POOL_TRAIN): the split-product image
+// of W1' = fold_scale * W1 * fold_w3 and b1' = b1 + fold_scale * W1 * fold_b3 (64)
 constexpr int HP_B = 2 * 4 * 4 * 256;
 constexpr int HP_W2 = HP_B + 68;
 constexpr int HP_X3 = HP_W2 + 64;
-constexpr int HEAD_PACK = HP_X3 + 2 * 8 * 3 * 256;
-static_assert(HP_X3 % 4 == 0, "16-byte aligned fragments");
+constexpr int HP_X3F = HP_X3 + 2 * 8 * 3 * 256;
+constexpr int HP_BF = HP_X3F + 2 * 8 * 3 * 256;
+constexpr int HEAD_PACK = HP_BF + 64;
+constexpr int HEAD_PACK_PLAIN = HP_X3F;          // what head_pack_value fills; the folded part: head_fold_item
+static_assert(HP_X3 % 4 == 0 && HP_X3F % 4 == 0, "16-byte aligned fragments");
 
-__device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, const float* __restrict__ b1,
-                                                 const float* __restrict__ w2, const float* __restrict__ b2, int e) {
+__device__ __forceinline__ float head_pack_value(const piml_collision_head& H, int e) {
+    const float* __restrict__ w1 = H.w1;
+    if (e >= HEAD_PACK_PLAIN) return 0.f;         // (the folded images: head_fold_item)
     if (e < HP_B) {
         const int u = e & 3, lane = (e >> 2) & 63, q = (e >> 8) & 3, rest = e >> 10;
         const int bp = rest & 3, ob = rest >> 2;
@@ -165,9 +179,58 @@ __device__ __forceinline__ float head_pack_value(const float* __restrict__ w1, c
         split3(w1[(size_t)i * DH + c], w1[(size_t)i * DH + c + 1], hi, mid, lo);
         return __uint_as_float(piece == 0 ? hi : (piece == 1 ? mid : lo));
     }
-    if (e >= HP_W2) return w2[e - HP_W2];
+    if (e >= HP_W2) return H.w2[e - HP_W2];
     const int g = e - HP_B;
-    return g < 64 ? b1[g] : (g == 64 ? b2[0] : 0.f);
+    return g < 64 ? H.b1[g] : (g == 64 ? H.b2[0] : 0.f);
+}
+
+// ---- the FOLDED images (PIML_POOL_TRAIN): W' = s W1 [W3 | b3] (64 x 129) per folded layer ----
+// A 128-term dot product per element is a chain of L2 round trips for a lone thread (measured: 30 us at the tail of the relfeat
+// forward, whose trailing workgroups these are, reduce.hpp), so a GROUP = (row i, 64 consecutive columns -- or the b3 column
+// alone) is cut over CH waves, each taking 128 / CH terms with every load in flight at once: lanes = columns (coalesced W3
+// rows), the W1 row wave-uniform (scalar loads), float64 partials meet in LDS and are added in a fixed order, the result is
+// rounded once and scattered into the images.  Lean on purpose: the relfeat forward's register budget is shared.
+constexpr int FOLD_GROUPS = DD * 3;                  // per folded layer: 64 rows x (columns 0 .. 63 | 64 .. 127 | the b3 column)
+
+template <int CH>
+__device__ __forceinline__ double fold_partial(const float* __restrict__ row, const float* __restrict__ col, int stride, int chunk) {
+    constexpr int N = DH / CH;
+    float wv[N], xv[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) { wv[t] = row[chunk * N + t]; xv[t] = col[(size_t)(chunk * N + t) * stride]; }
+    double a = 0.0;
+#pragma unroll
+    for (int t = 0; t < N; ++t) a += (double)wv[t] * (double)xv[t];
+    return a;
+}
+
+// the group's 64 finished values (lane = column) -> the decoder's folded images
+__device__ __forceinline__ void dec_fold_store(const piml_decoder_branch& J, int i, int hc, int lane, double sum) {
+    const float v = (float)((double)J.fold_scale * sum);
+    if (hc == 2) {
+        if (lane == 0) J.packed[DP_CF + i] = v;
+        return;
+    }
+    const int c = 64 * hc + lane;
+    // forward fragment: [ob][bp][q][lane][u], i = 32 ob + (lane & 31), c = 32 bp + 8 q + 4 h + u
+    J.packed[DP_A1F + ((((i >> 5) * 4 + (c >> 5)) * 4 + ((c >> 3) & 3)) * 64 + (i & 31) + 32 * ((c >> 2) & 1)) * 4 + (c & 3)] = v;
+    // transposed fragment: [blk][bp][q][lane][u], i = 32 bp + 8 q + 4 h + u, c = 32 blk + (lane & 31)
+    J.packed[DP_T1F + ((((c >> 5) * 2 + (i >> 5)) * 4 + ((i >> 3) & 3)) * 64 + (c & 31) + 32 * ((i >> 2) & 1)) * 4 + (i & 3)] = v;
+}
+__device__ __forceinline__ void head_fold_store(const piml_collision_head& H, int i, int hc, int lane, double sum) {
+    if (hc == 2) {
+        if (lane == 0) H.packed[HP_BF + i] = (float)((double)H.b1[i] + (double)H.fold_scale * sum);
+        return;
+    }
+    const float a = (float)((double)H.fold_scale * sum);
+    const float b = __shfl_down(a, 1, 64);              // the pair's second column
+    if (lane & 1) return;
+    const int c = 64 * hc + lane;
+    unsigned hi, mid, lo;
+    split3(a, b, hi, mid, lo);
+    // [ob][kb][piece][lane][d]: i = 32 ob + (lane & 31), c = 16 kb + 8 (lane >> 5) + 2 d
+    unsigned* dst = reinterpret_cast<unsigned*>(H.packed + HP_X3F) + ((((i >> 5) * 8 + (c >> 4)) * 3) * 64 + (i & 31) + 32 * ((c >> 3) & 1)) * 4 + ((c & 7) >> 1);
+    dst[0] = hi; dst[256] = mid; dst[512] = lo;
 }
 
 // ---- sums over per-workgroup partial slots (fixed order: deterministic), one block of 256 threads per column group ----

@@ -171,13 +171,13 @@ template <int WAVES, bool RES>
 __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatArgs A, const PackWork PK) {
     // a deferred weight pack (PIML_DEFER_PACK, reduce.hpp) rides as the launch's trailing workgroups: they reach a CU when
     // the short obstacle workgroups have left, under the tail of the pedestrian passes
+    extern __shared__ __attribute__((aligned(16))) float rf_lds[];
     if (PK.first_block >= 0 && (int)blockIdx.x >= PK.first_block) {
-        pack_block(PK.A, (int)blockIdx.x - PK.first_block, WAVES * 64);
+        pack_block(PK.A, (int)blockIdx.x - PK.first_block, WAVES * 64, reinterpret_cast<double*>(rf_lds));
         return;
     }
     // source tiles, structure-of-arrays so that a lane fetches 4 consecutive points per
     // ds_read_b128 (x) + ds_read_b128 (y)
-    extern __shared__ __attribute__((aligned(16))) float rf_lds[];
     float* const agent_x = rf_lds;
     float* const agent_y = rf_lds + kTile;
     unsigned short* const ring_base = reinterpret_cast<unsigned short*>(rf_lds + 2 * kTile);
@@ -616,7 +616,7 @@ static void relfeat_go(dim3 grid, dim3 block, void* stream, const RelfeatArgs& A
     PK.first_block = -1;
     if (forward_of_a_step && pending_pack_take(as_stream(stream), &PK.A)) {     // a pack left by piml_pinnsf_pack(PIML_DEFER_PACK)
         PK.first_block = (int)grid.x;
-        grid.x += (unsigned)(pack_blocks_per_set(W * 64) * (2 * PK.A.nbr + (PK.A.has_head ? 1 : 0)));
+        grid.x += (unsigned)pack_blocks_total(PK.A, W * 64);
     }
     relfeat_fwd_kernel<W, R><<<grid, block, bytes, as_stream(stream)>>>(A, PK);
 }
@@ -834,6 +834,10 @@ PIML_API int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_f
                            R, nred, g_ped_feat, g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state,
                            (const float2*)destination_rows, N, focal_begin, focal_count, kp_eff, ko_eff, g_state,
                            (float2*)g_destination, g_speed);
+        if (R.nunf > 0) {                      // PIML_POOL_TRAIN: the folded layers' gradients -> their factors' (network.hip)
+            trace_mark("relfeat_bwd", as_stream(stream));
+            return launch_unfold(R, as_stream(stream));
+        }
     } else {
         hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
                            g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,

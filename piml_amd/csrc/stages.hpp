@@ -15,6 +15,11 @@ int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* 
 // (enc_fwd_pool_x3_kernel); enc_pool_h2_ok: the configuration it serves
 bool enc_pool_h2_ok(const piml_encoder_branch* br, int nbr);
 int enc_stage_fwd_pool(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
+// PIML_POOL_TRAIN: training on the agents' sums of h2 (enc_fwd_sum_x3_kernel / the SUMS form of the one-pass backward);
+// enc_pool_train_ok: the configuration they serve
+bool enc_pool_train_ok(const piml_encoder_branch* br, int nbr);
+int enc_stage_fwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
+int enc_stage_bwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s);        // slots: one DW2_PART1 slot per workgroup
 int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
 int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate = false);
@@ -35,7 +40,11 @@ int dec_stage_bwd_dx(const piml_decoder_branch* br, int nbr, const float* g_pred
                      float* g_self, hipStream_t s);
 // dX chain + weight-gradient partials (no slot sum) in one launch
 int dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_pred, const float* self_features, float tau,
-                        float* g_self, hipStream_t s);
+                        float* g_self, hipStream_t s, bool sums = false);      // sums: PIML_POOL_TRAIN (folded first layer)
+// PIML_POOL_TRAIN: decoder tails on the agents' sums of h2 (`pooled` + second parts in `msgs`) with the folded first layer, and
+// the collision head (may be NULL) on the h2 rows with the folded W1, in one launch
+int dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features, float tau,
+                      float* acc, hipStream_t s);
 int dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s);   // partials (+ slot sum)
 
 // keep-masks of up to two row sets in ONE launch (one draw, streams[i] tells them apart); advances the draw counter

@@ -199,6 +199,10 @@ class _PINNSFBase(nn.Module):
     predictions_only = False    # set by the inference rollouts (BaseSimulator): the auxiliary collision head (`pinnsf_m`: on the messages,
                                 # `pinnsf_bm`: on the decoded rows) is not launched -- those loops read out[0] only (simulators.py:602) --
                                 # and forward returns None in its place
+    messages_wanted = True      # False: the caller reads predictions[0] (and the collision head's output, without training it) only --
+                                # what the reference's loops do unless reg_weight > 0 (src/models/simulators.py:331-347, :702-737).
+                                # `pinnsf` / `pinnsf_m` then run on the agents' SUMS of h2 where no dropout mask is active and the
+                                # library serves the shape (ops.fused_pinnsf(sums=True), PIML_POOL_TRAIN); out[1] / out[2] are None
     residual = False            # pinnsf_res corrector branch
     obs_encoder_in = 6          # PINNSF_residual uses args.obs_feature_dim instead
     taus = (2, 2)               # (non-ucy tau, ucy tau)
@@ -413,7 +417,7 @@ class _PINNSFBase(nn.Module):
             [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
                   predictor=[q.mlp[0].weight, q.mlp[0].bias]) for (f, e, p, d, q), sp in zip(cand, specs)],
-            self_features, self.tau, fold_epilogue=fold, head=head, packs=packs)
+            self_features, self.tau, fold_epilogue=fold, head=head, packs=packs, sums=not self.messages_wanted)
         acc, msgs = res[0], res[1]
         if not fold:
             if self_features.dim() == 3:
@@ -509,6 +513,16 @@ class _PINNSFBase(nn.Module):
             dec_w.append([t for lin in dl for t in (lin.weight, lin.bias)] + [q.mlp[0].weight, q.mlp[0].bias])
         return enc_w, dec_w, (None if (self.bottleneck or self.predictions_only) else self._fusable_head())
 
+    def _fold_spec(self):
+        """per branch the processor scale when a forward pass inside packed_weights() may run on the agents' sums of h2
+        (messages not wanted, no active dropout: the pack then also makes the folded images), else None"""
+        if self.messages_wanted or self.bottleneck or self.residual:
+            return None
+        procs = [self.ped_processor] + ([self.obs_processor] if self.obs_feature_dim > 0 else [])
+        if any(p.dropout_active() or not p.scales_input() for p in procs):
+            return None
+        return [2.0 for _ in procs]
+
     def _active_packs(self):
         return self._packs if (self._packs is not None and self._packs.active) else None
 
@@ -525,7 +539,7 @@ class _PINNSFBase(nn.Module):
         from .. import ops
         if self._packs is None:
             self._packs = ops.PinnsfPacks()
-        ops.pinnsf_prepack(self._packs, *spec)
+        ops.pinnsf_prepack(self._packs, *spec, fold=self._fold_spec())
         self._packs.active = True
         try:
             yield

@@ -1839,8 +1839,10 @@ ENCODER_MAX_IN = 8
 
 
 def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, g_msgs=None, g2=None, g1=None,
-                       g_x=None, partials=None, packed=None, grads=None, keep_bits=None, draw_p=None):
+                       g_x=None, partials=None, packed=None, grads=None, keep_bits=None, draw_p=None, relu_mask=None,
+                       sum_a=None, sum_b=None):
     B = _lib.EncoderBranch()
+    B.sum_a, B.sum_b = _ptr(sum_a), _ptr(sum_b)
     B.keep_bits = _ptr(keep_bits)
     if draw_p is not None:            # the forward draws the mask itself (into keep_bits) from the device's dropout state
         B.drop_state, B.drop_p = dropout_state(x2.device).data_ptr(), float(draw_p)
@@ -1853,6 +1855,8 @@ def _enc_branch_struct(x2, k, scale, wb, msgs, h1=None, h2=None, g_pooled=None, 
     # the sign bits of h1 / h2 ride behind h2's rows (_h2_buffer): 2 extra rows of 128 floats per 32-row tile
     R = x2.shape[0]
     B.relu_mask = (h2.data_ptr() + R * h2.shape[1] * 4) if (RELU_MASK and h2 is not None and h2.shape[0] >= R + 2 * ((R + 31) // 32)) else None
+    if relu_mask is not None:          # PIML_POOL_TRAIN: the sign words in a buffer of their own (a branch may have no h2 rows)
+        B.relu_mask = relu_mask.data_ptr()
     return B
 
 
@@ -2053,8 +2057,11 @@ def fused_encoders(branches, packs=None):
 # kernels: encoders (encoder.hip) -> neighbour-axis sum + decoder + predictor + desired force (decoder.hip).
 # ------------------------------------------------------------------------------------------------
 def _dec_branch_struct(msgs, agents, k, wb, packed, pooled=None, h1=None, d2=None, g_pre2=None, g_pre1=None,
-                       g_pooled=None, partials=None, grads=None):
+                       g_pooled=None, partials=None, grads=None, fold=None, dw1_out=None):
     B = _lib.DecoderBranch()
+    if fold is not None:              # (w3, b3, scale) of the branch's encoder: PIML_POOL_TRAIN (include/piml_hip.h)
+        B.fold_w3, B.fold_b3, B.fold_scale = fold[0].data_ptr(), fold[1].data_ptr(), float(fold[2])
+    B.dw1_out = _ptr(dw1_out)
     B.msgs, B.agents, B.k = msgs.data_ptr(), int(agents), int(k)
     B.w1, B.b1, B.w2, B.b2, B.w3, B.b3 = [t.data_ptr() for t in wb]
     B.pooled, B.h1, B.d2, B.g_pre2, B.g_pre1, B.g_pooled, B.partials = \
@@ -2075,6 +2082,7 @@ class PinnsfPacks:
         self.sig = None          # (data pointer, version) of the packed weights
         self.sig_enc = self.sig_dec = None       # the same per encoder / decoder branch (fused_encoders / fused_row_decoder)
         self.active = False
+        self.fold = None         # processor scales the decoders' / head's FOLDED images were packed with (PIML_POOL_TRAIN), or None
 
     def __deepcopy__(self, memo):          # images are derived data: a copied model packs for itself
         return PinnsfPacks()
@@ -2091,7 +2099,7 @@ class PinnsfPacks:
             self.hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt)
 
 
-def _pack_structs(enc_w, dec_w, head_w, packs):
+def _pack_structs(enc_w, dec_w, head_w, packs, fold=None):
     nbr = len(enc_w)
     earr = (_lib.EncoderBranch * nbr)()
     darr = (_lib.DecoderBranch * nbr)()
@@ -2101,11 +2109,15 @@ def _pack_structs(enc_w, dec_w, head_w, packs):
         earr[b].packed = packs.epack[b].data_ptr()
         darr[b].w1, darr[b].b1, darr[b].w2, darr[b].b2, darr[b].w3, darr[b].b3 = [t.data_ptr() for t in dec_w[b]]
         darr[b].packed = packs.dpack[b].data_ptr()
+        if fold is not None:
+            darr[b].fold_w3, darr[b].fold_b3, darr[b].fold_scale = enc_w[b][4].data_ptr(), enc_w[b][5].data_ptr(), float(fold[b])
     head = None
     if head_w is not None:
         head = _lib.CollisionHead()
         head.w1, head.b1, head.w2, head.b2 = [t.data_ptr() for t in head_w]
         head.packed = packs.hpack.data_ptr()
+        if fold is not None:
+            head.fold_w3, head.fold_b3, head.fold_scale = enc_w[0][4].data_ptr(), enc_w[0][5].data_ptr(), float(fold[0])
     return earr, darr, head
 
 
@@ -2122,19 +2134,23 @@ def _weights_sig(enc_w, dec_w, head_w):
 DEFER_PACK = _os.environ.get('PIML_DEFER_PACK', '1') != '0'
 
 
-def pinnsf_prepack(packs, enc_w, dec_w, head_w=None, defer=None):
+def pinnsf_prepack(packs, enc_w, dec_w, head_w=None, defer=None, fold=None):
     """Pack the weights of a fused PINNSF network into `packs` (one launch on the current stream).
     enc_w / dec_w: per branch (w1, b1, w2, b2, w3, b3) encoder and (w1, b1, w2, b2, wp, bp) decoder + predictor tensors;
     head_w: (w1, b1, w2, b2) of the collision head or None.  defer (default: PIML_DEFER_PACK != 0): the launch is left to
     the next relfeat forward on the stream, which runs the pack as its trailing workgroups (PIML_DEFER_PACK of the C ABI);
-    every consumer of the packs launches it itself if no relfeat forward came in between."""
+    every consumer of the packs launches it itself if no relfeat forward came in between.
+    fold: per branch the processor scale -- the same launch ALSO packs the decoders' first layers and the head's with the
+    encoders' last layer folded in (fused_pinnsf(..., sums=True) / PIML_POOL_TRAIN); None: plain images only."""
     import ctypes
     enc_w = [[_gpu_f32('encoder weight', t.detach()) for t in wb] for wb in enc_w]
     dec_w = [[_gpu_f32('decoder weight', t.detach()) for t in wb] for wb in dec_w]
     head_w = None if head_w is None else [_gpu_f32('head weight', t.detach()) for t in head_w]
     dev = enc_w[0][0].device
     packs.ensure(dev)
-    earr, darr, head = _pack_structs(enc_w, dec_w, head_w, packs)
+    fold = None if fold is None else tuple(float(f) for f in fold)
+    earr, darr, head = _pack_structs(enc_w, dec_w, head_w, packs, fold)
+    packs.fold = fold
     with torch.cuda.device(dev):
         flags = _lib.DEFER_PACK if (DEFER_PACK if defer is None else defer) else 0
         _lib.check(_lib.lib().piml_pinnsf_pack(earr, darr, len(enc_w), ctypes.byref(head) if head is not None else None,
@@ -2251,11 +2267,11 @@ class _FusedPinnsf(torch.autograd.Function):
     outputs: acc (..., N, 2) (= predictions when fold_epilogue), msgs (..., N, k, 128) per branch, and with a head
     sigmoid(head(msgs of branch 0)) (..., N, k)."""
     PER = 13
-    FIRST = 9          # index of the first branch tensor among the inputs
-    SELF = 8           # index of self_features
+    FIRST = 10         # index of the first branch tensor among the inputs
+    SELF = 9           # index of self_features
 
     @staticmethod
-    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, packs, nhead, keeps, self_features, *tensors):
+    def forward(ctx, need_grad, nbr, scales, tau, fold_epilogue, packs, nhead, keeps, sums, self_features, *tensors):
         import ctypes
         L = _lib.lib()
         PER = _FusedPinnsf.PER
@@ -2278,13 +2294,31 @@ class _FusedPinnsf(torch.autograd.Function):
                 raise ValueError('fused_pinnsf: both branches must share the leading (..., N) shape')
             x2s.append(x.reshape(-1, x.shape[-1]))
             ks.append(x.shape[-2])
+        if sums:            # PIML_POOL_TRAIN where the library serves the shape (and no sink sums gradients across passes)
+            probe = (_lib.EncoderBranch * nbr)()
+            for b in range(nbr):
+                probe[b].rows, probe[b].in_dim, probe[b].k = x2s[b].shape[0], x2s[b].shape[1], ks[b]
+            sums = bool(L.piml_pinnsf_pool_train_ok(probe, nbr)) and not FORK_NETWORK and \
+                (packs is None or packs.fold == tuple(float(sc) for sc in scales)) and \
+                not (need_grad and ParamGradSink._active is not None) and all(k is None for k in keeps)
+        ctx.sums = sums
+        sum_a, sum_b, masks = [None] * nbr, [None] * nbr, [None] * nbr
+        for b in range(nbr):
             R = x2s[b].shape[0]
-            msgs.append(torch.empty(R, H, **opt))
             h1s.append(None)
-            h2s.append(_h2_buffer(R, opt) if need_grad else None)
-        if need_grad and _h1_needed([x2.shape[0] for x2 in x2s], alone=False):
+            if sums:
+                # the agents' sums of h2 in two parts; the sign words of h1 / h2 (256 dwords per tile); the h2 rows only where the
+                # collision head reads them (branch 0)
+                msgs.append(None)
+                sum_a[b], sum_b[b] = torch.empty(agents, H, **opt), torch.empty(agents, H, **opt)
+                masks[b] = torch.empty(2 * ((R + 31) // 32), H, **opt)
+                h2s.append(torch.empty(R, H, **opt) if (nhead and b == 0) else None)
+            else:
+                msgs.append(torch.empty(R, H, **opt))
+                h2s.append(_h2_buffer(R, opt) if need_grad else None)
+        if not sums and need_grad and _h1_needed([x2.shape[0] for x2 in x2s], alone=False):
             h1s = [torch.empty(x2.shape[0], H, **opt) for x2 in x2s]
-        flags = _lib.FORK if FORK_NETWORK else 0
+        flags = (_lib.FORK if FORK_NETWORK else 0) | (_lib.POOL_TRAIN if sums else 0)
         if packs is not None:
             if packs.sig != _weights_sig(ewb, dwb, hwb):
                 raise ValueError('fused_pinnsf: `packs` were filled from other weight tensors, or the weights were modified in '
@@ -2297,26 +2331,33 @@ class _FusedPinnsf(torch.autograd.Function):
             hpack = torch.empty(L.piml_collision_head_pack_floats(), **opt) if nhead else None
         keeps, draws = zip(*[_resolve_keep(keeps[b], x2s[b].shape[0], H, dev) for b in range(nbr)])
         earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], msgs[b], h1s[b], h2s[b],
-                                                               packed=epack[b], keep_bits=keeps[b], draw_p=draws[b])
+                                                               packed=epack[b], keep_bits=keeps[b], draw_p=draws[b],
+                                                               relu_mask=masks[b], sum_a=sum_a[b], sum_b=sum_b[b])
                                             for b in range(nbr)])
-        pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
+        # (sums: the decoder reads the first parts from `pooled` and leaves the completed sums there)
+        pooled = sum_a if sums else [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
         dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
-        darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
-                                                               dh1[b], dd2[b]) for b in range(nbr)])
+        folds = [(ewb[b][4], ewb[b][5], scales[b]) if sums else None for b in range(nbr)]
+        darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(sum_b[b] if sums else msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
+                                                               dh1[b], dd2[b], fold=folds[b]) for b in range(nbr)])
         acc = torch.empty(agents, 2, **opt)
         head, coll = None, None
         if nhead:
             coll = torch.empty(x2s[0].shape[0], **opt)
             head = _lib.CollisionHead()
-            head.msgs, head.rows = msgs[0].data_ptr(), x2s[0].shape[0]
+            head.msgs, head.rows = (h2s[0] if sums else msgs[0]).data_ptr(), x2s[0].shape[0]
             head.w1, head.b1, head.w2, head.b2 = [t.data_ptr() for t in hwb]
             head.packed, head.out = hpack.data_ptr(), coll.data_ptr()
+            if sums:
+                head.fold_w3, head.fold_b3, head.fold_scale = ewb[0][4].data_ptr(), ewb[0][5].data_ptr(), float(scales[0])
         with torch.cuda.device(dev):
             _lib.check(L.piml_pinnsf_fwd(earr, darr, nbr, ctypes.byref(head) if head is not None else None, _ptr(sf),
                                          float(tau), _ptr(acc), flags, _stream()), 'piml_pinnsf_fwd')
         if need_grad:
-            ctx.save_for_backward(*x2s, *h1s, *h2s, *msgs, *pooled, *dh1, *dd2, *[w for wb in ewb for w in wb],
+            # (sums: the sign words in h2's place; the second parts, which the backward does not read, in the messages')
+            ctx.save_for_backward(*x2s, *h1s, *(masks if sums else h2s), *(sum_b if sums else msgs), *pooled, *dh1, *dd2,
+                                  *[w for wb in ewb for w in wb],
                                   *[w for wb in dwb for w in wb], epack, dpack, *([sf] if sf is not None else []),
                                   *(hwb if nhead else []))
         ctx.meta = (nbr, tuple(scales), float(tau), bool(fold_epilogue), tuple(ks), [tuple(x.shape) for x in xs],
@@ -2325,7 +2366,7 @@ class _FusedPinnsf(torch.autograd.Function):
         ctx.sink = ParamGradSink._active if need_grad else None
         ctx.params = tensors if need_grad else None       # (the Parameter objects themselves: p.grad is set on them / looked at)
         ctx.set_materialize_grads(False)
-        out = (acc.view(*lead, 2), *[msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
+        out = (acc.view(*lead, 2), *[None if sums else msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
         if nhead:
             out = out + (coll.view(*lead, ks[0]),)
         return out
@@ -2354,6 +2395,8 @@ class _FusedPinnsf(torch.autograd.Function):
         opt = dict(device=dev, dtype=torch.float32)
         H = ENCODER_HIDDEN
         flags = _lib.FORK if FORK_NETWORK else 0
+        if ctx.sums:
+            return _FusedPinnsf._backward_sums(ctx, g_acc, g_coll, grads, x2s, h2s, pooled, dh1, dd2, ewb, dwb, epack, dpack, sf)
         if g_coll is not None:           # rare (the reference trains this head for `pinnsf_bm` only): torch ops
             with torch.enable_grad():
                 ins = [t.detach().requires_grad_(True) for t in (msgs[0], *hwb)]
@@ -2461,7 +2504,88 @@ class _FusedPinnsf(torch.autograd.Function):
         return tuple(grads)
 
 
-def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, packs=None):
+def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb, dwb, epack, dpack, sf):
+    """Backward of a PIML_POOL_TRAIN forward (fused_pinnsf(..., sums=True)): decoder tails with the folded first layer ->
+    one-pass encoder backward on G2 = d/d(sum)[agent] * [h2 > 0] -> slot sums -> the folded layers' gradients unfolded."""
+    import ctypes
+    nbr, scales, tau, fold, ks, xshapes, sf_shape, agents, need_grad, nhead = ctx.meta
+    PER, FIRST = _FusedPinnsf.PER, _FusedPinnsf.FIRST
+    if g_coll is not None:
+        raise _lib.PimlHipError('fused_pinnsf(sums=True): the collision head\'s output received a gradient; this form serves callers '
+                                'that train on predictions[0] only (model.messages_wanted = True selects the message path)')
+    if g_acc is None:
+        return tuple(grads)
+    L = _lib.lib()
+    dev = x2s[0].device
+    opt = dict(device=dev, dtype=torch.float32)
+    H = ENCODER_HIDDEN
+    with torch.cuda.device(dev):
+        part1 = H * H + 1024 + 2 * H                       # a layer-1 slot: dW2 | dW1 (1024-float field) | db2 | db1
+        g_pooled = [torch.empty(agents, H, **opt) for _ in range(nbr)]
+        gxs = [torch.empty(x2s[b].shape, **opt) if ctx.needs_input_grad[FIRST + PER * b] else None for b in range(nbr)]
+        if len({g is None for g in gxs}) > 1:              # one kernel variant per launch: both inputs' gradients or neither
+            gxs = [g if g is not None else torch.empty(x2s[b].shape, **opt) for b, g in enumerate(gxs)]
+        earr = (_lib.EncoderBranch * nbr)(*[_enc_branch_struct(x2s[b], ks[b], scales[b], ewb[b], None, None, None, g_pooled[b], None,
+                                                               None, None, gxs[b], packed=epack[b], relu_mask=masks[b])
+                                            for b in range(nbr)])
+        w0 = ctypes.c_int(0)
+        total = L.piml_encoder_workgroups(earr, nbr, ctypes.byref(w0))
+        slots = [w0.value, total - w0.value] if nbr == 2 else [total]
+        parts = [torch.empty(n, part1, **opt) for n in slots]
+        flats = [torch.empty(L.piml_encoder_partial_floats(), **opt) for _ in range(nbr)]
+        for b in range(nbr):
+            earr[b].partials, earr[b].grads = parts[b].data_ptr(), flats[b].data_ptr()
+        ga = _gpu_f32('g_acc', g_acc).reshape(agents, 2)
+        want_self = fold and ctx.needs_input_grad[_FusedPinnsf.SELF]
+        g_self = torch.empty(agents, 7, **opt) if want_self else None
+        nwg = L.piml_decoder_workgroups(agents)
+        dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+        dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+        dw1 = [torch.empty(64, H, **opt) for _ in range(nbr)]
+        keep, dstructs = [], []
+        for b in range(nbr):
+            gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
+            keep += [gp2, gp1]
+            dstructs.append(_dec_branch_struct(pooled[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b], gp2, gp1,
+                                               g_pooled[b], dparts[b], dflats[b], fold=(ewb[b][4], ewb[b][5], scales[b]), dw1_out=dw1[b]))
+        darr = (_lib.DecoderBranch * nbr)(*dstructs)
+        flags = _lib.POOL_TRAIN
+        if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], None):
+            flags |= _lib.DEFER_SLOT_SUMS
+            _DEFER_KEEP[:] = [parts, dparts, dflats, flats, dw1]
+        _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags, _stream()), 'piml_pinnsf_bwd')
+        if want_self:
+            grads[_FusedPinnsf.SELF] = g_self.view(sf_shape)
+        for b in range(nbr):
+            flat = dflats[b]
+            o = FIRST + PER * b + 7
+            need = ctx.needs_input_grad[o:o + 6]
+            dW2 = flat[64 * H:64 * H + 4096].view(64, 64)
+            dW3 = flat[64 * H + 4096:64 * H + 4096 + 128].view(2, 64)
+            rest = flat[64 * H + 4096 + 128:]
+            # (views: AccumulateGrad keeps a gradient it is handed unread only while nobody else holds the tensor object)
+            for jx, t in enumerate((dw1[b].view(64, H), rest[:64], dW2, rest[64:128], dW3, rest[128:130])):      # (d/d(b1) = d/d(b1'))
+                if need[jx]:
+                    grads[o + jx] = t
+            flat = flats[b]
+            in_dim = x2s[b].shape[1]
+            o = FIRST + PER * b
+            need = ctx.needs_input_grad[o:o + 7]
+            if need[0]:
+                grads[o] = gxs[b].view(xshapes[b])
+            dW3, dW2 = flat[:H * H].view(H, H), flat[H * H:2 * H * H].view(H, H)
+            dW1 = flat[2 * H * H:2 * H * H + H * in_dim].view(H, in_dim)
+            db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
+            for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
+                if need[jx]:
+                    grads[o + jx] = t
+    return tuple(grads)
+
+
+_FusedPinnsf._backward_sums = staticmethod(_backward_sums)
+
+
+def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, packs=None, sums=False):
     """The non-bottleneck PINNSF network on the fused kernels.  branches: 1 or 2 dicts {x (..., N, k, in <= 8), scale,
     encoder: (w1, b1, w2, b2, w3, b3), decoder: (w1 (64,128), b1, w2 (64,64), b2), predictor: (w (2,64), b),
     keep_bits: optional int32 (rows, 4) train-mode dropout mask of the processor (see fused_encoders)}.
@@ -2469,7 +2593,12 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
     desired-force term (v0 d/|d| - v) / tau of self_features (..., N, 7) when fold_epilogue.
     head: (w1 (64,128), b1, w2 (1,64), b2) of the `pinnsf_m` collision head; its sigmoid output on the messages of
     branch 0, (..., N, k), is appended to the result (computed beside the decoder tails on a side stream).
-    packs: a PinnsfPacks filled by pinnsf_prepack from these very weights (skips the in-call packs)."""
+    packs: a PinnsfPacks filled by pinnsf_prepack from these very weights (skips the in-call packs).
+    sums: the caller reads neither branch's messages and trains on acc only (the reference's loops with reg_weight = 0,
+    src/models/simulators.py:331-347, :702-737).  Where no branch carries a dropout mask and the library serves the shape
+    (PIML_POOL_TRAIN, include/piml_hip.h) the network then runs on the agents' SUMS of h2: the messages are linear in h2, so
+    the neighbour-axis sum moves in front of the encoders' last layer, which is folded into the decoders' first (and the head's);
+    the returned messages are None.  Elsewhere the flag changes nothing."""
     if not 1 <= len(branches) <= 2:
         raise ValueError('fused_pinnsf: one or two branches')
     flat = []
@@ -2497,7 +2626,7 @@ def fused_pinnsf(branches, self_features, tau, fold_epilogue=True, head=None, pa
     if len({(k is None, isinstance(k, tuple)) for k in keeps}) > 1:
         raise ValueError('fused_pinnsf: the same kind of keep_bits (none / given bits / drawn) for every branch')
     out = _FusedPinnsf.apply(need_grad, len(branches), tuple(float(b['scale']) for b in branches), float(tau),
-                             bool(fold_epilogue), packs, int(head is not None), keeps, self_features, *flat)
+                             bool(fold_epilogue), packs, int(head is not None), keeps, bool(sums), self_features, *flat)
     nbr = len(branches)
     if head is not None:
         return out[0], list(out[1:1 + nbr]), out[1 + nbr]

@@ -120,7 +120,9 @@ def test_no_kernel_of_the_default_dispatch_spills():
     from piml_amd import _lib
     usage = _lib.kernel_resource_usage()
     assert len(usage) > 150 and not [k for k in usage if k.startswith('_Z')]
-    for name in ('relfeat_fwd_kernel<16, false>', 'enc_fwd_x3_kernel<0>', 'enc_bwd_fused_x3_kernel<true, false, false, true>',
+    for name in ('relfeat_fwd_kernel<16, false>', 'enc_fwd_x3_kernel<0>', 'enc_bwd_fused_x3_kernel<true, false, false, true, false>',
+                 'enc_fwd_sum_x3_kernel', 'enc_bwd_fused_x3_kernel<true, false, false, true, true>', 'dec_fwd_head_sum_kernel',
+                 'pinnsf_unfold_kernel',
                  'dec_fwd_head_kernel<true>', 'dec_bwd_split_kernel', 'relfeat_bwd_reduce_kernel', 'mlapm_bwd_sys_kernel<1>'):
         assert name in usage, name
     not_reached = {'dec_bwd_kernel', 'enc_bwd_fused8_x3_kernel<true, true, true, false>'}

@@ -1,0 +1,183 @@
+"""GPU: training on the agents' SUMS of h2 (ops.fused_pinnsf(sums=True), PIML_POOL_TRAIN of piml_pinnsf_fwd / bwd) against a float64
+restatement of the reference's arithmetic -- src/models/model.py:1271-1305 (`pinnsf_m`): encoders (:40-65), processor = 2 x
+(:82-119, quirk Q3), sum over the k neighbours (:1279-1283), decoders + predictors, desired force (:1289-1294), collision head
+(:1296-1300) -- for the outputs and EVERY gradient, and against the message path of the same library.  The algebra under test:
+the messages are linear in h2, so the sum moves in front of the encoders' last layer, which is folded into the decoders' first
+layer and the head's (pack.hpp: dec_fold_item / head_fold_item) and whose gradient is recovered from the folded layers'
+(network.hip: pinnsf_unfold_kernel).  Tolerance: 1e-5 of the tensor's largest magnitude (north-star bar); measured errors are
+printed."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+H = 128
+
+
+def make_net(agents, ks, with_head, seed):
+    g = torch.Generator().manual_seed(seed)
+
+    def mk(*shape, scale=0.2):
+        return (torch.randn(*shape, generator=g) * scale).to(DEV).requires_grad_(True)
+    brs = []
+    for k in ks:
+        x = mk(agents, k, 6, scale=1.0)
+        with torch.no_grad():
+            x[: max(agents // 7, 1), k // 2:, :] = 0.0            # zero-padded neighbour rows (quirk Q4)
+        brs.append(dict(x=x, scale=2.0, encoder=[mk(H, 6), mk(H), mk(H, H), mk(H), mk(H, H), mk(H)],
+                        decoder=[mk(64, H), mk(64), mk(64, 64), mk(64)], predictor=[mk(2, 64), mk(2)]))
+    sf = mk(agents, 7, scale=1.0)
+    head = [mk(64, H), mk(64), mk(1, 64), mk(1)] if with_head else None
+    wa = torch.randn(agents, 2, generator=g).to(DEV)
+    return brs, sf, head, wa, g
+
+
+def forward64(brs, sf, head, tau):
+    d = lambda t: t.detach().double().requires_grad_(True)
+    sf64 = d(sf)
+    leaves, acc, pre, msgs0 = [sf64], 0.0, [], None
+    for i, br in enumerate(brs):
+        x, e, dd, p = d(br['x']), [d(t) for t in br['encoder']], [d(t) for t in br['decoder']], [d(t) for t in br['predictor']]
+        z1 = x @ e[0].t() + e[1]
+        z2 = torch.relu(z1) @ e[2].t() + e[3]
+        m = 2.0 * (torch.relu(z2) @ e[4].t() + e[5])
+        zd = m.sum(dim=-2) @ dd[0].t() + dd[1]
+        acc = acc + (torch.relu(zd) @ dd[2].t() + dd[3]) @ p[0].t() + p[1]
+        pre += [z1, z2, zd.unsqueeze(1)]
+        if i == 0:
+            msgs0 = m
+        leaves += [x, *e, *dd, *p]
+    t = torch.norm(sf64[:, :2], dim=-1, keepdim=True)
+    t = torch.where(t == 0, t + 0.1, t)
+    acc = acc + (sf64[:, 6:7] * sf64[:, :2] / t - sf64[:, 2:4]) / tau
+    coll = None
+    if head is not None:
+        h64 = [t.detach().double() for t in head]
+        zh = msgs0 @ h64[0].t() + h64[1]
+        pre.append(zh)
+        coll = torch.sigmoid(torch.relu(zh) @ h64[2].t() + h64[3]).squeeze(-1)
+    return acc, coll, leaves, pre
+
+
+def dodge_relu_kinks(brs, sf, head, tau, g, rel=1e-5, rounds=20):
+    """Re-draw the inputs of the agents that put a ReLU pre-activation within `rel` of zero anywhere in the float64 evaluation:
+    two correct float32 evaluations round such a value to different sides, and the comparison would then measure one flipped
+    unit instead of the arithmetic (tests/test_encoder_gpu.py: dodge_relu_kinks)."""
+    for _ in range(rounds):
+        with torch.no_grad():
+            _, _, _, pre = forward64(brs, sf, head, tau)
+            bad = torch.zeros(sf.shape[0], dtype=torch.bool, device=DEV)
+            for z in pre:
+                bad |= (z.abs() < rel * z.abs().mean()).flatten(1).any(-1)
+            n = int(bad.sum())
+            if n == 0:
+                return
+            for br in brs:
+                br['x'][bad] = torch.randn(n, *br['x'].shape[1:], generator=g).to(DEV)
+    raise AssertionError('dodge_relu_kinks: still near a kink after re-drawing')
+
+
+def run(brs, sf, head, wa, tau, sums, packs=None):
+    from piml_amd import ops
+    res = ops.fused_pinnsf(brs, sf, tau, fold_epilogue=True, head=head, packs=packs, sums=sums)
+    leaves = [sf] + [t for br in brs for t in (br['x'], *br['encoder'], *br['decoder'], *br['predictor'])]
+    grads = torch.autograd.grad((res[0] * wa).sum(), leaves)
+    return res, grads
+
+
+@pytest.mark.parametrize('agents,ks,with_head', [(4096, (6, 10), True), (2500, (6, 10), False), (12000, (6, 2), True),
+                                                 (4099, (10, 6), True)])
+def test_sums_path_matches_float64_and_the_message_path(agents, ks, with_head):
+    from piml_amd import ops, _lib
+    tau = 0.5
+    brs, sf, head, wa, g = make_net(agents, ks, with_head, seed=31)
+    dodge_relu_kinks(brs, sf, head, tau, g)
+    probe = (_lib.EncoderBranch * 2)()
+    for b in range(2):
+        probe[b].rows, probe[b].in_dim, probe[b].k = agents * ks[b], 6, ks[b]
+    assert _lib.lib().piml_pinnsf_pool_train_ok(probe, 2), 'the library should serve this shape on the sums path'
+    res_s, grads_s = run(brs, sf, head, wa, tau, True)
+    res_m, grads_m = run(brs, sf, head, wa, tau, False)
+    assert all(m is None for m in res_s[1]) and all(m is not None for m in res_m[1])
+    acc64, coll64, leaves64, _ = forward64(brs, sf, head, tau)
+    grads64 = torch.autograd.grad((acc64 * wa.double()).sum(), leaves64)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    names = ['sf'] + [f'{p}.{n}' for p in ('ped', 'obs') for n in ('x', 'eW1', 'eb1', 'eW2', 'eb2', 'eW3', 'eb3', 'dW1', 'db1', 'dW2', 'db2', 'pW', 'pb')]
+    worst_s = {'acc': rel(res_s[0], acc64)}
+    worst_m = {'acc': rel(res_m[0], acc64)}
+    if with_head:
+        worst_s['coll'], worst_m['coll'] = rel(res_s[2], coll64), rel(res_m[2], coll64)
+    for nm, a, b, c in zip(names, grads_s, grads_m, grads64):
+        worst_s[nm], worst_m[nm] = rel(a, c), rel(b, c)
+    ws, wm = max(worst_s.values()), max(worst_m.values())
+    print(f'sums path agents={agents} k={ks} head={with_head}: max rel err vs float64 {ws:.1e} '
+          f'({max(worst_s, key=worst_s.get)}); message path {wm:.1e} ({max(worst_m, key=worst_m.get)})')
+    assert ws <= 1e-5, worst_s
+    # and the same call twice is bitwise the same (no atomics, fixed summation order)
+    res_2, grads_2 = run(brs, sf, head, wa, tau, True)
+    assert torch.equal(res_2[0], res_s[0]) and all(torch.equal(a, b) for a, b in zip(grads_2, grads_s))
+
+
+def test_sums_path_inside_packed_weights_and_deferred_slot_sums():
+    """The training loops' form: weights packed once (folded images included), the slot sums and the unfold deferred to the
+    relfeat backward's launch / the block's exit -- bitwise the plain call."""
+    from piml_amd import ops
+    tau = 0.5
+    brs, sf, head, wa, g = make_net(4096, (6, 10), True, seed=5)
+    res0, grads0 = run(brs, sf, head, wa, tau, True)
+    packs = ops.PinnsfPacks()
+    ops.pinnsf_prepack(packs, [br['encoder'] for br in brs], [br['decoder'] + br['predictor'] for br in brs], head, defer=False,
+                       fold=[2.0, 2.0])
+    with ops.deferred_slot_sums():
+        res1, grads1 = run(brs, sf, head, wa, tau, True, packs=packs)
+    torch.cuda.synchronize()
+    assert res1[1][0] is None and torch.equal(res1[0], res0[0]) and torch.equal(res1[2], res0[2])
+    for a, b in zip(grads1, grads0):
+        assert torch.equal(a, b)
+    # packs made without the folded images: the call takes the message path (and says so by returning the messages)
+    plain = ops.PinnsfPacks()
+    ops.pinnsf_prepack(plain, [br['encoder'] for br in brs], [br['decoder'] + br['predictor'] for br in brs], head, defer=False)
+    res2, _ = run(brs, sf, head, wa, tau, True, packs=plain)
+    assert res2[1][0] is not None
+
+
+def test_sums_path_refuses_a_gradient_on_the_collision_head():
+    from piml_amd import ops, _lib
+    brs, sf, head, wa, g = make_net(4096, (6, 10), True, seed=7)
+    res = ops.fused_pinnsf(brs, sf, 0.5, head=head, sums=True)
+    with pytest.raises(_lib.PimlHipError):
+        res[2].sum().backward()
+
+
+def test_model_messages_wanted_false_takes_the_sums_path():
+    """PINNSF_multitask with messages_wanted = False: same predictions and gradients as the default (to float32 rounding),
+    out[1] / out[2] are None; in train mode with dropout the flag changes nothing."""
+    import types
+    import piml_amd.models.model as MODEL
+    args = types.SimpleNamespace(
+        ped_feature_dim=6, obs_feature_dim=6, self_feature_dim=7, encoder_hidden_size=128,
+        processor_hidden_size=128, decoder_hidden_size=64, encoder_hidden_layers=3, processor_hidden_layers=16,
+        decoder_hidden_layers=2, dropout=0.5, activation='relu', dataset_name='gc1560')
+    torch.manual_seed(0)
+    net = MODEL.PINNSF_multitask(args).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    n = 4096
+    pf, of, sf = [(torch.randn(*s, generator=g)).to(DEV) for s in ((n, 6, 6), (n, 10, 6), (n, 7))]
+    outs = {}
+    for wanted in (True, False):
+        net.messages_wanted = wanted
+        net.zero_grad(set_to_none=True)
+        with net.packed_weights():
+            out = net(pf, of, sf)
+            out[0].sum().backward()
+        outs[wanted] = (out, [p.grad.clone() for p in net.parameters() if p.grad is not None])
+    assert outs[False][0][1] is None and outs[False][0][2] is None and outs[True][0][1] is not None
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    worst = max([rel(outs[False][0][0], outs[True][0][0]), rel(outs[False][0][3], outs[True][0][3])] +
+                [rel(a, b) for a, b in zip(outs[False][1], outs[True][1])])
+    print(f'model sums path vs message path: max rel diff {worst:.1e}')
+    assert len(outs[False][1]) == len(outs[True][1]) and worst <= 2e-5
+    net.train()
+    net.messages_wanted = False
+    out = net(pf, of, sf)
+    assert out[1] is not None
