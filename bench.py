@@ -321,7 +321,7 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None, messages=False):
+                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None, messages=False, p2p=None):
         from piml_amd import ops, _lib
         import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
@@ -336,7 +336,13 @@ class Step:
                                                      axis=-1), device=dev).requires_grad_(True)
         self.dest_own = torch.tensor(scene['destination'][rows], device=dev)
         self.v0_own = torch.tensor(scene['desired_speed'][rows], device=dev)
-        self.sh = ShardedScene(N, self.obstacles, group=group, force_collectives=True) if use_dist else None
+        # exchange='p2p': p2p = (forward, backward) P2PExchange objects (sharded.p2p_exchanges) -- both exchanges are launches
+        # of this library with their step counters on the device, so they sit INSIDE the captured graph; `group` may be None
+        self.p2p = p2p if exchange == 'p2p' else None
+        if exchange == 'p2p' and p2p is None:
+            raise ValueError("Step(exchange='p2p') needs p2p=(forward, backward)")
+        self.sh = (ShardedScene(N, self.obstacles, group=group, force_collectives=True, exchange='p2p' if self.p2p else 'rccl',
+                                p2p=self.p2p) if use_dist else None)
         torch.manual_seed(666)
         # eval (default): dropout off, the replayed step can be verified against an eager one.  train_mode: model.train()
         # with the reference's --dropout 0.5 (src/main.py:45, src/models/simulators.py:311): every step draws fresh
@@ -355,7 +361,7 @@ class Step:
         # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
         self.state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
         self.grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
-        self.bucket = [None, None]
+        self.bucket = [None, None, None, 0]
         # backward exchange: 'bucket' = ONE all-reduce of [d/d(state) (N, 6) | weight gradients] (the state gradient
         # travels N/n_own times wider than needed, but it is one latency-bound collective); 'rs' = reduce-scatter of
         # d/d(state) to the owners + all-reduce of the weight gradients (minimum bytes, two collectives)
@@ -381,7 +387,10 @@ class Step:
         acc = self.model(pf, of, self_features)[0]
         with self._deferred():     # the weight-gradient slot sums ride in the relfeat backward's launch
             acc.backward(self.ones)
-        if self.sh is not None:
+        if self.sh is not None and self.p2p is not None:
+            from piml_amd.sharded import allreduce_gradients_p2p
+            allreduce_gradients_p2p(self.params, self.p2p[1])
+        elif self.sh is not None:
             allreduce_gradients(self.params, self.group)
         return acc
 
@@ -411,13 +420,19 @@ class Step:
         grads = [p.grad for p in self.params if p.grad is not None]
         if self.exchange == 'bucket':
             self.bucket[:] = [torch.cat([self.state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
+        elif self.exchange == 'p2p':       # (padded to whole 16-byte stores)
+            n = sum(g.numel() for g in grads)
+            flat = torch.cat([g.reshape(-1) for g in grads] + ([grads[0].new_zeros((-n) % 4)] if n % 4 else []))
+            self.bucket[:] = [flat, grads, torch.empty_like(flat), n]
         else:
             self.bucket[:] = [torch.cat([g.reshape(-1) for g in grads]), grads]
         return acc
 
     def exchange_forward(self):
         from piml_amd.sharded import gather_records_into, gather_records_async
-        if self.pre is not None:                  # started, not awaited: `pre` runs under it (run / capture wait for it)
+        if self.p2p is not None:                  # every rank's block stored into every peer's buffer, copied out in rank order
+            self.p2p[0].exchange(bcast_src=self.state_own.detach().view(-1), out_bcast=self.state_all.detach().view(-1), sum=False)
+        elif self.pre is not None:                  # started, not awaited: `pre` runs under it (run / capture wait for it)
             self.gather_work = gather_records_async(self.state_all, self.state_own, self.b0, self.group)
         else:
             gather_records_into(self.state_all, self.state_own, self.group)
@@ -425,7 +440,14 @@ class Step:
     def exchange_backward(self):
         from piml_amd.sharded import reduce_scatter_grad, unflatten_gradients
         N, b0, n_own = self.N, self.b0, self.n_own
-        if self.exchange == 'bucket':
+        if self.p2p is not None:
+            # ONE launch: the partial d/d(state) rows of every owner's block to THAT owner + this rank's weight-gradient bucket to
+            # everybody, both added in rank order on arrival (the same sums on every rank: bit-reproducible)
+            flat, grads, out, n = self.bucket
+            self.p2p[1].exchange(scatter_src=self.state_all.grad.view(-1), bcast_src=flat, out_scatter=self.grad_own.view(-1),
+                                 out_bcast=out, sum=True)
+            unflatten_gradients(out[:n], grads)
+        elif self.exchange == 'bucket':
             dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
             unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
@@ -452,7 +474,7 @@ class Step:
             p.grad = None
 
     def barrier(self):
-        if self.use_dist:
+        if self.use_dist and self.group is not None:
             dist.barrier(group=self.group)
         torch.cuda.synchronize()
 
@@ -479,12 +501,12 @@ class Step:
             # events inside a captured graph, so the HIP events that time single kernels bracket extra eager
             # launches of them (same inputs, same output buffers) in front of sampled replays.
             graph = torch.cuda.CUDAGraph()
-            if self.use_dist:
+            if self.use_dist and self.p2p is None:
                 self.exchange_forward()
                 torch.cuda.synchronize()
             # the process group's watchdog thread polls the events of finished collectives: under the default 'global'
             # capture mode such a query from another thread invalidates the capture (seen: hipErrorStreamCaptureUnsupported)
-            cap_mode = 'thread_local' if self.use_dist else 'global'
+            cap_mode = 'thread_local' if (self.use_dist and self.group is not None) else 'global'
             if self.overlap:
                 import contextlib
                 pre = torch.cuda.CUDAGraph()
@@ -498,13 +520,17 @@ class Step:
                 self.pre = pre
             else:
                 with torch.cuda.graph(graph, capture_error_mode=cap_mode), self.model.packed_weights():
+                    if self.p2p is not None:      # the exchanges are launches of this library: INSIDE the graph
+                        self.exchange_forward()
                     feats = self.features_local() if self.use_dist else self.features()
                     (self.rest_local if self.use_dist else self.rest)(*feats)
+                    if self.p2p is not None:
+                        self.exchange_backward()
             self.static_feats = feats     # the captured step's feature / index buffers stay alive
             if self.pre is not None:
                 self.pre.replay()
             graph.replay()
-            if self.use_dist:
+            if self.use_dist and self.p2p is None:
                 self.exchange_backward()
             done = torch.cuda.Event()
             done.record()
@@ -521,7 +547,7 @@ class Step:
             print(f'[bench] HIP-graph capture unavailable ({type(ex).__name__}: {ex}); running eagerly',
                   file=sys.stderr)
             ok, self.graph = 0, None
-        if self.use_dist:   # all ranks must run the same mode
+        if self.use_dist and self.group is not None:   # all ranks must run the same mode
             t = torch.tensor([ok], device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
             if int(t.item()) == 0:
@@ -561,6 +587,9 @@ class Step:
     def run(self):
         """One step (exchange + compute), the way the timed region runs it."""
         if self.graph is not None:
+            if self.p2p is not None:              # ONE graph: exchange, compute, exchange
+                self.graph.replay()
+                return
             if self.use_dist:
                 self.exchange_forward()
             if self.pre is not None:
@@ -664,7 +693,7 @@ def main():
     ap.add_argument('--force-dist', type=int, default=0, help='exercise the sharded (RCCL) code path even with one rank')
     ap.add_argument('--two-streams', type=int, default=1, help='obstacle branch of the MLP on a side stream')
     ap.add_argument('--verify', type=int, default=1, help='after the timed region compare the replayed step with an eager autograd step')
-    ap.add_argument('--exchange', choices=('auto', 'bucket', 'rs'), default='auto',
+    ap.add_argument('--exchange', choices=('auto', 'bucket', 'rs', 'p2p'), default='auto',
                     help='backward exchange of the sharded step: one all-reduce of [state gradient | weight gradients] '
                          '(bucket) or reduce-scatter(state gradient) + all-reduce(weight gradients) (rs); auto = the cheaper '
                          'one under choose_exchange()\'s latency + bytes model (the other one is timed after the timed region)')
@@ -764,13 +793,29 @@ def main():
 
     scene, N_padded = pad_scene_np(synthetic_gc_scene(N_real, M, seed=args.seed), world if scaling == 'strong' else 1)
     assert N_padded == N
+    torch.manual_seed(666)
+    n_params = sum(p.numel() for p in getattr(MODEL, 'PINNSF_multitask')(model_args()).parameters())
     if args.exchange == 'auto':
-        torch.manual_seed(666)
-        n_params = sum(p.numel() for p in getattr(MODEL, 'PINNSF_multitask')(model_args()).parameters())
         args.exchange = choose_exchange(N, n_params, world) if use_dist else 'bucket'
         exchange_why = {k: round(exchange_cost_us(k, N, n_params, world), 2) for k in ('bucket', 'rs')}
     else:
         exchange_why = None
+    # the P2P-store exchange objects (receive buffers, flags, device-side step counters; IPC handles through the process group's
+    # object all-gather): made once, used by the main step and by the comparison legs
+    p2p = None
+    if use_dist and (args.exchange == 'p2p' or args.exchange_compare):
+        try:
+            from piml_amd.sharded import p2p_exchanges
+
+            def _all_bytes(b):
+                out = [None] * world
+                dist.all_gather_object(out, b)
+                return out
+            p2p = p2p_exchanges(rank, world, n_own, n_params, _all_bytes)
+        except Exception as ex:   # noqa: BLE001 - only fatal when it is the exchange that was asked for
+            if args.exchange == 'p2p':
+                raise
+            print(f'[bench] P2P exchange unavailable for the comparison leg ({type(ex).__name__}: {ex})', file=sys.stderr)
     # The obstacle branch of the MLP on a side stream makes two GEMM chains run concurrently inside the
     # captured graph.  Concurrent library GEMMs are only safe with kernels that never wait for
     # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some shapes
@@ -781,7 +826,7 @@ def main():
         args.verify = 0
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
               two_streams, bool(args.graph), exchange=args.exchange, overlap=bool(args.overlap),
-              train_mode=bool(args.train_mode), messages=bool(args.messages))
+              train_mode=bool(args.train_mode), messages=bool(args.messages), p2p=p2p)
     M_eff = st.M_eff
 
     if autotune:
@@ -1101,13 +1146,15 @@ def main():
     # ---- the other backward-exchange variant, all ranks, outside the timed region (informational) ----
     exchange_other = None
     if use_dist and args.exchange_compare and (world > 1 or args.force_dist):
-        other = 'rs' if args.exchange == 'bucket' else 'bucket'
         exchange_other = []
-        for exch, ovl in ((other, bool(args.overlap)), (args.exchange, not args.overlap)):
+        legs = [(e, False) for e in ('bucket', 'rs', 'p2p') if e != args.exchange and (e != 'p2p' or p2p is not None)]
+        if args.exchange != 'p2p':
+            legs.append((args.exchange, not args.overlap))
+        for exch, ovl in legs:
             tag = {'exchange': exch, 'overlap': ovl}
             try:
                 alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
-                           exchange=exch, overlap=ovl, messages=bool(args.messages))
+                           exchange=exch, overlap=ovl, messages=bool(args.messages), p2p=p2p)
                 alt.capture()
                 k = max(10, min(args.steps, 50))
                 el = alt.time_steps(k, 5)

@@ -938,6 +938,29 @@ int piml_p2p_export(void* devptr, piml_ipc_handle* out);
 int piml_p2p_open(const piml_ipc_handle* in, void** devptr);
 int piml_p2p_close(void* devptr);
 int piml_p2p_copy(void* dst, const void* src, size_t bytes, void* stream);
+/* The general exchange step, step counter ON THE DEVICE (no argument changes from step to step: the launch sits inside a captured
+ * HIP graph and is replayed with it).  Every rank sends to every receiver r the message [scatter part | broadcast part]:
+ *   scatter part   = scatter_src + r * scatter_floats   (the partial d/d(state) rows of r's agent block: reduce-scatter input)
+ *   broadcast part = bcast_src, bcast_floats floats      (the rank's own records forward, its weight-gradient bucket backward)
+ * into recv_r[parity][rank] (parity = step & 1), raises r's flag, waits for its own `world` flags, then writes
+ *   sum == 0: out_scatter[s * scatter_floats + e] / out_bcast[s * bcast_floats + e] = what sender s sent (all-gather layout);
+ *   sum == 1: out_scatter[e] / out_bcast[e] = the senders' parts added IN RANK ORDER (the same sum on every rank).
+ * An out pointer may be NULL (that part is not wanted).  Every count is a multiple of 4 floats; slot_floats >= scatter_floats +
+ * bcast_floats is the capacity of one (parity, sender) slot of the receive buffers (piml_p2p_alloc(2 * world * slot_floats * 4)).
+ * ctr: 2 + world dwords of device memory the host zeroed ONCE (ctr[0] = completed steps).  status: a device int the host zeroed;
+ * STICKY -- once a wait ran out (spin_limit rounds of ~4 us, 0: ~0.5 s) it is 1 and every later step returns at once, on this
+ * rank; the exchange is dead until the hosts rebuild it.  Reference: none (nn.DataParallel, src/models/simulators.py:64-67). */
+typedef struct piml_p2p_msg {
+    const float* scatter_src;
+    size_t scatter_floats;
+    const float* bcast_src;
+    size_t bcast_floats;
+    float* out_scatter;
+    float* out_bcast;
+    int sum;
+} piml_p2p_msg;
+int piml_p2p_exchange(const piml_p2p_msg* msg, int rank, int world, float* const* peer_recv, unsigned* const* peer_flags,
+                      size_t slot_floats, unsigned* ctr, unsigned spin_limit, int* status, void* stream);
 int piml_allgather_state_p2p(const float* own, size_t floats_per_rank, int rank, int world, float* const* peer_recv,
                              unsigned* const* peer_flags, unsigned seq, unsigned spin_limit, int* status, void* stream);
 

@@ -191,6 +191,15 @@ SIGNATURES = {
 }
 
 
+class P2PMsg(ctypes.Structure):
+    """piml_p2p_msg (include/piml_hip.h)."""
+    _fields_ = [('scatter_src', _p), ('scatter_floats', _z), ('bcast_src', _p), ('bcast_floats', _z),
+                ('out_scatter', _p), ('out_bcast', _p), ('sum', _i)]
+
+
+SIGNATURES['piml_p2p_exchange'] = [ctypes.POINTER(P2PMsg), _i, _i, ctypes.POINTER(_p), ctypes.POINTER(_p), _z, _p, ctypes.c_uint, _p, _p]
+
+
 class PimlHipError(RuntimeError):
     pass
 

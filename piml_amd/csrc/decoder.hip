@@ -1506,7 +1506,7 @@ static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, voi
 PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, true, stream); }
 // `packed` already holds the operand images of these weights (piml_pinnsf_pack / an earlier piml_rowdecoder_fwd)
 PIML_API int piml_rowdecoder_fwd_packed(const piml_decoder_branch* br, int nbr, void* stream) {
-    if (int e = pending_pack_flush()) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
+    if (int e = pending_pack_flush(as_stream(stream))) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
     return rowdecoder_fwd(br, nbr, false, stream);
 }
 

@@ -891,6 +891,8 @@ static int g_f3_dw3 = !(getenv("PIML_ENC_FUSED_DW3") && atoi(getenv("PIML_ENC_FU
 // PIML_ENC_DX_SPLIT=f32: the few-rows dX chain on the f32 matrix instruction even with split products elsewhere (A/B)
 static const bool g_dx_split_f32 = getenv("PIML_ENC_DX_SPLIT") && getenv("PIML_ENC_DX_SPLIT")[0] == 'f';
 
+bool piml::enc_f32_images_needed() { return !g_x3 || g_dx_split_f32; }
+
 // h1 may be absent (all branches) exactly when the backward runs without it: the dX chain on sign bits (relu_mask, more than
 // piml_encoder_split_tiles() tiles, split products) and the weight gradients on the layer-split kernel, which recomputes it
 static int enc_bwd_check(const piml_encoder_branch* br, int nbr) {
@@ -1248,7 +1250,7 @@ PIML_API int piml_encoder_fwd(const piml_encoder_branch* br, int nbr, void* stre
 
 // `packed` already holds the operand images of these weights (piml_encoder_pack / piml_pinnsf_pack)
 PIML_API int piml_encoder_fwd_packed(const piml_encoder_branch* br, int nbr, void* stream) {
-    if (int e = pending_pack_flush()) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
+    if (int e = pending_pack_flush(as_stream(stream))) return e;          // a deferred pack (PIML_DEFER_PACK) nobody took: now
     return enc_stage_fwd(br, nbr, as_stream(stream));
 }
 

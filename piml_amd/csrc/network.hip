@@ -176,7 +176,10 @@ PendingPack* pending_pack_entry() {
 }
 }  // namespace
 
-int pending_pack_flush() {
+// consumer: the stream of the launch that is about to read the images (nullptr: unknown -- the stream the pack was left on).  A
+// pack left on another stream than its consumer's runs on the CONSUMER's stream: there it is ordered in front of the reader
+// (and inside the same capture), which the stream it was left on does not promise.
+int pending_pack_flush(hipStream_t consumer) {
     PendingPack* P = pending_pack_entry();
     if (!P) return hipErrorInvalidDevice;
     PackAll A;
@@ -186,11 +189,11 @@ int pending_pack_flush() {
         if (!P->valid) return hipSuccess;
         A = P->A; s = P->stream; P->valid = false;
     }
-    return launch_pack(A, s);
+    return launch_pack(A, consumer ? consumer : s);
 }
 
 int pending_pack_leave(const PackAll& A, hipStream_t s) {
-    if (int e = pending_pack_flush()) return e;
+    if (int e = pending_pack_flush(nullptr)) return e;
     PendingPack* P = pending_pack_entry();
     if (!P) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_mu);
@@ -259,6 +262,7 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
     PackAll A = {};
     A.nbr = nbr;
     A.has_head = head != nullptr;
+    A.skip_f32 = enc_f32_images_needed() ? 0 : 1;
     for (int i = 0; i < nbr; ++i) {
         const piml_encoder_branch& e = enc[i];
         const piml_decoder_branch& d = dec[i];
@@ -285,7 +289,7 @@ PIML_API int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder
     return launch_pack(A, as_stream(stream));
 }
 
-PIML_API int piml_pinnsf_pack_flush(void) { return pending_pack_flush(); }
+PIML_API int piml_pinnsf_pack_flush(void) { return pending_pack_flush(nullptr); }
 
 // every slot sum of the backward pass (encoder + decoder partials) in one launch on `s`
 static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr, hipStream_t s, bool accumulate, bool defer = false,
@@ -332,7 +336,7 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
                              int flags, void* stream) {
     hipStream_t m = as_stream(stream);
     const bool pack = !(flags & PIML_PACKED_VALID);
-    PIML_TRY(pending_pack_flush());          // a deferred pack nobody took: now (no-op otherwise)
+    PIML_TRY(pending_pack_flush(m));         // a deferred pack nobody took: now, in front of this call's launches (no-op otherwise)
     if (flags & PIML_POOL_TRAIN) {            // training on the agents' sums of h2 (see the header)
         if ((flags & (PIML_FORK | PIML_POOL_H2)) || !enc_pool_train_ok(enc, nbr)) return hipErrorInvalidValue;
         for (int i = 0; i < nbr; ++i)

@@ -56,22 +56,39 @@ struct PackAll {
     piml_collision_head head;
     int nbr, has_head;
     int has_fold;         // a decoder branch or the head carries fold_w3: nbr + has_head fold sets ride behind the image sets
+    int skip_f32;         // the encoders' f32-instruction fragment images (4 x 16384 floats per branch) are not written: every
+                          // kernel the library would launch reads the split-product images (piml_encoder_products(1), the default)
 };
-constexpr int kPackMax = PACK_FLOATS > DEC_PACK ? (PACK_FLOATS > HEAD_PACK ? PACK_FLOATS : HEAD_PACK) : (DEC_PACK > HEAD_PACK ? DEC_PACK : HEAD_PACK);
-
-// element e of image set y (encoder branches, decoder branches, head)
-__device__ __forceinline__ void pack_element(const PackAll& A, int y, int e) {
-    if (y < A.nbr) {
-        const piml_encoder_branch& J = A.enc[y];
-        if (e < PACK_FLOATS) J.packed[e] = pack_value(J, e);
-    } else if (y < 2 * A.nbr) {
-        const piml_decoder_branch& J = A.dec[y - A.nbr];
-        if (e < DEC_PACK_PLAIN) J.packed[e] = dec_pack_value(J, e);
-    } else if (e < HEAD_PACK_PLAIN) {
-        A.head.packed[e] = head_pack_value(A.head, e);
-    }
+// live elements of an encoder set: with skip_f32 the two f32 fragment blocks [0, 32768) and [PACK_FWD, PACK_FWD + 32768) are left out
+constexpr int ENC_LIVE_X3 = PACK_FLOATS - 2 * 32768;
+__host__ __device__ inline int enc_set_elems(const PackAll& A) { return A.skip_f32 ? ENC_LIVE_X3 : PACK_FLOATS; }
+__host__ __device__ inline int pack_elems_total(const PackAll& A) {
+    return A.nbr * (enc_set_elems(A) + DEC_PACK_PLAIN) + (A.has_head ? HEAD_PACK_PLAIN : 0);
 }
-__host__ __device__ inline int pack_sets(const PackAll& A) { return 2 * A.nbr + (A.has_head ? 1 : 0); }
+
+// element t of the concatenated image sets (encoder branches, decoder branches, head)
+__device__ __forceinline__ void pack_flat(const PackAll& A, int t) {
+    const int ne = enc_set_elems(A);
+    for (int y = 0; y < A.nbr; ++y) {
+        if (t < ne) {
+            int e = t;
+            if (A.skip_f32) e = t < PACK_FWD - 32768 ? t + 32768 : t + 2 * 32768;      // [32768, PACK_FWD) | [PACK_FWD + 32768, PACK_FLOATS)
+            const piml_encoder_branch& J = A.enc[y];
+            J.packed[e] = pack_value(J, e);
+            return;
+        }
+        t -= ne;
+    }
+    for (int y = 0; y < A.nbr; ++y) {
+        if (t < DEC_PACK_PLAIN) {
+            const piml_decoder_branch& J = A.dec[y];
+            J.packed[t] = dec_pack_value(J, t);
+            return;
+        }
+        t -= DEC_PACK_PLAIN;
+    }
+    if (A.has_head && t < HEAD_PACK_PLAIN) A.head.packed[t] = head_pack_value(A.head, t);
+}
 __host__ __device__ inline int fold_sets(const PackAll& A) { return A.has_fold ? A.nbr + (A.has_head ? 1 : 0) : 0; }
 // the folded images (pack.hpp): a workgroup of `threads` threads takes (threads / 64) / CH groups, CH = 8 waves per group (4 for
 // 256 threads)
@@ -106,21 +123,28 @@ __device__ __forceinline__ void fold_block(const PackAll& A, int fb, int threads
         else dec_fold_store(J, i, hc, lane, sum);
     }
 }
-// the pack as trailing workgroups of another launch: `threads` threads per workgroup, workgroup `bid` of pack_blocks(...)
+// the pack as trailing workgroups of another launch: `threads` threads per workgroup, kPackPerThread elements per thread (a
+// thread's elements are `threads` apart: coalesced stores, independent gathers in flight together; fewer, fatter workgroups
+// -- 1 100 workgroups of one element per thread cost the relfeat forward 4 us of tail), then the fold workgroups
+constexpr int kPackPerThread = 4;
 struct PackWork {
     PackAll A;
     int first_block;          // blockIdx.x of the first pack workgroup; < 0: no pack rides in this launch
 };
-__host__ __device__ inline int pack_blocks_per_set(int threads) { return (kPackMax + threads - 1) / threads; }
-__host__ __device__ inline int pack_blocks_total(const PackAll& A, int threads) {
-    return pack_blocks_per_set(threads) * pack_sets(A) + fold_blocks(A, threads);
+__host__ __device__ inline int pack_plain_blocks(const PackAll& A, int threads) {
+    return (pack_elems_total(A) + threads * kPackPerThread - 1) / (threads * kPackPerThread);
 }
+__host__ __device__ inline int pack_blocks_total(const PackAll& A, int threads) { return pack_plain_blocks(A, threads) + fold_blocks(A, threads); }
 // red: `threads` doubles of LDS (the folded images' partial sums); the whole workgroup calls this
 __device__ __forceinline__ void pack_block(const PackAll& A, int bid, int threads, double* red) {
-    const int per = pack_blocks_per_set(threads), plain = per * pack_sets(A);
+    const int plain = pack_plain_blocks(A, threads);
     if (bid < plain) {
-        const int y = bid / per, x = bid - y * per;
-        pack_element(A, y, x * threads + (int)threadIdx.x);
+        const int total = pack_elems_total(A);
+#pragma unroll
+        for (int j = 0; j < kPackPerThread; ++j) {
+            const int t = (bid * kPackPerThread + j) * threads + (int)threadIdx.x;
+            if (t < total) pack_flat(A, t);
+        }
     } else if (threads >= 512) {
         fold_block<8>(A, bid - plain, threads, red);
     } else {
@@ -130,7 +154,7 @@ __device__ __forceinline__ void pack_block(const PackAll& A, int bid, int thread
 int launch_pack(const PackAll& A, hipStream_t s);
 int pending_pack_leave(const PackAll& A, hipStream_t s);
 bool pending_pack_take(hipStream_t s, PackAll* out);
-int pending_pack_flush();
+int pending_pack_flush(hipStream_t consumer);
 
 int launch_slot_sums(const ReduceAll& R, hipStream_t s);          // the stand-alone launch (pinnsf_reduce_kernel)
 // deferred sums of the current device: leave (a second deferral first launches the one already waiting, on ITS stream),

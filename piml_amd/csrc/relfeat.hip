@@ -524,14 +524,39 @@ __global__ __launch_bounds__(256) void relfeat_bwd_kernel(
 __global__ __launch_bounds__(256) void relfeat_bwd_reduce_kernel(
         const ReduceAll R, int nred, const float* __restrict__ g_ped, const float* __restrict__ g_obs,
         const float2* __restrict__ g_destf, const int* __restrict__ ped_idx, const int* __restrict__ obs_idx,
-        const float* __restrict__ p, const float2* __restrict__ dest, int N, int f0, int fcnt, int kpe, int koe, float* g_state,
-        float2* g_dest, float* __restrict__ g_speed) {
+        const float* __restrict__ p, int ld, const float2* __restrict__ dest, int C, int N, int f0, int fcnt, int kpe, int koe,
+        float* g_state, float2* g_dest, float* __restrict__ g_speed) {
     if ((int)blockIdx.x < nred) {
         reduce_block(R, (int)blockIdx.x);
         return;
     }
-    relfeat_bwd_rows((int)blockIdx.x - nred, g_ped, g_obs, g_destf, ped_idx, obs_idx, p, 6, dest, 1, N, f0, fcnt, kpe, koe, g_state,
+    relfeat_bwd_rows((int)blockIdx.x - nred, g_ped, g_obs, g_destf, ped_idx, obs_idx, p, ld, dest, C, N, f0, fcnt, kpe, koe, g_state,
                      g_dest, 7, g_speed);
+}
+
+// the relfeat backward over d/d(self_features) rows (gld = 7), carrying the slot sums a piml_pinnsf_bwd(PIML_DEFER_SLOT_SUMS) left on
+// this stream as its leading workgroups (and the unfold of PIML_POOL_TRAIN behind them)
+static int relfeat_bwd_self_launch(const float* g_ped_feat, const float* g_obs_feat, const float* g_self, const int* ped_idx,
+                                   const int* obs_idx, const float* position, int state_ld, const float* destination, int C, int N,
+                                   int focal_begin, int focal_count, int kp_eff, int ko_eff, float* g_state, float* g_destination,
+                                   float* g_speed, void* stream) {
+    const long rows = (long)C * focal_count;
+    ReduceAll R;
+    if (pending_slot_sums_take(as_stream(stream), &R)) {
+        const int nred = R.gx * R.nsets;
+        hipLaunchKernelGGL(relfeat_bwd_reduce_kernel, dim3((unsigned)(nred + (rows + 3) / 4)), dim3(256), 0, as_stream(stream),
+                           R, nred, g_ped_feat, g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, position, state_ld,
+                           (const float2*)destination, C, N, focal_begin, focal_count, kp_eff, ko_eff, g_state,
+                           (float2*)g_destination, g_speed);
+        trace_mark("relfeat_bwd", as_stream(stream));
+        if (R.nunf > 0) return launch_unfold(R, as_stream(stream));
+    } else {
+        hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
+                           g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, position, state_ld, (const float2*)destination, C, N,
+                           focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
+        trace_mark("relfeat_bwd", as_stream(stream));
+    }
+    return hipGetLastError();
 }
 
 // Deterministic variant of relfeat_bwd (no atomics, bit-reproducible): one thread per (source agent, component).
@@ -760,11 +785,8 @@ PIML_API int piml_relfeat_bwd_self(const float* g_ped_feat, const float* g_obs_f
     if (!g_self || !position || !destination || !g_state || !g_destination || (kp_eff > 0 && (!g_ped_feat || !ped_idx)) ||
         (ko_eff > 0 && (!g_obs_feat || !obs_idx)))
         return hipErrorInvalidValue;
-    const long rows = (long)C * focal_count;
-    hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat, g_obs_feat,
-                       (const float2*)g_self, ped_idx, obs_idx, position, state_ld, (const float2*)destination, C, N, focal_begin,
-                       focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
-    return hipGetLastError();
+    return relfeat_bwd_self_launch(g_ped_feat, g_obs_feat, g_self, ped_idx, obs_idx, position, state_ld, destination, C, N, focal_begin,
+                                   focal_count, kp_eff, ko_eff, g_state, g_destination, g_speed, stream);
 }
 
 // piml_relfeat_fwd that also advances a device-side frame counter by one (the captured inference-rollout frame ends with
@@ -827,24 +849,8 @@ PIML_API int piml_relfeat_self_bwd(const float* g_ped_feat, const float* g_obs_f
     if (!g_self || !state || !destination_rows || !g_state || !g_destination || (kp_eff > 0 && (!g_ped_feat || !ped_idx)) ||
         (ko_eff > 0 && (!g_obs_feat || !obs_idx)))
         return hipErrorInvalidValue;
-    ReduceAll R;
-    if (pending_slot_sums_take(as_stream(stream), &R)) {       // slot sums left by piml_pinnsf_bwd(PIML_DEFER_SLOT_SUMS) on this stream
-        const int nred = R.gx * R.nsets;
-        hipLaunchKernelGGL(relfeat_bwd_reduce_kernel, dim3((unsigned)(nred + (focal_count + 3) / 4)), dim3(256), 0, as_stream(stream),
-                           R, nred, g_ped_feat, g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state,
-                           (const float2*)destination_rows, N, focal_begin, focal_count, kp_eff, ko_eff, g_state,
-                           (float2*)g_destination, g_speed);
-        if (R.nunf > 0) {                      // PIML_POOL_TRAIN: the folded layers' gradients -> their factors' (network.hip)
-            trace_mark("relfeat_bwd", as_stream(stream));
-            return launch_unfold(R, as_stream(stream));
-        }
-    } else {
-        hipLaunchKernelGGL(relfeat_bwd_kernel, dim3((unsigned)((focal_count + 3) / 4)), dim3(256), 0, as_stream(stream), g_ped_feat,
-                           g_obs_feat, (const float2*)g_self, ped_idx, obs_idx, state, 6, (const float2*)destination_rows, 1, N,
-                           focal_begin, focal_count, kp_eff, ko_eff, g_state, (float2*)g_destination, 7, g_speed);
-    }
-    trace_mark("relfeat_bwd", as_stream(stream));
-    return hipGetLastError();
+    return relfeat_bwd_self_launch(g_ped_feat, g_obs_feat, g_self, ped_idx, obs_idx, state, 6, destination_rows, 1, N, focal_begin,
+                                   focal_count, kp_eff, ko_eff, g_state, g_destination, g_speed, stream);
 }
 
 PIML_API int piml_relfeat_bwd(const float* g_ped_feat, const float* g_obs_feat, const float* g_dest_feat,

@@ -9,6 +9,8 @@
 namespace piml {
 
 int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
+// false: no kernel the current settings dispatch reads the f32-instruction fragment images of `packed` (split products everywhere)
+bool enc_f32_images_needed();
 // packed image must be current; `zero` (optional): zero_n floats cleared by the launch
 int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
 // PIML_POOL_H2 (inference): the forward up to layer 2 and the agents' sums of h2 into `msgs` / `h2`, both (agents, 128)

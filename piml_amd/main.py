@@ -96,7 +96,8 @@ def set_exp_configs(args):
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(args.seed)
         from . import ops
-        ops.dropout_seed(args.seed)      # the fused kernels' own draw counter back to 0 (a repeated seed does not rewind it by itself)
+        # the fused kernels' own draw counter back to 0 (a repeated seed does not rewind it by itself), on the run's device
+        ops.dropout_seed(args.seed, getattr(args, 'device', None) if str(getattr(args, 'device', '')).startswith('cuda') else None)
 
 
 LAST_RUN = {}      # the objects of the most recent main() call (tests / notebooks): simulator, histories, args

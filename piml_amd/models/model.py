@@ -546,6 +546,12 @@ class _PINNSFBase(nn.Module):
         finally:
             self._packs.active = False
             self._ph2 = None            # the folded inference weights belong to this block's weights
+            if getattr(self._packs, 'pending_structs', None) is not None:
+                # a deferred pack no forward pass took (PIML_DEFER_PACK): run it now rather than leave raw weight pointers
+                # with the library beyond the block (no-op when it has run)
+                from .. import _lib
+                _lib.check(_lib.lib().piml_pinnsf_pack_flush(), 'piml_pinnsf_pack_flush')
+                self._packs.pending_structs = None
 
     def forward(self, ped_features, obs_features, self_features):
         assert (self_features.shape[-1] == 7), 'Error: PINN model do not accept inputs of historical velocity'

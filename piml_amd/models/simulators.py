@@ -90,6 +90,12 @@ class BaseSimulator(Pedestrians):
             raise NotImplementedError(f'{args.model}: only the PINNSF family is on the accelerated path')
         net = MODEL.MODEL_TABLE[args.model][1 if finetune else 0](args)
         net.fix_dest_norm = bool(getattr(args, 'fix_dest_norm', False))      # --fix_dest_norm (quirk Q2 off)
+        # this class's loops read predictions[1] (the pedestrian messages) only for the L1 regulariser and the PINN-loss
+        # pre-training target (:345-347, :339-341, :735-737), never predictions[2]: without those the `pinnsf` / `pinnsf_m`
+        # networks may run on the agents' sums of h2 (model.messages_wanted, PIML_POOL_TRAIN: large scenes, no active dropout)
+        if hasattr(net, 'messages_wanted'):
+            net.messages_wanted = bool(getattr(args, 'reg_weight', 0.0) > 0 or getattr(args, 'pinnsf_interaction', 'sim') != 'sim'
+                                       or getattr(args, 'messages_wanted', False))
         return net.to(args.device)
 
     def set_model(self, args):
@@ -699,7 +705,9 @@ class BaseSimulator(Pedestrians):
 
             def one_step():
                 self.optimizer.zero_grad(set_to_none=True)
-                with self._grad_sink.step():      # the frames' weight gradients summed inside the slot-sum launches
+                # the frames' weight gradients summed inside the slot-sum launches (the sink), and those launches riding as the
+                # leading workgroups of each frame's relfeat backward (ops.deferred_slot_sums: one launch less per frame)
+                with self._grad_sink.step(), ops.deferred_slot_sums():
                     out, aux = self._training_rollout(static)
                     out[0].backward()
                 self.optimizer.step()

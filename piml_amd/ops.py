@@ -1030,7 +1030,7 @@ class _PinnsfEpilogueKsum(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         if g is None:
-            return (None,) * 4
+            return (None,) * 5
         (sf,) = ctx.saved_tensors
         tau, kp, ko, shp_p, shp_o = ctx.meta
         g = g.contiguous()
@@ -1470,6 +1470,7 @@ def scale_ksum(e, scale=2.0, bias=None, keep_bits=None):
 # draws a fresh mask on every replay.
 # ------------------------------------------------------------------------------------------------
 _DROPOUT_STATE = {}        # device index -> [state tensor (4 x int64: seed, offset, ticket, 0), torch's CUDA seed seen last]
+_DROPOUT_RANK_MIX = {}     # device index -> the rank term dropout_seed folded into the seed (re-applied on automatic re-seeds)
 
 
 def dropout_state(device, seed=None):
@@ -1485,7 +1486,9 @@ def dropout_state(device, seed=None):
     if ent is None and capturing:
         raise _lib.PimlHipError('dropout_state: first use inside a stream capture (call ops.dropout_state(device) before)')
     if ent is None or ((seed is not None or ent[1] != torch_seed) and not capturing):
-        want = int(seed) if seed is not None else torch_seed
+        # (an automatic re-seed from torch's seed keeps the rank term of an earlier dropout_seed: the ranks of a sharded run
+        # must not fall back to identical masks when somebody calls torch.manual_seed again)
+        want = int(seed) if seed is not None else (torch_seed + _DROPOUT_RANK_MIX.get(idx, 0)) & ((1 << 64) - 1)
         signed = want - (1 << 64) if want >= (1 << 63) else want
         st = torch.tensor([signed, 0, 0, 0], dtype=torch.int64, device=device)
         if ent is None:
@@ -1506,7 +1509,9 @@ def dropout_seed(seed, device=None, rank=None):
     if rank is None:
         import torch.distributed as dist
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    mixed = (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & ((1 << 64) - 1)
+    mix = (0x9E3779B97F4A7C15 * int(rank)) & ((1 << 64) - 1)
+    _DROPOUT_RANK_MIX[device.index if device.index is not None else torch.cuda.current_device()] = mix
+    mixed = (int(seed) + mix) & ((1 << 64) - 1)
     return dropout_state(device, seed=mixed)
 
 
@@ -2229,6 +2234,8 @@ class ParamGradSink:
 
 _DEFER_DEPTH = 0
 _DEFER_KEEP = []        # the slot buffers deferred sums will read: alive until those sums have been launched
+_DEFER_SEEN = set()     # id(parameter) of every parameter that was handed a deferred gradient inside the open block
+_DEFER_DEVS = set()     # devices a deferral was left on (the flush at the block's exit visits each of them)
 
 
 class deferred_slot_sums:
@@ -2249,15 +2256,44 @@ class deferred_slot_sums:
         global _DEFER_DEPTH
         _DEFER_DEPTH -= 1
         if _DEFER_DEPTH == 0:
-            _lib.check(_lib.lib().piml_pinnsf_slot_sums_flush(), 'piml_pinnsf_slot_sums_flush')
-            _DEFER_KEEP.clear()
+            _flush_deferred_sums()
+            _DEFER_SEEN.clear()
         return False
 
 
-def _defer_slot_sums(params, sink):
+def _flush_deferred_sums():
+    """launch whatever sums are still waiting, on every device a deferral was left on (the library keeps one entry per device
+    and flushes the CURRENT device's)"""
+    for dev in list(_DEFER_DEVS) or [None]:
+        with (torch.cuda.device(dev) if dev is not None else contextlib.nullcontext()):
+            _lib.check(_lib.lib().piml_pinnsf_slot_sums_flush(), 'piml_pinnsf_slot_sums_flush')
+    _DEFER_DEVS.clear()
+    _DEFER_KEEP.clear()
+
+
+def _defer_slot_sums(params, sink, dev=None):
+    """May this backward pass leave its slot sums to the relfeat backward's launch?  Autograd is handed gradient buffers whose
+    sums have not run yet, which is only sound while nobody reads them before the block's next launch on the stream:
+      * a ParamGradSink owns the buffers (autograd sees no weight gradients at all): yes;
+      * otherwise every parameter must be without a .grad (AccumulateGrad then keeps the buffer it is handed -- a view object
+        nobody else holds -- instead of adding to it), without tensor / post-accumulate hooks (they would read it), and must not
+        have been handed a deferred gradient by an EARLIER node of this block (the engine adds two nodes' gradients for one
+        parameter as soon as the second arrives).
+    When the answer is no inside an open block, the sums still waiting are launched first: a buffer of an earlier node may be
+    about to be read."""
     if _DEFER_DEPTH <= 0 or FORK_NETWORK or _os.environ.get('PIML_DEFER_SLOT_SUMS', '1') == '0':
         return False
-    return sink is not None or all(getattr(p, 'grad', None) is None for p in params)
+    ok = sink is not None
+    if not ok:
+        ok = all(getattr(p, 'grad', None) is None and id(p) not in _DEFER_SEEN and not getattr(p, '_backward_hooks', None)
+                 and not getattr(p, '_post_accumulate_grad_hooks', None) for p in params)
+        if ok:
+            _DEFER_SEEN.update(id(p) for p in params)
+    if ok:
+        _DEFER_DEVS.add(dev)
+    else:
+        _flush_deferred_sums()
+    return ok
 
 
 class _FusedPinnsf(torch.autograd.Function):
@@ -2459,7 +2495,7 @@ class _FusedPinnsf(torch.autograd.Function):
                     dstructs.append(_dec_branch_struct(msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b],
                                                        gp2, gp1, g_pooled[b], dparts[b], dflats[b]))
                 darr = (_lib.DecoderBranch * nbr)(*dstructs)
-                if len(live) == nbr and _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink):
+                if len(live) == nbr and _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink, dev):
                     flags |= _lib.DEFER_SLOT_SUMS
                     _DEFER_KEEP[:] = [parts, dparts]       # (a second deferral launches the sums waiting so far: their buffers may go)
                 _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags,
@@ -2550,7 +2586,7 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
                                                g_pooled[b], dparts[b], dflats[b], fold=(ewb[b][4], ewb[b][5], scales[b]), dw1_out=dw1[b]))
         darr = (_lib.DecoderBranch * nbr)(*dstructs)
         flags = _lib.POOL_TRAIN
-        if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], None):
+        if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], None, dev):
             flags |= _lib.DEFER_SLOT_SUMS
             _DEFER_KEEP[:] = [parts, dparts, dflats, flats, dw1]
         _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags, _stream()), 'piml_pinnsf_bwd')

@@ -8,6 +8,7 @@ device pointer into the receive buffer (`gathered_ptr`), or a torch tensor throu
 The reference has no multi-process path at all (nn.DataParallel, src/models/simulators.py:64-67); the default exchange of
 this package is the RCCL all-gather (piml_amd/sharded.py)."""
 import ctypes
+import os
 
 import torch
 
@@ -29,6 +30,8 @@ class P2PExchange:
         self._opened = []
         self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
         self.seq = 0
+        # the general exchange (`exchange`): step counter and workgroup counters on the device, zeroed once
+        self.ctr = torch.zeros(2 + world, dtype=torch.int32, device='cuda')
 
     def handles(self):
         """(recv handle, flags handle) as bytes, for the peers."""
@@ -59,6 +62,49 @@ class P2PExchange:
                                               self.seq, spin_limit, self.status.data_ptr(), torch.cuda.current_stream().cuda_stream),
                    'piml_allgather_state_p2p')
         return self.gathered_ptr()
+
+    def exchange(self, scatter_src=None, bcast_src=None, out_scatter=None, out_bcast=None, sum=False, spin_limit=0):
+        """One step of the general exchange (piml_p2p_exchange: device-side step counter, capturable into a HIP graph) on the
+        current stream.  scatter_src: (world * n_s) floats, receiver r gets block r; bcast_src: n_b floats for every receiver;
+        n_s + n_b <= floats_per_rank (the slot size given to the constructor).  sum=False: out_scatter (world * n_s) / out_bcast
+        (world * n_b) receive the senders' parts in rank order; sum=True: out_scatter (n_s) / out_bcast (n_b) their sums in rank
+        order.  `ok()` (synchronising) tells whether every peer arrived; after a time-out the exchange stays dead."""
+        def flat(t, name, n=None):
+            if t is None:
+                return None
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError(f'P2PExchange.exchange: {name} must be a contiguous float32 GPU tensor')
+            if n is not None and t.numel() != n:
+                raise ValueError(f'P2PExchange.exchange: {name} has {t.numel()} elements, expected {n}')
+            return t
+        ns = 0 if scatter_src is None else flat(scatter_src, 'scatter_src').numel() // self.world
+        nb = 0 if bcast_src is None else flat(bcast_src, 'bcast_src').numel()
+        if scatter_src is not None and scatter_src.numel() != ns * self.world:
+            raise ValueError('P2PExchange.exchange: scatter_src must hold one block per rank')
+        mult = 1 if sum else self.world
+        flat(out_scatter, 'out_scatter', ns * mult if out_scatter is not None else None)
+        flat(out_bcast, 'out_bcast', nb * mult if out_bcast is not None else None)
+        if ns % 4 or nb % 4 or ns + nb == 0 or ns + nb > self.fpr:
+            raise ValueError(f'P2PExchange.exchange: parts of {ns} + {nb} floats (multiples of 4) must fit the slot of {self.fpr}')
+        m = _lib.P2PMsg()
+        m.scatter_src, m.scatter_floats = (scatter_src.data_ptr() if ns else None), ns
+        m.bcast_src, m.bcast_floats = (bcast_src.data_ptr() if nb else None), nb
+        m.out_scatter = out_scatter.data_ptr() if out_scatter is not None else None
+        m.out_bcast = out_bcast.data_ptr() if out_bcast is not None else None
+        m.sum = 1 if sum else 0
+        if not spin_limit:      # PIML_P2P_SPIN_LIMIT: rounds of ~4 us a wait may take (default ~0.5 s; hosts whose ranks start far apart raise it)
+            spin_limit = int(os.environ.get('PIML_P2P_SPIN_LIMIT', '0'))
+        _lib.check(_lib.lib().piml_p2p_exchange(ctypes.byref(m), self.rank, self.world, self._peer_recv, self._peer_flags, self.fpr,
+                                                self.ctr.data_ptr(), int(spin_limit), self.status.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), 'piml_p2p_exchange')
+
+    def connect_all(self, exchange_bytes):
+        """Open every peer's buffers.  exchange_bytes(own: bytes) -> list of every rank's bytes in rank order (e.g. a
+        torch.distributed all_gather_object, or pipes between the processes)."""
+        mine = b''.join(self.handles())
+        for peer, raw in enumerate(exchange_bytes(mine)):
+            if peer != self.rank:
+                self.connect(peer, (raw[:64], raw[64:128]))
 
     def gathered_ptr(self):
         return self._recv.value + (self.seq & 1) * self.world * self.fpr * 4

@@ -105,6 +105,55 @@ class _AllGatherRecordsAsync(torch.autograd.Function):
         return _AllGatherRecords.backward(ctx, g_full) + (None,)
 
 
+class _AllGatherRecordsP2P(torch.autograd.Function):
+    """_AllGatherRecords on the P2P-store exchange (piml_amd/p2p.py, include/piml_hip.h: piml_p2p_exchange): forward = every
+    rank's block stored into every peer's receive buffer and copied out in rank order; backward = the partial gradients of
+    every owner's block stored into THAT owner's buffer and added there in rank order.  No collective library, and both
+    launches are capturable (the step counter lives on the device)."""
+
+    @staticmethod
+    def forward(ctx, own, ex_fwd, ex_bwd):
+        own = own.contiguous()
+        full = torch.empty((ex_fwd.world * own.shape[0],) + tuple(own.shape[1:]), device=own.device, dtype=own.dtype)
+        ex_fwd.exchange(bcast_src=own.reshape(-1), out_bcast=full.view(-1), sum=False)
+        ctx.ex_bwd, ctx.own_shape = ex_bwd, tuple(own.shape)
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        g_own = torch.empty(ctx.own_shape, device=g_full.device, dtype=g_full.dtype)
+        ctx.ex_bwd.exchange(scatter_src=g_full.contiguous().view(-1), out_scatter=g_own.view(-1), sum=True)
+        return g_own, None, None
+
+
+def p2p_exchanges(rank, world, n_own, n_params, all_gather_bytes):
+    """(forward, backward) P2PExchange pair of one rank of an agent-block sharded step: the forward slot holds a rank's block of
+    records (n_own x 6 floats), the backward slot a block of state gradients + the weight-gradient bucket.
+    all_gather_bytes(own: bytes) -> every rank's bytes in rank order (torch.distributed.all_gather_object, pipes, ...)."""
+    from .p2p import P2PExchange
+    pad4 = lambda n: (n + 3) // 4 * 4
+    fwd = P2PExchange(rank, world, pad4(n_own * 6))
+    bwd = P2PExchange(rank, world, pad4(n_own * 6) + pad4(n_params))
+    if world > 1:
+        fwd.connect_all(all_gather_bytes)
+        bwd.connect_all(all_gather_bytes)
+    return fwd, bwd
+
+
+def allreduce_gradients_p2p(parameters, ex):
+    """allreduce_gradients on the P2P-store exchange: every rank's bucket to every peer, added in rank order (the same sum on
+    every rank)."""
+    flat, grads = flatten_gradients(parameters)
+    if flat is None:
+        return
+    pad = (-flat.numel()) % 4
+    if pad:
+        flat = torch.cat((flat, flat.new_zeros(pad)))
+    out = torch.empty_like(flat)
+    ex.exchange(bcast_src=flat, out_bcast=out, sum=True)
+    unflatten_gradients(out[:out.numel() - pad] if pad else out, grads)
+
+
 def gather_records_into(full, own, group=None):
     """Plain (non-autograd) all-gather into a caller-owned (N, w) buffer.  With `reduce_scatter_grad`
     this is the exchange pair for steps whose compute part is replayed from a captured HIP graph: the
@@ -180,13 +229,19 @@ class ShardedScene:
     the collectives with the gloo backend.
     """
 
-    def __init__(self, n_total, obstacles, group=None, feature_fn=None, force_collectives=False, **feature_params):
+    def __init__(self, n_total, obstacles, group=None, feature_fn=None, force_collectives=False, exchange='rccl', p2p=None,
+                 **feature_params):
         # force_collectives: issue the all-gather / reduce-scatter even in a 1-rank group (exercises the RCCL
         # code path on a single GPU; tests/test_sharded_gpu.py, bench.py --force-dist)
+        # exchange='p2p' with p2p = (forward, backward) P2PExchange objects (p2p_exchanges): the state exchange of both
+        # directions on P2P stores instead of RCCL collectives (rank / world are the exchange objects'; no process group needed)
         self.force_collectives = bool(force_collectives)
-        self.group = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
-        self.world = dist.get_world_size(self.group) if self.group is not None else 1
-        self.rank = dist.get_rank(self.group) if self.group is not None else 0
+        if exchange not in ('rccl', 'p2p') or (exchange == 'p2p') != (p2p is not None):
+            raise ValueError("ShardedScene: exchange='rccl', or exchange='p2p' together with p2p=(forward, backward)")
+        self.exchange, self.p2p = exchange, p2p
+        self.group = group if group is not None else (dist.group.WORLD if (dist.is_initialized() and p2p is None) else None)
+        self.world = p2p[0].world if p2p is not None else (dist.get_world_size(self.group) if self.group is not None else 1)
+        self.rank = p2p[0].rank if p2p is not None else (dist.get_rank(self.group) if self.group is not None else 0)
         self.n_total = n_total
         self.begin, self.count = agent_block(n_total, self.rank, self.world)
         self.obstacles = obstacles
@@ -201,6 +256,8 @@ class ShardedScene:
         """(n, 6) owner records -> (N, 6) everyone's records (autograd: reduce-scatter)."""
         if self.world == 1 and not self.force_collectives:
             return state_own
+        if self.p2p is not None:
+            return _AllGatherRecordsP2P.apply(state_own, self.p2p[0], self.p2p[1])
         return all_gather_records(state_own, self.group)
 
     def relative_features(self, state_own, destination_own):
