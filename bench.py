@@ -313,6 +313,68 @@ def secondary_measurements(scene, n, dev, _lib, prof=None, light=False):
                                       'replayed from one captured HIP graph) - forward, HIP events'}}
 
 
+def cfg4_projection(args, dev, messages, shards=8, scene_agents=16384):
+    """One rank's step of BASELINE.json configs[3] (16384 agents over 8 GPUs) measured on ONE GPU, and what follows from it.
+    The rank's compute is exact (2048 focal rows against all 16384 sources, the network on 2048 agents, relfeat backward over
+    its rows: Step(emulate_shard=True)); its exchanges run at world 1 over the bytes the rank contributes, in each form
+    (RCCL bucket all-reduce / reduce-scatter + all-reduce / P2P stores): their single-rank latency floor, NOT their cost with
+    seven peers.  The same scene on this one GPU is the strong-scaling baseline."""
+    from piml_amd.scenes import synthetic_gc_scene
+    from piml_amd.sharded import p2p_exchanges
+    import piml_amd.models.model as MODEL
+    out = {'shards': shards, 'scene_agents': scene_agents, 'focal_rows_per_rank': scene_agents // shards}
+    scene = synthetic_gc_scene(scene_agents, args.obstacles, seed=args.seed)
+    n_own = scene_agents // shards
+    k = 50
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29537')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    torch.manual_seed(666)
+    n_params = sum(p.numel() for p in MODEL.PINNSF_multitask(model_args()).parameters())
+    p2p = p2p_exchanges(0, 1, n_own, n_params, lambda b: [b])
+    compute_us = None
+    for form in ('bucket', 'rs', 'p2p'):
+        try:
+            st = Step(scene, scene_agents, n_own, 0, args.obstacles, dev, dist.group.WORLD, True, False, bool(args.graph), exchange=form,
+                      messages=messages, p2p=p2p, emulate_shard=True)
+            st.capture()
+            el = st.time_steps(k, 10)
+            out[f'rank_step_us_{form}'] = el / k * 1e6
+            if form != 'p2p' and st.graph is not None and compute_us is None:      # the captured compute alone (RCCL forms: the exchanges sit outside the graph)
+                for _ in range(10):
+                    st.graph.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    st.graph.replay()
+                torch.cuda.synchronize()
+                compute_us = (time.perf_counter() - t0) / k * 1e6
+            del st
+        except Exception as ex:   # noqa: BLE001 - informational
+            out[f'rank_step_us_{form}'] = f'{type(ex).__name__}: {ex}'
+    out['rank_compute_us'] = compute_us
+    try:
+        one = Step(scene, scene_agents, scene_agents, 0, args.obstacles, dev, None, False, False, bool(args.graph), messages=messages)
+        one.capture()
+        el = one.time_steps(20, 5)
+        out['single_gpu_us'] = el / 20 * 1e6
+        del one
+    except Exception as ex:   # noqa: BLE001 - informational
+        out['single_gpu_us'] = f'{type(ex).__name__}: {ex}'
+    if isinstance(out.get('single_gpu_us'), float) and compute_us:
+        out['speedup_ceiling_compute_only'] = out['single_gpu_us'] / compute_us
+        for form in ('bucket', 'rs', 'p2p'):
+            v = out.get(f'rank_step_us_{form}')
+            if isinstance(v, float):
+                out[f'exchange_floor_us_{form}'] = v - compute_us
+                out[f'projected_efficiency_{form}'] = out['single_gpu_us'] / (shards * v)
+    out['note'] = ('rank 0 of the 8-way sharded 16384-agent scene on ONE GPU: compute exact, exchanges at world 1 over this rank\'s bytes '
+                   '(their latency floor; with seven peers they cost more, the scaling curve is the multi-GPU run\'s); projected_efficiency = '
+                   'single_gpu_us / (8 x rank_step_us) is therefore an UPPER bound of the strong-scaling efficiency of that form')
+    return out
+
+
 F32_MFMA_PEAK_TFS = 157.3   # dense f32 matrix peak (v_mfma_f32_32x32x2_f32), same guide
 
 
@@ -321,7 +383,8 @@ class Step:
     the compute part and (sharded) the eager exchange either side of it."""
 
     def __init__(self, scene, N, n_own, b0, M, dev, group, use_dist, two_streams, use_graph, exchange='bucket',
-                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None, messages=False, p2p=None):
+                 overlap=False, model_name='PINNSF_multitask', train_mode=False, ops_module=None, messages=False, p2p=None,
+                 emulate_shard=False):
         from piml_amd import ops, _lib
         import piml_amd.models.model as MODEL
         from piml_amd.sharded import ShardedScene
@@ -360,6 +423,14 @@ class Step:
         # the stream either side of the replay.  `state_all` is the graph's static input: the all-gather
         # target and an autograd leaf whose .grad (N, 6) the captured backward fills.
         self.state_all = torch.zeros(N, 6, device=dev).requires_grad_(True) if use_dist else None
+        # emulate_shard (one process, a 1-rank group): ONE rank's share of a scene sharded over N / n_own ranks -- n_own focal rows
+        # against all N sources, the network on n_own agents -- with the peers' records already in place and every exchange run at
+        # world 1 over the bytes THIS rank contributes (its own block forward; its block of d/d(state) + the weight gradients
+        # backward): the compute of a rank of the real run exactly, its exchanges at their single-rank latency floor
+        self.emulate = bool(emulate_shard) and use_dist
+        if self.emulate:
+            with torch.no_grad():
+                self.state_all.copy_(torch.tensor(np.concatenate([scene[k] for k in ('position', 'velocity', 'acceleration')], axis=-1), device=dev))
         self.grad_own = torch.zeros(n_own, 6, device=dev) if use_dist else None
         self.bucket = [None, None, None, 0]
         # backward exchange: 'bucket' = ONE all-reduce of [d/d(state) (N, 6) | weight gradients] (the state gradient
@@ -420,18 +491,28 @@ class Step:
         grads = [p.grad for p in self.params if p.grad is not None]
         if self.exchange == 'bucket':
             self.bucket[:] = [torch.cat([self.state_all.grad.reshape(-1)] + [g.reshape(-1) for g in grads]), grads]
-        elif self.exchange == 'p2p':       # (padded to whole 16-byte stores)
-            n = sum(g.numel() for g in grads)
-            flat = torch.cat([g.reshape(-1) for g in grads] + ([grads[0].new_zeros((-n) % 4)] if n % 4 else []))
-            self.bucket[:] = [flat, grads, torch.empty_like(flat), n]
+        elif self.exchange == 'p2p':
+            # the fused network's gradients are views of a few flat buffers: those travel as they are and are summed IN PLACE (no
+            # concatenation, no copy back); anything else through a padded bucket
+            from piml_amd.sharded import grad_bases
+            bases = grad_bases(self.params)
+            if bases is not None and sum(b.numel() for b in bases) + self.n_own * 6 <= self.p2p[1].fpr:
+                self.bucket[:] = [bases, None, None, 0]
+            else:
+                n = sum(g.numel() for g in grads)
+                flat = torch.cat([g.reshape(-1) for g in grads] + ([grads[0].new_zeros((-n) % 4)] if n % 4 else []))
+                self.bucket[:] = [flat, grads, torch.empty_like(flat), n]
         else:
             self.bucket[:] = [torch.cat([g.reshape(-1) for g in grads]), grads]
         return acc
 
     def exchange_forward(self):
         from piml_amd.sharded import gather_records_into, gather_records_async
+        own_rows = self.state_all.detach()[self.b0:self.b0 + self.n_own] if self.emulate else self.state_all.detach()
         if self.p2p is not None:                  # every rank's block stored into every peer's buffer, copied out in rank order
-            self.p2p[0].exchange(bcast_src=self.state_own.detach().view(-1), out_bcast=self.state_all.detach().view(-1), sum=False)
+            self.p2p[0].exchange(bcast_src=self.state_own.detach().view(-1), out_bcast=own_rows.view(-1), sum=False)
+        elif self.emulate:
+            gather_records_into(own_rows, self.state_own, self.group)
         elif self.pre is not None:                  # started, not awaited: `pre` runs under it (run / capture wait for it)
             self.gather_work = gather_records_async(self.state_all, self.state_own, self.b0, self.group)
         else:
@@ -440,24 +521,35 @@ class Step:
     def exchange_backward(self):
         from piml_amd.sharded import reduce_scatter_grad, unflatten_gradients
         N, b0, n_own = self.N, self.b0, self.n_own
+        g_state = self.state_all.grad[b0:b0 + n_own] if self.emulate else self.state_all.grad      # (emulate: this rank's block only)
         if self.p2p is not None:
             # ONE launch: the partial d/d(state) rows of every owner's block to THAT owner + this rank's weight-gradient bucket to
             # everybody, both added in rank order on arrival (the same sums on every rank: bit-reproducible)
             flat, grads, out, n = self.bucket
-            self.p2p[1].exchange(scatter_src=self.state_all.grad.view(-1), bcast_src=flat, out_scatter=self.grad_own.view(-1),
-                                 out_bcast=out, sum=True)
-            unflatten_gradients(out[:n], grads)
+            if grads is None:             # in place on the gradients' own buffers
+                self.p2p[1].exchange(scatter_src=g_state.reshape(-1), bcast_src=flat, out_scatter=self.grad_own.view(-1),
+                                     out_bcast=flat, sum=True)
+            else:
+                self.p2p[1].exchange(scatter_src=g_state.reshape(-1), bcast_src=flat, out_scatter=self.grad_own.view(-1),
+                                     out_bcast=out, sum=True)
+                unflatten_gradients(out[:n], grads)
         elif self.exchange == 'bucket':
             dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             self.grad_own.copy_(self.bucket[0][:N * 6].view(N, 6)[b0:b0 + n_own])      # this rank's rows of d/d(state)
             unflatten_gradients(self.bucket[0][N * 6:], self.bucket[1])
         else:
-            reduce_scatter_grad(self.state_all.grad, self.group, out=self.grad_own)      # (all-reduce + slice on gloo: CPU tests)
+            reduce_scatter_grad(g_state, self.group, out=self.grad_own)      # (all-reduce + slice on gloo: CPU tests)
             dist.all_reduce(self.bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             unflatten_gradients(self.bucket[0], self.bucket[1])
 
     def step_body(self, timer=None):
         """One forward + backward pass of the hot path over the scene, eagerly."""
+        if self.emulate:                      # (no autograd all-gather with absent peers: the captured step's own pieces, eagerly)
+            with self.model.packed_weights():
+                self.exchange_forward()
+                self.rest_local(*self.features_local())
+                self.exchange_backward()
+            return None
         with self.model.packed_weights():     # the weight pack rides as trailing workgroups of the relfeat forward launch (PIML_DEFER_PACK)
             if timer is not None:
                 timer.start()
@@ -713,6 +805,9 @@ def main():
                     help='1: the model of the timed step in train() mode with the reference\'s --dropout 0.5 (fresh keep-masks '
                          'drawn on the device every step); the replayed step is then not compared with an eager one '
                          '(different masks).  Default 0: eval(); the train-mode step is reported under secondary.train_mode_step')
+    ap.add_argument('--emulate-shard', type=int, default=8,
+                    help='secondary.cfg4_projection: one rank\'s step of the 16384-agent scene sharded this many ways, measured on this one GPU '
+                         '(compute exact, exchanges at world 1) + the same scene on one GPU; 0 disables')
     ap.add_argument('--messages', type=int, default=0,
                     help='1: the model also materialises the per-row messages predictions[1:3] (the drop-in default of a bare model call); '
                          '0 (default): model.messages_wanted = False, what the reference\'s training loops need -- they read predictions[0] '
@@ -864,13 +959,14 @@ def main():
     def run_step(i, timed):
         if graph is not None:
             sample = timed == 'sample' and i in sample_at
-            if use_dist:
+            eager_exchange = use_dist and st.p2p is None      # (the P2P exchanges are launches INSIDE the captured graph)
+            if eager_exchange:
                 st.exchange_forward()
             if st.pre is not None:
                 st.pre.replay()                   # the own-block part of the step, under the all-gather
                 st.gather_work.wait()
             graph.replay()
-            if use_dist:
+            if eager_exchange:
                 st.exchange_backward()
             if sample:
                 tk, tc = timer_pool[len(sample_timers)]
@@ -1002,7 +1098,7 @@ def main():
     one_pass = False
     if x3_products and fused_mlp:      # the layer-split weight-gradient kernel (encoder_dw2.hip) above the few-rows bound
         from piml_amd import _lib as _plib
-        if _plib.lib().piml_encoder_dw2(-1) == 1 and N * (6 + 10) // 32 > _plib.lib().piml_encoder_split_tiles(-1):
+        if _plib.lib().piml_encoder_dw2(-1) == 1 and N * (6 + 10) // 32 > _plib.lib().piml_encoder_split_tiles_train(-1):
             dw = 'dw2'
             # ... and on top of it the one-pass backward (encoder_bwd3.hip): dX chain + every weight gradient in the `enc_bwd_dx`
             # stage, the `enc_bwd_dw` stage launches nothing (PIML_ENC_FUSED_BWD / PIML_ENC_FUSED_DW3 switch it back)
@@ -1189,6 +1285,11 @@ def main():
             secondary = secondary_measurements(scene, n_own, dev, _lib, prof, light=world > 1)
         except Exception as ex:   # noqa: BLE001 - informational figures must never cost the headline line
             secondary = {'error': f'{type(ex).__name__}: {ex}'}
+        if world == 1 and fused_mlp and not use_dist and args.emulate_shard:
+            try:
+                secondary['cfg4_projection'] = cfg4_projection(args, dev, bool(args.messages), shards=args.emulate_shard)
+            except Exception as ex:   # noqa: BLE001 - informational
+                secondary['cfg4_projection'] = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1 and fused_mlp:      # live evidence that the split products ARE f32 arithmetic: both forms against float64
             try:
                 secondary['encoder_products_vs_float64'] = encoder_products_check(dev, _lib)

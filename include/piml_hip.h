@@ -645,6 +645,12 @@ int piml_encoder_pack_floats(void);
 /* Up to this many 32-row tiles (both branches together) the forward runs with four waves per tile instead of one (few
  * rows: rollouts of real clips); the two forms are bitwise identical.  Returns the previous value; < 0 only queries. */
 long long piml_encoder_split_tiles(long long tiles);
+/* The same bound for a TRAINING pass (every branch carries relu_mask, i.e. a backward follows): default 48 tiles -- with the
+ * one-pass backward the one-wave kernels win from the real clips' sizes on (122 agents = 62 tiles), while a lone forward still
+ * wants four waves per tile up to piml_encoder_split_tiles().  piml_encoder_split_tiles(tiles >= 0) sets BOTH bounds (A/B),
+ * piml_encoder_split_tiles(-2) puts both back to their defaults (environment PIML_ENC_SPLIT_TILES[_TRAIN] at load time).
+ * Returns the previous value; < 0 only queries. */
+long long piml_encoder_split_tiles_train(long long tiles);
 /* Arithmetic of the two 128 x 128 layers' products.  1 (default): every f32 product as six bf16 x bf16 partial products of
  * exact three-way splits of both factors, accumulated in f32 (v_mfma_f32_32x32x16_bf16; what is dropped is below one f32
  * rounding of the product); 0: the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32).  Environment at load time:
@@ -939,24 +945,28 @@ int piml_p2p_open(const piml_ipc_handle* in, void** devptr);
 int piml_p2p_close(void* devptr);
 int piml_p2p_copy(void* dst, const void* src, size_t bytes, void* stream);
 /* The general exchange step, step counter ON THE DEVICE (no argument changes from step to step: the launch sits inside a captured
- * HIP graph and is replayed with it).  Every rank sends to every receiver r the message [scatter part | broadcast part]:
- *   scatter part   = scatter_src + r * scatter_floats   (the partial d/d(state) rows of r's agent block: reduce-scatter input)
- *   broadcast part = bcast_src, bcast_floats floats      (the rank's own records forward, its weight-gradient bucket backward)
+ * HIP graph and is replayed with it).  Every rank sends to every receiver r the message [scatter part | broadcast parts ...]:
+ *   scatter part    = scatter_src + r * scatter_floats   (the partial d/d(state) rows of r's agent block: reduce-scatter input)
+ *   broadcast parts = bcast_src[j], bcast_floats[j] floats, j < n_bcast <= PIML_P2P_MAX_PARTS
+ *                     (the rank's own records forward; its weight-gradient buffers backward)
  * into recv_r[parity][rank] (parity = step & 1), raises r's flag, waits for its own `world` flags, then writes
- *   sum == 0: out_scatter[s * scatter_floats + e] / out_bcast[s * bcast_floats + e] = what sender s sent (all-gather layout);
- *   sum == 1: out_scatter[e] / out_bcast[e] = the senders' parts added IN RANK ORDER (the same sum on every rank).
- * An out pointer may be NULL (that part is not wanted).  Every count is a multiple of 4 floats; slot_floats >= scatter_floats +
- * bcast_floats is the capacity of one (parity, sender) slot of the receive buffers (piml_p2p_alloc(2 * world * slot_floats * 4)).
- * ctr: 2 + world dwords of device memory the host zeroed ONCE (ctr[0] = completed steps).  status: a device int the host zeroed;
- * STICKY -- once a wait ran out (spin_limit rounds of ~4 us, 0: ~0.5 s) it is 1 and every later step returns at once, on this
+ *   sum == 0: out_scatter[s * scatter_floats + e] / out_bcast[j][s * bcast_floats[j] + e] = what sender s sent (all-gather layout);
+ *   sum == 1: out_scatter[e] / out_bcast[j][e] = the senders' parts added IN RANK ORDER (the same sum on every rank).
+ * An out pointer may be NULL (that part is not wanted) and may EQUAL its source (in-place sums: no result is written before every
+ * workgroup of the launch has read its sources).  Every count is a multiple of 4 floats; slot_floats >= the sum of the parts is
+ * the capacity of one (parity, sender) slot of the receive buffers (piml_p2p_alloc(2 * world * slot_floats * 4)).
+ * ctr: 3 + world dwords of device memory the host zeroed ONCE (ctr[0] = completed steps).  status: a device int the host zeroed;
+ * STICKY -- once a wait ran out (spin_limit rounds of ~0.5 us, 0: ~0.5 s) it is 1 and every later step returns at once, on this
  * rank; the exchange is dead until the hosts rebuild it.  Reference: none (nn.DataParallel, src/models/simulators.py:64-67). */
+#define PIML_P2P_MAX_PARTS 8
 typedef struct piml_p2p_msg {
     const float* scatter_src;
     size_t scatter_floats;
-    const float* bcast_src;
-    size_t bcast_floats;
     float* out_scatter;
-    float* out_bcast;
+    int n_bcast;
+    const float* bcast_src[PIML_P2P_MAX_PARTS];
+    size_t bcast_floats[PIML_P2P_MAX_PARTS];
+    float* out_bcast[PIML_P2P_MAX_PARTS];
     int sum;
 } piml_p2p_msg;
 int piml_p2p_exchange(const piml_p2p_msg* msg, int rank, int world, float* const* peer_recv, unsigned* const* peer_flags,

@@ -117,6 +117,7 @@ SIGNATURES = {
     'piml_encoder_partial_floats': [],
     'piml_encoder_pack_floats': [],
     'piml_encoder_split_tiles': [_ll],
+    'piml_encoder_split_tiles_train': [_ll],
     'piml_multi_copy': [ctypes.POINTER(_p), ctypes.POINTER(_p), ctypes.POINTER(_z), _i, _p],
     'piml_rollout_prologue': [_p] * 8 + [_i] * 4 + [_p] * 11 + [_p],
     'piml_rollout_losses_blocks': [_i, _i],
@@ -193,8 +194,8 @@ SIGNATURES = {
 
 class P2PMsg(ctypes.Structure):
     """piml_p2p_msg (include/piml_hip.h)."""
-    _fields_ = [('scatter_src', _p), ('scatter_floats', _z), ('bcast_src', _p), ('bcast_floats', _z),
-                ('out_scatter', _p), ('out_bcast', _p), ('sum', _i)]
+    _fields_ = [('scatter_src', _p), ('scatter_floats', _z), ('out_scatter', _p), ('n_bcast', _i),
+                ('bcast_src', _p * 8), ('bcast_floats', _z * 8), ('out_bcast', _p * 8), ('sum', _i)]
 
 
 SIGNATURES['piml_p2p_exchange'] = [ctypes.POINTER(P2PMsg), _i, _i, ctypes.POINTER(_p), ctypes.POINTER(_p), _z, _p, ctypes.c_uint, _p, _p]
@@ -217,6 +218,7 @@ def lib():
             fn.argtypes = args
             fn.restype = _i
         L.piml_encoder_split_tiles.restype = _ll
+        L.piml_encoder_split_tiles_train.restype = _ll
         L.piml_mlapm_bwd_workspace_floats.restype = _ll
         L.piml_error_string.argtypes = [_i]
         L.piml_error_string.restype = ctypes.c_char_p

@@ -855,12 +855,36 @@ int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) 
 }
 
 // row tiles (of 32) up to which the forward uses enc_fwd_split_kernel (PIML_ENC_SPLIT_TILES, piml_encoder_split_tiles)
-static long long g_split_tiles = getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 1024;
+static long long split_tiles_default() { return getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 1024; }
+// ... and the bound of a TRAINING pass (every branch carries relu_mask: a backward follows).  Round 5: with the one-pass backward
+// and the layer-1 slots the many-rows kernels win from the real clips' sizes on -- forward + backward of `pinnsf_m`, few-rows /
+// many-rows kernels: 84 / 84 us at 122 agents (62 tiles), 96 / 94 at 1024, 132 / 111 at 2048 (one rank of the 8-way sharded
+// 16384-agent scene), and 84 / 74, 96 / 83, 132 / 95 where the sums path applies (tools/sweep_split_tiles.py) -- while a lone
+// forward (validation, rollouts below the pooled path's bound) still wants four waves per tile
+static long long split_tiles_train_default() {
+    if (getenv("PIML_ENC_SPLIT_TILES_TRAIN")) return atoll(getenv("PIML_ENC_SPLIT_TILES_TRAIN"));
+    return getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 48;
+}
+static long long g_split_tiles = split_tiles_default();
+static long long g_split_tiles_train = split_tiles_train_default();
 
+// tiles >= 0: BOTH bounds (A/B, tests); -1: query the forward-only bound; -2: both back to their defaults
 PIML_API long long piml_encoder_split_tiles(long long tiles) {
     const long long old = g_split_tiles;
-    if (tiles >= 0) g_split_tiles = tiles;
+    if (tiles >= 0) g_split_tiles = g_split_tiles_train = tiles;
+    else if (tiles == -2) { g_split_tiles = split_tiles_default(); g_split_tiles_train = split_tiles_train_default(); }
     return old;
+}
+PIML_API long long piml_encoder_split_tiles_train(long long tiles) {
+    const long long old = g_split_tiles_train;
+    if (tiles >= 0) g_split_tiles_train = tiles;
+    return old;
+}
+// the bound that applies to these branches: a training pass (all of them carry relu_mask) or a lone forward
+static long long split_bound(const piml_encoder_branch* br, int nbr) {
+    for (int i = 0; i < nbr; ++i)
+        if (!br[i].relu_mask) return g_split_tiles;
+    return g_split_tiles_train;
 }
 
 // products of the two 128 x 128 layers: 1 = split bf16 products (encoder_x3.hip, f32-exact to one rounding per product),
@@ -954,7 +978,7 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
         return hipErrorInvalidValue;
     }
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
-    if (tiles[0] + tiles[1] <= g_split_tiles) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
+    if (tiles[0] + tiles[1] <= split_bound(br, nbr)) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         if (g_x3) {
             if (int e = x3_ready()) return e;
@@ -1033,7 +1057,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
     // few rows: four waves per tile.  (Measured: 23 vs 43 us at 256 tiles, 25 vs 44 at 512, 44 vs 45 at 1024, 62 vs 47 at 1536:
     // the backward form breaks even earlier than the forward, every wave rebuilding the whole g3.)
-    if ((tiles[0] + tiles[1]) * 4 <= g_split_tiles * 3) {
+    if ((tiles[0] + tiles[1]) * 4 <= split_bound(br, nbr) * 3) {
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         if (g_x3 && !g_dx_split_f32) {
             if (int e = x3_ready()) return e;
@@ -1047,7 +1071,7 @@ int piml::enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s
     if (g_x3) {
         if (int e = x3_ready()) return e;
         // the sign bits exist iff the forward ran on enc_fwd_x3_kernel (same rule as enc_stage_fwd) and was given the buffer
-        bool mask = tiles[0] + tiles[1] > g_split_tiles;
+        bool mask = tiles[0] + tiles[1] > split_bound(br, nbr);
         for (int i = 0; i < nbr; ++i) mask = mask && br[i].relu_mask != nullptr;
         enc_x3_launch_bwd_dx(A, total, mask, br[0].keep_bits != nullptr, s);
         return hipGetLastError();
@@ -1084,7 +1108,7 @@ bool piml::enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1
         tiles += (br[i].rows + 31) / 32;
         if ((br[i].keep_bits != nullptr) != (br[0].keep_bits != nullptr) || (br[i].h1 != nullptr) != (br[0].h1 != nullptr)) return false;
     }
-    if (tiles <= g_split_tiles) return false;
+    if (tiles <= split_bound(br, nbr)) return false;
     const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
     const int w[2] = {w0, total - w0};
     const bool f3 = enc_f3_used(br, nbr);
@@ -1197,7 +1221,7 @@ bool piml::enc_pool_train_ok(const piml_encoder_branch* br, int nbr) {
             return false;
         tiles += (b.rows + 31) / 32;
     }
-    if (tiles <= g_split_tiles) return false;
+    if (tiles <= g_split_tiles_train) return false;
     const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
     return nbr == 1 || (w0 >= 2 && total - w0 >= 2);
 }

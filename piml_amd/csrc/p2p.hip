@@ -74,17 +74,32 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(P2pArgs A) {
 // per receiver ...].  status is STICKY: once a wait has run out the exchange is dead -- later launches return at once (a rank
 // that went on alone would otherwise run two steps ahead of a peer and overwrite a parity half the peer is still reading).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kP2pParts = 1 + PIML_P2P_MAX_PARTS;        // the scatter part + the broadcast parts
 struct P2pX {
-    const float4* src_a; const float4* src_b;
-    float4* out_a; float4* out_b;
+    const float4* src[kP2pParts];          // part 0 = the scatter part (receiver r reads src[0] + r * n4[0])
+    float4* out[kP2pParts];
+    unsigned long long n4[kP2pParts], off4[kP2pParts];      // float4 per part, its offset inside a slot
+    int nparts;
     float* recv[kP2pMaxWorld];
     unsigned* flags[kP2pMaxWorld];
-    unsigned long long na4, nb4, slot4;
+    unsigned long long tot4, slot4;
     int rank, world, split, sum;
     unsigned spin_limit;
     unsigned* ctr;
     int* status;
 };
+
+// polls of the flag words sleep ~0.5 us between loads (s_sleep 16 = 1024 clocks)
+__device__ __forceinline__ bool p2p_wait(const unsigned* f, unsigned want, unsigned limit, int scope_system) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = scope_system ? __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                        : __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == want) return true;
+        if (++spins > limit) return false;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
 
 __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pX A) {
     __shared__ int sh_ok;
@@ -92,34 +107,39 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pX A) {
     if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;      // a dead exchange stays dead
     const unsigned seq = __hip_atomic_load(A.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (advanced by the LAST workgroup out)
     const int parity = (int)(seq & 1u);
-    const unsigned long long n4 = A.na4 + A.nb4;
+    // part of slot element e (parts are few: a linear walk)
+    auto part_of = [&](unsigned long long e) {
+        int j = 0;
+        while (j + 1 < A.nparts && e >= A.off4[j + 1]) ++j;
+        return j;
+    };
     {
         float4* dst = reinterpret_cast<float4*>(A.recv[r]) + ((size_t)parity * A.world + A.rank) * A.slot4;
-        const float4* sa = A.src_a + (size_t)r * A.na4;
-        for (unsigned long long e = (unsigned long long)b * 256 + tid; e < n4; e += (unsigned long long)A.split * 256)
-            dst[e] = e < A.na4 ? sa[e] : A.src_b[e - A.na4];
+        for (unsigned long long e = (unsigned long long)b * 256 + tid; e < A.tot4; e += (unsigned long long)A.split * 256) {
+            const int j = part_of(e);
+            dst[e] = A.src[j][(j == 0 ? (size_t)r * A.n4[0] : 0) + (e - A.off4[j])];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores ...
     __syncthreads();                                       // ... before the one lane that signals for the workgroup
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: the payload is visible to the peer before the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned sent = __hip_atomic_fetch_add(A.ctr + 2 + r, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned sent = __hip_atomic_fetch_add(A.ctr + 3 + r, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (sent == (unsigned)A.split - 1u) {              // receiver r's last slice is out: its flag
-            __hip_atomic_store(A.ctr + 2 + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.ctr + 3 + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.flags[r] + parity * A.world + A.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        __hip_atomic_fetch_add(A.ctr + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // this workgroup has read its part of the sources
         sh_ok = 1;
     }
     __syncthreads();
-    // every workgroup waits for this rank's own flags (one lane per sender), then takes its slice of the result
+    // wait: (i) for this rank's own flags, one lane per sender; (ii) lane 63: until EVERY workgroup of this launch has finished
+    // reading the sources -- the results may be written over them (in-place sums: out == src)
     if (tid < A.world) {
-        const unsigned* f = A.flags[A.rank] + parity * A.world + tid;
-        unsigned spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (++spins > A.spin_limit) { sh_ok = 0; break; }
-            __builtin_amdgcn_s_sleep(127);
-        }
+        if (!p2p_wait(A.flags[A.rank] + parity * A.world + tid, seq, A.spin_limit, 1)) sh_ok = 0;
+    } else if (tid == 63) {
+        if (!p2p_wait(A.ctr + 2, gridDim.x, A.spin_limit, 0)) sh_ok = 0;
     }
     __syncthreads();
     const bool ok = sh_ok != 0;
@@ -128,11 +148,11 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pX A) {
     if (ok) {
         const float4* base = reinterpret_cast<const float4*>(A.recv[A.rank]) + (size_t)parity * A.world * A.slot4;
         const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-        for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + tid; e < n4; e += stride) {
-            const bool in_a = e < A.na4;
-            float4* out = in_a ? A.out_a : A.out_b;
+        for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + tid; e < A.tot4; e += stride) {
+            const int j = part_of(e);
+            float4* out = A.out[j];
             if (!out) continue;
-            const unsigned long long eo = in_a ? e : e - A.na4, per = in_a ? A.na4 : A.nb4;
+            const unsigned long long eo = e - A.off4[j];
             if (A.sum) {
                 float4 acc = base[e];
                 for (int s = 1; s < A.world; ++s) {        // rank order: the same sum on every rank
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pX A) {
                 }
                 out[eo] = acc;
             } else {
-                for (int s = 0; s < A.world; ++s) out[(size_t)s * per + eo] = base[(size_t)s * A.slot4 + e];
+                for (int s = 0; s < A.world; ++s) out[(size_t)s * A.n4[j] + eo] = base[(size_t)s * A.slot4 + e];
             }
         }
     }
@@ -150,6 +170,7 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(P2pX A) {
         const unsigned done = __hip_atomic_fetch_add(A.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1u) {
             __hip_atomic_store(A.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A.ctr + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(A.ctr, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -219,26 +240,41 @@ PIML_API int piml_allgather_state_p2p(const float* own, size_t floats_per_rank, 
 
 PIML_API int piml_p2p_exchange(const piml_p2p_msg* msg, int rank, int world, float* const* peer_recv, unsigned* const* peer_flags,
                                size_t slot_floats, unsigned* ctr, unsigned spin_limit, int* status, void* stream) {
-    if (!msg || !peer_recv || !peer_flags || !ctr || !status || world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world)
-        return hipErrorInvalidValue;
-    const size_t na = msg->scatter_floats, nb = msg->bcast_floats;
-    if (na + nb == 0 || na % 4 || nb % 4 || slot_floats % 4 || na + nb > slot_floats || (na && !msg->scatter_src) || (nb && !msg->bcast_src))
+    if (!msg || !peer_recv || !peer_flags || !ctr || !status || world < 1 || world > kP2pMaxWorld || rank < 0 || rank >= world ||
+        msg->n_bcast < 0 || msg->n_bcast > PIML_P2P_MAX_PARTS)
         return hipErrorInvalidValue;
     P2pX A = {};
-    A.src_a = reinterpret_cast<const float4*>(msg->scatter_src);
-    A.src_b = reinterpret_cast<const float4*>(msg->bcast_src);
-    A.out_a = reinterpret_cast<float4*>(msg->out_scatter);
-    A.out_b = reinterpret_cast<float4*>(msg->out_bcast);
+    unsigned long long off = 0;
+    auto add = [&](const float* src, size_t n, float* out) {
+        if (n % 4 || !src) return false;
+        A.src[A.nparts] = reinterpret_cast<const float4*>(src);
+        A.out[A.nparts] = reinterpret_cast<float4*>(out);
+        A.n4[A.nparts] = n / 4;
+        A.off4[A.nparts] = off;
+        off += n / 4;
+        ++A.nparts;
+        return true;
+    };
+    // part 0 is always the scatter part (possibly empty: it then never matches an element)
+    if (msg->scatter_floats) {
+        if (!add(msg->scatter_src, msg->scatter_floats, msg->out_scatter)) return hipErrorInvalidValue;
+    } else {
+        A.nparts = 1;
+    }
+    for (int j = 0; j < msg->n_bcast; ++j)
+        if (msg->bcast_floats[j] && !add(msg->bcast_src[j], msg->bcast_floats[j], msg->out_bcast[j])) return hipErrorInvalidValue;
+    if (off == 0 || slot_floats % 4 || off > slot_floats / 4) return hipErrorInvalidValue;
     for (int r = 0; r < world; ++r) {
         if (!peer_recv[r] || !peer_flags[r]) return hipErrorInvalidValue;
         A.recv[r] = peer_recv[r];
         A.flags[r] = peer_flags[r];
     }
-    A.na4 = na / 4; A.nb4 = nb / 4; A.slot4 = slot_floats / 4;
+    A.tot4 = off; A.slot4 = slot_floats / 4;
     A.rank = rank; A.world = world; A.sum = msg->sum ? 1 : 0;
-    const unsigned long long n4 = A.na4 + A.nb4;
-    A.split = (int)(n4 / 1024 < 1 ? 1 : (n4 / 1024 > 16 ? 16 : n4 / 1024));
-    A.spin_limit = spin_limit ? spin_limit : 125000u;      // ~0.5 s
+    // workgroups per receiver: ~2 float4 per thread (loads of the fine-grained receive buffers are uncached round trips: many
+    // threads with few loads each), all of them resident at once (the waits spin): world * split <= 512
+    A.split = (int)(off / 512 < 1 ? 1 : (off / 512 > 64 ? 64 : off / 512));
+    A.spin_limit = spin_limit ? spin_limit : 1000000u;     // ~0.5 s
     A.ctr = ctr;
     A.status = status;
     hipLaunchKernelGGL(p2p_exchange_kernel, dim3((unsigned)(world * A.split)), dim3(256), 0, as_stream(stream), A);

@@ -850,11 +850,16 @@ class BaseSimulator(Pedestrians):
             return log
         self.optimizer.zero_grad()
         if channelled:                                                                     # channelled windows
-            out = self.test_multiple_rollouts_for_training(batch_data)
-            loss = out[0]
+            # the same gradient bookkeeping as the captured step (the frames' weight gradients summed by the slot-sum launches, those
+            # riding in the relfeat backward's launches): eager and captured steps run the same kernels in the same order
+            with self._grad_sink.step(), ops.deferred_slot_sums():
+                out = self.test_multiple_rollouts_for_training(batch_data)
+                out[0].backward()
             names = ('loss', 'mse', 'collision', 'hard_collision', 'collision_pred', 'acc_pred', 'reg')
             log.update({k: float(v.detach()) for k, v in zip(names, out)})
             log['n'] = int(torch.sum(batch_data.mask_p_pred == 1).item())
+            self.optimizer.step()
+            return log
         else:                                                                              # pointwise rows
             # (only with the hand-written kernels: capturing the library-GEMM path here segfaulted in hipStreamEndCapture
             # when an earlier capture of the process had used other GEMM selections -- that path stays eager, as before)

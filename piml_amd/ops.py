@@ -1881,7 +1881,11 @@ def _h1_needed(rows_per_branch, alone=True):
     # every branch on its own above the bound: the backward may run on a subset of them (branches without upstream gradient)
     per_branch = [(r + 31) // 32 for r in rows_per_branch]
     tiles = min(per_branch) if alone else sum(per_branch)
-    if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1 and tiles > L.piml_encoder_split_tiles(-1)):
+    # (h1 is skipped only where its 512 B per row matter -- above the forward-only bound of the few-rows kernels, 1024 tiles by
+    # default -- although the backward that recomputes it runs from the training bound on: a backward pass that arrives through
+    # the messages of ONE small branch still finds it)
+    if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1
+            and tiles > max(L.piml_encoder_split_tiles_train(-1), L.piml_encoder_split_tiles(-1))):
         return True
     arr = (_lib.EncoderBranch * len(rows_per_branch))()
     for b, r in enumerate(rows_per_branch):
@@ -2335,8 +2339,7 @@ class _FusedPinnsf(torch.autograd.Function):
             for b in range(nbr):
                 probe[b].rows, probe[b].in_dim, probe[b].k = x2s[b].shape[0], x2s[b].shape[1], ks[b]
             sums = bool(L.piml_pinnsf_pool_train_ok(probe, nbr)) and not FORK_NETWORK and \
-                (packs is None or packs.fold == tuple(float(sc) for sc in scales)) and \
-                not (need_grad and ParamGradSink._active is not None) and all(k is None for k in keeps)
+                (packs is None or packs.fold == tuple(float(sc) for sc in scales)) and all(k is None for k in keeps)
         ctx.sums = sums
         sum_a, sum_b, masks = [None] * nbr, [None] * nbr, [None] * nbr
         for b in range(nbr):
@@ -2568,7 +2571,24 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
         total = L.piml_encoder_workgroups(earr, nbr, ctypes.byref(w0))
         slots = [w0.value, total - w0.value] if nbr == 2 else [total]
         parts = [torch.empty(n, part1, **opt) for n in slots]
-        flats = [torch.empty(L.piml_encoder_partial_floats(), **opt) for _ in range(nbr)]
+        # weight gradients: fresh buffers handed to autograd, or -- inside ParamGradSink.step() -- the sink's persistent ones, summed
+        # across the backward passes of the step by the slot-sum launch itself (the folded layers' gradients accumulate FOLDED and
+        # are unfolded from their running sums: the unfold is linear)
+        sink = ParamGradSink.current(ctx.sink)
+        flags = _lib.POOL_TRAIN
+        flats = dflats = dw1 = None
+        if sink is not None:
+            ids = lambda lo, hi: tuple(id(t) for t in ctx.params[lo:hi])
+            flats, acc_e = sink.take([ids(PER * b + 1, PER * b + 7) for b in range(nbr)], L.piml_encoder_partial_floats(), opt)
+            dflats, acc_d = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], L.piml_decoder_partial_floats(), opt)
+            dw1, _ = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], 64 * H, opt)
+            if acc_e != acc_d:
+                raise _lib.PimlHipError('fused_pinnsf(sums=True): the encoders and decoders of one network went through different numbers '
+                                        'of backward passes inside ParamGradSink.step()')
+            if acc_e:
+                flags |= _lib.ACCUMULATE
+        else:
+            flats = [torch.empty(L.piml_encoder_partial_floats(), **opt) for _ in range(nbr)]
         for b in range(nbr):
             earr[b].partials, earr[b].grads = parts[b].data_ptr(), flats[b].data_ptr()
         ga = _gpu_f32('g_acc', g_acc).reshape(agents, 2)
@@ -2576,8 +2596,9 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
         g_self = torch.empty(agents, 7, **opt) if want_self else None
         nwg = L.piml_decoder_workgroups(agents)
         dparts = [torch.empty(nwg, L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
-        dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
-        dw1 = [torch.empty(64, H, **opt) for _ in range(nbr)]
+        if sink is None:
+            dflats = [torch.empty(L.piml_decoder_partial_floats(), **opt) for _ in range(nbr)]
+            dw1 = [torch.empty(64 * H, **opt) for _ in range(nbr)]
         keep, dstructs = [], []
         for b in range(nbr):
             gp2, gp1 = torch.empty(agents, 64, **opt), torch.empty(agents, 64, **opt)
@@ -2585,8 +2606,7 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
             dstructs.append(_dec_branch_struct(pooled[b], agents, ks[b], dwb[b], dpack[b], pooled[b], dh1[b], dd2[b], gp2, gp1,
                                                g_pooled[b], dparts[b], dflats[b], fold=(ewb[b][4], ewb[b][5], scales[b]), dw1_out=dw1[b]))
         darr = (_lib.DecoderBranch * nbr)(*dstructs)
-        flags = _lib.POOL_TRAIN
-        if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], None, dev):
+        if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink, dev):
             flags |= _lib.DEFER_SLOT_SUMS
             _DEFER_KEEP[:] = [parts, dparts, dflats, flats, dw1]
         _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags, _stream()), 'piml_pinnsf_bwd')
@@ -2602,7 +2622,10 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
             # (views: AccumulateGrad keeps a gradient it is handed unread only while nobody else holds the tensor object)
             for jx, t in enumerate((dw1[b].view(64, H), rest[:64], dW2, rest[64:128], dW3, rest[128:130])):      # (d/d(b1) = d/d(b1'))
                 if need[jx]:
-                    grads[o + jx] = t
+                    if sink is not None:
+                        sink.give(ctx.params[o + jx - FIRST], t)
+                    else:
+                        grads[o + jx] = t
             flat = flats[b]
             in_dim = x2s[b].shape[1]
             o = FIRST + PER * b
@@ -2614,7 +2637,10 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
             db3, db2, db1 = flat[2 * H * H + 8 * H:].view(3, H)
             for jx, t in zip(range(1, 7), (dW1, db1, dW2, db2, dW3, db3)):
                 if need[jx]:
-                    grads[o + jx] = t
+                    if sink is not None:
+                        sink.give(ctx.params[o + jx - FIRST], t)
+                    else:
+                        grads[o + jx] = t
     return tuple(grads)
 
 

@@ -31,7 +31,7 @@ class P2PExchange:
         self.status = torch.zeros(1, dtype=torch.int32, device='cuda')
         self.seq = 0
         # the general exchange (`exchange`): step counter and workgroup counters on the device, zeroed once
-        self.ctr = torch.zeros(2 + world, dtype=torch.int32, device='cuda')
+        self.ctr = torch.zeros(3 + world, dtype=torch.int32, device='cuda')
 
     def handles(self):
         """(recv handle, flags handle) as bytes, for the peers."""
@@ -65,34 +65,43 @@ class P2PExchange:
 
     def exchange(self, scatter_src=None, bcast_src=None, out_scatter=None, out_bcast=None, sum=False, spin_limit=0):
         """One step of the general exchange (piml_p2p_exchange: device-side step counter, capturable into a HIP graph) on the
-        current stream.  scatter_src: (world * n_s) floats, receiver r gets block r; bcast_src: n_b floats for every receiver;
-        n_s + n_b <= floats_per_rank (the slot size given to the constructor).  sum=False: out_scatter (world * n_s) / out_bcast
-        (world * n_b) receive the senders' parts in rank order; sum=True: out_scatter (n_s) / out_bcast (n_b) their sums in rank
-        order.  `ok()` (synchronising) tells whether every peer arrived; after a time-out the exchange stays dead."""
+        current stream.  scatter_src: (world * n_s) floats, receiver r gets block r.  bcast_src: a tensor, or a list of up to 8
+        tensors, every receiver gets all of them; the parts together must fit floats_per_rank (the slot size given to the
+        constructor).  sum=False: out_scatter (world * n_s) / out_bcast[j] (world * n_j) receive the senders' parts in rank order;
+        sum=True: out_scatter (n_s) / out_bcast[j] (n_j) their sums in rank order -- out_bcast[j] may BE bcast_src[j] (in place).
+        `ok()` (synchronising) tells whether every peer arrived; after a time-out the exchange stays dead."""
         def flat(t, name, n=None):
-            if t is None:
-                return None
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError(f'P2PExchange.exchange: {name} must be a contiguous float32 GPU tensor')
             if n is not None and t.numel() != n:
                 raise ValueError(f'P2PExchange.exchange: {name} has {t.numel()} elements, expected {n}')
             return t
+        as_list = lambda x: [] if x is None else (list(x) if isinstance(x, (list, tuple)) else [x])
+        srcs, outs = as_list(bcast_src), as_list(out_bcast)
+        if outs and len(outs) != len(srcs):
+            raise ValueError('P2PExchange.exchange: one out_bcast per bcast_src (or none)')
+        if len(srcs) > 8:
+            raise ValueError('P2PExchange.exchange: at most 8 broadcast parts')
+        mult = 1 if sum else self.world
         ns = 0 if scatter_src is None else flat(scatter_src, 'scatter_src').numel() // self.world
-        nb = 0 if bcast_src is None else flat(bcast_src, 'bcast_src').numel()
         if scatter_src is not None and scatter_src.numel() != ns * self.world:
             raise ValueError('P2PExchange.exchange: scatter_src must hold one block per rank')
-        mult = 1 if sum else self.world
-        flat(out_scatter, 'out_scatter', ns * mult if out_scatter is not None else None)
-        flat(out_bcast, 'out_bcast', nb * mult if out_bcast is not None else None)
-        if ns % 4 or nb % 4 or ns + nb == 0 or ns + nb > self.fpr:
-            raise ValueError(f'P2PExchange.exchange: parts of {ns} + {nb} floats (multiples of 4) must fit the slot of {self.fpr}')
+        if out_scatter is not None:
+            flat(out_scatter, 'out_scatter', ns * mult)
         m = _lib.P2PMsg()
         m.scatter_src, m.scatter_floats = (scatter_src.data_ptr() if ns else None), ns
-        m.bcast_src, m.bcast_floats = (bcast_src.data_ptr() if nb else None), nb
         m.out_scatter = out_scatter.data_ptr() if out_scatter is not None else None
-        m.out_bcast = out_bcast.data_ptr() if out_bcast is not None else None
+        m.n_bcast, total = len(srcs), ns
+        for j, t in enumerate(srcs):
+            flat(t, f'bcast_src[{j}]')
+            m.bcast_src[j], m.bcast_floats[j] = t.data_ptr(), t.numel()
+            if outs and outs[j] is not None:
+                m.out_bcast[j] = flat(outs[j], f'out_bcast[{j}]', t.numel() * mult).data_ptr()
+            total += t.numel()
+        if ns % 4 or any(t.numel() % 4 for t in srcs) or total == 0 or total > self.fpr:
+            raise ValueError(f'P2PExchange.exchange: parts of {total} floats in all (each a multiple of 4) must fit the slot of {self.fpr}')
         m.sum = 1 if sum else 0
-        if not spin_limit:      # PIML_P2P_SPIN_LIMIT: rounds of ~4 us a wait may take (default ~0.5 s; hosts whose ranks start far apart raise it)
+        if not spin_limit:      # PIML_P2P_SPIN_LIMIT: rounds of ~0.5 us a wait may take (default ~0.5 s; hosts whose ranks start far apart raise it)
             spin_limit = int(os.environ.get('PIML_P2P_SPIN_LIMIT', '0'))
         _lib.check(_lib.lib().piml_p2p_exchange(ctypes.byref(m), self.rank, self.world, self._peer_recv, self._peer_flags, self.fpr,
                                                 self.ctr.data_ptr(), int(spin_limit), self.status.data_ptr(),

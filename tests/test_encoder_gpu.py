@@ -466,7 +466,7 @@ def test_split_tile_forward_is_bitwise_the_one_wave_forward(agents):
             loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
             res[split] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
     finally:
-        L.piml_encoder_split_tiles(old)
+        L.piml_encoder_split_tiles(-2)          # both bounds back to their defaults
         L.piml_encoder_products(old_products)
     assert len(res[True]) == len(res[False])
     for a, b in zip(res[True], res[False]):
@@ -553,7 +553,7 @@ def test_split_tile_x3_forward_is_bitwise_the_one_wave_x3_forward(agents):
             with torch.no_grad():
                 res[split] = [t.clone() for o in ops.fused_encoders(brs) for t in o]
     finally:
-        L.piml_encoder_split_tiles(old)
+        L.piml_encoder_split_tiles(-2)          # both bounds back to their defaults
         L.piml_encoder_products(old_products)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
@@ -586,7 +586,7 @@ def test_split_tile_x3_backward_is_bitwise_the_one_wave_x3_backward(agents, drop
             loss = sum((m * 1e-2).sum() + p.square().sum() for m, p in outs)
             res[split] = [t.detach().clone() for o in outs for t in o] + list(torch.autograd.grad(loss, leaves))
     finally:
-        L.piml_encoder_split_tiles(old)
+        L.piml_encoder_split_tiles(-2)          # both bounds back to their defaults
         L.piml_encoder_products(old_products)
         L.piml_encoder_dw2(old_dw2)
     assert len(res[True]) == len(res[False]) == 4 + 14
@@ -607,7 +607,7 @@ def test_layer_split_weight_gradients(shapes, upstream, drop, recompute, monkeyp
     from piml_amd import ops, _lib
     L = _lib.lib()
     monkeypatch.setattr(ops, 'H1_RECOMPUTE', recompute)
-    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles(-1)
+    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles_train(-1)
     g = torch.Generator().manual_seed(77)
     branches = [dodge_relu_kinks(make_branch(n, k, d, seed=3 * i + 1, scale=4.0 if drop else 2.0)) for i, (n, k, d) in enumerate(shapes)]
     if drop:
@@ -685,7 +685,7 @@ def test_one_pass_backward(shapes, upstream, drop, form):
     (no atomics).  The no-input-gradient form (pointwise training) rides along: same weight gradients bit for bit."""
     from piml_amd import ops, _lib
     L = _lib.lib()
-    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles(-1)
+    assert sum((n * k + 31) // 32 for n, k, _ in shapes) > L.piml_encoder_split_tiles_train(-1)
     g = torch.Generator().manual_seed(78)
     branches = [dodge_relu_kinks(make_branch(n, k, d, seed=3 * i + 2, scale=4.0 if drop else 2.0)) for i, (n, k, d) in enumerate(shapes)]
     if drop:

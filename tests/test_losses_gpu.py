@@ -86,6 +86,9 @@ def test_param_grad_sink_equals_autograd_accumulation(model):
     sim = BaseSimulator(sim_args(model=model, dropout=0.0, learning_rate=1e-3))
     net = sim.model
     net.train(False)
+    # (the message path: on the sums path -- messages_wanted = False -- the sink accumulates the FOLDED layers' gradients and
+    # unfolds their running sums, which is the same arithmetic in another order: test_param_grad_sink_on_the_sums_path)
+    net.messages_wanted = True
     g = torch.Generator().manual_seed(11)
     frames = [(torch.randn(4, 122, 6, 6, generator=g).to(DEV), torch.randn(4, 122, 10, 6, generator=g).to(DEV),
                torch.randn(4, 122, 7, generator=g).to(DEV)) for _ in range(3)]
@@ -108,6 +111,49 @@ def test_param_grad_sink_equals_autograd_accumulation(model):
         assert (w is None) == (gt is None), name
         if w is not None:
             assert torch.equal(w, gt), name
+
+
+def test_param_grad_sink_on_the_sums_path():
+    """ops.ParamGradSink with the network on the agents' sums of h2 (model.messages_wanted = False): the folded layers' gradients
+    accumulate folded and are unfolded from their running sums -- equal to autograd's accumulation of the unfolded gradients to
+    float32 rounding (1e-6 of the tensor's largest entry), deterministic, and every parameter gets its gradient."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_simulator_gpu import sim_args
+    from piml_amd import ops
+    from piml_amd.models.simulators import BaseSimulator
+    import contextlib
+    torch.manual_seed(5)
+    sim = BaseSimulator(sim_args(model='pinnsf_m', dropout=0.0, learning_rate=1e-3))
+    net = sim.model
+    net.train(False)
+    assert net.messages_wanted is False
+    g = torch.Generator().manual_seed(11)
+    frames = [(torch.randn(4, 122, 6, 6, generator=g).to(DEV), torch.randn(4, 122, 10, 6, generator=g).to(DEV),
+               torch.randn(4, 122, 7, generator=g).to(DEV)) for _ in range(3)]
+
+    def run(use_sink):
+        for p in net.parameters():
+            p.grad = None
+        sink = ops.ParamGradSink()
+        with (sink.step() if use_sink else contextlib.nullcontext()):
+            loss = 0
+            for pf, of, sf in frames:
+                out = net(pf, of, sf)
+                assert out[1] is None and out[2] is None
+                loss = loss + out[0].square().sum()
+            loss.backward()
+        return [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+    want, got, again = run(False), run(True), run(True)
+    assert sum(w is not None for w in want) >= 24
+    worst = 0.0
+    for (name, _), w, gt, g2 in zip(net.named_parameters(), want, got, again):
+        assert (w is None) == (gt is None), name
+        if w is not None:
+            assert torch.equal(gt, g2), name
+            worst = max(worst, float((w - gt).abs().max() / w.abs().max()))
+    print(f'ParamGradSink on the sums path vs autograd accumulation: max rel diff {worst:.1e}')
+    assert worst <= 2e-6
 
 
 def test_multi_copy_one_launch_for_a_batch_of_tensors():

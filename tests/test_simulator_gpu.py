@@ -153,7 +153,9 @@ def test_two_stream_forward_equals_single_stream():
         got = sim.model(*args)
         torch.cuda.synchronize()
     for a, b in zip(got, ref):
-        assert torch.equal(a, b)
+        assert (a is None) == (b is None)          # (the simulator's model does not materialise messages nobody reads)
+        if a is not None:
+            assert torch.equal(a, b)
 
 
 def test_graphed_train_step_equals_eager(monkeypatch):

@@ -18,7 +18,7 @@ for r in rows:
     out.append((r['Kernel_Name'][:60], (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
     prev = e
 idx = [i for i, o in enumerate(out) if 'relfeat_fwd_kernel' in o[0]]
-lo = idx[-8] if len(idx) > 8 else 0
+lo = idx[len(idx) // 2] if len(idx) > 8 else 0          # the middle of the run: the timed region's replays
 for o in out[lo:lo + 60]:
     print(f'{o[0]:60s} dur {o[1]:8.2f} us   gap-before {o[2]:8.2f} us')
 PY
