@@ -880,10 +880,13 @@ PIML_API long long piml_encoder_split_tiles_train(long long tiles) {
     if (tiles >= 0) g_split_tiles_train = tiles;
     return old;
 }
-// the bound that applies to these branches: a training pass (all of them carry relu_mask) or a lone forward
+// the bound that applies to these branches: a training pass without a dropout mask (all of them carry relu_mask, none keep_bits /
+// drop_state), or anything else.  (With the in-kernel mask the four-waves-per-tile kernels stay ahead up to ~512 tiles: fine-tuning
+// step of 4 x 5 x 122 agents at p = 0.5 0.45 ms on them against 0.50 on the one-wave kernels, pointwise step of 128 rows 0.157
+// against 0.171; without a mask 0.44 -> 0.41 and 0.157 -> 0.155 the other way round, tools/train_mode_steps.py.)
 static long long split_bound(const piml_encoder_branch* br, int nbr) {
     for (int i = 0; i < nbr; ++i)
-        if (!br[i].relu_mask) return g_split_tiles;
+        if (!br[i].relu_mask || br[i].keep_bits || br[i].drop_state) return g_split_tiles;
     return g_split_tiles_train;
 }
 

@@ -267,10 +267,16 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         const bool live = tile < ntiles;                     // (bitwise combinations: a short-circuit would branch)
         const bool valid = live & (row < R);
         if (SUMS && i < 4) {                               // registers 4 i .. 4 i + 3: rows rho(r) + 4 h of the tile, this lane's feature
+            // agent of row 32 tile + m = a0 + (rem + m) / K with a0, rem = (32 tile) / K, % K on the scalar unit and (rem + m) < K + 32
+            // divided by a 16-bit reciprocal (exact below 2^10 for K < 64: one 24-bit multiply + shift; v_mul_hi_u32 is quarter
+            // rate).  No row test: R = agents * K, so a row or tile past the end is an agent past the end -- out of the resource's range
+            const unsigned t32 = __builtin_amdgcn_readfirstlane((unsigned)tile * 32u);
+            const unsigned a0 = __builtin_amdgcn_readfirstlane(__umulhi(t32, kmagic)), rem = t32 - a0 * K;
+            const unsigned base = (a0 * EH + 32 * w + n) * 4, x0 = rem + 4 * h, rcp = (65536u + K - 1) / K;
 #pragma unroll
             for (int r = 4 * i; r < 4 * i + 4; ++r) {
-                const unsigned rr = (unsigned)tile * 32 + rho(r) + 4 * h;
-                S.g2[r] = __uint_as_float(ld1(rs_gp, (live & (rr < R)) ? (__umulhi(rr, kmagic) * EH + 32 * w + n) * 4 : kOut));
+                const unsigned q = ((x0 + rho(r)) * rcp) >> 16;
+                S.g2[r] = __uint_as_float(ld1(rs_gp, base + q * (EH * 4)));
             }
         } else if (SUMS && i == 4) {
             S.m2 = ld1(rs_mk, live ? ((unsigned)tile * 256 + 128 + 2 * lane + (w >> 1)) * 4 : kOut);
@@ -286,11 +292,14 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             if (DROP) S.kw = ld1(rs_kb, valid ? (row * 4 + w) * 4 : kOut);
             pf_sc = valid ? scale : 0.f;
         } else if (i == 5) {
+            // (SUMS: H1 of tile t + 1 is built under layer B of tile t, so its x rows are requested TWO tiles ahead)
+            const unsigned xrow = SUMS ? row + 32u * (unsigned)nwg : row;
+            const bool xvalid = SUMS ? ((tile + nwg < ntiles) & (xrow < R)) : valid;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const unsigned cx = 2u * s + h;
-                const unsigned off = (row * IN + cx) * 4;
-                S.xa[s] = __uint_as_float(ld1(rs_x, (valid & (cx < IN)) ? off : kOut));
+                const unsigned off = (xrow * IN + cx) * 4;
+                S.xa[s] = __uint_as_float(ld1(rs_x, (xvalid & (cx < IN)) ? off : kOut));
             }
         } else {
             const unsigned srow = (unsigned)tile * 32 + (tid >> 3), cx = tid & 7;
@@ -345,12 +354,16 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
     // H1 = relu(...) -> pieces -> bufH, 18 steps: two split halves per register pair, a store step behind each k-step
     f32x16 hacc;
     unsigned hhi[4], hmid[4], hlo[4];
+    // SUMS: H1 is double-buffered (the G3 buffer is free there): buffer (par) holds the running tile's, buffer (par ^ 1) is written
+    // under layer B for the next tile
+    u32x4* const bufH2 = SUMS ? reinterpret_cast<u32x4*>(smem + F3_BUFA) + lane : bufH;
+    u32x4* hw = bufH;                                        // where h1_step writes
     auto h1_step = [&](int st) {
         if (st == 8 || st == 17) {
             const int s = st == 17;
-            bufH[((w * 2 + s) * 3 + 0) * 64] = (u32x4){hhi[0], hhi[1], hhi[2], hhi[3]};
-            bufH[((w * 2 + s) * 3 + 1) * 64] = (u32x4){hmid[0], hmid[1], hmid[2], hmid[3]};
-            bufH[((w * 2 + s) * 3 + 2) * 64] = (u32x4){hlo[0], hlo[1], hlo[2], hlo[3]};
+            hw[((w * 2 + s) * 3 + 0) * 64] = (u32x4){hhi[0], hhi[1], hhi[2], hhi[3]};
+            hw[((w * 2 + s) * 3 + 1) * 64] = (u32x4){hmid[0], hmid[1], hmid[2], hmid[3]};
+            hw[((w * 2 + s) * 3 + 2) * 64] = (u32x4){hlo[0], hlo[1], hlo[2], hlo[3]};
             return;
         }
         const int t = st > 8 ? st - 1 : st, q = t >> 1, d = q & 3;       // register pair q = (2 q, 2 q + 1), dword d of its k-step
@@ -413,9 +426,27 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         if (!SUMS) {
 #pragma unroll
             for (int i = 0; i < 22; ++i) g3_step(i);
-        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) xa[s] = S.xa[s];
+            for (int s = 0; s < 4; ++s) xa[s] = S.xa[s];
+        } else {
+            // H1 of the FIRST tile into buffer 0 (x of this tile: one plain load, the pipeline's requests run two tiles ahead), and
+            // the x rows of the second tile as `xa` (pf_step(5, tile - nwg) asks for tile + ... = the tile after `tile - nwg + nwg`)
+            float x0[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned cx = 2u * s + h, row0 = (unsigned)tile * 32 + n;
+                x0[s] = __uint_as_float(ld1(rs_x, ((tile < ntiles) & (row0 < R) & (cx < IN)) ? (row0 * IN + cx) * 4 : kOut));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xa[s] = S.xa[s];         // (pf_step(5, tile) above: the rows of tile + nwg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hacc[r] = b1v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f3_mfma32(hacc, x0[s], w1v[s]);
+            f3_settle(hacc);
+#pragma unroll
+            for (int st_ = 0; st_ < 18; ++st_) h1_step(st_);
+        }
     }
     F3_STAMP(15);
     for (; tile < ntiles; tile += nwg, par ^= 1) {
@@ -424,10 +455,12 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
         // ============ region X: layer A (G2 = (G3 W3) * [h2 > 0]); in its shadow the next tile's requests, the g_x store of
         // ============ the previous tile and H1 = relu(W1 x + b1) with its split ============
         const int ntile = tile + nwg;
+        if (!SUMS) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] = b1v;
+            for (int r = 0; r < 16; ++r) hacc[r] = b1v;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f3_mfma32(hacc, xa[s], w1v[s]);
+            for (int s = 0; s < 4; ++s) f3_mfma32(hacc, xa[s], w1v[s]);
+        }
         f32x16 acc;
         u32x4 opa[2][4], ahi[8];                               // operands of a k-block: pieces hi, mid, lo of the activations + LO of the weights
         unsigned m2w = 0;
@@ -459,13 +492,10 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             else if (f >= 10 && f < 28) h1_step(f - 10);
             else if (f >= 30 && f < 38) mk_step(f - 30, mk2);
         };
-        if (SUMS) {                                            // no layer A: the steps that rode between its products, in order
+        if (SUMS) {                                            // no layer A: the next tile's requests and the g_x store; H1 rides under layer B
 #pragma unroll
             for (int f = 0; f < 7; ++f) pf_step(f, ntile);
             if (GX) gx_store(prev_tile);
-            f3_settle(hacc);
-#pragma unroll
-            for (int st_ = 0; st_ < 18; ++st_) h1_step(st_);
         } else {
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
@@ -515,6 +545,13 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             o[3] = wlo[(8 + kb) * 64];
         };
         load_b(opa[0], 0);
+        if (SUMS) {                                            // H1 of the NEXT tile (its x rows arrived a tile ago) -> the other buffer
+            hw = par ? bufH : bufH2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hacc[r] = b1v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f3_mfma32(hacc, xa[s], w1v[s]);
+        }
         const unsigned* mk1 = reinterpret_cast<const unsigned*>(smem + mk_off + par * 1024);             // layer 0 of the pair: h1
         auto fill_y = [&](int sl) {
             if (sl < 40 && sl % 5 == 0) {
@@ -525,7 +562,11 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             const int f = sl < 40 ? sl - sl / 5 - 1 : sl - 8;
             if ((PIML_F3_SKIP & 2) && f >= 1) return;
             if (f == 0) stage(par ^ 1);
-            else if (f >= 1 && f < 23) { if (!SUMS) g3_step(f - 1); }
+            else if (f >= 1 && f < 23) {
+                if (!SUMS) g3_step(f - 1);
+                else if (f == 3) f3_settle(hacc);              // (three products behind the f32 instructions of H1)
+                else if (f >= 4 && f < 22) h1_step(f - 4);
+            }
             else if (f >= 30 && f < 38) mk_step(f - 30, mk1);
         };
 #pragma unroll
@@ -555,10 +596,11 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
                 g2f[p] = (u32x4){x.x, x.y, y.x, y.y};
             }
         };
+        const u32x4* const hr = (SUMS && par) ? bufH2 : bufH;  // this tile's H1 pieces
         auto load_h = [&](u32x4 (&o)[3], int u_) {
             const int s_ = u_ >> 2, jb_ = u_ & 3;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) o[p] = bufH[((jb_ * 2 + s_) * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) o[p] = hr[((jb_ * 2 + s_) * 3 + p) * 64];
         };
         float tv[2][2];                                      // g_x: two features' G1 values of this lane's row, one step ahead
         float4 tw[2][2];                                     //      and their W1 columns

@@ -923,21 +923,21 @@ constexpr int CC_IB = 8;
 // smallest non-negative float x with sqrtf(x) >= th, i.e. "sqrtf(d2) < th"  <=>  "d2 < x" for the correctly rounded,
 // monotone sqrtf both sides use; ok = false when th is outside the range where the short search below is exact (the caller
 // then keeps the square root)
-__device__ __noinline__ float lt_cut2(float th, bool& ok) {
-    ok = th > 1e-18f && th < 1e18f;
-    if (!ok) return 0.f;
+// (the flag travels in the RETURN value -- a negative result = not exact here: by reference it was a stack slot, 16 B of scratch
+// per lane in every kernel that calls this deliberately not-inlined function)
+__device__ __noinline__ float lt_cut2(float th) {
+    if (!(th > 1e-18f && th < 1e18f)) return -1.f;
     float x = th * th;
 #pragma unroll 1
     for (int it = 0; it < 8 && sqrtf(x) >= th; ++it) x = __uint_as_float(__float_as_uint(x) - 1u);       // now sqrtf(x) < th
-    ok = sqrtf(x) < th;
+    if (!(sqrtf(x) < th)) return -1.f;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const float nx = __uint_as_float(__float_as_uint(x) + 1u);
         if (sqrtf(nx) >= th) return nx;
         x = nx;
     }
-    ok = false;
-    return 0.f;
+    return -1.f;
 }
 
 // limits of the pair test for T thresholds: lim[h] is compared with d2 (use_sqrt false) or with sqrtf(d2) (true)
@@ -947,9 +947,8 @@ __device__ __forceinline__ bool cc_limits(const float* __restrict__ thr, float (
     float c2[T];
 #pragma unroll
     for (int h = 0; h < T; ++h) {
-        bool ok;
-        c2[h] = lt_cut2(thr[h], ok);
-        all = all && ok;
+        c2[h] = lt_cut2(thr[h]);
+        all = all && c2[h] >= 0.f;
     }
 #pragma unroll
     for (int h = 0; h < T; ++h) lim[h] = all ? c2[h] : thr[h];
