@@ -1077,7 +1077,7 @@ def main():
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
     prof = None
-    pname = next((f for f in ('r04_step_counters.json', 'r03_step_counters.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+    pname = next((f for f in ('r05_step_counters.json', 'r04_step_counters.json', 'r03_step_counters.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
     if world == 1 and pname:
         pj = json.load(open(os.path.join(ROOT, 'profiles', pname)))
         if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
@@ -1108,9 +1108,9 @@ def main():
                     'enc_bwd_dw': (f'enc_bwd_{dw}_x3_kernel' if dw == 'dw2' else ('enc_bwd_dw_x3w_kernel' if x3 else 'enc_bwd_dw_kernel')), 'pinnsf_reduce': 'pinnsf_reduce_kernel', 'relfeat_bwd': 'relfeat_bwd_kernel'}
     if 'pinnsf_reduce' not in stage_us and stage_us:      # the slot sums rode in the relfeat backward's launch (ops.deferred_slot_sums)
         stage_kernel['relfeat_bwd'] = 'relfeat_bwd_reduce_kernel'
-    sums_path = 'pinnsf_unfold' in stage_us       # PIML_POOL_TRAIN: the network ran on the agents' sums of h2 (--messages 0, eval mode)
+    sums_path = 'enc_fwd_sum' in stage_us         # PIML_POOL_TRAIN: the network ran on the agents' sums of h2 (--messages 0, eval mode)
     if sums_path:
-        stage_kernel.update({'enc_fwd': 'enc_fwd_sum_x3_kernel', 'dec_fwd_head': 'dec_fwd_head_sum_kernel', 'pinnsf_unfold': 'pinnsf_unfold_kernel'})
+        stage_kernel.update({'enc_fwd_sum': 'enc_fwd_sum_x3_kernel', 'dec_fwd_head_sum': 'dec_fwd_head_sum_kernel', 'pinnsf_unfold': 'pinnsf_unfold_kernel'})
     if one_pass:
         stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
         if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':
@@ -1148,12 +1148,15 @@ def main():
                 e['hbm_bytes'] = sk.get('hbm_bytes')
                 e['hbm_frac'] = sk['hbm_bytes'] / (us * 1e-6) / (HBM_PEAK_GBS * 1e9) if sk.get('hbm_bytes') else None
                 if kname in split_kernels and sk.get('flops'):
-                    bf16 = 6.0 * sk['flops'] * (2 * 128 * 128) / (2 * 128 * 128 + 6 * 128)      # executed: 6 x the two 128 x 128 layers
+                    # executed bf16 flops: 6 x the 128 x 128 layers' (recorded with the counters; older profiles: two layers per row)
+                    bf16 = sk.get('executed_bf16_flops') or 6.0 * sk['flops'] * (2 * 128 * 128) / (2 * 128 * 128 + 6 * 128)
                     e['mfma_frac'] = bf16 / (us * 1e-6) / 2.5e15
                     e['bound'] = 'hbm' if (e['hbm_frac'] or 0) >= e['mfma_frac'] else 'mfma'
                     e['frac'] = max(e['hbm_frac'] or 0, e['mfma_frac'])
                 elif sk.get('flops'):
                     e['bound'], e['frac'] = 'mfma', sk['flops'] / (us * 1e-6) / (F32_MFMA_PEAK_TFS * 1e12)
+                elif sk.get('bound') == 'hbm':       # moves its bytes at more than half of the HBM peak: priced against that ceiling
+                    e['bound'], e['frac'], e['valu_busy_frac'] = 'hbm', e['hbm_frac'], sk.get('valu_busy_frac')
                 else:
                     e['bound'], e['valu_busy_frac'] = sk.get('bound'), sk.get('frac')
                 e['counters_source'] = prof_src

@@ -17,6 +17,17 @@
  *  - absent agents are NaN positions (the reference's sentinel, src/data/data.py:141-143),
  *    never compacted;
  *  - leading dimensions (channels, time) are flattened by the caller into C "slices".
+ *
+ * Where to start.  A host that replaces the reference's per-timestep path binds FIFTEEN of the entries below (INTEGRATION.md
+ * sections 2 - 4); everything else in this header is the same path cut into components (for hosts that keep parts of the
+ * reference's torch.nn network, and for the parity tests), and measurement plumbing / A-B switches live in piml_hip_tuning.h:
+ *   features      piml_relfeat_self_fwd / piml_relfeat_self_bwd   (get_relative_features + the self_features cat, both ways)
+ *                 piml_heading_fwd                                 (multi-frame windows: the temporal heading fill)
+ *   network       piml_pinnsf_pack / piml_pinnsf_fwd / piml_pinnsf_bwd   (PINNSF.forward and its autograd, three calls)
+ *   closed form   piml_mlapm_step_fwd / piml_mlapm_step_bwd_ws    (MLAPM.step and its analytic gradient)
+ *   collisions    piml_collision_counts / piml_collision_label     (collision_detection(...).sum(-1), calculate_collision_label)
+ *   integrator    piml_rollout_step / piml_train_step_fwd / piml_train_step_bwd   (the frame bodies of the two rollout loops)
+ *   multi-GPU     piml_allgather_state + piml_reducescatter_grad (RCCL), or piml_p2p_exchange (P2P stores, capturable)
  */
 #ifndef PIML_HIP_H
 #define PIML_HIP_H
@@ -547,38 +558,6 @@ int piml_dropout_keep_bits(unsigned long long* state, long long rows, int cols, 
                            void* stream);
 
 /*
- * HIP-event timer for measuring a kernel live on the stream it is launched on, also while
- * that stream is being captured into a hipGraph (the record then becomes an external
- * event-record node).  create -> record(start) -> [kernel launches] -> record(stop) ->
- * elapsed_ms (synchronises on `stop`).  Not a reference interface: measurement plumbing.
- */
-int piml_timer_create(void** event);
-int piml_timer_record(void* event, void* stream);
-int piml_timer_elapsed_ms(void* start, void* stop, float* ms);
-int piml_timer_destroy(void* event);
-
-/*
- * Stage trace (measurement plumbing, bench.py's live per-kernel times): between piml_trace_begin and piml_trace_end every
- * launch stage of the library records a HIP event behind its launch on the launch stream (never inside a stream
- * capture); piml_trace_mark adds a mark of the caller's (`name` must stay valid until piml_trace_end; the first mark is
- * the start).  piml_trace_end closes the trace, waits for the last mark and returns the number n of intervals:
- * us[i] = microseconds between mark i and mark i + 1, names = the '\n'-separated names of marks 1 .. n.  At most 64
- * marks.  Meaningful only when the stream is kept busy in front of the traced launches (else host gaps are included).
- */
-int piml_trace_begin(void);
-int piml_trace_mark(const char* name, void* stream);
-int piml_trace_end(char* names, int names_cap, float* us, int us_cap);
-
-/*
- * Diagnostic (tests only): evaluates, per element, the exact float32 arithmetic of the
- * neighbour-selection predicates -- dist = |r| as torch.norm computes it and
- * cos = torch.cosine_similarity(r, h) (src/data/data.py:434, 439-440) -- so that it can be
- * pinned bit-for-bit against the CPU restatement.  All arrays have n elements.
- */
-int piml_probe_arith(const float* rx, const float* ry, const float* hx, const float* hy,
-                     float* dist, float* cosv, int n, void* stream);
-
-/*
  * Fused PINNSF encoder on the matrix cores (piml_amd/csrc/encoder_x3.hip: f32 products as split bf16 products, the
  * default; piml_amd/csrc/encoder.hip: the f32 matrix instruction; see piml_encoder_products): the reference's
  *   ped_encoder / obs_encoder = MLP(in, [128, 128, 128]) (src/models/model.py:40-65, built at :1232-1236),
@@ -642,35 +621,6 @@ typedef struct piml_encoder_branch {
 /* floats of one partial slot / of one `packed` buffer */
 int piml_encoder_partial_floats(void);
 int piml_encoder_pack_floats(void);
-/* Up to this many 32-row tiles (both branches together) the forward runs with four waves per tile instead of one (few
- * rows: rollouts of real clips); the two forms are bitwise identical.  Returns the previous value; < 0 only queries. */
-long long piml_encoder_split_tiles(long long tiles);
-/* The same bound for a TRAINING pass (every branch carries relu_mask, i.e. a backward follows): default 48 tiles -- with the
- * one-pass backward the one-wave kernels win from the real clips' sizes on (122 agents = 62 tiles), while a lone forward still
- * wants four waves per tile up to piml_encoder_split_tiles().  piml_encoder_split_tiles(tiles >= 0) sets BOTH bounds (A/B),
- * piml_encoder_split_tiles(-2) puts both back to their defaults (environment PIML_ENC_SPLIT_TILES[_TRAIN] at load time).
- * Returns the previous value; < 0 only queries. */
-long long piml_encoder_split_tiles_train(long long tiles);
-/* Arithmetic of the two 128 x 128 layers' products.  1 (default): every f32 product as six bf16 x bf16 partial products of
- * exact three-way splits of both factors, accumulated in f32 (v_mfma_f32_32x32x16_bf16; what is dropped is below one f32
- * rounding of the product); 0: the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32).  Environment at load time:
- * PIML_ENC_PRODUCTS=f32.  Returns the previous value; < 0 only queries. */
-int piml_encoder_products(int split_bf16);
-/* Weight gradients of the split-product backward above piml_encoder_split_tiles() tiles: 1 (default) = layer-split
- * workgroups (piml_amd/csrc/encoder_dw2.hip: a workgroup takes ONE of the two 128 x 128 products over a longer slab --
- * half the partial bytes -- and recomputes h1 from x when the branches carry none), 0 = one slab and both products per
- * workgroup (enc_bwd_dw_x3_kernel).  Environment at load time: PIML_ENC_DW2=0.  Returns the previous value; < 0 queries. */
-int piml_encoder_dw2(int layer_split);
-/* One-pass backward above piml_encoder_split_tiles() tiles (piml_amd/csrc/encoder_bwd3.hip; reference: the autograd of
- * src/models/model.py:40-65 under :82-119): 1 (default) = where the layer-split weight gradients run, the forward left
- * `relu_mask` and the branches carry the same kinds of upstream gradients, the dX chain and dW2 / dW1 / db2 / db1 are ONE launch
- * that keeps the pre-activation gradients on the CU -- `g2` / `g1` are neither written nor read and may be NULL -- and dW3 /
- * db3 are the layer-0 workgroups of piml_encoder_dw2's kernel; 0 = the dX kernel writes g2 / g1 and the weight-gradient kernel
- * reads them back; 2 = the one-pass kernel as eight waves of 16-feature blocks (encoder_bwd4.hip, two waves per SIMD; measured
- * level with the four-wave form, kept for A/B).  In the one-pass forms dW3 / db3 are a second phase of the same launch
- * (PIML_ENC_FUSED_DW3=0: the layer-0 workgroups of piml_encoder_dw2's kernel in a launch of their own).  Environment at load
- * time: PIML_ENC_FUSED_BWD=0 / 1 / 2.  Returns the previous value; < 0 only queries. */
-int piml_encoder_fused_bwd(int on);
 /* (re)fill `packed` from the weights; piml_encoder_fwd does this itself, piml_encoder_bwd expects it done */
 int piml_encoder_pack(const piml_encoder_branch* branches, int nbranches, void* stream);
 /* total workgroups of a launch over these branches; *wg_branch0 = how many of them serve branch 0 (the rest serve
@@ -894,7 +844,6 @@ int piml_pinnsf_pool_train_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */
-int piml_pinnsf_streams_init(void);
 int piml_pinnsf_pack(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,
                      const piml_collision_head* head, int flags, void* stream);
 int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbranches,

@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void pinnsf_unfold_kernel(ReduceAll R) {
     }
 }
 
+// (Round 5, built, parity green, measured and removed: the unfold as workgroups of the launch that sums the slots, gated by a
+// device-side ticket the decoder sets' sum workgroups raise -- sums written with device-scope stores, unfold reads through LDS in
+// one round of device-scope loads.  At the tail of the launch the chain [sums, ticket, uncached loads, products] ran 19 - 21 us
+// against 9.4 + 4.7 as two launches; dispatched early -- right behind the decoder sets -- the 258 polling workgroups cost the
+// launch more still, 33 us; an ACQUIRE in the poll invalidates the XCD's L2 on every round: 49 us.  Two launches it stays.)
 int launch_unfold(const ReduceAll& R, hipStream_t s) {
     if (R.nunf <= 0) return hipSuccess;
     hipLaunchKernelGGL(pinnsf_unfold_kernel, dim3(kUnfoldBlocks, (unsigned)R.nunf), dim3(256), 0, s, R);
@@ -343,9 +348,9 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
             if (dec[i].pooled != enc[i].sum_a || dec[i].msgs != enc[i].sum_b) return hipErrorInvalidValue;
         if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
         PIML_TRY(enc_stage_fwd_sum(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
-        trace_mark("enc_fwd", m);
+        trace_mark("enc_fwd_sum", m);
         PIML_TRY(dec_stage_fwd_sum(dec, nbr, head, self_features, tau, acc, m));
-        trace_mark("dec_fwd_head", m);
+        trace_mark("dec_fwd_head_sum", m);
         return hipSuccess;
     }
     if (flags & PIML_POOL_H2) {               // inference: the agents' sums of h2 instead of the messages (see the header)

@@ -8,15 +8,27 @@ import pytest
 from conftest import REPO
 
 
-def declared_symbols():
-    text = open(os.path.join(REPO, 'include', 'piml_hip.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(piml_[a-z0-9_]+)\s*\(', text)))
+HEADERS = ('piml_hip.h', 'piml_hip_tuning.h')      # the drop-in boundary | measurement plumbing, diagnostics, A/B switches
+
+
+def declared_symbols(headers=HEADERS):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(REPO, 'include', h)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        out |= set(re.findall(r'\b(piml_[a-z0-9_]+)\s*\(', text))
+    return sorted(out)
 
 
 def test_header_declares_entry_points():
     syms = declared_symbols()
     assert {'piml_relfeat_fwd', 'piml_relfeat_bwd', 'piml_heading_fwd', 'piml_abi_version'} <= set(syms)
+    # the boundary header carries no switch and no measurement helper; the tuning header nothing a host has to call
+    stable, tuning = set(declared_symbols(HEADERS[:1])), set(declared_symbols(HEADERS[1:]))
+    assert not (stable & tuning)
+    assert {'piml_encoder_split_tiles', 'piml_encoder_products', 'piml_trace_begin', 'piml_timer_create', 'piml_probe_arith'} <= tuning
+    assert {'piml_relfeat_self_fwd', 'piml_pinnsf_fwd', 'piml_pinnsf_bwd', 'piml_mlapm_step_fwd', 'piml_collision_counts',
+            'piml_p2p_exchange', 'piml_allgather_state'} <= stable
 
 
 def test_library_exports_every_declared_symbol():

@@ -66,7 +66,12 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'head_fwd_kernel': 2 * N * KP * (128 * 64 + 64),
     # decoder tails of both branches + the collision head on the pedestrian rows, one launch
     'dec_fwd_head_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2) + 2 * N * KP * (128 * 64 + 64),
+    # round 5, training on the agents' sums of h2 (PIML_POOL_TRAIN): the forward stops after layer 2, the backward has neither the
+    # W3^T chain layer nor dW3 (chain layer B + dW2 + dW1), decoder tails on the sums + the head on h2 rows (folded first layers)
+    'enc_fwd_sum_x3_kernel': 2 * ROWS * (6 * 128 + 128 * 128),
+    'dec_fwd_head_sum_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2) + 2 * N * KP * (128 * 64 + 64),
 }
+SUMS_BWD_FLOPS = 2 * ROWS * (2 * 128 * 128 + 2 * 6 * 128)      # enc_bwd_fused_x3_kernel<..., SUMS = true>
 
 
 def short(name):
@@ -77,7 +82,7 @@ def short(name):
 
 steps_profiled = None
 for r in rows:
-    if 'enc_fwd_kernel' in r['Name'] or 'enc_fwd_x3_kernel' in r['Name']:
+    if 'enc_fwd_kernel' in r['Name'] or 'enc_fwd_x3_kernel' in r['Name'] or 'enc_fwd_sum_x3_kernel' in r['Name']:
         steps_profiled = int(r['Calls'])
 kernels, step_hbm, step_us = [], 0.0, 0.0
 for r in rows:
@@ -90,16 +95,21 @@ for r in rows:
     hbm = 2 * fetch.get(name, {}).get('FETCH_SIZE', 0.0) * 1024 + write.get(name, {}).get('WRITE_SIZE', 0.0) * 1024
     c = sq.get(name, {})
     e = {'name': key, 'us': round(us, 2), 'launches_per_step': round(per_step, 2), 'hbm_bytes': round(hbm)}
+    sums_bwd = key == 'enc_bwd_fused_x3_kernel' and name.rstrip().endswith('true>(piml::F3Args)')      # the SUMS template flag
     if key in FLOPS and '_x3_' in key:
         # f32 arithmetic carried by six bf16 matrix instructions per k-block: priced against BOTH ceilings, the larger
-        # fraction names the bound.  Executed bf16 FLOPs = 6 x the two 128 x 128 layers' (the K <= 8 layer stays f32 / VALU).
-        bf16_flops = 6 * 2 * ROWS * 2 * 128 * 128 * (2 if 'fused' in key else 1)
+        # fraction names the bound.  Executed bf16 FLOPs = 6 x the 128 x 128 layers' (the K <= 8 layer stays f32 / VALU):
+        # two per row in the message forward and in the sums backward, four in the message backward, one in the sums forward.
+        layers = 1 if key == 'enc_fwd_sum_x3_kernel' else (2 if (sums_bwd or 'fused' not in key) else 4)
+        bf16_flops = 6 * 2 * ROWS * 128 * 128 * layers
+        if sums_bwd:
+            FLOPS[key] = SUMS_BWD_FLOPS
         mfma_frac = bf16_flops / (us * 1e-6) / BF16_MFMA_PEAK
         hbm_frac = hbm / (us * 1e-6) / HBM_PEAK
         e.update(bound='hbm' if hbm_frac >= mfma_frac else 'mfma', frac=round(max(hbm_frac, mfma_frac), 3),
                  hbm_frac=round(hbm_frac, 3), achieved_gbs=round(hbm / us / 1e3, 1),
                  mfma_frac=round(mfma_frac, 3), executed_bf16_tflops=round(bf16_flops / us / 1e6, 1), peak_bf16_tflops=2500.0,
-                 flops=FLOPS[key], f32_equivalent_tflops=round(FLOPS[key] / us / 1e6, 1))
+                 flops=FLOPS[key], f32_equivalent_tflops=round(FLOPS[key] / us / 1e6, 1), executed_bf16_flops=bf16_flops)
         if c.get('SQ_BUSY_CU_CYCLES'):
             e['mfma_pipe_busy_of_cu_busy'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
     elif key in FLOPS:
@@ -108,9 +118,14 @@ for r in rows:
         if c.get('SQ_BUSY_CU_CYCLES'):
             e['mfma_pipe_busy_of_cu_busy'] = round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
     elif c.get('SQ_BUSY_CU_CYCLES'):
-        # SQ_ACTIVE_INST_VALU counts quad-cycles; 4 SIMDs per CU
-        e.update(bound='valu' if 'relfeat_fwd' in key else 'latency',
-                 frac=round(4 * c['SQ_ACTIVE_INST_VALU'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3))
+        # SQ_ACTIVE_INST_VALU counts quad-cycles; 4 SIMDs per CU.  A kernel that moves its bytes at more than half of the HBM
+        # peak is bandwidth-bound whatever its issue rate (the slot sums inside relfeat_bwd_reduce_kernel)
+        hbm_frac = hbm / (us * 1e-6) / HBM_PEAK
+        valu = round(4 * c['SQ_ACTIVE_INST_VALU'] / (4 * c['SQ_BUSY_CU_CYCLES']), 3)
+        if hbm_frac >= 0.5:
+            e.update(bound='hbm', frac=round(hbm_frac, 3), hbm_frac=round(hbm_frac, 3), achieved_gbs=round(hbm / us / 1e3, 1), valu_busy_frac=valu)
+        else:
+            e.update(bound='valu' if 'relfeat_fwd' in key else 'latency', frac=valu, hbm_frac=round(hbm_frac, 3))
     kernels.append(e)
     step_hbm += hbm * per_step
     step_us += us * per_step
@@ -150,7 +165,8 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
     for e in kernels:
         fr = e.get('frac')
         what = {'mfma': f'{e.get("achieved_tflops")} TF/s = {fr} of 157.3 TF f32 MFMA', 'valu': f'{fr} of the SIMD issue cycles (VALU)',
-                'latency': f'VALU {fr} (launch / latency bound)'}.get(e.get('bound'), '')
+                'hbm': f'HBM {e.get("achieved_gbs")} GB/s = {fr} of 8 TB/s',
+                'latency': f'VALU {fr}, HBM {e.get("hbm_frac")} (launch / latency bound)'}.get(e.get('bound'), '')
         if '_x3_' in e['name']:
             what = (f'HBM {e["achieved_gbs"]} GB/s = {e["hbm_frac"]} of 8 TB/s; bf16 matrix pipe {e["executed_bf16_tflops"]} TF/s executed = '
                     f'{e["mfma_frac"]} of 2.5 PF ({e["f32_equivalent_tflops"]} TF/s of f32 work)')
