@@ -1196,6 +1196,11 @@ def main():
                                    ', forward+backward PINSF step (HIP relfeat fwd/bwd + PINNSF_multitask fwd/bwd)',
                        'agents_per_gpu': n_own, 'agents_total': N_real, 'obstacle_points': M_eff,
                        'pairs_per_step': pairs_step, 'topk_ped': 6, 'topk_obs': 10,
+                       'messages': ('materialised (--messages 1: model(...)[1:3] returned, the message path)' if args.messages else
+                                    'on request only (model.messages_wanted = False: every output and gradient the step reads is '
+                                    'produced; the neighbour-axis sum runs in front of the encoders\' last layer, which is folded '
+                                    'into the decoders\' first layer -- DESIGN.md 5, tests/test_sums_gpu.py; --messages 1 times the other form)' +
+                                    (' [train mode: a dropout mask sits between that layer and the sum, so this step computes the messages internally]' if args.train_mode else '')),
                        'sharding': 'single GPU' if not use_dist else
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -1214,7 +1219,7 @@ def main():
                          'kernels_with_vgpr_spills_note': 'every kernel of libpiml_hip.so with a non-zero .vgpr_spill_count in its code '
                                                           'object (kernels[].registers: the same source; vgprs = .vgpr_count, which counts '
                                                           'architectural + accumulation registers together); both are A/B forms the default dispatch does not launch '
-                                                          '(PIML_DEC_BWD_SPLIT=0, PIML_ENC_FUSED_BWD=2; profiles/r04_kernel_usage.md)'},
+                                                          '(PIML_DEC_BWD_SPLIT=0, PIML_ENC_FUSED_BWD=2; profiles/r05_kernel_usage.md)'},
         }
     import threading
     written = threading.Lock()

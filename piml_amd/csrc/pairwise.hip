@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void collision_counts_from_totals_kernel(const
 // tests per frame instead of N^2.  PASS 0 adds every colliding ordered pair to totals[h][i][j] (integer atomics: exact in any
 // order); PASS 1 (a second launch) finds the same pairs again and counts those with 0 < total <= 25 (friends rule,
 // data.py:587-591).  Coordinates beyond 1e5 cells (or a non-finite cell size) make the frame's workgroup walk all pairs.
-// 750 x 1024: 0.97 ms (tiled two-sweep form above) -> see DESIGN.md 4.7.
+// 750 x 1024: 0.97 ms (tiled two-sweep form above) -> see DESIGN_HISTORY.md 4.7.
 constexpr int CG_DIM = 32, CG_CELLS = CG_DIM * CG_DIM;
 
 template <int T, int PASS>

@@ -571,7 +571,7 @@ class _PINNSFBase(nn.Module):
             spec = None
             if ped_ok and obs_ok and tuple(ped_features.shape[:-2]) == tuple(obs_features.shape[:-2]):
                 # BOTH encoders in one launch per direction -- the row count of the many-rows kernels and of the one-pass
-                # backward (DESIGN.md 4.2d) instead of two few-rows launches.  A launch applies one KIND of mask to all its
+                # backward (DESIGN.md 4.5) instead of two few-rows launches.  A launch applies one KIND of mask to all its
                 # branches: in train mode the obstacle branch's bits are drawn up front (ops.dropout_keep_bits, one small
                 # launch) and the pedestrian branch, whose raw output the corrector reads, gets an all-ones mask
                 from .. import ops
