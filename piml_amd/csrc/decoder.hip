@@ -41,6 +41,21 @@ struct DecArgs {
                                   // back to `pooled` for the backward's dW1
 };
 
+#ifdef PIML_DEC_STAMPS
+// diagnostic build only (tools/dec_stamps.py): shader-clock stamps of thread 0 of every workgroup of the LAST decoder launch,
+// `wait` = drain the memory counters first, so that the stamp marks the arrival of everything requested so far
+__device__ unsigned long long g_dec_stamps[1024 * 16];
+#define DEC_STAMP(i, wait)                                                                         \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_dec_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define DEC_STAMP(i, wait)
+#endif
+
 __device__ __forceinline__ f32x16 dmfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -385,6 +400,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
 #pragma unroll
         for (int t = 0; t < 8; ++t) t1f[t] = PK[((!ROWS && A.pool_h2 == 2) ? DP_T1F : DP_T1) / 4 + (blk * 8 + t) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);           // the loads stay up here
+        if (SPLIT) { DEC_STAMP(1, false); DEC_STAMP(2, true); }
         f32x16 g2, g1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { g2[r] = 0.f; g1[r] = 0.f; }
@@ -419,8 +435,10 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[bi][ob][kh][r][lane] = g1[r];
+        if (SPLIT) DEC_STAMP(3, true);
     }
     __syncthreads();
+    if (SPLIT) DEC_STAMP(4, false);
     if (active) {
     float g1c[2][16];
 #pragma unroll
@@ -478,6 +496,7 @@ __device__ __forceinline__ void dec_bwd_dx_body(const DecArgs& A, long long tile
         }
     }
     }
+    if (SPLIT) DEC_STAMP(5, true);
     // desired-force backward (pinnsf_epilogue_bwd_kernel's arithmetic), one lane per agent
     if (!ROWS && wave == 0 && b == 0 && h == 0 && valid && A.g_self && A.self_features) {
         const float dx = sfv[0], dy = sfv[1], v0 = sfv[4], tau = A.tau;
@@ -566,58 +585,103 @@ __device__ __forceinline__ void dec_bwd_dw_body(const DecArgs& A, int b, int p, 
 
 // The same partials by FOUR waves (the (tile, branch) workgroups of dec_bwd_split_kernel): wave w owns blocks (0, w) and
 // (1, w) of dW1 (they share the pooled-column operand), block (w >> 1, w & 1) of dW2, waves 0 / 1 column block w of dW3.
-__device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p, int w, int lane, const float* keep_g2 = nullptr,
-                                                 const float* keep_g1 = nullptr) {
+__device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p, int w, int lane, const float* keep_g2, const float* keep_g1) {
+    // keep_g2 / keep_g1: the tile's gradients from the dX chain of the same workgroup (LDS [agent][64], zero past the end).
+    // Round 5 (in-kernel stamps, tools/dec_stamps.py): as one loop with 64-bit clamped row indices, per-lane predicated loads and a
+    // run-time choice of the gradients' source, REQUESTING the operands took 4.6 k of the workgroup's 26 k clocks and the slot stores
+    // 2.3 k -- 40 clocks per memory instruction, all address arithmetic and branches.  Now: one base pointer per operand, a full slab
+    // (wave-uniform) addressed by compile-time offsets, wave-uniform branches around the waves' optional third product.
     const piml_decoder_branch J = b ? A.br[1] : A.br[0];
     const long long R = J.agents;
     const long long s0 = (long long)p * DEC_SLAB < R ? (long long)p * DEC_SLAB : R;
-    const long long s1e = s0 + DEC_SLAB < R ? s0 + DEC_SLAB : R;
+    const int n = (int)(R - s0 < DEC_SLAB ? R - s0 : DEC_SLAB);          // agents of the slab (wave-uniform)
+    const long long sb = n > 0 ? s0 : 0;
     const int i = lane & 31, h = lane >> 5;
     const int mb2 = w >> 1, nb2 = w & 1;
     const bool do3 = w < 2;
+    constexpr int U = DEC_SLAB / 2;
+    const float* __restrict__ pooled0 = J.pooled + sb * DH + 32 * w + i;
+    const float* __restrict__ h10 = J.h1 + sb * DD + 32 * nb2 + i;
+    const float* __restrict__ d20 = J.d2 + sb * DD + 32 * nb2 + i;
+    const float* __restrict__ gp0 = A.g_pred + sb * 2 + (i & 1);
+    const float* kg1 = keep_g1 + h * DD + i;
+    const float* kg2 = keep_g2 + h * DD + 32 * mb2 + i;
+    float a1a[U], a1b[U], b1[U], a2[U], b2[U], a3[U], b3[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                 // every load of the slab is issued before its first MFMA
+        a1a[u] = kg1[2 * u * DD];
+        a1b[u] = kg1[2 * u * DD + 32];
+        a2[u] = kg2[2 * u * DD];
+        a3[u] = 0.f; b3[u] = 0.f;
+    }
+    if (n == DEC_SLAB) {
+        const float* pb = pooled0 + h * DH;
+        const float* hb = h10 + h * DD;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { b1[u] = pb[2 * u * DH]; b2[u] = hb[2 * u * DD]; }
+        if (do3) {
+            const float* db = d20 + h * DD;
+            const float* gb = gp0 + h * 2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { b3[u] = db[2 * u * DD]; a3[u] = gb[4 * u]; }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {             // rows past the end read the slab's first row; their products are masked
+            const int rc = 2 * u + h < n ? 2 * u + h : 0;
+            b1[u] = pooled0[rc * DH]; b2[u] = h10[rc * DD];
+        }
+        if (do3) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rc = 2 * u + h < n ? 2 * u + h : 0;
+                b3[u] = d20[rc * DD]; a3[u] = gp0[rc * 2];
+            }
+        }
+    }
+    DEC_STAMP(8, false);
+    DEC_STAMP(9, true);
     f32x16 c1a, c1b, c2, c3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c1a[r] = 0.f; c1b[r] = 0.f; c2[r] = 0.f; c3[r] = 0.f; }
     float s1a = 0.f, s1b = 0.f, s2 = 0.f, s3 = 0.f;
-    constexpr int U = DEC_SLAB / 2;
-    float a1a[U], a1b[U], b1[U], a2[U], b2[U], a3[U], b3[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {                 // every load of the slab is issued before its first MFMA
-        const long long row = s0 + 2 * u + h;
-        const bool ok = row < s1e;
-        const long long ro = ok ? row : (s0 < R ? s0 : 0);
-        if (keep_g1) {                 // the tile's gradients from the dX chain of the same workgroup (LDS, zero past the end)
-            a1a[u] = keep_g1[(2 * u + h) * DD + i];
-            a1b[u] = keep_g1[(2 * u + h) * DD + 32 + i];
-            a2[u] = keep_g2[(2 * u + h) * DD + 32 * mb2 + i];
-        } else {
-            a1a[u] = J.g_pre1[ro * DD + i];
-            a1b[u] = J.g_pre1[ro * DD + 32 + i];
-            a2[u] = J.g_pre2[ro * DD + 32 * mb2 + i];
-        }
-        b1[u] = J.pooled[ro * DH + 32 * w + i];
-        b2[u] = J.h1[ro * DD + 32 * nb2 + i];
-        a3[u] = (do3 && i < 2) ? A.g_pred[ro * 2 + i] : 0.f;
-        b3[u] = do3 ? J.d2[ro * DD + 32 * nb2 + i] : 0.f;
-    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const bool ok = s0 + 2 * u + h < s1e;
-        const float xa = ok ? a1a[u] : 0.f, xb = ok ? a1b[u] : 0.f, x2 = ok ? a2[u] : 0.f, x3 = ok ? a3[u] : 0.f;
-        c1a = dmfma(xa, b1[u], c1a);
-        c1b = dmfma(xb, b1[u], c1b);
-        c2 = dmfma(x2, b2[u], c2);
-        if (do3) c3 = dmfma(x3, b3[u], c3);
-        s1a += xa; s1b += xb; s2 += x2; s3 += x3;
+        c1a = dmfma(a1a[u], b1[u], c1a);
+        c1b = dmfma(a1b[u], b1[u], c1b);
+        c2 = dmfma(a2[u], b2[u], c2);
+        s1a += a1a[u]; s1b += a1b[u]; s2 += a2[u];
+    }
+    if (do3) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float x3 = (i < 2 && 2 * u + h < n) ? a3[u] : 0.f;        // g_pred has two columns
+            c3 = dmfma(x3, b3[u], c3);
+            s3 += x3;
+        }
     }
     float* P = J.partials + (size_t)p * DEC_PART;
+    DEC_STAMP(10, false);
+    {   // (the stamp must see the products done: read one accumulator)
+#ifdef PIML_DEC_STAMPS
+        asm volatile("v_mov_b32 %0, %0" : "+v"(c1a[0]));
+        DEC_STAMP(11, false);
+#endif
+    }
+    {
+        float* P1 = P + (size_t)(4 * h) * DH + 32 * w + i;                       // row rho(r) + 4 h of dW1's halves
+        float* P2 = P + DD * DH + (32 * mb2 + 4 * h) * DD + 32 * nb2 + i;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
-        P[(size_t)ri * DH + 32 * w + i] = c1a[r];
-        P[(size_t)(32 + ri) * DH + 32 * w + i] = c1b[r];
-        P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = c2[r];
-        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = c3[r];
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            P1[rr * DH] = c1a[r];
+            P1[(32 + rr) * DH] = c1b[r];
+            P2[rr * DD] = c2[r];
+        }
+        if (do3 && h == 0) {                                                       // dW3's two rows are registers 0 and 1 of half 0
+            float* P3 = P + DD * DH + DD * DD + 32 * nb2 + i;
+            P3[0] = c3[0]; P3[DD] = c3[1];
+        }
     }
     s1a += __shfl_xor(s1a, 32, 64);
     s1b += __shfl_xor(s1b, 32, 64);
@@ -629,6 +693,8 @@ __device__ __forceinline__ void dec_bwd_dw_body4(const DecArgs& A, int b, int p,
         if (nb2 == 0) Pb[DD + 32 * mb2 + i] = s2;                  // waves 0 and 2
         if (w == 0 && i < 8) Pb[2 * DD + i] = i < 2 ? s3 : 0.f;    // db3 + padding
     }
+    DEC_STAMP(12, false);
+    DEC_STAMP(13, true);
 }
 
 // dX chain + weight-gradient partials per (32-agent tile, branch): 2 x tiles workgroups of four waves
@@ -639,8 +705,11 @@ __global__ __launch_bounds__(256) void dec_bwd_split_kernel(DecArgs A) {
     // g_pre2 / g_pre1 of the tile never leave the workgroup: the dX chain leaves them in LDS ([agent][64]) and the weight-gradient
     // products read them there -- no stores to drain in front of the barrier, no round trip through L2 behind it (round 4)
     __shared__ __align__(16) float keep[2][32 * DD];
+    DEC_STAMP(0, false);
     dec_bwd_dx_body<false, true>(A, tile, b, keep[0], keep[1]);
+    DEC_STAMP(6, false);
     __syncthreads();
+    DEC_STAMP(7, false);
     dec_bwd_dw_body4(A, b, (int)tile, uniform((int)(threadIdx.x >> 6)), threadIdx.x & 63, keep[0], keep[1]);
 }
 
@@ -1216,6 +1285,12 @@ static bool dec_branch_ok(const piml_decoder_branch& b) {
 static int dec_dw_workgroups(long long agents) { return (int)((agents + DEC_SLAB - 1) / DEC_SLAB); }
 
 }  // namespace piml
+
+#ifdef PIML_DEC_STAMPS
+extern "C" __attribute__((visibility("default"))) int piml_dec_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(piml::g_dec_stamps), sizeof(unsigned long long) * 1024 * 16);
+}
+#endif
 
 using namespace piml;
 
