@@ -194,6 +194,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
         __syncthreads();
     }
     float4 pv[2][4];
+    if (SPLIT && !POOL && !ROWS) DEC_STAMP(0, false);
     if (active) {
         // ---- layer 1 partial: features of block ob, contraction over input blocks 2 kh, 2 kh + 1 ----
         if (POOL) {
@@ -210,6 +211,9 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pv[bl][q] = *reinterpret_cast<const float4*>(base + dfeat0(2 * kh + bl, q, h));
             if (!ROWS && A.pool_h2) {
+                // (round 5, measured and dropped: the second parts requested for every lane together with the first parts, instead of a
+                // branch on the straddlers -- one round trip less on paper, 12.8 -> 13.8 us in fact: this launch is bound by the bytes its
+                // waves pull through the CUs' L1s at its start, and that form pulls a quarter more)
                 const long long g0 = (valid ? agent : 0) * J.k;
                 if (valid && (g0 >> 5) != ((g0 + J.k - 1) >> 5)) {          // the agent's rows straddle two tiles: + its second part
                     const float* more = J.msgs + agent * DH;
@@ -232,6 +236,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
             a1[4 * q + 2] = kh ? 0.f : bq.z; a1[4 * q + 3] = kh ? 0.f : bq.w;
         }
         __builtin_amdgcn_sched_barrier(0);       // every load above is in flight before the first MFMA
+        if (SPLIT && !POOL && !ROWS) { DEC_STAMP(1, false); DEC_STAMP(2, true); }
 #pragma unroll
         for (int bl = 0; bl < 2; ++bl)
 #pragma unroll
@@ -244,8 +249,10 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
             }
 #pragma unroll
         for (int r = 0; r < 16; ++r) part1[bi][ob][kh][r][lane] = a1[r];
+        if (SPLIT && !POOL && !ROWS) DEC_STAMP(3, true);
     }
     __syncthreads();
+    if (SPLIT && !POOL && !ROWS) DEC_STAMP(4, false);
     if (active) {
         // training on the sums (pool_h2 == 2): the completed sum is the backward's layer-1 input (dW1 = g_pre1^T pooled); written
         // behind the barrier, when every wave of the workgroup has finished reading the first parts
@@ -285,8 +292,10 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) part2[bi][ob][kh][r][lane] = a2[r];
+        if (SPLIT && !POOL && !ROWS) DEC_STAMP(5, true);
     }
     __syncthreads();
+    if (SPLIT && !POOL && !ROWS) DEC_STAMP(6, false);
     if (active && ob == 0) {
         // ---- predictor partial over decoder-output block kh (M padded to 32: component c = register c of the h = 0 lanes) ----
         float y[16];
@@ -311,8 +320,10 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
             a3 = dmfma(w.w, y[4 * q + 3], a3);
         }
         if (h == 0) { part3[bi][kh][0][j] = a3[0]; part3[bi][kh][1][j] = a3[1]; }
+        if (SPLIT && !POOL && !ROWS) DEC_STAMP(7, true);
     }
     __syncthreads();
+    if (SPLIT && !POOL && !ROWS) DEC_STAMP(8, false);
     if (ROWS) {
         if ((wave & 3) == 0 && h == 0 && agent < J.agents)
             reinterpret_cast<float2*>(J.pred)[agent] = make_float2(part3[0][0][0][j] + part3[0][1][0][j],
@@ -341,6 +352,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
             reinterpret_cast<float2*>(A.acc)[agent] = make_float2(ax, ay);
         }
     }
+    if (SPLIT && !POOL && !ROWS) DEC_STAMP(9, true);
 }
 
 __global__ __launch_bounds__(512) void dec_fwd_kernel(DecArgs A) { dec_fwd_body<false>(A, blockIdx.x); }
@@ -1202,41 +1214,92 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, lo
 // 128 values are split once (lane (row, g): features 16 kb + 8 g + t of k-block kb, the order of the packed W1 pieces);
 // W1's pieces stream from the packed image (L2), one k-block ahead.  PIML_HEAD_PRODUCTS=f32 keeps the f32 instruction.
 // FOLD (PIML_POOL_TRAIN): the rows are h2 rows and W1 / b1 the images with the encoder's last layer folded in (pack.hpp: HP_X3F / HP_BF)
-template <int WAVES = 4, bool FOLD = false>
+// LDSW (round 5; the launches that pair the head with the decoder tails): the four waves of a workgroup read the SAME 48 KB of
+// weight pieces; streamed from L2 by every wave they were three quarters of what the launch pulled through the CUs' L1s at its
+// start (in-kernel stamps, tools/dec_stamps_fwd.py: issuing a head wave's first 25 loads took 9 k clocks, its sixteen k-blocks
+// 13 k for 3 k of products).  The workgroup now stages k-block groups 0 .. HEAD_LDS_GROUPS - 1 in LDS once (`wlds`, dynamic shared
+// memory) and reads the last group from L2 as before: fifteen groups = 45 KB is what fits beside the decoder body's static 33 KB
+// with two workgroups per CU.
+constexpr int HEAD_LDS_GROUPS = 15;
+constexpr int HEAD_LDS_BYTES = HEAD_LDS_GROUPS * 3 * 64 * 16;
+template <int WAVES = 4, bool FOLD = false, bool LDSW = false>
 __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs, long long rows,
-                                                 const float* __restrict__ packed, float* __restrict__ out, long long bx) {
+                                                 const float* __restrict__ packed, float* __restrict__ out, long long bx,
+                                                 u32x4* wlds = nullptr) {
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const long long row = (bx * WAVES + wave) * 32 + j;
-    if ((bx * WAVES + wave) * 32 >= rows) return;
+    const bool idle = (bx * WAVES + wave) * 32 >= rows;
+    if (!LDSW && idle) return;
     const bool valid = row < rows;
     const float* bias = packed + (FOLD ? HP_BF : HP_B);
-    const u32x4* W = reinterpret_cast<const u32x4*>(packed + (FOLD ? HP_X3F : HP_X3)) + lane;      // [ob][kb][piece] 64 apart
-    u32x4 wf[2][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) wf[0][p] = W[p * 64];
-    u32x4 xh[8], xm[8], xl[8];
+    const u32x4* Wg = reinterpret_cast<const u32x4*>(packed + (FOLD ? HP_X3F : HP_X3));       // [ob][kb][piece] 64 apart
+    const u32x4* W = Wg + lane;
+    constexpr int HEAD_PF = 2;
+    u32x4 wf[HEAD_PF][3];
+    if (FOLD) DEC_STAMP(0, false);
+    // the row's 128 values first (their split overlaps the wait for the weights)
+    float4 v[8][2];
     {
         const float* base = msgs + (valid ? row : 0) * DH + 8 * h;
-        float4 v[8][2];
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
             v[kb][0] = *reinterpret_cast<const float4*>(base + 16 * kb);
             v[kb][1] = *reinterpret_cast<const float4*>(base + 16 * kb + 4);
         }
+    }
+    // biases and second-layer weights of both output blocks too: left at their uses they were four more exposed round trips
+    float4 bq[2][4], w2q[2][4];
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) {
-            unsigned hi[4], mid[4], lo[4];
-            split3(v[kb][0].x, v[kb][0].y, hi[0], mid[0], lo[0]);
-            split3(v[kb][0].z, v[kb][0].w, hi[1], mid[1], lo[1]);
-            split3(v[kb][1].x, v[kb][1].y, hi[2], mid[2], lo[2]);
-            split3(v[kb][1].z, v[kb][1].w, hi[3], mid[3], lo[3]);
-            xh[kb] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-            xm[kb] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
-            xl[kb] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[ob][q] = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+            w2q[ob][q] = *reinterpret_cast<const float4*>(packed + HP_W2 + dfeat0(ob, q, h));
         }
+    const float b2s = packed[HP_B + 64];
+    u32x4 wtail[3];
+    if (LDSW) {
+        constexpr int N4 = HEAD_LDS_GROUPS * 3 * 64, ROUNDS = (N4 + WAVES * 64 - 1) / (WAVES * 64);
+        u32x4 st[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int e = r * WAVES * 64 + (int)threadIdx.x;
+            st[r] = Wg[e < N4 ? e : 0];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wtail[p] = W[(HEAD_LDS_GROUPS * 3 + p) * 64];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int e = r * WAVES * 64 + (int)threadIdx.x;
+            if (e < N4) wlds[e] = st[r];
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[0][p] = W[p * 64];
+    }
+    if (FOLD) { DEC_STAMP(1, false); DEC_STAMP(2, true); }
+    u32x4 xh[8], xm[8], xl[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        unsigned hi[4], mid[4], lo[4];
+        split3(v[kb][0].x, v[kb][0].y, hi[0], mid[0], lo[0]);
+        split3(v[kb][0].z, v[kb][0].w, hi[1], mid[1], lo[1]);
+        split3(v[kb][1].x, v[kb][1].y, hi[2], mid[2], lo[2]);
+        split3(v[kb][1].z, v[kb][1].w, hi[3], mid[3], lo[3]);
+        xh[kb] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        xm[kb] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+        xl[kb] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    }
+    const u32x4* WL = wlds + lane;
+    if (LDSW) {
+        __syncthreads();
+        if (idle) return;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wf[0][p] = WL[p * 64];
     }
     float dot = 0.f;
+    if (FOLD) DEC_STAMP(3, false);
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
         f32x16 acc, sm;
@@ -1244,27 +1307,29 @@ __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs,
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
-            acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+            acc[4 * q] = bq[ob][q].x; acc[4 * q + 1] = bq[ob][q].y; acc[4 * q + 2] = bq[ob][q].z; acc[4 * q + 3] = bq[ob][q].w;
         }
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
             const int g = ob * 8 + kb;
             if (g + 1 < 16) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wf[(g + 1) & 1][p] = W[((g + 1) * 3 + p) * 64];
+                for (int p = 0; p < 3; ++p)
+                    wf[(g + 1) & 1][p] = !LDSW ? W[((g + 1) * 3 + p) * 64] : (g + 1 < HEAD_LDS_GROUPS ? WL[((g + 1) * 3 + p) * 64] : wtail[p]);
             }
             kblock_x3(acc, sm, wf[g & 1][0], wf[g & 1][1], wf[g & 1][2], xh[kb], xm[kb], xl[kb]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w2 = *reinterpret_cast<const float4*>(packed + HP_W2 + dfeat0(ob, q, h));
+            const float4 w2 = w2q[ob][q];
             dot += w2.x * fmaxf(acc[4 * q] + sm[4 * q], 0.f) + w2.y * fmaxf(acc[4 * q + 1] + sm[4 * q + 1], 0.f) +
                    w2.z * fmaxf(acc[4 * q + 2] + sm[4 * q + 2], 0.f) + w2.w * fmaxf(acc[4 * q + 3] + sm[4 * q + 3], 0.f);
         }
     }
     dot += __shfl_xor(dot, 32, 64);
-    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + packed[HP_B + 64])));
+    if (FOLD) DEC_STAMP(4, false);
+    if (h == 0 && valid) out[row] = 1.f / (1.f + expf(-(dot + b2s)));
+    if (FOLD) DEC_STAMP(5, true);
 }
 
 // PIML_HEAD_PRODUCTS=f32: the collision head's 128 -> 64 layer on the f32 matrix instruction (A/B); default: split bf16 products
@@ -1369,7 +1434,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         if (A.nbr > 1) dec_fwd_body<false, true>(A, bx >> 1, bx & 1);
         else dec_fwd_body<false, true>(A, bx, 0);
     } else {
-        head_fwd_body_x3<4, true>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+        extern __shared__ __align__(16) float head_lds[];
+        head_fwd_body_x3<4, true, true>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
     }
 }
 
@@ -1393,7 +1459,7 @@ int piml::dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_c
     A.acc = acc;
     A.pool_h2 = 2;
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
-    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), head_blocks ? HEAD_LDS_BYTES : 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
 
