@@ -91,7 +91,7 @@ __device__ __forceinline__ void land_w3(const u32x4 (&w3r)[W3_ROUNDS], float* ld
 template <int DROP>
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(threadIdx.x >> 6));
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int wg0 = b ? A.wg_split : 0;
@@ -272,6 +272,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
 // from the tile its first row lies in, `h2` = the rest; both (agents, 128)): no atomics, no cleared buffer, and the decoder adds
 // them ((a k) >> 5 != (a k + k - 1) >> 5 says which agents have a second part).
 // ---------------------------------------------------------------------------------------------------------
+// x[l] + x[l ^ 32] in every lane: v_permlane32_swap (gfx950) exchanges the upper half of one register with the lower half of
+// another -- one vector instruction where __shfl_xor(x, 32) is a ds_bpermute and its wait
+__device__ __forceinline__ float add_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int K, int PH>
 __device__ __forceinline__ void pool_rows(const f32x16 (&a)[4], long long tile, long long agents, int lane, float* __restrict__ part_a,
                                           float* __restrict__ part_b) {
@@ -280,6 +288,11 @@ __device__ __forceinline__ void pool_rows(const f32x16 (&a)[4], long long tile, 
     const int i = lane & 31;
     const bool h = lane >= 32;
     const long long a0 = (tile * 32) / K;
+    // Round 5 (in-kernel stamps: the sums cost a wave 4.5 - 5 k clocks): every sum of the tile first, the stores behind them in ONE
+    // lane-half region -- as a store per sum each sat in an exec-mask region of its own, which kept the compiler from moving the
+    // next sum's lane exchange over it (24 exposed LDS round trips), and the index was 64-bit arithmetic with an `agent < agents`
+    // test per store.  `tile` is wave-uniform in the callers, so the addresses are scalar + a lane offset.
+    float tot[4][S];
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
         float sum[S];
@@ -295,18 +308,26 @@ __device__ __forceinline__ void pool_rows(const f32x16 (&a)[4], long long tile, 
             }
         }
 #pragma unroll
+        for (int s = 0; s < S; ++s) tot[blk][s] = add_halves(sum[s]);
+    }
+    float* __restrict__ pa = part_a + a0 * EH + i;
+    float* __restrict__ pb = part_b + a0 * EH + i;
+    const int left = (int)(agents - a0 < S ? agents - a0 : S);          // agents of the tile that exist (wave-uniform)
+    if (!h) {
+#pragma unroll
         for (int s = 0; s < S; ++s) {
-            const float tot = sum[s] + __shfl_xor(sum[s], 32);
-            const long long agent = a0 + s;
-            float* dst = (s == 0 && o != 0) ? part_b : part_a;
-            if (!h && agent < agents) dst[agent * EH + 32 * blk + i] = tot;
+            if (s < left) {
+                float* dst = (s == 0 && o != 0) ? pb : pa;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) dst[s * EH + 32 * blk] = tot[blk][s];
+            }
         }
     }
 }
 
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(threadIdx.x >> 6));      // in an SGPR: `tile` and every address built on it stay scalar
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int wg0 = b ? A.wg_split : 0;
@@ -395,22 +416,45 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A)
 // Reference arithmetic: src/models/model.py:40-65 (layers 1 - 2), :1279-1283 (the sum; layer 3 and the processor scale are folded
 // into the decoder's first layer, pack.hpp: fold_w).
 // ---------------------------------------------------------------------------------------------------------
+#ifdef PIML_ENC_STAMPS
+// diagnostic build only (tools/enc_stamps_fwd.py): shader-clock stamps of thread 0 of every workgroup of the last enc_fwd_sum launch
+__device__ unsigned long long g_enc_stamps[512 * 16];
+#define ENC_STAMP(i, wait)                                                                         \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+        if (threadIdx.x == 0 && blockIdx.x < 512) g_enc_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define ENC_STAMP(i, wait)
+#endif
+
 template <bool ROWS>
 __device__ __forceinline__ void store_h2_rows(const f32x16 (&a)[4], float* __restrict__ h2, long long tile, long long R, int lane) {
     if (!ROWS) return;
     const int j = lane & 31, h = lane >> 5;
+    // (round 5, in-kernel stamps: with a 64-bit row index and a bounds test per store, REQUESTING the 64 stores took the pedestrian
+    // workgroups -- the launch's critical path -- 8.4 k clocks; now a base pointer, compile-time offsets, a full tile without tests)
+    float* __restrict__ base = h2 + (tile * 32 + 4 * h) * EH + j;
+    const long long left = R - tile * 32 - 4 * h;          // rows of this lane half's first row on
+    if (R - tile * 32 >= 32) {
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
+        for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < R) h2[row * EH + 32 * blk + j] = a[blk][r];
-        }
+            for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * EH + 32 * blk] = a[blk][r];
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) < left) base[((r & 3) + 8 * (r >> 2)) * EH + 32 * blk] = a[blk][r];
+    }
 }
 
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(threadIdx.x >> 6));      // in an SGPR: `tile` and every address built on it stay scalar
     const int b = (A.nbr > 1 && (int)blockIdx.x >= A.wg_split) ? 1 : 0;
     const piml_encoder_branch J = b ? A.br[1] : A.br[0];
     const int wg0 = b ? A.wg_split : 0;
@@ -425,10 +469,13 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
     if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
     const float* x3 = J.packed + PACK_F32;
     float xb[4];
+    ENC_STAMP(0, false);
     load_x(xb, J.x, first, ntiles, R, IN, lane);
     stage_linear<X3_IMG>(lds, x3, tid);                                         // W2's image; W3 is not needed
     stage_linear<1024 + 384>(lds + X3_FWD_F32, J.packed + 32768, tid);
+    ENC_STAMP(1, true);
     __syncthreads();
+    ENC_STAMP(2, false);
     const int k = J.k;
     const long long agents = R / k;
     for (long long tile = first; tile < ntiles; tile += stride) {
@@ -455,7 +502,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
         }
         uint2* mrow = reinterpret_cast<uint2*>(J.relu_mask) + (tile * 2) * 64 + lane_t;
         mrow[0] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));       // h1: lane = row, bits = features (enc_fwd_x3_kernel's)
+        ENC_STAMP(3, false);
         split_tile(a, P);
+        ENC_STAMP(4, false);
         load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
         // ---- layer 2, exchanged operands: a[blk] = relu(h2)[row rho(r) + 4 h][feature 32 blk + (lane & 31)] ----
 #pragma unroll
@@ -472,8 +521,10 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[blk][r] = relu1(acc[r] + sm[r]);
         }
+        ENC_STAMP(5, false);
         mrow[64] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));      // h2: lane = feature, bits = the tile's rows
         if (J.h2) store_h2_rows<true>(a, J.h2, tile, R, lane_t);
+        ENC_STAMP(6, false);
         if (k == 6) {
             switch ((int)(tile % 3)) {
                 case 0: pool_rows<6, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
@@ -491,7 +542,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
         } else {
             pool_rows<2, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b);
         }
+        ENC_STAMP(7, false);
     }
+    ENC_STAMP(8, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1114,3 +1167,9 @@ void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {
 }
 
 }  // namespace piml
+
+#ifdef PIML_ENC_STAMPS
+extern "C" __attribute__((visibility("default"))) int piml_enc_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(piml::g_enc_stamps), sizeof(unsigned long long) * 512 * 16);
+}
+#endif
