@@ -1220,15 +1220,17 @@ __device__ __forceinline__ void head_fwd_body(const float* __restrict__ msgs, lo
 // 13 k for 3 k of products).  The workgroup now stages k-block groups 0 .. HEAD_LDS_GROUPS - 1 in LDS once (`wlds`, dynamic shared
 // memory) and reads the last group from L2 as before: fifteen groups = 45 KB is what fits beside the decoder body's static 33 KB
 // with two workgroups per CU.
-constexpr int HEAD_LDS_GROUPS = 15;
-constexpr int HEAD_LDS_BYTES = HEAD_LDS_GROUPS * 3 * 64 * 16;
-template <int WAVES = 4, bool FOLD = false, bool LDSW = false>
+// (dec_fwd_head_kernel, the message path: its decoder body also holds the pooled tile, 49.5 KB static -- ten groups there.)
+constexpr int HEAD_LDS_GROUPS = 15, HEAD_LDS_GROUPS_POOL = 10;
+constexpr int head_lds_bytes(int groups) { return groups * 3 * 64 * 16; }
+template <int WAVES = 4, bool FOLD = false, int HEAD_LDS_G = 0>
 __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs, long long rows,
                                                  const float* __restrict__ packed, float* __restrict__ out, long long bx,
                                                  u32x4* wlds = nullptr) {
     const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const long long row = (bx * WAVES + wave) * 32 + j;
+    constexpr bool LDSW = HEAD_LDS_G > 0;
     const bool idle = (bx * WAVES + wave) * 32 >= rows;
     if (!LDSW && idle) return;
     const bool valid = row < rows;
@@ -1260,15 +1262,17 @@ __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs,
     const float b2s = packed[HP_B + 64];
     u32x4 wtail[3];
     if (LDSW) {
-        constexpr int N4 = HEAD_LDS_GROUPS * 3 * 64, ROUNDS = (N4 + WAVES * 64 - 1) / (WAVES * 64);
+        constexpr int N4 = HEAD_LDS_G * 3 * 64, ROUNDS = LDSW ? (N4 + WAVES * 64 - 1) / (WAVES * 64) : 1;
         u32x4 st[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int e = r * WAVES * 64 + (int)threadIdx.x;
             st[r] = Wg[e < N4 ? e : 0];
         }
+        if (HEAD_LDS_G == 15) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wtail[p] = W[(HEAD_LDS_GROUPS * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) wtail[p] = W[(15 * 3 + p) * 64];
+        }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int e = r * WAVES * 64 + (int)threadIdx.x;
@@ -1315,7 +1319,8 @@ __device__ __forceinline__ void head_fwd_body_x3(const float* __restrict__ msgs,
             if (g + 1 < 16) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    wf[(g + 1) & 1][p] = !LDSW ? W[((g + 1) * 3 + p) * 64] : (g + 1 < HEAD_LDS_GROUPS ? WL[((g + 1) * 3 + p) * 64] : wtail[p]);
+                    wf[(g + 1) & 1][p] = g + 1 < HEAD_LDS_G ? WL[((g + 1) * 3 + p) * 64]
+                                                          : ((HEAD_LDS_G == 15 && g + 1 == 15) ? wtail[p] : W[((g + 1) * 3 + p) * 64]);
             }
             kblock_x3(acc, sm, wf[g & 1][0], wf[g & 1][1], wf[g & 1][2], xh[kb], xm[kb], xl[kb]);
         }
@@ -1421,7 +1426,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         if (A.nbr > 1) dec_fwd_body<true, true>(A, bx >> 1, bx & 1);
         else dec_fwd_body<true, true>(A, bx, 0);
     } else {
-        if (X3) head_fwd_body_x3<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
+        extern __shared__ __align__(16) float head_lds[];
+        if (X3) head_fwd_body_x3<4, false, HEAD_LDS_GROUPS_POOL>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
         else head_fwd_body<4>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks);
     }
 }
@@ -1435,7 +1441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         else dec_fwd_body<false, true>(A, bx, 0);
     } else {
         extern __shared__ __align__(16) float head_lds[];
-        head_fwd_body_x3<4, true, true>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
+        head_fwd_body_x3<4, true, HEAD_LDS_GROUPS>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
     }
 }
 
@@ -1459,7 +1465,7 @@ int piml::dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_c
     A.acc = acc;
     A.pool_h2 = 2;
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
-    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), head_blocks ? HEAD_LDS_BYTES : 0, s, A, Hd, tiles);
+    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), head_blocks ? head_lds_bytes(HEAD_LDS_GROUPS) : 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
 
@@ -1479,7 +1485,7 @@ int piml::dec_stage_fwd_fused(const piml_decoder_branch* br, int nbr, const piml
     A.tau = tau;
     A.acc = acc;
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
-    if (g_head_x3) hipLaunchKernelGGL(dec_fwd_head_kernel<true>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
+    if (g_head_x3) hipLaunchKernelGGL(dec_fwd_head_kernel<true>, dim3((unsigned)(tiles + head_blocks)), dim3(256), head_blocks ? head_lds_bytes(HEAD_LDS_GROUPS_POOL) : 0, s, A, Hd, tiles);
     else hipLaunchKernelGGL(dec_fwd_head_kernel<false>, dim3((unsigned)(tiles + head_blocks)), dim3(256), 0, s, A, Hd, tiles);
     return hipGetLastError();
 }
