@@ -99,13 +99,16 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     const long long R = J.rows;
     const int IN = J.in_dim;
     const long long ntiles = (R + 31) >> 5;
-    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    // wave-major: tile t of the first nwg tiles goes to wave 0 of workgroup t, the next nwg tiles to the workgroups' waves 1, ... --
+    // below nwg x 8 tiles the work spreads over the CUs (and over their SIMDs) before any SIMD gets a second wave (round 5: at the
+    // fine-tuning loop's 488 agents the block-major order kept 31 workgroups of eight waves busy and 225 CUs idle)
+    const long long first = (long long)wave * nwg + ((int)blockIdx.x - wg0);
     const long long stride = (long long)nwg * ENC_WAVES;
     if (A.zero)
         for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
     unsigned long long gseed = 0, goff = 0;
     if (DROP == 2) { gseed = A.gen_state[0]; goff = A.gen_state[1]; }
-    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) {               // whole workgroup idle
+    if ((long long)((int)blockIdx.x - wg0) >= ntiles) {               // whole workgroup idle (not even wave 0 has a tile)
         if (DROP == 2 && tid == 0) dropout_advance(A.gen_state, goff, gridDim.x);
         return;
     }
@@ -335,11 +338,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A)
     const long long R = J.rows;
     const int IN = J.in_dim;
     const long long ntiles = (R + 31) >> 5;
-    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    // wave-major: tile t of the first nwg tiles goes to wave 0 of workgroup t, the next nwg tiles to the workgroups' waves 1, ... --
+    // below nwg x 8 tiles the work spreads over the CUs (and over their SIMDs) before any SIMD gets a second wave (round 5: at the
+    // fine-tuning loop's 488 agents the block-major order kept 31 workgroups of eight waves busy and 225 CUs idle)
+    const long long first = (long long)wave * nwg + ((int)blockIdx.x - wg0);
     const long long stride = (long long)nwg * ENC_WAVES;
     if (A.zero)
         for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
-    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+    if ((long long)((int)blockIdx.x - wg0) >= ntiles) return;        // whole workgroup idle (not even wave 0 has a tile)
     const float* x3 = J.packed + PACK_F32;
     float xb[4];
     load_x(xb, J.x, first, ntiles, R, IN, lane);
@@ -462,11 +468,14 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
     const long long R = J.rows;
     const int IN = J.in_dim;
     const long long ntiles = (R + 31) >> 5;
-    const long long first = (long long)((int)blockIdx.x - wg0) * ENC_WAVES + wave;
+    // wave-major: tile t of the first nwg tiles goes to wave 0 of workgroup t, the next nwg tiles to the workgroups' waves 1, ... --
+    // below nwg x 8 tiles the work spreads over the CUs (and over their SIMDs) before any SIMD gets a second wave (round 5: at the
+    // fine-tuning loop's 488 agents the block-major order kept 31 workgroups of eight waves busy and 225 CUs idle)
+    const long long first = (long long)wave * nwg + ((int)blockIdx.x - wg0);
     const long long stride = (long long)nwg * ENC_WAVES;
     if (A.zero)
         for (int e = blockIdx.x * ENC_THREADS + tid; e < A.zero_n; e += gridDim.x * ENC_THREADS) A.zero[e] = 0.f;
-    if ((long long)((int)blockIdx.x - wg0) * ENC_WAVES >= ntiles) return;        // whole workgroup idle
+    if ((long long)((int)blockIdx.x - wg0) >= ntiles) return;        // whole workgroup idle (not even wave 0 has a tile)
     const float* x3 = J.packed + PACK_F32;
     float xb[4];
     ENC_STAMP(0, false);
