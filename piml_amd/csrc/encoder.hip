@@ -855,7 +855,10 @@ int piml::enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s) 
 }
 
 // row tiles (of 32) up to which the forward uses enc_fwd_split_kernel (PIML_ENC_SPLIT_TILES, piml_encoder_split_tiles)
-static long long split_tiles_default() { return getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 1024; }
+// (lone forward, graph-replayed, tools/sweep_lone_forward.py, with the wave-major tile order of round 5: four waves per tile 24.7 us
+// against 26.8 at 488 tiles, 33.2 against 29.0 at 751 -- the bound was 1024 while the one-wave kernels filled a workgroup's eight waves
+// before they used the next CU)
+static long long split_tiles_default() { return getenv("PIML_ENC_SPLIT_TILES") ? atoll(getenv("PIML_ENC_SPLIT_TILES")) : 640; }
 // ... and the bound of a TRAINING pass (every branch carries relu_mask: a backward follows).  Round 5: with the one-pass backward
 // and the layer-1 slots the many-rows kernels win from the real clips' sizes on -- forward + backward of `pinnsf_m`, few-rows /
 // many-rows kernels: 84 / 84 us at 122 agents (62 tiles), 96 / 94 at 1024, 132 / 111 at 2048 (one rank of the 8-way sharded
@@ -880,13 +883,14 @@ PIML_API long long piml_encoder_split_tiles_train(long long tiles) {
     if (tiles >= 0) g_split_tiles_train = tiles;
     return old;
 }
-// the bound that applies to these branches: a training pass without a dropout mask (all of them carry relu_mask, none keep_bits /
-// drop_state), or anything else.  (With the in-kernel mask the four-waves-per-tile kernels stay ahead up to ~512 tiles: fine-tuning
-// step of 4 x 5 x 122 agents at p = 0.5 0.45 ms on them against 0.50 on the one-wave kernels, pointwise step of 128 rows 0.157
-// against 0.171; without a mask 0.44 -> 0.41 and 0.157 -> 0.155 the other way round, tools/train_mode_steps.py.)
+// the bound that applies to these branches: a training pass (all of them carry relu_mask: the one-pass backward follows), or a lone
+// forward.  Until the wave-major tile order (round 5, encoder_x3.hip) steps with a dropout mask kept the lone forward's bound: the
+// four-waves-per-tile kernels were ahead there up to ~512 tiles (fine-tuning step of 4 x 5 x 122 agents at p = 0.5 0.45 ms against 0.50).
+// With it (tools/train_mode_steps.py, p = 0.5, PIML_ENC_SPLIT_TILES = 1024 / 48): pinnsf_m fine-tuning step 0.436 / 0.433 ms, pointwise
+// step of 1024 rows 0.174 / 0.165, pinnsf_bm fine-tuning step 0.900 / 0.871 -- one bound for every training pass.
 static long long split_bound(const piml_encoder_branch* br, int nbr) {
     for (int i = 0; i < nbr; ++i)
-        if (!br[i].relu_mask || br[i].keep_bits || br[i].drop_state) return g_split_tiles;
+        if (!br[i].relu_mask) return g_split_tiles;
     return g_split_tiles_train;
 }
 

@@ -1871,21 +1871,19 @@ H1_RECOMPUTE = _os.environ.get('PIML_H1_RECOMPUTE', '1') != '0'      # do not st
 def _h1_needed(rows_per_branch, alone=True):
     """False when the backward of these branches runs without h1 (include/piml_hip.h, piml_encoder_branch): sign bits for
     the dX chain + layer-split weight gradients that recompute it from x.  The forward then does not store it.
-    alone: the backward may run on any subset of the branches (fused_encoders: a branch without upstream gradient is left
-    out), so every branch has to be above the bound on its own; the PINNSF network's backward always has the gradient of
-    the accelerations for all of them, and the launch as a whole counts."""
+    The backward may run on any subset of the branches (fused_encoders: a branch without upstream gradient is left out; the PINNSF
+    network: a loss on the messages or the collision head alone), so every branch has to be above the training bound of the
+    one-wave kernels on its own (`alone` is kept for the callers' sake and no longer changes the answer)."""
     if not (H1_RECOMPUTE and RELU_MASK):
         return True
     import ctypes
     L = _lib.lib()
-    # every branch on its own above the bound: the backward may run on a subset of them (branches without upstream gradient)
+    # EVERY branch on its own above the training bound (round 5: also for the network, whose backward normally has a gradient for all
+    # branches -- but a loss on the collision head or the messages alone arrives through ONE branch, and that launch must not fall back
+    # to the few-rows kernels, which read h1; until the library used one bound for every training pass this case raised an error)
     per_branch = [(r + 31) // 32 for r in rows_per_branch]
-    tiles = min(per_branch) if alone else sum(per_branch)
-    # (h1 is skipped only where its 512 B per row matter -- above the forward-only bound of the few-rows kernels, 1024 tiles by
-    # default -- although the backward that recomputes it runs from the training bound on: a backward pass that arrives through
-    # the messages of ONE small branch still finds it)
-    if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1
-            and tiles > max(L.piml_encoder_split_tiles_train(-1), L.piml_encoder_split_tiles(-1))):
+    tiles = min(per_branch)
+    if not (L.piml_encoder_products(-1) == 1 and L.piml_encoder_dw2(-1) == 1 and tiles > L.piml_encoder_split_tiles_train(-1)):
         return True
     arr = (_lib.EncoderBranch * len(rows_per_branch))()
     for b, r in enumerate(rows_per_branch):

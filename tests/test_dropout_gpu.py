@@ -263,14 +263,17 @@ def test_train_mode_f32_instruction_kernels_match_too(products):
         _lib.lib().piml_encoder_products(old)
 
 
-def test_train_mode_draws_its_own_masks():
+@pytest.mark.parametrize('n', [300, 1500, 2100])
+def test_train_mode_draws_its_own_masks(n):
     """Without an injected mask every forward pass draws one: outputs differ from pass to pass, the kept fraction is
-    1 - p, the kept features are scale / (1 - p) times the eval-mode output, and backward uses the SAME mask."""
+    1 - p, the kept features are scale / (1 - p) times the eval-mode output, and backward uses the SAME mask.
+    The backward here arrives through the pedestrian messages ALONE, i.e. as an encoder launch of one branch: at 300 / 2100 agents
+    that branch is on the other side of a kernel-choice bound than the two branches together were in the forward (until round 5
+    the second case raised 'the forward did not store the layer-1 activations')."""
     import piml_amd.models.model as MODEL
     torch.manual_seed(0)
     net = MODEL.PINNSF_multitask(model_args(dropout=0.25)).to(DEV)
     g = torch.Generator().manual_seed(3)
-    n = 1500
     base = [torch.randn(n, 6, 6, generator=g).to(DEV), torch.randn(n, 10, 6, generator=g).to(DEV), torch.randn(n, 7, generator=g).to(DEV)]
     with torch.no_grad():
         ev = net.eval()(*base)
