@@ -67,11 +67,11 @@ static_assert(F3_LDS_BYTES <= 160 * 1024, "fits the CU");
 
 #ifdef PIML_F3_STAMPS
 // diagnostic build only (tools/f3_stamps.py): cycles of wave 0 between the stamps, summed over the workgroup's tiles
-__device__ unsigned long long g_f3_stamps[256 * 16];
+__device__ unsigned long long g_f3_stamps[256 * 64];          // [workgroup][wave 4][stamp 16]
 #define F3_STAMP(i)                                                        \
     do {                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                 \
-        if (w == 0) {                                                      \
+        {                                                                  \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
             st[i] += t_ - tprev;                                           \
             tprev = t_;                                                    \
@@ -880,14 +880,14 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
     }
 #ifdef PIML_F3_STAMPS
     F3_STAMP(12);
-    if (tid == 0)
-        for (int i = 0; i < 16; ++i) g_f3_stamps[blockIdx.x * 16 + i] = st[i];
+    if ((tid & 63) == 0)
+        for (int i = 0; i < 16; ++i) g_f3_stamps[blockIdx.x * 64 + w * 16 + i] = st[i];
 #endif
 }
 
 #ifdef PIML_F3_STAMPS
 extern "C" __attribute__((visibility("default"))) int piml_f3_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f3_stamps), sizeof(unsigned long long) * 256 * 16);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f3_stamps), sizeof(unsigned long long) * 256 * 64);
 }
 #endif
 

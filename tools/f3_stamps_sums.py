@@ -16,14 +16,15 @@ for _ in range(3):
     run(brs, sf, head, wa, 0.5, bool(sums))
 torch.cuda.synchronize()
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * (256 * 16))()
+buf = (ctypes.c_ulonglong * (256 * 64))()
 L.piml_f3_stamps.argtypes = [ctypes.c_void_p]
 assert L.piml_f3_stamps(buf) == 0
-st = np.array(buf[:], dtype=np.float64).reshape(256, 16)
+st = np.array(buf[:], dtype=np.float64).reshape(256, 4, 16)
 tiles = n * 16 / 32 / 256
-med = np.median(st, axis=0)
-print(f'{n} agents sums={sums}, {tiles:.1f} tiles per workgroup; cycles of wave 0 (median over 256 workgroups)')
+med = np.median(st, axis=0)                # [wave][stamp]
+print(f'{n} agents sums={sums}, {tiles:.1f} tiles per workgroup; cycles of waves 0 .. 3 (median over 256 workgroups)')
 for i, name in NAMES.items():
     once = 'once' in name
-    print(f'  {name:32s} {med[i] / (1 if once else tiles):10.0f}' + ('' if once else '  per tile'))
-print(f'  total per workgroup {st.sum(axis=1).mean():.0f} (max {st.sum(axis=1).max():.0f})')
+    print(f'  {name:32s} ' + ' '.join(f'{med[w, i] / (1 if once else tiles):8.0f}' for w in range(4)) + ('' if once else '  per tile'))
+tot = st.sum(axis=2)
+print('  total per wave ' + ' '.join(f'{tot[:, w].mean():8.0f}' for w in range(4)) + f' (max {tot.max():.0f})')
