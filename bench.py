@@ -1111,6 +1111,8 @@ def main():
     sums_path = 'enc_fwd_sum' in stage_us         # PIML_POOL_TRAIN: the network ran on the agents' sums of h2 (--messages 0, eval mode)
     if sums_path:
         stage_kernel.update({'enc_fwd_sum': 'enc_fwd_sum_x3_kernel', 'dec_fwd_head_sum': 'dec_fwd_head_sum_kernel', 'pinnsf_unfold': 'pinnsf_unfold_kernel'})
+    if 'dec_fwd_head_sum' in stage_us:            # also PIML_POOL_MSGS (a dropout step that returns no messages): the decoder launch on sums
+        stage_kernel['dec_fwd_head_sum'] = 'dec_fwd_head_sum_kernel'
     if one_pass:
         stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
         if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':
@@ -1200,7 +1202,7 @@ def main():
                                     'on request only (model.messages_wanted = False: every output and gradient the step reads is '
                                     'produced; the neighbour-axis sum runs in front of the encoders\' last layer, which is folded '
                                     'into the decoders\' first layer -- DESIGN.md 5, tests/test_sums_gpu.py; --messages 1 times the other form)' +
-                                    (' [train mode: a dropout mask sits between that layer and the sum, so this step computes the messages internally]' if args.train_mode else '')),
+                                    (' [train mode: a dropout mask sits between that layer and the sum -- the forward runs its last layer with exchanged operands and leaves the agents\' sums of the MESSAGES, rows stored for the collision head only (PIML_POOL_MSGS); plain backward]' if args.train_mode else '')),
                        'sharding': 'single GPU' if not use_dist else
                        f'agent blocks over {world} ranks, all-gather(p,v,a) + one all-reduce(state grad + weight grads) per step'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

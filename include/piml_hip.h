@@ -840,7 +840,20 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
                            enc[i].sum_a, dec[i].msgs = enc[i].sum_b, dec[i].fold_*, head->msgs = enc[0].h2, head->fold_*.
                            Served when piml_pinnsf_pool_train_ok(enc, nbranches): k in {2, 6, 10}, whole agents, split products,
                            more than piml_encoder_split_tiles() tiles, no keep_bits / drop_state; hipErrorInvalidValue otherwise */
+#define PIML_POOL_MSGS 128 /* piml_pinnsf_fwd only (the backward is the plain one): the agents' sums of the MESSAGES written by the
+                           encoder forward itself -- for training passes whose dropout mask keeps the sum from moving in front of the
+                           last layer (PIML_POOL_TRAIN) and whose caller does not read the per-row messages.  The last encoder layer
+                           runs with exchanged operands (a tile's rows on registers), the keep bits of a row travel from the lane that
+                           drew / loaded them to the lanes that own its features, and the sums leave as enc[i].sum_a / sum_b
+                           (dec[i].pooled = enc[i].sum_a, dec[i].msgs = enc[i].sum_b; the decoder completes them in `pooled`, where
+                           the backward's dW1 reads them).  enc[i].msgs may be NULL: the rows of a branch are stored only where it is
+                           not (the collision head's input: head->msgs = enc[0].msgs).  Everything the plain backward reads is left
+                           as by the plain forward (h2, relu_mask, keep_bits, the decoders' h1 / d2).  Reference arithmetic:
+                           src/models/model.py:82-119 (processor), :1279-1283 (the sum).  Served when
+                           piml_pinnsf_pool_msgs_ok(enc, nbranches): k in {2, 6, 10}, whole agents, split products, relu_mask given,
+                           more than piml_encoder_split_tiles_train() tiles; hipErrorInvalidValue otherwise */
 int piml_pinnsf_pool_train_ok(const piml_encoder_branch* enc, int nbranches);
+int piml_pinnsf_pool_msgs_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbranches);
 int piml_pinnsf_pack_flush(void);
 int piml_pinnsf_slot_sums_flush(void);   /* launch the deferred slot sums of the current device, if any are waiting (on their stream) */

@@ -58,7 +58,7 @@ class Corrector(ctypes.Structure):
                 ('partials_a', _p), ('partials_b', _p), ('grads', _p)]
 
 
-PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK, POOL_H2, POOL_TRAIN = 1, 2, 4, 8, 16, 32, 64          # piml_pinnsf_* flags
+PACKED_VALID, FORK, ACCUMULATE, DEFER_SLOT_SUMS, DEFER_PACK, POOL_H2, POOL_TRAIN, POOL_MSGS = 1, 2, 4, 8, 16, 32, 64, 128          # piml_pinnsf_* flags
 
 # name -> argtypes, in the order of include/piml_hip.h
 SIGNATURES = {
@@ -165,6 +165,7 @@ SIGNATURES = {
     'piml_corrector_bwd': [ctypes.POINTER(Corrector), _i, _p],
     'piml_pinnsf_pool_h2_ok': [ctypes.POINTER(EncoderBranch), _i],
     'piml_pinnsf_pool_train_ok': [ctypes.POINTER(EncoderBranch), _i],
+    'piml_pinnsf_pool_msgs_ok': [ctypes.POINTER(EncoderBranch), _i],
     'piml_pinnsf_streams_init': [],
     'piml_pinnsf_pack_flush': [],
     'piml_pinnsf_slot_sums_flush': [],

@@ -39,6 +39,8 @@ struct DecArgs {
                                   // 2 = PIML_POOL_TRAIN (forward and backward): the same, with the FOLDED first-layer images of
                                   // `packed` (DP_A1F / DP_T1F / DP_CF, pack.hpp), bias b1 + k c, and the completed sums written
                                   // back to `pooled` for the backward's dW1
+                                  // 3 = PIML_POOL_MSGS: `pooled` / `msgs` hold the two parts of the agents' sums of the MESSAGES
+                                  // (enc_fwd_x3_kernel<DROP, true>): plain images, completed sums written back like 2
 };
 
 #ifdef PIML_DEC_STAMPS
@@ -256,7 +258,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& A, long long tile, i
     if (active) {
         // training on the sums (pool_h2 == 2): the completed sum is the backward's layer-1 input (dW1 = g_pre1^T pooled); written
         // behind the barrier, when every wave of the workgroup has finished reading the first parts
-        if (!POOL && !ROWS && A.pool_h2 == 2 && ob == 0) {
+        if (!POOL && !ROWS && A.pool_h2 >= 2 && ob == 0) {
             const long long g0 = (valid ? agent : 0) * J.k;
             if (valid && (g0 >> 5) != ((g0 + J.k - 1) >> 5)) {
 #pragma unroll
@@ -1434,6 +1436,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 
 // PIML_POOL_TRAIN: the decoder tails on the agents' sums of h2 (no neighbour-axis sum here: dec_fwd_ph2_kernel's body with the
 // folded first layer, A.pool_h2 = 2) and the collision head on the h2 rows with the folded W1, in one launch as above
+// FOLD = false (PIML_POOL_MSGS): the sums are sums of the messages themselves -- plain first layers, the head on the message rows
+template <bool FOLD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dec_fwd_head_sum_kernel(DecArgs A, piml_collision_head Hd, int dec_blocks) {
     const int bx = blockIdx.x;
     if (bx < dec_blocks) {
@@ -1441,31 +1445,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         else dec_fwd_body<false, true>(A, bx, 0);
     } else {
         extern __shared__ __align__(16) float head_lds[];
-        head_fwd_body_x3<4, true, HEAD_LDS_GROUPS>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
+        head_fwd_body_x3<4, FOLD, HEAD_LDS_GROUPS>(Hd.msgs, Hd.rows, Hd.packed, Hd.out, (long long)bx - dec_blocks, reinterpret_cast<u32x4*>(head_lds));
     }
 }
 
 int piml::dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features,
-                            float tau, float* acc, hipStream_t s) {
+                            float tau, float* acc, hipStream_t s, bool fold) {
     DecArgs A;
     if (!acc) return hipErrorInvalidValue;
     if (int e = dec_fill(A, br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
-        if (!br[i].msgs || !br[i].fold_w3 || !br[i].fold_b3) return hipErrorInvalidValue;
+        if (!br[i].msgs || (fold && (!br[i].fold_w3 || !br[i].fold_b3))) return hipErrorInvalidValue;
     piml_collision_head Hd = {};
     int head_blocks = 0;
     if (h && h->rows > 0) {
         if (int e = head_check(h)) return e;
-        if (!h->fold_w3 || !h->fold_b3) return hipErrorInvalidValue;
+        if (fold && (!h->fold_w3 || !h->fold_b3)) return hipErrorInvalidValue;
+        if (!g_head_x3) return hipErrorInvalidValue;          // (the paired launch has the split-product head only)
         Hd = *h;
         head_blocks = (int)(((h->rows + 31) / 32 + 3) / 4);
     }
     A.self_features = self_features;
     A.tau = tau;
     A.acc = acc;
-    A.pool_h2 = 2;
+    A.pool_h2 = fold ? 2 : 3;
     const int tiles = (int)((br[0].agents + 31) / 32) * nbr;
-    hipLaunchKernelGGL(dec_fwd_head_sum_kernel, dim3((unsigned)(tiles + head_blocks)), dim3(256), head_blocks ? head_lds_bytes(HEAD_LDS_GROUPS) : 0, s, A, Hd, tiles);
+    const dim3 g((unsigned)(tiles + head_blocks));
+    const int lds = head_blocks ? head_lds_bytes(HEAD_LDS_GROUPS) : 0;
+    if (fold) hipLaunchKernelGGL(dec_fwd_head_sum_kernel<true>, g, dim3(256), lds, s, A, Hd, tiles);
+    else hipLaunchKernelGGL(dec_fwd_head_sum_kernel<false>, g, dim3(256), lds, s, A, Hd, tiles);
     return hipGetLastError();
 }
 

@@ -951,10 +951,10 @@ static int x3_ready() {
     return state;
 }
 
-int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {
+int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n, bool msum) {
     if (int e = enc_check(br, nbr)) return e;
     for (int i = 0; i < nbr; ++i)
-        if (!br[i].msgs) return hipErrorInvalidValue;
+        if (!br[i].msgs && !msum) return hipErrorInvalidValue;          // (PIML_POOL_MSGS: message rows only where somebody reads them)
     EncArgs A;
     const int total = fill_args(A, br, nbr);
     static bool attr_set = false;
@@ -985,6 +985,14 @@ int piml::enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, f
         return hipErrorInvalidValue;
     }
     long long tiles[2] = {(br[0].rows + 31) / 32, nbr > 1 ? (br[1].rows + 31) / 32 : 0};
+    if (msum) {          // PIML_POOL_MSGS: the agents' sums of the messages from the one-wave kernel's registers
+        if (!enc_pool_msgs_ok(br, nbr)) return hipErrorInvalidValue;
+        for (int i = 0; i < nbr; ++i)
+            if (!br[i].sum_a || !br[i].sum_b) return hipErrorInvalidValue;
+        if (int e = x3_ready()) return e;
+        enc_x3_launch_fwd(A, total, br[0].keep_bits != nullptr, s, true);
+        return hipGetLastError();
+    }
     if (tiles[0] + tiles[1] <= split_bound(br, nbr)) {       // few rows: four waves per tile (see enc_fwd_split_kernel)
         const int pairs0 = (int)((tiles[0] + 1) / 2), pairs1 = (int)((tiles[1] + 1) / 2);
         if (g_x3) {
@@ -1231,6 +1239,24 @@ bool piml::enc_pool_train_ok(const piml_encoder_branch* br, int nbr) {
     if (tiles <= g_split_tiles_train) return false;
     const int total = 256, w0 = split_workgroups(br, nbr, total, 1);
     return nbr == 1 || (w0 >= 2 && total - w0 >= 2);
+}
+
+// The agents' sums of the MESSAGES from the forward's registers (PIML_POOL_MSGS: the last layer with exchanged operands,
+// enc_fwd_x3_kernel<DROP, true>) serves: split products, a training pass above the one-wave bound (the one-pass backward follows:
+// every branch carries relu_mask), k = 2, 6 or 10 neighbours per agent, whole agents; with or without a dropout mask.
+// PIML_POOL_MSGS=0 in the environment turns it off (A/B).
+bool piml::enc_pool_msgs_ok(const piml_encoder_branch* br, int nbr) {
+    static const bool off = getenv("PIML_POOL_MSGS") && atoi(getenv("PIML_POOL_MSGS")) == 0;
+    if (off || !g_x3 || !br || nbr < 1 || nbr > 2) return false;
+    long long tiles = 0;
+    for (int i = 0; i < nbr; ++i) {
+        const piml_encoder_branch& b = br[i];
+        if ((b.k != 2 && b.k != 6 && b.k != 10) || b.rows <= 0 || b.rows % b.k || !b.relu_mask || b.in_dim < 1 || b.in_dim > 8 ||
+            b.rows >= (1ll << 22))
+            return false;
+        tiles += (b.rows + 31) / 32;
+    }
+    return tiles > g_split_tiles_train;
 }
 
 int piml::enc_stage_fwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero, long long zero_n) {

@@ -61,7 +61,7 @@ int enc_x3_set_attributes();
 // drop: every branch of the launch carries keep_bits (the processor's train-mode dropout)
 void enc_x3_launch_fwd_pool(const EncArgs& A, int total, hipStream_t s);      // inference: layers 1-2 + the agents' sums of h2
 void enc_x3_launch_fwd_sum(const EncArgs& A, int total, hipStream_t s);       // training on the agents' sums of h2 (PIML_POOL_TRAIN)
-void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s);   // A.gen_state: draw the masks in the kernel
+void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s, bool exch = false);   // A.gen_state: draw the masks in the kernel
 void enc_x3_launch_fwd_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx_split(const EncArgs& A, int pairs0, int pairs1, bool drop, hipStream_t s);      // few rows: four waves per tile
 void enc_x3_launch_bwd_dx(const EncArgs& A, int total, bool mask, bool drop, hipStream_t s);   // mask: the forward of these branches wrote relu_mask

@@ -86,9 +86,126 @@ __device__ __forceinline__ void land_w3(const u32x4 (&w3r)[W3_ROUNDS], float* ld
     __syncthreads();
 }
 
+#ifdef PIML_ENC_STAMPS
+// diagnostic build only (tools/enc_stamps_fwd.py): shader-clock stamps of thread 0 of every workgroup of the last enc_fwd_sum launch
+__device__ unsigned long long g_enc_stamps[512 * 16];
+#define ENC_STAMP(i, wait)                                                                         \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+        if (threadIdx.x == 0 && blockIdx.x < 512) g_enc_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define ENC_STAMP(i, wait)
+#endif
+
+template <int K, int PH>
+__device__ __forceinline__ void pool_rows(const f32x16 (&a)[4], long long tile, long long agents, int lane, float* __restrict__ part_a,
+                                          float* __restrict__ part_b);
+template <bool ROWS>
+__device__ __forceinline__ void store_h2_rows(const f32x16 (&a)[4], float* __restrict__ h2, long long tile, long long R, int lane);
+
+__device__ __forceinline__ float add_halves(float x);
+
+// ONE 32-feature block of pool_rows: the sums of the block's 16 registers per agent, stored at once (enc_fwd_x3_kernel<DROP, true>
+// cannot hold all four output blocks until the end: its last layer's operands fill the register file)
+template <int K, int PH>
+__device__ __forceinline__ void pool_block(const f32x16& ab, int blk, long long tile, long long agents, int lane, float* __restrict__ part_a,
+                                           float* __restrict__ part_b) {
+    constexpr int o = (PH * 32) % K;
+    constexpr int S = (o + 31) / K + 1;
+    const int i = lane & 31;
+    const bool h = lane >= 32;
+    const long long a0 = (tile * 32) / K;
+    float sum[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) sum[s] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m0 = (r & 3) + 8 * (r >> 2), s0 = (o + m0) / K, s1 = (o + m0 + 4) / K;
+        if (s0 == s1) sum[s0] += ab[r];
+        else {
+            sum[s0] += h ? 0.f : ab[r];
+            sum[s1] += h ? ab[r] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) sum[s] = add_halves(sum[s]);
+    float* __restrict__ pa = part_a + a0 * EH + 32 * blk + i;
+    float* __restrict__ pb = part_b + a0 * EH + 32 * blk + i;
+    const int left = (int)(agents - a0 < S ? agents - a0 : S);
+    if (!h) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s < left) ((s == 0 && o != 0) ? pb : pa)[s * EH] = sum[s];
+    }
+}
+__device__ __forceinline__ void pool_block_k(const f32x16& ab, int blk, int k, long long tile, long long agents, int lane,
+                                             float* __restrict__ part_a, float* __restrict__ part_b) {
+    if (k == 6) {
+        switch ((int)(tile % 3)) {
+            case 0: pool_block<6, 0>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            case 1: pool_block<6, 1>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            default: pool_block<6, 2>(ab, blk, tile, agents, lane, part_a, part_b); break;
+        }
+    } else if (k == 10) {
+        switch ((int)(tile % 5)) {
+            case 0: pool_block<10, 0>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            case 1: pool_block<10, 1>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            case 2: pool_block<10, 2>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            case 3: pool_block<10, 3>(ab, blk, tile, agents, lane, part_a, part_b); break;
+            default: pool_block<10, 4>(ab, blk, tile, agents, lane, part_a, part_b); break;
+        }
+    } else {
+        pool_block<2, 0>(ab, blk, tile, agents, lane, part_a, part_b);
+    }
+}
+// the block's 16 rows of one lane half, 128 contiguous bytes per row (store_h2_rows for one block)
+__device__ __forceinline__ void store_rows_block(const f32x16& ab, int blk, float* __restrict__ out, long long tile, long long R, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    float* __restrict__ base = out + (tile * 32 + 4 * h) * EH + 32 * blk + j;
+    const long long left = R - tile * 32 - 4 * h;
+    if (R - tile * 32 >= 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * EH] = ab[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((r & 3) + 8 * (r >> 2) < left) base[((r & 3) + 8 * (r >> 2)) * EH] = ab[r];
+    }
+}
+
+// the register -> agent map of a tile's rows is chosen by (tile mod k): wave-uniform
+__device__ __forceinline__ void pool_rows_k(const f32x16 (&a)[4], int k, long long tile, long long agents, int lane, float* __restrict__ part_a,
+                                            float* __restrict__ part_b) {
+    if (k == 6) {
+        switch ((int)(tile % 3)) {
+            case 0: pool_rows<6, 0>(a, tile, agents, lane, part_a, part_b); break;
+            case 1: pool_rows<6, 1>(a, tile, agents, lane, part_a, part_b); break;
+            default: pool_rows<6, 2>(a, tile, agents, lane, part_a, part_b); break;
+        }
+    } else if (k == 10) {
+        switch ((int)(tile % 5)) {
+            case 0: pool_rows<10, 0>(a, tile, agents, lane, part_a, part_b); break;
+            case 1: pool_rows<10, 1>(a, tile, agents, lane, part_a, part_b); break;
+            case 2: pool_rows<10, 2>(a, tile, agents, lane, part_a, part_b); break;
+            case 3: pool_rows<10, 3>(a, tile, agents, lane, part_a, part_b); break;
+            default: pool_rows<10, 4>(a, tile, agents, lane, part_a, part_b); break;
+        }
+    } else {
+        pool_rows<2, 0>(a, tile, agents, lane, part_a, part_b);
+    }
+}
+
 // DROP: 0 = no dropout, 1 = keep_bits given, 2 = the kernel draws the p = 0.5 mask itself (one Philox call per row, philox.hpp)
 // and leaves it in keep_bits for the backward
-template <int DROP>
+// EXCH (round 5, PIML_POOL_MSGS): the LAST layer with exchanged operands (kblock_x3_t: D'[row][feature], lane = feature, registers
+// = the tile's rows, as enc_fwd_sum_x3_kernel's layer 2), so that the neighbour-axis sum of the MESSAGES -- which a dropout mask
+// keeps from moving in front of this layer -- is additions between registers too: the agents' sums go to sum_a / sum_b, the message
+// rows are stored only for a branch that carries `msgs` (the collision head's input), 128 contiguous bytes per (row, block).  A
+// row's keep words are drawn / loaded by the lane that owns the row and handed to the lanes that own its features by ds_bpermute.
+template <int DROP, bool EXCH = false>
 __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(threadIdx.x >> 6));
@@ -116,11 +233,13 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
     const float* x3 = J.packed + PACK_F32;
     // the first tile's input row: requested before the staging loads (vmcnt retires in order)
     float xb[4];
+    ENC_STAMP(0, false);
     load_x(xb, J.x, first, ntiles, R, IN, lane);
     stage_linear<X3_IMG>(lds, x3, tid);
     stage_linear<1024 + 384>(lds + X3_FWD_F32, J.packed + 32768, tid);
     __syncthreads();
-    // W3's LDS part stays in flight (in registers) behind layers 1 and 2 of the first tile
+    // W3's LDS part stays in flight (in registers) behind layers 1 and 2 of the first tile.  (EXCH: landed at once -- with the
+    // gather of the keep words those 32 registers no longer fit, and hipcc spilled exactly them)
     u32x4 w3r[W3_ROUNDS];
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(x3 + X3_IMG);
@@ -131,6 +250,12 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
         }
     }
     bool w3_pending = true;
+    ENC_STAMP(1, false);
+    if (EXCH && DROP) {
+        land_w3(w3r, lds, tid);
+        w3_pending = false;
+    }
+    ENC_STAMP(2, false);
 
     for (long long tile = first; tile < ntiles; tile += stride) {
         // the operand addresses are made opaque per tile: as loop invariants the compiler hoists the bias and fragment
@@ -173,6 +298,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
         // sign bits for the dX chain (relu_mask): lane (row, h), layer L: bit 16 blk + r of a 64-bit word = register r of block blk > 0
         uint2* mrow = J.relu_mask ? reinterpret_cast<uint2*>(J.relu_mask) + (tile * 2) * 64 + lane_t : nullptr;
         if (mrow) mrow[0] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));
+        ENC_STAMP(3, false);
         split_tile(a, P);
         // ---- layer 2 (a is dead: reused for the outputs) ----
 #pragma unroll
@@ -203,6 +329,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
             }
         }
         if (mrow) mrow[64] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));
+        ENC_STAMP(4, false);
         if (w3_pending) {
             land_w3(w3r, lds, tid);
             w3_pending = false;
@@ -212,18 +339,80 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
         u32x4 tail[6];               // hi / mid of fragments 29 .. 31 (block 3, k-blocks 5 .. 7)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) lw[0][kb] = W3lo_g[kb * 64];
+        if (!EXCH) {
 #pragma unroll
-        for (int u = 0; u < 6; ++u) tail[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
+            for (int u = 0; u < 6; ++u) tail[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
+        }
         load_x(xb, J.x, tile + stride, ntiles, R, IN, lane);       // the next tile's input row
         uint4 kw = make_uint4(0u, 0u, 0u, 0u);
         if (DROP == 1 && valid) kw = reinterpret_cast<const uint4*>(J.keep_bits)[row];
+        // EXCH: bit r of keepx[blk] = keep (row rho(r) + 4 h, this lane's feature of block blk) -- the rows' words come from the lanes
+        // that own the rows (ds_bpermute), gathered into one word per block IN FRONT of the split, while the layer's 96 operand
+        // registers do not exist yet (the draw too: behind the split, where the plain form has it, the two do not fit)
+        unsigned keepx[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (EXCH && DROP) {
+            if (DROP == 2) {
+                const PhiloxOut r = keep_words_fair(gseed, goff, (unsigned)row, (unsigned)b);
+                kw = make_uint4(r.x, r.y, r.z, r.w);
+                if (valid && h == 0) reinterpret_cast<uint4*>(J.keep_bits)[row] = kw;
+            }
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const unsigned kwb = word_of(kw, blk);
+                unsigned t = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned wd = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((r & 3) + 8 * (r >> 2) + 4 * h), (int)kwb);
+                    t |= ((wd >> (lane_t & 31)) & 1u) << r;
+                }
+                keepx[blk] = t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         split_tile(a, P);
-        if (DROP == 2) {          // `a` is dead here (64 free registers).  Both lane halves of a row draw the same words; half 0 records them
+        if (!EXCH && DROP == 2) {          // `a` is dead here (64 free registers).  Both lane halves of a row draw the same words; half 0 records them
             const PhiloxOut r = keep_words_fair(gseed, goff, (unsigned)row, (unsigned)b);
             kw = make_uint4(r.x, r.y, r.z, r.w);
             if (valid && h == 0) reinterpret_cast<uint4*>(J.keep_bits)[row] = kw;
         }
         const float scale = J.scale;
+        ENC_STAMP(5, false);
+        if (EXCH) {
+            // (register budget: the LO pieces one block ahead, the last three fragments' hi / mid pieces only inside the block that uses
+            // them -- there is no block ahead of it -- and a row's sixteen keep bits gathered into ONE word in front of the products)
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                if (blk < 3) {
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) lw[(blk + 1) & 1][kb] = W3lo_g[((blk + 1) * 8 + kb) * 64];
+                }
+                u32x4 tl[6];
+                if (blk == 3) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) tl[u] = W3hm_g[(X3_FB3 * 2 + u) * 64];
+                }
+                const unsigned keepw = keepx[blk];
+                f32x16 acc, sm;
+                const float bv = bias[256 + 32 * blk + (lane_t & 31)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sm[r] = 0.f; acc[r] = bv; }
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    const int fb = blk * 8 + kb;
+                    const u32x4 wh = fb < X3_FB3 ? W3hm[(fb * 2) * 64] : tl[fb < X3_FB3 ? 0 : (fb - X3_FB3) * 2];
+                    const u32x4 wm = fb < X3_FB3 ? W3hm[(fb * 2 + 1) * 64] : tl[fb < X3_FB3 ? 0 : (fb - X3_FB3) * 2 + 1];
+                    kblock_x3_t(acc, sm, wh, wm, lw[blk & 1][kb], P.hi[kb], P.mid[kb], P.lo[kb]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[r] + sm[r];
+                    if (DROP) v = keep_if(v, keepw, r);
+                    acc[r] = scale * v;
+                }
+                if (J.msgs) store_rows_block(acc, blk, J.msgs, tile, R, lane_t);
+                pool_block_k(acc, blk, J.k, tile, R / J.k, lane_t, J.sum_a, J.sum_b);
+            }
+        } else
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             if (blk < 3) {
@@ -256,6 +445,9 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_x3_kernel(EncArgs A) {
             }
         }
     }
+    ENC_STAMP(6, false);
+    ENC_STAMP(7, false);
+    ENC_STAMP(8, true);
     if (w3_pending) land_w3(w3r, lds, tid);       // a wave without a tile: the barrier still counts it
     if (DROP == 2 && tid == 0) dropout_advance(A.gen_state, goff, gridDim.x);
 }
@@ -395,21 +587,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A)
             for (int r = 0; r < 16; ++r) a[blk][r] = relu1(acc[r] + sm[r]);
         }
         // ---- the agents' sums (wave-uniform choice of the register -> agent map) ----
-        if (k == 6) {
-            switch ((int)(tile % 3)) {
-                case 0: pool_rows<6, 0>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                case 1: pool_rows<6, 1>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                default: pool_rows<6, 2>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-            }
-        } else {
-            switch ((int)(tile % 5)) {
-                case 0: pool_rows<10, 0>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                case 1: pool_rows<10, 1>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                case 2: pool_rows<10, 2>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                case 3: pool_rows<10, 3>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-                default: pool_rows<10, 4>(a, tile, agents, lane_t, J.msgs, J.h2); break;
-            }
-        }
+        pool_rows_k(a, k, tile, agents, lane_t, J.msgs, J.h2);
     }
 }
 
@@ -422,19 +600,6 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_pool_x3_kernel(EncArgs A)
 // Reference arithmetic: src/models/model.py:40-65 (layers 1 - 2), :1279-1283 (the sum; layer 3 and the processor scale are folded
 // into the decoder's first layer, pack.hpp: fold_w).
 // ---------------------------------------------------------------------------------------------------------
-#ifdef PIML_ENC_STAMPS
-// diagnostic build only (tools/enc_stamps_fwd.py): shader-clock stamps of thread 0 of every workgroup of the last enc_fwd_sum launch
-__device__ unsigned long long g_enc_stamps[512 * 16];
-#define ENC_STAMP(i, wait)                                                                         \
-    do {                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
-        if (threadIdx.x == 0 && blockIdx.x < 512) g_enc_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    } while (0)
-#else
-#define ENC_STAMP(i, wait)
-#endif
 
 template <bool ROWS>
 __device__ __forceinline__ void store_h2_rows(const f32x16 (&a)[4], float* __restrict__ h2, long long tile, long long R, int lane) {
@@ -534,23 +699,7 @@ __global__ __launch_bounds__(ENC_THREADS) void enc_fwd_sum_x3_kernel(EncArgs A) 
         mrow[64] = make_uint2(sign_bits(a[0], a[1]), sign_bits(a[2], a[3]));      // h2: lane = feature, bits = the tile's rows
         if (J.h2) store_h2_rows<true>(a, J.h2, tile, R, lane_t);
         ENC_STAMP(6, false);
-        if (k == 6) {
-            switch ((int)(tile % 3)) {
-                case 0: pool_rows<6, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                case 1: pool_rows<6, 1>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                default: pool_rows<6, 2>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-            }
-        } else if (k == 10) {
-            switch ((int)(tile % 5)) {
-                case 0: pool_rows<10, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                case 1: pool_rows<10, 1>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                case 2: pool_rows<10, 2>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                case 3: pool_rows<10, 3>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-                default: pool_rows<10, 4>(a, tile, agents, lane_t, J.sum_a, J.sum_b); break;
-            }
-        } else {
-            pool_rows<2, 0>(a, tile, agents, lane_t, J.sum_a, J.sum_b);
-        }
+        pool_rows_k(a, k, tile, agents, lane_t, J.sum_a, J.sum_b);
         ENC_STAMP(7, false);
     }
     ENC_STAMP(8, true);
@@ -1133,6 +1282,9 @@ int enc_x3_set_attributes() {
         if (int e = set(f, X3_DX_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_pool_x3_kernel), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_sum_x3_kernel), X3_FWD_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<2, true>), X3_FWD_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<1, true>), X3_FWD_LDS_BYTES)) return e;
+    if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<0, true>), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<2>), X3_FWD_LDS_BYTES)) return e;
     if (int e = set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<1>), X3_FWD_LDS_BYTES)) return e;
     return set(reinterpret_cast<const void*>(enc_fwd_x3_kernel<0>), X3_FWD_LDS_BYTES);
@@ -1168,8 +1320,14 @@ void enc_x3_launch_fwd_sum(const EncArgs& A, int total, hipStream_t s) {
     hipLaunchKernelGGL(enc_fwd_sum_x3_kernel, dim3(total), dim3(ENC_THREADS), X3_FWD_LDS_BYTES, s, A);
 }
 
-void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s) {
+void enc_x3_launch_fwd(const EncArgs& A, int total, bool drop, hipStream_t s, bool exch) {
     const dim3 g(total), b(ENC_THREADS);
+    if (exch) {          // PIML_POOL_MSGS: the last layer with exchanged operands, the agents' sums of the messages from registers
+        if (drop && A.gen_state) hipLaunchKernelGGL((enc_fwd_x3_kernel<2, true>), g, b, X3_FWD_LDS_BYTES, s, A);
+        else if (drop) hipLaunchKernelGGL((enc_fwd_x3_kernel<1, true>), g, b, X3_FWD_LDS_BYTES, s, A);
+        else hipLaunchKernelGGL((enc_fwd_x3_kernel<0, true>), g, b, X3_FWD_LDS_BYTES, s, A);
+        return;
+    }
     if (drop && A.gen_state) hipLaunchKernelGGL(enc_fwd_x3_kernel<2>, g, b, X3_FWD_LDS_BYTES, s, A);
     else if (drop) hipLaunchKernelGGL(enc_fwd_x3_kernel<1>, g, b, X3_FWD_LDS_BYTES, s, A);
     else hipLaunchKernelGGL(enc_fwd_x3_kernel<0>, g, b, X3_FWD_LDS_BYTES, s, A);

@@ -335,6 +335,7 @@ PIML_API int piml_pinnsf_slot_sums_flush(void) { return pending_slot_sums_flush(
 
 PIML_API int piml_pinnsf_pool_h2_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_h2_ok(enc, nbr) ? 1 : 0; }
 PIML_API int piml_pinnsf_pool_train_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_train_ok(enc, nbr) ? 1 : 0; }
+PIML_API int piml_pinnsf_pool_msgs_ok(const piml_encoder_branch* enc, int nbr) { return enc_pool_msgs_ok(enc, nbr) ? 1 : 0; }
 
 PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_branch* dec, int nbr,
                              const piml_collision_head* head, const float* self_features, float tau, float* acc,
@@ -350,6 +351,18 @@ PIML_API int piml_pinnsf_fwd(const piml_encoder_branch* enc, const piml_decoder_
         PIML_TRY(enc_stage_fwd_sum(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0));
         trace_mark("enc_fwd_sum", m);
         PIML_TRY(dec_stage_fwd_sum(dec, nbr, head, self_features, tau, acc, m));
+        trace_mark("dec_fwd_head_sum", m);
+        return hipSuccess;
+    }
+    if (flags & PIML_POOL_MSGS) {             // the agents' sums of the messages from the encoder forward's registers (see the header)
+        if ((flags & (PIML_FORK | PIML_POOL_H2)) || !enc_pool_msgs_ok(enc, nbr)) return hipErrorInvalidValue;
+        for (int i = 0; i < nbr; ++i)
+            if (dec[i].pooled != enc[i].sum_a || dec[i].msgs != enc[i].sum_b) return hipErrorInvalidValue;
+        if (head && head->rows > 0 && head->msgs != enc[0].msgs) return hipErrorInvalidValue;      // the head reads the rows the forward stores
+        if (pack) PIML_TRY(piml_pinnsf_pack(enc, dec, nbr, head, 0, stream));
+        PIML_TRY(enc_stage_fwd(enc, nbr, m, nbr > 1 ? acc : nullptr, nbr > 1 ? dec[0].agents * 2 : 0, true));
+        trace_mark("enc_fwd", m);
+        PIML_TRY(dec_stage_fwd_sum(dec, nbr, head, self_features, tau, acc, m, false));
         trace_mark("dec_fwd_head_sum", m);
         return hipSuccess;
     }

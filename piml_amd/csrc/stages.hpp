@@ -12,7 +12,10 @@ int enc_stage_pack(const piml_encoder_branch* br, int nbr, hipStream_t s);
 // false: no kernel the current settings dispatch reads the f32-instruction fragment images of `packed` (split products everywhere)
 bool enc_f32_images_needed();
 // packed image must be current; `zero` (optional): zero_n floats cleared by the launch
-int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0);
+int enc_stage_fwd(const piml_encoder_branch* br, int nbr, hipStream_t s, float* zero = nullptr, long long zero_n = 0, bool msum = false);
+// msum = PIML_POOL_MSGS: the agents' sums of the messages written by the forward (sum_a / sum_b), message rows only where a branch
+// carries `msgs`; enc_pool_msgs_ok: the configuration that form serves
+bool enc_pool_msgs_ok(const piml_encoder_branch* br, int nbr);
 // PIML_POOL_H2 (inference): the forward up to layer 2 and the agents' sums of h2 into `msgs` / `h2`, both (agents, 128)
 // (enc_fwd_pool_x3_kernel); enc_pool_h2_ok: the configuration it serves
 bool enc_pool_h2_ok(const piml_encoder_branch* br, int nbr);
@@ -45,8 +48,9 @@ int dec_stage_bwd_fused(const piml_decoder_branch* br, int nbr, const float* g_p
                         float* g_self, hipStream_t s, bool sums = false);      // sums: PIML_POOL_TRAIN (folded first layer)
 // PIML_POOL_TRAIN: decoder tails on the agents' sums of h2 (`pooled` + second parts in `msgs`) with the folded first layer, and
 // the collision head (may be NULL) on the h2 rows with the folded W1, in one launch
+// fold = false (PIML_POOL_MSGS): the sums are the agents' sums of the MESSAGES (plain first layers, the head on the message rows)
 int dec_stage_fwd_sum(const piml_decoder_branch* br, int nbr, const piml_collision_head* h, const float* self_features, float tau,
-                      float* acc, hipStream_t s);
+                      float* acc, hipStream_t s, bool fold = true);
 int dec_stage_bwd_dw(const piml_decoder_branch* br, int nbr, const float* g_pred, bool reduce, hipStream_t s);   // partials (+ slot sum)
 
 // keep-masks of up to two row sets in ONE launch (one draw, streams[i] tells them apart); advances the draw counter

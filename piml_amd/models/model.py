@@ -202,7 +202,8 @@ class _PINNSFBase(nn.Module):
     messages_wanted = True      # False: the caller reads predictions[0] (and the collision head's output, without training it) only --
                                 # what the reference's loops do unless reg_weight > 0 (src/models/simulators.py:331-347, :702-737).
                                 # `pinnsf` / `pinnsf_m` then run on the agents' SUMS of h2 where no dropout mask is active and the
-                                # library serves the shape (ops.fused_pinnsf(sums=True), PIML_POOL_TRAIN); out[1] / out[2] are None
+                                # library serves the shape (ops.fused_pinnsf(sums=True), PIML_POOL_TRAIN), and under a dropout mask on
+                                # the sums of the messages the encoder forward leaves (PIML_POOL_MSGS); out[1] / out[2] are None
     residual = False            # pinnsf_res corrector branch
     obs_encoder_in = 6          # PINNSF_residual uses args.obs_feature_dim instead
     taus = (2, 2)               # (non-ucy tau, ucy tau)
@@ -417,7 +418,9 @@ class _PINNSFBase(nn.Module):
             [dict(x=f, scale=sp[0], keep_bits=sp[1], encoder=[t for lin in e.mlp[0::2] for t in (lin.weight, lin.bias)],
                   decoder=[t for lin in d.mlp[0::2] for t in (lin.weight, lin.bias)],
                   predictor=[q.mlp[0].weight, q.mlp[0].bias]) for (f, e, p, d, q), sp in zip(cand, specs)],
-            self_features, self.tau, fold_epilogue=fold, head=head, packs=packs, sums=not self.messages_wanted)
+            self_features, self.tau, fold_epilogue=fold, head=head, packs=packs,
+            # (a collision head outside the fused geometry reads the messages through torch below: they have to exist)
+            sums=not self.messages_wanted and (self.collision_head is None or head is not None or self.predictions_only))
         acc, msgs = res[0], res[1]
         if not fold:
             if self_features.dim() == 3:

@@ -2139,6 +2139,7 @@ def _weights_sig(enc_w, dec_w, head_w):
 
 
 DEFER_PACK = _os.environ.get('PIML_DEFER_PACK', '1') != '0'
+POOL_MSGS = _os.environ.get('PIML_POOL_MSGS', '1') != '0'      # fused_pinnsf(sums=True) under a dropout mask: the agents' sums of the messages from the forward's registers
 
 
 def pinnsf_prepack(packs, enc_w, dec_w, head_w=None, defer=None, fold=None):
@@ -2326,6 +2327,7 @@ class _FusedPinnsf(torch.autograd.Function):
             agents *= d
         sf = _gpu_f32('self_features', self_features).reshape(agents, 7) if fold_epilogue else None
         x2s, ks, msgs, h1s, h2s = [], [], [], [], []
+        msum = False
         for b in range(nbr):
             x = _gpu_f32('encoder input', xs[b])
             if tuple(x.shape[:-2]) != lead:
@@ -2336,14 +2338,26 @@ class _FusedPinnsf(torch.autograd.Function):
             probe = (_lib.EncoderBranch * nbr)()
             for b in range(nbr):
                 probe[b].rows, probe[b].in_dim, probe[b].k = x2s[b].shape[0], x2s[b].shape[1], ks[b]
+            wanted = sums
             sums = bool(L.piml_pinnsf_pool_train_ok(probe, nbr)) and not FORK_NETWORK and \
                 (packs is None or packs.fold == tuple(float(sc) for sc in scales)) and all(k is None for k in keeps)
+            # PIML_POOL_MSGS: the caller reads no messages, but a dropout mask (or packs without the folded images, or a gradient
+            # on the collision head: see backward) keeps the sum behind the last layer -- the forward kernel still leaves the
+            # agents' sums (last layer with exchanged operands) and stores message rows only for the head; plain backward
+            if wanted and not sums and need_grad and not FORK_NETWORK and RELU_MASK and POOL_MSGS:
+                for b in range(nbr):
+                    probe[b].relu_mask = 1          # (any non-NULL value: the probe looks at the configuration only)
+                msum = bool(L.piml_pinnsf_pool_msgs_ok(probe, nbr))
         ctx.sums = sums
         sum_a, sum_b, masks = [None] * nbr, [None] * nbr, [None] * nbr
         for b in range(nbr):
             R = x2s[b].shape[0]
             h1s.append(None)
-            if sums:
+            if msum:
+                msgs.append(torch.empty(R, H, **opt) if (nhead and b == 0) else None)
+                sum_a[b], sum_b[b] = torch.empty(agents, H, **opt), torch.empty(agents, H, **opt)
+                h2s.append(_h2_buffer(R, opt))
+            elif sums:
                 # the agents' sums of h2 in two parts; the sign words of h1 / h2 (256 dwords per tile); the h2 rows only where the
                 # collision head reads them (branch 0)
                 msgs.append(None)
@@ -2355,7 +2369,7 @@ class _FusedPinnsf(torch.autograd.Function):
                 h2s.append(_h2_buffer(R, opt) if need_grad else None)
         if not sums and need_grad and _h1_needed([x2.shape[0] for x2 in x2s], alone=False):
             h1s = [torch.empty(x2.shape[0], H, **opt) for x2 in x2s]
-        flags = (_lib.FORK if FORK_NETWORK else 0) | (_lib.POOL_TRAIN if sums else 0)
+        flags = (_lib.FORK if FORK_NETWORK else 0) | (_lib.POOL_TRAIN if sums else 0) | (_lib.POOL_MSGS if msum else 0)
         if packs is not None:
             if packs.sig != _weights_sig(ewb, dwb, hwb):
                 raise ValueError('fused_pinnsf: `packs` were filled from other weight tensors, or the weights were modified in '
@@ -2372,11 +2386,11 @@ class _FusedPinnsf(torch.autograd.Function):
                                                                relu_mask=masks[b], sum_a=sum_a[b], sum_b=sum_b[b])
                                             for b in range(nbr)])
         # (sums: the decoder reads the first parts from `pooled` and leaves the completed sums there)
-        pooled = sum_a if sums else [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
+        pooled = sum_a if (sums or msum) else [torch.empty(agents, H, **opt) for _ in range(nbr)]      # always: the decoder kernel reads it
         dh1 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         dd2 = [torch.empty(agents, 64, **opt) if need_grad else None for _ in range(nbr)]
         folds = [(ewb[b][4], ewb[b][5], scales[b]) if sums else None for b in range(nbr)]
-        darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(sum_b[b] if sums else msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
+        darr = (_lib.DecoderBranch * nbr)(*[_dec_branch_struct(sum_b[b] if (sums or msum) else msgs[b], agents, ks[b], dwb[b], dpack[b], pooled[b],
                                                                dh1[b], dd2[b], fold=folds[b]) for b in range(nbr)])
         acc = torch.empty(agents, 2, **opt)
         head, coll = None, None
@@ -2393,7 +2407,10 @@ class _FusedPinnsf(torch.autograd.Function):
                                          float(tau), _ptr(acc), flags, _stream()), 'piml_pinnsf_fwd')
         if need_grad:
             # (sums: the sign words in h2's place; the second parts, which the backward does not read, in the messages')
-            ctx.save_for_backward(*x2s, *h1s, *(masks if sums else h2s), *(sum_b if sums else msgs), *pooled, *dh1, *dd2,
+            # (msum: the pedestrian message rows where the head read them -- its backward needs them -- else the second parts, which
+            # only stand in the decoder structs' `msgs` field)
+            saved_msgs = sum_b if sums else ([msgs[b] if msgs[b] is not None else sum_b[b] for b in range(nbr)] if msum else msgs)
+            ctx.save_for_backward(*x2s, *h1s, *(masks if sums else h2s), *saved_msgs, *pooled, *dh1, *dd2,
                                   *[w for wb in ewb for w in wb],
                                   *[w for wb in dwb for w in wb], epack, dpack, *([sf] if sf is not None else []),
                                   *(hwb if nhead else []))
@@ -2403,7 +2420,7 @@ class _FusedPinnsf(torch.autograd.Function):
         ctx.sink = ParamGradSink._active if need_grad else None
         ctx.params = tensors if need_grad else None       # (the Parameter objects themselves: p.grad is set on them / looked at)
         ctx.set_materialize_grads(False)
-        out = (acc.view(*lead, 2), *[None if sums else msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
+        out = (acc.view(*lead, 2), *[None if (sums or msum) else msgs[b].view(*lead, ks[b], H) for b in range(nbr)])
         if nhead:
             out = out + (coll.view(*lead, ks[0]),)
         return out

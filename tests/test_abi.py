@@ -127,14 +127,16 @@ def test_tuning_file_is_consistent():
 
 def test_no_kernel_of_the_default_dispatch_spills():
     """Register / scratch figures straight from the code objects inside libpiml_hip.so (`_lib.kernel_resource_usage`): the only
-    kernels with a non-zero spill count are the two A/B forms the default dispatch never launches (profiles/r04_kernel_usage.md:
+    kernels with a non-zero spill count are the two A/B forms the default dispatch never launches (profiles/r05_kernel_usage.md:
     `PIML_DEC_BWD_SPLIT=0`, `PIML_ENC_FUSED_BWD=2`)."""
     pytest.importorskip('msgpack')          # (the code objects' metadata notes are msgpack; not a dependency of the package itself)
     from piml_amd import _lib
     usage = _lib.kernel_resource_usage()
     assert len(usage) > 150 and not [k for k in usage if k.startswith('_Z')]
-    for name in ('relfeat_fwd_kernel<16, false>', 'enc_fwd_x3_kernel<0>', 'enc_bwd_fused_x3_kernel<true, false, false, true, false>',
-                 'enc_fwd_sum_x3_kernel', 'enc_bwd_fused_x3_kernel<true, false, false, true, true>', 'dec_fwd_head_sum_kernel',
+    for name in ('relfeat_fwd_kernel<16, false>', 'enc_fwd_x3_kernel<0, false>', 'enc_fwd_x3_kernel<2, true>', 'enc_fwd_x3_kernel<1, true>',
+                 'enc_bwd_fused_x3_kernel<true, false, false, true, false>',
+                 'enc_fwd_sum_x3_kernel', 'enc_bwd_fused_x3_kernel<true, false, false, true, true>', 'dec_fwd_head_sum_kernel<true>',
+                 'dec_fwd_head_sum_kernel<false>',
                  'pinnsf_unfold_kernel',
                  'dec_fwd_head_kernel<true>', 'dec_bwd_split_kernel', 'relfeat_bwd_reduce_kernel', 'mlapm_bwd_sys_kernel<1>'):
         assert name in usage, name

@@ -134,11 +134,13 @@ def test_sums_path_inside_packed_weights_and_deferred_slot_sums():
     assert res1[1][0] is None and torch.equal(res1[0], res0[0]) and torch.equal(res1[2], res0[2])
     for a, b in zip(grads1, grads0):
         assert torch.equal(a, b)
-    # packs made without the folded images: the call takes the message path (and says so by returning the messages)
+    # packs made without the folded images: no PIML_POOL_TRAIN -- the call runs on the sums of the MESSAGES the encoder forward leaves
+    # (PIML_POOL_MSGS, test below), still without returning messages; PIML_POOL_MSGS=0 in the environment: the message path
     plain = ops.PinnsfPacks()
     ops.pinnsf_prepack(plain, [br['encoder'] for br in brs], [br['decoder'] + br['predictor'] for br in brs], head, defer=False)
     res2, _ = run(brs, sf, head, wa, tau, True, packs=plain)
-    assert res2[1][0] is not None
+    assert (res2[1][0] is None) == ops.POOL_MSGS
+    assert float((res2[0] - res0[0]).abs().max() / res0[0].abs().max()) <= 1e-5
 
 
 def test_sums_path_refuses_a_gradient_on_the_collision_head():
@@ -151,7 +153,7 @@ def test_sums_path_refuses_a_gradient_on_the_collision_head():
 
 def test_model_messages_wanted_false_takes_the_sums_path():
     """PINNSF_multitask with messages_wanted = False: same predictions and gradients as the default (to float32 rounding),
-    out[1] / out[2] are None; in train mode with dropout the flag changes nothing."""
+    out[1] / out[2] are None; in train mode with dropout the messages are not returned either (sums of the messages)."""
     import types
     import piml_amd.models.model as MODEL
     args = types.SimpleNamespace(
@@ -177,7 +179,74 @@ def test_model_messages_wanted_false_takes_the_sums_path():
                 [rel(a, b) for a, b in zip(outs[False][1], outs[True][1])])
     print(f'model sums path vs message path: max rel diff {worst:.1e}')
     assert len(outs[False][1]) == len(outs[True][1]) and worst <= 2e-5
+    # train mode: the dropout mask keeps the sum behind the last layer -- the forward leaves the sums of the messages instead
+    # (PIML_POOL_MSGS, parity under injected masks: test below), again without returning messages
+    from piml_amd import ops
     net.train()
     net.messages_wanted = False
     out = net(pf, of, sf)
-    assert out[1] is not None
+    assert (out[1] is None) == ops.POOL_MSGS and bool(torch.isfinite(out[0]).all())
+    out[0].sum().backward()
+
+
+@pytest.mark.parametrize('agents,ks,with_head,drop', [(4096, (6, 10), True, 'bits'), (2500, (6, 10), False, 'bits'), (4099, (10, 6), True, 'bits'),
+                                                      (4096, (6, 10), True, 'draw'), (12000, (6, 2), True, None)])
+def test_sums_of_the_messages_under_a_dropout_mask(agents, ks, with_head, drop):
+    """fused_pinnsf(sums=True) with a dropout mask on the processors (PIML_POOL_MSGS): the sum cannot move in front of the encoders'
+    last layer, so that layer runs with exchanged operands and the forward leaves the agents' sums of the MESSAGES; message rows are
+    stored for the collision head only; the backward is the message path's.  Against the message path with the SAME mask (injected
+    bits; for a mask drawn in the kernel: the bits the first call left) -- outputs and every gradient, incl. a gradient arriving on
+    the collision head's output -- and no messages returned.  drop None: packs without the folded images take the same route.
+    Reference arithmetic: src/models/model.py:82-119, :1279-1305."""
+    from piml_amd import ops
+    tau = 0.5
+    brs, sf, head, wa, g = make_net(agents, ks, with_head, seed=41)
+    keeps = None
+    if drop:
+        keeps = [ops.pack_keep_bits(torch.rand(agents * k, H, generator=g) >= 0.5).to(DEV) for k in ks]
+        for br, kb in zip(brs, keeps):
+            br['keep_bits'] = kb
+            br['scale'] = 4.0               # 2 / (1 - p)
+    packs = None
+    if drop is None:                        # plain packs (no folded images): sums=True cannot take PIML_POOL_TRAIN
+        packs = ops.PinnsfPacks()
+        ops.pinnsf_prepack(packs, [br['encoder'] for br in brs], [br['decoder'] + br['predictor'] for br in brs], head, defer=False)
+    wc = torch.randn(agents, ks[0], generator=g).to(DEV) if with_head else None
+    leaves = [sf] + [t for br in brs for t in (br['x'], *br['encoder'], *br['decoder'], *br['predictor'])] + (list(head) if with_head else [])
+
+    def go(sums):
+        res = ops.fused_pinnsf(brs, sf, tau, fold_epilogue=True, head=head, packs=packs, sums=sums)
+        loss = (res[0] * wa).sum() + ((res[-1] * wc).sum() if with_head else 0.0)
+        return res, torch.autograd.grad(loss, leaves, allow_unused=True)
+    if drop == 'draw':
+        # the call draws its mask (p = 0.5: inside the forward kernel) and its node keeps the bits for the backward; the message path then
+        # runs on exactly those bits, injected
+        for br in brs:
+            br['keep_bits'] = ('draw', 0.5)
+        res = ops.fused_pinnsf(brs, sf, tau, fold_epilogue=True, head=head, packs=packs, sums=True)
+        drawn = [kb.clone() for kb in res[0].grad_fn.keeps]
+        kept = float(torch.cat([ops.unpack_keep_bits(kb, H).float().flatten() for kb in drawn]).mean()) if hasattr(ops, 'unpack_keep_bits') else 0.5
+        assert abs(kept - 0.5) < 5e-3
+        loss = (res[0] * wa).sum() + ((res[-1] * wc).sum() if with_head else 0.0)
+        res_s, grads_s = res, torch.autograd.grad(loss, leaves, allow_unused=True)
+        for br, kb in zip(brs, drawn):
+            br['keep_bits'] = kb
+        res_m, grads_m = go(False)
+    else:
+        res_s, grads_s = go(True)
+        res_m, grads_m = go(False)
+    assert all(m is None for m in res_s[1]) and all(m is not None for m in res_m[1])
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    worst = {'acc': rel(res_s[0], res_m[0])}
+    if with_head:
+        worst['coll'] = rel(res_s[-1], res_m[-1])
+    for i, (a, b) in enumerate(zip(grads_s, grads_m)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            worst[f'grad{i}'] = rel(a, b)
+    w = max(worst.values())
+    print(f'sums of the messages agents={agents} k={ks} head={with_head} drop={drop}: max rel diff to the message path {w:.1e} ({max(worst, key=worst.get)})')
+    assert w <= 1e-5, worst
+    res_2, grads_2 = go(True)          # (drop == 'draw': now on the injected bits -- the same arithmetic, bit for bit)
+    assert torch.equal(res_2[0], res_s[0])
+
