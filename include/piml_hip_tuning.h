@@ -48,12 +48,13 @@ int piml_trace_end(char* names, int names_cap, float* us, int us_cap);
 int piml_probe_arith(const float* rx, const float* ry, const float* hx, const float* hy,
                      float* dist, float* cosv, int n, void* stream);
 
-/* Up to this many 32-row tiles (both branches together) the forward runs with four waves per tile instead of one (few
- * rows: rollouts of real clips); the two forms are bitwise identical.  Returns the previous value; < 0 only queries. */
+/* Up to this many 32-row tiles (both branches together; default 640) a LONE forward -- no relu_mask, no backward -- runs with
+ * four waves per tile instead of one (few rows: rollouts of real clips); the two forms are bitwise identical.  Returns the
+ * previous value; < 0 only queries. */
 long long piml_encoder_split_tiles(long long tiles);
-/* The same bound for a TRAINING pass (every branch carries relu_mask, i.e. a backward follows): default 48 tiles -- with the
- * one-pass backward the one-wave kernels win from the real clips' sizes on (122 agents = 62 tiles), while a lone forward still
- * wants four waves per tile up to piml_encoder_split_tiles().  piml_encoder_split_tiles(tiles >= 0) sets BOTH bounds (A/B),
+/* The same bound for a TRAINING pass (every branch carries relu_mask, i.e. a backward follows; with or without a dropout mask):
+ * default 48 tiles -- with the one-pass backward and the wave-major tile order the one-wave kernels win from the real clips'
+ * sizes on (122 agents = 62 tiles), while a lone forward still wants four waves per tile up to piml_encoder_split_tiles().  piml_encoder_split_tiles(tiles >= 0) sets BOTH bounds (A/B),
  * piml_encoder_split_tiles(-2) puts both back to their defaults (environment PIML_ENC_SPLIT_TILES[_TRAIN] at load time).
  * Returns the previous value; < 0 only queries. */
 long long piml_encoder_split_tiles_train(long long tiles);
