@@ -306,7 +306,17 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
     const int dslots = piml_decoder_workgroups(dec[0].agents);
     int n0[2] = {0, 0}, n1[2] = {0, 0};
     const bool dw2 = !sums && enc_dw2_used(enc, nbr, n0, n1);
+    // diagnostic builds (RESULTS WRONG ON PURPOSE): PIML_REDUCE_ENC_DIV / PIML_REDUCE_DEC_DIV = read only every n-th part of the
+    // encoder / decoder slots -- what the reduce launch would cost behind a reduction of the slots inside the producing kernels
+#ifndef PIML_REDUCE_ENC_DIV
+#define PIML_REDUCE_ENC_DIV 1
+#endif
+#ifndef PIML_REDUCE_DEC_DIV
+#define PIML_REDUCE_DEC_DIV 1
+#endif
+    int div = PIML_REDUCE_ENC_DIV;
     auto add = [&](const float* parts, float* grads, int slots, int lanes, int split, int off0, int off1) {
+        slots = (slots + div - 1) / div;
         R.set[n++] = ReduceSet{parts, grads, slots, lanes, split, off0, off1};
         if (lanes > maxl) maxl = lanes;
     };
@@ -322,6 +332,7 @@ static int reduce_all(const piml_encoder_branch* enc, const piml_decoder_branch*
             add(enc[i].partials, enc[i].grads, nbr == 1 ? total : (i == 0 ? w0 : total - w0), ENC_PART / 4, 0x7fffffff, 0, 0);
         }
     }
+    div = PIML_REDUCE_DEC_DIV;
     for (int i = 0; i < nbr; ++i) add(dec[i].partials, dec[i].grads, dslots, DEC_PART / 4, 0x7fffffff, 0, 0);
     R.nsets = n;
     R.gx = (maxl + 15) / 16;
