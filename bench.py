@@ -911,6 +911,13 @@ def main():
             if args.exchange == 'p2p':
                 raise
             print(f'[bench] P2P exchange unavailable for the comparison leg ({type(ex).__name__}: {ex})', file=sys.stderr)
+        if args.exchange != 'p2p':
+            # the comparison leg is all ranks or none: a rank that could not open its peers' buffers must not leave the others waiting
+            # for its stores (and for the collective behind the leg)
+            ok = torch.tensor([1 if p2p is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                p2p = None
     # The obstacle branch of the MLP on a side stream makes two GEMM chains run concurrently inside the
     # captured graph.  Concurrent library GEMMs are only safe with kernels that never wait for
     # co-residency: hipBLASLt's DEFAULT heuristics pick stream-K style kernels for some shapes
