@@ -631,8 +631,11 @@ int piml_encoder_fwd(const piml_encoder_branch* branches, int nbranches, void* s
  * pack per rollout or per back-propagated window instead of one per frame */
 int piml_encoder_fwd_packed(const piml_encoder_branch* branches, int nbranches, void* stream);
 int piml_encoder_bwd(const piml_encoder_branch* branches, int nbranches, void* stream);
-/* accumulate != 0: `grads` += the slot sums instead of = (a further backward pass through the same weights within one
- * optimiser step -- the frames of a training rollout; cf. PIML_ACCUMULATE of piml_pinnsf_bwd). */
+/* accumulate = 1 (or PIML_ACCUMULATE): `grads` += the slot sums instead of = (a further backward pass through the same weights
+ * within one optimiser step -- the frames of a training rollout; cf. PIML_ACCUMULATE of piml_pinnsf_bwd).  | PIML_DEFER_SLOT_SUMS:
+ * the slot sums are not launched here but left for the next piml_relfeat_self_bwd on the stream (or piml_pinnsf_slot_sums_flush),
+ * which runs them as leading workgroups of its launch -- together with those a piml_rowdecoder_bwd_acc of the same backward pass
+ * left (the bottleneck variants: three launches become one); `partials` and `grads` must stay alive until then. */
 int piml_encoder_bwd_acc(const piml_encoder_branch* branches, int nbranches, int accumulate, void* stream);
 /* pooled (agents, 128) = sum over k consecutive rows of msgs (agents * k, 128) */
 int piml_encoder_ksum(const float* msgs, long long agents, int k, float* pooled, void* stream);

@@ -1702,8 +1702,20 @@ PIML_API int piml_rowdecoder_bwd_acc(const piml_decoder_branch* br, int nbr, int
     }
     hipLaunchKernelGGL(rowdec_bwd_dw_lds_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 2 * RD_BUF * 4, s, A, slots0,
                        rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
+    // `accumulate`: 0 / 1, or flags -- PIML_ACCUMULATE and / or PIML_DEFER_SLOT_SUMS (the header)
+    const bool acc = (accumulate & 1) || (accumulate & PIML_ACCUMULATE);
+    if (accumulate & PIML_DEFER_SLOT_SUMS) {          // the slot sums ride in the relfeat backward's launch (network.hip)
+        ReduceAll R = {};
+        R.accumulate = acc ? 1 : 0;
+        R.set[0] = ReduceSet{br[0].partials, br[0].grads, slots0, DEC_PART / 4, 0x7fffffff, 0, 0};
+        if (nbr > 1) R.set[1] = ReduceSet{br[1].partials, br[1].grads, slots1, DEC_PART / 4, 0x7fffffff, 0, 0};
+        R.nsets = nbr;
+        R.gx = (DEC_PART / 4 + 15) / 16;
+        if (hipError_t e = hipGetLastError()) return e;
+        return pending_slot_sums_leave(R, s);
+    }
     hipLaunchKernelGGL(rowdec_reduce_kernel, dim3((DEC_PART / 4 + 15) / 16, nbr), dim3(256), 0, s, A, slots0, slots1,
-                       DEC_PART / 4, accumulate ? 1 : 0);
+                       DEC_PART / 4, acc ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -1207,12 +1207,35 @@ int piml::enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s
     return hipGetLastError();
 }
 
-int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate) {
+int piml::enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate, bool defer) {
     if (int e = enc_bwd_check(br, nbr)) return e;
     EncArgs A;
     fill_args(A, br, nbr);
     Reduce2Args R2 = {};
     R2.accumulate = accumulate ? 1 : 0;
+    if (defer) {          // PIML_DEFER_SLOT_SUMS: the description goes to the relfeat backward's launch (network.hip: reduce_all's sets)
+        ReduceAll R = {};
+        R.accumulate = accumulate ? 1 : 0;
+        int n = 0, maxl = 0;
+        auto add = [&](const float* parts, float* grads, int slots, int lanes, int split, int off0, int off1) {
+            R.set[n++] = ReduceSet{parts, grads, slots, lanes, split, off0, off1};
+            if (lanes > maxl) maxl = lanes;
+        };
+        int n0[2] = {0, 0}, n1[2] = {0, 0}, w0 = 0;
+        const int total = piml_encoder_workgroups(br, nbr, &w0);
+        const bool dw2 = enc_dw2_used(br, nbr, n0, n1);
+        for (int i = 0; i < nbr; ++i) {
+            if (dw2) {
+                add(br[i].partials, br[i].grads, n0[i], DW2_L0_LANES, DW2_L0_SPLIT, 0, DW2_L0_OFF1);
+                add(br[i].partials + (size_t)n0[i] * (DW2_L0_LANES * 4), br[i].grads, n1[i], DW2_L1_LANES, DW2_L1_SPLIT, DW2_L1_OFF0, DW2_L1_OFF1);
+            } else {
+                add(br[i].partials, br[i].grads, nbr == 1 ? total : (i == 0 ? w0 : total - w0), ENC_PART / 4, 0x7fffffff, 0, 0);
+            }
+        }
+        R.nsets = n;
+        R.gx = (maxl + 15) / 16;
+        return pending_slot_sums_leave(R, s);
+    }
     if (enc_dw2_used(br, nbr, R2.n0, R2.n1)) {
         for (int i = 0; i < nbr; ++i) R2.br[i] = br[i];
         hipLaunchKernelGGL(enc_reduce2_kernel, dim3((DW2_L1_LANES + 15) / 16, 2 * nbr), dim3(256), 0, s, R2);
@@ -1321,9 +1344,11 @@ PIML_API int piml_encoder_ksum(const float* msgs, long long agents, int k, float
 }
 
 PIML_API int piml_encoder_bwd_acc(const piml_encoder_branch* br, int nbr, int accumulate, void* stream) {
+    // `accumulate`: 0 / 1, or flags -- PIML_ACCUMULATE and / or PIML_DEFER_SLOT_SUMS (the header)
+    const bool acc = (accumulate & 1) || (accumulate & PIML_ACCUMULATE), defer = (accumulate & PIML_DEFER_SLOT_SUMS) != 0;
     if (int e = enc_stage_bwd_dx(br, nbr, as_stream(stream))) return e;
     if (int e = enc_stage_bwd_dw(br, nbr, as_stream(stream))) return e;
-    return enc_stage_reduce(br, nbr, as_stream(stream), accumulate != 0);
+    return enc_stage_reduce(br, nbr, as_stream(stream), acc, defer);
 }
 
 PIML_API int piml_encoder_bwd(const piml_encoder_branch* br, int nbr, void* stream) { return piml_encoder_bwd_acc(br, nbr, 0, stream); }

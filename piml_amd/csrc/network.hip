@@ -232,9 +232,27 @@ int pending_slot_sums_flush() {
 }
 
 int pending_slot_sums_leave(const ReduceAll& R, hipStream_t s) {
-    if (int e = pending_slot_sums_flush()) return e;          // sums already waiting: they run now, on the stream they were left on
     PendingSums* P = pending_entry();
     if (!P) return hipErrorInvalidDevice;
+    {
+        // Sums of ANOTHER operator of the same backward pass waiting on this stream (the bottleneck variants: row decoder, then
+        // encoders, piml_rowdecoder_bwd_acc / piml_encoder_bwd_acc with PIML_DEFER_SLOT_SUMS): the two descriptions become one
+        // launch -- when they fit, accumulate alike, carry no unfold, and write DIFFERENT gradient buffers (the same buffer twice
+        // is a second pass over the same parameters: its predecessor has to run first).
+        std::lock_guard<std::mutex> lock(g_mu);
+        ReduceAll& Q = P->R;
+        bool merge = P->valid && P->stream == s && Q.accumulate == R.accumulate && Q.nunf == 0 && R.nunf == 0 &&
+                     Q.nsets + R.nsets <= (int)(sizeof(Q.set) / sizeof(Q.set[0]));
+        for (int i = 0; merge && i < Q.nsets; ++i)
+            for (int j = 0; j < R.nsets; ++j)
+                if (Q.set[i].grads == R.set[j].grads) { merge = false; break; }
+        if (merge) {
+            for (int j = 0; j < R.nsets; ++j) Q.set[Q.nsets++] = R.set[j];
+            if (R.gx > Q.gx) Q.gx = R.gx;
+            return hipSuccess;
+        }
+    }
+    if (int e = pending_slot_sums_flush()) return e;          // sums already waiting: they run now, on the stream they were left on
     std::lock_guard<std::mutex> lock(g_mu);
     P->R = R; P->stream = s; P->valid = true;
     return hipSuccess;

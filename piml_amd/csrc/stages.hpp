@@ -27,7 +27,7 @@ int enc_stage_fwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s, flo
 int enc_stage_bwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t s);        // slots: one DW2_PART1 slot per workgroup
 int enc_stage_bwd_dx(const piml_encoder_branch* br, int nbr, hipStream_t s);
 int enc_stage_bwd_dw(const piml_encoder_branch* br, int nbr, hipStream_t s);          // dW partials (after bwd_dx)
-int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate = false);
+int enc_stage_reduce(const piml_encoder_branch* br, int nbr, hipStream_t s, bool accumulate = false, bool defer = false);      // defer: PIML_DEFER_SLOT_SUMS
 // true when enc_stage_bwd_dw writes these branches' partials as layer-split slots (encoder_dw2.hip); then
 // n0[i] / n1[i] = the layer-0 / layer-1 slots of branch i
 bool enc_dw2_used(const piml_encoder_branch* br, int nbr, int* n0, int* n1);

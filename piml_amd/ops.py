@@ -1953,7 +1953,7 @@ class _FusedEncoders(torch.autograd.Function):
         ctx.save_for_backward(*x2s, *h1s, *h2s, *[w for wb in wbs for w in wb], packed)
         ctx.meta = (nbr, tuple(scales), tuple(want_pooled), tuple(ks), [tuple(x.shape) for x in xs], need_grad)
         ctx.sink = ParamGradSink._active if need_grad else None
-        ctx.params = tensors if ctx.sink is not None else None
+        ctx.params = tensors if need_grad else None       # (the Parameter objects: the sink's keys / the deferral's .grad test)
         ctx.keeps = keeps
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -2006,8 +2006,14 @@ class _FusedEncoders(torch.autograd.Function):
             flats = [torch.empty(part, **opt) for _ in slots]
         for i in range(len(live)):
             arr[i].partials, arr[i].grads = parts[i].data_ptr(), flats[i].data_ptr()
+        # inside ops.deferred_slot_sums(): the slot sums ride in the relfeat backward's launch, merged with the row decoders' of the
+        # same pass (the bottleneck variants: three launches become one)
+        defer = _defer_slot_sums([ctx.params[7 * b + jx] for b in live for jx in range(1, 7)], sink, dev)
         with torch.cuda.device(dev):
-            _lib.check(L.piml_encoder_bwd_acc(arr, len(live), int(accumulate), _stream()), 'piml_encoder_bwd')
+            _lib.check(L.piml_encoder_bwd_acc(arr, len(live), int(accumulate) | (_lib.DEFER_SLOT_SUMS if defer else 0), _stream()),
+                       'piml_encoder_bwd')
+        if defer:
+            _defer_keep(parts, flats)
         H = ENCODER_HIDDEN
         for i, b in enumerate(live):
             flat = flats[i]
@@ -2237,6 +2243,14 @@ class ParamGradSink:
 
 _DEFER_DEPTH = 0
 _DEFER_KEEP = []        # the slot buffers deferred sums will read: alive until those sums have been launched
+
+
+def _defer_keep(*buffers):
+    """Operators that leave their slot sums one by one (fused_encoders, the row decoder): the library merges what is waiting on the
+    stream into one launch, so the buffers of the last few deferrals stay alive together; a further deferral launches its
+    predecessors (piml_amd/csrc/network.hip: pending_slot_sums_leave), whose buffers may then go."""
+    _DEFER_KEEP.append(buffers)
+    del _DEFER_KEEP[:-4]
 _DEFER_SEEN = set()     # id(parameter) of every parameter that was handed a deferred gradient inside the open block
 _DEFER_DEVS = set()     # devices a deferral was left on (the flush at the block's exit visits each of them)
 
@@ -2808,7 +2822,7 @@ class _FusedRowDecoder(torch.autograd.Function):
             ctx.save_for_backward(*e2, *h1, *d2, *[w for wb in wbs for w in wb], dpack)
         ctx.meta = (nbr, rows, [tuple(e.shape) for e in embs], need_grad)
         ctx.sink = ParamGradSink._active if need_grad else None
-        ctx.params = tensors if ctx.sink is not None else None
+        ctx.params = tensors if need_grad else None       # (the Parameter objects: the sink's keys / the deferral's .grad test)
         ctx.set_materialize_grads(False)
         out = []
         for b in range(nbr):
@@ -2855,9 +2869,13 @@ class _FusedRowDecoder(torch.autograd.Function):
             keep += [gp, gd, gp2, gp1, parts]
             flats.append(flat)
             gembs.append(gemb)
+        defer = _defer_slot_sums([ctx.params[PER * b + jx] for b in live for jx in range(1, 7)], sink, dev)
         with torch.cuda.device(dev):
-            _lib.check(L.piml_rowdecoder_bwd_acc((_lib.DecoderBranch * len(live))(*structs), len(live), int(accumulate), _stream()),
+            _lib.check(L.piml_rowdecoder_bwd_acc((_lib.DecoderBranch * len(live))(*structs), len(live),
+                                                 int(accumulate) | (_lib.DEFER_SLOT_SUMS if defer else 0), _stream()),
                        'piml_rowdecoder_bwd')
+        if defer:
+            _defer_keep(keep, flats)
         for i, b in enumerate(live):
             o = 2 + PER * b
             if ctx.needs_input_grad[o]:
