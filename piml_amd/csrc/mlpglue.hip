@@ -32,11 +32,8 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_fwd_kernel(const float2* 
 
 // g_self from g_out.  e = d / t; g_e = g v0 / tau; g_d = g_e / t + g_t * d / n  (0 where n == 0),
 // g_t = -(g_e . d) / t^2; g_v = -g / tau; g_a = 0; g_v0 = (g . e) / tau.
-__global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* __restrict__ g_out,
-                                                                   const float* __restrict__ sf, size_t rows, float tau,
-                                                                   float* __restrict__ g_self) {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
+__device__ __forceinline__ void epilogue_bwd_row(const float2* __restrict__ g_out, const float* __restrict__ sf, size_t r, float tau,
+                                                 float* __restrict__ g_self) {
     const float* s = sf + r * 7;
     const float dx = s[0], dy = s[1], v0 = s[6];
     const float2 g = g_out[r];
@@ -58,6 +55,14 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* 
     o[4] = 0.f;
     o[5] = 0.f;
     o[6] = (g.x * ex + g.y * ey) / tau;
+}
+
+__global__ __launch_bounds__(256) void pinnsf_epilogue_bwd_kernel(const float2* __restrict__ g_out,
+                                                                   const float* __restrict__ sf, size_t rows, float tau,
+                                                                   float* __restrict__ g_self) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    epilogue_bwd_row(g_out, sf, r, tau, g_self);
 }
 
 // Bottleneck variants: predictions = sum_k pred_ped[a, k] + sum_k pred_obs[a, k] + desired force (one thread per agent;
@@ -91,6 +96,25 @@ __global__ __launch_bounds__(256) void pinnsf_epilogue_ksum_bwd_kernel(const flo
     const float2 g = g_out[r];
     if (g_ped) for (int i = 0; i < kp; ++i) g_ped[r * kp + i] = g;
     if (g_obs) for (int i = 0; i < ko; ++i) g_obs[r * ko + i] = g;
+}
+
+// both halves of piml_pinnsf_epilogue_ksum_bwd in ONE launch (round 5: they were two launches of ~5 us over the same rows): the
+// first `blocks_self` workgroups write the desired-force gradient, the rest the broadcasts
+__global__ __launch_bounds__(256) void pinnsf_epilogue_ksum_bwd_both_kernel(const float2* __restrict__ g_out, const float* __restrict__ sf,
+                                                                             size_t rows, float tau, int kp, int ko, float* __restrict__ g_self,
+                                                                             float2* __restrict__ g_ped, float2* __restrict__ g_obs,
+                                                                             unsigned blocks_self) {
+    if (blockIdx.x >= blocks_self) {
+        const size_t r = (size_t)(blockIdx.x - blocks_self) * blockDim.x + threadIdx.x;
+        if (r >= rows) return;
+        const float2 g = g_out[r];
+        if (g_ped) for (int i = 0; i < kp; ++i) g_ped[r * kp + i] = g;
+        if (g_obs) for (int i = 0; i < ko; ++i) g_obs[r * ko + i] = g;
+        return;
+    }
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    epilogue_bwd_row(g_out, sf, r, tau, g_self);
 }
 
 // The same tail for channelled (C, N, 7) input with the reference's dim=1 norm (quirk Q2,
@@ -521,6 +545,13 @@ PIML_API int piml_pinnsf_epilogue_ksum_bwd(const float* g_out, const float* self
                                            int ko, float* g_self, float* g_pred_ped, float* g_pred_obs, void* stream) {
     if (rows == 0) return hipSuccess;
     if (!g_out || !self_features) return hipErrorInvalidValue;
+    if (g_self && (g_pred_ped || g_pred_obs)) {
+        const unsigned nb = blocks_for(rows, 256);
+        hipLaunchKernelGGL(pinnsf_epilogue_ksum_bwd_both_kernel, dim3(2 * nb), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float2*>(g_out), self_features, rows, tau, kp, ko, g_self,
+                           reinterpret_cast<float2*>(g_pred_ped), reinterpret_cast<float2*>(g_pred_obs), nb);
+        return hipGetLastError();
+    }
     if (g_self)
         hipLaunchKernelGGL(pinnsf_epilogue_bwd_kernel, dim3(blocks_for(rows, 256)), dim3(256), 0, as_stream(stream),
                            reinterpret_cast<const float2*>(g_out), self_features, rows, tau, g_self);
