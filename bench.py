@@ -694,8 +694,12 @@ class Step:
             self.reset_grads()
             self.step_body()
 
+    SPIN_REPLAYS = 600       # untimed replays in front of a secondary leg's timed steps (captured graphs only; the same count on every
+                             # rank): a leg of 50 steps behind an idle GPU otherwise measures the clock ramp -- the in-line train-mode
+                             # figure read 0.168 ms where a run of its own (--train-mode 1, 300 ms of spin-up) reads 0.153
+
     def time_steps(self, steps, warmup):
-        for _ in range(warmup):
+        for _ in range(max(warmup, self.SPIN_REPLAYS) if self.graph is not None else warmup):
             self.run()
         self.barrier()
         t0 = time.perf_counter()
