@@ -96,6 +96,11 @@ class BaseSimulator(Pedestrians):
         if hasattr(net, 'messages_wanted'):
             net.messages_wanted = bool(getattr(args, 'reg_weight', 0.0) > 0 or getattr(args, 'pinnsf_interaction', 'sim') != 'sim'
                                        or getattr(args, 'messages_wanted', False))
+        # ... and the auxiliary collision head's output (predictions[-1]) only for `pinnsf_bm` under collision_pred_weight > 0
+        # (:348-355, :731-733; :826-830 sees all-zero records for every other model): where no loop of this class reads it the head is
+        # not launched at all (model.predictions_only: forward returns None in its place -- what the inference rollouts already did)
+        if hasattr(net, 'predictions_only') and not getattr(args, 'head_wanted', False) and os.environ.get('PIML_HEAD_WANTED', '0') != '1':
+            net.predictions_only = not (args.model == 'pinnsf_bm' and getattr(args, 'collision_pred_weight', 0.0) > 0)
         return net.to(args.device)
 
     def set_model(self, args):
