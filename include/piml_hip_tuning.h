@@ -78,6 +78,12 @@ int piml_encoder_dw2(int layer_split);
  * (PIML_ENC_FUSED_DW3=0: the layer-0 workgroups of piml_encoder_dw2's kernel in a launch of their own).  Environment at load
  * time: PIML_ENC_FUSED_BWD=0 / 1 / 2.  Returns the previous value; < 0 only queries. */
 int piml_encoder_fused_bwd(int on);
+/* Backward of the sums path (PIML_POOL_TRAIN of piml_pinnsf_bwd; reference: the autograd of src/models/model.py:40-65 below
+ * the neighbour-axis sum :1279-1283): 2 (default) = two crews of four waves per workgroup -- the dX chain and the weight-gradient
+ * products on two waves of every SIMD (piml_amd/csrc/encoder_bwd5.hip); 1 = one wave per SIMD (encoder_bwd3.hip, round 5).  The
+ * two forms agree bitwise.  Environment at load time: PIML_ENC_SUMS_BWD=1 / 2.  Returns the previous value; other arguments
+ * only query. */
+int piml_encoder_sums_bwd(int form);
 /* The library-owned side streams of PIML_FORK (piml_pinnsf_fwd / bwd with the independent stages forked: measured slower inside
  * captured graphs, kept for A/B): created per device on first use, outside any capture; idempotent. */
 int piml_pinnsf_streams_init(void);

@@ -135,6 +135,7 @@ SIGNATURES = {
     'piml_encoder_products': [_i],
     'piml_encoder_dw2': [_i],
     'piml_encoder_fused_bwd': [_i],
+    'piml_encoder_sums_bwd': [_i],
     'piml_encoder_pack': [ctypes.POINTER(EncoderBranch), _i, _p],
     'piml_encoder_workgroups': [ctypes.POINTER(EncoderBranch), _i, ctypes.POINTER(_i)],
     'piml_encoder_fwd': [ctypes.POINTER(EncoderBranch), _i, _p],

@@ -27,7 +27,8 @@ FLAGS = CFLAGS + ['-shared']      # (the one-command form; kept for readers of o
 # per-file extras.  encoder_bwd3.hip: its vector work sits between matrix instructions issued by ONE wave per SIMD, where a
 # packed-f32 instruction (v_pk_fma_f32 / v_pk_add_f32, what the SLP vectoriser makes of two neighbouring scalar operations)
 # costs ~16 issue cycles against 2 x 4 (tools/probe_mfma_slots.hip).
-FILE_FLAGS = {'encoder_bwd3.hip': ['-fno-slp-vectorize'], 'encoder_bwd4.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'encoder_bwd3.hip': ['-fno-slp-vectorize'], 'encoder_bwd4.hip': ['-fno-slp-vectorize'],
+              'encoder_bwd5.hip': ['-fno-slp-vectorize']}
 
 
 def sources():

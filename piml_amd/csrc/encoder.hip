@@ -916,6 +916,16 @@ PIML_API int piml_encoder_fused_bwd(int on) {
     return old;
 }
 
+// Backward of the sums path (PIML_POOL_TRAIN): 2 (default) = two crews of four waves, two waves per SIMD (encoder_bwd5.hip);
+// 1 = the one-wave-per-SIMD kernel of round 5 (encoder_bwd3.hip, SUMS).  Bitwise the same results (A/B).  PIML_ENC_SUMS_BWD=1 / 2
+static int g_sums_bwd = getenv("PIML_ENC_SUMS_BWD") && atoi(getenv("PIML_ENC_SUMS_BWD")) == 1 ? 1 : 2;
+
+PIML_API int piml_encoder_sums_bwd(int form) {
+    const int old = g_sums_bwd;
+    if (form == 1 || form == 2) g_sums_bwd = form;
+    return old;
+}
+
 // PIML_ENC_FUSED_DW3=0: dW3 / db3 stay a launch of their own (the layer-0 workgroups of encoder_dw2.hip) behind the one-pass kernel
 static int g_f3_dw3 = !(getenv("PIML_ENC_FUSED_DW3") && atoi(getenv("PIML_ENC_FUSED_DW3")) == 0);
 
@@ -1311,11 +1321,11 @@ int piml::enc_stage_bwd_sum(const piml_encoder_branch* br, int nbr, hipStream_t 
     const int total = fill_args(A, br, nbr);
     if (int e = x3_ready()) return e;
     static int ready = -1;
-    if (ready < 0) ready = enc_f3_set_attributes();
+    if (ready < 0) { ready = enc_f3_set_attributes(); if (!ready) ready = enc_f5_set_attributes(); }
     if (ready) return ready;
     const int nA[2] = {nbr > 1 ? A.wg_split : total, nbr > 1 ? total - A.wg_split : 0};
     const int zero[2] = {0, 0};
-    enc_f3_launch(A, nA, zero, false, s, true);
+    if (g_sums_bwd == 1 || !enc_f5_launch(A, nA, s)) enc_f3_launch(A, nA, zero, false, s, true);
     return hipGetLastError();
 }
 

@@ -83,5 +83,9 @@ int enc_f3_set_attributes();
 // with_dw3: the launch also does dW3 / db3 (layer-0 slots, slot = workgroup index within the branch; needs slot0[b] == nA[b])
 // sums: the PIML_POOL_TRAIN form (G2 = g_pooled[agent] * [h2 > 0]: no W3^T layer, no dW3; sign words of h2 in the exchanged layout)
 void enc_f3_launch(const EncArgs& A, const int* nA, const int* slot0, bool with_dw3, hipStream_t s, bool sums = false);
+// encoder_bwd5.hip: the PIML_POOL_TRAIN backward as two crews of four waves (chain | weight gradients), two waves per SIMD;
+// bitwise the results of enc_f3_launch(..., sums = true).  false: a shape it does not take (the caller falls back)
+int enc_f5_set_attributes();
+bool enc_f5_launch(const EncArgs& A, const int* nA, hipStream_t s);
 
 }  // namespace piml
