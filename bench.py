@@ -313,6 +313,18 @@ def secondary_measurements(scene, n, dev, _lib, prof=None, light=False):
                                       'replayed from one captured HIP graph) - forward, HIP events'}}
 
 
+def p2p_alive(p2p, dev, collective):
+    """True when no exchange of the pair has raised its sticky time-out word, on ANY rank (MIN over the ranks when `collective`).  A
+    timed-out exchange is dead for good -- every later launch returns at its first instruction -- so a timed region that used it
+    measured skipped exchanges: the caller records an error instead of a time and rebuilds the pair before the next leg."""
+    ok = 1 if (p2p is None or all(e.ok() for e in p2p)) else 0
+    if collective and dist.is_initialized():
+        t = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    return bool(ok)
+
+
 def cfg4_projection(args, dev, messages, shards=8, scene_agents=16384):
     """One rank's step of BASELINE.json configs[3] (16384 agents over 8 GPUs) measured on ONE GPU, and what follows from it.
     The rank's compute is exact (2048 focal rows against all 16384 sources, the network on 2048 agents, relfeat backward over
@@ -341,6 +353,8 @@ def cfg4_projection(args, dev, messages, shards=8, scene_agents=16384):
             st.capture()
             el = st.time_steps(k, 10)
             out[f'rank_step_us_{form}'] = el / k * 1e6
+            if form == 'p2p' and not p2p_alive(p2p, dev, False):
+                out[f'rank_step_us_{form}'] = 'P2P exchange timed out (sticky status word set): the replays skipped it, no time recorded'
             if form != 'p2p' and st.graph is not None and compute_us is None:      # the captured compute alone (RCCL forms: the exchanges sit outside the graph)
                 for _ in range(10):
                     st.graph.replay()
@@ -404,6 +418,10 @@ class Step:
         self.p2p = p2p if exchange == 'p2p' else None
         if exchange == 'p2p' and p2p is None:
             raise ValueError("Step(exchange='p2p') needs p2p=(forward, backward)")
+        if exchange == 'p2p' and (overlap or two_streams):
+            # co-residency: the exchange kernel's workgroups spin until all of them (and the peers') have arrived -- nothing else may
+            # hold the CUs beside it (piml_amd/csrc/p2p.hip)
+            raise ValueError("Step(exchange='p2p'): no --overlap 1 / --two-streams with the P2P exchange (its workgroups must be co-resident)")
         self.sh = (ShardedScene(N, self.obstacles, group=group, force_collectives=True, exchange='p2p' if self.p2p else 'rccl',
                                 p2p=self.p2p) if use_dist else None)
         torch.manual_seed(666)
@@ -902,15 +920,18 @@ def main():
     # the P2P-store exchange objects (receive buffers, flags, device-side step counters; IPC handles through the process group's
     # object all-gather): made once, used by the main step and by the comparison legs
     p2p = None
+
+    def make_p2p():
+        from piml_amd.sharded import p2p_exchanges
+
+        def _all_bytes(b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+        return p2p_exchanges(rank, world, n_own, n_params, _all_bytes)
     if use_dist and (args.exchange == 'p2p' or args.exchange_compare):
         try:
-            from piml_amd.sharded import p2p_exchanges
-
-            def _all_bytes(b):
-                out = [None] * world
-                dist.all_gather_object(out, b)
-                return out
-            p2p = p2p_exchanges(rank, world, n_own, n_params, _all_bytes)
+            p2p = make_p2p()
         except Exception as ex:   # noqa: BLE001 - only fatal when it is the exchange that was asked for
             if args.exchange == 'p2p':
                 raise
@@ -928,6 +949,9 @@ def main():
     # and two of them on parallel graph branches deadlock (observed: replay never completes).  The
     # pre-tuned selections are validated for the cfg3 row counts only; otherwise the branches stay on one stream.
     two_streams = (bool(args.two_streams) and gemm_tuning == 'tunableop-file' and cfg3_shapes) or args.two_streams == 2
+    if args.exchange == 'p2p' and two_streams:
+        print('[bench] --exchange p2p: the side stream is off (the exchange kernel\'s workgroups must be co-resident)', file=sys.stderr)
+        two_streams = False
     if args.train_mode:
         args.verify = 0
     st = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD if use_dist else None, use_dist,
@@ -1026,6 +1050,11 @@ def main():
     elapsed = time.perf_counter() - t0
     _phase('timed region done')
     region_event_ms = region_timer.elapsed_ms()
+    if st.p2p is not None and not p2p_alive(st.p2p, dev, use_dist):
+        # the headline would be a step with its exchanges skipped: no line rather than a wrong one
+        print('[bench] FATAL: the P2P exchange timed out during the run (sticky status word set on some rank): the timed replays '
+              'skipped it.  Raise PIML_P2P_SPIN_LIMIT if the ranks start far apart, or use --exchange bucket.', file=sys.stderr, flush=True)
+        sys.exit(5)
     if graph is not None:           # the relfeat samples, behind the region (see above); two unsampled replays lead the burst
         for i in range(-2, n_samples):
             run_step(i, 'sample')
@@ -1270,13 +1299,21 @@ def main():
         for exch, ovl in legs:
             tag = {'exchange': exch, 'overlap': ovl}
             try:
-                alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams, bool(args.graph),
+                alt = Step(scene, N, n_own, rank * n_own, M, dev, dist.group.WORLD, True, two_streams and exch != 'p2p', bool(args.graph),
                            exchange=exch, overlap=ovl, messages=bool(args.messages), p2p=p2p)
                 alt.capture()
                 k = max(10, min(args.steps, 50))
                 el = alt.time_steps(k, 5)
                 t = torch.tensor([el], device=dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if exch == 'p2p' and not p2p_alive(p2p, dev, True):
+                    exchange_other.append(dict(tag, error='P2P exchange timed out (sticky status word set on some rank): the replays '
+                                                          'skipped it, no time recorded'))
+                    del alt
+                    for e in p2p:
+                        e.close()
+                    p2p = make_p2p()          # (collective: every rank rebuilds -- the MIN above made the verdict common)
+                    continue
                 exchange_other.append(dict(tag, ms_per_step=float(t.item()) / k * 1e3, steps=k, launch_mode=alt.mode))
                 del alt
             except Exception as ex:   # noqa: BLE001 - informational
@@ -1350,6 +1387,22 @@ def main():
                     del tr
                 except Exception as ex:   # noqa: BLE001 - informational
                     secondary[key] = {'error': f'{type(ex).__name__}: {ex}'}
+        if world == 1 and fused_mlp and not args.messages:
+            # the reference forward's literal output list [predictions, ped_msgs, obs_msgs, pred_collision]
+            # (src/models/model.py:1301-1305): the message path, every per-row tensor materialised
+            try:
+                ms = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), messages=True)
+                ms.capture()
+                k = max(10, min(args.steps, 50))
+                el = ms.time_steps(k, 5)
+                secondary['messages_step'] = {
+                    'ms_per_step': el / k * 1e3, 'steps': k, 'launch_mode': ms.mode,
+                    'note': '--messages 1: the same step with model.messages_wanted = True -- model(...)[1:3] (the per-neighbour messages, '
+                            'src/models/model.py:1301-1305) written and their gradient path kept: three encoder layers, the message-path '
+                            'decoder launch and the one-pass backward with its W3^T layer and dW3 phase (no fold, no sums path)'}
+                del ms
+            except Exception as ex:   # noqa: BLE001 - informational
+                secondary['messages_step'] = {'error': f'{type(ex).__name__}: {ex}'}
         if world == 1:       # the same step with the shipped experiments' model (src/configs/exp_configs/piml-*.yaml)
             try:
                 bm = Step(scene, N, N, 0, M, dev, None, False, False, bool(args.graph), model_name='PINNSF_bottleneck_multitask')
@@ -1386,6 +1439,18 @@ def main():
     if same_scene_1gpu is not None:
         out['single_gpu_same_scene'] = same_scene_1gpu
     if secondary is not None:
+        # every form of the step against the same SURVEY 8d contract bytes: the headline does not get to choose
+        for key, rk in (('train_mode_step', 'frac_train_mode'), ('messages_step', 'frac_messages'), ('pinnsf_bm_step', 'frac_pinnsf_bm'),
+                        ('train_mode_pinnsf_bm_step', 'frac_train_mode_pinnsf_bm'), ('f32_matrix_instruction_step', 'frac_f32_matrix_instruction')):
+            leg = secondary.get(key)
+            if isinstance(leg, dict) and leg.get('ms_per_step'):
+                leg['frac'] = bytes_step / (leg['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out['roofline'][rk] = leg['frac']
+        out['roofline']['frac_forms_note'] = ('frac = the default form of the step (eval(), messages on request only); frac_train_mode = '
+                                              'model.train() with dropout 0.5 (the reference\'s training configuration, src/main.py:45); '
+                                              'frac_messages = the reference forward\'s full output list materialised (src/models/model.py:1301-1305); '
+                                              'frac_pinnsf_bm = the shipped experiments\' model (src/configs/exp_configs/piml-gcdata.yaml:49-50); all '
+                                              'against the same algorithmic_bytes (secondary.<form>_step.ms_per_step)')
         out['secondary'] = secondary
         shard = (secondary.get('relfeat_shard_shape') or {}).get('fwd_us')
         if shard is not None and out['roofline']['kernels'] and out['roofline']['kernels'][0]['name'] == 'relfeat_fwd_kernel':

@@ -82,6 +82,18 @@ __device__ unsigned long long g_f3_stamps[256 * 64];          // [workgroup][wav
 #define F3_STAMP(i)
 #endif
 
+// The workgroup barrier of the tile loops: this wave's LDS operations done, nothing said about its loads in flight (the requests of
+// the next tile travel across it; __syncthreads() also waits for vmcnt(0) -- the stamps read 400 - 1040 cycles at B1 for that).
+// PIML_F3_SYNCTHREADS=1: the plain barrier (A/B)
+#ifndef PIML_F3_SYNCTHREADS
+#define PIML_F3_SYNCTHREADS 0
+#endif
+#if PIML_F3_SYNCTHREADS
+#define F3_BARRIER() __syncthreads()
+#else
+#define F3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 struct F3Args {
     EncArgs A;
     int nA[2];          // workgroups of branch 0 / branch 1 (grid = their sum)
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
     }
     F3_STAMP(15);
     for (; tile < ntiles; tile += nwg, par ^= 1) {
-        __syncthreads();                                                                   // B1: bufA, x rows, sign words, g_x partials
+        F3_BARRIER();                                                                      // B1: bufA, x rows, sign words, g_x partials
         F3_STAMP(0);
         // ============ region X: layer A (G2 = (G3 W3) * [h2 > 0]); in its shadow the next tile's requests, the g_x store of
         // ============ the previous tile and H1 = relu(W1 x + b1) with its split ============
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             }
         }
         F3_STAMP(2);
-        __syncthreads();                                                                   // B2: M, bufH
+        F3_BARRIER();                                                                      // B2: M, bufH
         F3_STAMP(3);
         // ============ region Y: layer B (G1 = (G2 W2) * [h1 > 0]) with the NEXT tile's G3 in its shadow (bufA is free: every
         // ============ wave has passed B2), then dW2 += G2^T H1 with G1's sums in its shadow ============
@@ -853,11 +865,11 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
             // image pair 0 holds tile t2, Q1 the requests of tile t2 + nwg, Q0 is free
             p2_load(Q0, t2 + 2 * nwg);
             mma_tile(0, Q1);
-            __syncthreads();
+            F3_BARRIER();
             if (t2 + nwg >= ntiles) break;
             p2_load(Q1, t2 + 3 * nwg);
             mma_tile(1, Q0);
-            __syncthreads();
+            F3_BARRIER();
         }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(c[jb]), "+a"(sm[jb]));

@@ -273,7 +273,11 @@ PIML_API int piml_p2p_exchange(const piml_p2p_msg* msg, int rank, int world, flo
     A.rank = rank; A.world = world; A.sum = msg->sum ? 1 : 0;
     // workgroups per receiver: ~2 float4 per thread (loads of the fine-grained receive buffers are uncached round trips: many
     // threads with few loads each), all of them resident at once (the waits spin): world * split <= 512
-    A.split = (int)(off / 512 < 1 ? 1 : (off / 512 > 64 ? 64 : off / 512));
+    // PIML_P2P_MAX_SPLIT: a lower cap -- several ranks SHARING one GPU (tests/test_p2p_gpu.py: 8 processes on one device) need all
+    // their launches resident together: world ranks x world x split workgroups <= 2048
+    static const int max_split = getenv("PIML_P2P_MAX_SPLIT") && atoi(getenv("PIML_P2P_MAX_SPLIT")) > 0 ? atoi(getenv("PIML_P2P_MAX_SPLIT")) : 64;
+    const int cap = max_split < 64 ? max_split : 64;
+    A.split = (int)(off / 512 < 1 ? 1 : (off / 512 > (unsigned long long)cap ? (unsigned long long)cap : off / 512));
     A.spin_limit = spin_limit ? spin_limit : 1000000u;     // ~0.5 s
     A.ctr = ctr;
     A.status = status;

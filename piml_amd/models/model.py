@@ -552,8 +552,12 @@ class _PINNSFBase(nn.Module):
             if getattr(self._packs, 'pending_structs', None) is not None:
                 # a deferred pack no forward pass took (PIML_DEFER_PACK): run it now rather than leave raw weight pointers
                 # with the library beyond the block (no-op when it has run)
+                # (the library keeps one pending pack per DEVICE: flush on the model's, which need not be the current one, and
+                # drop the structs -- the only references to the arrays the pending pack points into -- only behind that flush)
                 from .. import _lib
-                _lib.check(_lib.lib().piml_pinnsf_pack_flush(), 'piml_pinnsf_pack_flush')
+                import torch
+                with torch.cuda.device(next(self.parameters()).device):
+                    _lib.check(_lib.lib().piml_pinnsf_pack_flush(), 'piml_pinnsf_pack_flush')
                 self._packs.pending_structs = None
 
     def forward(self, ped_features, obs_features, self_features):

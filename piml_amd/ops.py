@@ -2198,12 +2198,13 @@ class ParamGradSink:
         self._bufs = {}          # key -> (encoder flats, decoder flats)
         self._seen = None        # keys that have had their first backward pass of the running step
         self._assign = None      # id(param) -> (param, view)
+        self._mode = None        # (key, size) -> 'plain' / 'fold': what the buffer accumulates in the running step
 
     @contextlib.contextmanager
     def step(self):
         if ParamGradSink._active is not None:
             raise RuntimeError('ParamGradSink.step() does not nest')
-        self._seen, self._assign = set(), {}
+        self._seen, self._assign, self._mode = set(), {}, {}
         ParamGradSink._active = self
         try:
             yield self
@@ -2211,15 +2212,23 @@ class ParamGradSink:
             ParamGradSink._active = None
             for p, view in self._assign.values():
                 p.grad = view if p.grad is None else p.grad + view
-            self._seen, self._assign = None, None
+            self._seen, self._assign, self._mode = None, None, None
 
-    def take(self, keys, size, opt):
+    def take(self, keys, size, opt, mode='plain'):
         """Persistent flat buffers (`size` floats) for the weight sets `keys` (one per branch of the call) in this backward
         pass -> (buffers, accumulate?).  accumulate: they hold the sums of the step's earlier passes.  One launch has one
         flag: when only some of the branches have been through a pass before (the last frame of a rollout may feed the
-        loss through one branch only), the others' buffers are cleared here and the launch accumulates into all of them."""
+        loss through one branch only), the others' buffers are cleared here and the launch accumulates into all of them.
+        mode: what the buffer's fields mean in this pass -- 'fold' when the decoder's first-layer field accumulates the gradient
+        of the FOLDED weight (the sums path; unfolded from the running sum at the step's end), 'plain' otherwise.  The two
+        must not meet in one buffer inside one step (their sum is neither gradient): a mix raises."""
         if not keys:
             return None, False
+        for k in keys:
+            if self._mode.setdefault((k, size), mode) != mode:
+                raise _lib.PimlHipError('ParamGradSink: one optimiser step mixes a sums-path pass and a message-path pass of the same '
+                                        'network (the folded and the plain first-layer gradients would be added into one buffer); '
+                                        'keep model.messages_wanted / dropout / packs.fold the same for every pass of a step')
         seen = [k in self._seen for k in keys]
         bufs = []
         for k, was in zip(keys, seen):
@@ -2529,7 +2538,7 @@ class _FusedPinnsf(torch.autograd.Function):
                 darr = (_lib.DecoderBranch * nbr)(*dstructs)
                 if len(live) == nbr and _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink, dev):
                     flags |= _lib.DEFER_SLOT_SUMS
-                    _DEFER_KEEP[:] = [parts, dparts]       # (a second deferral launches the sums waiting so far: their buffers may go)
+                    _defer_keep(parts, dparts)     # (append + bounded trim: the library may MERGE this deferral with one still waiting)
                 _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags,
                                              _stream()), 'piml_pinnsf_bwd')
                 if want_self:
@@ -2609,8 +2618,8 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
         if sink is not None:
             ids = lambda lo, hi: tuple(id(t) for t in ctx.params[lo:hi])
             flats, acc_e = sink.take([ids(PER * b + 1, PER * b + 7) for b in range(nbr)], L.piml_encoder_partial_floats(), opt)
-            dflats, acc_d = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], L.piml_decoder_partial_floats(), opt)
-            dw1, _ = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], 64 * H, opt)
+            dflats, acc_d = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], L.piml_decoder_partial_floats(), opt, mode='fold')
+            dw1, _ = sink.take([ids(PER * b + 7, PER * b + 13) for b in range(nbr)], 64 * H, opt, mode='fold')
             if acc_e != acc_d:
                 raise _lib.PimlHipError('fused_pinnsf(sums=True): the encoders and decoders of one network went through different numbers '
                                         'of backward passes inside ParamGradSink.step()')
@@ -2637,7 +2646,7 @@ def _backward_sums(ctx, g_acc, g_coll, grads, x2s, masks, pooled, dh1, dd2, ewb,
         darr = (_lib.DecoderBranch * nbr)(*dstructs)
         if _defer_slot_sums([ctx.params[PER * b + jx] for b in range(nbr) for jx in range(1, 13)], sink, dev):
             flags |= _lib.DEFER_SLOT_SUMS
-            _DEFER_KEEP[:] = [parts, dparts, dflats, flats, dw1]
+            _defer_keep(parts, dparts, dflats, flats, dw1)
         _lib.check(L.piml_pinnsf_bwd(earr, darr, nbr, _ptr(ga), _ptr(sf), float(tau), _ptr(g_self), flags, _stream()), 'piml_pinnsf_bwd')
         if want_self:
             grads[_FusedPinnsf.SELF] = g_self.view(sf_shape)

@@ -77,35 +77,78 @@ class P2PExchange:
                 raise ValueError(f'P2PExchange.exchange: {name} has {t.numel()} elements, expected {n}')
             return t
         as_list = lambda x: [] if x is None else (list(x) if isinstance(x, (list, tuple)) else [x])
+        pad4 = lambda n: (n + 3) // 4 * 4
+        ok16 = lambda t: t.data_ptr() % 16 == 0
         srcs, outs = as_list(bcast_src), as_list(out_bcast)
         if outs and len(outs) != len(srcs):
             raise ValueError('P2PExchange.exchange: one out_bcast per bcast_src (or none)')
         if len(srcs) > 8:
             raise ValueError('P2PExchange.exchange: at most 8 broadcast parts')
-        mult = 1 if sum else self.world
-        ns = 0 if scatter_src is None else flat(scatter_src, 'scatter_src').numel() // self.world
-        if scatter_src is not None and scatter_src.numel() != ns * self.world:
+        W = self.world
+        mult = 1 if sum else W
+        # The kernel moves 16-byte words: every part is a multiple of 4 floats on a 16-byte boundary.  A part that is not (an odd
+        # agent block: 501 rows x 6 floats; a row slice of a larger tensor) travels through a padded, aligned staging buffer --
+        # `copy_back` holds the (destination, staged view) pairs copied out behind the launch.  (Extra launches, off the fast path.)
+        copy_back = []
+
+        def stage_src(t, blocks):          # (blocks, n) floats -> (blocks, pad4(n)), zero-padded
+            n = t.numel() // blocks
+            if n % 4 == 0 and ok16(t):
+                return t, n
+            buf = torch.zeros(blocks, pad4(n), dtype=torch.float32, device=t.device)
+            buf[:, :n].copy_(t.view(blocks, n))
+            return buf, pad4(n)
+
+        def stage_out(t, blocks, n, staged_src=None):      # destination of (blocks, n) floats
+            if n % 4 == 0 and ok16(t) and staged_src is None:
+                return t
+            buf = staged_src if (staged_src is not None and blocks == 1) else torch.empty(blocks, pad4(n), dtype=torch.float32, device=t.device)
+            copy_back.append((t, buf.view(blocks, -1)[:, :n]))
+            return buf
+
+        ns = 0 if scatter_src is None else flat(scatter_src, 'scatter_src').numel() // W
+        if scatter_src is not None and scatter_src.numel() != ns * W:
             raise ValueError('P2PExchange.exchange: scatter_src must hold one block per rank')
         if out_scatter is not None:
             flat(out_scatter, 'out_scatter', ns * mult)
         m = _lib.P2PMsg()
-        m.scatter_src, m.scatter_floats = (scatter_src.data_ptr() if ns else None), ns
-        m.out_scatter = out_scatter.data_ptr() if out_scatter is not None else None
-        m.n_bcast, total = len(srcs), ns
+        keep = []                             # staging buffers stay alive until the launch is enqueued (stream-ordered allocator)
+        ns_k = 0
+        if ns:
+            sc, ns_k = stage_src(scatter_src, W)
+            keep.append(sc)
+            m.scatter_src = sc.data_ptr()
+        m.scatter_floats = ns_k
+        if out_scatter is not None:
+            o = stage_out(out_scatter, mult, ns)
+            keep.append(o)
+            m.out_scatter = o.data_ptr()
+        m.n_bcast, total = len(srcs), ns_k
         for j, t in enumerate(srcs):
             flat(t, f'bcast_src[{j}]')
-            m.bcast_src[j], m.bcast_floats[j] = t.data_ptr(), t.numel()
+            n = t.numel()
+            in_place = bool(outs) and outs[j] is not None and outs[j].data_ptr() == t.data_ptr()
+            src, n_k = stage_src(t, 1)
+            keep.append(src)
+            m.bcast_src[j], m.bcast_floats[j] = src.data_ptr(), n_k
             if outs and outs[j] is not None:
-                m.out_bcast[j] = flat(outs[j], f'out_bcast[{j}]', t.numel() * mult).data_ptr()
-            total += t.numel()
-        if ns % 4 or any(t.numel() % 4 for t in srcs) or total == 0 or total > self.fpr:
-            raise ValueError(f'P2PExchange.exchange: parts of {total} floats in all (each a multiple of 4) must fit the slot of {self.fpr}')
+                flat(outs[j], f'out_bcast[{j}]', n * mult)
+                if in_place and not sum:
+                    raise ValueError('P2PExchange.exchange: an in-place out_bcast needs sum=True')
+                o = stage_out(outs[j], mult, n, staged_src=src if (in_place and src is not t) else None)
+                keep.append(o)
+                m.out_bcast[j] = o.data_ptr()
+            total += n_k
+        if total == 0 or total > self.fpr:
+            raise ValueError(f'P2PExchange.exchange: parts of {total} floats in all (each padded to a multiple of 4) must fit the slot of {self.fpr}')
         m.sum = 1 if sum else 0
         if not spin_limit:      # PIML_P2P_SPIN_LIMIT: rounds of ~0.5 us a wait may take (default ~0.5 s; hosts whose ranks start far apart raise it)
             spin_limit = int(os.environ.get('PIML_P2P_SPIN_LIMIT', '0'))
         _lib.check(_lib.lib().piml_p2p_exchange(ctypes.byref(m), self.rank, self.world, self._peer_recv, self._peer_flags, self.fpr,
                                                 self.ctr.data_ptr(), int(spin_limit), self.status.data_ptr(),
                                                 torch.cuda.current_stream().cuda_stream), 'piml_p2p_exchange')
+        for dst, view in copy_back:
+            dst.view(view.shape).copy_(view)
 
     def connect_all(self, exchange_bytes):
         """Open every peer's buffers.  exchange_bytes(own: bytes) -> list of every rank's bytes in rank order (e.g. a

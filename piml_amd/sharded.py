@@ -297,6 +297,11 @@ class ShardedScene:
         the weight pack, the neighbour search among the block's own agents, the obstacle branch and the self features
         (ops.relative_features_local_part); after the wait, the remote half of the search and the network.  Same
         results as model_step (the split search is bit-identical; the HIP operators only, no injected feature_fn)."""
+        if self.p2p is not None:
+            # every workgroup of p2p_exchange_kernel spins until all of its launch and all of its peers' have arrived: correct only
+            # if they are co-resident, which an idle stream gives and a second stream full of search workgroups does not
+            raise ValueError("ShardedScene(exchange='p2p') has no overlapped step: the P2P exchange needs its workgroups co-resident "
+                             "(run it on the one stream, as model_step does; overlap the RCCL exchange instead)")
         group = self.group if self.group is not None else dist.group.WORLD
         holder = []
         state_full = _AllGatherRecordsAsync.apply(state_own, group, holder)

@@ -1,4 +1,4 @@
-"""CPU-only, world_size 2, gloo: the exchange bookkeeping of bench.Step -- the class the driver's multi-GPU run executes --
+"""CPU-only, world_size 2 / 4 / 8, gloo: the exchange bookkeeping of bench.Step -- the class the driver's multi-GPU run executes --
 with the CPU oracle standing in for the HIP feature operators (injected `ops_module`): the captured-step path's
 exchange_forward / features_local / rest_local / exchange_backward in both backward exchanges (`bucket`, `rs`) and the
 overlapped ordering (exchange started, own-block part, wait, remote part), each against the same step in ONE process.
@@ -9,6 +9,7 @@ import sys
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -41,30 +42,33 @@ def _ops_stub():
     return Stub
 
 
-def _scene():
+def _scene(n_real=N):
+    """the first n_real agents of the 64-agent scene"""
     sys.path.insert(0, REPO)
     from piml_amd.scenes import synthetic_gc_scene
     sc = synthetic_gc_scene(N, M, seed=4)
     sc['acceleration'] = (np.random.default_rng(0).standard_normal((N, 2)) * 0.3).astype(np.float32)
-    return sc
+    return {k: (v[:n_real] if getattr(v, 'shape', (0,))[0] == N else v) for k, v in sc.items()}
 
 
 def _single_process_reference(scene):
     import bench
+    N = scene['position'].shape[0]
     st = bench.Step(scene, N, N, 0, M, torch.device('cpu'), None, False, False, False, ops_module=_ops_stub())
     st.reset_grads()
     st.step_body()
     return st.state_own.grad.clone(), [None if p.grad is None else p.grad.clone() for p in st.params]
 
 
-def worker(rank, port, q):
+def worker(rank, port, q, WORLD=WORLD, n_real=N):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
+    torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         import bench
-        scene = _scene()
+        scene, N = bench.pad_scene_np(_scene(n_real), WORLD)      # what bench.py does for --gpus G (absent agents up to a multiple)
         n_own = N // WORLD
         results = {}
         for exchange, overlap in (('bucket', False), ('rs', False), ('bucket', True), ('rs', True)):
@@ -95,27 +99,33 @@ def worker(rank, port, q):
         dist.destroy_process_group()
 
 
-def test_bench_step_exchanges_match_single_process(oracle):
+@pytest.mark.parametrize('WORLD,n_real', [(2, 64), (4, 64), (8, 61)])
+def test_bench_step_exchanges_match_single_process(oracle, WORLD, n_real):
+    """bench.Step on 2 / 4 / 8 ranks in every exchange order against the same (padded) scene in one process (61 agents: padded to
+    64 for 8 ranks, nobody selects the absent agents)"""
     sys.path.insert(0, REPO)
-    gstate_ref, gparams_ref = _single_process_reference(_scene())
+    import bench
+    gstate_ref, gparams_ref = _single_process_reference(bench.pad_scene_np(_scene(n_real), WORLD)[0])
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, port, q, WORLD, n_real)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(WORLD))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n = N // WORLD
+    n = (n_real + WORLD - 1) // WORLD
     for rank in range(WORLD):
         assert len(got[rank]) == 5
         for key, (gstate, gparams) in got[rank].items():
+            real = max(0, min(n, n_real - rank * n))
             ref = torch.nan_to_num(gstate_ref[rank * n:(rank + 1) * n]).numpy()
             assert np.allclose(np.nan_to_num(gstate), ref, rtol=1e-4, atol=1e-5), (rank, key)
+            assert (np.nan_to_num(gstate[real:])[:, [0, 1, 4, 5]] == 0).all(), (rank, key)     # nobody selects an absent agent
             for g, r in zip(gparams, gparams_ref):
                 assert (g is None) == (r is None), (rank, key)
                 if g is not None:

@@ -1,4 +1,4 @@
-"""CPU-only, world_size 2, gloo: agent-block sharding (piml_amd/sharded.py) -- the all-gather of
+"""CPU-only, world_size 2 / 4 / 8, gloo: agent-block sharding (piml_amd/sharded.py) -- the all-gather of
 state records, the reduce-scatter of their gradients and the bucketed all-reduce of the MLP
 gradients -- with the CPU oracle standing in for the HIP kernel (injected feature_fn)."""
 import os
@@ -59,34 +59,45 @@ def model_args():
         dataset_name='gc1560')
 
 
-def scene_tensors():
+def scene_tensors(n_real=N):
+    """the first n_real agents of the 64-agent scene (61: a count that no world size divides)"""
     sc = synthetic_gc_scene(N, M, seed=4)
     rng = np.random.default_rng(0)
     acc = (rng.standard_normal((N, 2)) * 0.3).astype(np.float32)
     state = torch.tensor(np.concatenate((sc['position'], sc['velocity'], acc), -1))
-    return state, torch.tensor(sc['destination']), torch.tensor(sc['desired_speed']), torch.tensor(sc['obstacles'])
+    return state[:n_real], torch.tensor(sc['destination'])[:n_real], torch.tensor(sc['desired_speed'])[:n_real], torch.tensor(sc['obstacles'])
 
 
-def reference_single_process():
+def reference_single_process(n_real=N, world=1):
+    """the scene in ONE process, padded like the sharded run pads it (an absent agent still is a row of the network: its
+    bias-driven output feeds the weight gradients; that the padding changes nothing for the real agents is
+    test_pad_scene_keeps_the_result)"""
     from piml_amd.models.model import PINNSF_multitask
-    state, dest, v0, obs = scene_tensors()
-    state.requires_grad_(True)
+    from piml_amd.sharded import pad_scene
+    state, dest, v0, obs = scene_tensors(n_real)
+    state, dest, v0, _ = pad_scene(state, dest, v0, world)
+    n_pad = state.shape[0]
+    state = state.clone().requires_grad_(True)
     torch.manual_seed(1)
     model = PINNSF_multitask(model_args()).eval()
-    pf, of, df = feature_fn(state, dest, obs, 0, N)
+    pf, of, df = feature_fn(state, dest, obs, 0, n_pad)
     acc = model(pf, of, torch.cat((df, state[:, 2:4], state[:, 4:6], v0), -1))[0]
-    w = torch.linspace(-1, 1, N * 2).reshape(N, 2)
+    w = torch.linspace(-1, 1, n_pad * 2).reshape(n_pad, 2)
     (acc * w).sum().backward()
     return acc.detach(), state.grad.clone(), [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
 
 
-def worker(rank, port, q):
+def worker(rank, port, q, WORLD=WORLD, n_real=N):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     try:
         from piml_amd.models.model import PINNSF_multitask
-        from piml_amd.sharded import ShardedScene, agent_block, allreduce_gradients
-        state, dest, v0, obs = scene_tensors()
+        from piml_amd.sharded import ShardedScene, agent_block, allreduce_gradients, pad_scene
+        state, dest, v0, obs = scene_tensors(n_real)
+        state, dest, v0, n_back = pad_scene(state, dest, v0, WORLD)         # absent agents up to a multiple of the world size
+        N = state.shape[0]
+        assert n_back == n_real and N % WORLD == 0
         sh = ShardedScene(N, obs, feature_fn=feature_fn)
         assert (sh.begin, sh.count) == agent_block(N, rank, WORLD) == (rank * N // WORLD, N // WORLD)
         state_own = sh.own(state).clone().requires_grad_(True)
@@ -149,12 +160,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-def test_sharded_step_matches_single_process(oracle):
-    acc_ref, gstate_ref, gparams_ref = reference_single_process()
+@pytest.mark.parametrize('WORLD,n_real', [(2, 64), (4, 64), (8, 61)])
+def test_sharded_step_matches_single_process(oracle, WORLD, n_real):
+    """every rank's rows of the sharded step against the same scene in one process: world 2 / 4 / 8, and an agent count (61)
+    that no world size divides -- padded with absent agents, which nobody selects"""
+    acc_ref, gstate_ref, gparams_ref = reference_single_process(n_real, WORLD)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, port, q, WORLD, n_real)) for r in range(WORLD)]
     for p in procs:
         p.start()
     results = {}
@@ -164,13 +178,16 @@ def test_sharded_step_matches_single_process(oracle):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n = N // WORLD
+    n = (n_real + WORLD - 1) // WORLD
     for rank in range(WORLD):
         acc, gstate, gparams = results[rank]
-        rows = slice(rank * n, (rank + 1) * n)
-        assert np.allclose(acc, acc_ref[rows].numpy(), rtol=1e-5, atol=1e-6)
+        real = max(0, min(n, n_real - rank * n))                 # this rank's rows that are agents of the unpadded scene
+        rows = slice(rank * n, rank * n + real)
+        assert np.allclose(acc, acc_ref[rank * n:(rank + 1) * n].numpy(), rtol=1e-5, atol=1e-6)
         # reduce-scatter of the partial d/d(state): every source's gradient from ALL ranks' focal rows
-        assert np.allclose(gstate, gstate_ref[rows].numpy(), rtol=1e-4, atol=1e-5)
+        assert np.allclose(np.nan_to_num(gstate), np.nan_to_num(gstate_ref[rank * n:(rank + 1) * n].numpy()), rtol=1e-4, atol=1e-5)
+        # (an absent agent's row: no gradient through the neighbour search -- positions and accelerations stay zero)
+        assert (np.nan_to_num(gstate[real:])[:, [0, 1, 4, 5]] == 0).all()
         for g, ref in zip(gparams, gparams_ref):
             assert (g is None) == (ref is None)
             if g is not None:

@@ -178,7 +178,7 @@ def test_model_messages_wanted_false_takes_the_sums_path():
     worst = max([rel(outs[False][0][0], outs[True][0][0]), rel(outs[False][0][3], outs[True][0][3])] +
                 [rel(a, b) for a, b in zip(outs[False][1], outs[True][1])])
     print(f'model sums path vs message path: max rel diff {worst:.1e}')
-    assert len(outs[False][1]) == len(outs[True][1]) and worst <= 2e-5
+    assert len(outs[False][1]) == len(outs[True][1]) and worst <= 1e-5
     # train mode: the dropout mask keeps the sum behind the last layer -- the forward leaves the sums of the messages instead
     # (PIML_POOL_MSGS, parity under injected masks: test below), again without returning messages
     from piml_amd import ops
