@@ -21,8 +21,9 @@
 // Every buffer between the crews is double-buffered (the x rows three deep), so a tile costs ONE workgroup barrier -- a bare
 // s_barrier behind lgkmcnt(0): __syncthreads() would also wait for the loads that are in flight for the next tile.
 // Everything is plain VGPRs and builtin matrix instructions (<= 256 registers: no accumulator-file operands, no asm hazards).
-// Arithmetic, product order and summation order are those of enc_bwd_fused_x3_kernel<..., SUMS>: the two kernels agree BITWISE
-// (tests/test_sums_gpu.py::test_two_crew_backward_is_bitwise_the_one_wave_kernel).
+// Arithmetic, product order and summation order of every WEIGHT gradient are those of enc_bwd_fused_x3_kernel<..., SUMS>: the two
+// kernels agree BITWISE there; g_x is the same f32 arithmetic in another summation order (f32 matrix instruction, below)
+// (tests/test_sums_gpu.py::test_two_crew_backward_against_the_one_wave_kernel).
 // Fragment element order, images and the slot layout: encoder_bwd3.hip / pack.hpp.
 #include "common.hpp"
 #include "encoder.hpp"
@@ -44,7 +45,26 @@ constexpr int F5_XS = F5_T + 2 * F5_TBYTES;                  // x rows [ring 3][
 constexpr int F5_MK = F5_XS + 3 * 1024;                      // sign words of h1 [parity 2][128 dwords]
 constexpr int F5_W1 = F5_MK + 2 * 512;                       // W1 rows [128][8] floats
 constexpr int F5_GXP = F5_W1 + 4096;                         // g_x partials [parity 2][wave 4][row 32][8] floats
-constexpr int F5_TAB = F5_GXP + 2 * 4096;                    // gather table [rem < 16][half 2][register 16] byte offsets
+// 1: complementary halves -- crew A's products beside crew B's vector work, then crew A's vector work beside crew B's products;
+// 0: every wave interleaves its vector work with its own products (both waves of a SIMD want both pipes all the time)
+#ifndef PIML_F5_PHASED
+#define PIML_F5_PHASED 1
+#endif
+// 1: crew A's requests of the tile after the next between its products (second register set, 21 moves); 0: behind its vector
+// half.  Measured level-to-worse (30.2 - 30.5 against 29.5 - 29.7 us): what crew A saves, crew B's products lose -- the SIMD issues
+// about one instruction per six cycles whichever wave it comes from
+#ifndef PIML_F5_REQ_EARLY
+#define PIML_F5_REQ_EARLY 0
+#endif
+// 1: g_x = G1 W1 on v_mfma_f32_16x16x4_f32 -- the W1 operand is EIGHT registers per lane for the whole slab and the G1 operand one
+// conflict-light ds_read_b32 per product (16 per tile); 0: vector FMAs on W1 rows broadcast from LDS (32 ds_read_b128 per wave and
+// tile, which the stamps price at ~1000 cycles of the tile: the LDS pipe, not the FMAs, was crew B's vector half)
+#ifndef PIML_F5_GX_MFMA
+#define PIML_F5_GX_MFMA 1
+#endif
+static_assert(!PIML_F5_GX_MFMA || PIML_F5_PHASED, "the g_x products ride in the phased schedule");
+constexpr int F5_GXP_BYTES = PIML_F5_GX_MFMA ? 4 * 32 * 16 * 4 : 4096;      // one parity: [wave 4][row 32][16 | 8] floats
+constexpr int F5_TAB = F5_GXP + 2 * F5_GXP_BYTES;            // gather table [rem < 16][half 2][register 16] byte offsets
 constexpr int F5_KMAX = 16;
 constexpr int F5_LDS_BYTES = F5_TAB + F5_KMAX * 2 * 16 * 4;
 constexpr int F5_LDS_LAUNCH = F5_LDS_BYTES;
@@ -85,11 +105,7 @@ __device__ __forceinline__ constexpr int f5_rho(int r) { return (r & 3) + 8 * (r
 #ifndef PIML_F5_SKIP
 #define PIML_F5_SKIP 0
 #endif
-// 1: complementary halves -- crew A's products beside crew B's vector work, then crew A's vector work beside crew B's products;
-// 0: every wave interleaves its vector work with its own products (both waves of a SIMD want both pipes all the time)
-#ifndef PIML_F5_PHASED
-#define PIML_F5_PHASED 1
-#endif
+
 #define F5_SLOT(MF, FILL)                        \
     do {                                         \
         MF;                                      \
@@ -146,14 +162,23 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
 #pragma unroll
         for (int i = 0; i < (NZ + F5_THREADS - 1) / F5_THREADS; ++i)
             if (i * F5_THREADS + tid < NZ) z[i * F5_THREADS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4*>(smem + F5_GXP)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 2 * F5_GXP_BYTES / 16 / F5_THREADS; ++i) reinterpret_cast<float4*>(smem + F5_GXP)[i * F5_THREADS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         // agent of tile row m relative to the tile's first agent: (rem + m) / K with rem = (32 tile) % K; entry = byte offset of
         // that agent's 512-byte row of g_sum; register r of lane half hh holds row rho(r) + 4 hh
         if ((unsigned)tid < K * 32u) {
             const unsigned rem = (unsigned)tid >> 5, hh = ((unsigned)tid >> 4) & 1u, r = (unsigned)tid & 15u;
             reinterpret_cast<unsigned*>(smem + F5_TAB)[tid] = ((rem + 4u * hh + (unsigned)f5_rho((int)r)) / K) * (EH * 4);
         }
-        if (tid < 256) reinterpret_cast<float4*>(smem + F5_W1)[tid] = reinterpret_cast<const float4*>(J.packed + PACK_FWD + 32768)[tid];
+        if (tid < 256) {
+            const float* W1r = J.packed + PACK_FWD + 32768;     // W1 rows padded to 8 columns
+            if (INC == 6) {                                   // g_x: lane half h takes columns 3 h .. 3 h + 2 -> [feature][half][c, c, c, 0]
+                const float* src = W1r + (tid >> 1) * 8 + 3 * (tid & 1);
+                reinterpret_cast<float4*>(smem + F5_W1)[tid] = make_float4(src[0], src[1], src[2], 0.f);
+            } else {
+                reinterpret_cast<float4*>(smem + F5_W1)[tid] = reinterpret_cast<const float4*>(W1r)[tid];
+            }
+        }
     }
 
     if (crew == 0) {
@@ -228,6 +253,46 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             }
             mkv = ld1(rs_mk, tile < ntiles ? (unsigned)tile * 1024u + (unsigned)(ctid & 127) * 4u : kOut, 0u);
         };
+        // The same requests cut into six steps that ride between the products (PIML_F5_REQ_EARLY): a vector-memory instruction costs
+        // the lone issuer 15 - 30 cycles, the 22 of a tile were ~950 cycles of crew A's vector half; between products they are
+        // covered.  They land in a second register set (the first still holds the tile the vector half is about to consume).
+        float g2n[16];
+        unsigned m2n = 0, mkvn = 0;
+        float xan[NS];
+        uint4 tabv;
+        auto req_step = [&](int i, int tile) {
+            const unsigned t32 = __builtin_amdgcn_readfirstlane((unsigned)tile * 32u);
+            const unsigned a0 = __builtin_amdgcn_readfirstlane(__umulhi(t32, kmagic)), rem = t32 - a0 * K;
+            const bool live = tile < ntiles;
+            const uint4* tab = reinterpret_cast<const uint4*>(smem + F5_TAB + (rem * 32u + 16u * (unsigned)h) * 4u);
+            if (i == 0) { tabv = tab[0]; return; }
+            if (i <= 4) {
+                const unsigned gb = live ? gbase + a0 * (EH * 4) : kOut;
+                const uint4 o = tabv;
+                if (i < 4) tabv = tab[i];
+                g2n[4 * i - 4] = __uint_as_float(ld1(rs_gp, gb + o.x, 0u));
+                g2n[4 * i - 3] = __uint_as_float(ld1(rs_gp, gb + o.y, 0u));
+                g2n[4 * i - 2] = __uint_as_float(ld1(rs_gp, gb + o.z, 0u));
+                g2n[4 * i - 1] = __uint_as_float(ld1(rs_gp, gb + o.w, 0u));
+                return;
+            }
+            m2n = ld1(rs_mk, live ? (unsigned)tile * 1024u + (128u + 2u * (unsigned)lane + (unsigned)(w >> 1)) * 4u : kOut, 0u);
+            const unsigned row = (unsigned)tile * 32u + (unsigned)n;
+            const bool valid = live & (row < R);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const unsigned cx = 2u * s + h;
+                xan[s] = __uint_as_float(ld1(rs_x, (valid & (cx < IN)) ? (row * IN + cx) * 4u : kOut, 0u));
+            }
+            mkvn = ld1(rs_mk, live ? (unsigned)tile * 1024u + (unsigned)(ctid & 127) * 4u : kOut, 0u);
+        };
+        auto req_take = [&]() {                                // the incoming set becomes the current one
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g2[r] = g2n[r];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xa[s] = xan[s];
+            m2 = m2n; mkv = mkvn;
+        };
         // G2 of the requested tile = g2 * [h2 > 0] -> db2 -> bf16 pieces -> image `pm`; 16 steps (k-step s = j >> 3)
         float db1 = 0.f, db2 = 0.f;
         unsigned phi[4], pmid[4], plo[4];
@@ -297,12 +362,6 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 o[p] = (u32x4){x.x, x.y, y.x, y.y};
             }
         };
-        auto load_hi = [&](u32x4& o, int kb, int pm) {
-            const f5_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f5_lds_s16x4*)(smem + mr[0] + pm * F5_IMG + kb * 1024));
-            const f5_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f5_lds_s16x4*)(smem + mr[1] + pm * F5_IMG + kb * 1024));
-            const uint2 x = __builtin_bit_cast(uint2, lo4), y = __builtin_bit_cast(uint2, hi4);
-            o = (u32x4){x.x, x.y, y.x, y.y};
-        };
 
         F5_BARRIER();                                          // the table
         // ---- prologue: the first tile's images, the second tile's requests ----
@@ -326,7 +385,7 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             // the eight hi x hi on top: encoder_bwd3.hip); between them the NEXT tile's G2 and H1 images and the requests of the
             // tile after it
             f32x16 acc;
-            u32x4 opa[2][3], ohi[3];
+            u32x4 opa[2][3], ahi[8];                          // (ahi: the activations' hi pieces, kept for the eight hi x hi products)
             unsigned mkw[16];
             const unsigned* mk1 = reinterpret_cast<const unsigned*>(smem + mk_off + par * 512);
             auto fill_a = [&](int sl) {
@@ -335,13 +394,10 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                     if (kb < 8) load_b(opa[kb & 1], kb, par);
                     return;
                 }
-                if (sl >= 38) {                                // hi pieces again for the second pass, two products ahead
-                    const int kb = sl - 38;
-                    if (kb < 8) load_hi(ohi[kb % 3], kb, par);
-                    if (sl < 40) return;
-                }
+                if (sl == 38 || sl == 39) return;
                 const int f = sl < 40 ? sl - sl / 5 - 1 : sl - 10;     // free steps: 0 .. 29 under the small products, 30 .. 37 under the hi x hi ones
-                if (PIML_F5_PHASED) {                          // only the sign words of this tile ride here (late: they are used right behind)
+                if (PIML_F5_PHASED) {                          // the requests of the tile after the next; this tile's sign words (late: used right behind)
+                    if (PIML_F5_REQ_EARLY && f >= 2 && f < 14 && !(f & 1) && !(PIML_F5_SKIP & 128)) req_step(f / 2 - 1, tile + 2 * nwg);
                     if (f >= 30 && f < 34) {
 #pragma unroll
                         for (int i = 4 * (f - 30); i < 4 * (f - 30) + 4; ++i) mkw[i] = mk1[2 * f5_rho(i)];
@@ -364,6 +420,7 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
                 const u32x4 (&o)[3] = opa[kb & 1];
+                ahi[kb] = o[0];
 #define F5_MA(X) do { if (!(PIML_F5_SKIP & 64)) { X; } else if (kb == 0) acc = zero16; } while (0)
                 F5_SLOT(F5_MA(acc = mfma_bf(o[2], wh[kb], kb == 0 ? zero16 : acc)), fill_a(kb * 5 + 0));
                 F5_SLOT(F5_MA(acc = mfma_bf(o[1], wm[kb], acc)), fill_a(kb * 5 + 1));
@@ -374,12 +431,12 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
 #ifdef PIML_F5_ACC2
             f32x16 acc2 = zero16;
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) F5_SLOT(if (kb & 1) acc2 = mfma_bf(ohi[kb % 3], wh[kb], acc2); else acc = mfma_bf(ohi[kb % 3], wh[kb], acc), fill_a(40 + kb));
+            for (int kb = 0; kb < 8; ++kb) F5_SLOT(if (kb & 1) acc2 = mfma_bf(ahi[kb], wh[kb], acc2); else acc = mfma_bf(ahi[kb], wh[kb], acc), fill_a(40 + kb));
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 #else
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) F5_SLOT(F5_MA(acc = mfma_bf(ohi[kb % 3], wh[kb], acc)), fill_a(40 + kb));
+            for (int kb = 0; kb < 8; ++kb) F5_SLOT(F5_MA(acc = mfma_bf(ahi[kb], wh[kb], acc)), fill_a(40 + kb));
 #endif
             F5_STAMP(1);
             // G1: mask, db1, the lane's 16 rows of its feature -> the G1 tile
@@ -411,7 +468,10 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 }
                 F5_STAMP(7);
                 stage((it + 1) % 3, par ^ 1);
-                if (!(PIML_F5_SKIP & 128)) { req_g(tile + 2 * nwg); req_x(tile + 2 * nwg); }
+                if (!(PIML_F5_SKIP & 128)) {
+                    if (PIML_F5_REQ_EARLY) req_take();
+                    else { req_g(tile + 2 * nwg); req_x(tile + 2 * nwg); }
+                }
                 F5_STAMP(5);
             }
             F5_BARRIER();
@@ -437,6 +497,12 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
         float w1acc[INC];
 #pragma unroll
         for (int cc = 0; cc < INC; ++cc) w1acc[cc] = 0.f;
+        float w1g[8];                                          // B operand of the g_x products: W1[32 w + 4 j + (lane >> 4)][lane & 15]
+        {
+            const float* W1r = J.packed + PACK_FWD + 32768;     // W1 rows padded to 8 columns (zeros beyond in_dim)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w1g[j] = (lane & 15) < 8 ? W1r[(32 * w + 4 * j + (lane >> 4)) * 8 + (lane & 15)] : 0.f;
+        }
         const int fw = 32 * w + n;
         const int swz_w = (fw >> 1) & 7;
         const int mw_off = F5_M + fw * 64;                     // this lane's own feature of the G2 image (A fragments of dW2)
@@ -461,11 +527,20 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
         };
         // g_x of a finished tile: the four waves' partials, fixed order; crew thread (row ctid >> 3, column ctid & 7)
         auto gx_store = [&](int tile, int pm) {
-            const float* gp = reinterpret_cast<const float*>(smem + F5_GXP + pm * 4096) + ctid;
-            const float v = ((gp[0] + gp[256]) + gp[512]) + gp[768];
-            const unsigned grow = (unsigned)tile * 32u + (unsigned)(ctid >> 3), cx = (unsigned)ctid & 7u;
+            const unsigned grow = (unsigned)tile * 32u + (unsigned)(ctid >> 3), cs = (unsigned)ctid & 7u;
+            float v;
+            if (PIML_F5_GX_MFMA) {                           // [wave][row][16]: column = slot
+                const float* gp = reinterpret_cast<const float*>(smem + F5_GXP + pm * F5_GXP_BYTES) + (ctid >> 3) * 16 + (ctid & 7);
+                v = ((gp[0] + gp[512]) + gp[1024]) + gp[1536];
+            } else {
+                const float* gp = reinterpret_cast<const float*>(smem + F5_GXP + pm * F5_GXP_BYTES) + ctid;
+                v = ((gp[0] + gp[256]) + gp[512]) + gp[768];
+            }
+            // (vector form, INC == 6: slot 4 h + j of a row's eight holds column 3 h + j, slots 3 and 7 nothing)
+            const unsigned cx = (INC == 6 && !PIML_F5_GX_MFMA) ? 3u * (cs >> 2) + (cs & 3u) : cs;
+            const bool cok = (INC == 6 && !PIML_F5_GX_MFMA) ? (cs & 3u) != 3u : cx < IN;
             const unsigned off = (grow * IN + cx) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_gx, (int)(((tile >= 0) & (tile < ntiles) & (grow < R) & (cx < IN)) ? off : kOut), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_gx, (int)(((tile >= 0) & (tile < ntiles) & (grow < R) & cok) ? off : kOut), 0, 0);
         };
         // the lagging vector work on the G1 tile `pm` and x ring slot `xslot`
 #ifndef PIML_F5_GXD
@@ -478,7 +553,9 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
         auto gx_load = [&](int k, int pm) {                    // features 2 k, 2 k + 1 of the wave's block
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
+                if (PIML_F5_SKIP & 512) tv[k % GXR][e] = (float)k; else
                 tv[k % GXR][e] = *reinterpret_cast<const float*>(smem + t_col + pm * F5_TBYTES + (2 * k + e) * (F5_TROW * 4));
+                if (PIML_F5_SKIP & 256) tw[k % GXR][e] = make_float4(1.f, 2.f, 3.f, (float)k); else
                 tw[k % GXR][e] = *reinterpret_cast<const float4*>(smem + w1_off + (2 * k + e) * 32);
             }
         };
@@ -488,7 +565,8 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 const float v = tv[k % GXR][e];
                 const float4 wv = tw[k % GXR][e];
                 gx[0] = __fmaf_rn(wv.x, v, gx[0]); gx[1] = __fmaf_rn(wv.y, v, gx[1]);
-                gx[2] = __fmaf_rn(wv.z, v, gx[2]); gx[3] = __fmaf_rn(wv.w, v, gx[3]);
+                gx[2] = __fmaf_rn(wv.z, v, gx[2]);
+                if (INC == 8) gx[3] = __fmaf_rn(wv.w, v, gx[3]);
             }
         };
         float g1[16];
@@ -525,7 +603,43 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             }
         };
         // 27 steps: g_x (features two by two, loads a step ahead), its partial, dW1 (rows two by two, loads a step ahead)
-        auto lag_step = [&](int f, int pm, int xslot) {
+        // g_x on the f32 matrix instruction: D[row][c] = sum over the wave's 32 features of G1[row][f] W1[f][c], two chains (rows
+        // 0 .. 15 / 16 .. 31) of eight products (four features each); operand A: lane (m = row & 15, k = lane >> 4) reads
+        // G1[feature 4 j + k][row] from the tile, operand B: lane (k, n = column) holds W1[4 j + k][n] (0 beyond column 7)
+        f32x4 gd[2];
+        float ga[8][2];                                        // (all sixteen operands requested up front: 8 ds_read2_b32)
+        const int ga_off = F5_T + (32 * w + (lane >> 4)) * (F5_TROW * 4) + (lane & 15) * 4;      // + 4 j features, + 16 r rows
+        auto gm_load = [&](int j, int pm) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) ga[j][r] = *reinterpret_cast<const float*>(smem + ga_off + pm * F5_TBYTES + j * (4 * F5_TROW * 4) + r * 64);
+        };
+        // (these products ride between crew B's OWN products, not in its vector half: there crew A's chain of 51 dependent products
+        // owns the matrix pipe -- the older wave wins the arbitration every time -- and crew B's in-order stream stood behind its
+        // first g_x product for the whole of crew A's chain: 4.5 k cycles for the vector half instead of 3.5 k)
+        auto gxm_step = [&](int f, int pm) {                  // 0 .. 9; pm: the G1 tile
+            if (!GX) return;
+            if (f == 0) {
+                gd[0] = gd[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gm_load(j, pm);
+            } else if (f <= 8) {
+                const int j = f - 1;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) gd[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j][r], w1g[j], gd[r], 0, 0, 0);
+            } else if (f == 9) {                              // rows 16 r + 4 (lane >> 4) + i, column lane & 15
+                float* dst = reinterpret_cast<float*>(smem + F5_GXP + (pm ^ 1) * F5_GXP_BYTES) + (w * 32 + 4 * (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[(16 * r + i) * 16] = gd[r][i];
+            }
+        };
+        auto lag_step_m = [&](int f, int pm, int xslot) {     // dW1 alone: 10 steps
+            if (f == 0) { g1_load(0, pm); g1_load(1, pm); x_load(0, xslot); }
+            else if (f == 1) { x_load(1, xslot); x_fma(0); }
+            else if (f < 9) { if (f < 8) x_load(f, xslot); x_fma(f - 1); }
+        };
+        auto lag_step_v = [&](int f, int pm, int xslot) {
             if (f == 0) {
                 gx[0] = gx[1] = gx[2] = gx[3] = 0.f;
                 if (GX && !(PIML_F5_SKIP & 2)) {
@@ -537,12 +651,15 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 if (f == 15) g1_load(0, pm);
                 if (f == 16) { g1_load(1, pm); x_load(0, xslot); }
             } else if (f == 17) {
-                if (GX) reinterpret_cast<float4*>(smem + F5_GXP + (pm ^ 1) * 4096)[(w * 32 + n) * 2 + h] = make_float4(gx[0], gx[1], gx[2], gx[3]);
+                if (GX) reinterpret_cast<float4*>(smem + F5_GXP + (pm ^ 1) * F5_GXP_BYTES)[(w * 32 + n) * 2 + h] = make_float4(gx[0], gx[1], gx[2], gx[3]);
                 x_load(1, xslot); x_fma(0);
             } else if (f < 25) {
                 if (f < 24) x_load(f - 16, xslot);
                 x_fma(f - 17);
             }
+        };
+        auto lag_step = [&](int f, int pm, int xslot) {
+            if (PIML_F5_GX_MFMA) lag_step_m(f, pm, xslot); else lag_step_v(f, pm, xslot);
         };
 
 #ifdef PIML_F5_PRIO_B
@@ -567,7 +684,15 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 }
                 if (sl == 23) { load_g2(g2f, 1, par); return; }   // (behind the last product of k-step 0)
                 const int f = sl - sl / 6 - 1 - (sl > 23);         // 39 free steps
-                if ((PIML_F5_SKIP & 1) || PIML_F5_PHASED) return;
+                if (PIML_F5_PHASED) {
+                    if (PIML_F5_GX_MFMA && !(PIML_F5_SKIP & 2)) {
+                        if (f == 1) gxm_step(0, lpm);
+                        else if (f >= 6 && f < 14) gxm_step(f - 5, lpm);
+                        else if (f == 22) gxm_step(9, lpm);
+                    }
+                    return;
+                }
+                if (PIML_F5_SKIP & 1) return;
                 if (f == 0) { if (GX) gx_store(tile - 2 * nwg, par ^ 1); }
                 else if (f < 28) lag_step(f - 1, lpm, xslot);
             };
@@ -581,6 +706,9 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 for (int f = 17; f < 27; ++f) lag_step(f, lpm, xslot);
                 F5_STAMP(5);
             }
+#ifdef PIML_F5_PRIO_PROD
+            __builtin_amdgcn_s_setprio(PIML_F5_PRIO_PROD);      // the products' issue slots in front of crew A's vector stream (the older wave)
+#endif
             load_g2(g2f, 0, par);
             load_h(opb[0], 0, par);
 #pragma unroll
@@ -595,6 +723,9 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                 F5_SLOT(F5_MB(sm[jb] = mfma_bf(g2f[0], o[1], sm[jb])), fill_b(u * 6 + 4));
                 F5_SLOT(F5_MB(c[jb] = mfma_bf(g2f[0], o[0], c[jb])), fill_b(u * 6 + 5));
             }
+#ifdef PIML_F5_PRIO_PROD
+            __builtin_amdgcn_s_setprio(0);
+#endif
             F5_STAMP(1);
             F5_BARRIER();
         }
@@ -605,6 +736,10 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             if (GX) gx_store(tile - 2 * nwg, par ^ 1);
 #pragma unroll
             for (int f = 0; f < 27; ++f) lag_step(f, par ^ 1, (it + 2) % 3);
+            if (PIML_F5_GX_MFMA) {
+#pragma unroll
+                for (int f = 0; f < 10; ++f) gxm_step(f, par ^ 1);
+            }
             F5_BARRIER();
             if (GX) gx_store(tile - nwg, par);
             F5_BARRIER();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: bitwise test of the shipped library + stamps of the named variants
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6_f5b; mkdir -p $O
-timeout 900 python -m pytest tests/test_sums_gpu.py -x -q -k "two_crew" 2>&1 | tail -3 | tee $O/test.log
+timeout 900 python -m pytest tests/test_sums_gpu.py -x -q -k "two_crew or float64" 2>&1 | tail -3 | tee $O/test.log
 for v in "$@"; do
   echo "== variant $v" | tee -a $O/skip.log
   PIML_LIB=$GRAFT_REPO_ROOT/piml_amd/libpiml_hip_f5$v.so timeout 300 python tools/f5_stamps.py 2>&1 | grep -v -i "warn\|amdgpu.ids" | tail -10 | tee -a $O/skip.log
