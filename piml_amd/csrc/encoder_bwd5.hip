@@ -62,7 +62,15 @@ constexpr int F5_GXP = F5_W1 + 4096;                         // g_x partials [pa
 #ifndef PIML_F5_GX_MFMA
 #define PIML_F5_GX_MFMA 1
 #endif
+// 1: dW1 = G1^T X on the same instruction (two chains of eight products per tile into eight persistent registers; operands: one
+// ds_read_b32 of the G1 tile and one of the x rows per product) instead of 96 FMAs on 36 LDS reads per wave and tile.  Built,
+// green, and SLOWER (31.5 against 29.5 us): with it crew B has no vector half left, its 80 products start beside crew A's chain
+// and the tile becomes the matrix pipe's 134 x 32 cycles.  Off; the vector form is the default.
+#ifndef PIML_F5_DW1_MFMA
+#define PIML_F5_DW1_MFMA 0
+#endif
 static_assert(!PIML_F5_GX_MFMA || PIML_F5_PHASED, "the g_x products ride in the phased schedule");
+static_assert(!PIML_F5_DW1_MFMA || PIML_F5_GX_MFMA, "the dW1 products need the zero region the g_x products freed");
 constexpr int F5_GXP_BYTES = PIML_F5_GX_MFMA ? 4 * 32 * 16 * 4 : 4096;      // one parity: [wave 4][row 32][16 | 8] floats
 constexpr int F5_TAB = F5_GXP + 2 * F5_GXP_BYTES;            // gather table [rem < 16][half 2][register 16] byte offsets
 constexpr int F5_KMAX = 16;
@@ -170,7 +178,9 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             const unsigned rem = (unsigned)tid >> 5, hh = ((unsigned)tid >> 4) & 1u, r = (unsigned)tid & 15u;
             reinterpret_cast<unsigned*>(smem + F5_TAB)[tid] = ((rem + 4u * hh + (unsigned)f5_rho((int)r)) / K) * (EH * 4);
         }
-        if (tid < 256) {
+        if (tid < 256 && PIML_F5_GX_MFMA) {                  // no W1 rows in LDS: the region is the zero operand of the dW1 products' idle columns
+            reinterpret_cast<float4*>(smem + F5_W1)[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (tid < 256) {
             const float* W1r = J.packed + PACK_FWD + 32768;     // W1 rows padded to 8 columns
             if (INC == 6) {                                   // g_x: lane half h takes columns 3 h .. 3 h + 2 -> [feature][half][c, c, c, 0]
                 const float* src = W1r + (tid >> 1) * 8 + 3 * (tid & 1);
@@ -613,6 +623,27 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) ga[j][r] = *reinterpret_cast<const float*>(smem + ga_off + pm * F5_TBYTES + j * (4 * F5_TROW * 4) + r * 64);
         };
+        // dW1 the same way: D[feature][c] += sum over the tile's rows of G1[row][feature] x[row][c]; chain c2 = features 16 c2 .. + 15
+        // of the wave's block; operand A: lane (m = feature & 15, k = lane >> 4) reads G1[feature][row 4 j + k], operand B: lane
+        // (k, n = column) reads x[row 4 j + k][n] -- columns 8 .. 15 read zeros (the former W1 region)
+        f32x4 dw1m[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        float da[8][2], dbv[8];
+        const int da_off = F5_T + (32 * w + (lane & 15)) * (F5_TROW * 4) + (lane >> 4) * 4;      // + 16 c2 features, + 4 j rows
+        const int db_off = (lane & 15) < 8 ? F5_XS + (lane >> 4) * 32 + (lane & 15) * 4 : F5_W1 + (lane >> 4) * 32;
+        auto dwm_step = [&](int f, int pm, int xslot) {       // 0 .. 9
+            if (f < 2) {
+#pragma unroll
+                for (int j = 4 * f; j < 4 * f + 4; ++j) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) da[j][c2] = *reinterpret_cast<const float*>(smem + da_off + pm * F5_TBYTES + c2 * (16 * F5_TROW * 4) + j * 16);
+                    dbv[j] = *reinterpret_cast<const float*>(smem + db_off + xslot * 1024 + j * 128);
+                }
+            } else {
+                const int j = f - 2;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) dw1m[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[j][c2], dbv[j], dw1m[c2], 0, 0, 0);
+            }
+        };
         // (these products ride between crew B's OWN products, not in its vector half: there crew A's chain of 51 dependent products
         // owns the matrix pipe -- the older wave wins the arbitration every time -- and crew B's in-order stream stood behind its
         // first g_x product for the whole of crew A's chain: 4.5 k cycles for the vector half instead of 3.5 k)
@@ -635,6 +666,7 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
             }
         };
         auto lag_step_m = [&](int f, int pm, int xslot) {     // dW1 alone: 10 steps
+            if (PIML_F5_DW1_MFMA) return;
             if (f == 0) { g1_load(0, pm); g1_load(1, pm); x_load(0, xslot); }
             else if (f == 1) { x_load(1, xslot); x_fma(0); }
             else if (f < 9) { if (f < 8) x_load(f, xslot); x_fma(f - 1); }
@@ -690,6 +722,10 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
                         else if (f >= 6 && f < 14) gxm_step(f - 5, lpm);
                         else if (f == 22) gxm_step(9, lpm);
                     }
+                    if (PIML_F5_DW1_MFMA && !(PIML_F5_SKIP & 1)) {
+                        if (f == 2 || f == 3) dwm_step(f - 2, lpm, xslot);
+                        else if (f >= 14 && f < 22) dwm_step(f - 12, lpm, xslot);
+                    }
                     return;
                 }
                 if (PIML_F5_SKIP & 1) return;
@@ -740,6 +776,10 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
 #pragma unroll
                 for (int f = 0; f < 10; ++f) gxm_step(f, par ^ 1);
             }
+            if (PIML_F5_DW1_MFMA) {
+#pragma unroll
+                for (int f = 0; f < 10; ++f) dwm_step(f, par ^ 1, (it + 2) % 3);
+            }
             F5_BARRIER();
             if (GX) gx_store(tile - nwg, par);
             F5_BARRIER();
@@ -750,13 +790,22 @@ __global__ __launch_bounds__(F5_THREADS) void enc_bwd_sums2_kernel(F5Args F) {
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[(size_t)(32 * w + f5_rho(r) + 4 * h) * EH + 32 * jb + n] = c[jb][r] + sm[jb][r];
+        if (PIML_F5_DW1_MFMA) {                                // register i of chain c2: feature 32 w + 16 c2 + 4 (lane >> 4) + i, column lane & 15
+            if ((unsigned)(lane & 15) < IN) {
 #pragma unroll
-        for (int cc = 0; cc < INC; ++cc) w1acc[cc] += __shfl_xor(w1acc[cc], 32, 64);
-        if (h == 0) {
-            float* o = P + EH * EH + (size_t)(32 * w + n) * IN;
+                for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-            for (int cc = 0; cc < INC; ++cc)
-                if ((unsigned)cc < IN) o[cc] = w1acc[cc];
+                    for (int i = 0; i < 4; ++i) P[EH * EH + (size_t)(32 * w + 16 * c2 + 4 * (lane >> 4) + i) * IN + (lane & 15)] = dw1m[c2][i];
+            }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < INC; ++cc) w1acc[cc] += __shfl_xor(w1acc[cc], 32, 64);
+            if (h == 0) {
+                float* o = P + EH * EH + (size_t)(32 * w + n) * IN;
+#pragma unroll
+                for (int cc = 0; cc < INC; ++cc)
+                    if ((unsigned)cc < IN) o[cc] = w1acc[cc];
+            }
         }
         F5_STAMP(11);
     }
