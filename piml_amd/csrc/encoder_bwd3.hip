@@ -94,6 +94,15 @@ __device__ unsigned long long g_f3_stamps[256 * 64];          // [workgroup][wav
 #define F3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// 1: g_x = G1 W1 on v_mfma_f32_16x16x4_f32 (exact f32 products): per pass of 16 features two chains (rows 0 .. 15 / 16 .. 31) of four
+// products; the G1 operand is one ds_read_b32 of the wave's half tile per product, the W1 operand EIGHT registers for the whole
+// slab -- instead of 32 ds_read_b32 + 32 broadcast ds_read_b128 of W1 rows + 128 FMAs per wave and tile (the LDS pipe, not the
+// FMAs, was the price there: encoder_bwd5.hip).  Built, green (246 tests) and LEVEL here (58.3 against 58.4 us in the dropout step): the
+// lone wave's vector form already sits in the shadow of the dW2 products.  0 (default): the vector form
+#ifndef PIML_F3_GX_MFMA
+#define PIML_F3_GX_MFMA 0
+#endif
+
 struct F3Args {
     EncArgs A;
     int nA[2];          // workgroups of branch 0 / branch 1 (grid = their sum)
@@ -227,6 +236,9 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
 #pragma unroll
     for (int s = 0; s < 4; ++s) w1v[s] = W1rows[(32 * w + n) * 8 + 2 * s + h];
     const float b1v = J.b1[32 * w + n];
+    float w1g[8];                                             // B operand of the g_x products: W1[32 w + 16 p + 4 j + (lane >> 4)][lane & 15]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w1g[q] = (GX && PIML_F3_GX_MFMA && (lane & 15) < 8) ? W1rows[(32 * w + 4 * q + (lane >> 4)) * 8 + (lane & 15)] : 0.f;
 
     // ---- per-lane LDS addresses ----
     u32x4* const bufA = reinterpret_cast<u32x4*>(smem + F3_BUFA) + lane;
@@ -658,6 +670,29 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
                 w1acc[6] = __fmaf_rn(g, xb4.z, w1acc[6]); w1acc[7] = __fmaf_rn(g, xb4.w, w1acc[7]);
             }
         };
+        // g_x on the matrix instruction: operand A = lane (m = row & 15, k = lane >> 4) reads G1[feature 4 j + k of the pass][row 16 r + m]
+        f32x4 gd[2];
+        float ga[4][2];
+        const float* const Tm = Tbase + (lane >> 4) * F3_TROW + (lane & 15);        // + 4 j features, + 16 r rows
+        auto gm_load = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) ga[j][r] = Tm[4 * j * F3_TROW + 16 * r];
+        };
+        auto gm_mma = [&](int p_, int j) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) gd[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j][r], w1g[4 * p_ + j], gd[r], 0, 0, 0);
+        };
+        auto gm_store = [&]() {                              // rows 16 r + 4 (lane >> 4) + i, column lane & 15 (columns >= 8: a slot of the lane's own)
+            float* dst = (lane & 15) < 8 ? reinterpret_cast<float*>(smem + F3_GX) + (w * 32 + 4 * (lane >> 4)) * 8 + (lane & 15)
+                                          : reinterpret_cast<float*>(smem + F3_TDUMMY) + (w * 32 + (lane & 31)) * 4 - 0;
+            const int stride = (lane & 15) < 8 ? 8 : 0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(16 * r + i) * stride] = gd[r][i];
+        };
         auto fill_w = [&](int sl) {
             if (sl % 6 == 0) {
                 const int u_ = sl / 6 + 1;
@@ -674,12 +709,20 @@ __global__ __launch_bounds__(F3_THREADS) void enc_bwd_fused_x3_kernel(F3Args F) 
                     acc[r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)t);
                     db1 += acc[r];
                 }
+            } else if (GX && PIML_F3_GX_MFMA && f >= 8 && f < 26) {
+                if (f == 8) { gd[0] = gd[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; t_write(0); }
+                else if (f == 9) gm_load();
+                else if (f >= 11 && f < 15) gm_mma(0, f - 11);
+                else if (f == 15) t_write(1);                 // (behind the pass-0 reads: a wave's LDS operations complete in order)
+                else if (f == 16) gm_load();
+                else if (f >= 18 && f < 22) gm_mma(1, f - 18);
+                else if (f == 25) gm_store();
             } else if (GX && f == 8) { t_write(0); gx_load(0, 0); }
             else if (GX && f >= 9 && f < 17) { if (f < 16) gx_load(0, f - 8); gx_fma(f - 9); }
             else if (GX && f == 17) { t_write(1); gx_load(1, 0); }
             else if (GX && f >= 18 && f < 26) { if (f < 25) gx_load(1, f - 17); gx_fma(f - 18); }
             else if (f == 26) {
-                if (GX) reinterpret_cast<float4*>(smem + F3_GX)[(w * 32 + n) * 2 + h] = make_float4(gx[0], gx[1], gx[2], gx[3]);
+                if (GX && !PIML_F3_GX_MFMA) reinterpret_cast<float4*>(smem + F3_GX)[(w * 32 + n) * 2 + h] = make_float4(gx[0], gx[1], gx[2], gx[3]);
                 x_load(0);
             } else if (f >= 27 && f < 35) { if (f < 34) x_load(f - 26); x_fma(f - 27); }
         };
