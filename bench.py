@@ -1117,7 +1117,7 @@ def main():
     kernel_bytes = n_own * (24 * N + 8 * M_eff) + 488 * n_own         # this rank's relfeat launch
 
     prof = None
-    pname = next((f for f in ('r05_step_counters.json', 'r04_step_counters.json', 'r03_step_counters.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+    pname = next((f for f in ('r06_step_counters.json', 'r05_step_counters.json', 'r04_step_counters.json', 'r03_step_counters.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
     if world == 1 and pname:
         pj = json.load(open(os.path.join(ROOT, 'profiles', pname)))
         if pj.get('config', {}).get('agents_total') == N and pj['config'].get('obstacle_points') == M_eff:
@@ -1157,8 +1157,16 @@ def main():
         stage_kernel['enc_bwd_dx'] = 'enc_bwd_fused_x3_kernel'
         if os.environ.get('PIML_ENC_FUSED_DW3', '1') != '0':
             stage_kernel['enc_bwd_dw'] = '(no launch: dW3 is phase 2 of enc_bwd_fused_x3_kernel)'
+    if sums_path:
+        try:        # round 6: the sums path's backward as two crews of four waves (encoder_bwd5.hip) unless PIML_ENC_SUMS_BWD=1
+            from piml_amd import _lib as _plib2
+            if _plib2.lib().piml_encoder_sums_bwd(0) == 2:
+                stage_kernel['enc_bwd_dx'] = 'enc_bwd_sums2_kernel'
+        except Exception:   # noqa: BLE001 - an older library: the name stays
+            pass
     # kernels whose f32 products run as six bf16 products (priced against the bf16 matrix pipe AND the HBM ceiling)
-    split_kernels = {'enc_fwd_x3_kernel', 'enc_fwd_sum_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw2_x3_kernel', 'enc_bwd_dw_x3w_kernel', 'enc_bwd_fused_x3_kernel'}
+    split_kernels = {'enc_fwd_x3_kernel', 'enc_fwd_sum_x3_kernel', 'enc_bwd_dx_x3_kernel', 'enc_bwd_dw2_x3_kernel', 'enc_bwd_dw_x3w_kernel', 'enc_bwd_fused_x3_kernel',
+                     'enc_bwd_sums2_kernel'}
     static = {e['name']: e for e in (prof or {}).get('all_step_kernels', [])}
     if os.environ.get('PIML_DEC_BWD_SPLIT', '1') != '0':       # decoder backward as (tile, branch) workgroups (the default)
         stage_kernel['dec_bwd'] = 'dec_bwd_split_kernel'

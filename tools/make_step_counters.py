@@ -72,6 +72,7 @@ FLOPS = {   # algorithmic FLOPs per launch at cfg3 (2 x MACs), encoder: both bra
     'dec_fwd_head_sum_kernel': 2 * 2 * N * (128 * 64 + 64 * 64 + 64 * 2) + 2 * N * KP * (128 * 64 + 64),
 }
 SUMS_BWD_FLOPS = 2 * ROWS * (2 * 128 * 128 + 2 * 6 * 128)      # enc_bwd_fused_x3_kernel<..., SUMS = true>
+FLOPS['enc_bwd_sums2_kernel'] = SUMS_BWD_FLOPS                  # round 6: the same work as two crews of four waves (encoder_bwd5.hip)
 
 
 def short(name):
@@ -95,8 +96,8 @@ for r in rows:
     hbm = 2 * fetch.get(name, {}).get('FETCH_SIZE', 0.0) * 1024 + write.get(name, {}).get('WRITE_SIZE', 0.0) * 1024
     c = sq.get(name, {})
     e = {'name': key, 'us': round(us, 2), 'launches_per_step': round(per_step, 2), 'hbm_bytes': round(hbm)}
-    sums_bwd = key == 'enc_bwd_fused_x3_kernel' and name.rstrip().endswith('true>(piml::F3Args)')      # the SUMS template flag
-    if key in FLOPS and '_x3_' in key:
+    sums_bwd = (key == 'enc_bwd_fused_x3_kernel' and name.rstrip().endswith('true>(piml::F3Args)')) or key == 'enc_bwd_sums2_kernel'
+    if key in FLOPS and ('_x3_' in key or key == 'enc_bwd_sums2_kernel'):
         # f32 arithmetic carried by six bf16 matrix instructions per k-block: priced against BOTH ceilings, the larger
         # fraction names the bound.  Executed bf16 FLOPs = 6 x the 128 x 128 layers' (the K <= 8 layer stays f32 / VALU):
         # two per row in the message forward and in the sums backward, four in the message backward, one in the sums forward.
