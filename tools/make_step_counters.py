@@ -168,7 +168,7 @@ with open(os.path.join(dst, f'{tag}_summary.md'), 'w') as f:
         what = {'mfma': f'{e.get("achieved_tflops")} TF/s = {fr} of 157.3 TF f32 MFMA', 'valu': f'{fr} of the SIMD issue cycles (VALU)',
                 'hbm': f'HBM {e.get("achieved_gbs")} GB/s = {fr} of 8 TB/s',
                 'latency': f'VALU {fr}, HBM {e.get("hbm_frac")} (launch / latency bound)'}.get(e.get('bound'), '')
-        if '_x3_' in e['name']:
+        if '_x3_' in e['name'] or e['name'] == 'enc_bwd_sums2_kernel':
             what = (f'HBM {e["achieved_gbs"]} GB/s = {e["hbm_frac"]} of 8 TB/s; bf16 matrix pipe {e["executed_bf16_tflops"]} TF/s executed = '
                     f'{e["mfma_frac"]} of 2.5 PF ({e["f32_equivalent_tflops"]} TF/s of f32 work)')
         f.write(f'| `{e["name"]}` | {e["launches_per_step"]} | {e["us"]} | {e.get("bound", "")} | {what} | {e["hbm_bytes"] / 1e6:.2f} |\n')
