@@ -699,6 +699,10 @@ static int relfeat_launch(const float* position, const float* heading, const flo
     // L2->LDS traffic, while smaller groups shorten the barrier tails (the per-wave work is
     // data dependent) and spread small launches over more CUs.
     int waves = rows >= 16384 ? 8 : (rows >= 4096 ? 16 : (rows >= 1024 ? 8 : 4));   // measured (tools/time_*.py)
+    // more sources than one tile (every pass re-stages the tile behind two barriers: the shapes of a sharded scene): eight waves
+    // -- round 6, tools/time_sharded_shapes.py: 4096 focal rows x 8192 / 16384 / 32768 sources 26.4 / 36.5 / 57.7 us against
+    // 29.1 / 40.3 / 59.1 with sixteen (and 32.5 / 45.5 / 67.9 with four); 2048 x 16384: 29.7 / 32.8 / 34.0
+    if (N > kTile && rows >= 1024) waves = 8;
     if (const char* e = getenv("PIML_RELFEAT_WAVES")) waves = atoi(e);
     const int bpc = (focal_count + waves - 1) / waves;
     const dim3 grid((unsigned)(C * bpc)), block((unsigned)(waves * 64));
