@@ -319,6 +319,11 @@ __global__ __launch_bounds__(WAVES * 64) void relfeat_fwd_kernel(const RelfeatAr
             for (int j0 = 0; j0 <= tn_pad; j0 += 512) {
                 const bool flush = j0 == tn_pad;
                 if (!flush) {
+                    // (round 6, built bit-exact and dropped: the filter on the EXPANDED square s + (-2 px) x + (-2 py) y with s = x^2 + y^2
+                    // staged as a third LDS array -- two packed FMAs per pair of points instead of four packed operations, threshold
+                    // widened by the rounding bound 4e-6 (|p|^2 + cut2): 20.6 vs 20.8 us at the 4096-agent scene, 139 vs 115 at 16384
+                    // (eight-wave workgroups lose their third resident workgroup to the 16 KB), 28.5 vs 29.7 for a rank's share.  Phase 1
+                    // is ~6 of the launch's 20 us and trades vector instructions for LDS reads one for one.)
                     // phase 1: lane owns points j0 + 4*lane + {0..3} and j0 + 256 + 4*lane + {0..3}
                     // packed fp32 (v_pk_add/mul/fma): two points per instruction
                     // (round 4, measured and dropped: the next group's points fetched one trip ahead -- 16 more registers,
