@@ -434,6 +434,17 @@ int piml_train_step_bwd6(const float* g_position_out, const float* g_velocity_ou
                          const float* g_state6, const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T, int N,
                          int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred,
                          void* stream);
+/* piml_train_step_bwd6 with a third source: g_position_in (may be NULL) = a gradient that arrives on the frame's INPUT position
+ * itself -- the rollout loss reads every frame's position (src/models/simulators.py:728, :790-819) and the next frame's step
+ * reads it too; handed in here (C slices of (N, 2) contiguous floats, g_position_in_slice_stride floats apart: a time slice of
+ * the loss's (C, T, N, 2) gradient as it stands) it is added to g_position inside the launch instead of by a strided addition
+ * of the autograd engine per frame.  g_position_out_slice_stride != 0: g_position_out is laid out the same way (0: C * N
+ * contiguous rows). */
+int piml_train_step_bwd7(const float* g_position_out, long long g_position_out_slice_stride, const float* g_velocity_out,
+                         const float* g_acceleration_out,
+                         const float* g_state6, const float* g_position_in, long long g_position_in_slice_stride,
+                         const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T, int N, int t_next, float dt,
+                         float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
 
 
 /*
@@ -803,6 +814,14 @@ int piml_corrector_bwd(const piml_corrector* c, int accumulate, void* stream);
  * stage it hides: 0.247 ms/step serial vs 0.295 forked at cfg3, DESIGN.md.  The side streams are created per device on
  * first use, outside any capture: piml_pinnsf_streams_init, idempotent).
  */
+/* piml_pinnsf_unfold_defer(1, NULL): from now on (this device) a PIML_POOL_TRAIN backward does not launch the unfold of its folded
+ * layers' gradients behind its slot sums but leaves it with the library; piml_pinnsf_unfold_defer(0, stream) launches what is
+ * waiting (on `stream`, or on the stream it was left on when NULL) and ends the deferral.  For the backward passes of ONE
+ * optimiser step that accumulate into the same buffers (PIML_ACCUMULATE: the frames of the rollout of
+ * src/models/simulators.py:699-779): the unfold reads the folded layers' summed gradients and overwrites the unfolded ones, so
+ * only the last pass's matters -- one launch per step instead of one per pass.  Another network's backward in between launches
+ * what is waiting first.  Until the closing call dw1_out and the dW3 / db3 fields of the encoders' `grads` are NOT valid. */
+int piml_pinnsf_unfold_defer(int on, void* stream);
 #define PIML_PACKED_VALID 1
 #define PIML_FORK 2
 #define PIML_ACCUMULATE 4 /* piml_pinnsf_bwd: every branch's `grads` += the slot sums instead of = (a further backward pass through

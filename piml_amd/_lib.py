@@ -88,6 +88,8 @@ SIGNATURES = {
     'piml_train_step_fwd': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p],
     'piml_train_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_train_step_bwd6': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
+    'piml_pinnsf_unfold_defer': [_i, _p],
+    'piml_train_step_bwd7': [_p, _ll, _p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_bwd': [_p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_ksum_fwd': [_p, _i, _p, _i, _p, _z, _f, _p, _p],

@@ -144,11 +144,71 @@ __global__ __launch_bounds__(256) void pinnsf_unfold_kernel(ReduceAll R) {
 // one round of device-scope loads.  At the tail of the launch the chain [sums, ticket, uncached loads, products] ran 19 - 21 us
 // against 9.4 + 4.7 as two launches; dispatched early -- right behind the decoder sets -- the 258 polling workgroups cost the
 // launch more still, 33 us; an ACQUIRE in the poll invalidates the XCD's L2 on every round: 49 us.  Two launches it stays.)
-int launch_unfold(const ReduceAll& R, hipStream_t s) {
+static int launch_unfold_now(const ReduceAll& R, hipStream_t s) {
     if (R.nunf <= 0) return hipSuccess;
     hipLaunchKernelGGL(pinnsf_unfold_kernel, dim3(kUnfoldBlocks, (unsigned)R.nunf), dim3(256), 0, s, R);
     trace_mark("pinnsf_unfold", s);
     return hipGetLastError();
+}
+
+// ---- deferred unfold (piml_pinnsf_unfold_defer): one waiting entry per device ----
+// The unfold READS the folded layers' summed gradients and OVERWRITES the unfolded ones, so of the backward passes of one optimiser
+// step that accumulate into the same buffers (PIML_ACCUMULATE: the frames of a training rollout) only the LAST pass's unfold
+// matters -- the earlier ones compute from partial sums what the last one computes again.  While deferring, launch_unfold records
+// the sets instead of launching; another network's sets first launch what is waiting.
+namespace {
+struct PendingUnfold {
+    ReduceAll R;
+    hipStream_t stream = nullptr;
+    bool valid = false, deferring = false;
+};
+PendingUnfold g_pending_unfold[kMaxDevices];
+PendingUnfold* pending_unfold_entry() {
+    int dev = 0;
+    if (hipGetDevice(&dev) || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_pending_unfold[dev];
+}
+bool same_unfold(const ReduceAll& a, const ReduceAll& b) {
+    if (a.nunf != b.nunf) return false;
+    for (int i = 0; i < a.nunf; ++i)
+        if (a.unf[i].dgrads != b.unf[i].dgrads || a.unf[i].dw1_out != b.unf[i].dw1_out || a.unf[i].egrads != b.unf[i].egrads ||
+            a.unf[i].w1 != b.unf[i].w1 || a.unf[i].w3 != b.unf[i].w3 || a.unf[i].b3 != b.unf[i].b3 || a.unf[i].k != b.unf[i].k ||
+            a.unf[i].scale != b.unf[i].scale)
+            return false;
+    return true;
+}
+}  // namespace
+
+int launch_unfold(const ReduceAll& R, hipStream_t s) {
+    if (R.nunf <= 0) return hipSuccess;
+    PendingUnfold* P = pending_unfold_entry();
+    ReduceAll old;
+    hipStream_t olds = nullptr;
+    bool flush_old = false, deferred = false;
+    if (P) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (P->deferring) {
+            if (P->valid && !same_unfold(P->R, R)) { old = P->R; olds = P->stream; flush_old = true; }
+            P->R = R; P->stream = s; P->valid = true;
+            deferred = true;
+        }
+    }
+    if (!deferred) return launch_unfold_now(R, s);
+    return flush_old ? launch_unfold_now(old, olds) : (int)hipSuccess;
+}
+
+PIML_API int piml_pinnsf_unfold_defer(int on, void* stream) {
+    PendingUnfold* P = pending_unfold_entry();
+    if (!P) return hipErrorInvalidDevice;
+    ReduceAll R;
+    hipStream_t s = nullptr;
+    bool go = false;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (P->valid) { R = P->R; s = stream ? as_stream(stream) : P->stream; go = true; P->valid = false; }
+        P->deferring = on != 0;
+    }
+    return go ? launch_unfold_now(R, s) : (int)hipSuccess;
 }
 
 // ---- deferred slot sums (PIML_DEFER_SLOT_SUMS): one waiting entry per device ----

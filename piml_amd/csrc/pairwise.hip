@@ -1761,14 +1761,16 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
                                       const unsigned char* __restrict__ zero_mask, int C, int T, int N, int t_next,
                                       float dt, float2* __restrict__ gp,
                                       float2* __restrict__ gv, float2* __restrict__ ga,
-                                      float2* __restrict__ ga_pred) {
+                                      float2* __restrict__ ga_pred, const float2* __restrict__ gp_in = nullptr,
+                                      long long gp_in_cstride = 0, long long gp_o_cstride = 0) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)C * N) return;
     const int c = (int)(g / N), i = (int)(g - (long long)c * N);
     bool keep = true;
     if (new_flag && t_next < T) keep = new_flag[((size_t)c * T + t_next) * N + i] == 0;
     const float2 z = make_float2(0.f, 0.f);
-    float2 a = (keep && gp_o) ? gp_o[g] : z;
+    // (gp_o_cstride != 0: g_position_out is C slices of (N, 2) that far apart -- a time slice of the loss's gradient as it stands)
+    float2 a = (keep && gp_o) ? (gp_o_cstride ? gp_o[(size_t)c * gp_o_cstride + i] : gp_o[g]) : z;
     float2 b = (keep && gv_o) ? gv_o[g] : z, e = (keep && ga_o) ? ga_o[g] : z;
     if (keep && g6) {        // the features' share of d/d(p', v', a'), interleaved (C, N, 6)
         const float2 q0 = g6[3 * g], q1 = g6[3 * g + 1], q2 = g6[3 * g + 2];
@@ -1781,7 +1783,11 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
         if (m & 4u) e.x = 0.f;
         if (m & 8u) e.y = 0.f;
     }
-    if (gp) gp[g] = a;
+    // gp_in: a gradient that arrives on the INPUT position itself (the loss reads the frame's input through an alias output of
+    // the frame's autograd node): added to g_p only -- slices (N, 2) contiguous, gp_in_cstride float2 between the slices
+    float2 ain = z;
+    if (gp_in) ain = gp_in[(size_t)c * gp_in_cstride + i];
+    if (gp) gp[g] = make_float2(a.x + ain.x, a.y + ain.y);
     if (gv) gv[g] = make_float2(b.x + dt * a.x, b.y + dt * a.y);
     if (ga) ga[g] = make_float2(dt * b.x, dt * b.y);
     if (ga_pred) ga_pred[g] = e;
@@ -2071,6 +2077,23 @@ PIML_API int piml_train_step_bwd6(const float* g_position_out, const float* g_ve
                        piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
                        (const float2*)g_acceleration_out, (const float2*)g_state6, new_flag, zero_mask, C, T, N, t_next, dt,
                        (float2*)g_position, (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred);
+    return hipGetLastError();
+}
+
+PIML_API int piml_train_step_bwd7(const float* g_position_out, long long g_position_out_slice_stride, const float* g_velocity_out,
+                                  const float* g_acceleration_out,
+                                  const float* g_state6, const float* g_position_in, long long g_position_in_slice_stride,
+                                  const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T, int N, int t_next,
+                                  float dt, float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream) {
+    if (C < 0 || N < 0 || T < 0 || (g_position_in && (g_position_in_slice_stride & 1)) || (g_position_out_slice_stride & 1))
+        return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    const long n = (long)C * N;
+    hipLaunchKernelGGL(piml::train_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       piml::as_stream(stream), (const float2*)g_position_out, (const float2*)g_velocity_out,
+                       (const float2*)g_acceleration_out, (const float2*)g_state6, new_flag, zero_mask, C, T, N, t_next, dt,
+                       (float2*)g_position, (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred,
+                       (const float2*)g_position_in, g_position_in_slice_stride / 2, g_position_out_slice_stride / 2);
     return hipGetLastError();
 }
 

@@ -109,6 +109,19 @@ class BaseSimulator(Pedestrians):
     def set_ft_model(self, args):
         self.model = self._build(args, True)
 
+    def _const(self, dev, value):
+        """A 0-dim float32 constant on `dev`, made ONCE (outside any capture: _graphed_rollout_step asks for both before it warms
+        up) and never written: the zero every loss sum starts from, the one that seeds the backward pass and stands for the
+        accuracy of the absent collision head -- each `torch.zeros(())` / `zero + 1.0` / autograd's own ones_like was a launch of
+        the captured step (~6 us apiece at the fine-tuning loop's size: a launch-bound graph pays per node, not per byte)."""
+        key = (str(dev), float(value))
+        c = self._consts.get(key) if hasattr(self, '_consts') else None
+        if c is None:
+            if not hasattr(self, '_consts'):
+                self._consts = {}
+            c = self._consts[key] = torch.full((), float(value), device=dev, dtype=torch.float32)
+        return c
+
     def _side_stream_ok(self, rows):
         limit = getattr(self.args, 'mlp_side_stream_rows', self.SIDE_STREAM_MIN_ROWS)
         return limit is not None and rows >= limit
@@ -478,6 +491,13 @@ class BaseSimulator(Pedestrians):
         pro = None
         if self.fused_train_step and data.position.dim() == 4 and data.position.is_cuda and T == data.position.shape[1]:
             pro = ops.rollout_prologue(data, t_start)
+        if pro is not None and state[0].dim() == 4 and not state[0].is_contiguous():
+            # frame t_start of the three feature arrays, contiguous, in ONE launch (C x 3 contiguous chunks: ops.multi_copy) -- the
+            # fused network made each of them contiguous with a strided copy of its own
+            C0 = state[0].shape[0]
+            bufs = [torch.empty(tuple(x.shape), device=x.device, dtype=x.dtype) for x in state]
+            ops.multi_copy([b[c] for b in bufs for c in range(C0)], [x[c] for x in state for c in range(C0)])
+            state = bufs
         if pro is not None:
             mask_pred = pro['mask_pred']
             desired_speed = pro['speed']
@@ -496,7 +516,7 @@ class BaseSimulator(Pedestrians):
         dev = p_cur.device
         p_steps, a_steps, cnt_steps, lab_steps = [], [], [], []
         bm_head = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
-        zero = torch.zeros((), device=dev)          # (one zero for every sum that starts at 0: each torch.zeros is a launch)
+        zero = self._const(dev, 0.0)                # (one persistent zero for every sum that starts at 0: each torch.zeros is a launch)
         pred_collisions = true_collision = zero
         pred_steps, true_steps = [], []             # bm head: per-frame records, stacked and gated once after the loop
         loss = zero
@@ -549,10 +569,13 @@ class BaseSimulator(Pedestrians):
             if fused_step:
                 # :741-769 as one differentiable launch (integrator, waypoint switch, injection, NaN flag) and :772-779 (the
                 # features of the new state incl. the self_features rows) as a second, both inside ONE autograd node
-                p_cur, v_cur, a_cur, dest_cur, dest_idx, *state = ops.rollout_frame(
+                # (the frame's input position comes back as an ALIAS output: the loss reads that, so the tensor has one consumer and
+                # the loss's gradient is added inside the frame's backward launch -- no strided addition of the engine per frame)
+                p_cur, v_cur, a_cur, dest_cur, dest_idx, *state, p_alias = ops.rollout_frame(
                     p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt, new_flag_u8, series, t + 1,
                     nan_flag, obstacles, speed_rows, args.topk_ped, args.sight_angle_ped, args.dist_threshold_ped,
-                    args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs)
+                    args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs, alias_position=True)
+                p_steps[-1] = p_alias
             else:
                 nan_seen = a_next.isnan().any() if nan_seen is None else (nan_seen | a_next.isnan().any())
                 v_next = v_cur + a_cur * dt                                   # :741-743
@@ -596,9 +619,18 @@ class BaseSimulator(Pedestrians):
             label_collisions, label_hard = frames(lab_steps)
             collisions = collisions * (label_collisions.sum(dim=-2, keepdim=True) <= 0)
             hard_collisions = hard_collisions * (label_hard.sum(dim=-2, keepdim=True) <= 0)
-        if fused_step:
-            nan_seen = nan_flag != 0
-        aux = {'nan_seen': nan_seen, 'dest_idx_final': dest_idx.detach().clone(), 't_start': t_start}
+        aux = {'t_start': t_start}
+        if fused_step and pro is not None:
+            # the captured step reads the raw flag (BaseSimulator._pack_log_vec); `!= 0` is a launch, and so is a clone of the last
+            # frame's waypoint indices -- a fresh tensor of the frame step that nothing writes again
+            aux['nan_flag_i32'] = nan_flag
+            nan_seen = nan_flag
+            aux['dest_idx_final'] = dest_idx.detach()
+        else:
+            if fused_step:
+                nan_seen = nan_flag != 0
+            aux['dest_idx_final'] = dest_idx.detach().clone()
+        aux['nan_seen'] = nan_seen
         if not use_frames:
             aux['collisions'], aux['hard_collisions'] = torch.sum(collisions), torch.sum(hard_collisions)
 
@@ -659,7 +691,7 @@ class BaseSimulator(Pedestrians):
         if args.collision_pred_weight > 0 and not bm_head:
             # :826-830 with both tensors still all zeros (only `pinnsf_bm` fills them, :731-733): BCE(0, 0) = 0 and every
             # rounded prediction equals its label -- the values the six launches below would compute
-            collision_pred_acc = zero + 1.0
+            collision_pred_acc = self._const(dev, 1.0)
         elif args.collision_pred_weight > 0:                                  # :826-830
             # (c, t, n, k) records of :731-733: zeros in the frames before t_start, every frame times its gate -- one stack and
             # one product instead of two slice assignments per frame
@@ -708,13 +740,16 @@ class BaseSimulator(Pedestrians):
             saved_s = {id(p): {k: v.clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
                        for p in params}
 
+            one = self._const(static.position.device, 1.0)
+            self._const(static.position.device, 0.0)
+
             def one_step():
                 self.optimizer.zero_grad(set_to_none=True)
                 # the frames' weight gradients summed inside the slot-sum launches (the sink), and those launches riding as the
                 # leading workgroups of each frame's relfeat backward (ops.deferred_slot_sums: one launch less per frame)
                 with self._grad_sink.step(), ops.deferred_slot_sums():
                     out, aux = self._training_rollout(static)
-                    out[0].backward()
+                    out[0].backward(gradient=one)                 # (the persistent one: no ones_like fill in the graph)
                 self.optimizer.step()
                 return out, aux
             # inside the graph the obstacle branch of the MLP runs on a side stream (parallel chains of
@@ -741,10 +776,7 @@ class BaseSimulator(Pedestrians):
                 out, aux = one_step()
                 # every scalar the host reads after the step in ONE vector (one device-to-host read instead of eleven
                 # synchronising ones): the 7 loss terms, the two collision totals, the NaN flag, the predicted-agent count
-                aux['log_vec'] = torch.stack([*[o.detach().float().reshape(()) for o in out], aux['collisions'].float(),
-                                              aux['hard_collisions'].float(),
-                                              aux['nan_seen'].float() if torch.is_tensor(aux['nan_seen']) else out[0].detach().float() * 0,
-                                              aux['n_pred'] if 'n_pred' in aux else (static.mask_p_pred == 1).sum().float()])
+                aux['log_vec'] = self._pack_log_vec(out, aux, static)
             self.model.obs_stream = None
             entry = (graph, static, out, aux)
             self._graphed_steps[key] = entry
@@ -753,6 +785,26 @@ class BaseSimulator(Pedestrians):
         ops.multi_copy([getattr(static, k) for k in self._BATCH_TENSORS], [getattr(batch, k) for k in self._BATCH_TENSORS])
         graph.replay()
         return out, aux
+
+    def _pack_log_vec(self, out, aux, static):
+        """The eleven scalars the host reads after a step -- 7 loss terms, the two collision totals, the NaN flag, the predicted-agent
+        count -- in ONE float32 vector.  On the fused path ONE launch (ops.multi_copy of eleven 4-byte scalars; the NaN flag travels
+        as the raw int32 the frame step keeps on the device -- any set bit reads back as a non-zero float); otherwise torch.stack
+        (a conversion per non-float entry, a concatenation, a copy)."""
+        items = [o.detach() for o in out] + [aux['collisions'], aux['hard_collisions']]
+        nan_raw = aux.get('nan_flag_i32')
+        n_pred = aux.get('n_pred')
+        ok = (nan_raw is not None and n_pred is not None and nan_raw.dtype == torch.int32 and
+              all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in items + [n_pred]))
+        if ok:
+            vec = torch.empty(11, device=items[0].device, dtype=torch.float32)
+            dsts = [vec[i:i + 1] for i in range(9)] + [vec.view(torch.int32)[9:10], vec[10:11]]
+            srcs = [t.reshape(1) for t in items] + [nan_raw.reshape(1), n_pred.detach().reshape(1)]
+            ops.multi_copy(dsts, srcs)
+            return vec
+        return torch.stack([*[o.detach().float().reshape(()) for o in out], aux['collisions'].float(), aux['hard_collisions'].float(),
+                            aux['nan_seen'].float() if torch.is_tensor(aux['nan_seen']) else out[0].detach().float() * 0,
+                            aux['n_pred'] if 'n_pred' in aux else (static.mask_p_pred == 1).sum().float()])
 
     @staticmethod
     def _path_flags():

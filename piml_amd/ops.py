@@ -1675,8 +1675,9 @@ class _RolloutFrame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag,
-                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o):
+                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o, alias_p=False):
         L = _lib.lib()
+        p_arg = p
         p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
                                  (('position', p), ('velocity', v), ('acceleration', a), ('a_pred', a_pred), ('destination', dest))]
         o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
@@ -1712,15 +1713,20 @@ class _RolloutFrame(torch.autograd.Function):
         ctx.new_flag, ctx.zero_mask, ctx.geom, ctx.g6 = new_flag, zero_mask, (C, T, N, int(t_next), float(dt), kpe, koe), g6
         ctx.mark_non_differentiable(outs[3], idx_out)
         ctx.set_materialize_grads(False)
+        if alias_p:
+            # the frame's INPUT position once more, as an output: the rollout loss reads the position of every frame and so does the
+            # next frame's step -- read through this alias, the tensor has ONE consumer and the loss's gradient arrives HERE, where the
+            # step's backward launch adds it (piml_train_step_bwd7), instead of in a strided addition of the autograd engine per frame
+            return (*outs, idx_out, pf, of, sf, p_arg)
         return (*outs, idx_out, pf, of, sf)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gp_o, gv_o, ga_o, _gd, _gi, g_pf, g_of, g_sf):
+    def backward(ctx, gp_o, gv_o, ga_o, _gd, _gi, g_pf, g_of, g_sf, g_alias=None):
         C, T, N, t_next, dt, kpe, koe = ctx.geom
         feats = any(g is not None for g in (g_pf, g_of, g_sf))
         if not feats and all(g is None for g in (gp_o, gv_o, ga_o)):
-            return (None,) * 21
+            return (g_alias if ctx.needs_input_grad[0] else None,) + (None,) * 21
         pi, oi, p_out, dest_out = ctx.saved_tensors
         dev = p_out.device
         opt = dict(device=dev, dtype=torch.float32)
@@ -1743,20 +1749,35 @@ class _RolloutFrame(torch.autograd.Function):
             # an input whose gradient is identically zero gets None (not zeros): autograd then does not walk into the model
             # call that produced a_pred just to propagate nothing (g_p = g_p', g_v = g_v' + dt g_p', g_a = dt g_v', g_a_pred = g_a')
             hp, hv, ha = (gp_o is not None or feats), (gv_o is not None or feats), (ga_o is not None or feats)
-            live = (hp, hp or hv, hv, ha)
+            # the alias gradient as it stands when its (N, 2) slices are contiguous (a time slice of the loss's (C, T, N, 2) gradient)
+            def sliced(g):          # a (C, N, 2) gradient as it stands when its (N, 2) slices are contiguous -> (tensor, slice stride)
+                g_ = g if (g.is_cuda and g.dtype == torch.float32 and g.dim() == 3) else _gpu_f32('grad', g)
+                if not (g_.stride(2) == 1 and g_.stride(1) == 2 and g_.stride(0) % 2 == 0 and g_.data_ptr() % 8 == 0):
+                    g_ = g_.contiguous()
+                return g_, (0 if g_.is_contiguous() else g_.stride(0))
+            gin, gin_stride = None, 0
+            if g_alias is not None and need[0]:
+                gin, gin_stride = sliced(g_alias)
+                if gin_stride == 0:
+                    gin_stride = N * 2
+            live = (hp or gin is not None, hp or hv, hv, ha)
             gs = [torch.empty(C, N, 2, **opt) if (need[k] and live[k]) else None for k in range(4)]
-            cont = [None if g is None else _gpu_f32('grad', g) for g in (gp_o, gv_o, ga_o)]
-            _lib.check(L.piml_train_step_bwd6(
-                *[_ptr(g) for g in cont], _ptr(g6), _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
-                _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd6')
-        return (*gs,) + (None,) * 17
+            gpo, gpo_stride = (None, 0) if gp_o is None else sliced(gp_o)
+            cont = [None if g is None else _gpu_f32('grad', g) for g in (gv_o, ga_o)]
+            _lib.check(L.piml_train_step_bwd7(
+                _ptr(gpo), int(gpo_stride), *[_ptr(g) for g in cont], _ptr(g6), _ptr(gin), int(gin_stride),
+                _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
+                _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd7')
+        return (*gs,) + (None,) * 18
 
 
 def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt, new_flag, series,
                   t_next, nan_flag, obstacles, desired_speed, topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
-                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4):
+                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, alias_position=False):
     """train_rollout_step(..., zero_nan=True) + relative_features_self on its result as one autograd node (_RolloutFrame).
-    Returns (position', velocity', acceleration', destination', dest_idx', ped_features, obs_features, self_features)."""
+    Returns (position', velocity', acceleration', destination', dest_idx', ped_features, obs_features, self_features); with
+    alias_position a ninth element: the INPUT position again, as an output of the node -- a caller whose loss reads the frame's
+    position reads this alias, and the loss's gradient is added inside the node's backward launch (no accumulation per frame)."""
     if position.dim() != 3 or position.shape[-1] != 2 or not position.is_cuda:
         raise ValueError('rollout_frame: (C, N, 2) GPU state expected')
     if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
@@ -1764,8 +1785,9 @@ def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_id
     if DETERMINISTIC_BWD:        # the atomics-free feature backward exists for the plain operator only
         st = train_rollout_step(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt,
                                 new_flag=new_flag, series=series, t_next=t_next, nan_flag=nan_flag, zero_nan=True)
-        return (*st, *relative_features_self(st[0], st[1], st[2], st[3], obstacles, desired_speed, topk_ped, sight_angle_ped,
-                                             dist_threshold_ped, topk_obs, sight_angle_obs, dist_threshold_obs))
+        out = (*st, *relative_features_self(st[0], st[1], st[2], st[3], obstacles, desired_speed, topk_ped, sight_angle_ped,
+                                            dist_threshold_ped, topk_obs, sight_angle_obs, dist_threshold_obs))
+        return out + (position,) if alias_position else out
     C, N = position.shape[0], position.shape[1]
     if dest_idx.dtype != torch.int64 or dest_num.dtype != torch.int64 or tuple(dest_idx.shape) != (C, N) or dest_num.numel() != N:
         raise ValueError('rollout_frame: dest_idx (C, N) int64 and dest_num (N) int64 expected')
@@ -1783,7 +1805,7 @@ def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_id
     return _RolloutFrame.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(), waypoints.contiguous(),
                                dest_num.contiguous(), new_flag, series, int(t_next), float(dt), nan_flag, obstacles, desired_speed,
                                int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
-                               float(dist_threshold_ped), float(dist_threshold_obs))
+                               float(dist_threshold_ped), float(dist_threshold_obs), bool(alias_position))
 
 
 class _CollisionCorrection(torch.autograd.Function):
@@ -2206,9 +2228,18 @@ class ParamGradSink:
             raise RuntimeError('ParamGradSink.step() does not nest')
         self._seen, self._assign, self._mode = set(), {}, {}
         ParamGradSink._active = self
+        # the step's backward passes accumulate the FOLDED layers' gradients (sums path); their unfold is linear and overwrites
+        # its outputs, so one launch at the end of the step stands for one per pass (piml_pinnsf_unfold_defer)
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        if dev is not None:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().piml_pinnsf_unfold_defer(1, None), 'piml_pinnsf_unfold_defer')
         try:
             yield self
         finally:
+            if dev is not None:
+                with torch.cuda.device(dev):
+                    _lib.check(_lib.lib().piml_pinnsf_unfold_defer(0, _stream()), 'piml_pinnsf_unfold_defer')
             ParamGradSink._active = None
             for p, view in self._assign.values():
                 p.grad = view if p.grad is None else p.grad + view
