@@ -114,7 +114,7 @@ class BaseSimulator(Pedestrians):
         up) and never written: the zero every loss sum starts from, the one that seeds the backward pass and stands for the
         accuracy of the absent collision head -- each `torch.zeros(())` / `zero + 1.0` / autograd's own ones_like was a launch of
         the captured step (~6 us apiece at the fine-tuning loop's size: a launch-bound graph pays per node, not per byte)."""
-        key = (str(dev), float(value))
+        key = (str(dev), repr(float(value)))
         c = self._consts.get(key) if hasattr(self, '_consts') else None
         if c is None:
             if not hasattr(self, '_consts'):
@@ -852,11 +852,14 @@ class BaseSimulator(Pedestrians):
             drop_state = ops.dropout_state(static[0].device)
             drop_calls = drop_state[1].clone()
 
+            dev0 = static[0].device
+            one, nan_c = self._const(dev0, 1.0), self._const(dev0, float('nan'))      # made outside the capture, never written
+
             def one_step():
                 self.optimizer.zero_grad(set_to_none=True)
                 with self._packed_weights():
                     terms = self._pointwise_terms(static)
-                    terms[0].backward()
+                    terms[0].backward(gradient=one)               # (no ones_like fill in the graph)
                 self.optimizer.step()
                 return terms
             side = torch.cuda.Stream()
@@ -878,8 +881,7 @@ class BaseSimulator(Pedestrians):
             with torch.cuda.graph(graph):
                 terms = one_step()
                 # the scalars the host logs, in one vector: one synchronising read per step (absent terms: NaN placeholders)
-                log_vec = torch.stack([(t.detach().float().reshape(()) if t is not None else terms[0].detach().float() * float('nan'))
-                                       for t in terms])
+                log_vec = torch.stack([(t.detach().float().reshape(()) if t is not None else nan_c) for t in terms])
             entry = (graph, static, terms, log_vec)
             self._graphed_steps[key] = entry
         graph, static, terms, log_vec = entry
