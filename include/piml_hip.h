@@ -424,6 +424,18 @@ int piml_train_step_fwd(const float* position, const float* velocity, const floa
                         float* position_out, float* velocity_out, float* acceleration_out,
                         float* destination_out, int64_t* dest_idx_out, int* nan_flag, uint8_t* zero_mask,
                         void* stream);
+/* piml_train_step_fwd that also leaves the frame's INPUT position in a caller's buffer (position_copy: C slices of (N, 2)
+ * floats, position_copy_slice_stride floats apart -- frame t of the (C, T, N, 2) array of predicted positions the rollout loss
+ * reads, src/models/simulators.py:728, :790): the frames write that array themselves instead of a concatenation behind the loop.
+ * position_copy may be NULL (= piml_train_step_fwd). */
+int piml_train_step_fwd_copy(const float* position, const float* velocity, const float* acceleration, const float* a_pred,
+                             const float* destination, const int64_t* dest_idx, const float* waypoints, int D,
+                             int waypoints_per_slice, const int64_t* dest_num, const uint8_t* new_flag,
+                             const float* position_series, const float* velocity_series, const float* acceleration_series,
+                             const float* destination_series, const int64_t* dest_idx_series, int C, int T, int N, int t_next,
+                             float dt, float* position_out, float* velocity_out, float* acceleration_out, float* destination_out,
+                             int64_t* dest_idx_out, int* nan_flag, uint8_t* zero_mask, float* position_copy,
+                             long long position_copy_slice_stride, void* stream);
 int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out, const float* g_acceleration_out,
                         const uint8_t* new_flag, const uint8_t* zero_mask, int C, int T, int N, int t_next, float dt,
                         float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);

@@ -86,6 +86,7 @@ SIGNATURES = {
     'piml_collision_correction_fwd': [_p, _p, _p, _z, _i, _i, _f, _f, _p, _p],
     'piml_collision_correction_bwd': [_p, _p, _p, _p, _z, _i, _i, _f, _f, _p, _p, _p, _p],
     'piml_train_step_fwd': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p],
+    'piml_train_step_fwd_copy': [_p] * 7 + [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _p],
     'piml_train_step_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_train_step_bwd6': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_unfold_defer': [_i, _p],

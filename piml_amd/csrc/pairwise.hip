@@ -1719,6 +1719,7 @@ struct TrainStepArgs {
     const float2 *pos_s, *vel_s, *acc_s, *dest_s; const long long* dest_idx_s;
     float2 *p_out, *v_out, *a_out, *dest_out; long long* dest_idx_out; int* nan_flag; unsigned char* zero_mask;
     int C, T, N, t_next; float dt;
+    float2* p_copy; long long p_copy_cstride;            // optional: the INPUT position once more, slices p_copy_cstride float2 apart
 };
 
 // One thread per (slice, agent): lagged explicit Euler, waypoint switch at 0.5 m (nobody is removed
@@ -1728,6 +1729,7 @@ __global__ void train_step_fwd_kernel(const TrainStepArgs A) {
     if (g >= (long long)A.C * A.N) return;
     const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
     const float2 p = A.p[g], v = A.v[g], a = A.a[g], d = A.dest[g];
+    if (A.p_copy) A.p_copy[(size_t)c * A.p_copy_cstride + i] = p;      // frame t of the (C, T, N, 2) positions the rollout loss reads
     float2 an = A.a_pred[g];
     if (A.nan_flag && (an.x != an.x || an.y != an.y)) atomicOr(A.nan_flag, 1);           // :745
     float2 vn = make_float2(__fadd_rn(v.x, __fmul_rn(a.x, A.dt)), __fadd_rn(v.y, __fmul_rn(a.y, A.dt)));   // :741
@@ -2017,6 +2019,16 @@ PIML_API int piml_rollout_step_ksum(const float* pred_ped, int kp, const float* 
     return hipGetLastError();
 }
 
+static int train_step_fwd_impl(const float* position, const float* velocity, const float* acceleration,
+                               const float* a_pred, const float* destination, const int64_t* dest_idx,
+                               const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                               const uint8_t* new_flag, const float* position_series,
+                               const float* velocity_series, const float* acceleration_series,
+                               const float* destination_series, const int64_t* dest_idx_series, int C, int T,
+                               int N, int t_next, float dt, float* position_out, float* velocity_out,
+                               float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
+                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream);
+
 PIML_API int piml_train_step_fwd(const float* position, const float* velocity, const float* acceleration,
                                  const float* a_pred, const float* destination, const int64_t* dest_idx,
                                  const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
@@ -2026,6 +2038,38 @@ PIML_API int piml_train_step_fwd(const float* position, const float* velocity, c
                                  int N, int t_next, float dt, float* position_out, float* velocity_out,
                                  float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
                                  int* nan_flag, uint8_t* zero_mask, void* stream) {
+    return train_step_fwd_impl(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, D, waypoints_per_slice, dest_num,
+                               new_flag, position_series, velocity_series, acceleration_series, destination_series, dest_idx_series, C, T, N,
+                               t_next, dt, position_out, velocity_out, acceleration_out, destination_out, dest_idx_out, nan_flag, zero_mask,
+                               nullptr, 0, stream);
+}
+
+PIML_API int piml_train_step_fwd_copy(const float* position, const float* velocity, const float* acceleration,
+                                      const float* a_pred, const float* destination, const int64_t* dest_idx,
+                                      const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                                      const uint8_t* new_flag, const float* position_series,
+                                      const float* velocity_series, const float* acceleration_series,
+                                      const float* destination_series, const int64_t* dest_idx_series, int C, int T,
+                                      int N, int t_next, float dt, float* position_out, float* velocity_out,
+                                      float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
+                                      int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride,
+                                      void* stream) {
+    if (position_copy && (position_copy_slice_stride & 1)) return hipErrorInvalidValue;
+    return train_step_fwd_impl(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, D, waypoints_per_slice, dest_num,
+                               new_flag, position_series, velocity_series, acceleration_series, destination_series, dest_idx_series, C, T, N,
+                               t_next, dt, position_out, velocity_out, acceleration_out, destination_out, dest_idx_out, nan_flag, zero_mask,
+                               position_copy, position_copy_slice_stride, stream);
+}
+
+static int train_step_fwd_impl(const float* position, const float* velocity, const float* acceleration,
+                               const float* a_pred, const float* destination, const int64_t* dest_idx,
+                               const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                               const uint8_t* new_flag, const float* position_series,
+                               const float* velocity_series, const float* acceleration_series,
+                               const float* destination_series, const int64_t* dest_idx_series, int C, int T,
+                               int N, int t_next, float dt, float* position_out, float* velocity_out,
+                               float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
+                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream) {
     if (C < 0 || T <= 0 || N < 0 || D <= 0 || t_next < 0) return hipErrorInvalidValue;
     if ((long)C * N == 0) return hipSuccess;
     if (!position || !velocity || !acceleration || !a_pred || !destination || !dest_idx || !waypoints || !dest_num ||
@@ -2046,6 +2090,7 @@ PIML_API int piml_train_step_fwd(const float* position, const float* velocity, c
     A.dest_out = (float2*)destination_out; A.dest_idx_out = (long long*)dest_idx_out; A.nan_flag = nan_flag;
     A.zero_mask = zero_mask;
     A.C = C; A.T = T; A.N = N; A.t_next = t_next; A.dt = dt;
+    A.p_copy = (float2*)position_copy; A.p_copy_cstride = position_copy_slice_stride / 2;
     const long n = (long)C * N;
     hipLaunchKernelGGL(piml::train_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        piml::as_stream(stream), A);

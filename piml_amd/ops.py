@@ -1675,7 +1675,7 @@ class _RolloutFrame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag,
-                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o, alias_p=False):
+                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o, alias_p=False, stack=None):
         L = _lib.lib()
         p_arg = p
         p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
@@ -1700,11 +1700,15 @@ class _RolloutFrame(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:4])
         g6 = torch.empty(C, N, 6, **opt) if need else None
         with torch.cuda.device(dev):
-            _lib.check(L.piml_train_step_fwd(
+            copy_ptr, copy_stride = None, 0
+            if stack is not None:         # (buffer (C, T', N, 2) float32 contiguous, frame index): the input position into its frame
+                sbuf, st_ = stack
+                copy_ptr, copy_stride = sbuf.data_ptr() + int(st_) * N * 2 * 4, sbuf.shape[1] * N * 2
+            _lib.check(L.piml_train_step_fwd_copy(
                 _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
                 _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
                 float(dt), *[_ptr(x) for x in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
-                _ptr(zero_mask), _stream()), 'piml_train_step_fwd')
+                _ptr(zero_mask), copy_ptr, int(copy_stride), _stream()), 'piml_train_step_fwd_copy')
             _lib.check(L.piml_relfeat_fwd_self(
                 _ptr(outs[0]), None, _ptr(outs[1]), _ptr(outs[2]), 2, _ptr(outs[3]), _ptr(o), _ptr(v0), C, N, M, 0, N, kp, ko,
                 cos_p, cos_o, dthr_p, dthr_o, _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), _ptr(g6), _stream()),
@@ -1726,7 +1730,7 @@ class _RolloutFrame(torch.autograd.Function):
         C, T, N, t_next, dt, kpe, koe = ctx.geom
         feats = any(g is not None for g in (g_pf, g_of, g_sf))
         if not feats and all(g is None for g in (gp_o, gv_o, ga_o)):
-            return (g_alias if ctx.needs_input_grad[0] else None,) + (None,) * 21
+            return (g_alias if ctx.needs_input_grad[0] else None,) + (None,) * 22
         pi, oi, p_out, dest_out = ctx.saved_tensors
         dev = p_out.device
         opt = dict(device=dev, dtype=torch.float32)
@@ -1768,16 +1772,18 @@ class _RolloutFrame(torch.autograd.Function):
                 _ptr(gpo), int(gpo_stride), *[_ptr(g) for g in cont], _ptr(g6), _ptr(gin), int(gin_stride),
                 _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
                 _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd7')
-        return (*gs,) + (None,) * 18
+        return (*gs,) + (None,) * 19
 
 
 def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt, new_flag, series,
                   t_next, nan_flag, obstacles, desired_speed, topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
-                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, alias_position=False):
+                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, alias_position=False, stack=None):
     """train_rollout_step(..., zero_nan=True) + relative_features_self on its result as one autograd node (_RolloutFrame).
     Returns (position', velocity', acceleration', destination', dest_idx', ped_features, obs_features, self_features); with
     alias_position a ninth element: the INPUT position again, as an output of the node -- a caller whose loss reads the frame's
-    position reads this alias, and the loss's gradient is added inside the node's backward launch (no accumulation per frame)."""
+    position reads this alias, and the loss's gradient is added inside the node's backward launch (no accumulation per frame).
+    stack = (buffer (C, T, N, 2) float32 contiguous, t): the step's launch also writes the input position into frame t of the buffer
+    (ops.stack_of makes the filled buffer a differentiable function of the aliases: no concatenation behind the loop)."""
     if position.dim() != 3 or position.shape[-1] != 2 or not position.is_cuda:
         raise ValueError('rollout_frame: (C, N, 2) GPU state expected')
     if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
@@ -1805,7 +1811,30 @@ def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_id
     return _RolloutFrame.apply(position, velocity, acceleration, a_pred, destination, dest_idx.contiguous(), waypoints.contiguous(),
                                dest_num.contiguous(), new_flag, series, int(t_next), float(dt), nan_flag, obstacles, desired_speed,
                                int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
-                               float(dist_threshold_ped), float(dist_threshold_obs), bool(alias_position))
+                               float(dist_threshold_ped), float(dist_threshold_obs), bool(alias_position),
+                               None if (stack is None or DETERMINISTIC_BWD) else stack)
+
+
+class _StackOf(torch.autograd.Function):
+    """buffer (C, T, N, 2) whose frames t0 .. t0 + len(frames) - 1 the frame steps have ALREADY filled with `frames` (rollout_frame's
+    stack=): the buffer as a differentiable function of those frames -- forward launches nothing, backward hands every frame its
+    time slice of the gradient as it stands (the frame's backward launch takes it strided)."""
+
+    @staticmethod
+    def forward(ctx, buf, t0, *frames):
+        ctx.t0, ctx.n = int(t0), len(frames)
+        ctx.set_materialize_grads(False)
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None, None) + (None,) * ctx.n
+        return (None, None) + tuple(g[:, ctx.t0 + i] if ctx.needs_input_grad[2 + i] else None for i in range(ctx.n))
+
+
+def stack_of(buf, t0, frames):
+    return _StackOf.apply(buf, int(t0), *frames)
 
 
 class _CollisionCorrection(torch.autograd.Function):

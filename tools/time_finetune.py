@@ -1,5 +1,6 @@
-"""Graph-replayed fine-tuning step (HOT LOOP C) on the golden GC batch: time per step; run under
-rocprofv3 --kernel-trace --stats for the kernel mix (development aid)."""
+"""Graph-replayed fine-tuning step (HOT LOOP C) on the golden GC batch: time per step, as train_batch() in a loop (every step's
+scalars read before the next is queued) and as the training loop runs it (train_batch_async: step i + 1 queued before step i is
+read); run under rocprofv3 --kernel-trace --stats for the kernel mix (development aid)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -17,3 +18,13 @@ for _ in range(n):
     sim.train_batch(data)
 torch.cuda.synchronize()
 print(f'fine-tune step (graph): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
+torch.cuda.synchronize(); t0 = time.perf_counter()
+waiting = None
+for _ in range(n):
+    nxt = sim.train_batch_async(data)
+    if waiting is not None:
+        waiting()
+    waiting = nxt
+waiting()
+torch.cuda.synchronize()
+print(f'fine-tune step (graph, one step of lookahead as in train()): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
