@@ -63,6 +63,10 @@ long long piml_encoder_split_tiles_train(long long tiles);
  * rounding of the product); 0: the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32).  Environment at load time:
  * PIML_ENC_PRODUCTS=f32.  Returns the previous value; < 0 only queries. */
 int piml_encoder_products(int split_bf16);
+/* The same choice for the many-rows kernels of the row decoder (the bottleneck variants' decoder + predictor per neighbour row,
+ * src/models/model.py:1116-1122, 1182-1190): 1 (default) = split bf16 products, the weights split while the workgroup stages them;
+ * 0 = the f32 matrix-core instruction.  Environment at load time: PIML_ROWDEC_PRODUCTS=f32.  Returns the previous value; < 0 queries. */
+int piml_rowdecoder_products(int split_bf16);
 /* Weight gradients of the split-product backward above piml_encoder_split_tiles() tiles: 1 (default) = layer-split
  * workgroups (piml_amd/csrc/encoder_dw2.hip: a workgroup takes ONE of the two 128 x 128 products over a longer slab --
  * half the partial bytes -- and recomputes h1 from x when the branches carry none), 0 = one slab and both products per

@@ -136,6 +136,7 @@ SIGNATURES = {
     'piml_p2p_copy': [_p, _p, _z, _p],
     'piml_allgather_state_p2p': [_p, _z, _i, _i, ctypes.POINTER(_p), ctypes.POINTER(_p), ctypes.c_uint, ctypes.c_uint, _p, _p],
     'piml_encoder_products': [_i],
+    'piml_rowdecoder_products': [_i],
     'piml_encoder_dw2': [_i],
     'piml_encoder_fused_bwd': [_i],
     'piml_encoder_sums_bwd': [_i],

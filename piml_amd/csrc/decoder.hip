@@ -996,6 +996,321 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dx_big_kernel(DecArgs A, int w
     }
 }
 
+// ---- the same two kernels on SPLIT bf16 products (round 6; x3.hpp / encoder_x3.hip: every f32 operand as three bf16 pieces, a
+// k-block of 16 as six v_mfma_f32_32x32x16_bf16 = 192 cycles against 8 x 64 of the f32 instruction).  No new packed image: a split
+// fragment (fb = (output block, k-block kb), lane (i, h), element t = W[32 ob + i][16 kb + 8 (t >> 2) + 4 h + (t & 3)]) is the two
+// float4 (q = 2 (kb & 1), 2 (kb & 1) + 1; bp = kb >> 1) of the SAME lane of the f32 fragment image, so the workgroup splits the
+// weights while it stages them (three items per thread, once per launch).  The 64 -> 2 predictor is 64 FMAs per lane and one
+// cross-half add instead of 32 padded matrix instructions; W3^T (k = 2) stays on the f32 instruction (two per tile).
+// LDS (u32x4): [fb][piece 3][lane 64]. ----
+// dX kernel: 1 = the first tile's row loads between the staging's loads and its split, 0 (default, measured 0.5 us ahead) = behind
+// the staging's LDS stores
+#ifndef PIML_ROWDEC_HOIST
+#define PIML_ROWDEC_HOIST 0
+#endif
+struct RowPieces { u32x4 hi[8], mid[8], lo[8]; };
+template <int NB>          // NB accumulator blocks -> 2 NB k-blocks
+__device__ __forceinline__ void rowdec_split(const f32x16 (&in)[NB], RowPieces& P) {
+#pragma unroll
+    for (int kb = 0; kb < 2 * NB; ++kb) {
+        const f32x16& a = in[kb >> 1];
+        const int r = 8 * (kb & 1);
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split3(a[r + 2 * d], a[r + 2 * d + 1], hi[d], mid[d], lo[d]);
+        P.hi[kb] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        P.mid[kb] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+        P.lo[kb] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+// the f32 fragment image `src` ([ob][bp NBP][q 4][lane 64] float4) of NOB x NBP blocks -> split fragments [fb = ob * 2 NBP + kb][3][64];
+// in two halves: the loads (issued in FRONT of the first tile's row loads: the memory counter retires in order, and the weights
+// come from L2) and the split + LDS stores (behind them, while the rows are on their way)
+template <int NOB, int NBP>
+struct RowdecStage {
+    static constexpr int ITEMS = NOB * 2 * NBP * 64, ROUNDS = (ITEMS + 511) / 512;
+    float4 a[ROUNDS], b[ROUNDS];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int e = (r * 512 + tid) < ITEMS ? r * 512 + tid : 0;
+            const int lane = e & 63, fb = e >> 6, kb = fb % (2 * NBP), ob = fb / (2 * NBP);
+            a[r] = s4[((ob * NBP + (kb >> 1)) * 4 + 2 * (kb & 1)) * 64 + lane];
+            b[r] = s4[((ob * NBP + (kb >> 1)) * 4 + 2 * (kb & 1) + 1) * 64 + lane];
+        }
+    }
+    __device__ __forceinline__ void land(u32x4* dst, int tid) const {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int e = r * 512 + tid;
+            if (ITEMS % 512 == 0 || e < ITEMS) {
+                const int lane = e & 63, fb = e >> 6;
+                unsigned hi[4], mid[4], lo[4];
+                split3(a[r].x, a[r].y, hi[0], mid[0], lo[0]);
+                split3(a[r].z, a[r].w, hi[1], mid[1], lo[1]);
+                split3(b[r].x, b[r].y, hi[2], mid[2], lo[2]);
+                split3(b[r].z, b[r].w, hi[3], mid[3], lo[3]);
+                dst[(fb * 3 + 0) * 64 + lane] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+                dst[(fb * 3 + 1) * 64 + lane] = (u32x4){mid[0], mid[1], mid[2], mid[3]};
+                dst[(fb * 3 + 2) * 64 + lane] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    }
+};
+
+constexpr int RFX_W1 = 0, RFX_W2 = RFX_W1 + 16 * 3 * 64, RFX_F32 = RFX_W2 + 8 * 3 * 64;      // u32x4 units; then floats: bias 132 | W3 rows 128
+constexpr int RFX_LDS_BYTES = RFX_F32 * 16 + (132 + 128) * 4;
+
+__global__ __launch_bounds__(512) void rowdec_fwd_x3_kernel(DecArgs A, int wg_split) {
+    extern __shared__ __align__(16) unsigned char rx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= wg_split) ? 1 : 0;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - wg_split : (A.nbr > 1 ? wg_split : (int)gridDim.x);
+    const long long R = J.agents, ntiles = (R + 31) >> 5;
+    if ((long long)((int)blockIdx.x - wg0) * 8 >= ntiles) return;
+    u32x4* img = reinterpret_cast<u32x4*>(rx_smem);
+    float* fl = reinterpret_cast<float*>(rx_smem + RFX_F32 * 16);
+    const int j = lane & 31, h = lane >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * 8 + wave, stride = (long long)nwg * 8;
+    {
+        RowdecStage<2, 4> S1;
+        RowdecStage<2, 2> S2;
+        S1.load(J.packed + DP_A1, tid);
+        S2.load(J.packed + DP_A2, tid);
+        const float fv = tid < 132 ? J.packed[DP_B + tid] : ((tid >= 256 && tid < 384) ? J.w3[tid - 256] : 0.f);
+        S1.land(img + RFX_W1, tid);
+        S2.land(img + RFX_W2, tid);
+        if (tid < 132) fl[tid] = fv;
+        else if (tid >= 256 && tid < 384) fl[132 + tid - 256] = fv;
+    }
+    __syncthreads();
+    const float* bias = fl;
+    const float* w3r = fl + 132;
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));                      // (opaque per tile: keeps the fragment reads of a tile inside the loop)
+        const u32x4* W1 = img + RFX_W1 + lane_t;
+        const u32x4* W2 = img + RFX_W2 + lane_t;
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        RowPieces P;
+        {
+            // (the rows are requested HERE: in front of the weight staging, or a tile ahead, measured 2 us slower at the reference's
+            // row counts, where a wave has one tile -- 214 registers instead of 162 and every wave's loads in one burst)
+            f32x16 X[4];
+            const float* base = J.msgs + (valid ? row : 0) * DH;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + dfeat0(blk, q, h));
+                    X[blk][4 * q] = valid ? v.x : 0.f; X[blk][4 * q + 1] = valid ? v.y : 0.f;
+                    X[blk][4 * q + 2] = valid ? v.z : 0.f; X[blk][4 * q + 3] = valid ? v.w : 0.f;
+                }
+            rowdec_split<4>(X, P);
+        }
+        f32x16 a1[2], a2[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + dfeat0(ob, q, h));
+                acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const int fb = ob * 8 + kb;
+                kblock_x3(acc, sm, W1[(fb * 3) * 64], W1[(fb * 3 + 1) * 64], W1[(fb * 3 + 2) * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[ob][r] = relu1(acc[r] + sm[r]);
+        }
+        if (valid) {
+            float* o = J.h1 + row * DD;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(a1[ob][4 * q], a1[ob][4 * q + 1], a1[ob][4 * q + 2], a1[ob][4 * q + 3]);
+        }
+        rowdec_split<2>(a1, P);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + 64 + dfeat0(ob, q, h));
+                acc[4 * q] = bq.x; acc[4 * q + 1] = bq.y; acc[4 * q + 2] = bq.z; acc[4 * q + 3] = bq.w;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int fb = ob * 4 + kb;
+                kblock_x3(acc, sm, W2[(fb * 3) * 64], W2[(fb * 3 + 1) * 64], W2[(fb * 3 + 2) * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[ob][r] = acc[r] + sm[r];
+        }
+        if (valid) {
+            float* o = J.d2 + row * DD;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(a2[ob][4 * q], a2[ob][4 * q + 1], a2[ob][4 * q + 2], a2[ob][4 * q + 3]);
+        }
+        // the predictor: this lane's 32 features of the row, then the other lane half's
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wa = *reinterpret_cast<const float4*>(w3r + dfeat0(ob, q, h));
+                const float4 wb = *reinterpret_cast<const float4*>(w3r + 64 + dfeat0(ob, q, h));
+                p0 = __fmaf_rn(a2[ob][4 * q], wa.x, p0); p0 = __fmaf_rn(a2[ob][4 * q + 1], wa.y, p0);
+                p0 = __fmaf_rn(a2[ob][4 * q + 2], wa.z, p0); p0 = __fmaf_rn(a2[ob][4 * q + 3], wa.w, p0);
+                p1 = __fmaf_rn(a2[ob][4 * q], wb.x, p1); p1 = __fmaf_rn(a2[ob][4 * q + 1], wb.y, p1);
+                p1 = __fmaf_rn(a2[ob][4 * q + 2], wb.z, p1); p1 = __fmaf_rn(a2[ob][4 * q + 3], wb.w, p1);
+            }
+        p0 += __shfl_xor(p0, 32, 64);
+        p1 += __shfl_xor(p1, 32, 64);
+        if (h == 0 && valid) reinterpret_cast<float2*>(J.pred)[row] = make_float2(p0 + bias[128], p1 + bias[129]);
+    }
+}
+
+constexpr int RDXX_T2 = 0, RDXX_T1 = RDXX_T2 + 8 * 3 * 64, RDXX_F32 = RDXX_T1 + 16 * 3 * 64;      // u32x4 units; then W3^T 128 floats
+constexpr int RDXX_LDS_BYTES = RDXX_F32 * 16 + 128 * 4;
+
+__global__ __launch_bounds__(512) void rowdec_bwd_dx_x3_kernel(DecArgs A, int wg_split) {
+    extern __shared__ __align__(16) unsigned char rx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+    const int b = (A.nbr > 1 && (int)blockIdx.x >= wg_split) ? 1 : 0;
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const int wg0 = b ? wg_split : 0;
+    const int nwg = b ? (int)gridDim.x - wg_split : (A.nbr > 1 ? wg_split : (int)gridDim.x);
+    const long long R = J.agents, ntiles = (R + 31) >> 5;
+    if ((long long)((int)blockIdx.x - wg0) * 8 >= ntiles) return;
+    u32x4* img = reinterpret_cast<u32x4*>(rx_smem);
+    float* T3 = reinterpret_cast<float*>(rx_smem + RDXX_F32 * 16);
+    const int j = lane & 31, h = lane >> 5;
+    const long long first = (long long)((int)blockIdx.x - wg0) * 8 + wave, stride = (long long)nwg * 8;
+    // the tile's rows: requested in front of the weight staging (a further tile's: behind the first products of this one)
+    float2 gpv;
+    float4 hvv[2][4], gdv[2][4];
+    auto load_rows = [&](long long tile_) {
+        const long long row_ = tile_ * 32 + j, rr_ = row_ < R ? row_ : 0;
+        gpv = reinterpret_cast<const float2*>(J.g_pred_rows)[rr_];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hvv[ob][q] = *reinterpret_cast<const float4*>(J.h1 + rr_ * DD + dfeat0(ob, q, h));
+                gdv[ob][q] = J.g_d2 ? *reinterpret_cast<const float4*>(J.g_d2 + rr_ * DD + dfeat0(ob, q, h)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    {
+        RowdecStage<2, 2> S2;
+        RowdecStage<4, 2> S1;
+        S2.load(J.packed + DP_T2, tid);
+        S1.load(J.packed + DP_T1, tid);
+        const float fv = tid < 128 ? J.packed[DP_T3 + tid] : 0.f;
+        if (PIML_ROWDEC_HOIST && first < ntiles) load_rows(first);
+        S2.land(img + RDXX_T2, tid);
+        S1.land(img + RDXX_T1, tid);
+        if (tid < 128) T3[tid] = fv;
+    }
+    if (!PIML_ROWDEC_HOIST && first < ntiles) load_rows(first);
+    __syncthreads();
+    for (long long tile = first; tile < ntiles; tile += stride) {
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const u32x4* T2 = img + RDXX_T2 + lane_t;
+        const u32x4* T1 = img + RDXX_T1 + lane_t;
+        const long long row = tile * 32 + j;
+        const bool valid = row < R;
+        float2 gp = gpv;
+        if (!valid) gp = make_float2(0.f, 0.f);
+        const float bg = h ? gp.y : gp.x;
+        float4 hv[2][4], gd[2][4];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { hv[ob][q] = hvv[ob][q]; gd[ob][q] = gdv[ob][q]; }
+        f32x16 g2[2], g1[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g2[ob][r] = 0.f;
+            g2[ob] = dmfma(T3[64 * ob + lane_t], bg, g2[ob]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                g2[ob][4 * q] += valid ? gd[ob][q].x : 0.f; g2[ob][4 * q + 1] += valid ? gd[ob][q].y : 0.f;
+                g2[ob][4 * q + 2] += valid ? gd[ob][q].z : 0.f; g2[ob][4 * q + 3] += valid ? gd[ob][q].w : 0.f;
+            }
+            if (valid) {
+                float* o = J.g_pre2 + row * DD;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(g2[ob][4 * q], g2[ob][4 * q + 1], g2[ob][4 * q + 2], g2[ob][4 * q + 3]);
+            }
+        }
+        RowPieces P;
+        rowdec_split<2>(g2, P);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; sm[r] = 0.f; }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int fb = ob * 4 + kb;
+                kblock_x3(acc, sm, T2[(fb * 3) * 64], T2[(fb * 3 + 1) * 64], T2[(fb * 3 + 2) * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = hv[ob][q];
+                g1[ob][4 * q + 0] = (valid && a.x > 0.f) ? acc[4 * q + 0] + sm[4 * q + 0] : 0.f;
+                g1[ob][4 * q + 1] = (valid && a.y > 0.f) ? acc[4 * q + 1] + sm[4 * q + 1] : 0.f;
+                g1[ob][4 * q + 2] = (valid && a.z > 0.f) ? acc[4 * q + 2] + sm[4 * q + 2] : 0.f;
+                g1[ob][4 * q + 3] = (valid && a.w > 0.f) ? acc[4 * q + 3] + sm[4 * q + 3] : 0.f;
+            }
+            if (valid) {
+                float* o = J.g_pre1 + row * DD;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(ob, q, h)) = make_float4(g1[ob][4 * q], g1[ob][4 * q + 1], g1[ob][4 * q + 2], g1[ob][4 * q + 3]);
+            }
+        }
+        rowdec_split<2>(g1, P);
+        if (tile + stride < ntiles) load_rows(tile + stride);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x16 acc, sm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; sm[r] = 0.f; }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int fb = blk * 4 + kb;
+                kblock_x3(acc, sm, T1[(fb * 3) * 64], T1[(fb * 3 + 1) * 64], T1[(fb * 3 + 2) * 64], P.hi[kb], P.mid[kb], P.lo[kb]);
+            }
+            if (valid) {
+                float* o = J.g_pooled + row * DH;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(o + dfeat0(blk, q, h)) =
+                        make_float4(acc[4 * q] + sm[4 * q], acc[4 * q + 1] + sm[4 * q + 1], acc[4 * q + 2] + sm[4 * q + 2], acc[4 * q + 3] + sm[4 * q + 3]);
+            }
+        }
+    }
+}
+
 // The row-wise weight gradients with LDS staging (the encoder dW kernel's structure): a slab holds hundreds of rows, and
 // the agent-level body above would fetch every chunk with 96 dword loads per lane, several waves fetching the same
 // columns, and wait for each chunk in turn.  Here the workgroup stages 32-row chunks of the five operand arrays with
@@ -1120,6 +1435,185 @@ __global__ __launch_bounds__(512) void rowdec_bwd_dw_lds_kernel(DecArgs A, int s
         if (nb1 == 0) Pb[32 * mb1 + i] = s1;                       // waves 0 and 4
         if (do2 && nb2 == 0) Pb[DD + 32 * mb2 + i] = sx;           // waves 0 and 2
         if (w == 4 && i < 8) Pb[2 * DD + i] = i < 2 ? sx : 0.f;    // db3 + padding
+    }
+}
+
+// ---- the row-wise weight gradients on split bf16 products (round 6).  All three products contract over the ROWS, so both operands
+// of each are activations: a 32-row chunk of the five arrays is split into bf16 pieces while it is staged and laid into three
+// [piece 3][row 32][feature 128] images (8-byte chunks XOR-swizzled by the row, the layout of encoder_bwd3.hip's phase 2):
+//     E = the embeddings (128)      G = g_pre1 | g_pre2 (64 | 64)      H = h1 | d2 (64 | 64)
+// ds_read_b64_tr_b16 hands a lane its FEATURE's rows: fragments with the feature on the lane and the rows as the k index, for the A
+// operand (g_pre1 / g_pre2 blocks) and the B operand (embedding / h1 / d2 blocks) alike.  Wave w owns block (w >> 2, w & 3) of dW1
+// (64 x 128); waves 0 - 3 also block ((w >> 1) & 1, w & 1) of dW2 (64 x 64); waves 4, 5 the predictor's dW (2 x 64: the A fragment
+// is g_pred's two columns, built from the chunk's f32 copy, 30 zero rows).  A chunk is 12 (+ 12) products per wave instead of 16
+// (+ 16) f32 instructions of twice the cycles each.  The column sums (db1, db2, db3) are taken by the staging threads from the f32
+// values on their way into the images: per thread over its chunks, then over the 32 staging rows in a fixed order.  Two image sets:
+// one barrier per chunk. ----
+constexpr int RWX_IMG = 3 * 32 * 256;                          // bytes of one image
+constexpr int RWX_E = 0, RWX_G = RWX_IMG, RWX_H = 2 * RWX_IMG, RWX_GP = 3 * RWX_IMG, RWX_BUF = RWX_GP + 256;      // GP: [row 32][2] floats
+constexpr int RWX_LDS_BYTES = 2 * RWX_BUF;
+static_assert(RWX_LDS_BYTES <= 160 * 1024 && 32 * 132 * 4 <= RWX_LDS_BYTES, "fits the CU; the column sums' exchange fits the buffers");
+
+__global__ __launch_bounds__(512) void rowdec_bwd_dw_x3_kernel(DecArgs A, int slots0, long long slab0, long long slab1) {
+    extern __shared__ __align__(16) unsigned char rx_smem[];
+    typedef short rw_s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) rw_s16x4 rw_lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63, w = uniform((int)(tid >> 6));
+    const int b = (int)blockIdx.x >= slots0 ? 1 : 0;
+    const int p = (int)blockIdx.x - (b ? slots0 : 0);
+    const piml_decoder_branch J = b ? A.br[1] : A.br[0];
+    const long long R = J.agents, slab = b ? slab1 : slab0;
+    const long long s0 = (long long)p * slab < R ? (long long)p * slab : R;
+    const long long s1e = s0 + slab < R ? s0 + slab : R;
+    const int i = lane & 31, h = lane >> 5;
+    const int mb1 = w >> 2, nb1 = w & 3, mb2 = (w >> 1) & 1, nb2 = w & 1;
+    const bool do2 = w < 4, do3 = w == 4 || w == 5;
+    f32x16 c1, s1, cx, sx;          // main and small-term accumulators (x3.hpp) of the wave's two products
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c1[r] = 0.f; s1[r] = 0.f; cx[r] = 0.f; sx[r] = 0.f; }
+    // staging role: row srow of the chunk, float4 column sc4 of the 64-wide arrays (and sc4, sc4 + 64 of the embeddings)
+    const int srow = tid >> 4, c16 = tid & 15, sc4 = c16 * 4;
+    float4 sum1 = make_float4(0.f, 0.f, 0.f, 0.f), sum2 = sum1;      // column sums of g_pre1 / g_pre2 over this thread's rows
+    float sumgp = 0.f;                                               // of g_pred (threads 0 .. 63: row tid >> 1, component tid & 1)
+    struct Stage { float4 g1, g2, h1, d2, e0, e1; float gp; bool ok; };
+    auto stage_load = [&](long long rb) -> Stage {
+        Stage S;
+        const long long row = rb + srow;
+        S.ok = row < s1e;
+        const long long ro = S.ok ? row : (s0 < R ? s0 : 0);       // clamped: a readable row
+        S.g1 = *reinterpret_cast<const float4*>(J.g_pre1 + ro * DD + sc4);
+        S.g2 = *reinterpret_cast<const float4*>(J.g_pre2 + ro * DD + sc4);
+        S.h1 = *reinterpret_cast<const float4*>(J.h1 + ro * DD + sc4);
+        S.d2 = *reinterpret_cast<const float4*>(J.d2 + ro * DD + sc4);
+        S.e0 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + sc4);
+        S.e1 = *reinterpret_cast<const float4*>(J.msgs + ro * DH + 64 + sc4);
+        const long long gr = rb + ((tid & 63) >> 1);
+        S.gp = J.g_pred_rows[(gr < s1e ? gr : (s0 < R ? s0 : 0)) * 2 + (tid & 1)];
+        return S;
+    };
+    // chunk `chunk` (4 features) of row srow of an image: the three pieces of v
+    auto lay = [&](unsigned char* im, int chunk, const float4 v) {
+        unsigned h0, m0, l0, h1_, m1, l1;
+        split3(v.x, v.y, h0, m0, l0);
+        split3(v.z, v.w, h1_, m1, l1);
+        unsigned char* d = im + srow * 256 + ((chunk ^ (8 * (srow & 3))) * 8);
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1_);
+        *reinterpret_cast<uint2*>(d + 8192) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 16384) = make_uint2(l0, l1);
+    };
+    auto stage_write = [&](const Stage S, unsigned char* buf, long long rb) {
+        auto sel = [&](const float4 v) { return make_float4(S.ok ? v.x : 0.f, S.ok ? v.y : 0.f, S.ok ? v.z : 0.f, S.ok ? v.w : 0.f); };
+        const float4 g1 = sel(S.g1), g2 = sel(S.g2);
+        sum1.x += g1.x; sum1.y += g1.y; sum1.z += g1.z; sum1.w += g1.w;
+        sum2.x += g2.x; sum2.y += g2.y; sum2.z += g2.z; sum2.w += g2.w;
+        lay(buf + RWX_G, c16, g1);
+        lay(buf + RWX_G, 16 + c16, g2);
+        lay(buf + RWX_H, c16, sel(S.h1));
+        lay(buf + RWX_H, 16 + c16, sel(S.d2));
+        lay(buf + RWX_E, c16, sel(S.e0));
+        lay(buf + RWX_E, 16 + c16, sel(S.e1));
+        if (tid < 64) {
+            const float g = rb + (tid >> 1) < s1e ? S.gp : 0.f;
+            sumgp += g;
+            reinterpret_cast<float*>(buf + RWX_GP)[tid] = g;
+        }
+    };
+    // reader (encoder_bwd3.hip, phase 2): lane 4 q + pp of 16-lane group g16 supplies row r0 + q, chunk 8 blk + 4 (g16 & 1) + pp
+    int tr_off;
+    {
+        const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        tr_off = (4 * (g16 >> 1) + q) * 256 + (4 * (g16 & 1) + pp) * 8;
+    }
+    const int trq = (lane >> 2) & 3;
+    auto frag = [&](const unsigned char* im, int blk, int s_, int piece) -> u32x4 {
+        const int o0 = tr_off + (16 * s_) * 256 + ((8 * blk) ^ (8 * trq)) * 8 + piece * 8192;
+        const rw_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rw_lds_s16x4*)(im + o0));
+        const rw_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rw_lds_s16x4*)(im + o0 + 8 * 256));
+        const uint2 x = __builtin_bit_cast(uint2, lo4), y = __builtin_bit_cast(uint2, hi4);
+        return (u32x4){x.x, x.y, y.x, y.y};
+    };
+    auto compute = [&](const unsigned char* buf) {
+        u32x4 a[2][3], bq[2][3];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) { a[s_][pc] = frag(buf + RWX_G, mb1, s_, pc); bq[s_][pc] = frag(buf + RWX_E, nb1, s_, pc); }
+        u32x4 a2[2][3], b2[2][3];
+        if (do2) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) { a2[s_][pc] = frag(buf + RWX_G, 2 + mb2, s_, pc); b2[s_][pc] = frag(buf + RWX_H, nb2, s_, pc); }
+        } else if (do3) {
+            const float* gpl = reinterpret_cast<const float*>(buf + RWX_GP);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = i < 2 ? gpl[(16 * s_ + 8 * (t >> 2) + 4 * h + (t & 3)) * 2 + i] : 0.f;
+                unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) split3(v[2 * d], v[2 * d + 1], hh[d], mm[d], ll[d]);
+                a2[s_][0] = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+                a2[s_][1] = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+                a2[s_][2] = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) b2[s_][pc] = frag(buf + RWX_H, 2 + nb2, s_, pc);
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            kblock_x3(c1, s1, a[s_][0], a[s_][1], a[s_][2], bq[s_][0], bq[s_][1], bq[s_][2]);
+            if (do2 || do3) kblock_x3(cx, sx, a2[s_][0], a2[s_][1], a2[s_][2], b2[s_][0], b2[s_][1], b2[s_][2]);
+        }
+    };
+    if (s0 < s1e) {
+        const int nb = (int)((s1e - s0 + RD_CHUNK - 1) / RD_CHUNK);
+        // the loads of chunk t + 2 are requested as soon as the registers of chunk t + 1 are free -- in front of the barrier -- and
+        // looked at behind the products of chunk t + 1 (requested in front of the products of chunk t they had the products' time
+        // only: 25.8 us for the launch at the reference's row counts)
+        // (the barrier: this wave's LDS operations done, nothing said about its loads in flight -- __syncthreads() waits for them)
+#ifndef PIML_RWX_EARLY
+#define PIML_RWX_EARLY 1
+#endif
+        Stage S = stage_load(s0);
+        stage_write(S, rx_smem, s0);
+        if (PIML_RWX_EARLY) S = stage_load(s0 + RD_CHUNK);          // past the slab: clamped + zeroed, written but never read
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int t = 0; t < nb; ++t) {
+            unsigned char* cur = rx_smem + (t & 1) * RWX_BUF;
+            unsigned char* nxt = rx_smem + ((t + 1) & 1) * RWX_BUF;
+            if (!PIML_RWX_EARLY) S = stage_load(s0 + (long long)(t + 1) * RD_CHUNK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_write(S, nxt, s0 + (long long)(t + 1) * RD_CHUNK);
+            if (PIML_RWX_EARLY) S = stage_load(s0 + (long long)(t + 2) * RD_CHUNK);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float* P = J.partials + (size_t)p * DEC_PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * h;
+        P[(size_t)(32 * mb1 + ri) * DH + 32 * nb1 + i] = c1[r] + s1[r];
+        if (do2) P[DD * DH + (32 * mb2 + ri) * DD + 32 * nb2 + i] = cx[r] + sx[r];
+        if (do3 && ri < 2) P[DD * DH + DD * DD + ri * DD + 32 * nb2 + i] = cx[r] + sx[r];
+    }
+    // column sums: [staging row 32][g_pre1 64 | g_pre2 64 | g_pred 2 | pad 2] floats over the (dead) images, summed over the rows in order
+    float* red = reinterpret_cast<float*>(rx_smem);
+    *reinterpret_cast<float4*>(red + srow * 132 + sc4) = sum1;
+    *reinterpret_cast<float4*>(red + srow * 132 + 64 + sc4) = sum2;
+    if (tid < 64) red[(tid >> 1) * 132 + 128 + (tid & 1)] = sumgp;
+    __syncthreads();
+    float* Pb = P + DD * DH + DD * DD + 2 * DD;
+    if (tid < 136) {
+        float v = 0.f;
+        if (tid < 130)
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) v += red[r * 132 + tid];
+        Pb[tid] = v;                                                  // db1 64 | db2 64 | db3 2 | padding 6
     }
 }
 
@@ -1657,6 +2151,29 @@ static int rowdec_fill(DecArgs& A, const piml_decoder_branch* br, int nbr, bool 
     return hipSuccess;
 }
 
+// products of the row decoder's many-rows kernels: 1 = split bf16 products (rowdec_*_x3_kernel), 0 = the f32 matrix-core
+// instruction (PIML_ROWDEC_PRODUCTS=f32, piml_rowdecoder_products)
+static int g_rowdec_x3 = !(getenv("PIML_ROWDEC_PRODUCTS") && getenv("PIML_ROWDEC_PRODUCTS")[0] == 'f');
+
+PIML_API int piml_rowdecoder_products(int x3) {
+    const int old = g_rowdec_x3;
+    if (x3 >= 0) g_rowdec_x3 = x3 ? 1 : 0;
+    return old;
+}
+
+static int rowdec_x3_attributes() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowdec_fwd_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RFX_LDS_BYTES))
+        return e;
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowdec_bwd_dx_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RDXX_LDS_BYTES))
+        return e;
+    if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowdec_bwd_dw_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RWX_LDS_BYTES))
+        return e;
+    done = true;
+    return hipSuccess;
+}
+
 static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, void* stream);
 PIML_API int piml_rowdecoder_fwd(const piml_decoder_branch* br, int nbr, void* stream) { return rowdecoder_fwd(br, nbr, true, stream); }
 // `packed` already holds the operand images of these weights (piml_pinnsf_pack / an earlier piml_rowdecoder_fwd)
@@ -1674,7 +2191,12 @@ static int rowdecoder_fwd(const piml_decoder_branch* br, int nbr, bool pack, voi
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
     if (tiles0 + tiles1 > kRowdecBigTiles) {       // many rows: one wave per tile, fragments in LDS (rowdec_fwd_big_kernel)
         const int split = rowdec_wg_split(br, nbr, 256);
-        hipLaunchKernelGGL(rowdec_fwd_big_kernel, dim3(256), dim3(512), 0, s, A, split);
+        if (g_rowdec_x3) {
+            if (int e = rowdec_x3_attributes()) return e;
+            hipLaunchKernelGGL(rowdec_fwd_x3_kernel, dim3(256), dim3(512), RFX_LDS_BYTES, s, A, split);
+        } else {
+            hipLaunchKernelGGL(rowdec_fwd_big_kernel, dim3(256), dim3(512), 0, s, A, split);
+        }
         return hipGetLastError();
     }
     hipLaunchKernelGGL(rowdec_fwd_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
@@ -1688,9 +2210,14 @@ PIML_API int piml_rowdecoder_bwd_acc(const piml_decoder_branch* br, int nbr, int
     DecArgs A;
     if (int e = rowdec_fill(A, br, nbr, true)) return e;
     const int tiles0 = (int)((br[0].agents + 31) / 32), tiles1 = nbr > 1 ? (int)((br[1].agents + 31) / 32) : 0;
-    if (tiles0 + tiles1 > kRowdecBigTiles)
-        hipLaunchKernelGGL(rowdec_bwd_dx_big_kernel, dim3(256), dim3(512), 0, s, A, rowdec_wg_split(br, nbr, 256));
-    else
+    if (tiles0 + tiles1 > kRowdecBigTiles) {
+        if (g_rowdec_x3) {
+            if (int e = rowdec_x3_attributes()) return e;
+            hipLaunchKernelGGL(rowdec_bwd_dx_x3_kernel, dim3(256), dim3(512), RDXX_LDS_BYTES, s, A, rowdec_wg_split(br, nbr, 256));
+        } else {
+            hipLaunchKernelGGL(rowdec_bwd_dx_big_kernel, dim3(256), dim3(512), 0, s, A, rowdec_wg_split(br, nbr, 256));
+        }
+    } else
         hipLaunchKernelGGL(rowdec_bwd_dx_kernel, dim3((unsigned)(tiles0 + tiles1)), dim3(256), 0, s, A, tiles0);
     const int slots0 = piml_rowdecoder_slots(br[0].agents), slots1 = nbr > 1 ? piml_rowdecoder_slots(br[1].agents) : 0;
     static bool attr_set = false;
@@ -1700,8 +2227,14 @@ PIML_API int piml_rowdecoder_bwd_acc(const piml_decoder_branch* br, int nbr, int
             return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(rowdec_bwd_dw_lds_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 2 * RD_BUF * 4, s, A, slots0,
-                       rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
+    if (g_rowdec_x3 && tiles0 + tiles1 > kRowdecBigTiles) {
+        if (int e = rowdec_x3_attributes()) return e;
+        hipLaunchKernelGGL(rowdec_bwd_dw_x3_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), RWX_LDS_BYTES, s, A, slots0,
+                           rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
+    } else {
+        hipLaunchKernelGGL(rowdec_bwd_dw_lds_kernel, dim3((unsigned)(slots0 + slots1)), dim3(512), 2 * RD_BUF * 4, s, A, slots0,
+                           rowdec_slab(br[0].agents), nbr > 1 ? rowdec_slab(br[1].agents) : (long long)DEC_SLAB);
+    }
     // `accumulate`: 0 / 1, or flags -- PIML_ACCUMULATE and / or PIML_DEFER_SLOT_SUMS (the header)
     const bool acc = (accumulate & 1) || (accumulate & PIML_ACCUMULATE);
     if (accumulate & PIML_DEFER_SLOT_SUMS) {          // the slot sums ride in the relfeat backward's launch (network.hip)
