@@ -304,6 +304,22 @@ int piml_rollout_losses_frames_bwd(const float* g_mse_out, const float* g_collw_
                                    const float* g_total_out, float w_coll, float w_hard, const float* g_mse, const float* g_coll,
                                    const float* g_hard, long long n, float* g_p, void* stream);
 
+/* The collision-prediction loss of `pinnsf_bm` over the frames of a training rollout (src/models/simulators.py:731-733 per frame,
+ * :826-830 behind the loop) in ONE launch: pred_frames / feature_frames = HOST arrays of nframes (<= 32) device pointers, frame f's
+ * predictions (n = windows * agents * k values in (0, 1), the model's last output) and pedestrian features (n rows of feature_ld >= 4
+ * floats: relative position, relative velocity -- the label is calculate_collision_label of them, src/data/data.py:514-535); frame f
+ * is rollout frame t_start + f of T_total, gates (T_total floats, 0 / 1) = the reference's per-frame `if torch.sum(mask) > 0`.
+ *     out[0] = weight * F.binary_cross_entropy(pred * gate, label * gate, reduction='sum')   (logarithms clamped at -100)
+ *     out[1] = sum(round(pred * gate) == label * gate) / (T_total * n)                         (frames outside the rollout: equal)
+ * grad (nframes, n) = d out[0] / d pred (binary_cross_entropy_backward's (p - y) / max((1 - p) p, 1e-12)).  partial (2 floats per
+ * workgroup of piml_collision_pred_loss_blocks) and a zeroed ticket are needed when that is > 1.  bwd: g_pred = *g_loss * grad
+ * (g_loss NULL = 1), n = nframes * n values. */
+int piml_collision_pred_loss_blocks(long long n, int nframes);
+int piml_collision_pred_loss(const float* const* pred_frames, const float* const* feature_frames, int nframes, long long n, int k,
+                             int feature_ld, const float* gates, int t_start, int T_total, float weight, float* out, float* grad,
+                             float* partial, unsigned* ticket, void* stream);
+int piml_collision_pred_loss_bwd(const float* g_loss, const float* grad, long long n, float* g_pred, void* stream);
+
 
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);
@@ -773,7 +789,7 @@ int piml_head64_partial_floats(void);
 int piml_head64_slots(long long rows);
 int piml_head64_fwd(const piml_head64* head, void* stream);
 int piml_head64_bwd(const piml_head64* head, void* stream);
-int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream);   /* grads +=, see piml_encoder_bwd_acc */
+int piml_head64_bwd_acc(const piml_head64* head, int accumulate, void* stream);   /* grads +=, | PIML_DEFER_SLOT_SUMS: see piml_encoder_bwd_acc */
 
 /*
  * The corrector of `pinnsf_res` (src/models/model.py:1016-1020, :1050-1052; attn_pooling :950-970; ResDNN :82-119) on

@@ -128,6 +128,9 @@ SIGNATURES = {
     'piml_rollout_losses_bwd': [_p, _p, _p, _p, _p, _p, _ll, _p, _p],
     'piml_rollout_losses_frames': [_p, _p, _ll, _p, _p, ctypes.POINTER(_p), _i, _p, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p],
     'piml_rollout_losses_frames_bwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _ll, _p, _p],
+    'piml_collision_pred_loss_blocks': [_ll, _i],
+    'piml_collision_pred_loss': [ctypes.POINTER(_p), ctypes.POINTER(_p), _i, _ll, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _p],
+    'piml_collision_pred_loss_bwd': [_p, _p, _ll, _p, _p],
     'piml_p2p_alloc': [_z, ctypes.POINTER(_p)],
     'piml_p2p_free': [_p],
     'piml_p2p_export': [_p, _p],

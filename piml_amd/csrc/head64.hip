@@ -14,6 +14,7 @@
 //             one slot per workgroup, a slot sum afterwards (no atomics: bit-reproducible).
 #include "common.hpp"
 #include "pack.hpp"
+#include "reduce.hpp"
 #include "trace.hpp"
 #include "../../include/piml_hip.h"
 
@@ -252,8 +253,20 @@ PIML_API int piml_head64_bwd_acc(const piml_head64* A, int accumulate, void* str
     if (A->rows == 0) return hipSuccess;
     const int slots = piml_head64_slots(A->rows);
     hipLaunchKernelGGL(head64_bwd_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), *A);
+    // `accumulate`: 0 / 1, or flags -- PIML_ACCUMULATE and / or PIML_DEFER_SLOT_SUMS (the header)
+    const bool acc = (accumulate & 1) || (accumulate & PIML_ACCUMULATE);
+    if (accumulate & PIML_DEFER_SLOT_SUMS) {          // the slot sums ride in the relfeat backward's launch (network.hip)
+        ReduceAll R = {};
+        R.accumulate = acc ? 1 : 0;
+        R.set[0] = ReduceSet{A->partials, A->grads, slots, H64_PART / 4, 0x7fffffff, 0, 0};
+        R.nsets = 1;
+        R.gx = (H64_PART / 4 + 15) / 16;
+        if (hipError_t e = hipGetLastError()) return e;
+        trace_mark("head64_bwd", as_stream(stream));
+        return pending_slot_sums_leave(R, as_stream(stream));
+    }
     hipLaunchKernelGGL(head64_reduce_kernel, dim3((H64_PART / 4 + 15) / 16), dim3(256), 0, as_stream(stream), A->partials, A->grads, slots,
-                       accumulate ? 1 : 0);
+                       acc ? 1 : 0);
     trace_mark("head64_bwd", as_stream(stream));
     return hipGetLastError();
 }

@@ -181,9 +181,138 @@ __global__ __launch_bounds__(LOSS_THREADS) void rollout_losses_bwd_kernel(const 
         g_p[e] = a * g_mse[e] + b * g_coll[e] + c * g_hard[e];
 }
 
+// ---- the collision-prediction loss of `pinnsf_bm` in the fine-tuning step (src/models/simulators.py:731-733, 826-830) ----
+//     pred_collisions[:, t] = model(...)[-1] * gate_t      true_collision[:, t] = calculate_collision_label(ped_features) * gate_t
+//     loss = F.binary_cross_entropy(pred_collisions, true_collision, reduction='sum') * collision_pred_weight
+//     acc  = sum(round(pred_collisions) == true_collision) / numel          (frames before t_start: zeros on both sides)
+// On torch operators: a label launch per frame, two stacks, two products, BCE, sum, round, ==, sum, / and their backward incl. one
+// strided copy per frame -- 25 launches of a few microseconds on 4 x 5 x 122 x 6 numbers.  Here: ONE launch reads the frames'
+// predictions and pedestrian features where the model / the feature kernel left them, evaluates the label (data.py:514-535, the
+// arithmetic of collision_label_kernel), the clamped logarithms of binary_cross_entropy (log(p), log1p(-p), both >= -100) and
+// round-half-even, reduces both sums in a fixed order (the last workgroup out when there are several) and writes
+// d(loss)/d(prediction) = w gate (p - y) / max((1 - p) p, 1e-12) per frame, contiguous: the backward is one scaled copy.
+struct CplArgs {
+    const float* pred[32];       // frame f: (rows * k) predictions in (0, 1)
+    const float* feat[32];       // frame f: (rows * k, ld) pedestrian features: relative position, relative velocity
+    int nframes, k, ld, t_start, T_total;
+    long long n;                 // rows * k
+    const float* gates;          // (T_total) 0 / 1 floats
+    float weight;
+    float* out;                  // weighted loss | accuracy
+    float* grad;                 // (nframes, n)
+    float* partial;              // (blocks, 2)
+    unsigned* ticket;
+};
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = a; red[LOSS_THREADS + tid] = b;
+    __syncthreads();
+    for (int s = LOSS_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) { red[tid] += red[tid + s]; red[LOSS_THREADS + tid] += red[LOSS_THREADS + tid + s]; }
+        __syncthreads();
+    }
+    a = red[0]; b = red[LOSS_THREADS];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void collision_pred_loss_kernel(CplArgs A) {
+    __shared__ float red[2 * LOSS_THREADS];
+    __shared__ unsigned last;
+    const int f = blockIdx.y;
+    const float* pp = A.pred[0];
+    const float* ff = A.feat[0];
+#pragma unroll 1
+    for (int q = 1; q < 32; ++q) {                              // (a by-value pointer table indexed at run time lands in scratch)
+        pp = (q == f) ? A.pred[q] : pp;
+        ff = (q == f) ? A.feat[q] : ff;
+    }
+    const float g = A.gates[A.t_start + f];
+    float loss = 0.f, equal = 0.f;
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < A.n; e += (long long)gridDim.x * LOSS_THREADS) {
+        const float* fr = ff + e * A.ld;
+        const float px = fr[0], py = fr[1], vx = fr[2], vy = fr[3];
+        float hit = 0.f;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const float tau = __fmul_rn((float)t, 0.1f);        // torch.arange(10) * 0.1 in float32
+            const float d = norm2(__fadd_rn(px, __fmul_rn(vx, tau)), __fadd_rn(py, __fmul_rn(vy, tau)));
+            if (d < 0.5f && d != 0.f) hit = 1.f;
+        }
+        const float p = pp[e] * g, y = hit * g;
+        loss += (y - 1.f) * fmaxf(log1pf(-p), -100.f) - y * fmaxf(logf(p), -100.f);
+        equal += rintf(p) == y ? 1.f : 0.f;
+        A.grad[(long long)f * A.n + e] = A.weight * g * ((p - y) / fmaxf((1.f - p) * p, 1e-12f));
+    }
+    block_sum2(loss, equal, red);
+    const unsigned nblocks = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    auto finish = [&](float l, float q) {
+        if (threadIdx.x == 0) {
+            const float numel = (float)A.T_total * (float)A.n;
+            A.out[0] = l * A.weight;
+            A.out[1] = (q + (float)(A.T_total - A.nframes) * (float)A.n) / numel;      // the frames outside the rollout: 0 == 0
+        }
+    };
+    if (nblocks == 1) { finish(loss, equal); return; }
+    if (threadIdx.x == 0) {
+        A.partial[bid * 2] = loss; A.partial[bid * 2 + 1] = equal;
+        __threadfence();
+        last = atomicAdd(A.ticket, 1u) == nblocks - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float l = 0.f, q = 0.f;
+    for (unsigned b = threadIdx.x; b < nblocks; b += LOSS_THREADS) { l += A.partial[b * 2]; q += A.partial[b * 2 + 1]; }
+    __syncthreads();
+    block_sum2(l, q, red);
+    finish(l, q);
+    if (threadIdx.x == 0) *A.ticket = 0u;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void scale_by_scalar_kernel(const float* __restrict__ g, const float* __restrict__ x, long long n,
+                                                                      float* __restrict__ y) {
+    const float a = g ? *g : 1.f;
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * LOSS_THREADS) y[e] = a * x[e];
+}
+
 }  // namespace piml
 
 using namespace piml;
+
+PIML_API int piml_collision_pred_loss_blocks(long long n, int nframes) {
+    long long b = (n + 4 * LOSS_THREADS - 1) / (4 * LOSS_THREADS);
+    b = b < 1 ? 1 : (b > 64 ? 64 : b);
+    return (int)b * (nframes < 1 ? 1 : nframes);
+}
+
+PIML_API int piml_collision_pred_loss(const float* const* pred_frames, const float* const* feature_frames, int nframes, long long n,
+                                      int k, int feature_ld, const float* gates, int t_start, int T_total, float weight, float* out,
+                                      float* grad, float* partial, unsigned* ticket, void* stream) {
+    if (!pred_frames || !feature_frames || nframes < 1 || nframes > 32 || n < 1 || k < 1 || feature_ld < 4 || !gates || t_start < 0 ||
+        t_start + nframes > T_total || !out || !grad)
+        return hipErrorInvalidValue;
+    const int blocks = piml_collision_pred_loss_blocks(n, nframes);
+    if (blocks > 1 && (!partial || !ticket)) return hipErrorInvalidValue;
+    CplArgs A = {};
+    for (int f = 0; f < nframes; ++f) {
+        if (!pred_frames[f] || !feature_frames[f]) return hipErrorInvalidValue;
+        A.pred[f] = pred_frames[f]; A.feat[f] = feature_frames[f];
+    }
+    A.nframes = nframes; A.k = k; A.ld = feature_ld; A.t_start = t_start; A.T_total = T_total; A.n = n; A.gates = gates;
+    A.weight = weight; A.out = out; A.grad = grad; A.partial = partial; A.ticket = ticket;
+    hipLaunchKernelGGL(collision_pred_loss_kernel, dim3((unsigned)(blocks / nframes), (unsigned)nframes), dim3(LOSS_THREADS), 0,
+                       as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_collision_pred_loss_bwd(const float* g_loss, const float* grad, long long n, float* g_pred, void* stream) {
+    if (!grad || !g_pred || n < 1) return hipErrorInvalidValue;
+    long long b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)(b > 256 ? 256 : b)), dim3(LOSS_THREADS), 0, as_stream(stream), g_loss, grad,
+                       n, g_pred);
+    return hipGetLastError();
+}
 
 PIML_API int piml_rollout_losses_blocks(int C, int N) {
     const long long pairs = (long long)C * N;

@@ -28,7 +28,7 @@ struct UnfoldSet {
     float* egrads;         // encoder `grads` (ENC_PART layout)
 };
 struct ReduceAll {
-    ReduceSet set[6];
+    ReduceSet set[8];     // (the bottleneck variants leave 4 encoder + 2 row decoder + 1 head sets in one backward pass)
     int nsets;
     int accumulate;       // PIML_ACCUMULATE: grads += the sums
     int gx;               // workgroups per set (the widest set's (lanes + 15) / 16)

@@ -520,6 +520,7 @@ class BaseSimulator(Pedestrians):
         zero = self._const(dev, 0.0)                # (one persistent zero for every sum that starts at 0: each torch.zeros is a launch)
         pred_collisions = true_collision = zero
         pred_steps, true_steps = [], []             # bm head: per-frame records, stacked and gated once after the loop
+        fused_bce = bm_head and self.fused_rollout_losses and p_cur.is_cuda and p_cur.dtype == torch.float32 and T - t_start <= 32
         loss = zero
         reg_loss = zero
         nan_seen = None                             # (the fused frame step keeps its own flag on the device)
@@ -566,7 +567,8 @@ class BaseSimulator(Pedestrians):
             a_steps.append(a_cur)
             if bm_head:                                                       # :731-733
                 pred_steps.append(predictions[-1])
-                true_steps.append(self.calculate_collision_label(state[0]))
+                # (fused: the label is evaluated inside the loss launch, from the frame's pedestrian features where they lie)
+                true_steps.append(state[0] if fused_bce else self.calculate_collision_label(state[0]))
             if args.reg_weight > 0:                                           # :735-737 (cumulative, as shipped)
                 reg_loss = reg_loss + self.l1_reg_loss(p_msg, args.reg_weight, 'sum') * gf
                 loss = loss + reg_loss * gf
@@ -699,6 +701,10 @@ class BaseSimulator(Pedestrians):
             # :826-830 with both tensors still all zeros (only `pinnsf_bm` fills them, :731-733): BCE(0, 0) = 0 and every
             # rounded prediction equals its label -- the values the six launches below would compute
             collision_pred_acc = self._const(dev, 1.0)
+        elif args.collision_pred_weight > 0 and fused_bce:                    # :826-830 as one launch each way
+            collision_pred_loss, collision_pred_acc = ops.collision_pred_loss(pred_steps, true_steps, gates_f, t_start, T,
+                                                                              args.collision_pred_weight)
+            loss = loss + collision_pred_loss
         elif args.collision_pred_weight > 0:                                  # :826-830
             # (c, t, n, k) records of :731-733: zeros in the frames before t_start, every frame times its gate -- one stack and
             # one product instead of two slice assignments per frame

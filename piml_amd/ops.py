@@ -679,6 +679,22 @@ def collision_counts_frames(frames, thresholds):
 
 
 _LOSS_TICKETS = {}
+_ZEROS_RO = {}
+
+
+def _zeros_ro(shape, dev):
+    """A float32 zero tensor that is only ever READ (a gradient that did not arrive, handed to a kernel as zeros): one persistent
+    tensor per (shape, device) instead of a fill launch per use.  Made outside stream capture only -- a fill recorded into one
+    graph has not run when another graph reads the tensor; while capturing, an unknown shape gets a fresh torch.zeros."""
+    key = (tuple(shape), dev.index if isinstance(dev, torch.device) else dev)
+    z = _ZEROS_RO.get(key)
+    if z is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, device=dev, dtype=torch.float32)
+        z = torch.zeros(shape, device=dev, dtype=torch.float32)
+        if len(_ZEROS_RO) < 64:          # (never evicted: a captured graph may hold the pointer)
+            _ZEROS_RO[key] = z
+    return z
 
 
 def multi_copy(dsts, srcs):
@@ -859,6 +875,73 @@ def rollout_losses_frames(p, labels, mask_pred, gates, count_frames, focus, abno
     counts only feed the statistics (collision loss switched off)."""
     return _RolloutLossesFrames.apply(p, labels, mask_pred, gates, bool(focus), abnormal_mask, float(time_decay), float(w_coll),
                                       float(w_hard), *count_frames)
+
+
+class _CollisionPredLoss(torch.autograd.Function):
+    """inputs: gates_f (T,), t_start, T, weight, n frames, then the frames' predictions, then their pedestrian features.
+    outputs: weighted BCE sum, accuracy (piml_collision_pred_loss)."""
+
+    @staticmethod
+    def forward(ctx, gates_f, t_start, T, weight, nframes, *tensors):
+        import ctypes
+        L = _lib.lib()
+        preds = [_gpu_f32('prediction', t.detach()) for t in tensors[:nframes]]
+        feats = [_gpu_f32('ped_features', t.detach()) for t in tensors[nframes:]]
+        n, k, ld = preds[0].numel(), preds[0].shape[-1], feats[0].shape[-1]
+        if any(q.numel() != n for q in preds) or any(f.numel() != n * ld or f.shape[-2] != k for f in feats) or ld < 4:
+            raise ValueError('collision_pred_loss: predictions (..., k) and pedestrian features (..., k, >= 4) of one shape per frame')
+        gf = _gpu_f32('gates', gates_f.detach()).reshape(-1)
+        if gf.numel() != T or not 0 <= t_start or t_start + nframes > T or not 1 <= nframes <= 32:
+            raise ValueError('collision_pred_loss: gates (T,), t_start + frames <= T, at most 32 frames')
+        dev = preds[0].device
+        opt = dict(device=dev, dtype=torch.float32)
+        out = torch.empty(2, **opt)
+        grad = torch.empty(nframes, n, **opt)
+        blocks = L.piml_collision_pred_loss_blocks(n, nframes)
+        partial, ticket = None, None
+        if blocks > 1:
+            partial = torch.empty(blocks, 2, **opt)
+            ticket = _LOSS_TICKETS.get(dev)
+            if ticket is None:       # zeroed once; the launch leaves it zero
+                ticket = _LOSS_TICKETS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+        ptab = (ctypes.c_void_p * nframes)(*[q.data_ptr() for q in preds])
+        ftab = (ctypes.c_void_p * nframes)(*[f.data_ptr() for f in feats])
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_collision_pred_loss(ptab, ftab, nframes, n, k, ld, _ptr(gf), int(t_start), int(T), float(weight), _ptr(out),
+                                                  _ptr(grad), _ptr(partial), _ptr(ticket), _stream()), 'piml_collision_pred_loss')
+        ctx.save_for_backward(grad)
+        ctx.meta = (nframes, [tuple(t.shape) for t in tensors[:nframes]])
+        ctx.set_materialize_grads(False)
+        acc = out[1]
+        ctx.mark_non_differentiable(acc)
+        return out[0], acc
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, _g_acc):
+        nframes, shapes = ctx.meta
+        none = (None,) * (5 + 2 * nframes)
+        if g_loss is None or not any(ctx.needs_input_grad[5:5 + nframes]):
+            return none
+        grad, = ctx.saved_tensors
+        g = _gpu_f32('g_out', g_loss)
+        gp = torch.empty_like(grad)
+        with torch.cuda.device(grad.device):
+            _lib.check(_lib.lib().piml_collision_pred_loss_bwd(_ptr(g), _ptr(grad), grad.numel(), _ptr(gp), _stream()),
+                       'piml_collision_pred_loss_bwd')
+        return (None,) * 5 + tuple(gp[f].view(shapes[f]) for f in range(nframes)) + (None,) * nframes
+
+
+def collision_pred_loss(pred_frames, feature_frames, gates_f, t_start, T, weight):
+    """The collision-prediction loss of `pinnsf_bm` over the frames of a training rollout (src/models/simulators.py:731-733, 826-830) as
+    one launch each way: pred_frames / feature_frames = the model's last output (C, N, k) and the pedestrian features (C, N, k, 6) of
+    rollout frames t_start, t_start + 1, ...; gates_f (T,) 0 / 1 floats.  Returns (collision_pred_weight * BCE sum, accuracy), the
+    reference's two scalars; the labels (calculate_collision_label) are evaluated inside."""
+    if len(pred_frames) != len(feature_frames) or not pred_frames:
+        raise ValueError('collision_pred_loss: one feature tensor per prediction tensor')
+    if not pred_frames[0].is_cuda:
+        raise _lib.PimlHipError('collision_pred_loss: expected GPU tensors (piml_amd has no CPU path)')
+    return _CollisionPredLoss.apply(gates_f, int(t_start), int(T), float(weight), len(pred_frames), *pred_frames, *feature_frames)
 
 
 def rollout_losses(p, labels, mask_pred, gates, collisions=None, hard_collisions=None, abnormal_mask=None, time_decay=1.0):
@@ -1743,7 +1826,7 @@ class _RolloutFrame(torch.autograd.Function):
                     g6 = torch.zeros(C, N, 6, **opt)
 
                 def dense(g, shape):
-                    return torch.zeros(shape, **opt) if g is None else _gpu_f32('grad', g)
+                    return _zeros_ro(shape, dev) if g is None else _gpu_f32('grad', g)
                 g_pf, g_of, g_sf = dense(g_pf, (C, N, kpe, 6)), dense(g_of, (C, N, koe, 6)), dense(g_sf, (C, N, 7))
                 g_dest = torch.empty(C, N, 2, **opt)           # (the step's destination output carries no gradient)
                 _lib.check(L.piml_relfeat_bwd_self(
@@ -2927,7 +3010,7 @@ class _FusedRowDecoder(torch.autograd.Function):
                 sink = None
         for i, b in enumerate(live):
             R = rows[b]
-            gp = _gpu_f32('g_pred', gs[2 * b]).reshape(R, 2) if gs[2 * b] is not None else torch.zeros(R, 2, **opt)
+            gp = _gpu_f32('g_pred', gs[2 * b]).reshape(R, 2) if gs[2 * b] is not None else _zeros_ro((R, 2), dev)
             gd = _gpu_f32('g_decoded', gs[2 * b + 1]).reshape(R, 64) if gs[2 * b + 1] is not None else None
             gp2, gp1, gemb = torch.empty(R, 64, **opt), torch.empty(R, 64, **opt), torch.empty(R, H, **opt)
             parts = torch.empty(L.piml_rowdecoder_slots(R), L.piml_decoder_partial_floats(), **opt)
@@ -3069,8 +3152,13 @@ class _CollisionHead64(torch.autograd.Function):
         H.w1, H.b1, H.w2, H.b2 = [t.data_ptr() for t in (w1, b1, w2, b2)]
         H.hidden, H.out, H.g_out = hidden.data_ptr(), out.data_ptr(), g.data_ptr()
         H.g_x, H.partials, H.grads = _ptr(gx), partials.data_ptr(), grads.data_ptr()
+        # (inside a deferred_slot_sums block the slot sums join the row decoder's and the encoders' in the relfeat backward's launch)
+        defer = ctx.params is not None and _defer_slot_sums(list(ctx.params), sink, x2.device)
         with torch.cuda.device(x2.device):
-            _lib.check(L.piml_head64_bwd_acc(ctypes.byref(H), int(accumulate), _stream()), 'piml_head64_bwd')
+            _lib.check(L.piml_head64_bwd_acc(ctypes.byref(H), int(accumulate) | (_lib.DEFER_SLOT_SUMS if defer else 0), _stream()),
+                       'piml_head64_bwd')
+        if defer:
+            _defer_keep(partials, g, grads)
         need = ctx.needs_input_grad
         views = (grads[:4096].view(64, 64), grads[4096:4160], grads[4160:4224].view(1, 64), grads[4224:4225])
         if sink is not None:

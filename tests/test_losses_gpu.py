@@ -264,3 +264,46 @@ def test_rollout_losses_frames_equals_the_stacked_form(C, T, N, t_start, focus):
         assert close(cw, sums[1] * w_c) and close(hw, sums[2] * w_h)
     assert float(stats[0]) == float(coll.sum()) and float(stats[1]) == float(hard.sum()) and float(stats[2]) == float((mask == 1).sum())
     assert torch.allclose(gp, gw, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('C,T,N,k,t_start', [(4, 5, 122, 6, 0), (2, 7, 33, 6, 2), (4, 5, 976, 6, 0), (1, 3, 5, 4, 1)])
+def test_collision_pred_loss_equals_the_torch_expression(C, T, N, k, t_start):
+    """ops.collision_pred_loss (one launch each way) against the statements it replaces -- per frame the model's last output and
+    calculate_collision_label of the frame's pedestrian features (src/models/simulators.py:731-733), behind the loop two stacks
+    with zero frames before t_start, the gates, F.binary_cross_entropy(reduction='sum') * weight, the accuracy (:826-830) -- and
+    their autograd; incl. a gated-off frame, predictions at 0.5 (round half to even), near 0 and near 1 (clamped logarithms)."""
+    import torch.nn.functional as F
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(5)
+    nfr = T - t_start
+    gates_f = torch.ones(T)
+    gates_f[t_start + nfr // 2] = 0.0                                          # a frame nobody is predicted in
+    gates_f = gates_f.to(DEV)
+    preds, feats = [], []
+    for f in range(nfr):
+        p = torch.rand(C, N, k, generator=g)
+        p.view(-1)[:4] = torch.tensor([0.5, 1e-30, 1.0 - 1e-7, 0.5000001])
+        preds.append(p.to(DEV).requires_grad_(True))
+        x = torch.randn(C, N, k, 6, generator=g) * torch.tensor([0.6, 0.6, 1.0, 1.0, 1.0, 1.0])
+        x.view(-1, 6)[0] = 0.0                                                 # distance exactly zero: no collision (d != 0)
+        feats.append(x.to(DEV))
+    weight = 5e-2
+    got_loss, got_acc = ops.collision_pred_loss(preds, feats, gates_f, t_start, T, weight)
+    (got_loss * 1.7).backward()
+    got_grads = [p.grad.clone() for p in preds]
+    # the reference's statements
+    ref_p = [p.detach().clone().requires_grad_(True) for p in preds]
+    gk = gates_f.view(1, -1, 1, 1)
+    pad = [torch.zeros(C, N, k, device=DEV)] * t_start
+    pc = torch.stack(pad + ref_p, dim=1) * gk
+    tc = torch.stack(pad + [ops.collision_label(x) for x in feats], dim=1) * gk
+    want_loss = F.binary_cross_entropy(pc, tc, reduction='sum') * weight
+    want_acc = torch.sum(torch.round(pc) == tc) / tc.numel()
+    (want_loss * 1.7).backward()
+    assert abs(float(got_loss) - float(want_loss)) <= 2e-6 * abs(float(want_loss))
+    assert float(got_acc) == pytest.approx(float(want_acc), abs=1e-6)
+    for a, b in zip(got_grads, ref_p):
+        assert torch.allclose(a, b.grad, rtol=2e-6, atol=1e-7)
+    # deterministic
+    l2, _ = ops.collision_pred_loss([p.detach() for p in preds], feats, gates_f, t_start, T, weight)
+    assert torch.equal(l2, got_loss.detach())

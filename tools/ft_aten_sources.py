@@ -1,6 +1,6 @@
 """Which source line launches each aten kernel of one fine-tuning step (HOT LOOP C at the golden GC batch).  One EAGER step under
 torch.profiler with stacks: per (aten operator, innermost frame inside piml_amd/) the number of GPU kernels.
-python tools/ft_aten_sources.py [dropout]"""
+python tools/ft_aten_sources.py [dropout] [pinnsf_m | pinnsf_bm]"""
 import collections
 import os
 import sys
@@ -18,9 +18,10 @@ def main():
     from piml_amd.models.simulators import BaseSimulator
     p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollout.npz'), allow_pickle=False)
-    data = load_data(g, 'train_pinnsf_m')
+    model = sys.argv[2] if len(sys.argv) > 2 else 'pinnsf_m'
+    data = load_data(g, 'train_' + model)
     torch.manual_seed(666)
-    sim = BaseSimulator(sim_args(model='pinnsf_m', dropout=p, learning_rate=1e-3, hip_graph=False))
+    sim = BaseSimulator(sim_args(model=model, dropout=p, learning_rate=1e-3, hip_graph=False))
     sim.model.train(True)
     for _ in range(3):
         sim.train_batch(data)

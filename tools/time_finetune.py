@@ -8,8 +8,15 @@ import numpy as np, torch
 from test_simulator_gpu import sim_args, load_data, make_sim
 
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollout.npz'), allow_pickle=False)
-data = load_data(g, 'train_pinnsf_m')
-sim = make_sim(g, sim_args(learning_rate=1e-3, hip_graph=True), 'train_pinnsf_m/sd/')
+MODEL = sys.argv[2] if len(sys.argv) > 2 else 'pinnsf_m'          # python tools/time_finetune.py [steps] [pinnsf_m | pinnsf_bm]
+data = load_data(g, 'train_' + MODEL)
+if MODEL == 'pinnsf_m':
+    sim = make_sim(g, sim_args(learning_rate=1e-3, hip_graph=True), 'train_pinnsf_m/sd/')
+else:
+    from piml_amd.models.simulators import BaseSimulator
+    torch.manual_seed(666)
+    sim = BaseSimulator(sim_args(model=MODEL, dropout=0.0, learning_rate=1e-3, hip_graph=True))
+    sim.model.eval()
 for _ in range(6):
     sim.train_batch(data)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -17,7 +24,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 for _ in range(n):
     sim.train_batch(data)
 torch.cuda.synchronize()
-print(f'fine-tune step (graph): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
+print(f'{MODEL} fine-tune step (graph): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
 torch.cuda.synchronize(); t0 = time.perf_counter()
 waiting = None
 for _ in range(n):
@@ -27,4 +34,4 @@ for _ in range(n):
     waiting = nxt
 waiting()
 torch.cuda.synchronize()
-print(f'fine-tune step (graph, one step of lookahead as in train()): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
+print(f'{MODEL} fine-tune step (graph, one step of lookahead as in train()): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step')
