@@ -320,6 +320,19 @@ int piml_collision_pred_loss(const float* const* pred_frames, const float* const
                              float* partial, unsigned* ticket, void* stream);
 int piml_collision_pred_loss_bwd(const float* g_loss, const float* grad, long long n, float* g_pred, void* stream);
 
+/* The losses of a pointwise pre-training batch (src/models/simulators.py:333-352, pinnsf_interaction 'sim') and their gradients in ONE
+ * launch: pred (rows, 2), labels (rows, labels_ld >= 6 [+ k]) -- columns 4, 5 the acceleration label, 6 .. 6 + k - 1 the collision labels
+ * --, msgs (nmsg values, the model's second output) or NULL (reg_weight == 0), coll_pred (rows, k) (the model's last output,
+ * `pinnsf_bm` under collision_pred_weight > 0) or NULL.
+ *     out[1] = F.mse_loss(pred, labels[:, 4:6], 'sum')   out[2] = sum(reg_weight |msgs|)   out[3] = F.binary_cross_entropy(coll_pred,
+ *     labels[:, 6:], 'sum')   out[0] = out[1] (+ out[2]) (+ out[3])
+ * grad = [2 rows | nmsg | rows k] floats: d out[0] / d (pred | msgs | coll_pred); its backward is piml_collision_pred_loss_bwd (a copy
+ * scaled by the upstream gradient).  partial (3 floats per workgroup of piml_pointwise_losses_blocks) and a zeroed ticket when > 1. */
+int piml_pointwise_losses_blocks(long long rows, long long nmsg, int k);
+int piml_pointwise_losses(const float* pred, const float* labels, long long labels_ld, long long rows, const float* msgs, long long nmsg,
+                          float reg_weight, const float* coll_pred, int k, float* out, float* grad, float* partial, unsigned* ticket,
+                          void* stream);
+
 
 int piml_collision_counts(const float* position, int S, int N, const float* thresholds, int n_thresholds,
                           float* counts, void* stream);

@@ -270,6 +270,96 @@ __global__ __launch_bounds__(LOSS_THREADS) void collision_pred_loss_kernel(CplAr
     if (threadIdx.x == 0) *A.ticket = 0u;
 }
 
+// ---- the losses of a pointwise pre-training batch (HOT LOOP A, src/models/simulators.py:333-352, pinnsf_interaction 'sim') ----
+//     mse = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+//     reg = sum(reg_weight * |p_msg|)                                                  (reg_weight > 0)
+//     cp  = F.binary_cross_entropy(predictions[-1], labels[:, 6:], reduction='sum')    (`pinnsf_bm` under collision_pred_weight > 0)
+//     loss = mse + reg + cp
+// and their gradients -- 2 (pred - label), reg_weight sign(p_msg), (p - y) / max((1 - p) p, 1e-12) -- in one launch: on torch
+// operators 8 - 14 launches of a few microseconds on 128 rows.  One buffer for the three gradient fields: the backward is one
+// scaled copy (none at all when the upstream gradient is the step's constant one).
+struct PwlArgs {
+    const float* pred;           // (rows, 2)
+    const float* lab;            // (rows, ld): columns 4, 5 = the acceleration label, 6 .. 6 + k - 1 = the collision labels
+    long long ld, rows;
+    const float* msgs;           // (nmsg) or NULL
+    long long nmsg;
+    float reg_weight;
+    const float* coll;           // (rows, k) or NULL
+    int k;
+    float* out;                  // loss | mse | reg | cp
+    float* grad;                 // [2 rows | nmsg | rows k]
+    float* partial;              // (blocks, 3)
+    unsigned* ticket;
+};
+
+__global__ __launch_bounds__(LOSS_THREADS) void pointwise_losses_kernel(PwlArgs A) {
+    __shared__ float red[3 * LOSS_THREADS];
+    __shared__ unsigned last;
+    const long long n0 = 2 * A.rows, n1 = A.msgs ? A.nmsg : 0, n2 = A.coll ? A.rows * A.k : 0;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (long long e = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x; e < n0 + n1 + n2; e += (long long)gridDim.x * LOSS_THREADS) {
+        if (e < n0) {
+            const float d = A.pred[e] - A.lab[(e >> 1) * A.ld + 4 + (e & 1)];
+            s[0] += d * d;
+            A.grad[e] = 2.f * d;
+        } else if (e < n0 + n1) {
+            const float x = A.msgs[e - n0];
+            s[1] += A.reg_weight * fabsf(x);
+            A.grad[e] = x > 0.f ? A.reg_weight : (x < 0.f ? -A.reg_weight : 0.f);
+        } else {
+            const long long q = e - n0 - n1, r = q / A.k;
+            const float p = A.coll[q], y = A.lab[r * A.ld + 6 + (q - r * A.k)];
+            s[2] += (y - 1.f) * fmaxf(log1pf(-p), -100.f) - y * fmaxf(logf(p), -100.f);
+            A.grad[e] = (p - y) / fmaxf((1.f - p) * p, 1e-12f);
+        }
+    }
+    auto block_sum3 = [&](float (&v)[3]) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] = v[q];
+        __syncthreads();
+        for (int st = LOSS_THREADS / 2; st > 0; st >>= 1) {
+            if (tid < st) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) red[q * LOSS_THREADS + tid] += red[q * LOSS_THREADS + tid + st];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = red[q * LOSS_THREADS];
+        __syncthreads();
+    };
+    auto finish = [&](const float (&v)[3]) {
+        if (threadIdx.x == 0) {
+            // the order of the reference's additions: loss = mse; loss = loss + reg; loss = loss + cp
+            float t = v[0];
+            if (A.msgs) t = t + v[1];
+            if (A.coll) t = t + v[2];
+            A.out[0] = t; A.out[1] = v[0]; A.out[2] = v[1]; A.out[3] = v[2];
+        }
+    };
+    block_sum3(s);
+    if (gridDim.x == 1) { finish(s); return; }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A.partial[blockIdx.x * 3 + q] = s[q];
+        __threadfence();
+        last = atomicAdd(A.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float r[3] = {0.f, 0.f, 0.f};
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += LOSS_THREADS)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r[q] += A.partial[b * 3 + q];
+    __syncthreads();
+    block_sum3(r);
+    finish(r);
+    if (threadIdx.x == 0) *A.ticket = 0u;
+}
+
 __global__ __launch_bounds__(LOSS_THREADS) void scale_by_scalar_kernel(const float* __restrict__ g, const float* __restrict__ x, long long n,
                                                                       float* __restrict__ y) {
     const float a = g ? *g : 1.f;
@@ -303,6 +393,26 @@ PIML_API int piml_collision_pred_loss(const float* const* pred_frames, const flo
     A.weight = weight; A.out = out; A.grad = grad; A.partial = partial; A.ticket = ticket;
     hipLaunchKernelGGL(collision_pred_loss_kernel, dim3((unsigned)(blocks / nframes), (unsigned)nframes), dim3(LOSS_THREADS), 0,
                        as_stream(stream), A);
+    return hipGetLastError();
+}
+
+PIML_API int piml_pointwise_losses_blocks(long long rows, long long nmsg, int k) {
+    const long long n = 2 * rows + (nmsg > 0 ? nmsg : 0) + rows * (k > 0 ? k : 0);
+    long long b = (n + 4 * LOSS_THREADS - 1) / (4 * LOSS_THREADS);
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+
+PIML_API int piml_pointwise_losses(const float* pred, const float* labels, long long labels_ld, long long rows, const float* msgs,
+                                   long long nmsg, float reg_weight, const float* coll_pred, int k, float* out, float* grad, float* partial,
+                                   unsigned* ticket, void* stream) {
+    if (!pred || !labels || rows < 1 || labels_ld < 6 || !out || !grad || (msgs && nmsg < 1) || (coll_pred && (k < 1 || labels_ld < 6 + k)))
+        return hipErrorInvalidValue;
+    const int blocks = piml_pointwise_losses_blocks(rows, msgs ? nmsg : 0, coll_pred ? k : 0);
+    if (blocks > 1 && (!partial || !ticket)) return hipErrorInvalidValue;
+    PwlArgs A = {};
+    A.pred = pred; A.lab = labels; A.ld = labels_ld; A.rows = rows; A.msgs = msgs; A.nmsg = msgs ? nmsg : 0; A.reg_weight = reg_weight;
+    A.coll = coll_pred; A.k = coll_pred ? k : 0; A.out = out; A.grad = grad; A.partial = partial; A.ticket = ticket;
+    hipLaunchKernelGGL(pointwise_losses_kernel, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, as_stream(stream), A);
     return hipGetLastError();
 }
 

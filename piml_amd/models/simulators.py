@@ -121,6 +121,8 @@ class BaseSimulator(Pedestrians):
             if not hasattr(self, '_consts'):
                 self._consts = {}
             c = self._consts[key] = torch.full((), float(value), device=dev, dtype=torch.float32)
+            if float(value) == 1.0 and c.is_cuda:
+                ops.register_const_one(c)       # (a loss node fed this very tensor as its upstream gradient skips its scaling launch)
         return c
 
     def _side_stream_ok(self, rows):
@@ -830,6 +832,13 @@ class BaseSimulator(Pedestrians):
         ped_features, obs_features, self_features, labels = batch
         predictions = self.model(ped_features, obs_features, self_features)
         pred, p_msg = predictions[0], predictions[1]
+        bm_cp = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
+        if (args.pinnsf_interaction == 'sim' and self.fused_rollout_losses and pred.is_cuda and pred.dtype == torch.float32
+                and pred.dim() == 2 and labels.dim() == 2 and labels.shape[1] >= 6):
+            # :333-352 as ONE launch (ops.pointwise_losses: the three sums and their gradient fields)
+            loss, mse_loss, reg, cp = ops.pointwise_losses(pred, labels, args.reg_weight, p_msg if args.reg_weight > 0 else None,
+                                                           predictions[-1] if bm_cp else None)
+            return loss, mse_loss, (reg if args.reg_weight > 0 else None), (cp if bm_cp else None)
         if args.pinnsf_interaction == 'sim':
             mse_loss = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
         elif args.pinnsf_interaction == 'loss':                                        # PINN-loss pretraining
@@ -870,7 +879,9 @@ class BaseSimulator(Pedestrians):
 
             def one_step():
                 self.optimizer.zero_grad(set_to_none=True)
-                with self._packed_weights():
+                # (deferred_slot_sums: the slot sums of the bottleneck variants' three operators -- head, row decoder, encoders --
+                # become one launch at the block's exit; a fused network has one launch either way)
+                with self._packed_weights(), ops.deferred_slot_sums():
                     terms = self._pointwise_terms(static)
                     terms[0].backward(gradient=one)               # (no ones_like fill in the graph)
                 self.optimizer.step()

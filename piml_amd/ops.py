@@ -924,11 +924,7 @@ class _CollisionPredLoss(torch.autograd.Function):
         if g_loss is None or not any(ctx.needs_input_grad[5:5 + nframes]):
             return none
         grad, = ctx.saved_tensors
-        g = _gpu_f32('g_out', g_loss)
-        gp = torch.empty_like(grad)
-        with torch.cuda.device(grad.device):
-            _lib.check(_lib.lib().piml_collision_pred_loss_bwd(_ptr(g), _ptr(grad), grad.numel(), _ptr(gp), _stream()),
-                       'piml_collision_pred_loss_bwd')
+        gp = _scaled_grad(g_loss, grad)
         return (None,) * 5 + tuple(gp[f].view(shapes[f]) for f in range(nframes)) + (None,) * nframes
 
 
@@ -942,6 +938,91 @@ def collision_pred_loss(pred_frames, feature_frames, gates_f, t_start, T, weight
     if not pred_frames[0].is_cuda:
         raise _lib.PimlHipError('collision_pred_loss: expected GPU tensors (piml_amd has no CPU path)')
     return _CollisionPredLoss.apply(gates_f, int(t_start), int(T), float(weight), len(pred_frames), *pred_frames, *feature_frames)
+
+
+_CONST_ONES = set()        # data pointers of persistent tensors that hold 1.0 and are never written (register_const_one)
+
+
+def register_const_one(t):
+    """`t` (0-dim float32) holds 1.0 for as long as the process lives and nobody writes it (the `gradient=` of a captured step's
+    backward): a loss node whose upstream gradient IS this tensor hands out its stored gradient fields without a scaling launch."""
+    _CONST_ONES.add(t.data_ptr())
+
+
+def _scaled_grad(g_up, grad):
+    """g_up * grad (one launch) -- grad itself when g_up is a registered constant one"""
+    if g_up.data_ptr() in _CONST_ONES and g_up.numel() == 1:
+        return grad
+    g = _gpu_f32('g_out', g_up)
+    out = torch.empty_like(grad)
+    with torch.cuda.device(grad.device):
+        _lib.check(_lib.lib().piml_collision_pred_loss_bwd(_ptr(g), _ptr(grad), grad.numel(), _ptr(out), _stream()), 'piml_collision_pred_loss_bwd')
+    return out
+
+
+class _PointwiseLosses(torch.autograd.Function):
+    """inputs: pred (rows, 2), labels (rows, >= 6 [+ k]), reg_weight, msgs | None, coll_pred (rows, k) | None.
+    outputs: loss, mse, reg, cp (piml_pointwise_losses)."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, reg_weight, msgs, coll):
+        L = _lib.lib()
+        pc = _gpu_f32('pred', pred.detach())
+        lab = _gpu_f32('labels', labels.detach())
+        rows = pc.shape[0]
+        if pc.dim() != 2 or pc.shape[1] != 2 or lab.dim() != 2 or lab.shape[0] != rows or lab.shape[1] < 6:
+            raise ValueError('pointwise_losses: pred (rows, 2), labels (rows, >= 6)')
+        mc = None if msgs is None else _gpu_f32('msgs', msgs.detach())
+        cc = None if coll is None else _gpu_f32('coll_pred', coll.detach())
+        k = 0
+        if cc is not None:
+            k = cc.numel() // rows
+            if cc.numel() != rows * k or lab.shape[1] < 6 + k:
+                raise ValueError('pointwise_losses: coll_pred (rows, k) needs labels (rows, >= 6 + k)')
+        nmsg = 0 if mc is None else mc.numel()
+        dev = pc.device
+        opt = dict(device=dev, dtype=torch.float32)
+        out = torch.empty(4, **opt)
+        grad = torch.empty(2 * rows + nmsg + rows * k, **opt)
+        blocks = L.piml_pointwise_losses_blocks(rows, nmsg, k)
+        partial, ticket = None, None
+        if blocks > 1:
+            partial = torch.empty(blocks, 3, **opt)
+            ticket = _LOSS_TICKETS.get(dev)
+            if ticket is None:       # zeroed once; the launch leaves it zero
+                ticket = _LOSS_TICKETS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(L.piml_pointwise_losses(_ptr(pc), _ptr(lab), lab.shape[1], rows, _ptr(mc), nmsg, float(reg_weight), _ptr(cc), k,
+                                               _ptr(out), _ptr(grad), _ptr(partial), _ptr(ticket), _stream()), 'piml_pointwise_losses')
+        ctx.save_for_backward(grad)
+        ctx.meta = (rows, nmsg, k, tuple(pred.shape), None if msgs is None else tuple(msgs.shape), None if coll is None else tuple(coll.shape))
+        ctx.set_materialize_grads(False)
+        mse, reg, cp = out[1], out[2], out[3]
+        ctx.mark_non_differentiable(mse, reg, cp)        # (the step logs them; the gradient flows through the total)
+        return out[0], mse, reg, cp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, _a, _b, _c):
+        if g_loss is None:
+            return (None,) * 5
+        rows, nmsg, k, s_pred, s_msgs, s_coll = ctx.meta
+        grad, = ctx.saved_tensors
+        g = _scaled_grad(g_loss, grad)
+        need = ctx.needs_input_grad
+        return (g[:2 * rows].view(s_pred) if need[0] else None, None, None,
+                g[2 * rows:2 * rows + nmsg].view(s_msgs) if (nmsg and need[3]) else None,
+                g[2 * rows + nmsg:].view(s_coll) if (k and need[4]) else None)
+
+
+def pointwise_losses(pred, labels, reg_weight=0.0, msgs=None, coll_pred=None):
+    """The loss terms of a pointwise pre-training batch (src/models/simulators.py:333-352, pinnsf_interaction 'sim') as one launch:
+    (loss, mse, reg, cp) with mse = F.mse_loss(pred, labels[:, 4:6], 'sum'), reg = sum(reg_weight |msgs|) (msgs given),
+    cp = F.binary_cross_entropy(coll_pred, labels[:, 6:], 'sum') (coll_pred given), loss = their sum in the reference's order.  The
+    gradient flows through `loss`; the three terms are for the log."""
+    if not pred.is_cuda:
+        raise _lib.PimlHipError('pointwise_losses: expected GPU tensors (piml_amd has no CPU path)')
+    return _PointwiseLosses.apply(pred, labels, float(reg_weight), msgs, coll_pred)
 
 
 def rollout_losses(p, labels, mask_pred, gates, collisions=None, hard_collisions=None, abnormal_mask=None, time_decay=1.0):
@@ -3122,7 +3203,7 @@ class _CollisionHead64(torch.autograd.Function):
             ctx.save_for_backward(x2, hidden, out, *wb)
         ctx.x_shape = tuple(x.shape)
         ctx.sink = ParamGradSink._active if need_grad else None
-        ctx.params = (w1, b1, w2, b2) if ctx.sink is not None else None
+        ctx.params = (w1, b1, w2, b2) if need_grad else None     # (the Parameter objects: the sink's keys / the deferral's .grad test)
         ctx.set_materialize_grads(False)
         return out.view(x.shape[:-1])
 

@@ -307,3 +307,47 @@ def test_collision_pred_loss_equals_the_torch_expression(C, T, N, k, t_start):
     # deterministic
     l2, _ = ops.collision_pred_loss([p.detach() for p in preds], feats, gates_f, t_start, T, weight)
     assert torch.equal(l2, got_loss.detach())
+
+
+@pytest.mark.parametrize('rows,k,with_reg,with_cp', [(128, 6, True, True), (1024, 6, False, True), (4096, 6, True, False), (37, 6, False, False)])
+def test_pointwise_losses_equal_the_torch_expressions(rows, k, with_reg, with_cp):
+    """ops.pointwise_losses (one launch) against src/models/simulators.py:333-352: mse_loss(sum) on labels[:, 4:6], the L1 regulariser
+    of the messages, binary_cross_entropy(sum) on labels[:, 6:], their sum in the reference's order, and the gradients."""
+    import torch.nn.functional as F
+    from piml_amd import ops
+    g = torch.Generator().manual_seed(9)
+    pred = torch.randn(rows, 2, generator=g).to(DEV).requires_grad_(True)
+    msgs = (torch.randn(rows, k, 2, generator=g)).to(DEV).requires_grad_(True)
+    with torch.no_grad():
+        msgs.view(-1)[:3] = torch.tensor([0.0, -0.0, 1e-30], device=DEV)
+    coll = torch.rand(rows, k, generator=g)
+    coll.view(-1)[:3] = torch.tensor([0.5, 1e-30, 1.0 - 1e-7])
+    coll = coll.to(DEV).requires_grad_(True)
+    labels = torch.cat((torch.randn(rows, 6, generator=g), (torch.rand(rows, k, generator=g) < 0.2).float()), 1).to(DEV)
+    w = 1e-2
+    got = ops.pointwise_losses(pred, labels, w if with_reg else 0.0, msgs if with_reg else None, coll if with_cp else None)
+    (got[0] * 0.7).backward()
+    got_g = [t.grad.clone() if t.grad is not None else None for t in (pred, msgs, coll)]
+    for t in (pred, msgs, coll):
+        t.grad = None
+    mse = F.mse_loss(pred, labels[:, 4:6], reduction='sum')
+    loss = mse
+    reg = cp = None
+    if with_reg:
+        reg = torch.sum(w * torch.abs(msgs))
+        loss = loss + reg
+    if with_cp:
+        cp = F.binary_cross_entropy(coll, labels[:, 6:], reduction='sum')
+        loss = loss + cp
+    (loss * 0.7).backward()
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+    assert rel(got[0], loss) <= 2e-6 and rel(got[1], mse) <= 2e-6
+    if with_reg:
+        assert rel(got[2], reg) <= 2e-6
+    if with_cp:
+        assert rel(got[3], cp) <= 2e-6
+    for a, t in zip(got_g, (pred, msgs, coll)):
+        if t.grad is None:
+            assert a is None
+        else:
+            assert torch.allclose(a, t.grad, rtol=2e-6, atol=1e-7)
