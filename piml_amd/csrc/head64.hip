@@ -218,6 +218,106 @@ __global__ __launch_bounds__(256) void head64_bwd_kernel(piml_head64 A) {
     for (int e = threadIdx.x; e < H64_PART; e += 256) out[e] = e < HD * HD + 2 * HD + 1 ? P[e] : 0.f;
 }
 
+// The same backward with the FOUR waves of a workgroup on ONE tile (few rows: the training loops' 3 000 neighbour rows are 92 tiles =
+// 23 workgroups of the kernel above, each wave a chain of 128 dependent-issue matrix instructions and the workgroup a four-step
+// serial sum; here 92 workgroups, wave w = (K half w >> 1, output block w & 1) of g_x -- the halves meet in LDS, fixed order -- and
+// block (w >> 1, w & 1) of dW1: 16 + 16 instructions per wave, disjoint blocks, no serial sum; round 6).  One slot per TILE.
+__global__ __launch_bounds__(256) void head64_bwd_coop_kernel(piml_head64 A) {
+    __shared__ __attribute__((aligned(16))) float lds[4][32 * HD];       // per wave: its transposed 32 x 64 tile; later the slot image
+    __shared__ __attribute__((aligned(16))) float gxp[2][16][64];        // g_x partials of the waves with K half 1: [block][register][lane]
+    const int lane = threadIdx.x & 63, wave = uniform((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    const int wb = wave & 1, wk = wave >> 1;                             // g_x: output block / K half;  dW1: block (ob = wk, blk = wb)
+    const long long tile = blockIdx.x;
+    const long long row = tile * 32 + j;
+    const bool valid = row < A.rows;
+    const long long rr = valid ? row : 0;
+    float* T = lds[wave];
+    float gz = 0.f;
+    if (valid) {
+        const float o = A.out[row];
+        gz = A.g_out[row] * o * (1.f - o);
+    }
+    // this wave's half of the hidden features (block wk): g_hid (accumulator layout) and gz * hid
+    float ghv[16], gzh[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 hv = *reinterpret_cast<const float4*>(A.hidden + rr * HD + hfeat0(wk, q, h));
+        const float4 w2 = *reinterpret_cast<const float4*>(A.w2 + hfeat0(wk, q, h));
+        const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, ww[4] = {w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ghv[4 * q + u] = hh[u] > 0.f ? gz * ww[u] : 0.f;
+            gzh[4 * q + u] = gz * hh[u];
+        }
+    }
+    // ---- g_x block wb over the K half wk ----
+    f32x16 gx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+    if (A.g_x) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float w[4];                                                   // lane (i = j, h): W1[32 wk + 8 q + 4 h + u][32 wb + i]
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = A.w1[(size_t)(hfeat0(wk, q, h) + u) * HD + 32 * wb + j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gx = hmfma(w[u], ghv[4 * q + u], gx);
+        }
+        if (wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gxp[wb][r][lane] = gx[r];
+        }
+    }
+    // ---- this wave's transposed half tile: T[row j][feature f of block wk] ----
+    auto put = [&](const float (&v)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(T + j * HD + hfeat0(0, q, h)) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    };
+    put(ghv);
+    __syncthreads();
+    if (A.g_x && wk == 0 && valid) {
+        float* o = A.g_x + row * HD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(o + hfeat0(wb, q, h)) =
+                make_float4(gx[4 * q] + gxp[wb][4 * q][lane], gx[4 * q + 1] + gxp[wb][4 * q + 1][lane], gx[4 * q + 2] + gxp[wb][4 * q + 2][lane],
+                            gx[4 * q + 3] + gxp[wb][4 * q + 3][lane]);
+    }
+    // ---- dW1 block (wk, wb) = g_hid[:, block wk]^T x[:, block wb] over the tile's 32 rows ----
+    f32x16 dw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+    float s_db1 = 0.f, s_dw2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                                        // k-step s: rows 2 s + h of the tile
+        const long long xrow = tile * 32 + 2 * s + h;
+        const float b0 = A.x[(xrow < A.rows ? xrow : 0) * HD + 32 * wb + j];
+        const float a0 = T[(2 * s + h) * HD + j];
+        dw = hmfma(a0, b0, dw);
+        s_db1 += a0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    put(gzh);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) s_dw2 += T[(2 * s + h) * HD + j];
+    s_db1 += __shfl_xor(s_db1, 32, 64);
+    s_dw2 += __shfl_xor(s_dw2, 32, 64);
+    float s_db2 = h == 0 ? gz : 0.f;
+    s_db2 = wave_sum(s_db2);
+    // ---- the slot: disjoint blocks, every wave writes its own ----
+    float* out = A.partials + (size_t)blockIdx.x * H64_PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(32 * wk + (r & 3) + 8 * (r >> 2) + 4 * h) * HD + 32 * wb + j] = dw[r];
+    if (wb == 0 && h == 0) {
+        out[HD * HD + 32 * wk + j] = s_db1;
+        out[HD * HD + HD + 32 * wk + j] = s_dw2;
+    }
+    if (wave == 0 && lane < 4) out[HD * HD + 2 * HD + lane] = lane == 0 ? s_db2 : 0.f;
+}
+
 __global__ __launch_bounds__(256) void head64_reduce_kernel(const float* __restrict__ partials, float* __restrict__ grads, int slots,
                                                             int accumulate) {
     sum_slots_16x16(partials, grads, slots, H64_PART / 4, 0x7fffffff, 0, 0, accumulate != 0);
@@ -228,7 +328,12 @@ __global__ __launch_bounds__(256) void head64_reduce_kernel(const float* __restr
 using namespace piml;
 
 PIML_API int piml_head64_partial_floats(void) { return H64_PART; }
-PIML_API int piml_head64_slots(long long rows) { return rows <= 0 ? 0 : (int)((rows + 127) / 128); }
+// one slot per workgroup: four tiles per workgroup above kHead64CoopTiles tiles, one tile per workgroup (head64_bwd_coop_kernel) below
+constexpr long long kHead64CoopTiles = 2048;
+static bool head64_coop(long long rows) { return (rows + 31) / 32 <= kHead64CoopTiles; }
+PIML_API int piml_head64_slots(long long rows) {
+    return rows <= 0 ? 0 : (int)(head64_coop(rows) ? (rows + 31) / 32 : (rows + 127) / 128);
+}
 
 static int head64_check(const piml_head64* A, bool bwd) {
     if (!A || A->rows < 0 || A->rows >= (1ll << 25)) return hipErrorInvalidValue;
@@ -241,7 +346,7 @@ static int head64_check(const piml_head64* A, bool bwd) {
 PIML_API int piml_head64_fwd(const piml_head64* A, void* stream) {
     if (int e = head64_check(A, false)) return e;
     if (A->rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(head64_fwd_kernel, dim3((unsigned)piml_head64_slots(A->rows)), dim3(256), 0, as_stream(stream), *A);
+    hipLaunchKernelGGL(head64_fwd_kernel, dim3((unsigned)((A->rows + 127) / 128)), dim3(256), 0, as_stream(stream), *A);
     trace_mark("head64_fwd", as_stream(stream));
     return hipGetLastError();
 }
@@ -252,7 +357,8 @@ PIML_API int piml_head64_bwd_acc(const piml_head64* A, int accumulate, void* str
     if (int e = head64_check(A, true)) return e;
     if (A->rows == 0) return hipSuccess;
     const int slots = piml_head64_slots(A->rows);
-    hipLaunchKernelGGL(head64_bwd_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), *A);
+    if (head64_coop(A->rows)) hipLaunchKernelGGL(head64_bwd_coop_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), *A);
+    else hipLaunchKernelGGL(head64_bwd_kernel, dim3((unsigned)slots), dim3(256), 0, as_stream(stream), *A);
     // `accumulate`: 0 / 1, or flags -- PIML_ACCUMULATE and / or PIML_DEFER_SLOT_SUMS (the header)
     const bool acc = (accumulate & 1) || (accumulate & PIML_ACCUMULATE);
     if (accumulate & PIML_DEFER_SLOT_SUMS) {          // the slot sums ride in the relfeat backward's launch (network.hip)

@@ -802,7 +802,7 @@ def test_split_products_hold_across_magnitudes(xscale, wscale):
     assert worst <= 1e-6
 
 
-@pytest.mark.parametrize('rows', [(4096, 6), (122, 6), (1, 1), (37, 5), (3, 250, 6)])
+@pytest.mark.parametrize('rows', [(4096, 6), (122, 6), (1, 1), (37, 5), (3, 250, 6), (4096, 17), (4 * 122, 6)])       # (4096 x 17: above the one-tile-per-workgroup bound)
 def test_collision_head64_matches_float64(rows):
     """ops.collision_head64 (`pinnsf_bm`'s collision head, src/models/model.py:1183, 1214-1215, on head64.hip) against a
     float64 evaluation: output and every gradient; and bit-reproducible (no atomics)."""
