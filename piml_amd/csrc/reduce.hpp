@@ -28,7 +28,10 @@ struct UnfoldSet {
     float* egrads;         // encoder `grads` (ENC_PART layout)
 };
 struct ReduceAll {
-    ReduceSet set[8];     // (the bottleneck variants leave 4 encoder + 2 row decoder + 1 head sets in one backward pass)
+#ifndef PIML_REDUCE_SETS
+#define PIML_REDUCE_SETS 8       // (the bottleneck variants leave 4 encoder + 2 row decoder + 1 head sets in one backward pass)
+#endif
+    ReduceSet set[PIML_REDUCE_SETS];
     int nsets;
     int accumulate;       // PIML_ACCUMULATE: grads += the sums
     int gx;               // workgroups per set (the widest set's (lanes + 15) / 16)

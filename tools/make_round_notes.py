@@ -85,6 +85,16 @@ with open(os.path.join(dst, f'{TAG}_other_kernels.md'), 'w') as f:
         ps = per_step(csvname, 'rollout_losses_kernel')
         if ps:
             f.write(f'- `{name}`: {ps[0]:.1f} kernels per step, {ps[1]:.1f} of them this repository\'s ({ps[2]} steps profiled; `profiles/{csvname}`)\n')
+    # (round 6) ordered kernel lists of the captured steps, the loop with and without train()'s lookahead, the row decoder A/B
+    for name in ('finetune_step_pinnsf_m.txt', 'finetune_step_pinnsf_bm.txt', 'pointwise_step_pinnsf_m.txt', 'pointwise_step_pinnsf_bm.txt'):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f'{TAG}_{name}'))
+            last = open(os.path.join(src, name)).read().strip().splitlines()[-1]
+            f.write(f'- ordered list (durations, gaps) `profiles/{TAG}_{name}`: {last.lstrip("# ")} (under the profiler)\n')
+    if os.path.exists(os.path.join(src, 'time_finetune.log')):
+        f.write('\nThe fine-tuning step timed as `train_batch()` in a loop and as `train()` runs it (`tools/time_finetune.py`):\n\n```\n' + log('time_finetune.log') + '\n```\n')
+    if os.path.exists(os.path.join(src, 'time_rowdec.log')):
+        f.write('\n## The row decoder at 24 576 + 40 960 rows, f32 instruction (`*_big` / `*_lds`) against split bf16 products (`*_x3`) (`tools/time_rowdec.py`)\n\n```\n' + log('time_rowdec.log') + '\n```\n')
     if os.path.exists(os.path.join(dst, f'{TAG}_pinnsf_res_kernel_stats.csv')):
         f.write('\n## Kernel mix of the `pinnsf_res` step at cfg3 (`tools/time_res.py`)\n\n' + top(f'{TAG}_pinnsf_res_kernel_stats.csv', 18) + '\n\n')
     f.write('## Forward + backward step at cfg3 by model (`tools/time_models.py`)\n\n```\n' + log('time_models.log', ['ms/step']) + '\n```\n\n')

@@ -31,3 +31,12 @@ for MODEL in pinnsf_m pinnsf_bm; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/res -- python3 $R/tools/time_res.py > $O/res.log 2>&1
 cp $(ls $O/res/*/*kernel_stats.csv | head -1) $O/pinnsf_res_kernel_stats.csv; rm -rf $O/res
+# (round 6) the fine-tuning / pointwise steps as ordered kernel lists, the loop timed synchronously and with train()'s lookahead,
+# the row decoder's many-rows kernels in both arithmetic forms
+cd $R
+for MODEL in pinnsf_m pinnsf_bm; do
+  FT_MODEL=$MODEL bash tools/r5_ft_trace.sh > /dev/null 2>&1; cp gpurun_out/r5ft/step.txt $O/finetune_step_${MODEL}.txt
+  MODEL=$MODEL P=0 bash tools/r6_pw_trace.sh > /dev/null 2>&1; cp gpurun_out/r6pw/step.txt $O/pointwise_step_${MODEL}.txt
+  python3 tools/time_finetune.py 100 $MODEL 2>&1 | grep fine-tune >> $O/time_finetune.log
+done
+bash tools/prof_script.sh tools/time_rowdec.py 2>&1 | grep rowdec > $O/time_rowdec.log
