@@ -486,6 +486,29 @@ int piml_train_step_bwd7(const float* g_position_out, long long g_position_out_s
                          const float* g_state6, const float* g_position_in, long long g_position_in_slice_stride,
                          const unsigned char* new_flag, const unsigned char* zero_mask, int C, int T, int N, int t_next, float dt,
                          float* g_position, float* g_velocity, float* g_acceleration, float* g_a_pred, void* stream);
+/* The frame step with the model's TAIL in front of it, one launch each way.  In the training rollout the network sees channelled
+ * (C, N, .) input, where the reference's desired-force term takes its norm over the AGENT axis (quirk Q2: `torch.norm(self_features[...,
+ * :2], p=2, dim=1, keepdim=True)`, src/models/model.py:1290 / :1125 as evaluated at src/models/simulators.py:701), so the tail
+ *     predictions = sum_k acc_ped[c, n, k] (+ sum_k acc_obs[c, n, k]) + (v0 d / t - v) / tau,   t[c, comp] = || d[c, :, comp] ||_2 (0 -> 0.1)
+ * is a reduction over a slice's agents followed by piml_train_step_fwd_copy on the result (a_pred = predictions).  acc_ped (C, N, kp, 2):
+ * the decoder tails' sum (kp = 1) or the bottleneck variants' per-neighbour predictions; acc_obs likewise or NULL; self_features
+ * (C, N, 7).  Backward = piml_train_step_bwd7, then with g = d/d(predictions) (written to g_prediction (C, N, 2), required):
+ * g_acc_ped (C, N, kp, 2) / g_acc_obs = g broadcast over k (NULL: not written -- for kp = 1 g_prediction IS that gradient), g_self
+ * (C, N, 7) = piml_pinnsf_epilogue_agentnorm_bwd's (may be NULL).  Bitwise what the separate launches produce. */
+int piml_train_step_tail_fwd(const float* position, const float* velocity, const float* acceleration, const float* acc_ped, int kp,
+                             const float* acc_obs, int ko, const float* self_features, float tau, const float* destination,
+                             const int64_t* dest_idx, const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                             const uint8_t* new_flag, const float* position_series, const float* velocity_series,
+                             const float* acceleration_series, const float* destination_series, const int64_t* dest_idx_series, int C,
+                             int T, int N, int t_next, float dt, float* position_out, float* velocity_out, float* acceleration_out,
+                             float* destination_out, int64_t* dest_idx_out, int* nan_flag, uint8_t* zero_mask, float* position_copy,
+                             long long position_copy_slice_stride, void* stream);
+int piml_train_step_tail_bwd(const float* g_position_out, long long g_position_out_slice_stride, const float* g_velocity_out,
+                             const float* g_acceleration_out, const float* g_state6, const float* g_position_in,
+                             long long g_position_in_slice_stride, const unsigned char* new_flag, const unsigned char* zero_mask, int C,
+                             int T, int N, int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration,
+                             float* g_prediction, const float* self_features, float tau, int kp, int ko, float* g_acc_ped,
+                             float* g_acc_obs, float* g_self, void* stream);
 
 
 /*

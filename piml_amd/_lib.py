@@ -91,6 +91,9 @@ SIGNATURES = {
     'piml_train_step_bwd6': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_pinnsf_unfold_defer': [_i, _p],
     'piml_train_step_bwd7': [_p, _ll, _p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p],
+    'piml_train_step_tail_fwd': [_p, _p, _p, _p, _i, _p, _i, _p, _f, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f,
+                                 _p, _p, _p, _p, _p, _p, _p, _p, _ll, _p],
+    'piml_train_step_tail_bwd': [_p, _ll, _p, _p, _p, _p, _ll, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _f, _i, _i, _p, _p, _p, _p],
     'piml_pinnsf_epilogue_fwd': [_p, _p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_bwd': [_p, _p, _z, _f, _p, _p],
     'piml_pinnsf_epilogue_ksum_fwd': [_p, _i, _p, _i, _p, _z, _f, _p, _p],

@@ -1724,13 +1724,9 @@ struct TrainStepArgs {
 
 // One thread per (slice, agent): lagged explicit Euler, waypoint switch at 0.5 m (nobody is removed
 // in the training rollout), then agents entering at frame t_next are re-initialised from the series.
-__global__ void train_step_fwd_kernel(const TrainStepArgs A) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)A.C * A.N) return;
-    const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
+__device__ __forceinline__ void train_step_agent(const TrainStepArgs& A, long long g, int c, int i, float2 an) {
     const float2 p = A.p[g], v = A.v[g], a = A.a[g], d = A.dest[g];
     if (A.p_copy) A.p_copy[(size_t)c * A.p_copy_cstride + i] = p;      // frame t of the (C, T, N, 2) positions the rollout loss reads
-    float2 an = A.a_pred[g];
     if (A.nan_flag && (an.x != an.x || an.y != an.y)) atomicOr(A.nan_flag, 1);           // :745
     float2 vn = make_float2(__fadd_rn(v.x, __fmul_rn(a.x, A.dt)), __fadd_rn(v.y, __fmul_rn(a.y, A.dt)));   // :741
     float2 pn = make_float2(__fadd_rn(p.x, __fmul_rn(v.x, A.dt)), __fadd_rn(p.y, __fmul_rn(v.y, A.dt)));   // :742
@@ -1755,19 +1751,97 @@ __global__ void train_step_fwd_kernel(const TrainStepArgs A) {
     A.p_out[g] = pn; A.v_out[g] = vn; A.a_out[g] = an; A.dest_out[g] = dn; A.dest_idx_out[g] = idx;
 }
 
+__global__ void train_step_fwd_kernel(const TrainStepArgs A) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)A.C * A.N) return;
+    const int c = (int)(g / A.N), i = (int)(g - (long long)c * A.N);
+    train_step_agent(A, g, c, i, A.a_pred[g]);
+}
+
+// ---- the step with the model's TAIL in front of it (round 6): in the training rollout the network's output is channelled,
+// (C, N, .), and the reference's desired-force term takes its norm over the AGENT axis (quirk Q2, src/models/model.py:1290 as
+// evaluated at src/models/simulators.py:701) -- a reduction over a slice's agents, which kept this tail a launch of its own
+// (pinnsf_epilogue_agentnorm_fwd_kernel, mlpglue.hip) between the network and the step.  One workgroup per slice does both: the
+// two norms (the SAME block reduction, so the same bits), then per agent the prediction = sum of the kp (+ ko) per-neighbour
+// outputs + (v0 d / t - v) / tau and the step on it.  Backward likewise: the step's gradients, then the tail's (sum_n g_e d over
+// the slice, g_self, the broadcast to the neighbour rows). ----
+struct TailArgs {
+    const float2 *acc_ped, *acc_obs;     // (C, N, kp, 2) / (C, N, ko, 2) or NULL
+    int kp, ko;
+    const float* sf;                     // (C, N, 7)
+    float tau;
+};
+
+__device__ __forceinline__ float2 tail_block_sum2(float2 v, float2* sh) {      // = block_sum2 of mlpglue.hip (256 threads)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v.x = wave_sum(v.x);
+    v.y = wave_sum(v.y);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float2 s = make_float2(0.f, 0.f);
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        s.x += sh[w].x;
+        s.y += sh[w].y;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void train_step_tail_fwd_kernel(const TrainStepArgs A, const TailArgs E) {
+    __shared__ float2 sh[4];
+    const int c = blockIdx.x, N = A.N;
+    const size_t base = (size_t)c * N;
+    float2 sq = make_float2(0.f, 0.f);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = E.sf + (base + n) * 7;
+        sq.x += s[0] * s[0];
+        sq.y += s[1] * s[1];
+    }
+    sq = tail_block_sum2(sq, sh);
+    float tx = sqrtf(sq.x), ty = sqrtf(sq.y);
+    tx = (tx == 0.f) ? tx + 0.1f : tx;
+    ty = (ty == 0.f) ? ty + 0.1f : ty;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = E.sf + (base + n) * 7;
+        float2 a = make_float2(0.f, 0.f);
+        for (int i = 0; i < E.kp; ++i) {
+            const float2 q = E.acc_ped[(base + n) * E.kp + i];
+            a.x += q.x; a.y += q.y;
+        }
+        if (E.acc_obs) {
+            float2 o = make_float2(0.f, 0.f);
+            for (int i = 0; i < E.ko; ++i) {
+                const float2 q = E.acc_obs[(base + n) * E.ko + i];
+                o.x += q.x; o.y += q.y;
+            }
+            a.x += o.x;
+            a.y += o.y;
+        }
+        train_step_agent(A, (long long)(base + n), c, n,
+                         make_float2(a.x + (s[6] * (s[0] / tx) - s[2]) / E.tau, a.y + (s[6] * (s[1] / ty) - s[3]) / E.tau));
+    }
+}
+
 // keep = agent not re-initialised at t_next:  g_p = keep g_p',  g_v = keep (g_v' + dt g_p'),
 // g_a = keep dt g_v',  g_a_pred = keep g_a'.
-__global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
-                                      const float2* __restrict__ ga_o, const float2* __restrict__ g6,
-                                      const unsigned char* __restrict__ new_flag,
-                                      const unsigned char* __restrict__ zero_mask, int C, int T, int N, int t_next,
-                                      float dt, float2* __restrict__ gp,
-                                      float2* __restrict__ gv, float2* __restrict__ ga,
-                                      float2* __restrict__ ga_pred, const float2* __restrict__ gp_in = nullptr,
-                                      long long gp_in_cstride = 0, long long gp_o_cstride = 0) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)C * N) return;
-    const int c = (int)(g / N), i = (int)(g - (long long)c * N);
+struct TrainBwdArgs {
+    const float2 *gp_o, *gv_o, *ga_o, *g6;
+    const unsigned char *new_flag, *zero_mask;
+    int C, T, N, t_next;
+    float dt;
+    float2 *gp, *gv, *ga, *ga_pred;
+    const float2* gp_in;
+    long long gp_in_cstride, gp_o_cstride;
+};
+
+// one agent of train_step_bwd_kernel; returns d/d(a_pred)
+__device__ __forceinline__ float2 train_step_bwd_agent(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
+                                                       const float2* __restrict__ ga_o, const float2* __restrict__ g6,
+                                                       const unsigned char* __restrict__ new_flag,
+                                                       const unsigned char* __restrict__ zero_mask, int T, int N, int t_next, float dt,
+                                                       float2* __restrict__ gp, float2* __restrict__ gv, float2* __restrict__ ga,
+                                                       float2* __restrict__ ga_pred, const float2* __restrict__ gp_in,
+                                                       long long gp_in_cstride, long long gp_o_cstride, long long g, int c, int i) {
     bool keep = true;
     if (new_flag && t_next < T) keep = new_flag[((size_t)c * T + t_next) * N + i] == 0;
     const float2 z = make_float2(0.f, 0.f);
@@ -1793,6 +1867,65 @@ __global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const flo
     if (gv) gv[g] = make_float2(b.x + dt * a.x, b.y + dt * a.y);
     if (ga) ga[g] = make_float2(dt * b.x, dt * b.y);
     if (ga_pred) ga_pred[g] = e;
+    return e;
+}
+
+__global__ void train_step_bwd_kernel(const float2* __restrict__ gp_o, const float2* __restrict__ gv_o,
+                                      const float2* __restrict__ ga_o, const float2* __restrict__ g6,
+                                      const unsigned char* __restrict__ new_flag,
+                                      const unsigned char* __restrict__ zero_mask, int C, int T, int N, int t_next,
+                                      float dt, float2* __restrict__ gp,
+                                      float2* __restrict__ gv, float2* __restrict__ ga,
+                                      float2* __restrict__ ga_pred, const float2* __restrict__ gp_in = nullptr,
+                                      long long gp_in_cstride = 0, long long gp_o_cstride = 0) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)C * N) return;
+    const int c = (int)(g / N), i = (int)(g - (long long)c * N);
+    train_step_bwd_agent(gp_o, gv_o, ga_o, g6, new_flag, zero_mask, T, N, t_next, dt, gp, gv, ga, ga_pred, gp_in, gp_in_cstride,
+                         gp_o_cstride, g, c, i);
+}
+
+// the step's backward and the tail's (pinnsf_epilogue_agentnorm_bwd_kernel's arithmetic + the broadcast to the neighbour rows),
+// one workgroup per slice; B.ga_pred (C, N, 2) is written first and read back by the same thread: it is d/d(prediction), i.e.
+// the gradient of every summand of the tail's sum
+__global__ __launch_bounds__(256) void train_step_tail_bwd_kernel(const TrainBwdArgs B, const float* __restrict__ sf, float tau, int kp, int ko,
+                                                                  float2* __restrict__ g_ped, float2* __restrict__ g_obs,
+                                                                  float* __restrict__ g_self) {
+    __shared__ float2 sh[4];
+    const int c = blockIdx.x, N = B.N;
+    const size_t base = (size_t)c * N;
+    float2 sq = make_float2(0.f, 0.f), dot = make_float2(0.f, 0.f);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float2 g = train_step_bwd_agent(B.gp_o, B.gv_o, B.ga_o, B.g6, B.new_flag, B.zero_mask, B.T, N, B.t_next, B.dt, B.gp, B.gv, B.ga,
+                                              B.ga_pred, B.gp_in, B.gp_in_cstride, B.gp_o_cstride, (long long)(base + n), c, n);
+        const float* s = sf + (base + n) * 7;
+        sq.x += s[0] * s[0];
+        sq.y += s[1] * s[1];
+        dot.x += (g.x * s[6] / tau) * s[0];
+        dot.y += (g.y * s[6] / tau) * s[1];
+    }
+    sq = tail_block_sum2(sq, sh);
+    dot = tail_block_sum2(dot, sh);
+    const float nx = sqrtf(sq.x), ny = sqrtf(sq.y);
+    const float tx = (nx == 0.f) ? nx + 0.1f : nx, ty = (ny == 0.f) ? ny + 0.1f : ny;
+    const float gtx = -dot.x / (tx * tx), gty = -dot.y / (ty * ty);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float* s = sf + (base + n) * 7;
+        const float2 g = B.ga_pred[base + n];
+        if (g_self) {
+            const float gex = g.x * s[6] / tau, gey = g.y * s[6] / tau;
+            float* o = g_self + (base + n) * 7;
+            o[0] = gex / tx + (nx != 0.f ? gtx * (s[0] / nx) : 0.f);
+            o[1] = gey / ty + (ny != 0.f ? gty * (s[1] / ny) : 0.f);
+            o[2] = -g.x / tau;
+            o[3] = -g.y / tau;
+            o[4] = 0.f;
+            o[5] = 0.f;
+            o[6] = (g.x * (s[0] / tx) + g.y * (s[1] / ty)) / tau;
+        }
+        if (g_ped) for (int i = 0; i < kp; ++i) g_ped[(base + n) * kp + i] = g;
+        if (g_obs) for (int i = 0; i < ko; ++i) g_obs[(base + n) * ko + i] = g;
+    }
 }
 
 // ---- collision post-correction of PINNSF_polar_bottleneck_collision (src/models/model.py:1383-1444) ----
@@ -2027,7 +2160,8 @@ static int train_step_fwd_impl(const float* position, const float* velocity, con
                                const float* destination_series, const int64_t* dest_idx_series, int C, int T,
                                int N, int t_next, float dt, float* position_out, float* velocity_out,
                                float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
-                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream);
+                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream,
+                               const piml::TailArgs* tail = nullptr);
 
 PIML_API int piml_train_step_fwd(const float* position, const float* velocity, const float* acceleration,
                                  const float* a_pred, const float* destination, const int64_t* dest_idx,
@@ -2069,10 +2203,11 @@ static int train_step_fwd_impl(const float* position, const float* velocity, con
                                const float* destination_series, const int64_t* dest_idx_series, int C, int T,
                                int N, int t_next, float dt, float* position_out, float* velocity_out,
                                float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
-                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream) {
+                               int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride, void* stream,
+                               const piml::TailArgs* tail) {
     if (C < 0 || T <= 0 || N < 0 || D <= 0 || t_next < 0) return hipErrorInvalidValue;
     if ((long)C * N == 0) return hipSuccess;
-    if (!position || !velocity || !acceleration || !a_pred || !destination || !dest_idx || !waypoints || !dest_num ||
+    if (!position || !velocity || !acceleration || (!a_pred && !tail) || !destination || !dest_idx || !waypoints || !dest_num ||
         !position_out || !velocity_out || !acceleration_out || !destination_out || !dest_idx_out)
         return hipErrorInvalidValue;
     if (new_flag && t_next < T &&
@@ -2092,9 +2227,34 @@ static int train_step_fwd_impl(const float* position, const float* velocity, con
     A.C = C; A.T = T; A.N = N; A.t_next = t_next; A.dt = dt;
     A.p_copy = (float2*)position_copy; A.p_copy_cstride = position_copy_slice_stride / 2;
     const long n = (long)C * N;
-    hipLaunchKernelGGL(piml::train_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       piml::as_stream(stream), A);
+    if (tail)
+        hipLaunchKernelGGL(piml::train_step_tail_fwd_kernel, dim3((unsigned)C), dim3(256), 0, piml::as_stream(stream), A, *tail);
+    else
+        hipLaunchKernelGGL(piml::train_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           piml::as_stream(stream), A);
     return hipGetLastError();
+}
+
+PIML_API int piml_train_step_tail_fwd(const float* position, const float* velocity, const float* acceleration,
+                                      const float* acc_ped, int kp, const float* acc_obs, int ko, const float* self_features, float tau,
+                                      const float* destination, const int64_t* dest_idx,
+                                      const float* waypoints, int D, int waypoints_per_slice, const int64_t* dest_num,
+                                      const uint8_t* new_flag, const float* position_series,
+                                      const float* velocity_series, const float* acceleration_series,
+                                      const float* destination_series, const int64_t* dest_idx_series, int C, int T,
+                                      int N, int t_next, float dt, float* position_out, float* velocity_out,
+                                      float* acceleration_out, float* destination_out, int64_t* dest_idx_out,
+                                      int* nan_flag, uint8_t* zero_mask, float* position_copy, long long position_copy_slice_stride,
+                                      void* stream) {
+    if (!acc_ped || kp < 1 || (acc_obs && ko < 1) || !self_features || (position_copy && (position_copy_slice_stride & 1)))
+        return hipErrorInvalidValue;
+    piml::TailArgs E;
+    E.acc_ped = (const float2*)acc_ped; E.acc_obs = (const float2*)acc_obs; E.kp = kp; E.ko = acc_obs ? ko : 1;
+    E.sf = self_features; E.tau = tau;
+    return train_step_fwd_impl(position, velocity, acceleration, nullptr, destination, dest_idx, waypoints, D, waypoints_per_slice, dest_num,
+                               new_flag, position_series, velocity_series, acceleration_series, destination_series, dest_idx_series, C, T, N,
+                               t_next, dt, position_out, velocity_out, acceleration_out, destination_out, dest_idx_out, nan_flag, zero_mask,
+                               position_copy, position_copy_slice_stride, stream, &E);
 }
 
 PIML_API int piml_train_step_bwd(const float* g_position_out, const float* g_velocity_out,
@@ -2139,6 +2299,27 @@ PIML_API int piml_train_step_bwd7(const float* g_position_out, long long g_posit
                        (const float2*)g_acceleration_out, (const float2*)g_state6, new_flag, zero_mask, C, T, N, t_next, dt,
                        (float2*)g_position, (float2*)g_velocity, (float2*)g_acceleration, (float2*)g_a_pred,
                        (const float2*)g_position_in, g_position_in_slice_stride / 2, g_position_out_slice_stride / 2);
+    return hipGetLastError();
+}
+
+PIML_API int piml_train_step_tail_bwd(const float* g_position_out, long long g_position_out_slice_stride, const float* g_velocity_out,
+                                      const float* g_acceleration_out, const float* g_state6, const float* g_position_in,
+                                      long long g_position_in_slice_stride, const unsigned char* new_flag, const unsigned char* zero_mask,
+                                      int C, int T, int N, int t_next, float dt, float* g_position, float* g_velocity, float* g_acceleration,
+                                      float* g_prediction, const float* self_features, float tau, int kp, int ko, float* g_acc_ped,
+                                      float* g_acc_obs, float* g_self, void* stream) {
+    if (C < 0 || N < 0 || T < 0 || (g_position_in && (g_position_in_slice_stride & 1)) || (g_position_out_slice_stride & 1) || kp < 1 ||
+        (g_acc_obs && ko < 1))
+        return hipErrorInvalidValue;
+    if ((long)C * N == 0) return hipSuccess;
+    if (!g_prediction || !self_features) return hipErrorInvalidValue;
+    piml::TrainBwdArgs B;
+    B.gp_o = (const float2*)g_position_out; B.gv_o = (const float2*)g_velocity_out; B.ga_o = (const float2*)g_acceleration_out;
+    B.g6 = (const float2*)g_state6; B.new_flag = new_flag; B.zero_mask = zero_mask; B.C = C; B.T = T; B.N = N; B.t_next = t_next; B.dt = dt;
+    B.gp = (float2*)g_position; B.gv = (float2*)g_velocity; B.ga = (float2*)g_acceleration; B.ga_pred = (float2*)g_prediction;
+    B.gp_in = (const float2*)g_position_in; B.gp_in_cstride = g_position_in_slice_stride / 2; B.gp_o_cstride = g_position_out_slice_stride / 2;
+    hipLaunchKernelGGL(piml::train_step_tail_bwd_kernel, dim3((unsigned)C), dim3(256), 0, piml::as_stream(stream), B, self_features, tau, kp,
+                       g_acc_obs ? ko : 1, (float2*)g_acc_ped, (float2*)g_acc_obs, g_self);
     return hipGetLastError();
 }
 

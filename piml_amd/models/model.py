@@ -195,6 +195,9 @@ class _PINNSFBase(nn.Module):
     collision_head = None       # None | 'msgs' (pinnsf_m) | 'decoded' (pinnsf_bm)
     defer_ksum_epilogue = False # set around an inference frame's forward by BaseSimulator: the bottleneck variants leave their epilogue
     pending_ksum = None         # (neighbour-axis sums + desired force) to the integrator launch and park its operands here
+    defer_train_tail = False    # set around a TRAINING rollout frame's forward by BaseSimulator (fused frame step): under the reference's
+    pending_tail = None         # agent-axis norm (channelled input, quirk Q2) the tail -- neighbour-axis sums + desired force -- is left
+                                # to the frame step's launch (ops.rollout_frame tail=): operands parked here, out[0] is None
     _ph2 = None                 # folded weights + operand images of the pooled inference path (see _pooled_inference)
     predictions_only = False    # set by the inference rollouts (BaseSimulator): the auxiliary collision head (`pinnsf_m`: on the messages,
                                 # `pinnsf_bm`: on the decoded rows) is not launched -- those loops read out[0] only (simulators.py:602) --
@@ -423,7 +426,9 @@ class _PINNSFBase(nn.Module):
             sums=not self.messages_wanted and (self.collision_head is None or head is not None or self.predictions_only))
         acc, msgs = res[0], res[1]
         if not fold:
-            if self_features.dim() == 3:
+            if self_features.dim() == 3 and self._park_tail(acc, None, self_features):
+                acc = None
+            elif self_features.dim() == 3:
                 acc = ops.pinnsf_epilogue(acc, None, self_features, self.tau, agent_norm=True)
             else:
                 acc = acc + self.desired_force(self_features)
@@ -438,6 +443,14 @@ class _PINNSFBase(nn.Module):
             else:
                 out.append(torch.sigmoid(self.ped_collision_predictor(msgs[0])).squeeze())
         return out
+
+    def _park_tail(self, acc_ped, acc_obs, self_features):
+        """Leave the agent-norm tail to the caller's frame step?  (training rollout, channelled input, no corrector branch)"""
+        if not (self.defer_train_tail and torch.is_grad_enabled() and self_features.dim() == 3 and not self.fix_dest_norm
+                and not self.residual and self_features.is_cuda and self_features.dtype == torch.float32):
+            return False
+        self.pending_tail = (acc_ped, acc_obs, self_features, self.tau)
+        return True
 
     def _pooled_inference(self, cand, specs, self_features, fold):
         """Inference frames (predictions only, eval mode, inside packed_weights()): the neighbour-axis sum BEFORE the
@@ -651,6 +664,8 @@ class _PINNSFBase(nn.Module):
             # itself (ops.rollout_step ksum=); out[0] is None
             self.pending_ksum = (ped_msgs, out_obs, self.tau)
             predictions = None
+        elif ksum_tail and self._park_tail(ped_msgs, out_obs, self_features):
+            predictions = None
         elif ksum_tail:
             from .. import ops
             predictions = ops.pinnsf_epilogue_ksum(ped_msgs, out_obs, self_features, self.tau,
@@ -659,7 +674,10 @@ class _PINNSFBase(nn.Module):
                 and (self_features.dim() in (2, 3) or self.fix_dest_norm):
             from .. import ops       # one fused kernel; 3-D input without fix_dest_norm keeps the dim=1 quirk (Q2)
             quirk = self_features.dim() == 3 and not self.fix_dest_norm
-            predictions = ops.pinnsf_epilogue(acc, acc_o, self_features, self.tau, agent_norm=quirk)
+            if quirk and self._park_tail(acc, acc_o, self_features):
+                predictions = None
+            else:
+                predictions = ops.pinnsf_epilogue(acc, acc_o, self_features, self.tau, agent_norm=quirk)
         else:
             if acc_o is not None:
                 acc = acc + acc_o

@@ -66,6 +66,7 @@ class BaseSimulator(Pedestrians):
     # way (ops.train_rollout_step); False keeps the torch-op expression of the same arithmetic
     fused_train_step = True
     fused_rollout_losses = True      # ops.rollout_losses for the mse / collision-focus sums of the training rollout (else torch operators)
+    tail_in_step = os.environ.get('PIML_TAIL_IN_STEP', '1') != '0'      # the model's agent-norm tail inside the fused frame step's launches (ops.rollout_frame tail=)
 
     def __init__(self, args):
         super().__init__()
@@ -556,8 +557,18 @@ class BaseSimulator(Pedestrians):
         p_buf = None
         if fused_step and pro is not None and t_start == 0 and not ops.DETERMINISTIC_BWD:
             p_buf = torch.empty(p_cur.shape[0], T, p_cur.shape[1], 2, device=dev, dtype=torch.float32)
+        # the model's tail under the agent-axis norm rides in the frame step's launch (ops.rollout_frame tail=; forward and backward)
+        park_tail = fused_step and self.tail_in_step and hasattr(self.model, 'defer_train_tail') and not ops.DETERMINISTIC_BWD
         for t in range(t_start, T):
-            predictions = self.model(*state)                                  # :701
+            tail = None
+            if park_tail:
+                self.model.defer_train_tail, self.model.pending_tail = True, None
+            try:
+                predictions = self.model(*state)                              # :701
+            finally:
+                if park_tail:
+                    tail = self.model.pending_tail
+                    self.model.defer_train_tail, self.model.pending_tail = False, None
             p_msg = predictions[1]
             gf = gates_f[t]
 
@@ -585,7 +596,7 @@ class BaseSimulator(Pedestrians):
                     p_cur, v_cur, a_cur, a_next, dest_cur, dest_idx, waypoints, dest_num_i64, dt, new_flag_u8, series, t + 1,
                     nan_flag, obstacles, speed_rows, args.topk_ped, args.sight_angle_ped, args.dist_threshold_ped,
                     args.topk_obs, args.sight_angle_obs, args.dist_threshold_obs, alias_position=True,
-                    stack=None if p_buf is None else (p_buf, t))
+                    stack=None if p_buf is None else (p_buf, t), tail=tail)
                 p_steps[-1] = p_alias
             else:
                 nan_seen = a_next.isnan().any() if nan_seen is None else (nan_seen | a_next.isnan().any())

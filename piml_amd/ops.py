@@ -1839,11 +1839,24 @@ class _RolloutFrame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p, v, a, a_pred, dest, dest_idx, waypoints, dest_num, new_flag, series, t_next, dt, nan_flag,
-                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o, alias_p=False, stack=None):
+                obstacles, speed, kp, ko, cos_p, cos_o, dthr_p, dthr_o, alias_p=False, stack=None, tail_ped=None, tail_obs=None,
+                tail_sf=None, tail_tau=None):
         L = _lib.lib()
         p_arg = p
-        p, v, a, a_pred, dest = [_gpu_f32(n, x) for n, x in
-                                 (('position', p), ('velocity', v), ('acceleration', a), ('a_pred', a_pred), ('destination', dest))]
+        p, v, a, dest = [_gpu_f32(n, x) for n, x in (('position', p), ('velocity', v), ('acceleration', a), ('destination', dest))]
+        # tail_*: the model's tail rides in the step's launch (piml_train_step_tail_fwd): a_pred is None, the prediction is made there
+        tail = tail_ped is not None
+        if tail:
+            t_ped = _gpu_f32('tail acc_ped', tail_ped)
+            t_obs = _gpu_f32('tail acc_obs', tail_obs) if tail_obs is not None else None
+            t_sf = _gpu_f32('tail self_features', tail_sf)
+            Cn = p.shape[0] * p.shape[1]
+            tkp, tko = t_ped.numel() // (Cn * 2), (t_obs.numel() // (Cn * 2) if t_obs is not None else 1)
+            if tuple(t_sf.shape) != (p.shape[0], p.shape[1], 7) or t_ped.numel() != Cn * tkp * 2 or \
+                    (t_obs is not None and t_obs.numel() != Cn * tko * 2):
+                raise ValueError('rollout_frame: tail = (acc_ped (C, N[, k], 2), acc_obs | None, self_features (C, N, 7), tau)')
+        else:
+            a_pred = _gpu_f32('a_pred', a_pred)
         o = _gpu_f32('obstacles', obstacles).reshape(-1, 2)
         v0 = _gpu_f32('desired_speed', speed)
         C, N = p.shape[0], p.shape[1]
@@ -1861,23 +1874,35 @@ class _RolloutFrame(torch.autograd.Function):
         pf, of, sf = torch.empty(C, N, kpe, 6, **opt), torch.empty(C, N, koe, 6, **opt), torch.empty(C, N, 7, **opt)
         pi = torch.empty(C, N, kpe, device=dev, dtype=torch.int32)
         oi = torch.empty(C, N, koe, device=dev, dtype=torch.int32)
-        need = any(ctx.needs_input_grad[:4])
+        need = any(ctx.needs_input_grad[:4]) or (tail and any(ctx.needs_input_grad[23:26]))
         g6 = torch.empty(C, N, 6, **opt) if need else None
         with torch.cuda.device(dev):
             copy_ptr, copy_stride = None, 0
             if stack is not None:         # (buffer (C, T', N, 2) float32 contiguous, frame index): the input position into its frame
                 sbuf, st_ = stack
                 copy_ptr, copy_stride = sbuf.data_ptr() + int(st_) * N * 2 * 4, sbuf.shape[1] * N * 2
-            _lib.check(L.piml_train_step_fwd_copy(
-                _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
-                _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
-                float(dt), *[_ptr(x) for x in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
-                _ptr(zero_mask), copy_ptr, int(copy_stride), _stream()), 'piml_train_step_fwd_copy')
+            if tail:
+                _lib.check(L.piml_train_step_tail_fwd(
+                    _ptr(p), _ptr(v), _ptr(a), _ptr(t_ped), tkp, _ptr(t_obs), tko, _ptr(t_sf), float(tail_tau), _ptr(dest), _ptr(dest_idx),
+                    _ptr(waypoints), D, per_slice, _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N,
+                    int(t_next), float(dt), *[_ptr(x) for x in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
+                    _ptr(zero_mask), copy_ptr, int(copy_stride), _stream()), 'piml_train_step_tail_fwd')
+            else:
+                _lib.check(L.piml_train_step_fwd_copy(
+                    _ptr(p), _ptr(v), _ptr(a), _ptr(a_pred), _ptr(dest), _ptr(dest_idx), _ptr(waypoints), D, per_slice,
+                    _ptr(dest_num), _ptr(new_flag) if new_flag is not None else None, *sp, C, T, N, int(t_next),
+                    float(dt), *[_ptr(x) for x in outs], _ptr(idx_out), _ptr(nan_flag) if nan_flag is not None else None,
+                    _ptr(zero_mask), copy_ptr, int(copy_stride), _stream()), 'piml_train_step_fwd_copy')
             _lib.check(L.piml_relfeat_fwd_self(
                 _ptr(outs[0]), None, _ptr(outs[1]), _ptr(outs[2]), 2, _ptr(outs[3]), _ptr(o), _ptr(v0), C, N, M, 0, N, kp, ko,
                 cos_p, cos_o, dthr_p, dthr_o, _ptr(pf), _ptr(of), _ptr(sf), _ptr(pi), _ptr(oi), _ptr(g6), _stream()),
                 'piml_relfeat_fwd_self')
-        ctx.save_for_backward(pi, oi, outs[0], outs[3])
+        if tail:
+            ctx.save_for_backward(pi, oi, outs[0], outs[3], t_sf)
+            ctx.tail = (tkp, tko, float(tail_tau), tuple(tail_ped.shape), None if tail_obs is None else tuple(tail_obs.shape))
+        else:
+            ctx.save_for_backward(pi, oi, outs[0], outs[3])
+            ctx.tail = None
         ctx.new_flag, ctx.zero_mask, ctx.geom, ctx.g6 = new_flag, zero_mask, (C, T, N, int(t_next), float(dt), kpe, koe), g6
         ctx.mark_non_differentiable(outs[3], idx_out)
         ctx.set_materialize_grads(False)
@@ -1894,8 +1919,8 @@ class _RolloutFrame(torch.autograd.Function):
         C, T, N, t_next, dt, kpe, koe = ctx.geom
         feats = any(g is not None for g in (g_pf, g_of, g_sf))
         if not feats and all(g is None for g in (gp_o, gv_o, ga_o)):
-            return (g_alias if ctx.needs_input_grad[0] else None,) + (None,) * 22
-        pi, oi, p_out, dest_out = ctx.saved_tensors
+            return (g_alias if ctx.needs_input_grad[0] else None,) + (None,) * 26
+        pi, oi, p_out, dest_out = ctx.saved_tensors[:4]
         dev = p_out.device
         opt = dict(device=dev, dtype=torch.float32)
         L = _lib.lib()
@@ -1932,17 +1957,37 @@ class _RolloutFrame(torch.autograd.Function):
             gs = [torch.empty(C, N, 2, **opt) if (need[k] and live[k]) else None for k in range(4)]
             gpo, gpo_stride = (None, 0) if gp_o is None else sliced(gp_o)
             cont = [None if g is None else _gpu_f32('grad', g) for g in (gv_o, ga_o)]
-            _lib.check(L.piml_train_step_bwd7(
-                _ptr(gpo), int(gpo_stride), *[_ptr(g) for g in cont], _ptr(g6), _ptr(gin), int(gin_stride),
-                _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
-                _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd7')
-        return (*gs,) + (None,) * 19
+            g_tail = (None, None, None)
+            if ctx.tail is not None and ha and any(need[23:26]):
+                # the step's backward and the tail's in one launch: d/d(prediction) -> the tail's summands (broadcast over k) and g_self
+                tkp, tko, tau, shp_p, shp_o = ctx.tail
+                t_sf = ctx.saved_tensors[4]
+                g_pred = torch.empty(C, N, 2, **opt)
+                g_tp = (torch.empty(shp_p, **opt) if tkp > 1 else g_pred.view(shp_p)) if need[23] else None
+                g_to = (torch.empty(shp_o, **opt) if tko > 1 else g_pred.view(shp_o)) if (shp_o is not None and need[24]) else None
+                g_tsf = torch.empty(C, N, 7, **opt) if need[25] else None
+                _lib.check(L.piml_train_step_tail_bwd(
+                    _ptr(gpo), int(gpo_stride), *[_ptr(g) for g in cont], _ptr(g6), _ptr(gin), int(gin_stride),
+                    _ptr(ctx.new_flag) if ctx.new_flag is not None else None, _ptr(ctx.zero_mask), C, T, N, t_next, dt,
+                    *[_ptr(g) for g in gs[:3]], _ptr(g_pred), _ptr(t_sf), tau, tkp, tko,
+                    _ptr(g_tp) if (g_tp is not None and tkp > 1) else None, _ptr(g_to) if (g_to is not None and tko > 1) else None,
+                    _ptr(g_tsf), _stream()), 'piml_train_step_tail_bwd')
+                g_tail = (g_tp, g_to, g_tsf)
+            else:
+                _lib.check(L.piml_train_step_bwd7(
+                    _ptr(gpo), int(gpo_stride), *[_ptr(g) for g in cont], _ptr(g6), _ptr(gin), int(gin_stride),
+                    _ptr(ctx.new_flag) if ctx.new_flag is not None else None,
+                    _ptr(ctx.zero_mask), C, T, N, t_next, dt, *[_ptr(g) for g in gs], _stream()), 'piml_train_step_bwd7')
+        return (*gs,) + (None,) * 19 + g_tail + (None,)
 
 
 def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt, new_flag, series,
                   t_next, nan_flag, obstacles, desired_speed, topk_ped=6, sight_angle_ped=90, dist_threshold_ped=4,
-                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, alias_position=False, stack=None):
+                  topk_obs=10, sight_angle_obs=90, dist_threshold_obs=4, alias_position=False, stack=None, tail=None):
     """train_rollout_step(..., zero_nan=True) + relative_features_self on its result as one autograd node (_RolloutFrame).
+    tail = (acc_ped (C, N[, k], 2), acc_obs | None, self_features (C, N, 7), tau) with a_pred None: the model's tail under the
+    reference's agent-axis norm (ops.pinnsf_epilogue / pinnsf_epilogue_ksum with agent_norm=True) is evaluated inside the step's
+    launch, its backward inside the step's backward launch (piml_train_step_tail_fwd / bwd; bitwise the separate launches).
     Returns (position', velocity', acceleration', destination', dest_idx', ped_features, obs_features, self_features); with
     alias_position a ninth element: the INPUT position again, as an output of the node -- a caller whose loss reads the frame's
     position reads this alias, and the loss's gradient is added inside the node's backward launch (no accumulation per frame).
@@ -1952,6 +1997,12 @@ def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_id
         raise ValueError('rollout_frame: (C, N, 2) GPU state expected')
     if topk_ped > MAX_TOPK or topk_obs > MAX_TOPK:
         raise ValueError(f'topk must be <= {MAX_TOPK}')
+    if tail is not None and (DETERMINISTIC_BWD or a_pred is not None):
+        if a_pred is not None:
+            raise ValueError('rollout_frame: a_pred or tail, not both')
+        a_pred = (pinnsf_epilogue_ksum(tail[0], tail[1], tail[2], tail[3], agent_norm=True) if tail[0].dim() == 4 else
+                  pinnsf_epilogue(tail[0], tail[1], tail[2], tail[3], agent_norm=True))
+        tail = None
     if DETERMINISTIC_BWD:        # the atomics-free feature backward exists for the plain operator only
         st = train_rollout_step(position, velocity, acceleration, a_pred, destination, dest_idx, waypoints, dest_num, dt,
                                 new_flag=new_flag, series=series, t_next=t_next, nan_flag=nan_flag, zero_nan=True)
@@ -1976,7 +2027,8 @@ def rollout_frame(position, velocity, acceleration, a_pred, destination, dest_id
                                dest_num.contiguous(), new_flag, series, int(t_next), float(dt), nan_flag, obstacles, desired_speed,
                                int(topk_ped), int(topk_obs), cos_threshold(sight_angle_ped), cos_threshold(sight_angle_obs),
                                float(dist_threshold_ped), float(dist_threshold_obs), bool(alias_position),
-                               None if (stack is None or DETERMINISTIC_BWD) else stack)
+                               None if (stack is None or DETERMINISTIC_BWD) else stack,
+                               *((None, None, None, None) if tail is None else (tail[0], tail[1], tail[2], float(tail[3]))))
 
 
 class _StackOf(torch.autograd.Function):

@@ -351,3 +351,58 @@ def test_pointwise_losses_equal_the_torch_expressions(rows, k, with_reg, with_cp
             assert a is None
         else:
             assert torch.allclose(a, t.grad, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('kind', ['sum', 'sum_obs', 'ksum'])
+def test_frame_node_with_the_models_tail_equals_the_separate_launches(kind):
+    """ops.rollout_frame(tail=...) (piml_train_step_tail_fwd / bwd: the model's tail under the agent-axis norm, quirk Q2, inside the
+    frame step's launches) against ops.pinnsf_epilogue[_ksum](agent_norm=True) followed by ops.rollout_frame(a_pred): every output
+    and every gradient BITWISE (same reductions, same arithmetic), at a slice size above one pass of the workgroup (N = 300)."""
+    import types
+    from piml_amd import ops
+    from piml_amd.scenes import synthetic_gc_scene
+    g = torch.Generator().manual_seed(19)
+    C, T, N, M = 3, 4, 300, 40
+    sc = synthetic_gc_scene(N, M, seed=4, channels=C * T)
+    f = lambda k: torch.tensor(sc[k], device='cuda').view(C, T, N, -1).contiguous()
+    data = types.SimpleNamespace(position=f('position'), velocity=f('velocity'), acceleration=f('acceleration'), destination=f('destination'))
+    data.dest_idx = torch.randint(0, 3, (C, T, N), generator=g).cuda()
+    data.mask_p = (torch.rand(C, T, N, generator=g) > 0.3).float().cuda()
+    data.mask_p_pred = (data.mask_p * (torch.rand(C, T, N, generator=g) > 0.4).float().cuda()).contiguous()
+    data.self_features = torch.randn(C, T, N, 7, generator=g).cuda()
+    pro = ops.rollout_prologue(data, 0)
+    obstacles = torch.tensor(sc['obstacles'], device='cuda')
+    waypoints = torch.rand(4, N, 2, generator=g).cuda() * 30
+    dest_num = torch.full((N,), 4, dtype=torch.int64, device='cuda')
+    series = (data.position, data.velocity, data.acceleration, data.destination, data.dest_idx)
+    kp, ko = (6, 10) if kind == 'ksum' else (1, 1)
+    res = []
+    for fused in (True, False):
+        gg = torch.Generator().manual_seed(4)
+        leaves = [torch.nan_to_num(pro[k]).clone().requires_grad_(True) for k in ('p', 'v', 'a')]
+        acc_p = torch.randn(*((C, N, kp, 2) if kind == 'ksum' else (C, N, 2)), generator=gg).cuda().requires_grad_(True)
+        acc_o = None if kind == 'sum' else torch.randn(*((C, N, ko, 2) if kind == 'ksum' else (C, N, 2)), generator=gg).cuda().requires_grad_(True)
+        sf = torch.randn(C, N, 7, generator=gg).cuda()
+        sf[1, :, 0] = 0.0                             # a slice whose x components are all zero: the norm's 0 -> 0.1 branch
+        sf.requires_grad_(True)
+        nan_flag = torch.zeros((), dtype=torch.int32, device='cuda')
+        tail = (acc_p, acc_o, sf, 2.0)
+        if fused:
+            out = ops.rollout_frame(*leaves, None, pro['dest'], pro['dest_idx'], waypoints, dest_num, 0.08, pro['new_flag_u8'], series, 1,
+                                    nan_flag, obstacles, pro['speed'], tail=tail)
+        else:
+            a_pred = ops.pinnsf_epilogue_ksum(acc_p, acc_o, sf, 2.0, agent_norm=True) if kind == 'ksum' else \
+                ops.pinnsf_epilogue(acc_p, acc_o, sf, 2.0, agent_norm=True)
+            out = ops.rollout_frame(*leaves, a_pred, pro['dest'], pro['dest_idx'], waypoints, dest_num, 0.08, pro['new_flag_u8'], series, 1,
+                                    nan_flag, obstacles, pro['speed'])
+        ws = [torch.randn(o.shape, generator=torch.Generator().manual_seed(20 + i)).cuda() for i, o in enumerate(out)]
+        loss = sum((torch.nan_to_num(o) * w).sum() for o, w in zip(out, ws) if o.dtype == torch.float32 and o.requires_grad)
+        grads = torch.autograd.grad(loss, leaves + [acc_p, sf] + ([acc_o] if acc_o is not None else []))
+        res.append((out, grads))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
+    # (p, v, a: the features' backward adds with float atomics in both forms; the tail's own gradients: bitwise)
+    for a, b in zip(res[0][1][:3], res[1][1][:3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[0][1][3:], res[1][1][3:]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)      # (they depend on the atomics' d/d(a') too)
