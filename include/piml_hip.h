@@ -808,7 +808,9 @@ int piml_collision_head_fwd(const float* msgs, long long rows, const float* w1, 
  * fwd: x -> out (rows), hidden (rows, 64: post-ReLU, saved for bwd; NULL for inference).
  * bwd: g_out (rows), out, hidden, x -> g_x (rows, 64; NULL = not wanted); partials = piml_head64_slots(rows) slots of
  *      piml_head64_partial_floats() floats of scratch; grads (same layout as one slot) = [dW1 64x64 | db1 64 | dw2 64 |
- *      db2 1 | 3 pad].  Two launches (tiles + slot sum), no atomics.
+ *      db2 1 | 3 pad].  Two launches (tiles + slot sum), no atomics.  One slot per workgroup: four 32-row tiles per workgroup above
+ *      2048 tiles, below that ONE tile per workgroup with its four waves on disjoint blocks of the tile's products (the training
+ *      loops' few thousand rows: 14.6 -> 6 us per launch).
  */
 typedef struct piml_head64 {
     const float* x;

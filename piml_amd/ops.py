@@ -940,13 +940,14 @@ def collision_pred_loss(pred_frames, feature_frames, gates_f, t_start, T, weight
     return _CollisionPredLoss.apply(gates_f, int(t_start), int(T), float(weight), len(pred_frames), *pred_frames, *feature_frames)
 
 
-_CONST_ONES = set()        # data pointers of persistent tensors that hold 1.0 and are never written (register_const_one)
+_CONST_ONES = {}           # data pointer -> the persistent tensor that holds 1.0 and is never written (register_const_one)
 
 
 def register_const_one(t):
-    """`t` (0-dim float32) holds 1.0 for as long as the process lives and nobody writes it (the `gradient=` of a captured step's
-    backward): a loss node whose upstream gradient IS this tensor hands out its stored gradient fields without a scaling launch."""
-    _CONST_ONES.add(t.data_ptr())
+    """`t` (0-dim float32) holds 1.0 and nobody ever writes it (the `gradient=` of a captured step's backward): a loss node whose
+    upstream gradient IS this tensor hands out its stored gradient fields without a scaling launch.  The registry keeps the tensor
+    alive -- its address must never come back as somebody else's gradient."""
+    _CONST_ONES[t.data_ptr()] = t
 
 
 def _scaled_grad(g_up, grad):
