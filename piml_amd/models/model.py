@@ -62,6 +62,7 @@ FUSED_CORRECTOR = os.environ.get('PIML_FUSED_CORRECTOR', '1') != '0'
 PREPACK = os.environ.get('PIML_PREPACK', '1') != '0'          # packed_weights(): pack once per block
 # inference frames (predictions only, eval): neighbour-axis sum before the encoders' last layer (ops.fused_pinnsf_pooled)
 POOLED_INFERENCE = os.environ.get('PIML_POOLED_INFERENCE', '1') != '0'
+TAIL_IN_STEP_MAX_AGENTS = 256          # agents per slice up to which a training frame's tail rides in the frame step's launches
 
 
 def activation_layer(act_name, negative_slope=0.1):
@@ -446,8 +447,12 @@ class _PINNSFBase(nn.Module):
 
     def _park_tail(self, acc_ped, acc_obs, self_features):
         """Leave the agent-norm tail to the caller's frame step?  (training rollout, channelled input, no corrector branch)"""
+        # (one workgroup per slice does the tail and the step: ahead of the separate launches while a slice's agents are ONE pass of its
+        # 256 threads -- the real clips' 122 agents: 0.346 against 0.364 ms per fine-tuning step -- and behind them at 976 agents, 0.518
+        # against 0.498, where the separate step spreads over many workgroups)
         if not (self.defer_train_tail and torch.is_grad_enabled() and self_features.dim() == 3 and not self.fix_dest_norm
-                and not self.residual and self_features.is_cuda and self_features.dtype == torch.float32):
+                and not self.residual and self_features.is_cuda and self_features.dtype == torch.float32
+                and self_features.shape[1] <= TAIL_IN_STEP_MAX_AGENTS):
             return False
         self.pending_tail = (acc_ped, acc_obs, self_features, self.tau)
         return True

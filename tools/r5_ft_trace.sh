@@ -2,7 +2,7 @@
 # ordered kernel list of one replayed fine-tuning step (FT_MODEL=pinnsf_m | pinnsf_bm, 4 x 5 x 122) with durations and gaps
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5ft; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/p -- python3 $R/tools/time_finetune.py ${FT_STEPS:-50} ${FT_MODEL:-pinnsf_m} > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/p -- python3 $R/tools/time_finetune.py ${FT_STEPS:-50} ${FT_MODEL:-pinnsf_m} ${FT_TIMES:-1} > $O/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob, os, re
 O = os.path.join(os.environ['GRAFT_REPO_ROOT'], 'gpurun_out/r5ft')

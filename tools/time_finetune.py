@@ -10,6 +10,10 @@ from test_simulator_gpu import sim_args, load_data, make_sim
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rollout.npz'), allow_pickle=False)
 MODEL = sys.argv[2] if len(sys.argv) > 2 else 'pinnsf_m'          # python tools/time_finetune.py [steps] [pinnsf_m | pinnsf_bm]
 data = load_data(g, 'train_' + MODEL)
+if len(sys.argv) > 3 and int(sys.argv[3]) > 1:                     # python tools/time_finetune.py [steps] [model] [agent axis x this]
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from train_mode_steps import tiled
+    data = tiled(data, int(sys.argv[3]))
 if MODEL == 'pinnsf_m':
     sim = make_sim(g, sim_args(learning_rate=1e-3, hip_graph=True), 'train_pinnsf_m/sd/')
 else:
