@@ -328,6 +328,18 @@ int piml_collision_pred_loss_bwd(const float* g_loss, const float* grad, long lo
  *     labels[:, 6:], 'sum')   out[0] = out[1] (+ out[2]) (+ out[3])
  * grad = [2 rows | nmsg | rows k] floats: d out[0] / d (pred | msgs | coll_pred); its backward is piml_collision_pred_loss_bwd (a copy
  * scaled by the upstream gradient).  partial (3 floats per workgroup of piml_pointwise_losses_blocks) and a zeroed ticket when > 1. */
+/* One Adam step of n parameter tensors in ONE launch (the optimiser of both training loops: torch.optim.Adam(model.parameters(), lr,
+ * weight_decay), src/models/simulators.py:69-71, :104-129, stepped at :319 / :358-359): params / grads / exp_avg / exp_avg_sq / steps =
+ * HOST arrays of n device pointers (float32, contiguous; steps: one float counter per tensor, as torch keeps them with
+ * capturable=True), sizes their element counts.  Per tensor: step += 1; grad += weight_decay * param; exp_avg = beta1 exp_avg +
+ * (1 - beta1) grad; exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2; param -= (lr / (1 - beta1^step)) exp_avg / (sqrt(exp_avg_sq) /
+ * sqrt(1 - beta2^step) + eps) -- torch's fused kernel operation for operation (doubles for the hyper-parameters), bitwise equal to it.
+ * A tensor is cut into pieces of 1024 elements, one workgroup each; the tensor's last workgroup out (tickets) writes its counter. */
+int piml_adam_tickets(void);   /* unsigned counters `tickets` must hold (zeroed once; every launch leaves them zero) */
+int piml_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, float* const* steps,
+                   const long long* sizes, int n, double lr, double beta1, double beta2, double weight_decay, double eps,
+                   unsigned* tickets, void* stream);
+
 int piml_pointwise_losses_blocks(long long rows, long long nmsg, int k);
 int piml_pointwise_losses(const float* pred, const float* labels, long long labels_ld, long long rows, const float* msgs, long long nmsg,
                           float reg_weight, const float* coll_pred, int k, float* out, float* grad, float* partial, unsigned* ticket,

@@ -134,6 +134,8 @@ SIGNATURES = {
     'piml_collision_pred_loss_blocks': [_ll, _i],
     'piml_collision_pred_loss': [ctypes.POINTER(_p), ctypes.POINTER(_p), _i, _ll, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _p],
     'piml_collision_pred_loss_bwd': [_p, _p, _ll, _p, _p],
+    'piml_adam_tickets': [],
+    'piml_adam_step': [ctypes.POINTER(_p)] * 5 + [ctypes.POINTER(_ll), _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _p, _p],
     'piml_pointwise_losses_blocks': [_ll, _ll, _i],
     'piml_pointwise_losses': [_p, _p, _ll, _ll, _p, _ll, _f, _p, _i, _p, _p, _p, _p, _p],
     'piml_p2p_alloc': [_z, ctypes.POINTER(_p)],

@@ -141,9 +141,18 @@ class BaseSimulator(Pedestrians):
         fused = on_gpu and bool(getattr(self.args, 'fused_adam', 1))
         return dict(capturable=on_gpu, fused=True) if fused else dict(capturable=on_gpu)
 
+    def _adam(self, params, **kw):
+        """torch.optim.Adam -- on the GPU the same optimiser stepped by ONE launch of this package (piml_amd.optim.Adam: bitwise
+        PyTorch's fused kernel, whose step is `_foreach_add_` + a multi-tensor launch, 18 us of every training step);
+        PIML_ADAM=torch or args.fused_adam = 0 keep PyTorch's own step."""
+        kw = dict(kw, **self._adam_kw())
+        if kw.get('fused') and os.environ.get('PIML_ADAM', 'piml') != 'torch':
+            from ..optim import Adam
+            return Adam(params, **kw)
+        return torch.optim.Adam(params, **kw)
+
     def set_optimizer(self, args):
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=args.learning_rate,
-                                          weight_decay=args.weight_decay, **self._adam_kw())
+        self.optimizer = self._adam(self.model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
         self._graphed_steps = {}
 
     def set_ft_optimizer(self, args):
@@ -151,15 +160,13 @@ class BaseSimulator(Pedestrians):
             corr = list(self.model.corrector.parameters())
             ids = {id(p) for p in corr}
             rest = [p for p in self.model.parameters() if id(p) not in ids]
-            self.optimizer = torch.optim.Adam(
+            self.optimizer = self._adam(
                 [{'params': corr, 'lr': args.learning_rate * args.ft_lr_decay2},
                  {'params': rest, 'lr': args.learning_rate * args.finetune_lr_decay}],
-                lr=args.learning_rate, weight_decay=args.weight_decay, **self._adam_kw())
+                lr=args.learning_rate, weight_decay=args.weight_decay)
         else:
-            self.optimizer = torch.optim.Adam(self.model.parameters(),
-                                              lr=args.learning_rate * args.finetune_lr_decay,
-                                              weight_decay=args.weight_decay * args.finetune_wd_aug,
-                                              **self._adam_kw())
+            self.optimizer = self._adam(self.model.parameters(), lr=args.learning_rate * args.finetune_lr_decay,
+                                        weight_decay=args.weight_decay * args.finetune_wd_aug)
         self._graphed_steps = {}
 
     def set_scheduler(self, args):

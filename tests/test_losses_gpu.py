@@ -406,3 +406,30 @@ def test_frame_node_with_the_models_tail_equals_the_separate_launches(kind):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     for a, b in zip(res[0][1][3:], res[1][1][3:]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)      # (they depend on the atomics' d/d(a') too)
+
+
+@pytest.mark.parametrize('wd', [0.0, 1e-4])
+def test_one_launch_adam_is_bitwise_pytorchs_fused_adam(wd):
+    """piml_amd.optim.Adam (piml_adam_step: every parameter of a group and its step counter in ONE launch) against
+    torch.optim.Adam(fused=True, capturable=True) -- the optimiser of both training loops (src/models/simulators.py:69-71) -- over eight
+    steps on PINNSF's parameter shapes plus odd sizes: parameters and optimiser state bitwise, state_dict()s interchangeable."""
+    from piml_amd.optim import Adam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 6), (128,), (128, 128), (128,), (128, 128), (128,), (64, 128), (64,), (64, 64), (64,), (2, 64), (2,), (1,), (7, 3), (1025,)]
+    mine = [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.2).to(DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    kw = dict(lr=2e-4, weight_decay=wd, capturable=True, fused=True)
+    oa, ob = Adam(mine, **kw), torch.optim.Adam(ref, **kw)
+    for it in range(8):
+        for p, q in zip(mine, ref):
+            gr = (torch.randn(*p.shape, generator=g) * (10.0 ** (it % 3 - 2))).to(DEV)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        for p, q in zip(mine, ref):
+            assert torch.equal(p, q), (it, tuple(p.shape))
+    sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+    for k in sb:
+        for name in ('step', 'exp_avg', 'exp_avg_sq'):
+            assert torch.equal(sa[k][name], sb[k][name]), (k, name)
+    ob.load_state_dict(oa.state_dict())        # interchangeable

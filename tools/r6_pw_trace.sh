@@ -8,7 +8,7 @@ import csv, glob, os, re
 O = os.path.join(os.environ['GRAFT_REPO_ROOT'], 'gpurun_out/r6pw')
 f = sorted(glob.glob(O + '/p/**/*kernel_trace.csv', recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-marks = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name']]
+marks = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name'].lower()]
 a, b = marks[-3], marks[-2]
 prev = int(rows[a]['End_Timestamp'])
 out = []
