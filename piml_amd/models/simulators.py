@@ -852,7 +852,8 @@ class BaseSimulator(Pedestrians):
         pred, p_msg = predictions[0], predictions[1]
         bm_cp = args.collision_pred_weight > 0 and args.model == 'pinnsf_bm'
         if (args.pinnsf_interaction == 'sim' and self.fused_rollout_losses and pred.is_cuda and pred.dtype == torch.float32
-                and pred.dim() == 2 and labels.dim() == 2 and labels.shape[1] >= 6):
+                and pred.dim() == 2 and labels.dim() == 2 and labels.shape[1] >= 6
+                and (not bm_cp or (predictions[-1].dim() == 2 and labels.shape[1] >= 6 + predictions[-1].shape[-1]))):
             # :333-352 as ONE launch (ops.pointwise_losses: the three sums and their gradient fields)
             loss, mse_loss, reg, cp = ops.pointwise_losses(pred, labels, args.reg_weight, p_msg if args.reg_weight > 0 else None,
                                                            predictions[-1] if bm_cp else None)

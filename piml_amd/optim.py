@@ -56,9 +56,10 @@ class Adam(torch.optim.Adam):
             sizes = (ctypes.c_longlong * n)(*[p.numel() for p in params])
             beta1, beta2 = group['betas']
             dev = params[0].device
-            tickets = self._tickets.get(dev)
+            cache = self.__dict__.setdefault('_tickets', {})      # (an unpickled / deep-copied optimiser comes without it)
+            tickets = cache.get(dev)
             if tickets is None:        # zeroed once; every launch leaves them zero
-                tickets = self._tickets[dev] = torch.zeros(L.piml_adam_tickets(), dtype=torch.int32, device=dev)
+                tickets = cache[dev] = torch.zeros(L.piml_adam_tickets(), dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(L.piml_adam_step(tab(params), tab(grads), tab(exp_avgs), tab(exp_avg_sqs), tab(steps), sizes, n,
                                             float(group['lr']), float(beta1), float(beta2), float(group['weight_decay']),
