@@ -20,7 +20,8 @@ class Adam(torch.optim.Adam):
         self._tickets = {}
 
     def _eligible(self, group, params, grads, exp_avgs, exp_avg_sqs, steps):
-        if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') or not isinstance(group['lr'], float):
+        if group.get('amsgrad') or group.get('maximize') or group.get('differentiable') or group.get('decoupled_weight_decay') \
+                or not isinstance(group['lr'], float):
             return False
         if getattr(self, 'grad_scale', None) is not None or getattr(self, 'found_inf', None) is not None:
             return False
