@@ -414,3 +414,33 @@ def test_bottleneck_inference_frames_equal_operator_sequence(model_name):
     assert float(ref[1].abs().max()) > 0
     for key, got in res.items():
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), key
+
+
+@pytest.mark.parametrize('model', ['pinnsf_m', 'pinnsf_bm'])
+def test_pointwise_training_is_bitwise_the_same_under_pytorchs_adam(model, monkeypatch):
+    """HOT LOOP A for forty captured steps (dropout 0.5, weight decay, reg_weight, the collision head's BCE for pinnsf_bm) with
+    piml_amd.optim.Adam (one launch, piml_adam_step) and with torch.optim.Adam(fused=True, capturable=True): the pointwise step has
+    no float atomics, so every parameter and every logged loss must agree BITWISE -- the one-launch optimiser is PyTorch's arithmetic."""
+    from piml_amd.models.simulators import BaseSimulator
+    from piml_amd import ops
+    runs = []
+    for which in ('piml', 'torch'):
+        monkeypatch.setenv('PIML_ADAM', which)
+        torch.manual_seed(666)
+        ops.dropout_seed(666, DEV)
+        sim = BaseSimulator(sim_args(model=model, learning_rate=2e-4, reg_weight=1e-2, collision_pred_weight=5e-2, hip_graph=True))
+        assert type(sim.optimizer).__module__.startswith('piml_amd' if which == 'piml' else 'torch')
+        sim.model.train()
+        g = torch.Generator().manual_seed(5)
+        logs = []
+        for it in range(40):
+            rows = 128
+            batch = (torch.randn(rows, 6, 6, generator=g).to(DEV), torch.randn(rows, 10, 6, generator=g).to(DEV),
+                     torch.randn(rows, 7, generator=g).to(DEV),
+                     torch.cat((torch.randn(rows, 6, generator=g), (torch.rand(rows, 6, generator=g) < 0.2).float()), 1).to(DEV))
+            logs.append(sim.train_batch(batch))
+        runs.append(([p.detach().clone() for p in sim.model.parameters()], logs))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    for la, lb in zip(runs[0][1], runs[1][1]):
+        assert la == lb
