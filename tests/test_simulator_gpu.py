@@ -444,3 +444,27 @@ def test_pointwise_training_is_bitwise_the_same_under_pytorchs_adam(model, monke
         assert torch.equal(a, b)
     for la, lb in zip(runs[0][1], runs[1][1]):
         assert la == lb
+
+
+@pytest.mark.parametrize('model_name', ['pinnsf_m', 'pinnsf_bm'])
+def test_fused_rollout_losses_and_tail_in_step_equal_their_torch_forms(model_name):
+    """The fine-tuning rollout with this round's one-launch forms -- the collision-prediction loss (ops.collision_pred_loss: labels,
+    gates, BCE, accuracy), the rollout losses, the model's agent-norm tail inside the frame step's launches (ops.rollout_frame tail=) --
+    against the same rollout on their torch / separate-launch forms: every returned scalar (incl. the prediction accuracy) and every
+    parameter gradient."""
+    g = golden('rollout')
+    tag = f'train_{model_name}'
+    res = {}
+    for fused in (True, False):
+        sim = make_sim(g, sim_args(model=model_name, collision_pred_weight=5e-2), f'{tag}/sd/')
+        sim.fused_rollout_losses = fused
+        sim.tail_in_step = fused
+        out = sim.test_multiple_rollouts_for_training(load_data(g, tag))
+        out[0].backward()
+        res[fused] = ([float(x.detach()) for x in out], [None if p.grad is None else p.grad.clone() for p in sim.model.parameters()])
+    assert np.allclose(res[True][0], res[False][0], rtol=2e-5, atol=1e-7), (res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) <= 1e-4 * scale
